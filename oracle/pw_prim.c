@@ -1,0 +1,86 @@
+/*
+ * oracle/pw_prim.c -- TEST INFRASTRUCTURE, not product code.
+ *
+ * Scalar C restatement of the one arithmetic primitive everything on the
+ * pywindow hot path is built from: sklearn.metrics.pairwise.euclidean_distances
+ * as the reference calls it at utilities.py:366 (N x N, "X is Y"), :384 and
+ * :1116 (N x 1).  sklearn 1.6/1.7 (sklearn/metrics/pairwise.py:391-440)
+ * computes   d = sqrt(max((-2 * X.Y^T + |x|^2) + |y|^2, 0))
+ * with |x|^2 from einsum("ij,ij->i") and X.Y^T from OpenBLAS dgemm/dgemv; the
+ * exact association below was established bit-for-bit against that stack
+ * (OpenBLAS 0.3.29 AVX-512 kernels) -- SURVEY.md section 8a-0 -- and is
+ * re-checked by tests/test_oracle.py against captured objective values in the
+ * golden fixtures.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library (through oracle/pw_oracle.py).
+ */
+#include <math.h>
+#include <stdint.h>
+
+/* |x|^2 the way numpy's einsum("ij,ij->i") sums three products */
+static inline double sqnorm3(const double *x) {
+    return (x[0] * x[0] + x[2] * x[2]) + x[1] * x[1];
+}
+
+void pwo_row_sqnorms(int64_t n, const double *xyz, double *xx) {
+    for (int64_t i = 0; i < n; ++i) xx[i] = sqnorm3(xyz + 3 * i);
+}
+
+/* distance atom i -> point p (N x 1 call shape: dgemv association) */
+static inline double dist_point(const double *x, double xx, const double *p, double pp) {
+    double g = fma(x[2], p[2], fma(x[0], p[0], x[1] * p[1]));
+    double d2 = ((-2.0 * g) + xx) + pp;
+    return sqrt(d2 > 0.0 ? d2 : 0.0);
+}
+
+/* min_i (|r_i - p| - vdw_i), first index on ties: pore_diameter()/2 (utilities.py:375-388) */
+double pwo_min_gap(int64_t n, const double *xyz, const double *xx, const double *vdw,
+                   const double *p, int64_t *argmin) {
+    double pp = sqnorm3(p);
+    double best = INFINITY;
+    int64_t bi = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double v = dist_point(xyz + 3 * i, xx[i], p, pp) - vdw[i];
+        if (v < best) { best = v; bi = i; }
+    }
+    if (argmin) *argmin = bi;
+    return best;
+}
+
+/* all N gaps, for tests */
+void pwo_gaps(int64_t n, const double *xyz, const double *xx, const double *vdw,
+              const double *p, double *out) {
+    double pp = sqnorm3(p);
+    for (int64_t i = 0; i < n; ++i)
+        out[i] = dist_point(xyz + 3 * i, xx[i], p, pp) - vdw[i];
+}
+
+/* max_dim (utilities.py:355-372): argmax over the upper triangle (diagonal
+ * included, value 0 + 2 vdw_i) of d_ij + (vdw_i + vdw_j); first maximum in
+ * row-major order.  N x N call shape: dgemm association, diagonal forced 0. */
+double pwo_max_dim(int64_t n, const double *xyz, const double *xx, const double *vdw,
+                   int64_t *oi, int64_t *oj) {
+    double best = -INFINITY;
+    int64_t bi = 0, bj = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double *a = xyz + 3 * i;
+        for (int64_t j = i; j < n; ++j) {
+            const double *b = xyz + 3 * j;
+            double d;
+            if (i == j) {
+                d = 0.0;
+            } else {
+                double g = fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0]));
+                double d2 = ((-2.0 * g) + xx[i]) + xx[j];
+                d = sqrt(d2 > 0.0 ? d2 : 0.0);
+            }
+            double v = d + (vdw[i] + vdw[j]);
+            if (v > best) { best = v; bi = i; bj = j; }
+        }
+    }
+    /* np.triu zeroes the strict lower triangle: a 0 there can only win if every
+     * upper-triangle entry is <= 0, impossible with positive radii. */
+    *oi = bi; *oj = bj;
+    return best;
+}

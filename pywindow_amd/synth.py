@@ -1,0 +1,102 @@
+"""Synthetic DL_POLY trajectories for the benchmark configurations.
+
+SURVEY.md section 8(d), config 2: frame ``k`` of the synthetic trajectory is the
+CC3 cage of the reference's known-answer test (tests/test_validate_cc3.py:5-350,
+kept here as the data file ``data/cc3_base.xyz``) plus iid N(0, sigma) noise per
+coordinate drawn from ``numpy.random.default_rng(20260000 + k)``.  The frames
+are serialised as DL_POLY HISTORY text (keytrj=0, imcon=0, ``%12.4E``
+coordinates; layout of examples/data/input/HISTORY_singlemol_short) and every
+consumer works from the *parsed* text, because the 5-significant-digit format
+quantises the coordinates.
+"""
+
+from __future__ import annotations
+
+import pathlib
+
+import numpy as np
+
+SEED_BASE = 20260000
+_DATA = pathlib.Path(__file__).resolve().parent / "data"
+
+
+def load_cc3_base() -> tuple[np.ndarray, np.ndarray]:
+    """Return ``(elements (N,) str, coordinates (N,3) f64)`` of the CC3 cage."""
+    elements = []
+    xyz = []
+    with (_DATA / "cc3_base.xyz").open() as fh:
+        n = int(fh.readline())
+        fh.readline()
+        for _ in range(n):
+            tok = fh.readline().split()
+            elements.append(tok[0])
+            # repr-precision text: float() round-trips the f64 exactly
+            xyz.append((float(tok[1]), float(tok[2]), float(tok[3])))
+    return np.array(elements), np.array(xyz, dtype=np.float64)
+
+
+def noisy_frame(base: np.ndarray, seed: int, sigma: float = 0.10) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    return base + rng.normal(0.0, sigma, size=base.shape)
+
+
+def _fmt_e(v: float) -> str:
+    return "%12.4E" % v
+
+
+def history_text(
+    elements,
+    frames,
+    title: str = "synthetic CC3 trajectory (pywindow_amd.synth)",
+    tstep: float = 0.0007,
+) -> str:
+    """Serialise frames (iterable of (N,3) arrays) as a keytrj=0/imcon=0 HISTORY."""
+    elements = list(elements)
+    natms = len(elements)
+    out = [title, "%10d%10d%10d" % (0, 0, natms)]
+    for k, xyz in enumerate(frames):
+        out.append(
+            "timestep%10d%10d%10d%10d%12.6f" % (k + 1, natms, 0, 0, tstep)
+        )
+        for i, el in enumerate(elements):
+            out.append("%-8s%10d%12.6f%12.6f" % (el, i + 1, 0.0, 0.0))
+            out.append(_fmt_e(xyz[i, 0]) + _fmt_e(xyz[i, 1]) + _fmt_e(xyz[i, 2]))
+    return "\n".join(out) + "\n"
+
+
+def write_synthetic_history(
+    path,
+    n_frames: int,
+    sigma: float = 0.10,
+    seed_base: int = SEED_BASE,
+) -> pathlib.Path:
+    """Write the config-2 style trajectory (CC3 + noise) to ``path``."""
+    elements, base = load_cc3_base()
+    frames = (noisy_frame(base, seed_base + k, sigma) for k in range(n_frames))
+    path = pathlib.Path(path)
+    path.write_text(history_text(elements, frames))
+    return path
+
+
+def quantise_like_history(xyz: np.ndarray) -> np.ndarray:
+    """Coordinates after a ``%12.4E`` text round trip (what a parser would see)."""
+    flat = np.array([float(_fmt_e(v)) for v in np.asarray(xyz).ravel()])
+    return flat.reshape(np.asarray(xyz).shape)
+
+
+def synthetic_units(
+    n_frames: int,
+    sigma: float = 0.10,
+    seed_base: int = SEED_BASE,
+    first: int = 0,
+) -> tuple[np.ndarray, np.ndarray]:
+    """In-memory equivalent of writing + parsing the synthetic HISTORY.
+
+    Returns ``(elements (N,), coordinates (n_frames, N, 3))`` with the text
+    quantisation applied, for frames ``first .. first+n_frames-1``.
+    """
+    elements, base = load_cc3_base()
+    out = np.empty((n_frames,) + base.shape)
+    for k in range(n_frames):
+        out[k] = quantise_like_history(noisy_frame(base, seed_base + first + k, sigma))
+    return elements, out
