@@ -1,0 +1,51 @@
+// tests/hostsim/lbfgsb_probe.cpp -- exposes pw::Lbfgsb<N> step by step so the
+// Python test can run SciPy's own _lbfgsb.setulb in lockstep and compare every
+// intermediate.  Test infrastructure only.
+#include "../../pywindow_amd/csrc/pw_lbfgsb.hpp"
+#include <new>
+#include <string.h>
+using namespace pw;
+template <int N> static void dump(Lbfgsb<N>* s, double* wa_out, int* ints, double* dbl) {
+    const int m = LB_M;
+    double* p = wa_out;
+    memcpy(p, s->ws, sizeof(double) * m * N); p += m * N;
+    memcpy(p, s->wy, sizeof(double) * m * N); p += m * N;
+    memcpy(p, s->sy, sizeof(double) * m * m); p += m * m;
+    memcpy(p, s->ss, sizeof(double) * m * m); p += m * m;
+    memcpy(p, s->wt, sizeof(double) * m * m); p += m * m;
+    memcpy(p, s->wn, sizeof(double) * 4 * m * m); p += 4 * m * m;
+    memcpy(p, s->wn1, sizeof(double) * 4 * m * m); p += 4 * m * m;
+    memcpy(p, s->z, sizeof(double) * N); p += N;
+    memcpy(p, s->r, sizeof(double) * N); p += N;
+    memcpy(p, s->d, sizeof(double) * N); p += N;
+    memcpy(p, s->t, sizeof(double) * N); p += N;
+    memcpy(p, s->xp, sizeof(double) * N); p += N;
+    memcpy(p, s->wa, sizeof(double) * 8 * m); p += 8 * m;
+    ints[0] = s->task; ints[1] = s->msg; ints[2] = s->col; ints[3] = s->head; ints[4] = s->iter;
+    ints[5] = s->iupdat; ints[6] = s->nfgv; ints[7] = s->ifun; ints[8] = s->iback; ints[9] = s->info;
+    ints[10] = s->nfree; ints[11] = s->nskip; ints[12] = s->updatd;
+    dbl[0] = s->theta; dbl[1] = s->stp; dbl[2] = s->gd; dbl[3] = s->gdold; dbl[4] = s->dtd;
+    dbl[5] = s->dnorm; dbl[6] = s->sbgnrm; dbl[7] = s->stpmx; dbl[8] = s->fold;
+}
+#define DEF(N)                                                                               \
+    extern "C" void* hs_lb##N##_new(const double* x0, const double* l, const double* u,      \
+                                    const int* nbd, double factr, double pgtol, int maxls) { \
+        auto* s = new Lbfgsb<N>();                                                           \
+        memset((void*)s, 0, sizeof(*s));                                                     \
+        s->setup(x0, l, u, nbd, factr, pgtol, maxls);                                        \
+        return s;                                                                            \
+    }                                                                                        \
+    extern "C" void hs_lb##N##_free(void* h) { delete (Lbfgsb<N>*)h; }                       \
+    extern "C" void hs_lb##N##_step(void* h, double* x, double f, const double* g,          \
+                                    int set_fg) {                                            \
+        auto* s = (Lbfgsb<N>*)h;                                                             \
+        if (set_fg) { s->f = f; for (int i = 0; i < N; ++i) s->g[i] = g[i]; }                \
+        s->step();                                                                           \
+        for (int i = 0; i < N; ++i) x[i] = s->x[i];                                          \
+    }                                                                                        \
+    extern "C" void hs_lb##N##_dump(void* h, double* wa, int* ints, double* dbl) {           \
+        dump<N>((Lbfgsb<N>*)h, wa, ints, dbl);                                               \
+    }
+DEF(1)
+DEF(2)
+DEF(3)

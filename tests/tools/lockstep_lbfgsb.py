@@ -1,0 +1,132 @@
+"""Run SciPy's own L-BFGS-B engine (scipy.optimize._lbfgsb.setulb) and
+pw::Lbfgsb<N> (tests/hostsim/liblbprobe.so) in lockstep on the pore-centre
+objective of golden-fixture molecules; report the first call at which any bit of
+x / workspace / task differs.  Development + test tool (SciPy required)."""
+import ctypes, sys, pathlib
+import numpy as np
+from scipy.optimize import _lbfgsb
+REPO = pathlib.Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(REPO))
+from oracle import pw_oracle as O
+from pywindow_amd import element_data as E
+
+L = ctypes.CDLL(str(REPO / "tests/hostsim/liblbprobe.so"))
+dp = ctypes.POINTER(ctypes.c_double); ip = ctypes.POINTER(ctypes.c_int)
+P = lambda a: a.ctypes.data_as(dp)
+for n in (1, 2, 3):
+    getattr(L, f"hs_lb{n}_new").restype = ctypes.c_void_p
+    getattr(L, f"hs_lb{n}_new").argtypes = [dp, dp, dp, ip, ctypes.c_double, ctypes.c_double, ctypes.c_int]
+    getattr(L, f"hs_lb{n}_step").argtypes = [ctypes.c_void_p, dp, ctypes.c_double, dp, ctypes.c_int]
+    getattr(L, f"hs_lb{n}_dump").argtypes = [ctypes.c_void_p, dp, ip, dp]
+    getattr(L, f"hs_lb{n}_free").argtypes = [ctypes.c_void_p]
+
+M = 10
+def fd_grad(fun, x, f0, lb, ub, h=1e-8):
+    """scipy.optimize._numdiff.approx_derivative('2-point', abs_step=h, bounds)"""
+    n = len(x); g = np.zeros(n)
+    for i in range(n):
+        hi = h
+        lower = x[i] - lb[i]; upper = ub[i] - x[i]
+        xi = x[i] + hi
+        violated = xi < lb[i] or xi > ub[i]
+        fitting = abs(hi) <= max(lower, upper)
+        if violated and fitting: hi = -hi
+        elif not fitting:
+            hi = upper if upper >= lower else -lower
+        x1 = x.copy(); x1[i] = x[i] + hi
+        dx = x1[i] - x[i]
+        g[i] = (fun(x1) - f0) / dx
+    return g
+
+def layout(n):
+    m = M
+    names = [("ws", m*n), ("wy", m*n), ("sy", m*m), ("ss", m*m), ("wt", m*m), ("wn", 4*m*m), ("snd", 4*m*m),
+             ("z", n), ("r", n), ("d", n), ("t", n), ("xp", n), ("wa", 8*m)]
+    out = {}; o = 0
+    for k, s in names: out[k] = (o, o+s); o += s
+    return out, o
+
+def lockstep(fun, x0, lb, ub, nbd, verbose=False, maxcalls=5000):
+    n = len(x0); lay, tot = layout(n)
+    # scipy side
+    x = np.array(x0, float); low = np.where(np.isinf(lb), 0.0, lb); up = np.where(np.isinf(ub), 0.0, ub)
+    nbd = np.array(nbd, np.int32)
+    f = np.array(0.0); g = np.zeros(n)
+    wa = np.zeros(2*M*n + 5*n + 11*M*M + 8*M); iwa = np.zeros(3*n, np.int32)
+    task = np.zeros(2, np.int32); ln_task = np.zeros(2, np.int32)
+    lsave = np.zeros(4, np.int32); isave = np.zeros(44, np.int32); dsave = np.zeros(29)
+    # mine
+    h = getattr(L, f"hs_lb{n}_new")(P(np.array(x0, float)), P(low.copy()), P(up.copy()), nbd.ctypes.data_as(ip), 1e7, 1e-5, 20)
+    mx = np.array(x0, float); mf = 0.0; mg = np.zeros(n); mset = 0
+    mwa = np.zeros(tot); mint = np.zeros(16, np.int32); mdbl = np.zeros(16)
+    nit = 0; ncall = 0; first_bad = None
+    while ncall < maxcalls:
+        _lbfgsb.setulb(M, x, low, up, nbd, f, g, 1e7, 1e-5, wa, iwa, task, lsave, isave, dsave, 20, ln_task)
+        getattr(L, f"hs_lb{n}_step")(h, P(mx), mf, P(mg), mset)
+        getattr(L, f"hs_lb{n}_dump")(h, P(mwa), mint.ctypes.data_as(ip), P(mdbl))
+        ncall += 1
+        # compare
+        bad = []
+        if not np.array_equal(x, mx): bad.append(("x", x.copy(), mx.copy()))
+        if task[0] != mint[0] : bad.append(("task", task.copy(), mint[:2].copy()))
+        for k, (a, b) in lay.items():
+            if k in ("snd", "wa", "xp", "t"): continue
+            sa = wa[a:b]; sb = mwa[a:b]
+            if not np.array_equal(sa, sb):
+                idx = np.nonzero(sa != sb)[0]
+                bad.append((k, idx[:6], sa[idx[:6]], sb[idx[:6]]))
+        if bad and first_bad is None:
+            first_bad = (ncall, nit, bad)
+            if verbose:
+                print("FIRST MISMATCH at call", ncall, "iter", nit, "task", task, "mine", mint[:2], "col", mint[2])
+                for b in bad: print("   ", b)
+            break
+        if task[0] == 3:
+            fv = fun(x); gv = fd_grad(fun, x, fv, lb, ub); f = np.array(fv); g = gv
+            if np.array_equal(x, mx): mf, mg = fv, gv.copy()
+            else: mf = fun(mx); mg = fd_grad(fun, mx, mf, lb, ub)
+            mset = 1
+        elif task[0] == 1:
+            nit += 1; mset = 0
+        else:
+            break
+    getattr(L, f"hs_lb{n}_free")(h)
+    return dict(x=x.copy(), mx=mx.copy(), nit=nit, ncall=ncall, task=task.copy(), mtask=mint[:2].copy(), first_bad=first_bad, f=float(f))
+
+def cage_from_fixture(g, u):
+    off = g["atom_offset"]; el = g["elements"][off[u]:off[u+1]]; xyz = g["coordinates"][off[u]:off[u+1]]
+    ids = E.element_ids(el)
+    return O.Cage(xyz, E.VDW[ids], E.MASS[ids])
+
+if __name__ == "__main__":
+    tag = sys.argv[1] if len(sys.argv) > 1 else "md20"
+    g = np.load(REPO / f"tests/golden/{tag}.npz")
+    nunits = len(g["atom_offset"]) - 1
+    ok = 0
+    for u in range(nunits):
+        cage = cage_from_fixture(g, u)
+        com = O.centre_of_mass(cage); r = O.pore_diameter(cage, com)[0] / 2
+        lb = com - r; ub = com + r
+        fun = lambda c: -(cage.gap(c)[0] * 2)
+        res = lockstep(fun, com, lb, ub, [2, 2, 2], verbose=(u < 3))
+        same = res["first_bad"] is None
+        ok += same
+        gx = g["st_opt_x"][u]
+        print(u, "lockstep_ok", same, "calls", res["ncall"], "nit", res["nit"], "task", res["task"], res["mtask"],
+              "scipy_x==golden", np.array_equal(res["x"], gx), "mine==golden", np.array_equal(res["mx"], gx))
+    print("lockstep identical:", ok, "of", nunits)
+
+
+def z_problems(tag):
+    """n = 1 window-neck searches (utilities.py:1296-1303) from the trace fixtures."""
+    g = np.load(REPO / f"tests/golden/{tag}.npz")
+    cols = list(g["win_table_cols"]); tab = g["win_table"]; wu = g["win_unit"]
+    off = g["atom_offset"]
+    for u in g["trace_units"]:
+        rows = np.nonzero(wu == u)[0]
+        el = g["elements"][off[u]:off[u+1]]; ids = E.element_ids(el)
+        for w, ri in enumerate(rows):
+            key = f"tr{u}_w{w}_rot"
+            if key not in g: continue
+            cage = O.Cage(g[key], E.VDW[ids], E.MASS[ids])
+            yield u, w, cage, tab[ri][cols.index("z_lb")], tab[ri][cols.index("z_x")]
