@@ -1,0 +1,142 @@
+/*
+ * pywindow_amd.h -- C ABI of libpywindow_hip.so, the MI355X (gfx950) engine for
+ * pywindow's per-molecule structural analysis.
+ *
+ * The reference (marcinmiklitz/pywindow) is pure Python and has no FFI layer; the
+ * boundary this library stands behind is the set of free functions that
+ * src/pywindow/_internal/molecular.py:29-44 imports from utilities.py and that
+ * Molecule.full_analysis() chains (molecular.py:156-202).  One *unit* is one
+ * (frame, molecule); a batch is every unit of a trajectory, analysed by one
+ * kernel launch per GPU.  Each entry point below names the reference function
+ * it replaces.
+ *
+ * Conventions: plain pointers and sizes, caller-allocated buffers, no
+ * exceptions across the ABI -- every function returns 0 on success or a
+ * negative PW_E_* code.  All arithmetic is IEEE double.  There is no CPU
+ * fallback: without a usable HIP device every compute call fails with
+ * PW_E_NO_DEVICE.
+ */
+#ifndef PYWINDOW_AMD_H
+#define PYWINDOW_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PW_W_MAX 16       /* windows reported per molecule (more => PW_ST_WINDOW_OVERFLOW) */
+#define PW_P_MAX 2048     /* sampling vectors per molecule the workspace is sized for */
+
+/* error codes */
+#define PW_OK 0
+#define PW_E_NO_DEVICE (-1)
+#define PW_E_BAD_ARG (-2)
+#define PW_E_HIP (-3)
+#define PW_E_TOO_LARGE (-4) /* a molecule has more atoms than fit in LDS */
+#define PW_E_NOMEM (-5)
+
+/* stage selection bits for pw_analysis_* */
+#define PW_STAGE_BASIC 1u   /* molecular_weight, center_of_mass, max_dim, pore_diameter */
+#define PW_STAGE_AVG 2u     /* find_average_diameter */
+#define PW_STAGE_OPT 4u     /* opt_pore_diameter */
+#define PW_STAGE_WINDOWS 8u /* find_windows (implies PW_STAGE_OPT) */
+#define PW_STAGE_ALL 15u
+
+/* per-unit status bits (pw_unit_out.status) */
+#define PW_ST_OK 0
+#define PW_ST_NEGATIVE_PORE 1      /* pore radius <= 0: the reference's bounds would be inverted */
+#define PW_ST_WINDOW_OVERFLOW 2    /* more than PW_W_MAX clusters */
+#define PW_ST_POINTS_OVERFLOW 4    /* more than PW_P_MAX sampling vectors */
+#define PW_ST_WINDOW_DROPPED 8     /* a cluster's refined path scan failed (reference: None + warning) */
+#define PW_ST_WINDOW_NEGATIVE 16   /* a window diameter < 0 (reference: warning) */
+
+/* Input batch: ragged molecules, atoms of unit u are [atom_offset[u], atom_offset[u+1]). */
+typedef struct pw_batch_in {
+    int64_t n_units;
+    const int64_t *atom_offset; /* n_units + 1 */
+    const double *xyz;          /* sum(N) x 3, row-major as numpy (N,3) */
+    const double *vdw;          /* per atom: atomic_vdw_radius[element] (tables.py:111-197) */
+    const double *mass;         /* per atom: atomic_mass[element]      (tables.py:22-108)  */
+} pw_batch_in;
+
+/* Fixed-size result record of one unit == Molecule.properties (molecular.py:215-352). */
+typedef struct pw_unit_out {
+    int32_t n_atoms;
+    int32_t status;
+    double mw;             /* molecular_weight()        utilities.py:96  */
+    double com[3];         /* center_of_mass()          utilities.py:127 */
+    double maxd;           /* max_dim()                 utilities.py:355 */
+    int32_t maxd_i, maxd_j;
+    double avg_d;          /* find_average_diameter()   utilities.py:1586 */
+    double pore_d;         /* pore_diameter()           utilities.py:375 */
+    int32_t pore_atom;
+    int32_t pore_opt_atom;
+    double pore_vol;       /* sphere_volume(pore_d/2)   utilities.py:429 */
+    double pore_opt_d;     /* opt_pore_diameter()       utilities.py:400 */
+    double pore_opt_c[3];
+    double pore_vol_opt;
+    int32_t n_windows;     /* find_windows(): -1 => None, else number of windows  utilities.py:1364 */
+    int32_t n_clusters;
+    double win_d[PW_W_MAX];
+    double win_c[PW_W_MAX][3];
+    /* diagnostics (not part of the reference's dict; used by the parity tests) */
+    int32_t n_points;      /* sampling vectors in find_windows */
+    int32_t n_points_avg;  /* sampling vectors in find_average_diameter */
+    int32_t n_survivors;   /* vectors that reach the outside */
+    int32_t opt_nit, opt_nfev, opt_task, opt_msg;
+    int32_t n_eval;        /* point-vs-molecule evaluations performed */
+    double eps;            /* DBSCAN radius */
+    double sphere_r;       /* sampling sphere radius in find_windows */
+} pw_unit_out;
+
+typedef struct pw_context pw_context;   /* device, stream, workspace */
+typedef struct pw_resident pw_resident; /* a batch resident in HBM */
+
+int pw_device_count(void);
+const char *pw_version(void);
+const char *pw_last_error(void);
+
+int pw_context_create(int device, pw_context **ctx);
+void pw_context_destroy(pw_context *ctx);
+
+/* Host-buffer path: H2D copy, one launch, D2H copy, synchronous.
+ * Replaces the per-frame loop `mol.full_analysis()` of trajectory.py:518-522
+ * for `stages == PW_STAGE_ALL`; partial `stages` give the fine-grained calls
+ * (pore_diameter, max_dim, ... ) the parity tests exercise one by one. */
+int pw_analysis_batch(pw_context *ctx, const pw_batch_in *in, uint32_t stages, pw_unit_out *out);
+
+/* Resident path (inputs stay in HBM between launches; used by bench.py and the
+ * trajectory driver when several analyses run on the same frames). */
+int pw_resident_upload(pw_context *ctx, const pw_batch_in *in, pw_resident **res);
+int pw_resident_launch(pw_context *ctx, pw_resident *res, uint32_t stages); /* async on ctx stream */
+int pw_resident_sync(pw_context *ctx);
+int pw_resident_download(pw_context *ctx, pw_resident *res, pw_unit_out *out);
+void pw_resident_free(pw_context *ctx, pw_resident *res);
+/* `iters` back-to-back launches bracketed by HIP events on the launch stream;
+ * writes the average milliseconds per launch. */
+int pw_resident_time(pw_context *ctx, pw_resident *res, uint32_t stages, int iters, float *ms_per_launch);
+/* raw device pointer of the result records (for RCCL gathers by the host side) */
+void *pw_resident_device_results(pw_resident *res);
+int64_t pw_resident_units(pw_resident *res);
+/* the HIP stream (hipStream_t) launches are issued on, as an opaque pointer */
+void *pw_context_stream(pw_context *ctx);
+
+/* Native DL_POLY HISTORY ingest (trajectory.py:647-766): see pw_history_* in
+ * pywindow_amd/csrc/pw_history.cpp */
+typedef struct pw_history pw_history;
+int pw_history_open(const char *path, pw_history **h);
+int64_t pw_history_frames(const pw_history *h);
+int64_t pw_history_atoms(const pw_history *h);
+int pw_history_keytrj(const pw_history *h);
+int pw_history_imcon(const pw_history *h);
+/* atom keys of frame 0, NUL-separated, into buf (returns bytes needed) */
+int64_t pw_history_atom_keys(const pw_history *h, char *buf, int64_t buflen);
+/* coordinates of frames [first, first+count) -> xyz[count][natoms][3]; lattice[count][9] may be NULL */
+int pw_history_read(const pw_history *h, int64_t first, int64_t count, double *xyz, double *lattice);
+void pw_history_close(pw_history *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYWINDOW_AMD_H */

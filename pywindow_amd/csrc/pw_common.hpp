@@ -7,6 +7,7 @@
 // without a GPU.  Everything is FP64 and must be built with -ffp-contract=off:
 // fused multiply-adds appear only where written (pw_fma).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)

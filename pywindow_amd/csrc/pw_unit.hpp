@@ -1,0 +1,1124 @@
+// pw_unit.hpp -- the per-unit analysis pipeline: everything
+// Molecule.full_analysis() (reference molecular.py:156-202) computes for one
+// (frame, molecule), executed by one team (pw_team.hpp): a workgroup on gfx950
+// or a single host thread in tests/hostsim.
+//
+// Stage map (reference file utilities.py unless noted):
+//   load_unit            coordinates -> LDS, structure-of-arrays, |r|^2 cached
+//   stage_basic          molecular_weight :96, center_of_mass :127, max_dim :355,
+//                        pore_diameter :375
+//   stage_opt            opt_pore_diameter :400 (L-BFGS-B, pw_lbfgsb.hpp)
+//   stage_average        find_average_diameter :1586, vector_analysis_reversed :1556
+//   stage_windows        find_windows :1364 = sampling :1409-1434, vector_preanalysis
+//                        :1132, vector_analysis :1100, DBSCAN :1478, window_analysis
+//                        :1191 (L-BFGS-B on z, 20x20 grid + Nelder-Mead on xy)
+//
+// Distance primitive: the bit-exact restatement of sklearn's
+// euclidean_distances:  g = fma(z,pz, fma(x,px, y*py)),
+// d = sqrt(max(((-2 g) + |r|^2) + |p|^2, 0)), |v|^2 = (v0^2 + v2^2) + v1^2.
+//
+// Parallel decomposition: bulk stages are "lanes over points" (each lane owns a
+// sampling vector / grid point and loops over the atoms, which every lane reads
+// from the same LDS address -> broadcast, conflict-free); the optimiser chains
+// are "lanes over atoms" with an exact wave-level (value, index) min reduction.
+// No floating-point sum is ever reduced across lanes: sums whose order matters
+// (numpy pairwise sums, row-sequential sums) are reproduced in the reference's
+// order.
+#pragma once
+#include "../../include/pywindow_amd.h"
+#include "pw_lbfgsb.hpp"
+#include "pw_math.hpp"
+#include "pw_team.hpp"
+
+namespace pw {
+
+constexpr double GOLDEN_ANGLE = 2.399963229728653;   // np.pi * (3 - np.sqrt(5))
+constexpr double FOUR_PI = 12.566370614359172;       // 4 * np.pi
+constexpr double FOUR_THIRDS_PI = 4.1887902047863905;  // 4 / 3 * np.pi
+constexpr double TWO_PI = 6.283185307179586;
+constexpr double ONE_PI = 3.141592653589793;
+
+struct Frame {
+    double *x, *y, *z, *xx;
+    const double* vdw;
+};
+
+// ---- global-memory workspace of one team (sized for PW_P_MAX vectors) ----------
+struct TeamWorkspace {
+    double knn[PW_P_MAX * 10];
+    double pts[PW_P_MAX * 3];     // sampling vectors of find_windows
+    double vals[PW_P_MAX];        // per-ray exit distance / per-survivor 2*gap
+    double leaf[256];
+    int surv_k[PW_P_MAX];
+    int labels[PW_P_MAX];
+    unsigned char flag[PW_P_MAX];
+    unsigned char core[PW_P_MAX];
+    int stack[PW_P_MAX];
+    unsigned long long adj[PW_P_MAX * (PW_P_MAX / 64)];
+};
+
+// ---- per-unit scalars kept in LDS ----------------------------------------------
+struct UnitVars {
+    double com[3];
+    double mw;
+    double centroid[3];
+    double maxd;
+    int maxd_i, maxd_j;
+    double pore_g;
+    int pore_atom;
+    double opt_c[3];
+    double opt_g;
+    int opt_atom;
+    double shift[3];
+    double eps;
+    double radius;
+    int P;
+    int n_surv;
+    int n_clusters;
+    int n_eval;
+    int status;
+    // cross-wave reduction scratch
+    double red_v[16];
+    int red_i[16];
+    // window results by cluster
+    int win_ok[PW_W_MAX];
+    double win_d[PW_W_MAX];
+    double win_c[PW_W_MAX][3];
+};
+
+// LDS layout helper: everything a team needs, carved from one byte buffer.
+struct UnitShared {
+    UnitVars* v;
+    double* vdw;
+    double* mass;
+    Frame A;        // input coordinates
+    Frame S;        // shifted coordinates (COM frame, then pore-centre frame)
+    Frame R[8];     // per-wave rotated coordinates (window frames)
+    void* lb[8];    // per-wave optimiser state
+    PW_HD static size_t bytes(int nmax, int nwaves) {
+        size_t n = (size_t)((nmax + 1) & ~1);
+        size_t b = sizeof(UnitVars);
+        b = (b + 15) & ~(size_t)15;
+        b += n * 8 * 2;                       // vdw, mass
+        b += n * 8 * 4 * (2 + (size_t)nwaves);  // A, S, R[w]
+        b += (size_t)nwaves * ((sizeof(Lbfgsb<3>) + 15) & ~(size_t)15);
+        return b;
+    }
+    PW_HD void carve(unsigned char* base, int nmax, int nwaves) {
+        size_t n = (size_t)((nmax + 1) & ~1);
+        unsigned char* p = base;
+        v = (UnitVars*)p;
+        p += (sizeof(UnitVars) + 15) & ~(size_t)15;
+        double* d = (double*)p;
+        vdw = d; d += n;
+        mass = d; d += n;
+        A.x = d; d += n; A.y = d; d += n; A.z = d; d += n; A.xx = d; d += n; A.vdw = vdw;
+        S.x = d; d += n; S.y = d; d += n; S.z = d; d += n; S.xx = d; d += n; S.vdw = vdw;
+        for (int w = 0; w < nwaves; ++w) {
+            R[w].x = d; d += n; R[w].y = d; d += n; R[w].z = d; d += n; R[w].xx = d; d += n;
+            R[w].vdw = vdw;
+        }
+        p = (unsigned char*)d;
+        for (int w = 0; w < nwaves; ++w) {
+            lb[w] = p;
+            p += (sizeof(Lbfgsb<3>) + 15) & ~(size_t)15;
+        }
+    }
+};
+
+// ---- small numerics --------------------------------------------------------------
+PW_HD inline double sq3(double a, double b, double c) { return (a * a + c * c) + b * b; }
+// np.linalg.norm of a 3-vector: sqrt(ddot) with the BLAS FMA chain
+PW_HD inline double norm3(double a, double b, double c) {
+    return pw_sqrt(pw_fma(c, c, pw_fma(b, b, a * a)));
+}
+PW_HD inline double gap_atom(const Frame& F, int i, double px, double py, double pz, double pp) {
+    double g = pw_fma(F.z[i], pz, pw_fma(F.x[i], px, F.y[i] * py));
+    double d2 = ((-2.0 * g) + F.xx[i]) + pp;
+    double d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
+    return d - F.vdw[i];
+}
+// one thread, all atoms
+PW_HD inline double point_gap(const Frame& F, int n, double px, double py, double pz, int* arg) {
+    double pp = sq3(px, py, pz);
+    double best = PW_INF;
+    int bi = 0;
+    for (int i = 0; i < n; ++i) {
+        double v = gap_atom(F, i, px, py, pz, pp);
+        if (v < best) { best = v; bi = i; }
+    }
+    if (arg) *arg = bi;
+    return best;
+}
+// one wave, atoms spread over lanes; result in every lane
+template <class T>
+PW_HD inline double wave_gap(const Frame& F, int n, double px, double py, double pz, int* arg) {
+    double pp = sq3(px, py, pz);
+    double best = PW_INF;
+    int bi = 0x7fffffff;
+    for (int i = T::lane(); i < n; i += T::WSIZE) {
+        double v = gap_atom(F, i, px, py, pz, pp);
+        if (v < best) { best = v; bi = i; }
+    }
+    T::wave_argmin(best, bi);
+    if (arg) *arg = bi;
+    return best;
+}
+
+// numpy's float64 add.reduce over a contiguous 1-D array: pairwise blocks of
+// <= 128 with 8 accumulators, halves split at multiples of 8, and the outer
+// iterator feeding 8192-element buffers sequentially.
+PW_HD inline double np_leaf_sum(const double* a, int n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r = r + a[i];
+        return r;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i = 8;
+    int lim = n - (n % 8);
+    for (; i < lim; i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res = res + a[i];
+    return res;
+}
+struct NpSeg { int off, len, stage; };
+// enumerate the leaves of the pairwise recursion over [off, off+n) in order
+PW_HD inline int np_leaves(int off, int n, int* loff, int* llen) {
+    NpSeg st[24];
+    int top = 0, nl = 0;
+    st[top++] = NpSeg{off, n, 0};
+    while (top) {
+        NpSeg c = st[--top];
+        if (c.len <= 128) {
+            loff[nl] = c.off; llen[nl] = c.len; ++nl;
+        } else {
+            int n2 = c.len / 2;
+            n2 -= n2 % 8;
+            st[top++] = NpSeg{c.off + n2, c.len - n2, 0};
+            st[top++] = NpSeg{c.off, n2, 0};
+        }
+    }
+    return nl;
+}
+// combine leaf sums in recursion order
+PW_HD inline double np_combine(int n, const double* leafsum) {
+    NpSeg st[24];
+    double vals[24];
+    int top = 0, vtop = 0, li = 0;
+    st[top++] = NpSeg{0, n, 0};
+    while (top) {
+        NpSeg& c = st[top - 1];
+        if (c.len <= 128) {
+            vals[vtop++] = leafsum[li++];
+            --top;
+        } else if (c.stage == 0) {
+            int n2 = c.len / 2;
+            n2 -= n2 % 8;
+            c.stage = 1;
+            st[top++] = NpSeg{c.off, n2, 0};
+        } else if (c.stage == 1) {
+            int n2 = c.len / 2;
+            n2 -= n2 % 8;
+            c.stage = 2;
+            int o = c.off, l = c.len;
+            st[top++] = NpSeg{o + n2, l - n2, 0};
+        } else {
+            double r = vals[--vtop];
+            double l = vals[--vtop];
+            vals[vtop++] = l + r;
+            --top;
+        }
+    }
+    return vals[0];
+}
+// serial version (one thread)
+PW_HD inline double np_sum_serial(const double* a, int n) {
+    double total = 0.0;
+    bool first = true;
+    for (int s = 0; s < n; s += 8192) {
+        int len = n - s < 8192 ? n - s : 8192;
+        int loff[160], llen[160];
+        double ls[160];
+        int nl = np_leaves(0, len, loff, llen);
+        for (int i = 0; i < nl; ++i) ls[i] = np_leaf_sum(a + s + loff[i], llen[i]);
+        double part = np_combine(len, ls);
+        total = first ? part : total + part;
+        first = false;
+    }
+    return total;
+}
+// team version: leaves in parallel, combine by thread 0; result broadcast via LDS slot
+template <class T>
+PW_HD inline double np_sum_team(const double* a, int n, double* leafbuf, double* slot) {
+    double total = 0.0;
+    bool first = true;
+    for (int s = 0; s < n; s += 8192) {
+        int len = n - s < 8192 ? n - s : 8192;
+        int loff[160], llen[160];
+        int nl = np_leaves(0, len, loff, llen);
+        for (int i = T::tid(); i < nl; i += T::SIZE) leafbuf[i] = np_leaf_sum(a + s + loff[i], llen[i]);
+        T::sync();
+        if (T::tid() == 0) {
+            double part = np_combine(len, leafbuf);
+            total = first ? part : total + part;
+        }
+        first = false;
+        T::sync();
+    }
+    if (T::tid() == 0) *slot = total;
+    T::sync();
+    double r = *slot;
+    T::sync();
+    return r;
+}
+
+// ---- sampling sphere -----------------------------------------------------------------
+struct Sphere {
+    int P;
+    double R, start, stop, step;
+    PW_HD void init(double radius, int count) {
+        P = count;
+        R = radius;
+        start = 1.0 - 1.0 / (double)count;
+        stop = 1.0 / (double)count - 1.0;
+        step = (stop - start) / (double)(count - 1);
+    }
+    PW_HD double zunit(int k) const { return (k == P - 1) ? stop : (double)k * step + start; }
+    PW_HD void point(int k, double* px, double* py, double* pz) const {
+        double theta = GOLDEN_ANGLE * (double)k;
+        double z = zunit(k);
+        double ring = pw_sqrt(1.0 - z * z);
+        double s, c;
+        pw_sincos(theta, &s, &c);
+        *px = ring * c * R;
+        *py = ring * s * R;
+        *pz = z * R;
+    }
+};
+PW_HD inline int sampling_count(double radius) {
+    double area = FOUR_PI * (radius * radius);
+    return (int)(pw_log10(area) * 250.0);
+}
+
+// Ray from the centroid along (dx,dy,dz) against every atom (utilities.py:1138-1158 /
+// 1561-1578).  Returns whether any atom is "in the way" and the largest |p_out|.
+PW_HD inline bool ray_scan(const Frame& F, int n, const double* cen, double dx, double dy,
+                           double dz, double* farthest) {
+    double nrm = norm3(dx, dy, dz);
+    double ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
+    bool any = false;
+    double far = -1.0;
+    for (int i = 0; i < n; ++i) {
+        double rx = F.x[i] - cen[0], ry = F.y[i] - cen[1], rz = F.z[i] - cen[2];
+        double along = pw_fma(rz, uz, pw_fma(rx, ux, ry * uy));
+        double sq = sq3(rx, ry, rz);
+        double perp = pw_sqrt(sq - along * along);  // NaN when negative, as numpy
+        double radicand = F.vdw[i] * F.vdw[i] - perp * perp;
+        if (radicand > 0.0) {
+            double half = pw_sqrt(radicand);
+            double tin = along - half, tout = along + half;
+            double ix = cen[0] + tin * ux, iy = cen[1] + tin * uy, iz = cen[2] + tin * uz;
+            double ox = cen[0] + tout * ux, oy = cen[1] + tout * uy, oz = cen[2] + tout * uz;
+            double nin = norm3(ix, iy, iz), nout = norm3(ox, oy, oz);
+            if (nin < nout) {
+                any = true;
+                if (nout > far) far = nout;
+            }
+        }
+    }
+    *farthest = far;
+    return any;
+}
+
+// numpy floor division a // b for positive doubles (npy_divmod)
+PW_HD inline double np_floordiv(double a, double b) {
+    double mod = __builtin_fmod(a, b);
+    double div = (a - mod) / b;
+    if (mod != 0.0) {
+        if ((b < 0.0) != (mod < 0.0)) div -= 1.0;
+    }
+    double fl;
+    if (div != 0.0) {
+        fl = __builtin_floor(div);
+        if (div - fl > 0.5) fl += 1.0;
+    } else {
+        fl = 0.0;
+    }
+    return fl;
+}
+
+// vector_analysis (utilities.py:1100-1129) by ONE thread: walk 0 -> v.
+// returns false if some point is inside a vdW sphere.
+PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx, double vy, double vz,
+                                   double inc, double* out_2gap, int* out_pos, double* out_chunk,
+                                   int* n_eval) {
+    double nrm = norm3(vx, vy, vz);
+    int chunks = (int)np_floordiv(nrm, inc);
+    double cx = vx / (double)chunks, cy = vy / (double)chunks, cz = vz / (double)chunks;
+    double best = PW_INF;
+    int pos = 0;
+    bool ok = true;
+    for (int k = 0; k <= chunks; ++k) {
+        double m = point_gap(F, n, cx * (double)k, cy * (double)k, cz * (double)k, nullptr);
+        if (!(m > 0.0)) { ok = false; break; }
+        if (m < best) { best = m; pos = k; }
+    }
+    if (n_eval) *n_eval += chunks + 1;
+    if (!ok) return false;
+    *out_2gap = best * 2.0;
+    *out_pos = pos;
+    out_chunk[0] = cx; out_chunk[1] = cy; out_chunk[2] = cz;
+    return true;
+}
+
+// ---- stage: load --------------------------------------------------------------------------
+template <class T>
+PW_HD inline void load_unit(UnitShared& sh, int n, const double* xyz, const double* vdw,
+                            const double* mass) {
+    for (int i = T::tid(); i < n; i += T::SIZE) {
+        double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        sh.A.x[i] = x; sh.A.y[i] = y; sh.A.z[i] = z;
+        sh.A.xx[i] = sq3(x, y, z);
+        sh.vdw[i] = vdw[i];
+        sh.mass[i] = mass[i];
+    }
+    if (T::tid() == 0) {
+        sh.v->n_eval = 0;
+        sh.v->status = 0;
+    }
+    T::sync();
+}
+
+// shifted copy S = A - c (elementwise), with |r|^2 and the row-sequential centroid
+template <class T>
+PW_HD inline void make_shifted(UnitShared& sh, int n, double cx, double cy, double cz) {
+    for (int i = T::tid(); i < n; i += T::SIZE) {
+        double x = sh.A.x[i] - cx, y = sh.A.y[i] - cy, z = sh.A.z[i] - cz;
+        sh.S.x[i] = x; sh.S.y[i] = y; sh.S.z[i] = z;
+        sh.S.xx[i] = sq3(x, y, z);
+    }
+    T::sync();
+    if (T::tid() < 3) {
+        const double* a = T::tid() == 0 ? sh.S.x : (T::tid() == 1 ? sh.S.y : sh.S.z);
+        double s = a[0];
+        for (int i = 1; i < n; ++i) s = s + a[i];
+        sh.v->centroid[T::tid()] = s / (double)n;
+    }
+    if (T::SIZE < 3 && T::tid() == 0) {
+        for (int c = 1; c < 3; ++c) {
+            const double* a = c == 1 ? sh.S.y : sh.S.z;
+            double s = a[0];
+            for (int i = 1; i < n; ++i) s = s + a[i];
+            sh.v->centroid[c] = s / (double)n;
+        }
+    }
+    T::sync();
+}
+
+// max_dim over frame F (utilities.py:355-372); result in sh.v->maxd*, all threads.
+template <class T>
+PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n) {
+    double best = -PW_INF;
+    int bidx = 0x7fffffff;
+    // rows paired (i, n-1-i) for balance
+    for (int r = T::tid(); r < n; r += T::SIZE) {
+        int i = (r & 1) ? (n - 1 - (r >> 1)) : (r >> 1);
+        double xi = F.x[i], yi = F.y[i], zi = F.z[i], xxi = F.xx[i], vi = F.vdw[i];
+        for (int j = i; j < n; ++j) {
+            double d;
+            if (j == i) {
+                d = 0.0;
+            } else {
+                double g = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
+                double d2 = ((-2.0 * g) + xxi) + F.xx[j];
+                d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
+            }
+            double v = d + (vi + F.vdw[j]);
+            int idx = i * n + j;
+            if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
+        }
+    }
+    T::wave_argmax(best, bidx);
+    if (T::lane() == 0) { sh.v->red_v[T::wave()] = best; sh.v->red_i[T::wave()] = bidx; }
+    T::sync();
+    if (T::tid() == 0) {
+        double b = sh.v->red_v[0];
+        int bi = sh.v->red_i[0];
+        for (int w = 1; w < T::NWAVES; ++w) {
+            double v = sh.v->red_v[w];
+            int vi = sh.v->red_i[w];
+            if (v > b || (v == b && vi < bi)) { b = v; bi = vi; }
+        }
+        sh.v->maxd = b;
+        sh.v->maxd_i = bi / n;
+        sh.v->maxd_j = bi % n;
+    }
+    T::sync();
+}
+
+// ---- stage: basic -------------------------------------------------------------------------
+template <class T>
+PW_HD inline void stage_basic(UnitShared& sh, int n, pw_unit_out* out) {
+    UnitVars& v = *sh.v;
+    if (T::tid() == 0) v.mw = np_sum_serial(sh.mass, n);
+    T::sync();
+    // centre of mass: per component the row-sequential sum of x_i*m_i over the mass
+    auto com_comp = [&](int c) {
+        const double* a = c == 0 ? sh.A.x : (c == 1 ? sh.A.y : sh.A.z);
+        double s = a[0] * sh.mass[0];
+        for (int i = 1; i < n; ++i) s = s + a[i] * sh.mass[i];
+        v.com[c] = s / v.mw;
+    };
+    if (T::SIZE >= 3) {
+        if (T::tid() < 3) com_comp(T::tid());
+    } else if (T::tid() == 0) {
+        com_comp(0); com_comp(1); com_comp(2);
+    }
+    T::sync();
+    team_max_dim<T>(sh, sh.A, n);
+    if (T::wave() == 0) {
+        int arg;
+        double g = wave_gap<T>(sh.A, n, v.com[0], v.com[1], v.com[2], &arg);
+        if (T::lane() == 0) { v.pore_g = g; v.pore_atom = arg; v.n_eval += 1; }
+    }
+    T::sync();
+    if (T::tid() == 0) {
+        out->n_atoms = n;
+        out->mw = v.mw;
+        out->com[0] = v.com[0]; out->com[1] = v.com[1]; out->com[2] = v.com[2];
+        out->maxd = v.maxd; out->maxd_i = v.maxd_i; out->maxd_j = v.maxd_j;
+        out->pore_d = v.pore_g * 2.0;
+        out->pore_atom = v.pore_atom;
+        double r = out->pore_d / 2.0;
+        DD r2 = two_prod(r, r);
+        DD r3 = dd_mul_d(r2, r);
+        out->pore_vol = FOUR_THIRDS_PI * (r3.hi + r3.lo);
+    }
+    T::sync();
+}
+
+// forward-difference gradient step exactly as scipy.optimize._numdiff (2-point,
+// abs_step 1e-8, _adjust_scheme_to_bounds '1-sided')
+PW_HD inline double fd_step(double x, double lb, double ub) {
+    double h = 1e-8;
+    double lower = x - lb, upper = ub - x;
+    double xh = x + h;
+    bool violated = (xh < lb) || (xh > ub);
+    bool fitting = pw_abs(h) <= pw_max(lower, upper);
+    if (violated && fitting) h = -h;
+    else if (!fitting) h = (upper >= lower) ? upper : -lower;
+    return h;
+}
+
+// ---- stage: optimised pore (wave 0) --------------------------------------------------------
+template <class T>
+PW_HD inline void stage_opt(UnitShared& sh, int n, pw_unit_out* out) {
+    UnitVars& v = *sh.v;
+    if (T::wave() == 0) {
+        Lbfgsb<3>* S = (Lbfgsb<3>*)sh.lb[0];
+        double r = v.pore_g;  // pore_diameter / 2
+        double lo[3], up[3], x0[3];
+        int nbd[3] = {2, 2, 2};
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = v.com[c] - r;
+            up[c] = v.com[c] + r;
+            x0[c] = v.com[c];
+        }
+        bool bad = !(r > 0.0);
+        int nit = 0, nfev = 0;
+        bool have_last = false;
+        double lx = 0.0, ly = 0.0, lz = 0.0, lf = 0.0, lg[3] = {0.0, 0.0, 0.0};
+        if (!bad) {
+            S->setup(x0, lo, up, nbd, 1e7, 1e-5, 20);
+            for (;;) {
+                S->step();
+                T::wave_sync();
+                if (S->task == LB_FG) {
+                    double px = S->x[0], py = S->x[1], pz = S->x[2];
+                    // scipy's ScalarFunction re-uses f and g when asked for the point it
+                    // evaluated last (_differentiable_functions.py: fun_and_grad)
+                    if (!(have_last && px == lx && py == ly && pz == lz)) {
+                        double f0 = -(wave_gap<T>(sh.A, n, px, py, pz, nullptr) * 2.0);
+                        for (int c = 0; c < 3; ++c) {
+                            double xc = c == 0 ? px : (c == 1 ? py : pz);
+                            double h = fd_step(xc, lo[c], up[c]);
+                            double x1 = xc + h;
+                            double dx = x1 - xc;
+                            double f1 = -(wave_gap<T>(sh.A, n, c == 0 ? x1 : px, c == 1 ? x1 : py,
+                                                      c == 2 ? x1 : pz, nullptr) * 2.0);
+                            lg[c] = (f1 - f0) / dx;
+                        }
+                        lf = f0;
+                        lx = px; ly = py; lz = pz;
+                        have_last = true;
+                        nfev += 4;
+                    }
+                    S->f = lf;
+                    S->g[0] = lg[0]; S->g[1] = lg[1]; S->g[2] = lg[2];
+                    T::wave_sync();
+                } else if (S->task == LB_NEW_X) {
+                    nit += 1;
+                    if (nit >= 15000) break;
+                } else {
+                    break;
+                }
+            }
+        }
+        double cx = bad ? v.com[0] : S->x[0], cy = bad ? v.com[1] : S->x[1],
+               cz = bad ? v.com[2] : S->x[2];
+        int arg;
+        double g = wave_gap<T>(sh.A, n, cx, cy, cz, &arg);
+        if (T::lane() == 0) {
+            v.opt_c[0] = cx; v.opt_c[1] = cy; v.opt_c[2] = cz;
+            v.opt_g = g;
+            v.opt_atom = arg;
+            v.n_eval += nfev + 1;
+            if (bad) v.status |= PW_ST_NEGATIVE_PORE;
+            out->pore_opt_d = g * 2.0;
+            out->pore_opt_atom = arg;
+            out->pore_opt_c[0] = cx; out->pore_opt_c[1] = cy; out->pore_opt_c[2] = cz;
+            double rr = out->pore_opt_d / 2.0;
+            DD r2 = two_prod(rr, rr);
+            DD r3 = dd_mul_d(r2, rr);
+            out->pore_vol_opt = FOUR_THIRDS_PI * (r3.hi + r3.lo);
+            out->opt_nit = nit;
+            out->opt_nfev = nfev;
+            out->opt_task = bad ? -1 : S->task;
+            out->opt_msg = bad ? 0 : S->msg;
+        }
+    }
+    T::sync();
+}
+
+// ---- stage: average diameter ---------------------------------------------------------------
+template <class T>
+PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out) {
+    UnitVars& v = *sh.v;
+    make_shifted<T>(sh, n, v.com[0], v.com[1], v.com[2]);
+    // preserve the input-frame max_dim: the shifted frame's replaces it only here
+    double keep_d = v.maxd;
+    int keep_i = v.maxd_i, keep_j = v.maxd_j;
+    T::sync();
+    team_max_dim<T>(sh, sh.S, n);
+    double radius = v.maxd;
+    T::sync();
+    if (T::tid() == 0) { v.maxd = keep_d; v.maxd_i = keep_i; v.maxd_j = keep_j; }
+    int P = sampling_count(radius);
+    if (P > PW_P_MAX) {
+        if (T::tid() == 0) { v.status |= PW_ST_POINTS_OVERFLOW; out->avg_d = 0.0; out->n_points_avg = P; }
+        T::sync();
+        return;
+    }
+    Sphere sp;
+    sp.init(radius, P);
+    double cen[3] = {v.centroid[0], v.centroid[1], v.centroid[2]};
+    for (int k = T::tid(); k < P; k += T::SIZE) {
+        double px, py, pz, far;
+        sp.point(k, &px, &py, &pz);
+        bool hit = ray_scan(sh.S, n, cen, px, py, pz, &far);
+        ws->vals[k] = far;
+        ws->flag[k] = hit ? 1 : 0;
+    }
+    T::sync();
+    // compact in ray order (thread 0), then the numpy mean
+    if (T::tid() == 0) {
+        int m = 0;
+        for (int k = 0; k < P; ++k)
+            if (ws->flag[k]) ws->knn[m++] = ws->vals[k];
+        v.n_surv = m;
+    }
+    T::sync();
+    int m = v.n_surv;
+    double sum = np_sum_team<T>(ws->knn, m, ws->leaf, &v.red_v[15]);
+    if (T::tid() == 0) {
+        out->avg_d = (sum / (double)m) * 2.0;
+        out->n_points_avg = P;
+    }
+    T::sync();
+}
+
+// ---- Nelder-Mead in the window plane (scipy.optimize.fmin defaults, N = 2) ------------------
+template <class T>
+PW_HD inline void wave_fmin_xy(const Frame& F, int n, double z, double x0, double y0, double* xo,
+                               double* yo, int* n_eval) {
+    const int maxfun = 400, maxiter = 400;
+    const double xatol = 1e-4, fatol = 1e-4;
+    double sx[3], sy[3], fs[3];
+    int fcalls = 0;
+    auto fun = [&](double x, double y) {
+        fcalls += 1;
+        return -(wave_gap<T>(F, n, x, y, z, nullptr) * 2.0);
+    };
+    sx[0] = x0; sy[0] = y0;
+    sx[1] = (x0 != 0.0) ? (1.0 + 0.05) * x0 : 0.00025; sy[1] = y0;
+    sx[2] = x0; sy[2] = (y0 != 0.0) ? (1.0 + 0.05) * y0 : 0.00025;
+    for (int k = 0; k < 3; ++k) fs[k] = fun(sx[k], sy[k]);
+    auto sort3 = [&]() {  // stable insertion sort by fs
+        for (int i = 1; i < 3; ++i) {
+            double f = fs[i], a = sx[i], b = sy[i];
+            int j = i - 1;
+            while (j >= 0 && fs[j] > f) {
+                fs[j + 1] = fs[j]; sx[j + 1] = sx[j]; sy[j + 1] = sy[j];
+                --j;
+            }
+            fs[j + 1] = f; sx[j + 1] = a; sy[j + 1] = b;
+        }
+    };
+    sort3();
+    int iterations = 1;
+    while (fcalls < maxfun && iterations < maxiter) {
+        double dx1 = pw_abs(sx[1] - sx[0]), dx2 = pw_abs(sx[2] - sx[0]);
+        double dy1 = pw_abs(sy[1] - sy[0]), dy2 = pw_abs(sy[2] - sy[0]);
+        double mx = pw_max(pw_max(dx1, dy1), pw_max(dx2, dy2));
+        double mf = pw_max(pw_abs(fs[0] - fs[1]), pw_abs(fs[0] - fs[2]));
+        if (mx <= xatol && mf <= fatol) break;
+        double bx = (sx[0] + sx[1]) / 2.0, by = (sy[0] + sy[1]) / 2.0;
+        double xr = 2.0 * bx - sx[2], yr = 2.0 * by - sy[2];
+        bool over = false;  // _MaxFuncCallError
+        auto guarded = [&](double x, double y, double* f) {
+            if (fcalls >= maxfun) { over = true; return false; }
+            *f = fun(x, y);
+            return true;
+        };
+        double fxr;
+        if (guarded(xr, yr, &fxr)) {
+            bool doshrink = false;
+            if (fxr < fs[0]) {
+                double xe = 3.0 * bx - 2.0 * sx[2], ye = 3.0 * by - 2.0 * sy[2];
+                double fxe;
+                if (guarded(xe, ye, &fxe)) {
+                    if (fxe < fxr) { sx[2] = xe; sy[2] = ye; fs[2] = fxe; }
+                    else { sx[2] = xr; sy[2] = yr; fs[2] = fxr; }
+                }
+            } else if (fxr < fs[1]) {
+                sx[2] = xr; sy[2] = yr; fs[2] = fxr;
+            } else if (fxr < fs[2]) {
+                double xc = 1.5 * bx - 0.5 * sx[2], yc = 1.5 * by - 0.5 * sy[2];
+                double fxc;
+                if (guarded(xc, yc, &fxc)) {
+                    if (fxc <= fxr) { sx[2] = xc; sy[2] = yc; fs[2] = fxc; }
+                    else doshrink = true;
+                }
+            } else {
+                double xcc = 0.5 * bx + 0.5 * sx[2], ycc = 0.5 * by + 0.5 * sy[2];
+                double fxcc;
+                if (guarded(xcc, ycc, &fxcc)) {
+                    if (fxcc < fs[2]) { sx[2] = xcc; sy[2] = ycc; fs[2] = fxcc; }
+                    else doshrink = true;
+                }
+            }
+            if (doshrink && !over) {
+                for (int j = 1; j < 3 && !over; ++j) {
+                    sx[j] = sx[0] + 0.5 * (sx[j] - sx[0]);
+                    sy[j] = sy[0] + 0.5 * (sy[j] - sy[0]);
+                    double f;
+                    if (guarded(sx[j], sy[j], &f)) fs[j] = f;
+                }
+            }
+            if (!over) iterations += 1;
+        }
+        sort3();
+    }
+    *xo = sx[0];
+    *yo = sy[0];
+    *n_eval += fcalls;
+}
+
+// ---- one window (utilities.py:1191-1361), executed by ONE wave -------------------------------
+template <class T>
+PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int n, int cluster,
+                              const Sphere& sp) {
+    UnitVars& v = *sh.v;
+    const int w = T::wave();
+    Frame& R = sh.R[w];
+    int evals = 0;
+    // (i) the vector of the cluster with the largest 2*gap, first occurrence
+    double best = -PW_INF;
+    int bidx = 0x7fffffff;
+    for (int s = T::lane(); s < v.n_surv; s += T::WSIZE) {
+        if (ws->labels[s] == cluster) {
+            double val = ws->vals[s];
+            if (val > best || (val == best && s < bidx)) { best = val; bidx = s; }
+        }
+    }
+    T::wave_argmax(best, bidx);
+    const double* pv = &ws->pts[3 * ws->surv_k[bidx]];
+    double vx = pv[0], vy = pv[1], vz = pv[2];
+    // (ii) refined path scan, increment 0.1, lanes over path points
+    double nrm = norm3(vx, vy, vz);
+    int chunks = (int)np_floordiv(nrm, 0.1);
+    double cx = vx / (double)chunks, cy = vy / (double)chunks, cz = vz / (double)chunks;
+    double pbest = PW_INF;
+    int ppos = 0x7fffffff;
+    bool ok = true;
+    for (int k = T::lane(); k <= chunks; k += T::WSIZE) {
+        double m = point_gap(sh.S, n, cx * (double)k, cy * (double)k, cz * (double)k, nullptr);
+        if (!(m > 0.0)) ok = false;
+        if (m < pbest) { pbest = m; ppos = k; }
+    }
+    evals += chunks + 1;
+    ok = T::wave_all(ok);
+    if (!ok) {
+        if (T::lane() == 0) {
+            v.win_ok[cluster] = 0;
+            v.red_i[8 + w] += evals;
+        }
+        return;
+    }
+    T::wave_argmin(pbest, ppos);
+    double new_z = norm3(cx * (double)ppos, cy * (double)ppos, cz * (double)ppos);
+    // (iii) rotation angles (utilities.py:1235-1259)
+    double c1 = pw_abs(vx * 1.0 + vy * 0.0 + 0.0 * 0.0) /
+                (pw_sqrt(vx * vx + vy * vy + 0.0 * 0.0) * pw_sqrt(1.0 * 1.0 + 0.0 * 0.0 + 0.0 * 0.0));
+    double c2 = pw_abs(vx * 0.0 + vy * 0.0 + vz * 1.0) /
+                (pw_sqrt(vx * vx + vy * vy + vz * vz) * pw_sqrt(0.0 * 0.0 + 0.0 * 0.0 + 1.0 * 1.0));
+    double a1 = pw_acos01(c1), a2 = pw_acos01(c2);
+    bool sxp = vx >= 0.0, syp = vy >= 0.0, szp = vz >= 0.0;
+    if (szp) {
+        if (sxp && syp) { a1 = -a1; a2 = -a2; }
+        else if (!sxp && syp) { a1 = TWO_PI + a1; }
+        else if (sxp && !syp) { a2 = -a2; }
+        else { a1 = TWO_PI - a1; }
+    } else {
+        if (sxp && syp) { a1 = -a1; a2 = ONE_PI + a2; }
+        else if (!sxp && syp) { a2 = ONE_PI - a2; }
+        else if (sxp && !syp) { a2 = a2 + ONE_PI; }
+        else { a1 = -a1; a2 = ONE_PI - a2; }
+    }
+    double s1, co1, s2, co2;
+    pw_sincos(a1, &s1, &co1);
+    pw_sincos(a2, &s2, &co2);
+    // rows of a 3x3 matrix times a vector through BLAS dgemv: fma(m2,v2, fma(m0,v0, m1*v1))
+    auto row = [](double m0, double m1, double m2, double x, double y, double z) {
+        return pw_fma(m2, z, pw_fma(m0, x, m1 * y));
+    };
+    for (int i = T::lane(); i < n; i += T::WSIZE) {
+        double x = sh.S.x[i], y = sh.S.y[i], z = sh.S.z[i];
+        double x1 = row(co1, -s1, 0.0, x, y, z);
+        double y1 = row(s1, co1, 0.0, x, y, z);
+        double z1 = row(0.0, 0.0, 1.0, x, y, z);
+        double x2 = row(co2, 0.0, s2, x1, y1, z1);
+        double y2 = row(0.0, 1.0, 0.0, x1, y1, z1);
+        double z2 = row(-s2, 0.0, co2, x1, y1, z1);
+        x2 = x2 - 0.0; y2 = y2 - 0.0; z2 = z2 - new_z;
+        R.x[i] = x2; R.y[i] = y2; R.z[i] = z2;
+        R.xx[i] = sq3(x2, y2, z2);
+    }
+    T::wave_sync();
+    // (iv) diameter at the neck
+    double d0 = wave_gap<T>(R, n, 0.0, 0.0, 0.0, nullptr) * 2.0;
+    evals += 1;
+    // (v) neck position along z: L-BFGS-B, n = 1, bounds [-new_z, +inf)
+    Lbfgsb<1>* S = (Lbfgsb<1>*)sh.lb[w];
+    double lo1[1] = {-new_z}, up1[1] = {0.0}, x01[1] = {0.0};
+    int nbd1[1] = {1};
+    if (x01[0] < lo1[0]) x01[0] = lo1[0];   // np.clip(x0, lb, ub)
+    S->setup(x01, lo1, up1, nbd1, 1e7, 1e-5, 20);
+    int nit = 0;
+    bool have_last = false;
+    double lz = 0.0, lf = 0.0, lg = 0.0;
+    for (;;) {
+        S->step();
+        T::wave_sync();
+        if (S->task == LB_FG) {
+            double zc = S->x[0];
+            if (!(have_last && zc == lz)) {
+                double f0 = wave_gap<T>(R, n, 0.0, 0.0, zc, nullptr) * 2.0;
+                double h = fd_step(zc, lo1[0], PW_INF);
+                double z1 = zc + h;
+                double dz = z1 - zc;
+                double f1 = wave_gap<T>(R, n, 0.0, 0.0, z1, nullptr) * 2.0;
+                evals += 2;
+                lf = f0;
+                lg = (f1 - f0) / dz;
+                lz = zc;
+                have_last = true;
+            }
+            S->f = lf;
+            S->g[0] = lg;
+            T::wave_sync();
+        } else if (S->task == LB_NEW_X) {
+            nit += 1;
+            if (nit >= 15000) break;
+        } else {
+            break;
+        }
+    }
+    double zopt = S->x[0];
+    // (vi) brute 20 x 20 grid over +-d0/2, lanes over grid points, first minimum
+    double hlf = d0 / 2.0;
+    double gstart = -hlf;
+    double gstep = (hlf - gstart) / 19.0;
+    double gbest = PW_INF;
+    int gidx = 0x7fffffff;
+    for (int q = T::lane(); q < 400; q += T::WSIZE) {
+        int ix = q / 20, iy = q % 20;
+        double gx = (double)ix * gstep + gstart, gy = (double)iy * gstep + gstart;
+        double f = -(point_gap(R, n, gx, gy, zopt, nullptr) * 2.0);
+        if (f < gbest) { gbest = f; gidx = q; }
+    }
+    evals += 400;
+    T::wave_argmin(gbest, gidx);
+    double gx0 = (double)(gidx / 20) * gstep + gstart, gy0 = (double)(gidx % 20) * gstep + gstart;
+    double xo, yo;
+    wave_fmin_xy<T>(R, n, zopt, gx0, gy0, &xo, &yo, &evals);
+    // (vii) final diameter, (viii) back-rotation
+    double dfin = wave_gap<T>(R, n, xo, yo, zopt, nullptr) * 2.0;
+    evals += 1;
+    double wx = xo, wy = yo, wz = zopt + new_z;
+    double sm2, cm2, sm1, cm1;
+    pw_sincos(-a2, &sm2, &cm2);
+    pw_sincos(-a1, &sm1, &cm1);
+    double tx = row(cm2, 0.0, sm2, wx, wy, wz);
+    double ty = row(0.0, 1.0, 0.0, wx, wy, wz);
+    double tz = row(-sm2, 0.0, cm2, wx, wy, wz);
+    double ux = row(cm1, -sm1, 0.0, tx, ty, tz);
+    double uy = row(sm1, cm1, 0.0, tx, ty, tz);
+    double uz = row(0.0, 0.0, 1.0, tx, ty, tz);
+#ifdef PW_HOST_DEBUG
+    printf("DBG cluster %d vec %.17g %.17g %.17g a1 %.17g a2 %.17g new_z %.17g d0 %.17g zopt %.17g g0 %.17g %.17g xy %.17g %.17g dfin %.17g\n", cluster, vx, vy, vz, a1, a2, new_z, d0, zopt, gx0, gy0, xo, yo, dfin);
+#endif
+    if (T::lane() == 0) {
+        v.win_ok[cluster] = 1;
+        v.win_d[cluster] = dfin;
+        v.win_c[cluster][0] = ux + v.shift[0];
+        v.win_c[cluster][1] = uy + v.shift[1];
+        v.win_c[cluster][2] = uz + v.shift[2];
+        v.red_i[8 + w] += evals;
+    }
+}
+
+// ---- stage: windows ----------------------------------------------------------------------------
+template <class T>
+PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out) {
+    UnitVars& v = *sh.v;
+    // shift so that the optimised pore centre is the origin (utilities.py:1388-1390)
+    if (T::tid() == 0) {
+        for (int c = 0; c < 3; ++c) {
+            double adjust = v.com[c] - v.opt_c[c];
+            v.shift[c] = v.com[c] - adjust;
+        }
+        for (int c = 0; c < PW_W_MAX; ++c) v.win_ok[c] = 0;
+        for (int w = 0; w < 8; ++w) v.red_i[8 + w] = 0;
+    }
+    T::sync();
+    make_shifted<T>(sh, n, v.shift[0], v.shift[1], v.shift[2]);
+    double keep_d = v.maxd;
+    int keep_i = v.maxd_i, keep_j = v.maxd_j;
+    T::sync();
+    team_max_dim<T>(sh, sh.S, n);
+    double radius = v.maxd / 2.0;
+    T::sync();
+    if (T::tid() == 0) { v.maxd = keep_d; v.maxd_i = keep_i; v.maxd_j = keep_j; }
+    int P = sampling_count(radius);
+    if (T::tid() == 0) {
+        out->n_points = P;
+        out->sphere_r = radius;
+        out->n_windows = -1;
+        out->n_clusters = 0;
+        out->n_survivors = 0;
+        out->eps = 0.0;
+    }
+    if (P > PW_P_MAX || P < 16) {
+        if (T::tid() == 0) v.status |= PW_ST_POINTS_OVERFLOW;
+        T::sync();
+        return;
+    }
+    Sphere sp;
+    sp.init(radius, P);
+    for (int k = T::tid(); k < P; k += T::SIZE)
+        sp.point(k, &ws->pts[3 * k], &ws->pts[3 * k + 1], &ws->pts[3 * k + 2]);
+    T::sync();
+    // ---- eps: mean of all 10-NN distances (self included), utilities.py:1427-1434 ----
+    {
+        // candidates within an index window; exactness is verified per point and a
+        // full scan is done when the window cannot be proven sufficient
+        double zstep = pw_abs(sp.step) * radius;
+        int W = (int)(4.0 * pw_sqrt((double)P)) + 8;
+        for (int k = T::tid(); k < P; k += T::SIZE) {
+            double px = ws->pts[3 * k], py = ws->pts[3 * k + 1], pz = ws->pts[3 * k + 2];
+            double t[10];
+            int lo = k - W < 0 ? 0 : k - W, hi = k + W > P - 1 ? P - 1 : k + W;
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int q = 0; q < 10; ++q) t[q] = PW_INF;
+                for (int j = lo; j <= hi; ++j) {
+                    double ax = px - ws->pts[3 * j], ay = py - ws->pts[3 * j + 1],
+                           az = pz - ws->pts[3 * j + 2];
+                    double d = 0.0;
+                    d = d + ax * ax; d = d + ay * ay; d = d + az * az;
+                    if (d < t[9]) {
+                        int q = 9;
+                        while (q > 0 && t[q - 1] > d) { t[q] = t[q - 1]; --q; }
+                        t[q] = d;
+                    }
+                }
+                bool full = (lo == 0 && hi == P - 1);
+                if (full || pw_sqrt(t[9]) < (double)(W - 1) * zstep) break;
+                lo = 0; hi = P - 1;
+            }
+            for (int q = 0; q < 10; ++q) ws->knn[k * 10 + q] = pw_sqrt(t[q]);
+        }
+        T::sync();
+        double sum = np_sum_team<T>(ws->knn, P * 10, ws->leaf, &v.red_v[15]);
+        double m = sum / (double)(P * 10);
+        if (T::tid() == 0) { v.eps = m + pw_sqrt(m); out->eps = v.eps; }
+        T::sync();
+    }
+    // ---- sampling vectors: ray test + coarse path scan, one vector per thread ----
+    {
+        double cen[3] = {v.centroid[0], v.centroid[1], v.centroid[2]};
+        int evals = 0;
+        for (int k = T::tid(); k < P; k += T::SIZE) {
+            double px = ws->pts[3 * k], py = ws->pts[3 * k + 1], pz = ws->pts[3 * k + 2], far;
+            bool hit = ray_scan(sh.S, n, cen, px, py, pz, &far);
+            unsigned char okf = 0;
+            if (!hit) {
+                double g2, chunk[3];
+                int pos;
+                if (path_scan_thread(sh.S, n, px, py, pz, 1.0, &g2, &pos, chunk, &evals)) {
+                    okf = 1;
+                    ws->knn[k] = g2;
+                }
+            }
+            ws->flag[k] = okf;
+        }
+        T::sync();
+        if (T::tid() == 0) {
+            int m = 0;
+            for (int k = 0; k < P; ++k)
+                if (ws->flag[k]) { ws->surv_k[m] = k; ws->vals[m] = ws->knn[k]; ++m; }
+            v.n_surv = m;
+            out->n_survivors = m;
+        }
+        T::sync();
+        (void)evals;
+    }
+    int ns = v.n_surv;
+    if (ns == 0) {
+        // no vector reaches the outside: find_windows returns None
+        if (T::tid() == 0) out->n_windows = -1;
+        T::sync();
+        return;
+    }
+    // ---- DBSCAN(eps, min_samples = 5) on the survivors' end points -----------------------
+    {
+        const int words = (ns + 63) / 64;
+        double e2 = v.eps * v.eps;
+        for (int i = T::tid(); i < ns; i += T::SIZE) {
+            const double* pi = &ws->pts[3 * ws->surv_k[i]];
+            double px = pi[0], py = pi[1], pz = pi[2];
+            int cnt = 0;
+            for (int wd = 0; wd < words; ++wd) {
+                unsigned long long bits = 0;
+                int jend = (wd * 64 + 64 < ns) ? wd * 64 + 64 : ns;
+                for (int j = wd * 64; j < jend; ++j) {
+                    const double* pj = &ws->pts[3 * ws->surv_k[j]];
+                    double ax = px - pj[0], ay = py - pj[1], az = pz - pj[2];
+                    double d = 0.0;
+                    d = d + ax * ax; d = d + ay * ay; d = d + az * az;
+                    if (d <= e2) { bits |= 1ull << (j - wd * 64); ++cnt; }
+                }
+                ws->adj[(size_t)i * (PW_P_MAX / 64) + wd] = bits;
+            }
+            ws->core[i] = cnt >= 5 ? 1 : 0;
+            ws->labels[i] = -1;
+        }
+        T::sync();
+        if (T::tid() == 0) {
+            // sklearn/cluster/_dbscan_inner.pyx: depth-first expansion in index order
+            int label = 0;
+            for (int i0 = 0; i0 < ns; ++i0) {
+                if (ws->labels[i0] != -1 || !ws->core[i0]) continue;
+                // The reference pushes a neighbour once per incident edge; labelling at
+                // push time visits the same set and gives the same labels (core points:
+                // connected components numbered by their smallest index; border points:
+                // the first -- lowest-numbered -- cluster that touches them) with a stack
+                // that never holds more than ns entries.
+                int top = 0;
+                ws->labels[i0] = label;
+                ws->stack[top++] = i0;
+                while (top) {
+                    int i = ws->stack[--top];
+                    for (int wd = 0; wd < words; ++wd) {
+                        unsigned long long bits = ws->adj[(size_t)i * (PW_P_MAX / 64) + wd];
+                        while (bits) {
+                            int b = __builtin_ctzll(bits);
+                            bits &= bits - 1;
+                            int nb = wd * 64 + b;
+                            if (ws->labels[nb] == -1) {
+                                ws->labels[nb] = label;
+                                if (ws->core[nb]) ws->stack[top++] = nb;
+                            }
+                        }
+                    }
+                }
+                label += 1;
+            }
+            v.n_clusters = label;
+            out->n_clusters = label;
+            if (label > PW_W_MAX) v.status |= PW_ST_WINDOW_OVERFLOW;
+        }
+        T::sync();
+    }
+    // ---- one window per cluster, clusters dealt round-robin to the waves -------------------
+    int ncl = v.n_clusters < PW_W_MAX ? v.n_clusters : PW_W_MAX;
+    for (int c = T::wave(); c < ncl; c += T::NWAVES) wave_window<T>(sh, ws, n, c, sp);
+    T::sync();
+    if (T::tid() == 0) {
+        int m = 0;
+        for (int c = 0; c < ncl; ++c) {
+            if (v.win_ok[c]) {
+                out->win_d[m] = v.win_d[c];
+                out->win_c[m][0] = v.win_c[c][0];
+                out->win_c[m][1] = v.win_c[c][1];
+                out->win_c[m][2] = v.win_c[c][2];
+                if (v.win_d[c] < 0.0) v.status |= PW_ST_WINDOW_NEGATIVE;
+                ++m;
+            } else {
+                v.status |= PW_ST_WINDOW_DROPPED;
+            }
+        }
+        out->n_windows = m;
+        for (int w = 0; w < T::NWAVES && w < 8; ++w) v.n_eval += v.red_i[8 + w];
+    }
+    T::sync();
+}
+
+// ---- the unit ------------------------------------------------------------------------------------
+template <class T>
+PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const double* xyz,
+                               const double* vdw, const double* mass, unsigned stages,
+                               pw_unit_out* out) {
+    if (stages & PW_STAGE_WINDOWS) stages |= PW_STAGE_OPT;
+    stages |= PW_STAGE_BASIC;
+    if (T::tid() == 0) {
+        out->avg_d = 0.0;
+        out->pore_opt_d = 0.0; out->pore_opt_atom = -1; out->pore_vol_opt = 0.0;
+        out->pore_opt_c[0] = out->pore_opt_c[1] = out->pore_opt_c[2] = 0.0;
+        out->n_windows = -1; out->n_clusters = 0;
+        out->n_points = 0; out->n_points_avg = 0; out->n_survivors = 0;
+        out->opt_nit = 0; out->opt_nfev = 0; out->opt_task = 0; out->opt_msg = 0;
+        out->eps = 0.0; out->sphere_r = 0.0;
+        for (int w = 0; w < PW_W_MAX; ++w) {
+            out->win_d[w] = 0.0;
+            out->win_c[w][0] = out->win_c[w][1] = out->win_c[w][2] = 0.0;
+        }
+    }
+    load_unit<T>(sh, n, xyz, vdw, mass);
+    stage_basic<T>(sh, n, out);
+    if (stages & PW_STAGE_OPT) stage_opt<T>(sh, n, out);
+    if (stages & PW_STAGE_AVG) stage_average<T>(sh, ws, n, out);
+    if ((stages & PW_STAGE_WINDOWS) && !(sh.v->status & PW_ST_NEGATIVE_PORE))
+        stage_windows<T>(sh, ws, n, out);
+    if (T::tid() == 0) {
+        out->status = sh.v->status;
+        out->n_eval = sh.v->n_eval;
+    }
+    T::sync();
+}
+
+}  // namespace pw

@@ -1,0 +1,29 @@
+// tests/hostsim/unit_probe.cpp -- runs the unit pipeline of
+// pywindow_amd/csrc/pw_unit.hpp on the HOST with a one-thread team, so the
+// control flow of the HIP kernels can be checked against the golden vectors in
+// a container without a GPU.  Test infrastructure only: the product library
+// (libpywindow_hip.so) never links or calls this.
+#include "../../pywindow_amd/csrc/pw_unit.hpp"
+#include <stdlib.h>
+#include <string.h>
+using namespace pw;
+extern "C" int hs_analysis_batch(long n_units, const long* off, const double* xyz, const double* vdw,
+                                 const double* mass, unsigned stages, pw_unit_out* out) {
+    int nmax = 0;
+    for (long u = 0; u < n_units; ++u) { int n = (int)(off[u + 1] - off[u]); if (n > nmax) nmax = n; }
+    size_t bytes = UnitShared::bytes(nmax, 1);
+    unsigned char* lds = (unsigned char*)aligned_alloc(16, (bytes + 15) & ~(size_t)15);
+    TeamWorkspace* ws = (TeamWorkspace*)malloc(sizeof(TeamWorkspace));
+    if (!lds || !ws) return -5;
+    for (long u = 0; u < n_units; ++u) {
+        memset(lds, 0, bytes);
+        UnitShared sh;
+        sh.carve(lds, nmax, 1);
+        int n = (int)(off[u + 1] - off[u]);
+        memset(&out[u], 0, sizeof(pw_unit_out));
+        analyse_unit<HostTeam>(sh, ws, n, xyz + 3 * off[u], vdw + off[u], mass + off[u], stages, &out[u]);
+    }
+    free(lds); free(ws);
+    return 0;
+}
+extern "C" int hs_sizeof_unit_out() { return (int)sizeof(pw_unit_out); }
