@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""bench.py -- trajectory frames/s for full_analysis (pore + windows) on the
+1000-frame synthetic CC3 trajectory (BASELINE.json config 2), N GPUs of one node.
+
+One *step* = one pass of the whole hot path (all stages) over the rank's batch
+of 1000 frames, inputs already resident in HBM.  Weak scaling: every rank
+analyses its own 1000 frames (frames rank*1000 .. rank*1000+999 of the synthetic
+generator); no data-path collective.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAMES = 1000
+ALGO_BYTES_PER_UNIT = 24 * 168 + 600   # coordinates read once + one result record
+ALGO_FLOP_PER_UNIT = 2.0e7
+HBM_PEAK_GBS = 8000.0
+FP64_VECTOR_PEAK_TFLOPS = 78.6
+
+
+def cpu_baseline(elements, frames, vdw, mass, budget_s=20.0):
+    """The oracle (numpy/scipy/sklearn restatement of the reference's path,
+    bit-identical to it on the golden inputs) timed on this host, one core."""
+    from oracle import pw_oracle as O
+
+    O.build()
+    t0 = time.perf_counter()
+    n = 0
+    while n < len(frames) and (n < 2 or time.perf_counter() - t0 < budget_s):
+        O.full_analysis(frames[n], vdw, mass)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} frames of the same synthetic trajectory, oracle/pw_oracle.py, 1 process"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=FRAMES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from pywindow_amd import _lib, synth
+    from pywindow_amd import element_data as E
+
+    elements, frames = synth.synthetic_units(args.frames, first=rank * args.frames)
+    ids = E.element_ids(elements)
+    vdw, mass = E.VDW[ids], E.MASS[ids]
+    ctx = _lib.Context(local_rank)
+    res = ctx.upload(_lib.Batch.uniform(frames, vdw, mass))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        res.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res.launch()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res.launch()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    out = res.download()
+    ok = bool((out["status"] == 0).all())
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        value = world * args.frames * args.steps / elapsed
+        # kernel duration measured with HIP events on the launch stream
+        k_ms = res.time_launches(max(3, min(args.steps, 10)))
+        units_per_s = args.frames / (k_ms * 1e-3)
+        achieved_gbs = units_per_s * ALGO_BYTES_PER_UNIT / 1e9
+        line = {
+            "metric": "trajectory frames/sec full_analysis (pore+windows), CC3 1k-frame",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "CC3 1000-frame synthetic DL_POLY trajectory (BASELINE configs[1]), "
+                                   "per-frame pore+windows, 168 atoms/frame",
+                       "frames_per_gpu": args.frames, "stages": "all", "results_ok": ok,
+                       "windows_eq_4": int((out["n_windows"] == 4).sum())},
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "pw_analyse_kernel", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_UNIT * args.frames,
+                         "fp64_valu": {"achieved_tflops": units_per_s * ALGO_FLOP_PER_UNIT / 1e12,
+                                       "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                                       "frac": units_per_s * ALGO_FLOP_PER_UNIT / 1e12 / FP64_VECTOR_PEAK_TFLOPS}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(elements, frames, vdw, mass)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -106,6 +106,12 @@ void pw_context_destroy(pw_context *ctx);
  * (pore_diameter, max_dim, ... ) the parity tests exercise one by one. */
 int pw_analysis_batch(pw_context *ctx, const pw_batch_in *in, uint32_t stages, pw_unit_out *out);
 
+/* Fine-grained: min_i(|r_i - p| - vdw_i) and its first argmin at arbitrary points,
+ * point q belonging to unit unit_of_point[q]  (pore_diameter(.., com=p)[0]/2 and [1],
+ * utilities.py:375-388; the objective of every optimiser on the path). */
+int pw_point_gaps(pw_context *ctx, const pw_batch_in *in, const int64_t *unit_of_point,
+                  const double *points, int64_t n_points, double *gap, int32_t *argmin);
+
 /* Resident path (inputs stay in HBM between launches; used by bench.py and the
  * trajectory driver when several analyses run on the same frames). */
 int pw_resident_upload(pw_context *ctx, const pw_batch_in *in, pw_resident **res);

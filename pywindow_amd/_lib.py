@@ -1,0 +1,298 @@
+"""ctypes binding of libpywindow_hip.so (C ABI in include/pywindow_amd.h).
+
+There is no CPU fallback: importing this module only loads the shared library;
+every compute call needs a HIP device and raises :class:`PwHipError` otherwise.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import pathlib
+
+import numpy as np
+
+W_MAX = 16
+P_MAX = 2048
+
+STAGE_BASIC = 1
+STAGE_AVG = 2
+STAGE_OPT = 4
+STAGE_WINDOWS = 8
+STAGE_ALL = 15
+
+ST_NEGATIVE_PORE = 1
+ST_WINDOW_OVERFLOW = 2
+ST_POINTS_OVERFLOW = 4
+ST_WINDOW_DROPPED = 8
+ST_WINDOW_NEGATIVE = 16
+
+_PKG = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libpywindow_hip.so"
+
+
+class PwHipError(RuntimeError):
+    """The HIP engine is missing, has no device, or a call failed."""
+
+
+class BatchIn(ctypes.Structure):
+    _fields_ = [
+        ("n_units", ctypes.c_int64),
+        ("atom_offset", ctypes.POINTER(ctypes.c_int64)),
+        ("xyz", ctypes.POINTER(ctypes.c_double)),
+        ("vdw", ctypes.POINTER(ctypes.c_double)),
+        ("mass", ctypes.POINTER(ctypes.c_double)),
+    ]
+
+
+#: numpy mirror of ``pw_unit_out`` (natural C alignment)
+UNIT_OUT_DTYPE = np.dtype(
+    [
+        ("n_atoms", np.int32),
+        ("status", np.int32),
+        ("mw", np.float64),
+        ("com", np.float64, (3,)),
+        ("maxd", np.float64),
+        ("maxd_i", np.int32),
+        ("maxd_j", np.int32),
+        ("avg_d", np.float64),
+        ("pore_d", np.float64),
+        ("pore_atom", np.int32),
+        ("pore_opt_atom", np.int32),
+        ("pore_vol", np.float64),
+        ("pore_opt_d", np.float64),
+        ("pore_opt_c", np.float64, (3,)),
+        ("pore_vol_opt", np.float64),
+        ("n_windows", np.int32),
+        ("n_clusters", np.int32),
+        ("win_d", np.float64, (W_MAX,)),
+        ("win_c", np.float64, (W_MAX, 3)),
+        ("n_points", np.int32),
+        ("n_points_avg", np.int32),
+        ("n_survivors", np.int32),
+        ("opt_nit", np.int32),
+        ("opt_nfev", np.int32),
+        ("opt_task", np.int32),
+        ("opt_msg", np.int32),
+        ("n_eval", np.int32),
+        ("eps", np.float64),
+        ("sphere_r", np.float64),
+    ],
+    align=True,
+)
+
+#: every symbol include/pywindow_amd.h declares (checked by the CPU test-suite)
+EXPORTED_SYMBOLS = [
+    "pw_device_count",
+    "pw_version",
+    "pw_last_error",
+    "pw_context_create",
+    "pw_context_destroy",
+    "pw_analysis_batch",
+    "pw_point_gaps",
+    "pw_resident_upload",
+    "pw_resident_launch",
+    "pw_resident_sync",
+    "pw_resident_download",
+    "pw_resident_free",
+    "pw_resident_time",
+    "pw_resident_device_results",
+    "pw_resident_units",
+    "pw_context_stream",
+    "pw_history_open",
+    "pw_history_frames",
+    "pw_history_atoms",
+    "pw_history_keytrj",
+    "pw_history_imcon",
+    "pw_history_atom_keys",
+    "pw_history_read",
+    "pw_history_close",
+]
+
+_lib = None
+
+
+def load():
+    """Load libpywindow_hip.so (built by ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise PwHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback."
+        )
+    try:
+        L = ctypes.CDLL(str(LIB_PATH))
+    except OSError as exc:  # pragma: no cover - depends on the machine
+        raise PwHipError(f"cannot load {LIB_PATH}: {exc}") from exc
+    vp = ctypes.c_void_p
+    L.pw_device_count.restype = ctypes.c_int
+    L.pw_version.restype = ctypes.c_char_p
+    L.pw_last_error.restype = ctypes.c_char_p
+    L.pw_context_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.pw_context_destroy.argtypes = [vp]
+    L.pw_context_destroy.restype = None
+    L.pw_analysis_batch.argtypes = [vp, ctypes.POINTER(BatchIn), ctypes.c_uint32, vp]
+    L.pw_point_gaps.argtypes = [vp, ctypes.POINTER(BatchIn), vp, vp, ctypes.c_int64, vp, vp]
+    L.pw_resident_upload.argtypes = [vp, ctypes.POINTER(BatchIn), ctypes.POINTER(vp)]
+    L.pw_resident_launch.argtypes = [vp, vp, ctypes.c_uint32]
+    L.pw_resident_sync.argtypes = [vp]
+    L.pw_resident_download.argtypes = [vp, vp, vp]
+    L.pw_resident_free.argtypes = [vp, vp]
+    L.pw_resident_free.restype = None
+    L.pw_resident_time.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    L.pw_resident_device_results.argtypes = [vp]
+    L.pw_resident_device_results.restype = vp
+    L.pw_resident_units.argtypes = [vp]
+    L.pw_resident_units.restype = ctypes.c_int64
+    L.pw_context_stream.argtypes = [vp]
+    L.pw_context_stream.restype = vp
+    L.pw_history_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+    L.pw_history_frames.argtypes = [vp]
+    L.pw_history_frames.restype = ctypes.c_int64
+    L.pw_history_atoms.argtypes = [vp]
+    L.pw_history_atoms.restype = ctypes.c_int64
+    L.pw_history_keytrj.argtypes = [vp]
+    L.pw_history_imcon.argtypes = [vp]
+    L.pw_history_atom_keys.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
+    L.pw_history_atom_keys.restype = ctypes.c_int64
+    L.pw_history_read.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, vp]
+    L.pw_history_close.argtypes = [vp]
+    L.pw_history_close.restype = None
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load().pw_last_error().decode(errors="replace")
+        raise PwHipError(f"{what} failed with code {rc}: {msg}")
+
+
+def _dptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+class Batch:
+    """Host-side description of a ragged batch of molecules (keeps arrays alive)."""
+
+    def __init__(self, atom_offset, xyz, vdw, mass):
+        self.atom_offset = np.ascontiguousarray(atom_offset, dtype=np.int64)
+        self.xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        self.vdw = np.ascontiguousarray(vdw, dtype=np.float64)
+        self.mass = np.ascontiguousarray(mass, dtype=np.float64)
+        n_atoms = int(self.atom_offset[-1]) if len(self.atom_offset) else 0
+        if len(self.xyz) != n_atoms or len(self.vdw) != n_atoms or len(self.mass) != n_atoms:
+            raise ValueError("atom_offset does not match the per-atom arrays")
+        self.n_units = len(self.atom_offset) - 1
+        self.c = BatchIn(
+            self.n_units,
+            self.atom_offset.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+            _dptr(self.xyz),
+            _dptr(self.vdw),
+            _dptr(self.mass),
+        )
+
+    @classmethod
+    def uniform(cls, coords, vdw, mass):
+        """``coords`` (U, N, 3) of one molecule type; ``vdw``/``mass`` (N,)."""
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        u, n, _ = coords.shape
+        off = np.arange(u + 1, dtype=np.int64) * n
+        return cls(off, coords.reshape(-1, 3), np.tile(vdw, u), np.tile(mass, u))
+
+
+class Context:
+    """One GPU: stream + workspace.  ``device`` is the HIP ordinal."""
+
+    def __init__(self, device: int = 0):
+        L = load()
+        h = ctypes.c_void_p()
+        _check(L.pw_context_create(device, ctypes.byref(h)), "pw_context_create")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            load().pw_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def analyse(self, batch: Batch, stages: int = STAGE_ALL) -> np.ndarray:
+        out = np.zeros(batch.n_units, dtype=UNIT_OUT_DTYPE)
+        if batch.n_units == 0:
+            return out
+        _check(
+            load().pw_analysis_batch(self._h, ctypes.byref(batch.c), stages, out.ctypes.data),
+            "pw_analysis_batch",
+    "pw_point_gaps",
+        )
+        return out
+
+    def point_gaps(self, batch: Batch, unit_of_point, points):
+        """min_i(|r_i - p| - vdw_i), argmin for each point (objective of the optimisers)."""
+        u = np.ascontiguousarray(unit_of_point, dtype=np.int64)
+        p = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        gap = np.zeros(len(p))
+        arg = np.zeros(len(p), dtype=np.int32)
+        _check(
+            load().pw_point_gaps(self._h, ctypes.byref(batch.c), u.ctypes.data, p.ctypes.data, len(p),
+                                 gap.ctypes.data, arg.ctypes.data),
+            "pw_point_gaps",
+        )
+        return gap, arg
+
+    def upload(self, batch: Batch) -> "Resident":
+        return Resident(self, batch)
+
+    @property
+    def stream(self) -> int:
+        return load().pw_context_stream(self._h) or 0
+
+
+class Resident:
+    """A batch kept in HBM across launches."""
+
+    def __init__(self, ctx: Context, batch: Batch):
+        self.ctx = ctx
+        self.n_units = batch.n_units
+        h = ctypes.c_void_p()
+        _check(load().pw_resident_upload(ctx._h, ctypes.byref(batch.c), ctypes.byref(h)), "pw_resident_upload")
+        self._h = h
+
+    def launch(self, stages: int = STAGE_ALL):
+        _check(load().pw_resident_launch(self.ctx._h, self._h, stages), "pw_resident_launch")
+
+    def sync(self):
+        _check(load().pw_resident_sync(self.ctx._h), "pw_resident_sync")
+
+    def download(self) -> np.ndarray:
+        out = np.zeros(self.n_units, dtype=UNIT_OUT_DTYPE)
+        if self.n_units:
+            _check(load().pw_resident_download(self.ctx._h, self._h, out.ctypes.data), "pw_resident_download")
+        return out
+
+    def time_launches(self, iters: int, stages: int = STAGE_ALL) -> float:
+        ms = ctypes.c_float()
+        _check(load().pw_resident_time(self.ctx._h, self._h, stages, iters, ctypes.byref(ms)), "pw_resident_time")
+        return float(ms.value)
+
+    @property
+    def device_results_ptr(self) -> int:
+        return load().pw_resident_device_results(self._h) or 0
+
+    def free(self):
+        if self._h:
+            load().pw_resident_free(self.ctx._h, self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.free()
+        except Exception:
+            pass

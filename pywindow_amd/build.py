@@ -1,0 +1,50 @@
+"""Build libpywindow_hip.so in-tree with hipcc for gfx950 (no CPU fallback exists).
+
+    python -m pywindow_amd.build            # rebuild if sources are newer
+"""
+
+from __future__ import annotations
+
+import os
+import pathlib
+import shutil
+import subprocess
+import sys
+
+PKG = pathlib.Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+OUT = PKG / "libpywindow_hip.so"
+SOURCES = ["pw_kernels.hip", "pw_history.cpp"]
+# -ffp-contract=off: the numerical core relies on explicit fma() only (pw_common.hpp)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and pathlib.Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (expected /opt/rocm/bin/hipcc)")
+
+
+def stale() -> bool:
+    if not OUT.exists():
+        return True
+    t = OUT.stat().st_mtime
+    deps = list(CSRC.glob("*")) + [PKG.parent / "include" / "pywindow_amd.h"]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> pathlib.Path:
+    if not force and not stale():
+        return OUT
+    cmd = [hipcc(), *FLAGS, "-x", "hip", str(CSRC / "pw_kernels.hip"), "-x", "c++",
+           str(CSRC / "pw_history.cpp"), "-o", str(OUT)]
+    if verbose:
+        print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

@@ -1,0 +1,383 @@
+// pw_kernels.hip -- gfx950 kernels and the C ABI of libpywindow_hip.so
+// (include/pywindow_amd.h).
+//
+// One persistent workgroup analyses one (frame, molecule) unit at a time: its
+// coordinates, radii and the optimiser state live in LDS for the unit's whole
+// lifetime (UnitShared, pw_unit.hpp), units are handed out by an atomic work
+// counter so uneven optimiser iteration counts do not idle CUs, and one launch
+// covers every unit of a trajectory.  The arithmetic is FP64 vector ALU work with
+// exact wave-level (value, index) min reductions; there is nothing GEMM-shaped
+// here and MFMA is not used.
+//
+// Built with:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (fused
+// multiply-adds only where the source writes pw_fma).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/pywindow_amd.h"
+#include "pw_unit.hpp"
+
+using namespace pw;
+
+namespace {
+
+thread_local char g_err[512] = "";
+void set_err(const char* what, hipError_t e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+}
+#define HIP_TRY(call)                         \
+    do {                                      \
+        hipError_t e_ = (call);               \
+        if (e_ != hipSuccess) {               \
+            set_err(#call, e_);               \
+            return PW_E_HIP;                  \
+        }                                     \
+    } while (0)
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
+pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
+                  const double* __restrict__ vdw, const double* __restrict__ mass, unsigned stages,
+                  int nmax, TeamWorkspace* __restrict__ workspaces, unsigned long long* counter,
+                  pw_unit_out* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ long s_unit;
+    using T = DeviceTeam<NW>;
+    UnitShared sh;
+    sh.carve(lds, nmax, NW);
+    TeamWorkspace* ws = workspaces + blockIdx.x;
+    for (;;) {
+        if (threadIdx.x == 0) s_unit = (long)atomicAdd(counter, 1ull);
+        __syncthreads();
+        long u = s_unit;
+        __syncthreads();
+        if (u >= n_units) break;
+        long a0 = atom_offset[u];
+        int n = (int)(atom_offset[u + 1] - a0);
+        analyse_unit<T>(sh, ws, n, xyz + 3 * a0, vdw + a0, mass + a0, stages, out + u);
+    }
+}
+
+// Fine-grained entry: min_i(|r_i - p| - vdw_i) and its first argmin for arbitrary
+// points p (reference pore_diameter(elements, coordinates, com=p)/2,
+// utilities.py:375-388).  One lane per point, atoms streamed from global memory.
+__global__ void pw_point_gap_kernel(long n_points, const long* __restrict__ unit_of_point,
+                                    const double* __restrict__ points,
+                                    const long* __restrict__ atom_offset,
+                                    const double* __restrict__ xyz, const double* __restrict__ vdw,
+                                    double* __restrict__ gap, int* __restrict__ arg) {
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_points) return;
+    long u = unit_of_point[q];
+    long a0 = atom_offset[u];
+    int n = (int)(atom_offset[u + 1] - a0);
+    double px = points[3 * q], py = points[3 * q + 1], pz = points[3 * q + 2];
+    double pp = sq3(px, py, pz);
+    double best = PW_INF;
+    int bi = 0;
+    for (int i = 0; i < n; ++i) {
+        double x = xyz[3 * (a0 + i)], y = xyz[3 * (a0 + i) + 1], z = xyz[3 * (a0 + i) + 2];
+        double xx = sq3(x, y, z);
+        double g = pw_fma(z, pz, pw_fma(x, px, y * py));
+        double d2 = ((-2.0 * g) + xx) + pp;
+        double d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
+        double v = d - vdw[a0 + i];
+        if (v < best) { best = v; bi = i; }
+    }
+    gap[q] = best;
+    arg[q] = bi;
+}
+
+}  // namespace
+
+struct pw_context {
+    int device;
+    hipStream_t stream;
+    int n_cu;
+    size_t lds_per_cu;
+    TeamWorkspace* ws;
+    int ws_blocks;
+    unsigned long long* counter;
+    hipEvent_t ev0, ev1;
+};
+
+struct pw_resident {
+    long n_units;
+    long n_atoms;
+    int nmax;
+    long* d_offset;
+    double* d_xyz;
+    double* d_vdw;
+    double* d_mass;
+    pw_unit_out* d_out;
+};
+
+static int ensure_workspace(pw_context* c, int blocks) {
+    if (c->ws_blocks >= blocks) return PW_OK;
+    if (c->ws) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(c->ws));
+        c->ws = nullptr;
+        c->ws_blocks = 0;
+    }
+    HIP_TRY(hipMalloc((void**)&c->ws, (size_t)blocks * sizeof(TeamWorkspace)));
+    c->ws_blocks = blocks;
+    return PW_OK;
+}
+
+// choose the team width and grid for a batch
+static int plan_launch(pw_context* c, long n_units, int nmax, int* nw_out, size_t* lds_out,
+                       int* grid_out) {
+    const size_t max_lds = 160 * 1024 - 256;
+    int nw = 4;
+    size_t lds = UnitShared::bytes(nmax, nw) + 64;
+    while (lds > max_lds && nw > 1) {
+        nw >>= 1;
+        lds = UnitShared::bytes(nmax, nw) + 64;
+    }
+    if (lds > max_lds) {
+        snprintf(g_err, sizeof(g_err), "molecule with %d atoms does not fit in LDS", nmax);
+        return PW_E_TOO_LARGE;
+    }
+    int per_cu = (int)(c->lds_per_cu / lds);
+    int wave_cap = 32 / nw;  // 32 waves per CU
+    if (per_cu > wave_cap) per_cu = wave_cap;
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    long grid = (long)c->n_cu * per_cu;
+    if (grid > n_units) grid = n_units;
+    if (grid < 1) grid = 1;
+    *nw_out = nw;
+    *lds_out = lds;
+    *grid_out = (int)grid;
+    return PW_OK;
+}
+
+template <int NW>
+static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, size_t lds, int grid) {
+    auto kern = pw_analyse_kernel<NW>;
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, r->n_units, r->d_offset,
+                       r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, c->ws, c->counter, r->d_out);
+    HIP_TRY(hipGetLastError());
+    return PW_OK;
+}
+
+extern "C" {
+
+const char* pw_version(void) { return "pywindow_amd 0.1 (gfx950)"; }
+const char* pw_last_error(void) { return g_err; }
+
+int pw_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pw_context_create(int device, pw_context** out) {
+    if (!out) return PW_E_BAD_ARG;
+    int n = pw_device_count();
+    if (n <= 0 || device < 0 || device >= n) {
+        snprintf(g_err, sizeof(g_err), "no usable HIP device (count=%d, requested %d)", n, device);
+        return PW_E_NO_DEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    pw_context* c = new (std::nothrow) pw_context();
+    if (!c) return PW_E_NOMEM;
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount;
+    c->lds_per_cu = 160 * 1024;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void**)&c->counter, sizeof(unsigned long long)));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    *out = c;
+    return PW_OK;
+}
+
+void pw_context_destroy(pw_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->counter) (void)hipFree(c->counter);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void* pw_context_stream(pw_context* c) { return c ? (void*)c->stream : nullptr; }
+
+int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
+    if (!c || !r) return PW_E_BAD_ARG;
+    if (r->n_units == 0) return PW_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int nw, grid;
+    size_t lds;
+    int rc = plan_launch(c, r->n_units, r->nmax, &nw, &lds, &grid);
+    if (rc != PW_OK) return rc;
+    rc = ensure_workspace(c, grid);
+    if (rc != PW_OK) return rc;
+    if (nw == 4) return launch_nw<4>(c, r, stages, lds, grid);
+    if (nw == 2) return launch_nw<2>(c, r, stages, lds, grid);
+    return launch_nw<1>(c, r, stages, lds, grid);
+}
+
+int pw_resident_sync(pw_context* c) {
+    if (!c) return PW_E_BAD_ARG;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PW_OK;
+}
+
+int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) {
+    if (!c || !in || !out || in->n_units < 0) return PW_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    pw_resident* r = new (std::nothrow) pw_resident();
+    if (!r) return PW_E_NOMEM;
+    memset(r, 0, sizeof(*r));
+    r->n_units = (long)in->n_units;
+    long natoms = in->n_units ? (long)in->atom_offset[in->n_units] : 0;
+    r->n_atoms = natoms;
+    int nmax = 0;
+    for (long u = 0; u < r->n_units; ++u) {
+        long n = (long)(in->atom_offset[u + 1] - in->atom_offset[u]);
+        if (n <= 0) {
+            delete r;
+            snprintf(g_err, sizeof(g_err), "unit %ld has %ld atoms", u, n);
+            return PW_E_BAD_ARG;
+        }
+        if (n > nmax) nmax = (int)n;
+    }
+    r->nmax = nmax;
+    if (r->n_units) {
+        HIP_TRY(hipMalloc((void**)&r->d_offset, sizeof(long) * (r->n_units + 1)));
+        HIP_TRY(hipMalloc((void**)&r->d_xyz, sizeof(double) * 3 * natoms));
+        HIP_TRY(hipMalloc((void**)&r->d_vdw, sizeof(double) * natoms));
+        HIP_TRY(hipMalloc((void**)&r->d_mass, sizeof(double) * natoms));
+        HIP_TRY(hipMalloc((void**)&r->d_out, sizeof(pw_unit_out) * r->n_units));
+        HIP_TRY(hipMemcpyAsync(r->d_offset, in->atom_offset, sizeof(long) * (r->n_units + 1),
+                               hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(r->d_xyz, in->xyz, sizeof(double) * 3 * natoms, hipMemcpyHostToDevice,
+                               c->stream));
+        HIP_TRY(hipMemcpyAsync(r->d_vdw, in->vdw, sizeof(double) * natoms, hipMemcpyHostToDevice,
+                               c->stream));
+        HIP_TRY(hipMemcpyAsync(r->d_mass, in->mass, sizeof(double) * natoms, hipMemcpyHostToDevice,
+                               c->stream));
+        HIP_TRY(hipMemsetAsync(r->d_out, 0, sizeof(pw_unit_out) * r->n_units, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    *out = r;
+    return PW_OK;
+}
+
+int pw_resident_download(pw_context* c, pw_resident* r, pw_unit_out* out) {
+    if (!c || !r || !out) return PW_E_BAD_ARG;
+    if (r->n_units == 0) return PW_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(out, r->d_out, sizeof(pw_unit_out) * r->n_units, hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PW_OK;
+}
+
+void pw_resident_free(pw_context* c, pw_resident* r) {
+    if (!r) return;
+    if (c) (void)hipSetDevice(c->device);
+    if (r->d_offset) (void)hipFree(r->d_offset);
+    if (r->d_xyz) (void)hipFree(r->d_xyz);
+    if (r->d_vdw) (void)hipFree(r->d_vdw);
+    if (r->d_mass) (void)hipFree(r->d_mass);
+    if (r->d_out) (void)hipFree(r->d_out);
+    delete r;
+}
+
+void* pw_resident_device_results(pw_resident* r) { return r ? (void*)r->d_out : nullptr; }
+int64_t pw_resident_units(pw_resident* r) { return r ? r->n_units : 0; }
+
+int pw_resident_time(pw_context* c, pw_resident* r, uint32_t stages, int iters, float* ms) {
+    if (!c || !r || !ms || iters < 1) return PW_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = pw_resident_launch(c, r, stages);  // warm-up, also sizes the workspace
+    if (rc != PW_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < iters; ++i) {
+        rc = pw_resident_launch(c, r, stages);
+        if (rc != PW_OK) return rc;
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float total = 0.f;
+    HIP_TRY(hipEventElapsedTime(&total, c->ev0, c->ev1));
+    *ms = total / (float)iters;
+    return PW_OK;
+}
+
+int pw_analysis_batch(pw_context* c, const pw_batch_in* in, uint32_t stages, pw_unit_out* out) {
+    if (!c || !in || !out) return PW_E_BAD_ARG;
+    pw_resident* r = nullptr;
+    int rc = pw_resident_upload(c, in, &r);
+    if (rc != PW_OK) return rc;
+    rc = pw_resident_launch(c, r, stages);
+    if (rc == PW_OK) rc = pw_resident_download(c, r, out);
+    pw_resident_free(c, r);
+    return rc;
+}
+
+int pw_point_gaps(pw_context* c, const pw_batch_in* in, const int64_t* unit_of_point,
+                  const double* points, int64_t n_points, double* gap, int32_t* argmin) {
+    if (!c || !in || !unit_of_point || !points || !gap || !argmin || n_points < 0) return PW_E_BAD_ARG;
+    if (n_points == 0) return PW_OK;
+    for (int64_t q = 0; q < n_points; ++q)
+        if (unit_of_point[q] < 0 || unit_of_point[q] >= in->n_units) return PW_E_BAD_ARG;
+    pw_resident* r = nullptr;
+    int rc = pw_resident_upload(c, in, &r);
+    if (rc != PW_OK) return rc;
+    long* d_u = nullptr;
+    double *d_p = nullptr, *d_g = nullptr;
+    int* d_a = nullptr;
+    auto cleanup = [&]() {
+        if (d_u) (void)hipFree(d_u);
+        if (d_p) (void)hipFree(d_p);
+        if (d_g) (void)hipFree(d_g);
+        if (d_a) (void)hipFree(d_a);
+        pw_resident_free(c, r);
+    };
+#define PG_TRY(call)                                   \
+    do {                                               \
+        hipError_t e_ = (call);                        \
+        if (e_ != hipSuccess) {                        \
+            set_err(#call, e_);                        \
+            cleanup();                                 \
+            return PW_E_HIP;                           \
+        }                                              \
+    } while (0)
+    PG_TRY(hipMalloc((void**)&d_u, sizeof(long) * n_points));
+    PG_TRY(hipMalloc((void**)&d_p, sizeof(double) * 3 * n_points));
+    PG_TRY(hipMalloc((void**)&d_g, sizeof(double) * n_points));
+    PG_TRY(hipMalloc((void**)&d_a, sizeof(int) * n_points));
+    PG_TRY(hipMemcpyAsync(d_u, unit_of_point, sizeof(long) * n_points, hipMemcpyHostToDevice, c->stream));
+    PG_TRY(hipMemcpyAsync(d_p, points, sizeof(double) * 3 * n_points, hipMemcpyHostToDevice, c->stream));
+    int block = 256;
+    long grid = (n_points + block - 1) / block;
+    hipLaunchKernelGGL(pw_point_gap_kernel, dim3((unsigned)grid), dim3(block), 0, c->stream,
+                       (long)n_points, d_u, d_p, r->d_offset, r->d_xyz, r->d_vdw, d_g, d_a);
+    PG_TRY(hipGetLastError());
+    PG_TRY(hipMemcpyAsync(gap, d_g, sizeof(double) * n_points, hipMemcpyDeviceToHost, c->stream));
+    PG_TRY(hipMemcpyAsync(argmin, d_a, sizeof(int) * n_points, hipMemcpyDeviceToHost, c->stream));
+    PG_TRY(hipStreamSynchronize(c->stream));
+#undef PG_TRY
+    cleanup();
+    return PW_OK;
+}
+
+}  // extern "C"

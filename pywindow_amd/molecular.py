@@ -1,0 +1,227 @@
+"""``Molecule`` / ``MolecularSystem`` with the reference's API surface for the hot
+path (reference molecular.py:60-352, 554-836), backed by the HIP engine.
+
+Only what ``full_analysis`` and the trajectory driver need is here: loading a
+system dict, force-field key handling, ``system_to_molecule`` and the nine
+``calculate_*`` methods with the reference's ``properties`` schema.  File
+writers and the periodic ``rebuild_system`` are outside the accelerated path.
+"""
+
+from __future__ import annotations
+
+from copy import deepcopy
+
+import numpy as np
+
+from . import _lib, engine
+from .element_data import OPLS_KEY_TO_ELEMENT
+
+
+class _AtomKeyError(Exception):
+    def __init__(self, message: str) -> None:
+        self.message = message
+
+
+class _AtomKeyConflictError(Exception):
+    def __init__(self, message: str) -> None:
+        self.message = message
+
+
+class _ForceFieldError(Exception):
+    def __init__(self, message: str) -> None:
+        self.message = message
+
+
+def _is_number(s: str) -> bool:
+    try:
+        float(s)
+    except ValueError:
+        return False
+    return True
+
+
+def decipher_atom_key(atom_key: str, forcefield: str) -> str:
+    """Force-field atom key -> element (reference utilities.py:267-341)."""
+    ff = forcefield.upper()
+    if ff in ("DLF", "DL_F"):
+        head = ""
+        for ch in atom_key:
+            if head and _is_number(ch):
+                break
+            head += ch
+        else:
+            # the reference indexes past the end here; a key without digits is an error there too
+            raise IndexError("string index out of range")
+        return "".join(c for c in head if not _is_number(c) and c != "?")
+    if ff in ("OPLS", "OPLSAA", "OPLS2005", "OPLS3"):
+        if atom_key in ("ne", "he", "na"):
+            raise _AtomKeyConflictError(
+                f"One of the OPLS conflicting atom_keys has occured '{atom_key}'. "
+                "For how to solve this issue see the manual or "
+                "MolecularSystem._atom_key_swap() doc string."
+            )
+        try:
+            return OPLS_KEY_TO_ELEMENT[atom_key]
+        except KeyError:
+            raise _AtomKeyError(
+                f"OPLS atom key {atom_key} was not found in OPLS keys dictionary."
+            ) from None
+    raise _ForceFieldError(
+        f"Unfortunetely, '{forcefield}' forcefield is not supported by pyWINDOW."
+    )
+
+
+class Molecule:
+    """A single discrete molecule; every ``calculate_*`` runs on the GPU."""
+
+    def __init__(self, mol: dict, system_name: str, mol_id) -> None:
+        self.mol = mol
+        self.no_of_atoms = len(mol["elements"])
+        self.elements = mol["elements"]
+        if "atom_ids" in mol:
+            self.atom_ids = mol["atom_ids"]
+        self.coordinates = mol["coordinates"]
+        self.parent_system = system_name
+        self.molecule_id = mol_id
+        self.properties = {"no_of_atoms": self.no_of_atoms}
+        self._cache: dict[int, np.void] = {}
+
+    # one launch per stage set; records are cached so that chained calls
+    # (pore volume -> pore diameter, ...) do not recompute -- the reference does
+    # recompute (molecular.py:279, 317) but is deterministic, so results agree
+    def _record(self, stages: int):
+        for have, rec in self._cache.items():
+            if have & stages == stages:
+                return rec
+        rec = engine.analyse([(self.elements, self.coordinates)], stages)[0]
+        self._cache = {stages: rec}
+        return rec
+
+    def _invalidate(self):
+        self._cache = {}
+
+    def full_analysis(self, ncpus: int = 1) -> dict:  # noqa: ARG002
+        """All nine properties in ONE kernel launch (reference molecular.py:156-202)."""
+        rec = self._record(_lib.STAGE_ALL)
+        self._fill_from(rec)
+        return self.properties
+
+    def _fill_from(self, rec):
+        engine.warn_like_reference(rec)
+        props = engine.record_to_properties(rec)
+        self.MW = float(rec["mw"])
+        self.centre_of_mass = props["centre_of_mass"]
+        md = props["maximum_diameter"]
+        self.maxd_atom_1, self.maxd_atom_2, self.maximum_diameter = md["atom_1"], md["atom_2"], md["diameter"]
+        self.average_diameter = props["average_diameter"]
+        self.pore_diameter, self.pore_closest_atom = props["pore_diameter"]["diameter"], props["pore_diameter"]["atom"]
+        self.pore_volume = props["pore_volume"]
+        po = props["pore_diameter_opt"]
+        self.pore_diameter_opt, self.pore_opt_closest_atom, self.pore_opt_COM = (
+            po["diameter"], po["atom_1"], po["centre_of_mass"])
+        self.pore_volume_opt = props["pore_volume_opt"]
+        # key order of the reference's dict
+        for key in ("centre_of_mass", "maximum_diameter", "average_diameter", "pore_diameter",
+                    "pore_volume", "pore_diameter_opt", "pore_volume_opt", "windows"):
+            self.properties[key] = props[key]
+
+    def molecular_weight(self) -> float:
+        self.MW = float(self._record(_lib.STAGE_BASIC)["mw"])
+        return self.MW
+
+    def calculate_centre_of_mass(self) -> np.ndarray:
+        self.centre_of_mass = np.array(self._record(_lib.STAGE_BASIC)["com"])
+        self.properties["centre_of_mass"] = self.centre_of_mass
+        return self.centre_of_mass
+
+    def calculate_maximum_diameter(self) -> float:
+        r = self._record(_lib.STAGE_BASIC)
+        self.maxd_atom_1, self.maxd_atom_2, self.maximum_diameter = int(r["maxd_i"]), int(r["maxd_j"]), float(r["maxd"])
+        self.properties["maximum_diameter"] = {
+            "diameter": self.maximum_diameter, "atom_1": self.maxd_atom_1, "atom_2": self.maxd_atom_2}
+        return self.maximum_diameter
+
+    def calculate_average_diameter(self) -> float:
+        self.average_diameter = float(self._record(_lib.STAGE_AVG)["avg_d"])
+        self.properties["average_diameter"] = self.average_diameter
+        return self.average_diameter
+
+    def calculate_pore_diameter(self) -> float:
+        r = self._record(_lib.STAGE_BASIC)
+        self.pore_diameter, self.pore_closest_atom = float(r["pore_d"]), int(r["pore_atom"])
+        self.properties["pore_diameter"] = {"diameter": self.pore_diameter, "atom": self.pore_closest_atom}
+        return self.pore_diameter
+
+    def calculate_pore_volume(self) -> float:
+        self.calculate_pore_diameter()
+        self.pore_volume = float(self._record(_lib.STAGE_BASIC)["pore_vol"])
+        self.properties["pore_volume"] = self.pore_volume
+        return self.pore_volume
+
+    def calculate_pore_diameter_opt(self) -> float:
+        r = self._record(_lib.STAGE_OPT)
+        self.pore_diameter_opt = float(r["pore_opt_d"])
+        self.pore_opt_closest_atom = int(r["pore_opt_atom"])
+        self.pore_opt_COM = np.array(r["pore_opt_c"])
+        self.properties["pore_diameter_opt"] = {
+            "diameter": self.pore_diameter_opt, "atom_1": self.pore_opt_closest_atom,
+            "centre_of_mass": self.pore_opt_COM}
+        return self.pore_diameter_opt
+
+    def calculate_pore_volume_opt(self) -> float:
+        self.calculate_pore_diameter_opt()
+        self.pore_volume_opt = float(self._record(_lib.STAGE_OPT)["pore_vol_opt"])
+        self.properties["pore_volume_opt"] = self.pore_volume_opt
+        return self.pore_volume_opt
+
+    def calculate_windows(self, ncpus: int = 1):  # noqa: ARG002
+        r = self._record(_lib.STAGE_WINDOWS)
+        engine.warn_like_reference(r)
+        win = engine.windows_of(r)
+        if win is not None:
+            self.properties["windows"] = {"diameters": win[0], "centre_of_mass": win[1]}
+            return win[0]
+        self.properties["windows"] = {"diameters": None, "centre_of_mass": None}
+        return None
+
+    def shift_to_origin(self) -> None:
+        com = self.calculate_centre_of_mass()
+        self.coordinates = np.asarray(self.coordinates, float) - np.array([com] * self.no_of_atoms)
+        self.mol["coordinates"] = self.coordinates
+        self._invalidate()
+
+
+class MolecularSystem:
+    """Container of a (possibly multi-molecule) system (reference molecular.py:554-836)."""
+
+    def __init__(self) -> None:
+        self.system_id = 0
+        self.system: dict = {}
+
+    @classmethod
+    def load_system(cls, dict_: dict, system_id: str | int = "system") -> "MolecularSystem":
+        obj = cls()
+        obj.system = dict_
+        obj.system_id = system_id
+        return obj
+
+    def swap_atom_keys(self, swap_dict: dict, dict_key: str = "atom_ids") -> None:
+        """Reference molecular.py:710-749."""
+        if "atom_ids" not in self.system:
+            dict_key = "elements"
+        for atom_key in range(len(self.system[dict_key])):
+            for key in swap_dict:
+                if self.system[dict_key][atom_key] == key:
+                    self.system[dict_key][atom_key] = swap_dict[key]
+
+    def decipher_atom_keys(self, forcefield: str = "DLF", dict_key: str = "atom_ids") -> None:
+        """Reference molecular.py:751-796."""
+        if "atom_ids" not in self.system:
+            dict_key = "elements"
+        temp = deepcopy(self.system[dict_key])
+        for element in range(len(temp)):
+            temp[element] = str(decipher_atom_key(temp[element], forcefield=forcefield))
+        self.system["elements"] = temp
+
+    def system_to_molecule(self) -> Molecule:
+        return Molecule(self.system, self.system_id, 0)

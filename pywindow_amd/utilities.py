@@ -1,0 +1,84 @@
+"""Function-level mirror of the reference's hot-path interface.
+
+Same names, argument meaning and error behaviour as the free functions
+``molecular.py:29-44`` imports from the reference's ``utilities.py``; every call
+is executed by the HIP engine (a batch of one molecule).  For bulk work use
+:mod:`pywindow_amd.trajectory` / :func:`pywindow_amd.engine.analyse`, which put
+all molecules x frames into one launch.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib, engine
+from .element_data import atomic_mass, atomic_vdw_radius  # noqa: F401  (re-exported)
+
+
+def _one(elements, coordinates, stages):
+    return engine.analyse([(elements, coordinates)], stages)[0]
+
+
+def molecular_weight(elements) -> float:
+    """Reference utilities.py:96-107."""
+    dummy = np.zeros((len(elements), 3))
+    return float(_one(elements, dummy + np.arange(len(elements))[:, None], _lib.STAGE_BASIC)["mw"])
+
+
+def center_of_mass(elements, coordinates) -> np.ndarray:
+    """Reference utilities.py:127-148."""
+    return np.array(_one(elements, coordinates, _lib.STAGE_BASIC)["com"])
+
+
+def shift_com(elements, coordinates, com_adjust=np.zeros(3)) -> np.ndarray:  # noqa: B008
+    """Reference utilities.py:344-352 (coordinates translated by COM - adjust)."""
+    com = center_of_mass(elements, coordinates)
+    coordinates = np.asarray(coordinates, dtype=float)
+    return coordinates - np.array([com - com_adjust] * coordinates.shape[0])
+
+
+def max_dim(elements, coordinates) -> tuple[int, int, float]:
+    """Reference utilities.py:355-372."""
+    r = _one(elements, coordinates, _lib.STAGE_BASIC)
+    return int(r["maxd_i"]), int(r["maxd_j"]), float(r["maxd"])
+
+
+def pore_diameter(elements, coordinates, com=None) -> tuple[float, int]:
+    """Reference utilities.py:375-388."""
+    if com is None:
+        r = _one(elements, coordinates, _lib.STAGE_BASIC)
+        return float(r["pore_d"]), int(r["pore_atom"])
+    gaps, idx = engine.context().point_gaps(
+        engine.make_batch([(elements, coordinates)]), np.zeros(1, np.int64), np.asarray(com, float).reshape(1, 3)
+    )
+    return float(gaps[0] * 2), int(idx[0])
+
+
+def sphere_volume(sphere_radius: float) -> float:
+    """Reference utilities.py:429-431."""
+    return float(4 / 3 * np.pi * sphere_radius**3)
+
+
+def opt_pore_diameter(elements, coordinates, bounds=None, com=None):
+    """Reference utilities.py:400-426 (default bounds / start only, which is all
+    ``Molecule`` ever uses)."""
+    if bounds is not None or com is not None:
+        raise NotImplementedError("custom bounds / start are not reachable from Molecule (SURVEY 5.6)")
+    r = _one(elements, coordinates, _lib.STAGE_OPT)
+    return float(r["pore_opt_d"]), int(r["pore_opt_atom"]), np.array(r["pore_opt_c"])
+
+
+def find_average_diameter(elements, coordinates, adjust=1, processes=None) -> float:
+    """Reference utilities.py:1586-1650 (``adjust`` fixed at its default 1)."""
+    if adjust != 1:
+        raise NotImplementedError("adjust != 1 is not reachable from Molecule (SURVEY 5.6)")
+    return float(_one(elements, coordinates, _lib.STAGE_AVG)["avg_d"])
+
+
+def find_windows(elements, coordinates, processes=None, adjust=1, pore_opt=True, increment=1.0):
+    """Reference utilities.py:1364-1553 with the knobs ``Molecule`` uses."""
+    if adjust != 1 or pore_opt is not True or increment != 1.0:
+        raise NotImplementedError("non-default find_windows knobs are not reachable from Molecule")
+    r = _one(elements, coordinates, _lib.STAGE_WINDOWS)
+    engine.warn_like_reference(r)
+    return engine.windows_of(r)

@@ -1,0 +1,83 @@
+"""Shared helpers for the test-suite: golden fixtures and record comparison."""
+import pathlib
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+GOLDEN = ROOT / "tests" / "golden"
+GROUPS = ("static", "md20", "synth64", "periodic8")
+
+# tolerances (relative) -- SURVEY.md section 8: deterministic quantities are bit-exact;
+# window quantities go through numpy's SIMD arccos, which cannot be reproduced
+# bit for bit, so they carry north_star's 1e-6.
+TOL_WINDOW = 1e-6
+
+
+def load_group(tag):
+    return np.load(GOLDEN / f"{tag}.npz")
+
+
+def group_batch(g):
+    """(atom_offset, xyz, vdw, mass) for a golden group."""
+    from pywindow_amd import element_data as E
+
+    ids = E.element_ids(g["elements"])
+    return g["atom_offset"].astype(np.int64), np.ascontiguousarray(g["coordinates"]), E.VDW[ids], E.MASS[ids]
+
+
+def molecules(g):
+    off = g["atom_offset"]
+    return [(g["elements"][off[u]:off[u + 1]], g["coordinates"][off[u]:off[u + 1]]) for u in range(len(off) - 1)]
+
+
+def rel(a, b):
+    a = np.asarray(a, float)
+    b = np.asarray(b, float)
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)) if a.size else 0.0
+
+
+def check_records(recs, g, *, exact_scalars=True, tol_window=TOL_WINDOW, where=""):
+    """Compare engine records (structured array / sequence of mappings) with a golden group."""
+    n = len(g["atom_offset"]) - 1
+    assert len(recs) == n
+    stats = {"win_d": 0.0, "win_c_abs": 0.0}
+    for u in range(n):
+        r = recs[u]
+        tag = f"{where} unit {u} ({g['names'][u]})"
+        assert int(r["n_atoms"]) == int(g["n_atoms"][u]), tag
+        for k in ("maxd_i", "maxd_j", "pore_atom", "pore_opt_atom", "n_windows"):
+            assert int(r[k]) == int(g[k][u]), f"{tag}: {k} {r[k]} != {g[k][u]}"
+        for k in ("mw", "maxd", "avg_d", "pore_d", "pore_vol", "pore_opt_d", "pore_vol_opt"):
+            if exact_scalars:
+                assert float(r[k]) == float(g[k][u]), f"{tag}: {k} {float(r[k])!r} != {float(g[k][u])!r}"
+            else:
+                assert rel(r[k], g[k][u]) <= 1e-12, f"{tag}: {k}"
+        for k in ("com", "pore_opt_c"):
+            if exact_scalars:
+                assert np.array_equal(np.asarray(r[k]), g[k][u]), f"{tag}: {k}"
+            else:
+                assert rel(r[k], g[k][u]) <= 1e-12, f"{tag}: {k}"
+        if "opt_nit" in getattr(r, "dtype", np.dtype([])).names or ():
+            assert int(r["opt_nit"]) == int(g["st_opt_nit"][u]), f"{tag}: opt_nit"
+            assert int(r["opt_nfev"]) == int(g["st_opt_nfev"][u]), f"{tag}: opt_nfev"
+            assert int(r["n_points"]) == int(g["st_n_points"][u]), f"{tag}: n_points"
+            npass = int(g["st_pass_offset"][u + 1] - g["st_pass_offset"][u])
+            assert int(r["n_survivors"]) == npass, f"{tag}: n_survivors"
+            if npass:
+                assert float(r["eps"]) == float(g["st_eps"][u]), f"{tag}: eps"
+        k = int(g["n_windows"][u])
+        if k > 0:
+            # the reference's tests compare after sorting by diameter (tests/test_validate_cc3.py:423-439)
+            p = np.argsort(np.asarray(r["win_d"][:k]))
+            q = np.argsort(g["win_d"][u][:k])
+            wd = np.asarray(r["win_d"][:k])[p]
+            gd = g["win_d"][u][:k][q]
+            e = rel(wd, gd)
+            assert e <= tol_window, f"{tag}: window diameters rel err {e:.3e}"
+            stats["win_d"] = max(stats["win_d"], e)
+            wc = np.asarray(r["win_c"][:k]).reshape(k, 3)[p]
+            gc = g["win_c"][u][:k][q]
+            ea = float(np.max(np.abs(wc - gc)))
+            assert ea <= 1e-4, f"{tag}: window centres abs err {ea:.3e}"
+            stats["win_c_abs"] = max(stats["win_c_abs"], ea)
+    return stats

@@ -1,0 +1,31 @@
+import pathlib
+import sys
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (HIP device); run with -m gpu")
+
+
+@pytest.fixture(scope="session")
+def hostsim():
+    """CPU-only harnesses that compile the kernel headers with a one-thread team."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("hostsim_build", ROOT / "tests" / "hostsim" / "build.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build()
+    return ROOT / "tests" / "hostsim"
+
+
+@pytest.fixture(scope="session")
+def hip_ctx():
+    from pywindow_amd import _lib
+
+    return _lib.Context(0)

@@ -1,0 +1,84 @@
+"""The reference-shaped API (Molecule / functions / DLPOLY.analysis) on the GPU."""
+import numpy as np
+import pytest
+
+from _util import load_group, molecules, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def test_molecule_full_analysis_schema_and_values():
+    import pywindow_amd as pw
+
+    g = load_group("static")
+    el, xyz = molecules(g)[0]
+    ms = pw.MolecularSystem.load_system({"elements": el, "coordinates": xyz}, "test")
+    mol = ms.system_to_molecule()
+    p = mol.full_analysis()
+    assert list(p) == ["no_of_atoms", "centre_of_mass", "maximum_diameter", "average_diameter",
+                       "pore_diameter", "pore_volume", "pore_diameter_opt", "pore_volume_opt", "windows"]
+    assert p["no_of_atoms"] == 168 and isinstance(p["no_of_atoms"], int)
+    assert p["maximum_diameter"] == {"diameter": 22.179369990077188, "atom_1": 12, "atom_2": 54}
+    assert p["pore_diameter"] == {"diameter": 5.397020177310022, "atom": 29}
+    assert isinstance(p["centre_of_mass"], np.ndarray) and p["windows"]["centre_of_mass"].shape == (4, 3)
+    assert mol.MW == 1117.5479999999998
+    # method-by-method calls agree with the one-launch path
+    mol2 = ms.system_to_molecule()
+    assert mol2.calculate_maximum_diameter() == p["maximum_diameter"]["diameter"]
+    assert mol2.calculate_pore_volume() == p["pore_volume"]
+    assert mol2.calculate_average_diameter() == p["average_diameter"]
+    assert mol2.calculate_pore_diameter_opt() == p["pore_diameter_opt"]["diameter"]
+    assert np.array_equal(mol2.calculate_windows(), p["windows"]["diameters"])
+    mol2.shift_to_origin()
+    assert np.max(np.abs(mol2.calculate_centre_of_mass())) < 1e-12
+
+
+def test_no_window_molecule_gives_none():
+    import pywindow_amd as pw
+
+    g = load_group("static")
+    el, xyz = molecules(g)[1]   # C60, reference tests/test_validate_windows.py:2001-2007
+    mol = pw.Molecule({"elements": el, "coordinates": xyz}, "c60", 0)
+    assert mol.calculate_windows() is None
+    assert mol.properties["windows"] == {"diameters": None, "centre_of_mass": None}
+    assert pw.find_windows(el, xyz) is None
+
+
+def test_function_level_mirror():
+    import pywindow_amd as pw
+
+    g = load_group("md20")
+    el, xyz = molecules(g)[3]
+    assert pw.molecular_weight(el) == g["mw"][3]
+    assert np.array_equal(pw.center_of_mass(el, xyz), g["com"][3])
+    assert pw.max_dim(el, xyz) == (int(g["maxd_i"][3]), int(g["maxd_j"][3]), float(g["maxd"][3]))
+    assert pw.pore_diameter(el, xyz) == (float(g["pore_d"][3]), int(g["pore_atom"][3]))
+    d, a, c = pw.opt_pore_diameter(el, xyz)
+    assert d == g["pore_opt_d"][3] and a == g["pore_opt_atom"][3] and np.array_equal(c, g["pore_opt_c"][3])
+    assert pw.pore_diameter(el, xyz, com=c) == (d, a)
+    assert pw.find_average_diameter(el, xyz) == g["avg_d"][3]
+    wd, wc = pw.find_windows(el, xyz)
+    assert rel(np.sort(wd), np.sort(g["win_d"][3][:4])) < 1e-6
+    with pytest.raises(KeyError):
+        pw.molecular_weight(np.array(["Qq"]))
+
+
+def test_dlpoly_batched_analysis(tmp_path):
+    import pywindow_amd as pw
+    from pywindow_amd import synth
+
+    path = synth.write_synthetic_history(tmp_path / "HISTORY_synth", 12)
+    traj = pw.DLPOLY(path)
+    assert traj.no_of_frames == 12 and traj.no_of_atoms == 168
+    traj.analysis(frames=[0, 1, 2, 5])
+    assert sorted(traj.analysis_output) == [0, 1, 2, 5]
+    traj.analysis()      # the rest; already analysed frames are skipped (override=False)
+    assert sorted(traj.analysis_output) == list(range(12))
+    g = load_group("synth64")
+    for f in range(12):
+        p = traj.analysis_output[f]["0"]
+        assert p["pore_diameter_opt"]["diameter"] == g["pore_opt_d"][f]
+        assert p["average_diameter"] == g["avg_d"][f]
+        assert len(p["windows"]["diameters"]) == g["n_windows"][f]
+    with pytest.raises(Exception):
+        traj.analysis(frames="bogus")

@@ -1,0 +1,128 @@
+"""Parity tests proper: the HIP engine (through the C ABI) against the golden
+vectors produced by the reference, against the oracle run live, and -- at the
+benchmark's full size -- through size-independent properties."""
+import numpy as np
+import pytest
+
+from _util import GROUPS, check_records, group_batch, load_group, molecules, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def analyse_group(ctx, g, stages=15):
+    from pywindow_amd import _lib
+
+    off, xyz, vdw, mass = group_batch(g)
+    return ctx.analyse(_lib.Batch(off, xyz, vdw, mass), stages)
+
+
+@pytest.mark.parametrize("tag", GROUPS)
+def test_hip_matches_reference_golden(hip_ctx, tag):
+    g = load_group(tag)
+    out = analyse_group(hip_ctx, g)
+    stats = check_records(out, g, where=f"hip/{tag}")
+    assert (out["status"] == 0).all()
+    print(tag, "worst window rel err", stats)
+
+
+def test_objective_is_bit_exact(hip_ctx):
+    """min_i(|r_i - p| - vdw_i) at random points: bit-identical to the oracle's C
+    primitive (itself bit-identical to sklearn's euclidean_distances)."""
+    from oracle import pw_oracle as O
+    from pywindow_amd import _lib
+
+    g = load_group("static")
+    off, xyz, vdw, mass = group_batch(g)
+    batch = _lib.Batch(off, xyz, vdw, mass)
+    rng = np.random.default_rng(7)
+    n_units = len(off) - 1
+    units = rng.integers(0, n_units, 4000)
+    pts = np.empty((len(units), 3))
+    cages = []
+    for u in range(n_units):
+        sl = slice(off[u], off[u + 1])
+        cages.append(O.Cage(xyz[sl], vdw[sl], mass[sl]))
+    for q, u in enumerate(units):
+        pts[q] = cages[u].xyz.mean(0) + rng.normal(0, 3.0, 3)
+    gap, arg = hip_ctx.point_gaps(batch, units, pts)
+    for q, u in enumerate(units):
+        v, i = cages[u].gap(pts[q])
+        assert gap[q] == v and arg[q] == i, (q, u, gap[q], v)
+
+
+def test_hip_matches_live_oracle(hip_ctx):
+    """Same seeded inputs through the oracle (numpy/scipy/sklearn + C primitive) and the GPU."""
+    from oracle import pw_oracle as O
+    from pywindow_amd import _lib, synth
+    from pywindow_amd import element_data as E
+
+    elements, frames = synth.synthetic_units(3, first=500)
+    ids = E.element_ids(elements)
+    out = hip_ctx.analyse(_lib.Batch.uniform(frames, E.VDW[ids], E.MASS[ids]))
+    for k in range(len(frames)):
+        ref = O.full_analysis(frames[k], E.VDW[ids], E.MASS[ids])
+        r = out[k]
+        for key in ("mw", "maxd", "avg_d", "pore_d", "pore_opt_d"):
+            assert float(r[key]) == ref[key], (k, key)
+        assert np.array_equal(r["pore_opt_c"], ref["pore_opt_c"])
+        assert int(r["n_windows"]) == ref["n_windows"]
+        n = ref["n_windows"]
+        assert rel(np.sort(r["win_d"][:n]), np.sort(ref["win_d"][:n])) <= 1e-6
+
+
+def test_stage_entry_points(hip_ctx):
+    g = load_group("periodic8")
+    basic = analyse_group(hip_ctx, g, stages=1)
+    assert np.array_equal(basic["pore_d"], g["pore_d"]) and np.array_equal(basic["maxd"], g["maxd"])
+    avg = analyse_group(hip_ctx, g, stages=2)
+    assert np.array_equal(avg["avg_d"], g["avg_d"])
+    opt = analyse_group(hip_ctx, g, stages=4)
+    assert np.array_equal(opt["pore_opt_d"], g["pore_opt_d"])
+    win = analyse_group(hip_ctx, g, stages=8)
+    assert np.array_equal(win["n_windows"], g["n_windows"])
+
+
+def test_full_size_properties(hip_ctx):
+    """BASELINE config 2 (1000 CC3 frames): results do not depend on batch
+    composition or order, and reproduce run to run."""
+    from pywindow_amd import _lib, synth
+    from pywindow_amd import element_data as E
+
+    elements, frames = synth.synthetic_units(1000)
+    ids = E.element_ids(elements)
+    vdw, mass = E.VDW[ids], E.MASS[ids]
+    res = hip_ctx.upload(_lib.Batch.uniform(frames, vdw, mass))
+    res.launch()
+    a = res.download()
+    res.launch()
+    b = res.download()
+    assert a.tobytes() == b.tobytes(), "not reproducible run to run"
+    # the first 64 frames are the golden synth64 group
+    g = load_group("synth64")
+    check_records(a[:64], g, where="hip/1000-frame batch")
+    # permuted order + a ragged neighbour (different N) in the same launch
+    perm = np.random.default_rng(3).permutation(1000)[:200]
+    sub = hip_ctx.analyse(_lib.Batch.uniform(frames[perm], vdw, mass))
+    keys = [k for k in a.dtype.names]
+    for k in keys:
+        assert np.array_equal(sub[k], a[perm][k]), k
+    assert (a["n_windows"] == 4).sum() > 950
+    assert (a["status"] == 0).all()
+
+
+def test_ragged_batch_and_edge_cases(hip_ctx):
+    from pywindow_amd import _lib
+
+    g = load_group("static")
+    out_all = analyse_group(hip_ctx, g)
+    mols = molecules(g)
+    from pywindow_amd import engine
+
+    # single-unit launches equal the batched launch
+    for u in (1, 5, 10):
+        one = engine.analyse([mols[u]])[0]
+        for k in out_all.dtype.names:
+            assert np.array_equal(one[k], out_all[u][k]), (u, k)
+    # empty batch
+    empty = hip_ctx.analyse(_lib.Batch(np.zeros(1, np.int64), np.zeros((0, 3)), np.zeros(0), np.zeros(0)))
+    assert len(empty) == 0

@@ -1,0 +1,69 @@
+"""The kernel SOURCE (pywindow_amd/csrc/*.hpp), compiled for the host with a
+one-thread team, against every golden vector produced by the reference.  This
+is how the control flow of the HIP kernels is checked in a container without a
+GPU; the GPU build of the same headers is checked by test_gpu_parity.py."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from _util import GROUPS, check_records, group_batch, load_group
+from pywindow_amd import _lib
+
+
+def run_hostsim(hostsim, g, stages=15):
+    L = ctypes.CDLL(str(hostsim / "libunitprobe.so"))
+    off, xyz, vdw, mass = group_batch(g)
+    vdw = np.ascontiguousarray(vdw)
+    mass = np.ascontiguousarray(mass)
+    out = np.zeros(len(off) - 1, dtype=_lib.UNIT_OUT_DTYPE)
+    rc = L.hs_analysis_batch(ctypes.c_long(len(off) - 1), off.ctypes.data_as(ctypes.c_void_p),
+                             xyz.ctypes.data_as(ctypes.c_void_p), vdw.ctypes.data_as(ctypes.c_void_p),
+                             mass.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(stages),
+                             out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    return out
+
+
+@pytest.mark.parametrize("tag", GROUPS)
+def test_host_team_matches_reference(hostsim, tag):
+    g = load_group(tag)
+    out = run_hostsim(hostsim, g)
+    stats = check_records(out, g, where=tag)
+    # window quantities: far inside north_star's 1e-6
+    assert stats["win_d"] < 1e-7
+    assert (out["status"] == 0).all()
+
+
+def test_reference_known_answers(hostsim):
+    """Literals of the reference's own tests (tests/test_validate_cc3.py:353-439,
+    test_validate_windows.py:1944-2087, test_validate_average_diameter.py:2373-2415)."""
+    g = load_group("static")
+    out = run_hostsim(hostsim, g)
+    names = list(g["names"])
+    cc3 = out[names.index("cc3")]
+    np.testing.assert_almost_equal(cc3["com"], [12.4, 12.4, 12.4])
+    assert cc3["maxd"] == 22.179369990077188 and (cc3["maxd_i"], cc3["maxd_j"]) == (12, 54)
+    np.testing.assert_almost_equal(cc3["avg_d"], 13.832017514255472, decimal=7)
+    assert cc3["pore_d"] == 5.397020177310022
+    assert cc3["pore_vol"] == 82.31154385154417
+    assert cc3["pore_opt_d"] == 5.397020177310022
+    np.testing.assert_almost_equal(np.sort(cc3["win_d"][:4]),
+                                   np.sort([3.63778746, 3.63562103, 3.62896512, 3.63707237]), decimal=7)
+    assert out[names.index("windows_case_1")]["n_windows"] == -1   # C60: no windows -> None
+    for case, nwin in (("windows_case_2", 2), ("windows_case_3", 3), ("windows_case_4", 4), ("windows_case_5", 6)):
+        assert out[names.index(case)]["n_windows"] == nwin
+    np.testing.assert_almost_equal(np.sort(out[names.index("windows_case_2")]["win_d"][:2]),
+                                   np.sort([3.72937988, 3.34146021]), decimal=3)
+    for case, avg in (("avgdiam_case_1", 12.38895620), ("avgdiam_case_2", 13.36606775), ("avgdiam_case_3", 18.10740925),
+                      ("avgdiam_case_4", 19.23547068), ("avgdiam_case_5", 24.03139233)):
+        np.testing.assert_almost_equal(out[names.index(case)]["avg_d"], avg, decimal=3)
+
+
+def test_stage_selection(hostsim):
+    g = load_group("periodic8")
+    basic = run_hostsim(hostsim, g, stages=1)
+    assert (basic["n_windows"] == -1).all() and (basic["avg_d"] == 0).all()
+    assert np.array_equal(basic["pore_d"], g["pore_d"])
+    opt = run_hostsim(hostsim, g, stages=4)
+    assert np.array_equal(opt["pore_opt_d"], g["pore_opt_d"])
