@@ -230,7 +230,6 @@ class Context:
         _check(
             load().pw_analysis_batch(self._h, ctypes.byref(batch.c), stages, out.ctypes.data),
             "pw_analysis_batch",
-    "pw_point_gaps",
         )
         return out
 

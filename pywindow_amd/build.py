@@ -16,7 +16,6 @@ CSRC = PKG / "csrc"
 OUT = PKG / "libpywindow_hip.so"
 SOURCES = ["pw_kernels.hip", "pw_history.cpp"]
 # -ffp-contract=off: the numerical core relies on explicit fma() only (pw_common.hpp)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 
 def hipcc() -> str:
@@ -37,11 +36,23 @@ def stale() -> bool:
 def build(force: bool = False, verbose: bool = True) -> pathlib.Path:
     if not force and not stale():
         return OUT
-    cmd = [hipcc(), *FLAGS, "-x", "hip", str(CSRC / "pw_kernels.hip"), "-x", "c++",
-           str(CSRC / "pw_history.cpp"), "-o", str(OUT)]
-    if verbose:
-        print("+", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    # two translation units, compiled separately (mixing "-x hip" and "-x c++" in one
+    # hipcc command silently drops --offload-arch) and linked by hipcc
+    obj_k = CSRC / "pw_kernels.o"
+    obj_h = CSRC / "pw_history.o"
+    cmds = [
+        [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c",
+         str(CSRC / "pw_kernels.hip"), "-o", str(obj_k)],
+        ["g++", "-O2", "-std=c++17", "-fPIC", "-c", str(CSRC / "pw_history.cpp"), "-o", str(obj_h)],
+        [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", str(obj_k), str(obj_h), "-o", str(OUT)],
+    ]
+    for cmd in cmds:
+        if verbose:
+            print("+", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    text = subprocess.run(["strings", str(OUT)], capture_output=True, text=True).stdout
+    if "amdgcn-amd-amdhsa--gfx950" not in text:
+        raise RuntimeError("built library does not contain a gfx950 code object")
     return OUT
 
 
