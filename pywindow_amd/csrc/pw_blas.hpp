@@ -65,59 +65,64 @@ PW_HD inline void b_dcopy(int n, const double* x, double* y) {
 // kernel/x86_64/dgemv_t_4.c: rows in chunks of 4 (m & -4) through the
 // 4x4 / 4x2 / 4x1 micro-kernels (columns grouped 4,2,1), the m & 3 leftover
 // rows in a scalar tail.  Only m <= 11 is supported (m & -4 in {0,4,8}).
-PW_HD inline void b_dgemv_t_sub(int m, int n, const double* A, int lda, const double* x,
-                                double* y, int incy) {
+// One output element of that product: returns the NEW y_k given the old one.
+// `k` is the column's position among the n columns (it selects the micro-kernel).
+PW_HD inline double b_dgemv_t_elem(int m, int n, int k, const double* a, const double* x, double yk) {
     const int m1 = m & -4, m3 = m & 3;
     const int n4 = (n >> 2) << 2;
-    for (int k = 0; k < n; ++k) {
-        const double* a = A + (long)k * lda;
-        double* yk = y + (long)k * incy;
-        if (m1) {
-            double t;
-            if (k < n4) {
-                // 4x4 AVX2 kernel: one 4-lane FMA accumulator over the chunks
-                double l0 = a[0] * x[0], l1 = a[1] * x[1], l2 = a[2] * x[2], l3 = a[3] * x[3];
-                if (m1 == 8) {
-                    l0 = pw_fma(a[4], x[4], l0);
-                    l1 = pw_fma(a[5], x[5], l1);
-                    l2 = pw_fma(a[6], x[6], l2);
-                    l3 = pw_fma(a[7], x[7], l3);
-                }
-                t = (l0 + l2) + (l1 + l3);
-            } else if ((n & 2) && k < n4 + 2) {
-                // 4x2 SSE2 kernel: separately rounded products, 2-lane accumulator
-                double q0 = a[0] * x[0] + a[2] * x[2];
-                double q1 = a[1] * x[1] + a[3] * x[3];
-                if (m1 == 8) {
-                    q0 = q0 + (a[4] * x[4] + a[6] * x[6]);
-                    q1 = q1 + (a[5] * x[5] + a[7] * x[7]);
-                }
-                t = q0 + q1;
-            } else {
-                // 4x1 kernel
-                double l0 = a[0] * x[0], l1 = a[1] * x[1], l2 = a[2] * x[2], l3 = a[3] * x[3];
-                if (m1 == 8) {
-                    l0 = l0 + a[4] * x[4];
-                    l1 = l1 + a[5] * x[5];
-                    l2 = l2 + a[6] * x[6];
-                    l3 = l3 + a[7] * x[7];
-                }
-                t = (l0 + l2) + (l1 + l3);
+    if (m1) {
+        double t;
+        if (k < n4) {
+            // 4x4 AVX2 kernel: one 4-lane FMA accumulator over the chunks
+            double l0 = a[0] * x[0], l1 = a[1] * x[1], l2 = a[2] * x[2], l3 = a[3] * x[3];
+            if (m1 == 8) {
+                l0 = pw_fma(a[4], x[4], l0);
+                l1 = pw_fma(a[5], x[5], l1);
+                l2 = pw_fma(a[6], x[6], l2);
+                l3 = pw_fma(a[7], x[7], l3);
             }
-            *yk = *yk - t;
+            t = (l0 + l2) + (l1 + l3);
+        } else if ((n & 2) && k < n4 + 2) {
+            // 4x2 SSE2 kernel: separately rounded products, 2-lane accumulator
+            double q0 = a[0] * x[0] + a[2] * x[2];
+            double q1 = a[1] * x[1] + a[3] * x[3];
+            if (m1 == 8) {
+                q0 = q0 + (a[4] * x[4] + a[6] * x[6]);
+                q1 = q1 + (a[5] * x[5] + a[7] * x[7]);
+            }
+            t = q0 + q1;
+        } else {
+            // 4x1 kernel
+            double l0 = a[0] * x[0], l1 = a[1] * x[1], l2 = a[2] * x[2], l3 = a[3] * x[3];
+            if (m1 == 8) {
+                l0 = l0 + a[4] * x[4];
+                l1 = l1 + a[5] * x[5];
+                l2 = l2 + a[6] * x[6];
+                l3 = l3 + a[7] * x[7];
+            }
+            t = (l0 + l2) + (l1 + l3);
         }
-        if (m3 == 1) {
-            *yk = pw_fma(a[m1], -x[m1], *yk);
-        } else if (m3 == 2) {
-            double t = a[m1 + 1] * (-x[m1 + 1]);
-            t = pw_fma(a[m1], -x[m1], t);
-            *yk = *yk + t;
-        } else if (m3 == 3) {
-            double t = a[m1 + 1] * (-x[m1 + 1]);
-            t = pw_fma(a[m1], -x[m1], t);
-            t = pw_fma(a[m1 + 2], -x[m1 + 2], t);
-            *yk = *yk + t;
-        }
+        yk = yk - t;
+    }
+    if (m3 == 1) {
+        yk = pw_fma(a[m1], -x[m1], yk);
+    } else if (m3 == 2) {
+        double t = a[m1 + 1] * (-x[m1 + 1]);
+        t = pw_fma(a[m1], -x[m1], t);
+        yk = yk + t;
+    } else if (m3 == 3) {
+        double t = a[m1 + 1] * (-x[m1 + 1]);
+        t = pw_fma(a[m1], -x[m1], t);
+        t = pw_fma(a[m1 + 2], -x[m1 + 2], t);
+        yk = yk + t;
+    }
+    return yk;
+}
+PW_HD inline void b_dgemv_t_sub(int m, int n, const double* A, int lda, const double* x,
+                                double* y, int incy) {
+    for (int k = 0; k < n; ++k) {
+        double* yk = y + (long)k * incy;
+        *yk = b_dgemv_t_elem(m, n, k, A + (long)k * lda, x, *yk);
     }
 }
 
@@ -169,31 +174,29 @@ PW_HD inline void b_dtrsv_ut(int n, const double* a, int lda, double* x) {
 // solved (FMA chain from zero, then one subtraction) followed by a
 // right-looking solve that multiplies by the pre-inverted diagonal.  n <= 15
 // here (no full 16-row block), which covers col <= m = 10.
-PW_HD inline void b_dtrsm_ut(int n, int nrhs, const double* a, int lda, double* b, int ldb) {
-    double inv[16];
-    for (int i = 0; i < n; ++i) inv[i] = 1.0 / a[i + (long)i * lda];
-    for (int c = 0; c < nrhs; ++c) {
-        double* x = b + (long)c * ldb;
-        int s = 0;
-        for (int bs = 8; bs > 0; bs >>= 1) {
-            if (!(n & bs)) continue;
-            int e = s + bs;
-            if (s > 0) {
-                for (int k = s; k < e; ++k) {
-                    const double* ck = a + (long)k * lda;
-                    double acc = ck[0] * x[0];
-                    for (int j = 1; j < s; ++j) acc = pw_fma(ck[j], x[j], acc);
-                    x[k] = x[k] - acc;
-                }
+PW_HD inline void b_dtrsm_ut_col(int n, const double* a, int lda, double* x) {
+    int s = 0;
+    for (int bs = 8; bs > 0; bs >>= 1) {
+        if (!(n & bs)) continue;
+        int e = s + bs;
+        if (s > 0) {
+            for (int k = s; k < e; ++k) {
+                const double* ck = a + (long)k * lda;
+                double acc = ck[0] * x[0];
+                for (int j = 1; j < s; ++j) acc = pw_fma(ck[j], x[j], acc);
+                x[k] = x[k] - acc;
             }
-            for (int i = s; i < e; ++i) {
-                x[i] = x[i] * inv[i];
-                double nx = -x[i];
-                for (int k = i + 1; k < e; ++k) x[k] = pw_fma(nx, a[i + (long)k * lda], x[k]);
-            }
-            s = e;
         }
+        for (int i = s; i < e; ++i) {
+            x[i] = x[i] * (1.0 / a[i + (long)i * lda]);
+            double nx = -x[i];
+            for (int k = i + 1; k < e; ++k) x[k] = pw_fma(nx, a[i + (long)k * lda], x[k]);
+        }
+        s = e;
     }
+}
+PW_HD inline void b_dtrsm_ut(int n, int nrhs, const double* a, int lda, double* b, int ldb) {
+    for (int c = 0; c < nrhs; ++c) b_dtrsm_ut_col(n, a, lda, b + (long)c * ldb);
 }
 // LAPACK dtrtrs front end: singularity check (exact zero on the diagonal).
 PW_HD inline int b_dtrtrs_u(bool trans, int n, int nrhs, const double* a, int lda, double* b,

@@ -14,7 +14,9 @@
 #include <hip/hip_runtime.h>
 #define PW_HD __host__ __device__
 #define PW_D __device__
+#define PW_NOINLINE __attribute__((noinline))
 #else
+#define PW_NOINLINE
 #define PW_HD
 #define PW_D
 #endif

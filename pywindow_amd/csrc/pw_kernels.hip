@@ -125,6 +125,9 @@ static int ensure_workspace(pw_context* c, int blocks) {
         c->ws_blocks = 0;
     }
     HIP_TRY(hipMalloc((void**)&c->ws, (size_t)blocks * sizeof(TeamWorkspace)));
+#ifdef PW_PROFILE
+    for (int b = 0; b < blocks; ++b) HIP_TRY(hipMemset(c->ws[b].prof, 0, sizeof(c->ws[b].prof)));
+#endif
     c->ws_blocks = blocks;
     return PW_OK;
 }
@@ -378,6 +381,26 @@ int pw_point_gaps(pw_context* c, const pw_batch_in* in, const int64_t* unit_of_p
 #undef PG_TRY
     cleanup();
     return PW_OK;
+}
+
+/* diagnostic builds (-DPW_PROFILE): sum of the in-kernel stage timers over all teams, in
+ * 100 MHz ticks; zeroes them afterwards.  Returns PW_E_BAD_ARG in normal builds. */
+int pw_debug_stage_ticks(pw_context* c, unsigned long long* out32) {
+#ifdef PW_PROFILE
+    if (!c || !out32 || !c->ws) return PW_E_BAD_ARG;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 32; ++i) out32[i] = 0;
+    for (int b = 0; b < c->ws_blocks; ++b) {
+        unsigned long long tmp[32];
+        HIP_TRY(hipMemcpy(tmp, c->ws[b].prof, sizeof(tmp), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 32; ++i) out32[i] += tmp[i];
+        HIP_TRY(hipMemset(c->ws[b].prof, 0, sizeof(tmp)));
+    }
+    return PW_OK;
+#else
+    (void)c; (void)out32;
+    return PW_E_BAD_ARG;
+#endif
 }
 
 }  // extern "C"

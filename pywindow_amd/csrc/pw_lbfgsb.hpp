@@ -15,11 +15,30 @@
 // and comparing x, the workspace matrices and the task code after every call
 // (tests/test_lbfgsb_lockstep.py).
 //
+// Execution model: the routines are written for a *team of lanes* (pw_team.hpp).
+// Scalars and the length-n vectors (n <= 3) are computed redundantly by every
+// lane; everything indexed by the correction count (vectors of length col / 2col,
+// the col x col and 2col x 2col matrices) is spread over the lanes element by
+// element, each element keeping the reference's own sequential accumulation
+// order, with a wave-level sync between dependent phases.  Triangular solves run
+// as systolic sweeps (one division per step, the updates of a step in parallel).
+// With a one-lane team (host tests) the same code degenerates to the plain
+// sequential algorithm.
+//
 // Written from the algorithm description; single-source for host tests and
 // gfx950.  State lives in one plain struct (about 10 KB) that the HIP kernel
 // keeps in LDS, one instance per wavefront.
 #pragma once
 #include "pw_blas.hpp"
+#include "pw_team.hpp"
+
+#if defined(PW_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define LB_T0(var) long long var = wall_clock64()
+#define LB_T1(slot, var) do { if (prof && T::lane() == 0) atomicAdd(&prof[slot], (unsigned long long)(wall_clock64() - var)); } while (0)
+#else
+#define LB_T0(var) do {} while (0)
+#define LB_T1(slot, var) do {} while (0)
+#endif
 
 namespace pw {
 
@@ -59,6 +78,8 @@ struct Lbfgsb {
     double wn[M2 * M2], wn1[M2 * M2];
     double z[N], r[N], d[N], t[N], xp[N];
     double wa[8 * M];
+    double acc[2 * M];  // running dot products of the systolic triangular solves
+    unsigned long long* prof;  // stage timers (diagnostic builds only), else null
     int index[N], iwhere[N], indx2[N];
     // ---- scalars kept between calls ----
     int task, msg;
@@ -88,6 +109,7 @@ struct Lbfgsb {
         maxls = maxls_;
         task = LB_START;
         msg = 0;
+        prof = nullptr;
     }
 
     PW_HD double& SY(int i, int j) { return sy[i + M * j]; }
@@ -97,6 +119,94 @@ struct Lbfgsb {
     PW_HD double& WN1(int i, int j) { return wn1[i + M2 * j]; }
     PW_HD double* WS(int j) { return ws + j * N; }
     PW_HD double* WY(int j) { return wy + j * N; }
+
+
+    // ---- team-parallel dense kernels (element-wise identical to pw_blas.hpp) -------------
+    template <class T>
+    PW_HD int p_dpotrf_u(int n, double* a, int lda) {
+        for (int j = 0; j < n; ++j) {
+            double* cj = a + (long)j * lda;
+            double ajj = cj[j] - b_ddot(j, cj, cj);
+            if (ajj <= 0.0) {
+                T::wave_sync();
+                if (T::lane() == 0) cj[j] = ajj;
+                T::wave_sync();
+                return j + 1;
+            }
+            ajj = pw_sqrt(ajj);
+            int rem = n - j - 1;
+            double inv = 1.0 / ajj;
+            for (int k = T::lane(); k < rem; k += T::WSIZE) {
+                double* ck = a + (long)(j + 1 + k) * lda;
+                double y = b_dgemv_t_elem(j, rem, k, ck, cj, ck[j]);
+                ck[j] = y * inv;
+            }
+            T::wave_sync();
+            if (T::lane() == 0) cj[j] = ajj;
+            T::wave_sync();
+        }
+        return 0;
+    }
+    // solve U x = b (no-trans), one right-hand side: level-2 TRSV order
+    template <class T>
+    PW_HD void p_dtrsv_un(int n, const double* a, int lda, double* x) {
+        for (int i = n - 1; i >= 0; --i) {
+            const double* ci = a + (long)i * lda;
+            double xi = x[i] / ci[i];
+            T::wave_sync();
+            if (T::lane() == 0) x[i] = xi;
+            double nx = -xi;
+            for (int k = T::lane(); k < i; k += T::WSIZE) x[k] = pw_fma(nx, ci[k], x[k]);
+            T::wave_sync();
+        }
+    }
+    // solve U^T x = b, one right-hand side: DOT order (b_ddot), as a systolic sweep
+    template <class T>
+    PW_HD void p_dtrsv_ut(int n, const double* a, int lda, double* x) {
+        for (int i = T::lane(); i < n; i += T::WSIZE) acc[i] = 0.0;
+        T::wave_sync();
+        for (int s = 0; s < n; ++s) {
+            double xs = x[s];
+            if (s > 0) xs = xs - acc[s];
+            xs = xs / a[s + (long)s * lda];
+            T::wave_sync();
+            if (T::lane() == 0) x[s] = xs;
+            for (int i = s + 1 + T::lane(); i < n; i += T::WSIZE) {
+                const double* ci = a + (long)i * lda;
+                if (i >= 16 && s < 16) {
+                    // rows 16.. take their first 16 terms through the SIMD ddot kernel order
+                    if (s == 15) {
+                        double sl[4];
+                        for (int l = 0; l < 4; ++l) {
+                            double x12 = (12 + l == 15) ? xs : x[12 + l];
+                            double a0 = ci[l] * x[l];
+                            double a1 = ci[4 + l] * x[4 + l];
+                            double a2 = ci[8 + l] * x[8 + l];
+                            double a3 = ci[12 + l] * x12;
+                            sl[l] = ((a0 + a1) + a2) + a3;
+                        }
+                        acc[i] = (sl[0] + sl[2]) + (sl[1] + sl[3]);
+                    }
+                } else {
+                    acc[i] = pw_fma(xs, ci[s], acc[i]);
+                }
+            }
+            T::wave_sync();
+        }
+    }
+    template <class T>
+    PW_HD int p_dtrtrs_u(bool trans, int n, int nrhs, const double* a, int lda, double* b, int ldb) {
+        for (int i = 0; i < n; ++i)
+            if (a[i + (long)i * lda] == 0.0) return i + 1;
+        if (nrhs == 1) {
+            if (trans) p_dtrsv_ut<T>(n, a, lda, b);
+            else p_dtrsv_un<T>(n, a, lda, b);
+        } else {
+            for (int c = T::lane(); c < nrhs; c += T::WSIZE) b_dtrsm_ut_col(n, a, lda, b + (long)c * ldb);
+            T::wave_sync();
+        }
+        return 0;
+    }
 
     // ---- projgr: infinity norm of the projected gradient ------------------
     PW_HD void projgr() {
@@ -141,25 +251,31 @@ struct Lbfgsb {
     }
 
     // ---- bmv: product of the 2m x 2m middle matrix with a vector ----------
-    PW_HD int bmv(const double* v, double* p) {
+    template <class T>
+    PW_NOINLINE PW_HD int bmv(const double* v, double* p) {
         if (col == 0) return 0;
-        p[col] = v[col];
-        for (int i = 1; i < col; ++i) {
-            double sum = 0.0;
-            for (int k = 0; k < i; ++k) sum = sum + SY(i, k) * v[k] / SY(k, k);
-            p[col + i] = v[col + i] + sum;
+        for (int i = T::lane(); i < col; i += T::WSIZE) {
+            if (i == 0) {
+                p[col] = v[col];
+            } else {
+                double sum = 0.0;
+                for (int k = 0; k < i; ++k) sum = sum + SY(i, k) * v[k] / SY(k, k);
+                p[col + i] = v[col + i] + sum;
+            }
         }
-        int inf = b_dtrtrs_u(true, col, 1, wt, M, p + col, col);
+        T::wave_sync();
+        int inf = p_dtrtrs_u<T>(true, col, 1, wt, M, p + col, col);
         if (inf != 0) return inf;
-        for (int i = 0; i < col; ++i) p[i] = v[i] / pw_sqrt(SY(i, i));
-        inf = b_dtrtrs_u(false, col, 1, wt, M, p + col, col);
+        for (int i = T::lane(); i < col; i += T::WSIZE) p[i] = v[i] / pw_sqrt(SY(i, i));
+        inf = p_dtrtrs_u<T>(false, col, 1, wt, M, p + col, col);
         if (inf != 0) return inf;
-        for (int i = 0; i < col; ++i) p[i] = -p[i] / pw_sqrt(SY(i, i));
-        for (int i = 0; i < col; ++i) {
+        for (int i = T::lane(); i < col; i += T::WSIZE) {
+            double pi = -p[i] / pw_sqrt(SY(i, i));
             double sum = 0.0;
             for (int k = i + 1; k < col; ++k) sum = sum + SY(k, i) * p[col + k] / SY(i, i);
-            p[i] = p[i] + sum;
+            p[i] = pi + sum;
         }
+        T::wave_sync();
         return 0;
     }
 
@@ -211,7 +327,8 @@ struct Lbfgsb {
 
     // ---- cauchy: generalized Cauchy point ----------------------------------
     // workspace: p = wa[0..2m), c = wa[2m..4m), wbp = wa[4m..6m), v = wa[6m..8m)
-    PW_HD int cauchy() {
+    template <class T>
+    PW_NOINLINE PW_HD int cauchy() {
         double* p = wa;
         double* c = wa + 2 * M;
         double* wbp = wa + 4 * M;
@@ -231,7 +348,8 @@ struct Lbfgsb {
         int col2 = 2 * col;
         double f1 = 0.0;
         double tl = 0.0, tu = 0.0;
-        for (int i = 0; i < col2; ++i) p[i] = 0.0;
+        for (int i = T::lane(); i < col2; i += T::WSIZE) p[i] = 0.0;
+        T::wave_sync();
         for (int i = 0; i < N; ++i) {
             double neggi = -g[i];
             if (iwhere[i] != 3 && iwhere[i] != -1) {
@@ -254,10 +372,11 @@ struct Lbfgsb {
             } else {
                 d[i] = neggi;
                 f1 = f1 - neggi * neggi;
-                for (int j = 0; j < col; ++j) {
-                    p[j] = p[j] + WY(pointr)[i] * neggi;
-                    p[col + j] = p[col + j] + WS(pointr)[i] * neggi;
-                    pointr = (pointr + 1) % M;
+                // lane j owns p[j] and p[col + j]; the sum over the variables i stays sequential
+                for (int j = T::lane(); j < col; j += T::WSIZE) {
+                    int pj = (pointr + j) % M;
+                    p[j] = p[j] + WY(pj)[i] * neggi;
+                    p[col + j] = p[col + j] + WS(pj)[i] * neggi;
                 }
                 if (nbd[i] <= 2 && nbd[i] != 0 && neggi < 0.0) {
                     nbreak += 1;
@@ -282,14 +401,17 @@ struct Lbfgsb {
                 }
             }
         }
-        if (theta != 1.0) b_dscal(col, theta, p + col);
+        T::wave_sync();
+        if (theta != 1.0)
+            for (int j = T::lane(); j < col; j += T::WSIZE) p[col + j] = theta * p[col + j];
         b_dcopy(N, x, xcp);
-        if (nbreak == 0 && nfree_l == N + 1) return 0;
-        for (int j = 0; j < col2; ++j) c[j] = 0.0;
+        if (nbreak == 0 && nfree_l == N + 1) { T::wave_sync(); return 0; }
+        for (int j = T::lane(); j < col2; j += T::WSIZE) c[j] = 0.0;
+        T::wave_sync();
         double f2 = -theta * f1;
         double f2_org = f2;
         if (col > 0) {
-            int inf = bmv(p, v);
+            int inf = bmv<T>(p, v);
             if (inf != 0) return inf;
             f2 = f2 - b_ddot(col2, v, p);
         }
@@ -345,19 +467,21 @@ struct Lbfgsb {
                 f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;
                 f2 = f2 - theta * dibp2;
                 if (col > 0) {
-                    b_daxpy(col2, dt, p, c);
-                    int pointr = head;
-                    for (int j = 0; j < col; ++j) {
-                        wbp[j] = WY(pointr)[ibp];
-                        wbp[col + j] = theta * WS(pointr)[ibp];
-                        pointr = (pointr + 1) % M;
+                    for (int j = T::lane(); j < col2; j += T::WSIZE) c[j] = pw_fma(dt, p[j], c[j]);
+                    for (int j = T::lane(); j < col; j += T::WSIZE) {
+                        int pj = (head + j) % M;
+                        wbp[j] = WY(pj)[ibp];
+                        wbp[col + j] = theta * WS(pj)[ibp];
                     }
-                    int inf = bmv(wbp, v);
+                    T::wave_sync();
+                    int inf = bmv<T>(wbp, v);
                     if (inf != 0) return inf;
                     double wmc = b_ddot(col2, c, v);
                     double wmp = b_ddot(col2, p, v);
                     double wmw = b_ddot(col2, wbp, v);
-                    b_daxpy(col2, -dibp, wbp, p);
+                    T::wave_sync();
+                    for (int j = T::lane(); j < col2; j += T::WSIZE) p[j] = pw_fma(-dibp, wbp[j], p[j]);
+                    T::wave_sync();
                     f1 = f1 + dibp * wmc;
                     f2 = f2 + 2.0 * dibp * wmp - dibp2 * wmw;
                 }
@@ -380,7 +504,11 @@ struct Lbfgsb {
             tsum = tsum + dtm;
             b_daxpy(N, tsum, d, xcp);
         }
-        if (col > 0) b_daxpy(col2, dtm, p, c);
+        if (col > 0) {
+            T::wave_sync();
+            for (int j = T::lane(); j < col2; j += T::WSIZE) c[j] = pw_fma(dtm, p[j], c[j]);
+        }
+        T::wave_sync();
         return 0;
     }
 
@@ -420,23 +548,42 @@ struct Lbfgsb {
     }
 
     // ---- formk ------------------------------------------------------------------
-    PW_HD int formk() {
+    template <class T>
+    PW_NOINLINE PW_HD int formk() {
         const int nsub = nfree;
         if (updatd) {
             if (iupdat > M) {
-                for (int jy = 0; jy < M - 1; ++jy) {
-                    int js = M + jy;
-                    b_dcopy(M - (jy + 1), &WN1(jy + 1, jy + 1), &WN1(jy, jy));
-                    b_dcopy(M - (jy + 1), &WN1(js + 1, js + 1), &WN1(js, js));
-                    b_dcopy(M - 1, &WN1(M + 1, jy + 1), &WN1(M, jy));
+                // shift the old part of WN1 up-left by one: every target reads a cell of the
+                // next column, so the whole shift is "read all, then write all"
+                for (int pass = 0; pass < 2; ++pass) {
+                    // block (1,1) and (2,2): element (r, jy) <- (r+1, jy+1), r = jy..M-2
+                    // block (2,1): element (M+r, jy) <- (M+r+1, jy+1), r = 0..M-2
+                    // values staged through the (unused here) snd-sized scratch: wn
+                    for (int e = T::lane(); e < (M - 1) * (M - 1); e += T::WSIZE) {
+                        int jy = e / (M - 1), r = e % (M - 1);
+                        if (pass == 0) {
+                            if (r >= jy) {
+                                WN(r, jy) = WN1(r + 1, jy + 1);
+                                WN(M + r, M + jy) = WN1(M + r + 1, M + jy + 1);
+                            }
+                            WN(M + r, jy) = WN1(M + r + 1, jy + 1);
+                        } else {
+                            if (r >= jy) {
+                                WN1(r, jy) = WN(r, jy);
+                                WN1(M + r, M + jy) = WN(M + r, M + jy);
+                            }
+                            WN1(M + r, jy) = WN(M + r, jy);
+                        }
+                    }
+                    T::wave_sync();
                 }
             }
             int ipntr = head + col - 1;
             if (ipntr >= M) ipntr -= M;
             int iy = col - 1;
             int is = M + col - 1;
-            int jpntr = head;
-            for (int jy = 0; jy < col; ++jy) {
+            for (int jy = T::lane(); jy < col; jy += T::WSIZE) {
+                int jpntr = (head + jy) % M;
                 int js = M + jy;
                 double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0;
                 for (int k = 0; k < nsub; ++k) {
@@ -451,94 +598,96 @@ struct Lbfgsb {
                 WN1(iy, jy) = temp1;
                 WN1(is, js) = temp2;
                 WN1(is, jy) = temp3;
-                jpntr = (jpntr + 1) % M;
             }
+            T::wave_sync();
             int jy = col - 1;
-            jpntr = head + col - 1;
+            int jpntr = head + col - 1;
             if (jpntr >= M) jpntr -= M;
-            ipntr = head;
-            for (int i = 0; i < col; ++i) {
+            for (int i = T::lane(); i < col; i += T::WSIZE) {
+                int ip = (head + i) % M;
                 int is2 = M + i;
                 double temp3 = 0.0;
                 for (int k = 0; k < nsub; ++k) {
                     int k1 = index[k];
-                    temp3 = temp3 + WS(ipntr)[k1] * WY(jpntr)[k1];
+                    temp3 = temp3 + WS(ip)[k1] * WY(jpntr)[k1];
                 }
-                ipntr = (ipntr + 1) % M;
                 WN1(is2, jy) = temp3;
             }
+            T::wave_sync();
         }
         int upcl = updatd ? col - 1 : col;
-        int ipntr = head;
-        for (int iy = 0; iy < upcl; ++iy) {
-            int is = M + iy;
-            int jpntr = head;
-            for (int jy = 0; jy <= iy; ++jy) {
-                int js = M + jy;
-                double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0, temp4 = 0.0;
-                for (int k = 0; k < nenter; ++k) {
-                    int k1 = indx2[k];
-                    temp1 = temp1 + WY(ipntr)[k1] * WY(jpntr)[k1];
-                    temp2 = temp2 + WS(ipntr)[k1] * WS(jpntr)[k1];
-                }
-                for (int k = ileave - 1; k < N; ++k) {
-                    int k1 = indx2[k];
-                    temp3 = temp3 + WY(ipntr)[k1] * WY(jpntr)[k1];
-                    temp4 = temp4 + WS(ipntr)[k1] * WS(jpntr)[k1];
-                }
-                WN1(iy, jy) = WN1(iy, jy) + temp1 - temp3;
-                WN1(is, js) = WN1(is, js) - temp2 + temp4;
-                jpntr = (jpntr + 1) % M;
+        // modify the old parts in blocks (1,1) and (2,2): pairs (iy, jy <= iy)
+        for (int e = T::lane(); e < upcl * upcl; e += T::WSIZE) {
+            int iy = e / upcl, jy = e % upcl;
+            if (jy > iy) continue;
+            int ipntr = (head + iy) % M, jpntr = (head + jy) % M;
+            int is = M + iy, js = M + jy;
+            double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0, temp4 = 0.0;
+            for (int k = 0; k < nenter; ++k) {
+                int k1 = indx2[k];
+                temp1 = temp1 + WY(ipntr)[k1] * WY(jpntr)[k1];
+                temp2 = temp2 + WS(ipntr)[k1] * WS(jpntr)[k1];
             }
-            ipntr = (ipntr + 1) % M;
-        }
-        ipntr = head;
-        for (int is = M; is < M + upcl; ++is) {
-            int jpntr = head;
-            for (int jy = 0; jy < upcl; ++jy) {
-                double temp1 = 0.0, temp3 = 0.0;
-                for (int k = 0; k < nenter; ++k) {
-                    int k1 = indx2[k];
-                    temp1 = temp1 + WS(ipntr)[k1] * WY(jpntr)[k1];
-                }
-                for (int k = ileave - 1; k < N; ++k) {
-                    int k1 = indx2[k];
-                    temp3 = temp3 + WS(ipntr)[k1] * WY(jpntr)[k1];
-                }
-                if (is <= jy + M) WN1(is, jy) = WN1(is, jy) + temp1 - temp3;
-                else WN1(is, jy) = WN1(is, jy) - temp1 + temp3;
-                jpntr = (jpntr + 1) % M;
+            for (int k = ileave - 1; k < N; ++k) {
+                int k1 = indx2[k];
+                temp3 = temp3 + WY(ipntr)[k1] * WY(jpntr)[k1];
+                temp4 = temp4 + WS(ipntr)[k1] * WS(jpntr)[k1];
             }
-            ipntr = (ipntr + 1) % M;
+            WN1(iy, jy) = WN1(iy, jy) + temp1 - temp3;
+            WN1(is, js) = WN1(is, js) - temp2 + temp4;
         }
-        // form the upper triangle of WN
-        for (int iy = 0; iy < col; ++iy) {
-            int is = col + iy;
-            int is1 = M + iy;
-            for (int jy = 0; jy <= iy; ++jy) {
-                int js = col + jy;
-                int js1 = M + jy;
-                WN(jy, iy) = WN1(iy, jy) / theta;
+        // modify the old parts in block (2,1): all (is, jy)
+        for (int e = T::lane(); e < upcl * upcl; e += T::WSIZE) {
+            int ii = e / upcl, jy = e % upcl;
+            int is = M + ii;
+            int ipntr = (head + ii) % M, jpntr = (head + jy) % M;
+            double temp1 = 0.0, temp3 = 0.0;
+            for (int k = 0; k < nenter; ++k) {
+                int k1 = indx2[k];
+                temp1 = temp1 + WS(ipntr)[k1] * WY(jpntr)[k1];
+            }
+            for (int k = ileave - 1; k < N; ++k) {
+                int k1 = indx2[k];
+                temp3 = temp3 + WS(ipntr)[k1] * WY(jpntr)[k1];
+            }
+            if (is <= jy + M) WN1(is, jy) = WN1(is, jy) + temp1 - temp3;
+            else WN1(is, jy) = WN1(is, jy) - temp1 + temp3;
+        }
+        T::wave_sync();
+        // form the upper triangle of WN from WN1: pairs (iy, jy)
+        for (int e = T::lane(); e < col * col; e += T::WSIZE) {
+            int iy = e / col, jy = e % col;
+            int is = col + iy, is1 = M + iy;
+            if (jy <= iy) {
+                int js = col + jy, js1 = M + jy;
+                double w = WN1(iy, jy) / theta;
+                if (jy == iy) w = w + SY(iy, iy);
+                WN(jy, iy) = w;
                 WN(js, is) = WN1(is1, js1) * theta;
             }
-            for (int jy = 0; jy < iy; ++jy) WN(jy, is) = -WN1(is1, jy);
-            for (int jy = iy; jy < col; ++jy) WN(jy, is) = WN1(is1, jy);
-            WN(iy, iy) = WN(iy, iy) + SY(iy, iy);
+            if (jy < iy) WN(jy, is) = -WN1(is1, jy);
+            else WN(jy, is) = WN1(is1, jy);
         }
-        int inf = b_dpotrf_u(col, wn, M2);
+        T::wave_sync();
+        int inf = p_dpotrf_u<T>(col, wn, M2);
         if (inf != 0) return -1;
         int col2 = 2 * col;
-        inf = b_dtrtrs_u(true, col, col, wn, M2, &WN(0, col), M2);
-        for (int is = col; is < col2; ++is)
-            for (int js = is; js < col2; ++js)
-                WN(is, js) = WN(is, js) + b_ddot(col, &WN(0, is), &WN(0, js));
-        inf = b_dpotrf_u(col, &WN(col, col), M2);
+        inf = p_dtrtrs_u<T>(true, col, col, wn, M2, &WN(0, col), M2);
+        for (int e = T::lane(); e < col * col; e += T::WSIZE) {
+            int is = col + e / col, js = col + e % col;
+            if (js < is) continue;
+            WN(is, js) = WN(is, js) + b_ddot(col, &WN(0, is), &WN(0, js));
+        }
+        T::wave_sync();
+        inf = p_dpotrf_u<T>(col, &WN(col, col), M2);
+        (void)col2;
         if (inf != 0) return -2;
         return 0;
     }
 
     // ---- cmprlb -------------------------------------------------------------------
-    PW_HD int cmprlb() {
+    template <class T>
+    PW_NOINLINE PW_HD int cmprlb() {
         if (!cnstnd && col > 0) {
             for (int i = 0; i < N; ++i) r[i] = -g[i];
         } else {
@@ -546,7 +695,8 @@ struct Lbfgsb {
                 int k = index[i];
                 r[i] = -theta * (z[k] - x[k]) - g[k];
             }
-            int inf = bmv(wa + 2 * M, wa);
+            T::wave_sync();
+            int inf = bmv<T>(wa + 2 * M, wa);
             if (inf != 0) return -8;
             int pointr = head;
             for (int j = 0; j < col; ++j) {
@@ -563,31 +713,34 @@ struct Lbfgsb {
     }
 
     // ---- subsm -----------------------------------------------------------------------
-    PW_HD int subsm() {
+    template <class T>
+    PW_NOINLINE PW_HD int subsm() {
         const int nsub = nfree;
         double* wv = wa;
         double* dd = r;   // direction / reduced gradient
         double* xs = z;   // on entry the Cauchy point, on exit the subspace minimiser
         if (nsub <= 0) return 0;
-        int pointr = head;
-        for (int i = 0; i < col; ++i) {
+        T::wave_sync();
+        for (int i = T::lane(); i < col; i += T::WSIZE) {
+            int pi = (head + i) % M;
             double temp1 = 0.0, temp2 = 0.0;
             for (int j = 0; j < nsub; ++j) {
                 int k = index[j];
-                temp1 = temp1 + WY(pointr)[k] * dd[j];
-                temp2 = temp2 + WS(pointr)[k] * dd[j];
+                temp1 = temp1 + WY(pi)[k] * dd[j];
+                temp2 = temp2 + WS(pi)[k] * dd[j];
             }
             wv[i] = temp1;
             wv[col + i] = theta * temp2;
-            pointr = (pointr + 1) % M;
         }
+        T::wave_sync();
         int col2 = 2 * col;
-        int inf = b_dtrtrs_u(true, col2, 1, wn, M2, wv, col2);
+        int inf = p_dtrtrs_u<T>(true, col2, 1, wn, M2, wv, col2);
         if (inf != 0) return inf;
-        for (int i = 0; i < col; ++i) wv[i] = -wv[i];
-        inf = b_dtrtrs_u(false, col2, 1, wn, M2, wv, col2);
+        for (int i = T::lane(); i < col; i += T::WSIZE) wv[i] = -wv[i];
+        T::wave_sync();
+        inf = p_dtrtrs_u<T>(false, col2, 1, wn, M2, wv, col2);
         if (inf != 0) return inf;
-        pointr = head;
+        int pointr = head;
         for (int jy = 0; jy < col; ++jy) {
             int js = col + jy;
             for (int i = 0; i < nsub; ++i) {
@@ -815,7 +968,8 @@ struct Lbfgsb {
     // ---- lnsrlb --------------------------------------------------------------------------
     // returns true if a new (f,g) evaluation is requested, false when the line
     // search finished (task NEW_X) or failed (info != 0)
-    PW_HD bool lnsrlb(bool reentry) {
+    template <class T>
+    PW_NOINLINE PW_HD bool lnsrlb(bool reentry) {
         const double big = 1.0e10, ftol = 1.0e-3, gtol = 0.9, xtol = 0.1;
         if (!reentry) {
             dnorm = b_dnrm2(N, d);
@@ -878,7 +1032,8 @@ struct Lbfgsb {
     }
 
     // ---- matupd ---------------------------------------------------------------------------
-    PW_HD void matupd(double rr, double dr) {
+    template <class T>
+    PW_NOINLINE PW_HD void matupd(double rr, double dr) {
         if (iupdat <= M) {
             col = iupdat;
             itail = (head + iupdat - 1) % M;
@@ -889,35 +1044,66 @@ struct Lbfgsb {
         b_dcopy(N, d, WS(itail));
         b_dcopy(N, r, WY(itail));
         theta = rr / dr;
+        T::wave_sync();
         if (iupdat > M) {
-            for (int j = 0; j < col - 1; ++j) {
-                b_dcopy(j + 1, &SS(1, j + 1), &SS(0, j));
-                b_dcopy(col - (j + 1), &SY(j + 1, j + 1), &SY(j, j));
+            // move the old information up-left by one (read everything, then write)
+            double keep_ss[2], keep_sy[2];
+            int cnt = (col - 1) * (col - 1);
+            for (int q = 0; q < 2; ++q) {
+                int e = T::lane() + q * T::WSIZE;
+                if (e < cnt && T::WSIZE > 1) {
+                    int j = e / (col - 1), i = e % (col - 1);
+                    keep_ss[q] = (i <= j) ? SS(i + 1, j + 1) : 0.0;
+                    keep_sy[q] = (i >= j) ? SY(i + 1, j + 1) : 0.0;
+                }
             }
+            if (T::WSIZE > 1) {
+                T::wave_sync();
+                for (int q = 0; q < 2; ++q) {
+                    int e = T::lane() + q * T::WSIZE;
+                    if (e < cnt) {
+                        int j = e / (col - 1), i = e % (col - 1);
+                        if (i <= j) SS(i, j) = keep_ss[q];
+                        if (i >= j) SY(i, j) = keep_sy[q];
+                    }
+                }
+            } else {
+                for (int j = 0; j < col - 1; ++j) {
+                    b_dcopy(j + 1, &SS(1, j + 1), &SS(0, j));
+                    b_dcopy(col - (j + 1), &SY(j + 1, j + 1), &SY(j, j));
+                }
+            }
+            T::wave_sync();
         }
-        int pointr = head;
-        for (int j = 0; j < col - 1; ++j) {
-            SY(col - 1, j) = b_ddot(N, d, WY(pointr));
-            SS(j, col - 1) = b_ddot(N, WS(pointr), d);
-            pointr = (pointr + 1) % M;
+        for (int j = T::lane(); j < col - 1; j += T::WSIZE) {
+            int pj = (head + j) % M;
+            SY(col - 1, j) = b_ddot(N, d, WY(pj));
+            SS(j, col - 1) = b_ddot(N, WS(pj), d);
         }
-        if (stp == 1.0) SS(col - 1, col - 1) = dtd;
-        else SS(col - 1, col - 1) = stp * stp * dtd;
-        SY(col - 1, col - 1) = dr;
+        if (T::lane() == 0) {
+            if (stp == 1.0) SS(col - 1, col - 1) = dtd;
+            else SS(col - 1, col - 1) = stp * stp * dtd;
+            SY(col - 1, col - 1) = dr;
+        }
+        T::wave_sync();
     }
 
     // ---- formt -------------------------------------------------------------------------------
-    PW_HD int formt() {
-        for (int j = 0; j < col; ++j) WT(0, j) = theta * SS(0, j);
-        for (int i = 1; i < col; ++i) {
-            for (int j = i; j < col; ++j) {
-                int k1 = (i < j ? i : j);
+    template <class T>
+    PW_NOINLINE PW_HD int formt() {
+        for (int e = T::lane(); e < col * col; e += T::WSIZE) {
+            int i = e / col, j = e % col;
+            if (j < i) continue;
+            if (i == 0) {
+                WT(0, j) = theta * SS(0, j);
+            } else {
                 double ddum = 0.0;
-                for (int k = 0; k < k1; ++k) ddum = ddum + SY(i, k) * SY(j, k) / SY(k, k);
+                for (int k = 0; k < i; ++k) ddum = ddum + SY(i, k) * SY(j, k) / SY(k, k);
                 WT(i, j) = ddum + theta * SS(i, j);
             }
         }
-        int inf = b_dpotrf_u(col, wt, M);
+        T::wave_sync();
+        int inf = p_dpotrf_u<T>(col, wt, M);
         if (inf != 0) return -3;
         return 0;
     }
@@ -935,7 +1121,8 @@ struct Lbfgsb {
     // On return: task == LB_FG      -> evaluate f,g at x, store in f,g, call again
     //            task == LB_NEW_X   -> an iteration finished, call again to continue
     //            otherwise          -> finished (task/msg say why)
-    PW_HD void step() {
+    template <class T>
+    PW_NOINLINE PW_HD void step() {
         int entry;  // 0 fresh, 1 after FG_START, 2 after FG_LNSRCH, 3 after NEW_X
         if (task == LB_START) {
             epsmch = 2.220446049250313e-16;
@@ -982,7 +1169,9 @@ struct Lbfgsb {
                     wrk = updatd;
                     nseg = 0;
                 } else {
-                    int inf = cauchy();
+                    LB_T0(tc);
+                    int inf = cauchy<T>();
+                    LB_T1(16, tc);
                     if (inf != 0) { refresh(); continue; }
                     nintol += nseg;
                     wrk = freev();
@@ -990,18 +1179,26 @@ struct Lbfgsb {
                 }
                 if (!(nfree == 0 || col == 0)) {
                     if (wrk) {
-                        int inf = formk();
+                        LB_T0(tk);
+                        int inf = formk<T>();
+                        LB_T1(17, tk);
                         if (inf != 0) { refresh(); continue; }
                     }
-                    int inf = cmprlb();
-                    if (inf == 0) inf = subsm();
+                    LB_T0(tm);
+                    int inf = cmprlb<T>();
+                    LB_T1(18, tm);
+                    LB_T0(tsb);
+                    if (inf == 0) inf = subsm<T>();
+                    LB_T1(19, tsb);
                     if (inf != 0) { refresh(); continue; }
                 }
                 (void)have_dir;
                 for (int i = 0; i < N; ++i) d[i] = z[i] - x[i];
             }
             if (!resume_newx) {
-                bool need_fg = lnsrlb(resume_ls);
+                LB_T0(tl);
+                bool need_fg = lnsrlb<T>(resume_ls);
+                LB_T1(20, tl);
                 resume_ls = false;
                 if (info != 0 || iback >= maxls) {
                     b_dcopy(N, t, x);
@@ -1064,8 +1261,12 @@ struct Lbfgsb {
             }
             updatd = true;
             iupdat += 1;
-            matupd(rr, dr);
-            int inf = formt();
+            LB_T0(tu);
+            matupd<T>(rr, dr);
+            LB_T1(21, tu);
+            LB_T0(tf);
+            int inf = formt<T>();
+            LB_T1(22, tf);
             if (inf != 0) { refresh(); continue; }
         }
     }

@@ -90,7 +90,7 @@ PW_HD inline DD inv_fact(int n) {
 }
 
 // sin and cos of a double argument as double-doubles.  |x| < ~1e5.
-PW_HD inline void sincos_dd(double x, DD* s_out, DD* c_out) {
+PW_NOINLINE PW_HD inline void sincos_dd(double x, DD* s_out, DD* c_out) {
     // pi/2 in 33-bit pieces: k * piece is exact for |k| < 2^20
     const double P1 = 1.5707963267341256, P2 = 6.077100506303966e-11,
                  P3 = 2.0222662487111665e-21, P4 = 8.478427660348229e-32,

@@ -30,6 +30,16 @@
 #include "pw_math.hpp"
 #include "pw_team.hpp"
 
+// Optional in-kernel stage timers (diagnostic build only: -DPW_PROFILE): the 100 MHz
+// constant clock accumulated per stage by lane 0 of each wave into TeamWorkspace::prof.
+#if defined(PW_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define PW_T0(var) long long var = wall_clock64()
+#define PW_T1(ws, slot, var) do { if (T::lane() == 0) atomicAdd((unsigned long long*)&(ws)->prof[slot], (unsigned long long)(wall_clock64() - var)); } while (0)
+#else
+#define PW_T0(var) do {} while (0)
+#define PW_T1(ws, slot, var) do {} while (0)
+#endif
+
 namespace pw {
 
 constexpr double GOLDEN_ANGLE = 2.399963229728653;   // np.pi * (3 - np.sqrt(5))
@@ -49,12 +59,15 @@ struct TeamWorkspace {
     double pts[PW_P_MAX * 3];     // sampling vectors of find_windows
     double vals[PW_P_MAX];        // per-ray exit distance / per-survivor 2*gap
     double leaf[256];
+    double acc8[8 * 160];
+    int leaf_tab[324];
     int surv_k[PW_P_MAX];
     int labels[PW_P_MAX];
     unsigned char flag[PW_P_MAX];
     unsigned char core[PW_P_MAX];
     int stack[PW_P_MAX];
     unsigned long long adj[PW_P_MAX * (PW_P_MAX / 64)];
+    unsigned long long prof[32];
 };
 
 // ---- per-unit scalars kept in LDS ----------------------------------------------
@@ -80,6 +93,8 @@ struct UnitVars {
     // cross-wave reduction scratch
     double red_v[16];
     int red_i[16];
+    // DBSCAN bitsets: core / unlabelled / frontier / next (PW_P_MAX bits each)
+    unsigned long long bits[4][PW_P_MAX / 64];
     // window results by cluster
     int win_ok[PW_W_MAX];
     double win_d[PW_W_MAX];
@@ -125,6 +140,14 @@ struct UnitShared {
         }
     }
 };
+
+PW_HD inline void team_atomic_or(unsigned long long* p, unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicOr(p, v);
+#else
+    *p |= v;
+#endif
+}
 
 // ---- small numerics --------------------------------------------------------------
 PW_HD inline double sq3(double a, double b, double c) { return (a * a + c * c) + b * b; }
@@ -251,16 +274,52 @@ PW_HD inline double np_sum_serial(const double* a, int n) {
     }
     return total;
 }
-// team version: leaves in parallel, combine by thread 0; result broadcast via LDS slot
+// team version.  The eight strided accumulators of every leaf are independent
+// sequential chains, so (leaf, accumulator) pairs are spread over the threads;
+// one thread per leaf then folds them exactly as numpy does, and thread 0
+// combines the leaves in recursion order.  `tab` needs 2*160 ints, `acc8` 8*160
+// doubles, `leafbuf` 160 doubles (team-shared memory).
 template <class T>
-PW_HD inline double np_sum_team(const double* a, int n, double* leafbuf, double* slot) {
+PW_HD inline double np_sum_team(const double* a, int n, int* tab, double* acc8, double* leafbuf,
+                                double* slot) {
     double total = 0.0;
     bool first = true;
     for (int s = 0; s < n; s += 8192) {
         int len = n - s < 8192 ? n - s : 8192;
-        int loff[160], llen[160];
-        int nl = np_leaves(0, len, loff, llen);
-        for (int i = T::tid(); i < nl; i += T::SIZE) leafbuf[i] = np_leaf_sum(a + s + loff[i], llen[i]);
+        if (T::tid() == 0) tab[320] = np_leaves(0, len, tab, tab + 160);
+        T::sync();
+        int nl = tab[320];
+        for (int task = T::tid(); task < nl * 8; task += T::SIZE) {
+            int lf = task >> 3, c = task & 7;
+            const double* b = a + s + tab[lf];
+            int ln = tab[160 + lf];
+            if (ln < 8) {
+                if (c == 0) {
+                    double r = 0.0;
+                    for (int i = 0; i < ln; ++i) r = r + b[i];
+                    acc8[task] = r;
+                }
+            } else {
+                double r = b[c];
+                int lim = ln - (ln % 8);
+                for (int i = 8 + c; i < lim; i += 8) r = r + b[i];
+                acc8[task] = r;
+            }
+        }
+        T::sync();
+        for (int lf = T::tid(); lf < nl; lf += T::SIZE) {
+            const double* b = a + s + tab[lf];
+            int ln = tab[160 + lf];
+            const double* r = acc8 + 8 * lf;
+            double res;
+            if (ln < 8) {
+                res = r[0];
+            } else {
+                res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                for (int i = ln - (ln % 8); i < ln; ++i) res = res + b[i];
+            }
+            leafbuf[lf] = res;
+        }
         T::sync();
         if (T::tid() == 0) {
             double part = np_combine(len, leafbuf);
@@ -306,7 +365,7 @@ PW_HD inline int sampling_count(double radius) {
 
 // Ray from the centroid along (dx,dy,dz) against every atom (utilities.py:1138-1158 /
 // 1561-1578).  Returns whether any atom is "in the way" and the largest |p_out|.
-PW_HD inline bool ray_scan(const Frame& F, int n, const double* cen, double dx, double dy,
+PW_NOINLINE PW_HD inline bool ray_scan(const Frame& F, int n, const double* cen, double dx, double dy,
                            double dz, double* farthest) {
     double nrm = norm3(dx, dy, dz);
     double ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
@@ -353,7 +412,7 @@ PW_HD inline double np_floordiv(double a, double b) {
 
 // vector_analysis (utilities.py:1100-1129) by ONE thread: walk 0 -> v.
 // returns false if some point is inside a vdW sphere.
-PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx, double vy, double vz,
+PW_NOINLINE PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx, double vy, double vz,
                                    double inc, double* out_2gap, int* out_pos, double* out_chunk,
                                    int* n_eval) {
     double nrm = norm3(vx, vy, vz);
@@ -421,7 +480,7 @@ PW_HD inline void make_shifted(UnitShared& sh, int n, double cx, double cy, doub
 
 // max_dim over frame F (utilities.py:355-372); result in sh.v->maxd*, all threads.
 template <class T>
-PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n) {
+PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n) {
     double best = -PW_INF;
     int bidx = 0x7fffffff;
     // rows paired (i, n-1-i) for balance
@@ -462,9 +521,13 @@ PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n) {
 
 // ---- stage: basic -------------------------------------------------------------------------
 template <class T>
-PW_HD inline void stage_basic(UnitShared& sh, int n, pw_unit_out* out) {
+PW_NOINLINE PW_HD inline void stage_basic(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out) {
     UnitVars& v = *sh.v;
-    if (T::tid() == 0) v.mw = np_sum_serial(sh.mass, n);
+    v.mw = 0.0;
+    {
+        double mwsum = np_sum_team<T>(sh.mass, n, ws->leaf_tab, ws->acc8, ws->leaf, &v.red_v[15]);
+        if (T::tid() == 0) v.mw = mwsum;
+    }
     T::sync();
     // centre of mass: per component the row-sequential sum of x_i*m_i over the mass
     auto com_comp = [&](int c) {
@@ -516,7 +579,8 @@ PW_HD inline double fd_step(double x, double lb, double ub) {
 
 // ---- stage: optimised pore (wave 0) --------------------------------------------------------
 template <class T>
-PW_HD inline void stage_opt(UnitShared& sh, int n, pw_unit_out* out) {
+PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out) {
+    (void)ws;
     UnitVars& v = *sh.v;
     if (T::wave() == 0) {
         Lbfgsb<3>* S = (Lbfgsb<3>*)sh.lb[0];
@@ -534,13 +598,19 @@ PW_HD inline void stage_opt(UnitShared& sh, int n, pw_unit_out* out) {
         double lx = 0.0, ly = 0.0, lz = 0.0, lf = 0.0, lg[3] = {0.0, 0.0, 0.0};
         if (!bad) {
             S->setup(x0, lo, up, nbd, 1e7, 1e-5, 20);
+#ifdef PW_PROFILE
+            S->prof = ws->prof;
+#endif
             for (;;) {
-                S->step();
+                PW_T0(t_s);
+                S->template step<T>();
                 T::wave_sync();
+                PW_T1(ws, 0, t_s);
                 if (S->task == LB_FG) {
                     double px = S->x[0], py = S->x[1], pz = S->x[2];
                     // scipy's ScalarFunction re-uses f and g when asked for the point it
                     // evaluated last (_differentiable_functions.py: fun_and_grad)
+                    PW_T0(t_e);
                     if (!(have_last && px == lx && py == ly && pz == lz)) {
                         double f0 = -(wave_gap<T>(sh.A, n, px, py, pz, nullptr) * 2.0);
                         for (int c = 0; c < 3; ++c) {
@@ -560,6 +630,7 @@ PW_HD inline void stage_opt(UnitShared& sh, int n, pw_unit_out* out) {
                     S->f = lf;
                     S->g[0] = lg[0]; S->g[1] = lg[1]; S->g[2] = lg[2];
                     T::wave_sync();
+                    PW_T1(ws, 1, t_e);
                 } else if (S->task == LB_NEW_X) {
                     nit += 1;
                     if (nit >= 15000) break;
@@ -596,7 +667,7 @@ PW_HD inline void stage_opt(UnitShared& sh, int n, pw_unit_out* out) {
 
 // ---- stage: average diameter ---------------------------------------------------------------
 template <class T>
-PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out) {
+PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out) {
     UnitVars& v = *sh.v;
     make_shifted<T>(sh, n, v.com[0], v.com[1], v.com[2]);
     // preserve the input-frame max_dim: the shifted frame's replaces it only here
@@ -633,7 +704,7 @@ PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, int n, pw_uni
     }
     T::sync();
     int m = v.n_surv;
-    double sum = np_sum_team<T>(ws->knn, m, ws->leaf, &v.red_v[15]);
+    double sum = np_sum_team<T>(ws->knn, m, ws->leaf_tab, ws->acc8, ws->leaf, &v.red_v[15]);
     if (T::tid() == 0) {
         out->avg_d = (sum / (double)m) * 2.0;
         out->n_points_avg = P;
@@ -643,7 +714,7 @@ PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, int n, pw_uni
 
 // ---- Nelder-Mead in the window plane (scipy.optimize.fmin defaults, N = 2) ------------------
 template <class T>
-PW_HD inline void wave_fmin_xy(const Frame& F, int n, double z, double x0, double y0, double* xo,
+PW_NOINLINE PW_HD inline void wave_fmin_xy(const Frame& F, int n, double z, double x0, double y0, double* xo,
                                double* yo, int* n_eval) {
     const int maxfun = 400, maxiter = 400;
     const double xatol = 1e-4, fatol = 1e-4;
@@ -730,7 +801,7 @@ PW_HD inline void wave_fmin_xy(const Frame& F, int n, double z, double x0, doubl
 
 // ---- one window (utilities.py:1191-1361), executed by ONE wave -------------------------------
 template <class T>
-PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int n, int cluster,
+PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int n, int cluster,
                               const Sphere& sp) {
     UnitVars& v = *sh.v;
     const int w = T::wave();
@@ -748,6 +819,7 @@ PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int n, int clus
     T::wave_argmax(best, bidx);
     const double* pv = &ws->pts[3 * ws->surv_k[bidx]];
     double vx = pv[0], vy = pv[1], vz = pv[2];
+    PW_T0(t_p);
     // (ii) refined path scan, increment 0.1, lanes over path points
     double nrm = norm3(vx, vy, vz);
     int chunks = (int)np_floordiv(nrm, 0.1);
@@ -770,6 +842,8 @@ PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int n, int clus
         return;
     }
     T::wave_argmin(pbest, ppos);
+    PW_T1(ws, 2, t_p);
+    PW_T0(t_r);
     double new_z = norm3(cx * (double)ppos, cy * (double)ppos, cz * (double)ppos);
     // (iii) rotation angles (utilities.py:1235-1259)
     double c1 = pw_abs(vx * 1.0 + vy * 0.0 + 0.0 * 0.0) /
@@ -812,6 +886,7 @@ PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int n, int clus
     // (iv) diameter at the neck
     double d0 = wave_gap<T>(R, n, 0.0, 0.0, 0.0, nullptr) * 2.0;
     evals += 1;
+    PW_T1(ws, 3, t_r);
     // (v) neck position along z: L-BFGS-B, n = 1, bounds [-new_z, +inf)
     Lbfgsb<1>* S = (Lbfgsb<1>*)sh.lb[w];
     double lo1[1] = {-new_z}, up1[1] = {0.0}, x01[1] = {0.0};
@@ -822,9 +897,12 @@ PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int n, int clus
     bool have_last = false;
     double lz = 0.0, lf = 0.0, lg = 0.0;
     for (;;) {
-        S->step();
+        PW_T0(t_zs);
+        S->template step<T>();
         T::wave_sync();
+        PW_T1(ws, 4, t_zs);
         if (S->task == LB_FG) {
+            PW_T0(t_ze);
             double zc = S->x[0];
             if (!(have_last && zc == lz)) {
                 double f0 = wave_gap<T>(R, n, 0.0, 0.0, zc, nullptr) * 2.0;
@@ -841,6 +919,7 @@ PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int n, int clus
             S->f = lf;
             S->g[0] = lg;
             T::wave_sync();
+            PW_T1(ws, 5, t_ze);
         } else if (S->task == LB_NEW_X) {
             nit += 1;
             if (nit >= 15000) break;
@@ -849,6 +928,7 @@ PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int n, int clus
         }
     }
     double zopt = S->x[0];
+    PW_T0(t_b);
     // (vi) brute 20 x 20 grid over +-d0/2, lanes over grid points, first minimum
     double hlf = d0 / 2.0;
     double gstart = -hlf;
@@ -864,8 +944,11 @@ PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int n, int clus
     evals += 400;
     T::wave_argmin(gbest, gidx);
     double gx0 = (double)(gidx / 20) * gstep + gstart, gy0 = (double)(gidx % 20) * gstep + gstart;
+    PW_T1(ws, 6, t_b);
+    PW_T0(t_n);
     double xo, yo;
     wave_fmin_xy<T>(R, n, zopt, gx0, gy0, &xo, &yo, &evals);
+    PW_T1(ws, 7, t_n);
     // (vii) final diameter, (viii) back-rotation
     double dfin = wave_gap<T>(R, n, xo, yo, zopt, nullptr) * 2.0;
     evals += 1;
@@ -894,7 +977,7 @@ PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int n, int clus
 
 // ---- stage: windows ----------------------------------------------------------------------------
 template <class T>
-PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out) {
+PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out) {
     UnitVars& v = *sh.v;
     // shift so that the optimised pore centre is the origin (utilities.py:1388-1390)
     if (T::tid() == 0) {
@@ -934,6 +1017,7 @@ PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_uni
         sp.point(k, &ws->pts[3 * k], &ws->pts[3 * k + 1], &ws->pts[3 * k + 2]);
     T::sync();
     // ---- eps: mean of all 10-NN distances (self included), utilities.py:1427-1434 ----
+    PW_T0(t_eps);
     {
         // candidates within an index window; exactness is verified per point and a
         // full scan is done when the window cannot be proven sufficient
@@ -941,33 +1025,41 @@ PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_uni
         int W = (int)(4.0 * pw_sqrt((double)P)) + 8;
         for (int k = T::tid(); k < P; k += T::SIZE) {
             double px = ws->pts[3 * k], py = ws->pts[3 * k + 1], pz = ws->pts[3 * k + 2];
-            double t[10];
+            double t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
             int lo = k - W < 0 ? 0 : k - W, hi = k + W > P - 1 ? P - 1 : k + W;
             for (int pass = 0; pass < 2; ++pass) {
-                for (int q = 0; q < 10; ++q) t[q] = PW_INF;
+                t0 = t1 = t2 = t3 = t4 = t5 = t6 = t7 = t8 = t9 = PW_INF;
                 for (int j = lo; j <= hi; ++j) {
                     double ax = px - ws->pts[3 * j], ay = py - ws->pts[3 * j + 1],
                            az = pz - ws->pts[3 * j + 2];
                     double d = 0.0;
                     d = d + ax * ax; d = d + ay * ay; d = d + az * az;
-                    if (d < t[9]) {
-                        int q = 9;
-                        while (q > 0 && t[q - 1] > d) { t[q] = t[q - 1]; --q; }
-                        t[q] = d;
+                    if (d < t9) {
+                        // sorted insertion by a compare-exchange chain (registers only)
+                        double lo_, v_ = d;
+#define PW_CE(tq) lo_ = pw_min(tq, v_); v_ = pw_max(tq, v_); tq = lo_;
+                        PW_CE(t0) PW_CE(t1) PW_CE(t2) PW_CE(t3) PW_CE(t4)
+                        PW_CE(t5) PW_CE(t6) PW_CE(t7) PW_CE(t8) PW_CE(t9)
+#undef PW_CE
                     }
                 }
                 bool full = (lo == 0 && hi == P - 1);
-                if (full || pw_sqrt(t[9]) < (double)(W - 1) * zstep) break;
+                if (full || pw_sqrt(t9) < (double)(W - 1) * zstep) break;
                 lo = 0; hi = P - 1;
             }
-            for (int q = 0; q < 10; ++q) ws->knn[k * 10 + q] = pw_sqrt(t[q]);
+            double* row = &ws->knn[k * 10];
+            row[0] = pw_sqrt(t0); row[1] = pw_sqrt(t1); row[2] = pw_sqrt(t2); row[3] = pw_sqrt(t3);
+            row[4] = pw_sqrt(t4); row[5] = pw_sqrt(t5); row[6] = pw_sqrt(t6); row[7] = pw_sqrt(t7);
+            row[8] = pw_sqrt(t8); row[9] = pw_sqrt(t9);
         }
         T::sync();
-        double sum = np_sum_team<T>(ws->knn, P * 10, ws->leaf, &v.red_v[15]);
+        double sum = np_sum_team<T>(ws->knn, P * 10, ws->leaf_tab, ws->acc8, ws->leaf, &v.red_v[15]);
         double m = sum / (double)(P * 10);
         if (T::tid() == 0) { v.eps = m + pw_sqrt(m); out->eps = v.eps; }
         T::sync();
     }
+    if (T::wave() == 0) PW_T1(ws, 8, t_eps);
+    PW_T0(t_smp);
     // ---- sampling vectors: ray test + coarse path scan, one vector per thread ----
     {
         double cen[3] = {v.centroid[0], v.centroid[1], v.centroid[2]};
@@ -997,6 +1089,7 @@ PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_uni
         T::sync();
         (void)evals;
     }
+    if (T::wave() == 0) PW_T1(ws, 9, t_smp);
     int ns = v.n_surv;
     if (ns == 0) {
         // no vector reaches the outside: find_windows returns None
@@ -1004,10 +1097,33 @@ PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_uni
         T::sync();
         return;
     }
+    PW_T0(t_db);
     // ---- DBSCAN(eps, min_samples = 5) on the survivors' end points -----------------------
+    // sklearn labels (sklearn/cluster/_dbscan_inner.pyx): core points = connected components
+    // of the eps-graph numbered by their smallest member index; a border point takes the
+    // label of the first (lowest-numbered) cluster with a core point next to it.  Both are
+    // independent of the traversal order inside a cluster, so each cluster is grown
+    // breadth-first with bitset frontiers, all lanes expanding frontier members at once.
     {
         const int words = (ns + 63) / 64;
         double e2 = v.eps * v.eps;
+        unsigned long long* core = v.bits[0];
+        unsigned long long* unl = v.bits[1];
+        unsigned long long* frontier = v.bits[2];
+        unsigned long long* next = v.bits[3];
+        // adjacency rows live in LDS (the window frames are idle now) when they fit
+        size_t npad = (size_t)((n + 1) & ~1);
+        size_t cap_words = (size_t)T::NWAVES * 4 * npad;
+        unsigned long long* adj;
+        int stride;
+        if ((size_t)ns * (size_t)words <= cap_words) { adj = (unsigned long long*)sh.R[0].x; stride = words; }
+        else { adj = ws->adj; stride = PW_P_MAX / 64; }
+        for (int wd = T::tid(); wd < words; wd += T::SIZE) {
+            core[wd] = 0;
+            int nb = ns - wd * 64;
+            unl[wd] = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+        }
+        T::sync();
         for (int i = T::tid(); i < ns; i += T::SIZE) {
             const double* pi = &ws->pts[3 * ws->surv_k[i]];
             double px = pi[0], py = pi[1], pz = pi[2];
@@ -1022,52 +1138,72 @@ PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_uni
                     d = d + ax * ax; d = d + ay * ay; d = d + az * az;
                     if (d <= e2) { bits |= 1ull << (j - wd * 64); ++cnt; }
                 }
-                ws->adj[(size_t)i * (PW_P_MAX / 64) + wd] = bits;
+                adj[(size_t)i * stride + wd] = bits;
             }
-            ws->core[i] = cnt >= 5 ? 1 : 0;
+            if (cnt >= 5) team_atomic_or(&core[i >> 6], 1ull << (i & 63));
             ws->labels[i] = -1;
         }
         T::sync();
-        if (T::tid() == 0) {
-            // sklearn/cluster/_dbscan_inner.pyx: depth-first expansion in index order
-            int label = 0;
-            for (int i0 = 0; i0 < ns; ++i0) {
-                if (ws->labels[i0] != -1 || !ws->core[i0]) continue;
-                // The reference pushes a neighbour once per incident edge; labelling at
-                // push time visits the same set and gives the same labels (core points:
-                // connected components numbered by their smallest index; border points:
-                // the first -- lowest-numbered -- cluster that touches them) with a stack
-                // that never holds more than ns entries.
-                int top = 0;
-                ws->labels[i0] = label;
-                ws->stack[top++] = i0;
-                while (top) {
-                    int i = ws->stack[--top];
-                    for (int wd = 0; wd < words; ++wd) {
-                        unsigned long long bits = ws->adj[(size_t)i * (PW_P_MAX / 64) + wd];
-                        while (bits) {
-                            int b = __builtin_ctzll(bits);
-                            bits &= bits - 1;
-                            int nb = wd * 64 + b;
-                            if (ws->labels[nb] == -1) {
-                                ws->labels[nb] = label;
-                                if (ws->core[nb]) ws->stack[top++] = nb;
-                            }
+        int label = 0;
+        for (;;) {
+            int seed = -1;
+            for (int wd = 0; wd < words; ++wd) {
+                unsigned long long m = unl[wd] & core[wd];
+                if (m) { seed = wd * 64 + __builtin_ctzll(m); break; }
+            }
+            if (seed < 0) break;
+            T::sync();
+            for (int wd = T::tid(); wd < words; wd += T::SIZE) frontier[wd] = 0;
+            T::sync();
+            if (T::tid() == 0) {
+                unsigned long long b = 1ull << (seed & 63);
+                frontier[seed >> 6] = b;
+                unl[seed >> 6] &= ~b;
+                ws->labels[seed] = label;
+            }
+            T::sync();
+            for (;;) {
+                for (int wd = T::tid(); wd < words; wd += T::SIZE) next[wd] = 0;
+                T::sync();
+                for (int i = T::tid(); i < ns; i += T::SIZE) {
+                    if ((frontier[i >> 6] >> (i & 63)) & 1ull) {
+                        for (int wd = 0; wd < words; ++wd) {
+                            unsigned long long b = adj[(size_t)i * stride + wd] & unl[wd];
+                            if (b) team_atomic_or(&next[wd], b);
                         }
                     }
                 }
-                label += 1;
+                T::sync();
+                bool any = false;
+                for (int wd = 0; wd < words; ++wd) any = any || (next[wd] != 0);
+                if (!any) break;
+                for (int i = T::tid(); i < ns; i += T::SIZE)
+                    if ((next[i >> 6] >> (i & 63)) & 1ull) ws->labels[i] = label;
+                T::sync();
+                for (int wd = T::tid(); wd < words; wd += T::SIZE) {
+                    unsigned long long nx = next[wd];
+                    unl[wd] &= ~nx;
+                    frontier[wd] = nx & core[wd];
+                }
+                T::sync();
             }
+            label += 1;
+        }
+        T::sync();
+        if (T::tid() == 0) {
             v.n_clusters = label;
             out->n_clusters = label;
             if (label > PW_W_MAX) v.status |= PW_ST_WINDOW_OVERFLOW;
         }
         T::sync();
     }
+    if (T::wave() == 0) PW_T1(ws, 10, t_db);
+    PW_T0(t_w);
     // ---- one window per cluster, clusters dealt round-robin to the waves -------------------
     int ncl = v.n_clusters < PW_W_MAX ? v.n_clusters : PW_W_MAX;
     for (int c = T::wave(); c < ncl; c += T::NWAVES) wave_window<T>(sh, ws, n, c, sp);
     T::sync();
+    if (T::wave() == 0) PW_T1(ws, 12, t_w);
     if (T::tid() == 0) {
         int m = 0;
         for (int c = 0; c < ncl; ++c) {
@@ -1109,9 +1245,13 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
         }
     }
     load_unit<T>(sh, n, xyz, vdw, mass);
-    stage_basic<T>(sh, n, out);
-    if (stages & PW_STAGE_OPT) stage_opt<T>(sh, n, out);
-    if (stages & PW_STAGE_AVG) stage_average<T>(sh, ws, n, out);
+    stage_basic<T>(sh, ws, n, out);
+    if (stages & PW_STAGE_OPT) stage_opt<T>(sh, ws, n, out);
+    if (stages & PW_STAGE_AVG) {
+        PW_T0(t_a);
+        stage_average<T>(sh, ws, n, out);
+        if (T::wave() == 0) PW_T1(ws, 13, t_a);
+    }
     if ((stages & PW_STAGE_WINDOWS) && !(sh.v->status & PW_ST_NEGATIVE_PORE))
         stage_windows<T>(sh, ws, n, out);
     if (T::tid() == 0) {

@@ -40,7 +40,7 @@ template <int N> static void dump(Lbfgsb<N>* s, double* wa_out, int* ints, doubl
                                     int set_fg) {                                            \
         auto* s = (Lbfgsb<N>*)h;                                                             \
         if (set_fg) { s->f = f; for (int i = 0; i < N; ++i) s->g[i] = g[i]; }                \
-        s->step();                                                                           \
+        s->template step<HostTeam>();                                                                         \
         for (int i = 0; i < N; ++i) x[i] = s->x[i];                                          \
     }                                                                                        \
     extern "C" void hs_lb##N##_dump(void* h, double* wa, int* ints, double* dbl) {           \

@@ -72,6 +72,11 @@ def lockstep(fun, x0, lb, ub, nbd, verbose=False, maxcalls=5000):
         for k, (a, b) in lay.items():
             if k in ("snd", "wa", "xp", "t"): continue
             sa = wa[a:b]; sb = mwa[a:b]
+            if k == "wn":
+                # only the upper triangle (column-major) is ever read; pw::Lbfgsb uses the
+                # strict lower triangle as staging space when it shifts WN1
+                keep = np.tril(np.ones((2 * M, 2 * M), bool)).ravel()
+                sa = np.where(keep, sa, 0.0); sb = np.where(keep, sb, 0.0)
             if not np.array_equal(sa, sb):
                 idx = np.nonzero(sa != sb)[0]
                 bad.append((k, idx[:6], sa[idx[:6]], sb[idx[:6]]))

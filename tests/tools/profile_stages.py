@@ -1,0 +1,35 @@
+"""Build a -DPW_PROFILE variant of the library and print in-kernel stage shares."""
+import ctypes, pathlib, subprocess, sys, json
+ROOT = pathlib.Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+import numpy as np
+csrc = ROOT / "pywindow_amd" / "csrc"
+so = ROOT / "tests" / "tools" / "libpw_prof.so"
+so.parent.mkdir(exist_ok=True)
+if "--build" in sys.argv:
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-DPW_PROFILE", "-c", str(csrc / "pw_kernels.hip"), "-o", "/tmp/pwk_prof.o"])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-c", str(csrc / "pw_history.cpp"), "-o", "/tmp/pwh_prof.o"])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "/tmp/pwk_prof.o", "/tmp/pwh_prof.o", "-o", str(so)])
+    sys.exit(0)
+from pywindow_amd import _lib, synth
+from pywindow_amd import element_data as E
+_lib.LIB_PATH = so
+L = _lib.load()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+elements, frames = synth.synthetic_units(n)
+ids = E.element_ids(elements)
+ctx = _lib.Context(0)
+res = ctx.upload(_lib.Batch.uniform(frames, E.VDW[ids], E.MASS[ids]))
+res.launch(); res.sync()
+buf = (ctypes.c_ulonglong * 32)()
+L.pw_debug_stage_ticks.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+L.pw_debug_stage_ticks(ctx._h, buf)   # reset
+ms = res.time_launches(1)
+L.pw_debug_stage_ticks(ctx._h, buf)
+names2 = {16:"lb.cauchy",17:"lb.formk",18:"lb.cmprlb",19:"lb.subsm",20:"lb.lnsrlb",21:"lb.matupd",22:"lb.formt"}
+names = ["opt.step", "opt.eval", "win.path", "win.rotate", "win.z.step", "win.z.eval", "win.brute", "win.nm", "eps", "sampling", "dbscan", "-", "windows(total)", "average"]
+t = np.array(list(buf), float)[:14] / 100.0 / 2   # two launches (warm-up + timed) -> microseconds per launch
+t2 = np.array(list(buf), float) / 100.0 / 2
+d = {k: round(v / n, 2) for k, v in zip(names, t)}
+d.update({v: round(t2[k] / n, 2) for k, v in names2.items()})
+print(json.dumps({"units": n, "kernel_ms": ms, "us_per_unit": d}))
