@@ -159,7 +159,7 @@ PW_HD inline double ext_to_double(Ext64 a) {
 }
 
 // dnrm2 for short unit-stride vectors: one extended accumulator, sequential.
-PW_HD inline double b_dnrm2(int n, const double* x) {
+PW_NOINLINE PW_HD inline double b_dnrm2(int n, const double* x) {
     Ext64 s; s.m = 0; s.e = 0;
     for (int i = 0; i < n; ++i) s = ext_add(s, ext_square(x[i]));
     return ext_to_double(ext_sqrt(s));

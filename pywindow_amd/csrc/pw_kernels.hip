@@ -39,7 +39,7 @@ void set_err(const char* what, hipError_t e) {
     } while (0)
 
 template <int NW>
-__global__ void __launch_bounds__(NW * 64)
+__global__ void __launch_bounds__(NW * 64, 2)
 pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
                   const double* __restrict__ vdw, const double* __restrict__ mass, unsigned stages,
                   int nmax, TeamWorkspace* __restrict__ workspaces, unsigned long long* counter,

@@ -48,9 +48,23 @@ constexpr double FOUR_THIRDS_PI = 4.1887902047863905;  // 4 / 3 * np.pi
 constexpr double TWO_PI = 6.283185307179586;
 constexpr double ONE_PI = 3.141592653589793;
 
+// Atoms are stored grouped by van-der-Waals radius (few distinct radii per
+// molecule): within one group min_i(|r_i-p| - vdw) = sqrt(min_i |r_i-p|^2) - vdw
+// exactly (sqrt is monotone and correctly rounded), so bulk evaluations need one
+// square root per group instead of one per atom.  `perm` maps the stored
+// position back to the caller's atom index (used for every reported index and for
+// first-index tie-breaks), `inv` is its inverse.
+constexpr int PW_KCLS = 8;
+struct ClassInfo {
+    int k;                  // number of groups; 0 => more than PW_KCLS radii, no grouping used
+    int off[PW_KCLS + 1];   // group g = stored positions [off[g], off[g+1])
+    double vdw[PW_KCLS];
+};
 struct Frame {
     double *x, *y, *z, *xx;
     const double* vdw;
+    const int* perm;
+    const ClassInfo* cls;
 };
 
 // ---- global-memory workspace of one team (sized for PW_P_MAX vectors) ----------
@@ -83,6 +97,7 @@ struct UnitVars {
     double opt_g;
     int opt_atom;
     double shift[3];
+    ClassInfo cls;
     double eps;
     double radius;
     int P;
@@ -104,8 +119,10 @@ struct UnitVars {
 // LDS layout helper: everything a team needs, carved from one byte buffer.
 struct UnitShared {
     UnitVars* v;
-    double* vdw;
-    double* mass;
+    double* vdw;    // stored (grouped) order
+    double* mass;   // caller's order
+    int* perm;
+    int* inv;
     Frame A;        // input coordinates
     Frame S;        // shifted coordinates (COM frame, then pore-centre frame)
     Frame R[8];     // per-wave rotated coordinates (window frames)
@@ -115,6 +132,7 @@ struct UnitShared {
         size_t b = sizeof(UnitVars);
         b = (b + 15) & ~(size_t)15;
         b += n * 8 * 2;                       // vdw, mass
+        b += n * 4 * 2;                       // perm, inv
         b += n * 8 * 4 * (2 + (size_t)nwaves);  // A, S, R[w]
         b += (size_t)nwaves * ((sizeof(Lbfgsb<3>) + 15) & ~(size_t)15);
         return b;
@@ -127,11 +145,13 @@ struct UnitShared {
         double* d = (double*)p;
         vdw = d; d += n;
         mass = d; d += n;
-        A.x = d; d += n; A.y = d; d += n; A.z = d; d += n; A.xx = d; d += n; A.vdw = vdw;
-        S.x = d; d += n; S.y = d; d += n; S.z = d; d += n; S.xx = d; d += n; S.vdw = vdw;
+        perm = (int*)d; d += n / 2;
+        inv = (int*)d; d += n / 2;
+        A.x = d; d += n; A.y = d; d += n; A.z = d; d += n; A.xx = d; d += n; A.vdw = vdw; A.perm = perm; A.cls = &v->cls;
+        S.x = d; d += n; S.y = d; d += n; S.z = d; d += n; S.xx = d; d += n; S.vdw = vdw; S.perm = perm; S.cls = &v->cls;
         for (int w = 0; w < nwaves; ++w) {
             R[w].x = d; d += n; R[w].y = d; d += n; R[w].z = d; d += n; R[w].xx = d; d += n;
-            R[w].vdw = vdw;
+            R[w].vdw = vdw; R[w].perm = perm; R[w].cls = &v->cls;
         }
         p = (unsigned char*)d;
         for (int w = 0; w < nwaves; ++w) {
@@ -161,19 +181,40 @@ PW_HD inline double gap_atom(const Frame& F, int i, double px, double py, double
     double d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
     return d - F.vdw[i];
 }
-// one thread, all atoms
+// one thread, all atoms, exact value AND first argmin (caller's atom numbering)
 PW_HD inline double point_gap(const Frame& F, int n, double px, double py, double pz, int* arg) {
     double pp = sq3(px, py, pz);
     double best = PW_INF;
-    int bi = 0;
+    int bi = 0x7fffffff;
     for (int i = 0; i < n; ++i) {
         double v = gap_atom(F, i, px, py, pz, pp);
-        if (v < best) { best = v; bi = i; }
+        int oi = F.perm[i];
+        if (v < best || (v == best && oi < bi)) { best = v; bi = oi; }
     }
     if (arg) *arg = bi;
     return best;
 }
-// one wave, atoms spread over lanes; result in every lane
+// one thread, all atoms, VALUE only: per radius group the minimum squared distance,
+// then one sqrt per group.  Bit-identical to point_gap's value.
+PW_HD inline double point_gap_value(const Frame& F, int n, double px, double py, double pz) {
+    const ClassInfo& C = *F.cls;
+    if (C.k == 0) return point_gap(F, n, px, py, pz, nullptr);
+    double pp = sq3(px, py, pz);
+    double best = PW_INF;
+    for (int g = 0; g < C.k; ++g) {
+        double m2 = PW_INF;
+#pragma unroll 8
+        for (int i = C.off[g]; i < C.off[g + 1]; ++i) {
+            double gg = pw_fma(F.z[i], pz, pw_fma(F.x[i], px, F.y[i] * py));
+            double d2 = ((-2.0 * gg) + F.xx[i]) + pp;
+            m2 = pw_min(m2, d2);
+        }
+        double d = pw_sqrt(m2 > 0.0 ? m2 : 0.0);
+        best = pw_min(best, d - C.vdw[g]);
+    }
+    return best;
+}
+// one wave, atoms spread over lanes; value and first argmin (caller's numbering) in every lane
 template <class T>
 PW_HD inline double wave_gap(const Frame& F, int n, double px, double py, double pz, int* arg) {
     double pp = sq3(px, py, pz);
@@ -181,7 +222,8 @@ PW_HD inline double wave_gap(const Frame& F, int n, double px, double py, double
     int bi = 0x7fffffff;
     for (int i = T::lane(); i < n; i += T::WSIZE) {
         double v = gap_atom(F, i, px, py, pz, pp);
-        if (v < best) { best = v; bi = i; }
+        int oi = F.perm[i];
+        if (v < best || (v == best && oi < bi)) { best = v; bi = oi; }
     }
     T::wave_argmin(best, bi);
     if (arg) *arg = bi;
@@ -371,21 +413,42 @@ PW_NOINLINE PW_HD inline bool ray_scan(const Frame& F, int n, const double* cen,
     double ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
     bool any = false;
     double far = -1.0;
-    for (int i = 0; i < n; ++i) {
-        double rx = F.x[i] - cen[0], ry = F.y[i] - cen[1], rz = F.z[i] - cen[2];
-        double along = pw_fma(rz, uz, pw_fma(rx, ux, ry * uy));
-        double sq = sq3(rx, ry, rz);
-        double perp = pw_sqrt(sq - along * along);  // NaN when negative, as numpy
-        double radicand = F.vdw[i] * F.vdw[i] - perp * perp;
-        if (radicand > 0.0) {
-            double half = pw_sqrt(radicand);
-            double tin = along - half, tout = along + half;
-            double ix = cen[0] + tin * ux, iy = cen[1] + tin * uy, iz = cen[2] + tin * uz;
-            double ox = cen[0] + tout * ux, oy = cen[1] + tout * uy, oz = cen[2] + tout * uz;
-            double nin = norm3(ix, iy, iz), nout = norm3(ox, oy, oz);
-            if (nin < nout) {
-                any = true;
-                if (nout > far) far = nout;
+    // Two steps per block of 64 atoms: a cheap conservative screen (no square roots)
+    // marks the atoms whose sphere the line can touch; only those go through the
+    // reference's exact arithmetic.  Screen: the reference needs
+    // vdw^2 - fl(sqrt(q))^2 > 0 with q = |rel|^2 - along^2 (NaN for q < 0 => no hit);
+    // q > vdw^2 (1 + 1e-14) makes that impossible whatever the rounding.
+    for (int blk = 0; blk < n; blk += 64) {
+        unsigned long long mask = 0;
+        int jend = n - blk < 64 ? n - blk : 64;
+#pragma unroll 8
+        for (int j = 0; j < jend; ++j) {
+            int i = blk + j;
+            double rx = F.x[i] - cen[0], ry = F.y[i] - cen[1], rz = F.z[i] - cen[2];
+            double along = pw_fma(rz, uz, pw_fma(rx, ux, ry * uy));
+            double q = sq3(rx, ry, rz) - along * along;
+            double r2 = F.vdw[i] * F.vdw[i];
+            if (q >= 0.0 && q <= r2 * (1.0 + 1e-14)) mask |= 1ull << j;
+        }
+        while (mask) {
+            int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            int i = blk + j;
+            double rx = F.x[i] - cen[0], ry = F.y[i] - cen[1], rz = F.z[i] - cen[2];
+            double along = pw_fma(rz, uz, pw_fma(rx, ux, ry * uy));
+            double sq = sq3(rx, ry, rz);
+            double perp = pw_sqrt(sq - along * along);
+            double radicand = F.vdw[i] * F.vdw[i] - perp * perp;
+            if (radicand > 0.0) {
+                double half = pw_sqrt(radicand);
+                double tin = along - half, tout = along + half;
+                double ix = cen[0] + tin * ux, iy = cen[1] + tin * uy, iz = cen[2] + tin * uz;
+                double ox = cen[0] + tout * ux, oy = cen[1] + tout * uy, oz = cen[2] + tout * uz;
+                double nin = norm3(ix, iy, iz), nout = norm3(ox, oy, oz);
+                if (nin < nout) {
+                    any = true;
+                    if (nout > far) far = nout;
+                }
             }
         }
     }
@@ -422,7 +485,7 @@ PW_NOINLINE PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx,
     int pos = 0;
     bool ok = true;
     for (int k = 0; k <= chunks; ++k) {
-        double m = point_gap(F, n, cx * (double)k, cy * (double)k, cz * (double)k, nullptr);
+        double m = point_gap_value(F, n, cx * (double)k, cy * (double)k, cz * (double)k);
         if (!(m > 0.0)) { ok = false; break; }
         if (m < best) { best = m; pos = k; }
     }
@@ -438,16 +501,47 @@ PW_NOINLINE PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx,
 template <class T>
 PW_HD inline void load_unit(UnitShared& sh, int n, const double* xyz, const double* vdw,
                             const double* mass) {
-    for (int i = T::tid(); i < n; i += T::SIZE) {
-        double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-        sh.A.x[i] = x; sh.A.y[i] = y; sh.A.z[i] = z;
-        sh.A.xx[i] = sq3(x, y, z);
-        sh.vdw[i] = vdw[i];
-        sh.mass[i] = mass[i];
-    }
+    UnitVars& v = *sh.v;
     if (T::tid() == 0) {
-        sh.v->n_eval = 0;
-        sh.v->status = 0;
+        v.n_eval = 0;
+        v.status = 0;
+        // group atoms by radius (stable: ascending atom index inside a group)
+        ClassInfo& C = v.cls;
+        int cnt[PW_KCLS];
+        int k = 0;
+        bool ok = true;
+        for (int i = 0; i < n && ok; ++i) {
+            double r = vdw[i];
+            int g = 0;
+            while (g < k && C.vdw[g] != r) ++g;
+            if (g == k) {
+                if (k == PW_KCLS) { ok = false; break; }
+                C.vdw[k] = r; cnt[k] = 0; ++k;
+            }
+            sh.inv[i] = g;          // group id for now
+            cnt[g] += 1;
+        }
+        if (ok) {
+            C.k = k;
+            int o = 0;
+            for (int g = 0; g < k; ++g) { C.off[g] = o; o += cnt[g]; cnt[g] = C.off[g]; }
+            C.off[k] = o;
+            for (int i = 0; i < n; ++i) { int g = sh.inv[i]; sh.inv[i] = cnt[g]++; }
+        } else {
+            C.k = 0;
+            C.off[0] = 0;
+            for (int i = 0; i < n; ++i) sh.inv[i] = i;
+        }
+    }
+    T::sync();
+    for (int i = T::tid(); i < n; i += T::SIZE) {
+        int pos = sh.inv[i];
+        double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        sh.A.x[pos] = x; sh.A.y[pos] = y; sh.A.z[pos] = z;
+        sh.A.xx[pos] = sq3(x, y, z);
+        sh.vdw[pos] = vdw[i];
+        sh.perm[pos] = i;
+        sh.mass[i] = mass[i];
     }
     T::sync();
 }
@@ -461,19 +555,17 @@ PW_HD inline void make_shifted(UnitShared& sh, int n, double cx, double cy, doub
         sh.S.xx[i] = sq3(x, y, z);
     }
     T::sync();
-    if (T::tid() < 3) {
-        const double* a = T::tid() == 0 ? sh.S.x : (T::tid() == 1 ? sh.S.y : sh.S.z);
-        double s = a[0];
-        for (int i = 1; i < n; ++i) s = s + a[i];
-        sh.v->centroid[T::tid()] = s / (double)n;
-    }
-    if (T::SIZE < 3 && T::tid() == 0) {
-        for (int c = 1; c < 3; ++c) {
-            const double* a = c == 1 ? sh.S.y : sh.S.z;
-            double s = a[0];
-            for (int i = 1; i < n; ++i) s = s + a[i];
-            sh.v->centroid[c] = s / (double)n;
-        }
+    // centroid: np.sum(coordinates, axis=0) / N -- rows added in the caller's atom order
+    auto cen_comp = [&](int c) {
+        const double* a = c == 0 ? sh.S.x : (c == 1 ? sh.S.y : sh.S.z);
+        double s = a[sh.inv[0]];
+        for (int i = 1; i < n; ++i) s = s + a[sh.inv[i]];
+        sh.v->centroid[c] = s / (double)n;
+    };
+    if (T::SIZE >= 3) {
+        if (T::tid() < 3) cen_comp(T::tid());
+    } else if (T::tid() == 0) {
+        cen_comp(0); cen_comp(1); cen_comp(2);
     }
     T::sync();
 }
@@ -487,17 +579,22 @@ PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n
     for (int r = T::tid(); r < n; r += T::SIZE) {
         int i = (r & 1) ? (n - 1 - (r >> 1)) : (r >> 1);
         double xi = F.x[i], yi = F.y[i], zi = F.z[i], xxi = F.xx[i], vi = F.vdw[i];
+        int oi = F.perm[i];
         for (int j = i; j < n; ++j) {
             double d;
             if (j == i) {
                 d = 0.0;
             } else {
                 double g = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
-                double d2 = ((-2.0 * g) + xxi) + F.xx[j];
+                // entry (row, column) of the reference's matrix has row < column in the
+                // caller's numbering: the row norm is added first
+                double d2 = (oi < F.perm[j]) ? ((-2.0 * g) + xxi) + F.xx[j]
+                                             : ((-2.0 * g) + F.xx[j]) + xxi;
                 d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
             }
             double v = d + (vi + F.vdw[j]);
-            int idx = i * n + j;
+            int oj = F.perm[j];
+            int idx = oi < oj ? oi * n + oj : oj * n + oi;
             if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
         }
     }
@@ -532,8 +629,8 @@ PW_NOINLINE PW_HD inline void stage_basic(UnitShared& sh, TeamWorkspace* ws, int
     // centre of mass: per component the row-sequential sum of x_i*m_i over the mass
     auto com_comp = [&](int c) {
         const double* a = c == 0 ? sh.A.x : (c == 1 ? sh.A.y : sh.A.z);
-        double s = a[0] * sh.mass[0];
-        for (int i = 1; i < n; ++i) s = s + a[i] * sh.mass[i];
+        double s = a[sh.inv[0]] * sh.mass[0];
+        for (int i = 1; i < n; ++i) s = s + a[sh.inv[i]] * sh.mass[i];
         v.com[c] = s / v.mw;
     };
     if (T::SIZE >= 3) {
@@ -696,11 +793,18 @@ PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, i
     }
     T::sync();
     // compact in ray order (thread 0), then the numpy mean
-    if (T::tid() == 0) {
+    // order-preserving compaction by wave 0 (ballot + prefix popcount)
+    if (T::wave() == 0) {
         int m = 0;
-        for (int k = 0; k < P; ++k)
-            if (ws->flag[k]) ws->knn[m++] = ws->vals[k];
-        v.n_surv = m;
+        for (int base = 0; base < P; base += T::WSIZE) {
+            int k = base + T::lane();
+            bool f = k < P && ws->flag[k] != 0;
+            unsigned long long bal = T::ballot(f);
+            int pos = m + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
+            if (f) ws->knn[pos] = ws->vals[k];
+            m += __builtin_popcountll(bal);
+        }
+        if (T::lane() == 0) v.n_surv = m;
     }
     T::sync();
     int m = v.n_surv;
@@ -828,7 +932,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     int ppos = 0x7fffffff;
     bool ok = true;
     for (int k = T::lane(); k <= chunks; k += T::WSIZE) {
-        double m = point_gap(sh.S, n, cx * (double)k, cy * (double)k, cz * (double)k, nullptr);
+        double m = point_gap_value(sh.S, n, cx * (double)k, cy * (double)k, cz * (double)k);
         if (!(m > 0.0)) ok = false;
         if (m < pbest) { pbest = m; ppos = k; }
     }
@@ -938,7 +1042,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     for (int q = T::lane(); q < 400; q += T::WSIZE) {
         int ix = q / 20, iy = q % 20;
         double gx = (double)ix * gstep + gstart, gy = (double)iy * gstep + gstart;
-        double f = -(point_gap(R, n, gx, gy, zopt, nullptr) * 2.0);
+        double f = -(point_gap_value(R, n, gx, gy, zopt) * 2.0);
         if (f < gbest) { gbest = f; gidx = q; }
     }
     evals += 400;
@@ -1079,12 +1183,17 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             ws->flag[k] = okf;
         }
         T::sync();
-        if (T::tid() == 0) {
+        if (T::wave() == 0) {
             int m = 0;
-            for (int k = 0; k < P; ++k)
-                if (ws->flag[k]) { ws->surv_k[m] = k; ws->vals[m] = ws->knn[k]; ++m; }
-            v.n_surv = m;
-            out->n_survivors = m;
+            for (int base = 0; base < P; base += T::WSIZE) {
+                int k = base + T::lane();
+                bool f = k < P && ws->flag[k] != 0;
+                unsigned long long bal = T::ballot(f);
+                int pos = m + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
+                if (f) { ws->surv_k[pos] = k; ws->vals[pos] = ws->knn[k]; }
+                m += __builtin_popcountll(bal);
+            }
+            if (T::lane() == 0) { v.n_surv = m; out->n_survivors = m; }
         }
         T::sync();
         (void)evals;
