@@ -1,0 +1,76 @@
+"""Native DL_POLY HISTORY ingest and the host logic of the batched driver (no GPU)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from _util import load_group
+from pywindow_amd import _lib, synth
+from pywindow_amd.molecular import MolecularSystem, _AtomKeyConflictError, decipher_atom_key
+from pywindow_amd.trajectory import DLPOLY, _FunctionError, shard_range
+
+
+def test_history_roundtrip(tmp_path):
+    path = synth.write_synthetic_history(tmp_path / "HISTORY", 7)
+    traj = DLPOLY(path)
+    assert (traj.no_of_frames, traj.no_of_atoms) == (7, 168)
+    assert traj.periodic_boundary == "nonperiodic" and traj.content_type == "coordinates"
+    el, frames = synth.synthetic_units(7)
+    assert np.array_equal(traj.read_coordinates(0, 7), frames)
+    assert np.array_equal(traj.read_coordinates(3, 2), frames[3:5])
+    assert list(traj.elements()) == list(el)
+    # the synthetic frames are the golden synth64 inputs
+    g = load_group("synth64")
+    assert np.array_equal(frames.reshape(-1, 3), g["coordinates"][: 7 * 168])
+    ms = traj.get_frames(2)
+    assert isinstance(ms, MolecularSystem) and np.array_equal(ms.system["coordinates"], frames[2])
+
+
+def test_history_with_lattice_and_velocities(tmp_path):
+    lines = ["title", "%10d%10d%10d" % (1, 3, 2)]
+    for f in range(2):
+        lines.append("timestep%10d%10d%10d%10d%12.6f" % (f, 2, 1, 3, 0.001))
+        lines += ["  10.0 0.0 0.0", "  0.0 11.0 0.0", "  0.0 0.5 12.0"]
+        for a in range(2):
+            lines.append("%-8s%10d%12.6f%12.6f" % ("C" + str(a + 1), a + 1, 12.0, 0.0))
+            lines.append("%12.4E%12.4E%12.4E" % (a + f, 2 * a, 3.5))
+            lines.append("%12.4E%12.4E%12.4E" % (9, 9, 9))
+    p = tmp_path / "H2"
+    p.write_text("\n".join(lines) + "\n")
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    assert L.pw_history_open(str(p).encode(), ctypes.byref(h)) == 0
+    assert (L.pw_history_frames(h), L.pw_history_atoms(h), L.pw_history_keytrj(h), L.pw_history_imcon(h)) == (2, 2, 1, 3)
+    xyz = np.zeros((2, 2, 3))
+    lat = np.zeros((2, 9))
+    assert L.pw_history_read(h, 0, 2, xyz.ctypes.data, lat.ctypes.data) == 0
+    assert np.array_equal(xyz[1], [[1.0, 0.0, 3.5], [2.0, 2.0, 3.5]])
+    assert np.array_equal(lat[0].reshape(3, 3), np.array([[10, 0, 0], [0, 11, 0], [0, 0.5, 12]]).T)
+    assert L.pw_history_read(h, 1, 2, xyz.ctypes.data, None) != 0   # out of range -> error code
+    L.pw_history_close(h)
+    assert L.pw_history_open(b"/nonexistent/HISTORY", ctypes.byref(h)) != 0
+
+
+def test_force_field_keys():
+    assert decipher_atom_key("ca", "opls") == "C" and decipher_atom_key("ni", "OPLS") == "N"
+    assert decipher_atom_key("C12", "DLF") == "C" and decipher_atom_key("Zn1", "dl_f") == "Zn"
+    with pytest.raises(_AtomKeyConflictError):
+        decipher_atom_key("he", "opls")
+    ms = MolecularSystem.load_system({"atom_ids": np.array(["he", "ca"]), "coordinates": np.zeros((2, 3))})
+    ms.swap_atom_keys({"he": "H"})
+    ms.decipher_atom_keys("opls")
+    assert list(ms.system["elements"]) == ["H", "C"]
+
+
+def test_frame_selection_and_sharding(tmp_path):
+    traj = DLPOLY(synth.write_synthetic_history(tmp_path / "HISTORY", 5))
+    assert traj._select("all") == [0, 1, 2, 3, 4] and traj._select(3) == [3] and traj._select((1, 3)) == [1, 2]
+    with pytest.raises(_FunctionError):
+        traj._select("bogus")
+    with pytest.raises(_FunctionError):
+        traj._select([0, "1"])
+    # contiguous, exhaustive, ordered shards
+    for n, w in ((1000, 8), (10, 3), (5, 8), (0, 2)):
+        parts = [shard_range(n, r, w) for r in range(w)]
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))

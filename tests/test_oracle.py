@@ -1,0 +1,64 @@
+"""Pins the ORACLE (oracle/pw_oracle.py + oracle/pw_prim.c) against golden vectors
+produced by the reference itself (tests/golden/make_golden.py): bit-for-bit on
+every quantity, optimiser outputs included."""
+import numpy as np
+import pytest
+
+from _util import load_group, molecules
+
+# (group, unit): the reference's own known-answer inputs + real MD + synthetic + periodic
+CASES = [("static", 0), ("static", 1), ("static", 2), ("static", 6), ("md20", 0), ("md20", 12),
+         ("synth64", 3), ("periodic8", 5)]
+
+
+@pytest.mark.parametrize("tag,u", CASES)
+def test_oracle_reproduces_reference_bit_for_bit(tag, u):
+    from oracle import pw_oracle as O
+    from pywindow_amd import element_data as E
+
+    g = load_group(tag)
+    el, xyz = molecules(g)[u]
+    ids = E.element_ids(el)
+    r = O.full_analysis(xyz, E.VDW[ids], E.MASS[ids])
+    for k in ("mw", "maxd", "avg_d", "pore_d", "pore_vol", "pore_opt_d", "pore_vol_opt"):
+        assert r[k] == float(g[k][u]), (k, r[k], float(g[k][u]))
+    for k in ("maxd_i", "maxd_j", "pore_atom", "pore_opt_atom", "n_windows", "n_atoms"):
+        assert r[k] == int(g[k][u]), k
+    assert np.array_equal(r["com"], g["com"][u])
+    assert np.array_equal(r["pore_opt_c"], g["pore_opt_c"][u])
+    n = max(int(g["n_windows"][u]), 0)
+    assert np.array_equal(r["win_d"][:n], g["win_d"][u][:n])
+    assert np.array_equal(r["win_c"][:n], g["win_c"][u][:n])
+
+
+def test_distance_primitive_matches_captured_objective_values():
+    """The C primitive against objective values the reference evaluated through
+    sklearn's euclidean_distances (L-BFGS-B evaluation traces in the fixtures)."""
+    from oracle import pw_oracle as O
+    from pywindow_amd import element_data as E
+
+    for tag in ("static", "md20"):
+        g = load_group(tag)
+        mols = molecules(g)
+        for u in g["trace_units"][:4]:
+            el, xyz = mols[u]
+            ids = E.element_ids(el)
+            cage = O.Cage(xyz, E.VDW[ids], E.MASS[ids])
+            tr = g[f"tr{u}_opt"]
+            for row in tr[:: max(1, len(tr) // 60)]:
+                assert -(cage.gap(row[:3])[0] * 2) == row[3]
+
+
+def test_reference_literals():
+    """Numbers printed in the reference's tests (tests/test_validate_cc3.py:357-412)."""
+    from oracle import pw_oracle as O
+    from pywindow_amd import element_data as E
+
+    g = load_group("static")
+    el, xyz = molecules(g)[0]
+    ids = E.element_ids(el)
+    cage = O.Cage(xyz, E.VDW[ids], E.MASS[ids])
+    assert O.max_dim(cage) == (12, 54, 22.179369990077188)
+    assert O.pore_diameter(cage) == (5.397020177310022, 29)
+    assert O.molecular_weight(cage.mass) == 1117.5479999999998
+    np.testing.assert_almost_equal(O.centre_of_mass(cage), [12.4, 12.4, 12.4])
