@@ -42,14 +42,17 @@ template <int NW>
 __global__ void __launch_bounds__(NW * 64, 2)
 pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
                   const double* __restrict__ vdw, const double* __restrict__ mass, unsigned stages,
-                  int nmax, TeamWorkspace* __restrict__ workspaces, unsigned long long* counter,
+                  int nmax, int nrot, int nlb, TeamWorkspace* __restrict__ workspaces,
+                  unsigned long long* __restrict__ adj_base, unsigned long long* counter,
                   pw_unit_out* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ long s_unit;
     using T = DeviceTeam<NW>;
     UnitShared sh;
-    sh.carve(lds, nmax, NW);
+    sh.carve(lds, nmax, nrot, nlb);
     TeamWorkspace* ws = workspaces + blockIdx.x;
+    if (threadIdx.x == 0) ws->adj = adj_base ? adj_base + (size_t)blockIdx.x * PW_ADJ_WORDS : nullptr;
+    __syncthreads();
     for (;;) {
         if (threadIdx.x == 0) s_unit = (long)atomicAdd(counter, 1ull);
         __syncthreads();
@@ -96,13 +99,17 @@ __global__ void pw_point_gap_kernel(long n_points, const long* __restrict__ unit
 
 struct pw_context {
     int device;
-    hipStream_t stream;
+    hipStream_t stream;      // main stream (launch order, timing events)
+    hipStream_t aux;         // second stream: stages that do not depend on the optimiser
     int n_cu;
     size_t lds_per_cu;
     TeamWorkspace* ws;
     int ws_blocks;
-    unsigned long long* counter;
-    hipEvent_t ev0, ev1;
+    unsigned long long* adj;
+    int adj_blocks;
+    unsigned long long* counter;   // 4 work counters
+    hipEvent_t ev0, ev1, ev_fork, ev_join;
+    int fused;               // PW_FUSED=1: one launch per analysis instead of the pipeline
 };
 
 struct pw_resident {
@@ -116,60 +123,82 @@ struct pw_resident {
     pw_unit_out* d_out;
 };
 
-static int ensure_workspace(pw_context* c, int blocks) {
-    if (c->ws_blocks >= blocks) return PW_OK;
-    if (c->ws) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipFree(c->ws));
+static int ensure_workspace(pw_context* c, int blocks, int adj_blocks) {
+    if (c->ws_blocks < blocks) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->ws) HIP_TRY(hipFree(c->ws));
         c->ws = nullptr;
         c->ws_blocks = 0;
+        HIP_TRY(hipMalloc((void**)&c->ws, (size_t)blocks * sizeof(TeamWorkspace)));
+        HIP_TRY(hipMemset(c->ws, 0, (size_t)blocks * sizeof(TeamWorkspace)));
+        c->ws_blocks = blocks;
     }
-    HIP_TRY(hipMalloc((void**)&c->ws, (size_t)blocks * sizeof(TeamWorkspace)));
-#ifdef PW_PROFILE
-    for (int b = 0; b < blocks; ++b) HIP_TRY(hipMemset(c->ws[b].prof, 0, sizeof(c->ws[b].prof)));
-#endif
-    c->ws_blocks = blocks;
+    if (c->adj_blocks < adj_blocks) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->adj) HIP_TRY(hipFree(c->adj));
+        c->adj = nullptr;
+        c->adj_blocks = 0;
+        HIP_TRY(hipMalloc((void**)&c->adj, (size_t)adj_blocks * PW_ADJ_WORDS * sizeof(unsigned long long)));
+        c->adj_blocks = adj_blocks;
+    }
     return PW_OK;
 }
 
-// choose the team width and grid for a batch
-static int plan_launch(pw_context* c, long n_units, int nmax, int* nw_out, size_t* lds_out,
-                       int* grid_out) {
+struct LaunchPlan {
+    int nw, nrot, nlb, grid;
+    size_t lds;
+};
+
+// team width, LDS carve and grid for one launch.  want_nw: preferred waves per team;
+// rot/lb: whether window frames / optimiser states are needed (per wave).
+static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool rot, int lb_per_team,
+                       LaunchPlan* p) {
     const size_t max_lds = 160 * 1024 - 256;
-    int nw = 4;
-    size_t lds = UnitShared::bytes(nmax, nw) + 64;
-    while (lds > max_lds && nw > 1) {
+    int nw = want_nw;
+    for (;;) {
+        int nrot = rot ? nw : 0;
+        int nlb = lb_per_team < 0 ? nw : lb_per_team;
+        size_t lds = UnitShared::bytes(nmax, nrot, nlb) + 64;
+        if (lds <= max_lds || nw == 1) {
+            if (lds > max_lds) {
+                snprintf(g_err, sizeof(g_err), "molecule with %d atoms does not fit in LDS", nmax);
+                return PW_E_TOO_LARGE;
+            }
+            p->nw = nw; p->nrot = nrot; p->nlb = nlb; p->lds = lds;
+            break;
+        }
         nw >>= 1;
-        lds = UnitShared::bytes(nmax, nw) + 64;
     }
-    if (lds > max_lds) {
-        snprintf(g_err, sizeof(g_err), "molecule with %d atoms does not fit in LDS", nmax);
-        return PW_E_TOO_LARGE;
-    }
-    int per_cu = (int)(c->lds_per_cu / lds);
-    int wave_cap = 32 / nw;  // 32 waves per CU
+    int per_cu = (int)(c->lds_per_cu / p->lds);
+    int wave_cap = 16 / p->nw;  // kernels are built for 2 waves per SIMD
     if (per_cu > wave_cap) per_cu = wave_cap;
-    if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     long grid = (long)c->n_cu * per_cu;
     if (grid > n_units) grid = n_units;
     if (grid < 1) grid = 1;
-    *nw_out = nw;
-    *lds_out = lds;
-    *grid_out = (int)grid;
+    p->grid = (int)grid;
     return PW_OK;
 }
 
 template <int NW>
-static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, size_t lds, int grid) {
+static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const LaunchPlan& p, hipStream_t st,
+                     int ws_first, bool with_adj, int counter_slot) {
     auto kern = pw_analyse_kernel<NW>;
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-    HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, c->stream, r->n_units, r->d_offset,
-                       r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, c->ws, c->counter, r->d_out);
+                                (int)p.lds));
+    HIP_TRY(hipMemsetAsync(c->counter + counter_slot, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
+                       r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb,
+                       c->ws + ws_first, with_adj ? c->adj : (unsigned long long*)nullptr,
+                       c->counter + counter_slot, r->d_out);
     HIP_TRY(hipGetLastError());
     return PW_OK;
+}
+static int launch_plan(pw_context* c, pw_resident* r, unsigned stages, const LaunchPlan& p, hipStream_t st,
+                       int ws_first, bool with_adj, int counter_slot) {
+    if (p.nw == 4) return launch_nw<4>(c, r, stages, p, st, ws_first, with_adj, counter_slot);
+    if (p.nw == 2) return launch_nw<2>(c, r, stages, p, st, ws_first, with_adj, counter_slot);
+    return launch_nw<1>(c, r, stages, p, st, ws_first, with_adj, counter_slot);
 }
 
 extern "C" {
@@ -200,9 +229,14 @@ int pw_context_create(int device, pw_context** out) {
     c->n_cu = prop.multiProcessorCount;
     c->lds_per_cu = 160 * 1024;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc((void**)&c->counter, sizeof(unsigned long long)));
+    HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void**)&c->counter, 4 * sizeof(unsigned long long)));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    const char* fz = getenv("PW_FUSED");
+    c->fused = (fz && fz[0] == '1') ? 1 : 0;
     *out = c;
     return PW_OK;
 }
@@ -214,6 +248,10 @@ void pw_context_destroy(pw_context* c) {
     if (c->counter) (void)hipFree(c->counter);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->adj) (void)hipFree(c->adj);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -224,15 +262,54 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     if (!c || !r) return PW_E_BAD_ARG;
     if (r->n_units == 0) return PW_OK;
     HIP_TRY(hipSetDevice(c->device));
-    int nw, grid;
-    size_t lds;
-    int rc = plan_launch(c, r->n_units, r->nmax, &nw, &lds, &grid);
+    stages &= PW_STAGE_ALL;
+    const bool pipeline = !c->fused && (stages & PW_STAGE_WINDOWS) != 0;
+    int rc;
+    if (!pipeline) {
+        // one launch: every requested stage inside the same team
+        LaunchPlan p;
+        bool win = (stages & PW_STAGE_WINDOWS) != 0;
+        bool opt = win || (stages & PW_STAGE_OPT);
+        rc = plan_launch(c, r->n_units, r->nmax, (win || (stages & PW_STAGE_AVG)) ? 4 : 1, win,
+                         win ? -1 : (opt ? 1 : 0), &p);
+        if (rc != PW_OK) return rc;
+        rc = ensure_workspace(c, p.grid, win ? p.grid : 0);
+        if (rc != PW_OK) return rc;
+        return launch_plan(c, r, stages, p, c->stream, 0, win, 0);
+    }
+    // Pipeline: the analysis is split by parallel shape.
+    //   A (main stream): stage_basic + pore-centre optimiser, ONE wave per unit -- the serial
+    //     chain; every unit of a 1000-frame batch runs at once instead of idling 3 waves.
+    //   B (aux stream, concurrent with A): average diameter, 4 waves per unit.
+    //   C (main, after A and B): window search with the pore centre taken from the record.
+    LaunchPlan pa, pb, pc;
+    rc = plan_launch(c, r->n_units, r->nmax, 1, false, 1, &pa);
     if (rc != PW_OK) return rc;
-    rc = ensure_workspace(c, grid);
+    bool do_avg = (stages & PW_STAGE_AVG) != 0;
+    pb.grid = 0;
+    if (do_avg) {
+        rc = plan_launch(c, r->n_units, r->nmax, 4, false, 0, &pb);
+        if (rc != PW_OK) return rc;
+    }
+    rc = plan_launch(c, r->n_units, r->nmax, 4, true, -1, &pc);
     if (rc != PW_OK) return rc;
-    if (nw == 4) return launch_nw<4>(c, r, stages, lds, grid);
-    if (nw == 2) return launch_nw<2>(c, r, stages, lds, grid);
-    return launch_nw<1>(c, r, stages, lds, grid);
+    int need = pa.grid + pb.grid;
+    if (pc.grid > need) need = pc.grid;
+    rc = ensure_workspace(c, need, pc.grid);
+    if (rc != PW_OK) return rc;
+    HIP_TRY(hipMemsetAsync(r->d_out, 0, sizeof(pw_unit_out) * r->n_units, c->stream));
+    if (do_avg) {
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        rc = launch_plan(c, r, PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pb, c->aux, pa.grid, false, 1);
+        if (rc != PW_OK) return rc;
+        HIP_TRY(hipEventRecord(c->ev_join, c->aux));
+    }
+    rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->stream, 0, false, 0);
+    if (rc != PW_OK) return rc;
+    if (do_avg) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    return launch_plan(c, r, PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pc,
+                       c->stream, 0, true, 2);
 }
 
 int pw_resident_sync(pw_context* c) {

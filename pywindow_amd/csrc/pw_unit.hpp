@@ -80,9 +80,10 @@ struct TeamWorkspace {
     unsigned char flag[PW_P_MAX];
     unsigned char core[PW_P_MAX];
     int stack[PW_P_MAX];
-    unsigned long long adj[PW_P_MAX * (PW_P_MAX / 64)];
     unsigned long long prof[32];
+    unsigned long long* adj;   // PW_P_MAX x PW_P_MAX/64 words, only for launches that run DBSCAN
 };
+constexpr size_t PW_ADJ_WORDS = (size_t)PW_P_MAX * (PW_P_MAX / 64);
 
 // ---- per-unit scalars kept in LDS ----------------------------------------------
 struct UnitVars {
@@ -127,17 +128,19 @@ struct UnitShared {
     Frame S;        // shifted coordinates (COM frame, then pore-centre frame)
     Frame R[8];     // per-wave rotated coordinates (window frames)
     void* lb[8];    // per-wave optimiser state
-    PW_HD static size_t bytes(int nmax, int nwaves) {
+    size_t rot_words;  // 8-byte words in the rotated-frame region (reused as DBSCAN adjacency)
+    // nrot = rotated window frames, nlb = optimiser states (both 0..nwaves)
+    PW_HD static size_t bytes(int nmax, int nrot, int nlb) {
         size_t n = (size_t)((nmax + 1) & ~1);
         size_t b = sizeof(UnitVars);
         b = (b + 15) & ~(size_t)15;
         b += n * 8 * 2;                       // vdw, mass
         b += n * 4 * 2;                       // perm, inv
-        b += n * 8 * 4 * (2 + (size_t)nwaves);  // A, S, R[w]
-        b += (size_t)nwaves * ((sizeof(Lbfgsb<3>) + 15) & ~(size_t)15);
+        b += n * 8 * 4 * (2 + (size_t)nrot);  // A, S, R[w]
+        b += (size_t)nlb * ((sizeof(Lbfgsb<3>) + 15) & ~(size_t)15);
         return b;
     }
-    PW_HD void carve(unsigned char* base, int nmax, int nwaves) {
+    PW_HD void carve(unsigned char* base, int nmax, int nrot, int nlb) {
         size_t n = (size_t)((nmax + 1) & ~1);
         unsigned char* p = base;
         v = (UnitVars*)p;
@@ -149,12 +152,14 @@ struct UnitShared {
         inv = (int*)d; d += n / 2;
         A.x = d; d += n; A.y = d; d += n; A.z = d; d += n; A.xx = d; d += n; A.vdw = vdw; A.perm = perm; A.cls = &v->cls;
         S.x = d; d += n; S.y = d; d += n; S.z = d; d += n; S.xx = d; d += n; S.vdw = vdw; S.perm = perm; S.cls = &v->cls;
-        for (int w = 0; w < nwaves; ++w) {
+        for (int w = 0; w < 8; ++w) { R[w].x = R[w].y = R[w].z = R[w].xx = nullptr; lb[w] = nullptr; }
+        for (int w = 0; w < nrot; ++w) {
             R[w].x = d; d += n; R[w].y = d; d += n; R[w].z = d; d += n; R[w].xx = d; d += n;
             R[w].vdw = vdw; R[w].perm = perm; R[w].cls = &v->cls;
         }
+        rot_words = (size_t)nrot * 4 * n;
         p = (unsigned char*)d;
-        for (int w = 0; w < nwaves; ++w) {
+        for (int w = 0; w < nlb; ++w) {
             lb[w] = p;
             p += (sizeof(Lbfgsb<3>) + 15) & ~(size_t)15;
         }
@@ -279,6 +284,38 @@ PW_HD inline double np_combine(int n, const double* leafsum) {
         NpSeg& c = st[top - 1];
         if (c.len <= 128) {
             vals[vtop++] = leafsum[li++];
+            --top;
+        } else if (c.stage == 0) {
+            int n2 = c.len / 2;
+            n2 -= n2 % 8;
+            c.stage = 1;
+            st[top++] = NpSeg{c.off, n2, 0};
+        } else if (c.stage == 1) {
+            int n2 = c.len / 2;
+            n2 -= n2 % 8;
+            c.stage = 2;
+            int o = c.off, l = c.len;
+            st[top++] = NpSeg{o + n2, l - n2, 0};
+        } else {
+            double r = vals[--vtop];
+            double l = vals[--vtop];
+            vals[vtop++] = l + r;
+            --top;
+        }
+    }
+    return vals[0];
+}
+// serial, array-free version for n <= 8192 (one thread): depth-first over the same
+// recursion, leaves summed as they are reached
+PW_HD inline double np_sum_small(const double* a, int n) {
+    NpSeg st[24];
+    double vals[24];
+    int top = 0, vtop = 0;
+    st[top++] = NpSeg{0, n, 0};
+    while (top) {
+        NpSeg& c = st[top - 1];
+        if (c.len <= 128) {
+            vals[vtop++] = np_leaf_sum(a + c.off, c.len);
             --top;
         } else if (c.stage == 0) {
             int n2 = c.len / 2;
@@ -618,12 +655,17 @@ PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n
 
 // ---- stage: basic -------------------------------------------------------------------------
 template <class T>
-PW_NOINLINE PW_HD inline void stage_basic(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out) {
+PW_NOINLINE PW_HD inline void stage_basic(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
+                                           bool com_only) {
     UnitVars& v = *sh.v;
-    v.mw = 0.0;
-    {
-        double mwsum = np_sum_team<T>(sh.mass, n, ws->leaf_tab, ws->acc8, ws->leaf, &v.red_v[15]);
-        if (T::tid() == 0) v.mw = mwsum;
+    (void)ws;
+    if (T::tid() == 0) {
+        double tot = 0.0;
+        for (int s0 = 0; s0 < n; s0 += 8192) {
+            double part = np_sum_small(sh.mass + s0, n - s0 < 8192 ? n - s0 : 8192);
+            tot = s0 == 0 ? part : tot + part;
+        }
+        v.mw = tot;
     }
     T::sync();
     // centre of mass: per component the row-sequential sum of x_i*m_i over the mass
@@ -639,6 +681,7 @@ PW_NOINLINE PW_HD inline void stage_basic(UnitShared& sh, TeamWorkspace* ws, int
         com_comp(0); com_comp(1); com_comp(2);
     }
     T::sync();
+    if (com_only) return;
     team_max_dim<T>(sh, sh.A, n);
     if (T::wave() == 0) {
         int arg;
@@ -1221,12 +1264,16 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         unsigned long long* frontier = v.bits[2];
         unsigned long long* next = v.bits[3];
         // adjacency rows live in LDS (the window frames are idle now) when they fit
-        size_t npad = (size_t)((n + 1) & ~1);
-        size_t cap_words = (size_t)T::NWAVES * 4 * npad;
+        size_t cap_words = sh.rot_words;
         unsigned long long* adj;
         int stride;
         if ((size_t)ns * (size_t)words <= cap_words) { adj = (unsigned long long*)sh.R[0].x; stride = words; }
         else { adj = ws->adj; stride = PW_P_MAX / 64; }
+        if (adj == nullptr) {   // launch without a global adjacency buffer and LDS too small
+            if (T::tid() == 0) v.status |= PW_ST_POINTS_OVERFLOW;
+            T::sync();
+            return;
+        }
         for (int wd = T::tid(); wd < words; wd += T::SIZE) {
             core[wd] = 0;
             int nb = ns - wd * 64;
@@ -1334,13 +1381,31 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
 }
 
 // ---- the unit ------------------------------------------------------------------------------------
+// internal stage bits used when one analysis is split over several launches
+constexpr unsigned PW_STAGE_REUSE_OPT = 16u;   // pore centre already in the record (earlier launch)
+constexpr unsigned PW_STAGE_MERGE = 32u;       // record is shared with other launches: no resets
+constexpr unsigned PW_STAGE_COM_ONLY = 64u;    // only what later stages need from stage_basic
+
+PW_HD inline void record_or_status(pw_unit_out* out, int st, int evals) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (st) atomicOr(&out->status, st);
+    atomicAdd(&out->n_eval, evals);
+#else
+    out->status |= st;
+    out->n_eval += evals;
+#endif
+}
+
 template <class T>
 PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const double* xyz,
                                const double* vdw, const double* mass, unsigned stages,
                                pw_unit_out* out) {
-    if (stages & PW_STAGE_WINDOWS) stages |= PW_STAGE_OPT;
-    stages |= PW_STAGE_BASIC;
-    if (T::tid() == 0) {
+    const bool merge = (stages & PW_STAGE_MERGE) != 0;
+    const bool reuse_opt = (stages & PW_STAGE_REUSE_OPT) != 0;
+    if ((stages & PW_STAGE_WINDOWS) && !reuse_opt) stages |= PW_STAGE_OPT;
+    if (T::tid() == 0 && !merge) {
+        out->status = 0;
+        out->n_eval = 0;
         out->avg_d = 0.0;
         out->pore_opt_d = 0.0; out->pore_opt_atom = -1; out->pore_vol_opt = 0.0;
         out->pore_opt_c[0] = out->pore_opt_c[1] = out->pore_opt_c[2] = 0.0;
@@ -1354,8 +1419,17 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
         }
     }
     load_unit<T>(sh, n, xyz, vdw, mass);
-    stage_basic<T>(sh, ws, n, out);
+    stage_basic<T>(sh, ws, n, out, (stages & PW_STAGE_COM_ONLY) != 0);
     if (stages & PW_STAGE_OPT) stage_opt<T>(sh, ws, n, out);
+    if (reuse_opt) {
+        if (T::tid() == 0) {
+            sh.v->opt_c[0] = out->pore_opt_c[0];
+            sh.v->opt_c[1] = out->pore_opt_c[1];
+            sh.v->opt_c[2] = out->pore_opt_c[2];
+            if (out->status & PW_ST_NEGATIVE_PORE) sh.v->status |= PW_ST_NEGATIVE_PORE;
+        }
+        T::sync();
+    }
     if (stages & PW_STAGE_AVG) {
         PW_T0(t_a);
         stage_average<T>(sh, ws, n, out);
@@ -1364,8 +1438,12 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
     if ((stages & PW_STAGE_WINDOWS) && !(sh.v->status & PW_ST_NEGATIVE_PORE))
         stage_windows<T>(sh, ws, n, out);
     if (T::tid() == 0) {
-        out->status = sh.v->status;
-        out->n_eval = sh.v->n_eval;
+        if (merge) {
+            record_or_status(out, sh.v->status, sh.v->n_eval);
+        } else {
+            out->status = sh.v->status;
+            out->n_eval = sh.v->n_eval;
+        }
     }
     T::sync();
 }

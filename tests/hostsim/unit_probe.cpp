@@ -11,19 +11,20 @@ extern "C" int hs_analysis_batch(long n_units, const long* off, const double* xy
                                  const double* mass, unsigned stages, pw_unit_out* out) {
     int nmax = 0;
     for (long u = 0; u < n_units; ++u) { int n = (int)(off[u + 1] - off[u]); if (n > nmax) nmax = n; }
-    size_t bytes = UnitShared::bytes(nmax, 1);
+    size_t bytes = UnitShared::bytes(nmax, 1, 1);
     unsigned char* lds = (unsigned char*)aligned_alloc(16, (bytes + 15) & ~(size_t)15);
     TeamWorkspace* ws = (TeamWorkspace*)malloc(sizeof(TeamWorkspace));
     if (!lds || !ws) return -5;
+    ws->adj = (unsigned long long*)malloc(sizeof(unsigned long long) * PW_ADJ_WORDS);
     for (long u = 0; u < n_units; ++u) {
         memset(lds, 0, bytes);
         UnitShared sh;
-        sh.carve(lds, nmax, 1);
+        sh.carve(lds, nmax, 1, 1);
         int n = (int)(off[u + 1] - off[u]);
         memset(&out[u], 0, sizeof(pw_unit_out));
         analyse_unit<HostTeam>(sh, ws, n, xyz + 3 * off[u], vdw + off[u], mass + off[u], stages, &out[u]);
     }
-    free(lds); free(ws);
+    free(ws->adj); free(lds); free(ws);
     return 0;
 }
 extern "C" int hs_sizeof_unit_out() { return (int)sizeof(pw_unit_out); }
