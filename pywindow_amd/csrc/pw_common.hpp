@@ -21,7 +21,21 @@
 #define PW_D
 #endif
 
+// LDS (address space 3) qualification: pointers that always point into the team's
+// shared memory carry it on the device so that loads/stores become ds_* instead of
+// flat_* instructions; PW_ASSUME_LDS tells the optimiser the same about `this`.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PW_LDS __attribute__((address_space(3)))
+#define PW_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
+#else
+#define PW_LDS
+#define PW_ASSUME_LDS(p) do {} while (0)
+#endif
+
 namespace pw {
+
+typedef PW_LDS double ldouble;
+typedef PW_LDS int lint;
 
 PW_HD inline double pw_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 PW_HD inline double pw_sqrt(double a) { return __builtin_sqrt(a); }

@@ -96,6 +96,7 @@ struct Lbfgsb {
     // ------------------------------------------------------------------
     PW_HD void setup(const double* x0, const double* lo, const double* up, const int* nb,
                      double factr_, double pgtol_, int maxls_) {
+        PW_ASSUME_LDS(this);
         for (int i = 0; i < N; ++i) {
             x[i] = x0[i];
             l[i] = lo[i];
@@ -124,6 +125,7 @@ struct Lbfgsb {
     // ---- team-parallel dense kernels (element-wise identical to pw_blas.hpp) -------------
     template <class T>
     PW_HD int p_dpotrf_u(int n, double* a, int lda) {
+        PW_ASSUME_LDS(this);
         for (int j = 0; j < n; ++j) {
             double* cj = a + (long)j * lda;
             double ajj = cj[j] - b_ddot(j, cj, cj);
@@ -150,6 +152,7 @@ struct Lbfgsb {
     // solve U x = b (no-trans), one right-hand side: level-2 TRSV order
     template <class T>
     PW_HD void p_dtrsv_un(int n, const double* a, int lda, double* x) {
+        PW_ASSUME_LDS(this);
         for (int i = n - 1; i >= 0; --i) {
             const double* ci = a + (long)i * lda;
             double xi = x[i] / ci[i];
@@ -163,6 +166,7 @@ struct Lbfgsb {
     // solve U^T x = b, one right-hand side: DOT order (b_ddot), as a systolic sweep
     template <class T>
     PW_HD void p_dtrsv_ut(int n, const double* a, int lda, double* x) {
+        PW_ASSUME_LDS(this);
         for (int i = T::lane(); i < n; i += T::WSIZE) acc[i] = 0.0;
         T::wave_sync();
         for (int s = 0; s < n; ++s) {
@@ -196,6 +200,7 @@ struct Lbfgsb {
     }
     template <class T>
     PW_HD int p_dtrtrs_u(bool trans, int n, int nrhs, const double* a, int lda, double* b, int ldb) {
+        PW_ASSUME_LDS(this);
         for (int i = 0; i < n; ++i)
             if (a[i + (long)i * lda] == 0.0) return i + 1;
         if (nrhs == 1) {
@@ -210,6 +215,7 @@ struct Lbfgsb {
 
     // ---- projgr: infinity norm of the projected gradient ------------------
     PW_HD void projgr() {
+        PW_ASSUME_LDS(this);
         sbgnrm = 0.0;
         for (int i = 0; i < N; ++i) {
             double gi = g[i];
@@ -226,6 +232,7 @@ struct Lbfgsb {
 
     // ---- active: project x0, classify variables ----------------------------
     PW_HD void active() {
+        PW_ASSUME_LDS(this);
         prjctd = false;
         cnstnd = false;
         boxed = true;
@@ -253,6 +260,7 @@ struct Lbfgsb {
     // ---- bmv: product of the 2m x 2m middle matrix with a vector ----------
     template <class T>
     PW_NOINLINE PW_HD int bmv(const double* v, double* p) {
+        PW_ASSUME_LDS(this);
         if (col == 0) return 0;
         for (int i = T::lane(); i < col; i += T::WSIZE) {
             if (i == 0) {
@@ -329,6 +337,7 @@ struct Lbfgsb {
     // workspace: p = wa[0..2m), c = wa[2m..4m), wbp = wa[4m..6m), v = wa[6m..8m)
     template <class T>
     PW_NOINLINE PW_HD int cauchy() {
+        PW_ASSUME_LDS(this);
         double* p = wa;
         double* c = wa + 2 * M;
         double* wbp = wa + 4 * M;
@@ -514,6 +523,7 @@ struct Lbfgsb {
 
     // ---- freev ---------------------------------------------------------------
     PW_HD bool freev() {
+        PW_ASSUME_LDS(this);
         nenter = 0;
         ileave = N + 1;  // 1-based
         if (iter > 0 && cnstnd) {
@@ -550,6 +560,7 @@ struct Lbfgsb {
     // ---- formk ------------------------------------------------------------------
     template <class T>
     PW_NOINLINE PW_HD int formk() {
+        PW_ASSUME_LDS(this);
         const int nsub = nfree;
         if (updatd) {
             if (iupdat > M) {
@@ -688,6 +699,7 @@ struct Lbfgsb {
     // ---- cmprlb -------------------------------------------------------------------
     template <class T>
     PW_NOINLINE PW_HD int cmprlb() {
+        PW_ASSUME_LDS(this);
         if (!cnstnd && col > 0) {
             for (int i = 0; i < N; ++i) r[i] = -g[i];
         } else {
@@ -715,6 +727,7 @@ struct Lbfgsb {
     // ---- subsm -----------------------------------------------------------------------
     template <class T>
     PW_NOINLINE PW_HD int subsm() {
+        PW_ASSUME_LDS(this);
         const int nsub = nfree;
         double* wv = wa;
         double* dd = r;   // direction / reduced gradient
@@ -903,6 +916,7 @@ struct Lbfgsb {
     // ---- dcsrch ------------------------------------------------------------------------
     PW_HD void dcsrch(double fv, double gv, double& st, double ftol, double gtol, double xtol,
                       double stpmin, double stpmax) {
+        PW_ASSUME_LDS(this);
         const double p5 = 0.5, p66 = 0.66, xtrapl = 1.1, xtrapu = 4.0;
         if (ls_task == 0) {
             if (st < stpmin) ls_task = 4;
@@ -970,6 +984,7 @@ struct Lbfgsb {
     // search finished (task NEW_X) or failed (info != 0)
     template <class T>
     PW_NOINLINE PW_HD bool lnsrlb(bool reentry) {
+        PW_ASSUME_LDS(this);
         const double big = 1.0e10, ftol = 1.0e-3, gtol = 0.9, xtol = 0.1;
         if (!reentry) {
             dnorm = b_dnrm2(N, d);
@@ -1034,6 +1049,7 @@ struct Lbfgsb {
     // ---- matupd ---------------------------------------------------------------------------
     template <class T>
     PW_NOINLINE PW_HD void matupd(double rr, double dr) {
+        PW_ASSUME_LDS(this);
         if (iupdat <= M) {
             col = iupdat;
             itail = (head + iupdat - 1) % M;
@@ -1091,6 +1107,7 @@ struct Lbfgsb {
     // ---- formt -------------------------------------------------------------------------------
     template <class T>
     PW_NOINLINE PW_HD int formt() {
+        PW_ASSUME_LDS(this);
         for (int e = T::lane(); e < col * col; e += T::WSIZE) {
             int i = e / col, j = e % col;
             if (j < i) continue;
@@ -1123,6 +1140,7 @@ struct Lbfgsb {
     //            otherwise          -> finished (task/msg say why)
     template <class T>
     PW_NOINLINE PW_HD void step() {
+        PW_ASSUME_LDS(this);
         int entry;  // 0 fresh, 1 after FG_START, 2 after FG_LNSRCH, 3 after NEW_X
         if (task == LB_START) {
             epsmch = 2.220446049250313e-16;

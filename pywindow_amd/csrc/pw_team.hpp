@@ -24,6 +24,9 @@ struct HostTeam {
     // (value, index) minimum with smallest-index tie-break, broadcast to all lanes
     PW_HD static void wave_argmin(double& v, int& idx) { (void)v; (void)idx; }
     PW_HD static void wave_argmax(double& v, int& idx) { (void)v; (void)idx; }
+    PW_HD static void row_argmin4(double v, int idx, double* outv, int* outi) {
+        for (int r = 0; r < 4; ++r) { outv[r] = v; outi[r] = idx; }
+    }
     PW_HD static unsigned long long ballot(bool p) { return p ? 1ull : 0ull; }
     PW_HD static bool wave_all(bool p) { return p; }
     PW_HD static bool wave_any(bool p) { return p; }
@@ -48,25 +51,62 @@ struct DeviceTeam {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __device__ static void wave_argmin(double& v, int& idx) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            double ov = __shfl_xor(v, off, 64);
-            int oi = __shfl_xor(idx, off, 64);
-            bool take = (ov < v) || (ov == v && oi < idx);
-            v = take ? ov : v;
-            idx = take ? oi : idx;
-        }
+    // ---- DPP reductions -----------------------------------------------------------
+    // Cross-lane moves through the data-parallel-primitive path (no LDS crossbar):
+    // row_shr 1,2,4,8 fold each row of 16 lanes into its lane 15, row_bcast15/31 fold
+    // the four rows into lane 63, v_readlane broadcasts.  Lanes that receive nothing
+    // keep their own value, so op(x, x) = x for min/max.
+    template <int CTRL, int ROW_MASK, int BANK_MASK>
+    __device__ static int dpp_i(int x) {
+        return __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, BANK_MASK, false);
     }
-    __device__ static void wave_argmax(double& v, int& idx) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            double ov = __shfl_xor(v, off, 64);
-            int oi = __shfl_xor(idx, off, 64);
-            bool take = (ov > v) || (ov == v && oi < idx);
-            v = take ? ov : v;
-            idx = take ? oi : idx;
-        }
+    template <int CTRL, int ROW_MASK, int BANK_MASK>
+    __device__ static double dpp_d(double x) {
+        union { double d; int i[2]; } a, b;
+        a.d = x;
+        b.i[0] = dpp_i<CTRL, ROW_MASK, BANK_MASK>(a.i[0]);
+        b.i[1] = dpp_i<CTRL, ROW_MASK, BANK_MASK>(a.i[1]);
+        return b.d;
+    }
+    __device__ static double lane_d(double x, int lane) {
+        union { double d; int i[2]; } a;
+        a.d = x;
+        a.i[0] = __builtin_amdgcn_readlane(a.i[0], lane);
+        a.i[1] = __builtin_amdgcn_readlane(a.i[1], lane);
+        return a.d;
+    }
+    template <bool IS_MIN, int CTRL, int ROW_MASK, int BANK_MASK>
+    __device__ static void arg_step(double& v, int& idx) {
+        double ov = dpp_d<CTRL, ROW_MASK, BANK_MASK>(v);
+        int oi = dpp_i<CTRL, ROW_MASK, BANK_MASK>(idx);
+        bool take = IS_MIN ? ((ov < v) || (ov == v && oi < idx)) : ((ov > v) || (ov == v && oi < idx));
+        v = take ? ov : v;
+        idx = take ? oi : idx;
+    }
+    template <bool IS_MIN>
+    __device__ static void arg_reduce16(double& v, int& idx) {   // result in lane 15 of each row
+        arg_step<IS_MIN, 0x111, 0xf, 0xf>(v, idx);
+        arg_step<IS_MIN, 0x112, 0xf, 0xf>(v, idx);
+        arg_step<IS_MIN, 0x114, 0xf, 0xe>(v, idx);
+        arg_step<IS_MIN, 0x118, 0xf, 0xc>(v, idx);
+    }
+    template <bool IS_MIN>
+    __device__ static void arg_reduce64(double& v, int& idx) {
+        arg_reduce16<IS_MIN>(v, idx);
+        arg_step<IS_MIN, 0x142, 0xa, 0xf>(v, idx);
+        arg_step<IS_MIN, 0x143, 0xc, 0xf>(v, idx);
+        v = lane_d(v, 63);
+        idx = __builtin_amdgcn_readlane(idx, 63);
+    }
+    __device__ static void wave_argmin(double& v, int& idx) { arg_reduce64<true>(v, idx); }
+    __device__ static void wave_argmax(double& v, int& idx) { arg_reduce64<false>(v, idx); }
+    // four independent reductions, one per row of 16 lanes; out[r] = result of row r (all lanes)
+    __device__ static void row_argmin4(double v, int idx, double* outv, int* outi) {
+        arg_reduce16<true>(v, idx);
+        outv[0] = lane_d(v, 15); outi[0] = __builtin_amdgcn_readlane(idx, 15);
+        outv[1] = lane_d(v, 31); outi[1] = __builtin_amdgcn_readlane(idx, 31);
+        outv[2] = lane_d(v, 47); outi[2] = __builtin_amdgcn_readlane(idx, 47);
+        outv[3] = lane_d(v, 63); outi[3] = __builtin_amdgcn_readlane(idx, 63);
     }
     __device__ static unsigned long long ballot(bool p) { return __ballot(p); }
     __device__ static bool wave_all(bool p) { return __all(p); }

@@ -61,10 +61,10 @@ struct ClassInfo {
     double vdw[PW_KCLS];
 };
 struct Frame {
-    double *x, *y, *z, *xx;
-    const double* vdw;
-    const int* perm;
-    const ClassInfo* cls;
+    ldouble *x, *y, *z, *xx;
+    const ldouble* vdw;
+    const lint* perm;
+    const PW_LDS ClassInfo* cls;
 };
 
 // ---- global-memory workspace of one team (sized for PW_P_MAX vectors) ----------
@@ -119,15 +119,15 @@ struct UnitVars {
 
 // LDS layout helper: everything a team needs, carved from one byte buffer.
 struct UnitShared {
-    UnitVars* v;
-    double* vdw;    // stored (grouped) order
-    double* mass;   // caller's order
-    int* perm;
-    int* inv;
+    PW_LDS UnitVars* v;
+    ldouble* vdw;    // stored (grouped) order
+    ldouble* mass;   // caller's order
+    lint* perm;
+    lint* inv;
     Frame A;        // input coordinates
     Frame S;        // shifted coordinates (COM frame, then pore-centre frame)
     Frame R[8];     // per-wave rotated coordinates (window frames)
-    void* lb[8];    // per-wave optimiser state
+    PW_LDS void* lb[8];    // per-wave optimiser state
     size_t rot_words;  // 8-byte words in the rotated-frame region (reused as DBSCAN adjacency)
     // nrot = rotated window frames, nlb = optimiser states (both 0..nwaves)
     PW_HD static size_t bytes(int nmax, int nrot, int nlb) {
@@ -142,14 +142,14 @@ struct UnitShared {
     }
     PW_HD void carve(unsigned char* base, int nmax, int nrot, int nlb) {
         size_t n = (size_t)((nmax + 1) & ~1);
-        unsigned char* p = base;
-        v = (UnitVars*)p;
+        PW_LDS unsigned char* p = (PW_LDS unsigned char*)base;
+        v = (PW_LDS UnitVars*)p;
         p += (sizeof(UnitVars) + 15) & ~(size_t)15;
-        double* d = (double*)p;
+        ldouble* d = (ldouble*)p;
         vdw = d; d += n;
         mass = d; d += n;
-        perm = (int*)d; d += n / 2;
-        inv = (int*)d; d += n / 2;
+        perm = (lint*)d; d += n / 2;
+        inv = (lint*)d; d += n / 2;
         A.x = d; d += n; A.y = d; d += n; A.z = d; d += n; A.xx = d; d += n; A.vdw = vdw; A.perm = perm; A.cls = &v->cls;
         S.x = d; d += n; S.y = d; d += n; S.z = d; d += n; S.xx = d; d += n; S.vdw = vdw; S.perm = perm; S.cls = &v->cls;
         for (int w = 0; w < 8; ++w) { R[w].x = R[w].y = R[w].z = R[w].xx = nullptr; lb[w] = nullptr; }
@@ -158,17 +158,17 @@ struct UnitShared {
             R[w].vdw = vdw; R[w].perm = perm; R[w].cls = &v->cls;
         }
         rot_words = (size_t)nrot * 4 * n;
-        p = (unsigned char*)d;
+        p = (PW_LDS unsigned char*)d;
         for (int w = 0; w < nlb; ++w) {
-            lb[w] = p;
+            lb[w] = (PW_LDS void*)p;
             p += (sizeof(Lbfgsb<3>) + 15) & ~(size_t)15;
         }
     }
 };
 
-PW_HD inline void team_atomic_or(unsigned long long* p, unsigned long long v) {
+PW_HD inline void team_atomic_or(PW_LDS unsigned long long* p, unsigned long long v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    atomicOr(p, v);
+    atomicOr((unsigned long long*)p, v);
 #else
     *p |= v;
 #endif
@@ -202,7 +202,7 @@ PW_HD inline double point_gap(const Frame& F, int n, double px, double py, doubl
 // one thread, all atoms, VALUE only: per radius group the minimum squared distance,
 // then one sqrt per group.  Bit-identical to point_gap's value.
 PW_HD inline double point_gap_value(const Frame& F, int n, double px, double py, double pz) {
-    const ClassInfo& C = *F.cls;
+    const auto& C = *F.cls;
     if (C.k == 0) return point_gap(F, n, px, py, pz, nullptr);
     double pp = sq3(px, py, pz);
     double best = PW_INF;
@@ -233,6 +233,31 @@ PW_HD inline double wave_gap(const Frame& F, int n, double px, double py, double
     T::wave_argmin(best, bi);
     if (arg) *arg = bi;
     return best;
+}
+
+// Four points at once (the f and the three forward-difference points of one gradient
+// request): each row of 16 lanes takes one point and the atoms are spread over the row.
+// Values only; identical to four wave_gap calls.
+template <class T>
+PW_HD inline void wave_gap4(const Frame& F, int n, const double* px, const double* py,
+                            const double* pz, double* out) {
+    if (T::WSIZE == 64) {
+        int g = T::lane() >> 4, l = T::lane() & 15;
+        double qx = g == 0 ? px[0] : (g == 1 ? px[1] : (g == 2 ? px[2] : px[3]));
+        double qy = g == 0 ? py[0] : (g == 1 ? py[1] : (g == 2 ? py[2] : py[3]));
+        double qz = g == 0 ? pz[0] : (g == 1 ? pz[1] : (g == 2 ? pz[2] : pz[3]));
+        double pp = sq3(qx, qy, qz);
+        double best = PW_INF;
+        int bi = 0x7fffffff;
+        for (int i = l; i < n; i += 16) {
+            double v = gap_atom(F, i, qx, qy, qz, pp);
+            if (v < best) { best = v; bi = i; }
+        }
+        int oi[4];
+        T::row_argmin4(best, bi, out, oi);
+    } else {
+        for (int q = 0; q < 4; ++q) out[q] = wave_gap<T>(F, n, px[q], py[q], pz[q], nullptr);
+    }
 }
 
 // numpy's float64 add.reduce over a contiguous 1-D array: pairwise blocks of
@@ -538,12 +563,12 @@ PW_NOINLINE PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx,
 template <class T>
 PW_HD inline void load_unit(UnitShared& sh, int n, const double* xyz, const double* vdw,
                             const double* mass) {
-    UnitVars& v = *sh.v;
+    auto& v = *sh.v;
     if (T::tid() == 0) {
         v.n_eval = 0;
         v.status = 0;
         // group atoms by radius (stable: ascending atom index inside a group)
-        ClassInfo& C = v.cls;
+        auto& C = v.cls;
         int cnt[PW_KCLS];
         int k = 0;
         bool ok = true;
@@ -594,7 +619,7 @@ PW_HD inline void make_shifted(UnitShared& sh, int n, double cx, double cy, doub
     T::sync();
     // centroid: np.sum(coordinates, axis=0) / N -- rows added in the caller's atom order
     auto cen_comp = [&](int c) {
-        const double* a = c == 0 ? sh.S.x : (c == 1 ? sh.S.y : sh.S.z);
+        const ldouble* a = c == 0 ? sh.S.x : (c == 1 ? sh.S.y : sh.S.z);
         double s = a[sh.inv[0]];
         for (int i = 1; i < n; ++i) s = s + a[sh.inv[i]];
         sh.v->centroid[c] = s / (double)n;
@@ -657,12 +682,12 @@ PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n
 template <class T>
 PW_NOINLINE PW_HD inline void stage_basic(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
                                            bool com_only) {
-    UnitVars& v = *sh.v;
+    auto& v = *sh.v;
     (void)ws;
     if (T::tid() == 0) {
         double tot = 0.0;
         for (int s0 = 0; s0 < n; s0 += 8192) {
-            double part = np_sum_small(sh.mass + s0, n - s0 < 8192 ? n - s0 : 8192);
+            double part = np_sum_small((const double*)(sh.mass + s0), n - s0 < 8192 ? n - s0 : 8192);
             tot = s0 == 0 ? part : tot + part;
         }
         v.mw = tot;
@@ -670,7 +695,7 @@ PW_NOINLINE PW_HD inline void stage_basic(UnitShared& sh, TeamWorkspace* ws, int
     T::sync();
     // centre of mass: per component the row-sequential sum of x_i*m_i over the mass
     auto com_comp = [&](int c) {
-        const double* a = c == 0 ? sh.A.x : (c == 1 ? sh.A.y : sh.A.z);
+        const ldouble* a = c == 0 ? sh.A.x : (c == 1 ? sh.A.y : sh.A.z);
         double s = a[sh.inv[0]] * sh.mass[0];
         for (int i = 1; i < n; ++i) s = s + a[sh.inv[i]] * sh.mass[i];
         v.com[c] = s / v.mw;
@@ -721,9 +746,10 @@ PW_HD inline double fd_step(double x, double lb, double ub) {
 template <class T>
 PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out) {
     (void)ws;
-    UnitVars& v = *sh.v;
+    auto& v = *sh.v;
     if (T::wave() == 0) {
         Lbfgsb<3>* S = (Lbfgsb<3>*)sh.lb[0];
+        PW_ASSUME_LDS(S);
         double r = v.pore_g;  // pore_diameter / 2
         double lo[3], up[3], x0[3];
         int nbd[3] = {2, 2, 2};
@@ -752,15 +778,21 @@ PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n
                     // evaluated last (_differentiable_functions.py: fun_and_grad)
                     PW_T0(t_e);
                     if (!(have_last && px == lx && py == ly && pz == lz)) {
-                        double f0 = -(wave_gap<T>(sh.A, n, px, py, pz, nullptr) * 2.0);
+                        double qx[4] = {px, px, px, px}, qy[4] = {py, py, py, py}, qz[4] = {pz, pz, pz, pz};
+                        double dxs[3];
                         for (int c = 0; c < 3; ++c) {
                             double xc = c == 0 ? px : (c == 1 ? py : pz);
                             double h = fd_step(xc, lo[c], up[c]);
                             double x1 = xc + h;
-                            double dx = x1 - xc;
-                            double f1 = -(wave_gap<T>(sh.A, n, c == 0 ? x1 : px, c == 1 ? x1 : py,
-                                                      c == 2 ? x1 : pz, nullptr) * 2.0);
-                            lg[c] = (f1 - f0) / dx;
+                            dxs[c] = x1 - xc;
+                            if (c == 0) qx[1] = x1; else if (c == 1) qy[2] = x1; else qz[3] = x1;
+                        }
+                        double gv[4];
+                        wave_gap4<T>(sh.A, n, qx, qy, qz, gv);
+                        double f0 = -(gv[0] * 2.0);
+                        for (int c = 0; c < 3; ++c) {
+                            double f1 = -(gv[c + 1] * 2.0);
+                            lg[c] = (f1 - f0) / dxs[c];
                         }
                         lf = f0;
                         lx = px; ly = py; lz = pz;
@@ -808,7 +840,7 @@ PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n
 // ---- stage: average diameter ---------------------------------------------------------------
 template <class T>
 PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out) {
-    UnitVars& v = *sh.v;
+    auto& v = *sh.v;
     make_shifted<T>(sh, n, v.com[0], v.com[1], v.com[2]);
     // preserve the input-frame max_dim: the shifted frame's replaces it only here
     double keep_d = v.maxd;
@@ -950,7 +982,7 @@ PW_NOINLINE PW_HD inline void wave_fmin_xy(const Frame& F, int n, double z, doub
 template <class T>
 PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int n, int cluster,
                               const Sphere& sp) {
-    UnitVars& v = *sh.v;
+    auto& v = *sh.v;
     const int w = T::wave();
     Frame& R = sh.R[w];
     int evals = 0;
@@ -1036,6 +1068,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     PW_T1(ws, 3, t_r);
     // (v) neck position along z: L-BFGS-B, n = 1, bounds [-new_z, +inf)
     Lbfgsb<1>* S = (Lbfgsb<1>*)sh.lb[w];
+    PW_ASSUME_LDS(S);
     double lo1[1] = {-new_z}, up1[1] = {0.0}, x01[1] = {0.0};
     int nbd1[1] = {1};
     if (x01[0] < lo1[0]) x01[0] = lo1[0];   // np.clip(x0, lb, ub)
@@ -1052,11 +1085,13 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
             PW_T0(t_ze);
             double zc = S->x[0];
             if (!(have_last && zc == lz)) {
-                double f0 = wave_gap<T>(R, n, 0.0, 0.0, zc, nullptr) * 2.0;
                 double h = fd_step(zc, lo1[0], PW_INF);
                 double z1 = zc + h;
                 double dz = z1 - zc;
-                double f1 = wave_gap<T>(R, n, 0.0, 0.0, z1, nullptr) * 2.0;
+                double zx[4] = {0.0, 0.0, 0.0, 0.0}, zz[4] = {zc, z1, zc, z1}, gv[4];
+                wave_gap4<T>(R, n, zx, zx, zz, gv);
+                double f0 = gv[0] * 2.0;
+                double f1 = gv[1] * 2.0;
                 evals += 2;
                 lf = f0;
                 lg = (f1 - f0) / dz;
@@ -1125,7 +1160,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
 // ---- stage: windows ----------------------------------------------------------------------------
 template <class T>
 PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out) {
-    UnitVars& v = *sh.v;
+    auto& v = *sh.v;
     // shift so that the optimised pore centre is the origin (utilities.py:1388-1390)
     if (T::tid() == 0) {
         for (int c = 0; c < 3; ++c) {
@@ -1259,15 +1294,15 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     {
         const int words = (ns + 63) / 64;
         double e2 = v.eps * v.eps;
-        unsigned long long* core = v.bits[0];
-        unsigned long long* unl = v.bits[1];
-        unsigned long long* frontier = v.bits[2];
-        unsigned long long* next = v.bits[3];
+        PW_LDS unsigned long long* core = v.bits[0];
+        PW_LDS unsigned long long* unl = v.bits[1];
+        PW_LDS unsigned long long* frontier = v.bits[2];
+        PW_LDS unsigned long long* next = v.bits[3];
         // adjacency rows live in LDS (the window frames are idle now) when they fit
         size_t cap_words = sh.rot_words;
         unsigned long long* adj;
         int stride;
-        if ((size_t)ns * (size_t)words <= cap_words) { adj = (unsigned long long*)sh.R[0].x; stride = words; }
+        if ((size_t)ns * (size_t)words <= cap_words) { adj = (unsigned long long*)(double*)sh.R[0].x; stride = words; }
         else { adj = ws->adj; stride = PW_P_MAX / 64; }
         if (adj == nullptr) {   // launch without a global adjacency buffer and LDS too small
             if (T::tid() == 0) v.status |= PW_ST_POINTS_OVERFLOW;
