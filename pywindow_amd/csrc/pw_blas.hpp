@@ -25,7 +25,7 @@ namespace pw {
 // ddot, unit stride, n < 32.  kernel/x86_64/ddot.c: the first n & -16 elements
 // go through the AVX kernel (4 accumulators x 4 lanes, FMA), the tail is a
 // sequential FMA chain onto the partial result.
-PW_NOINLINE PW_HD inline double b_ddot(int n, const double* x, const double* y) {
+PW_HD inline double b_ddot(int n, const double* x, const double* y) {
     double dot = 0.0;
     int i = 0;
     if (n >= 16) {
@@ -67,7 +67,7 @@ PW_HD inline void b_dcopy(int n, const double* x, double* y) {
 // rows in a scalar tail.  Only m <= 11 is supported (m & -4 in {0,4,8}).
 // One output element of that product: returns the NEW y_k given the old one.
 // `k` is the column's position among the n columns (it selects the micro-kernel).
-PW_NOINLINE PW_HD inline double b_dgemv_t_elem(int m, int n, int k, const double* a, const double* x, double yk) {
+PW_HD inline double b_dgemv_t_elem(int m, int n, int k, const double* a, const double* x, double yk) {
     const int m1 = m & -4, m3 = m & 3;
     const int n4 = (n >> 2) << 2;
     if (m1) {
@@ -174,7 +174,7 @@ PW_HD inline void b_dtrsv_ut(int n, const double* a, int lda, double* x) {
 // solved (FMA chain from zero, then one subtraction) followed by a
 // right-looking solve that multiplies by the pre-inverted diagonal.  n <= 15
 // here (no full 16-row block), which covers col <= m = 10.
-PW_NOINLINE PW_HD inline void b_dtrsm_ut_col(int n, const double* a, int lda, double* x) {
+PW_HD inline void b_dtrsm_ut_col(int n, const double* a, int lda, double* x) {
     int s = 0;
     for (int bs = 8; bs > 0; bs >>= 1) {
         if (!(n & bs)) continue;

@@ -259,7 +259,7 @@ struct Lbfgsb {
 
     // ---- bmv: product of the 2m x 2m middle matrix with a vector ----------
     template <class T>
-    PW_NOINLINE PW_HD int bmv(const double* v, double* p) {
+    PW_HD int bmv(const double* v, double* p) {
         PW_ASSUME_LDS(this);
         if (col == 0) return 0;
         for (int i = T::lane(); i < col; i += T::WSIZE) {
@@ -336,7 +336,7 @@ struct Lbfgsb {
     // ---- cauchy: generalized Cauchy point ----------------------------------
     // workspace: p = wa[0..2m), c = wa[2m..4m), wbp = wa[4m..6m), v = wa[6m..8m)
     template <class T>
-    PW_NOINLINE PW_HD int cauchy() {
+    PW_HD int cauchy() {
         PW_ASSUME_LDS(this);
         double* p = wa;
         double* c = wa + 2 * M;
@@ -559,7 +559,7 @@ struct Lbfgsb {
 
     // ---- formk ------------------------------------------------------------------
     template <class T>
-    PW_NOINLINE PW_HD int formk() {
+    PW_HD int formk() {
         PW_ASSUME_LDS(this);
         const int nsub = nfree;
         if (updatd) {
@@ -698,7 +698,7 @@ struct Lbfgsb {
 
     // ---- cmprlb -------------------------------------------------------------------
     template <class T>
-    PW_NOINLINE PW_HD int cmprlb() {
+    PW_HD int cmprlb() {
         PW_ASSUME_LDS(this);
         if (!cnstnd && col > 0) {
             for (int i = 0; i < N; ++i) r[i] = -g[i];
@@ -726,7 +726,7 @@ struct Lbfgsb {
 
     // ---- subsm -----------------------------------------------------------------------
     template <class T>
-    PW_NOINLINE PW_HD int subsm() {
+    PW_HD int subsm() {
         PW_ASSUME_LDS(this);
         const int nsub = nfree;
         double* wv = wa;
@@ -983,7 +983,7 @@ struct Lbfgsb {
     // returns true if a new (f,g) evaluation is requested, false when the line
     // search finished (task NEW_X) or failed (info != 0)
     template <class T>
-    PW_NOINLINE PW_HD bool lnsrlb(bool reentry) {
+    PW_HD bool lnsrlb(bool reentry) {
         PW_ASSUME_LDS(this);
         const double big = 1.0e10, ftol = 1.0e-3, gtol = 0.9, xtol = 0.1;
         if (!reentry) {
@@ -1048,7 +1048,7 @@ struct Lbfgsb {
 
     // ---- matupd ---------------------------------------------------------------------------
     template <class T>
-    PW_NOINLINE PW_HD void matupd(double rr, double dr) {
+    PW_HD void matupd(double rr, double dr) {
         PW_ASSUME_LDS(this);
         if (iupdat <= M) {
             col = iupdat;
@@ -1106,7 +1106,7 @@ struct Lbfgsb {
 
     // ---- formt -------------------------------------------------------------------------------
     template <class T>
-    PW_NOINLINE PW_HD int formt() {
+    PW_HD int formt() {
         PW_ASSUME_LDS(this);
         for (int e = T::lane(); e < col * col; e += T::WSIZE) {
             int i = e / col, j = e % col;
@@ -1139,7 +1139,7 @@ struct Lbfgsb {
     //            task == LB_NEW_X   -> an iteration finished, call again to continue
     //            otherwise          -> finished (task/msg say why)
     template <class T>
-    PW_NOINLINE PW_HD void step() {
+    PW_HD void step() {
         PW_ASSUME_LDS(this);
         int entry;  // 0 fresh, 1 after FG_START, 2 after FG_LNSRCH, 3 after NEW_X
         if (task == LB_START) {
