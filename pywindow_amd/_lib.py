@@ -121,6 +121,10 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback."
         )
+    # the pipeline runs several kernels side by side: give the runtime enough hardware queues
+    import os
+
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     try:
         L = ctypes.CDLL(str(LIB_PATH))
     except OSError as exc:  # pragma: no cover - depends on the machine

@@ -1205,15 +1205,24 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         // full scan is done when the window cannot be proven sufficient
         double zstep = pw_abs(sp.step) * radius;
         int W = (int)(4.0 * pw_sqrt((double)P)) + 8;
+        // stage the points in LDS (window frames are idle) when they fit
+        ldouble* lp = ((size_t)P * 3 <= sh.rot_words) ? sh.R[0].x : (ldouble*)nullptr;
+        if (lp) {
+            for (int e = T::tid(); e < 3 * P; e += T::SIZE) lp[e] = ws->pts[e];
+            T::sync();
+        }
         for (int k = T::tid(); k < P; k += T::SIZE) {
             double px = ws->pts[3 * k], py = ws->pts[3 * k + 1], pz = ws->pts[3 * k + 2];
             double t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
             int lo = k - W < 0 ? 0 : k - W, hi = k + W > P - 1 ? P - 1 : k + W;
             for (int pass = 0; pass < 2; ++pass) {
                 t0 = t1 = t2 = t3 = t4 = t5 = t6 = t7 = t8 = t9 = PW_INF;
+#pragma unroll 4
                 for (int j = lo; j <= hi; ++j) {
-                    double ax = px - ws->pts[3 * j], ay = py - ws->pts[3 * j + 1],
-                           az = pz - ws->pts[3 * j + 2];
+                    double qx, qy, qz;
+                    if (lp) { qx = lp[3 * j]; qy = lp[3 * j + 1]; qz = lp[3 * j + 2]; }
+                    else { qx = ws->pts[3 * j]; qy = ws->pts[3 * j + 1]; qz = ws->pts[3 * j + 2]; }
+                    double ax = px - qx, ay = py - qy, az = pz - qz;
                     double d = 0.0;
                     d = d + ax * ax; d = d + ay * ay; d = d + az * az;
                     if (d < t9) {
@@ -1242,23 +1251,16 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     }
     if (T::wave() == 0) PW_T1(ws, 8, t_eps);
     PW_T0(t_smp);
-    // ---- sampling vectors: ray test + coarse path scan, one vector per thread ----
+    // ---- sampling vectors (utilities.py:1457-1467): ray pre-analysis for every vector,
+    //      then the coarse path scan for the vectors that hit nothing.  Two dense phases
+    //      with an order-preserving compaction in between, so no lane idles while its
+    //      neighbours walk a path.
     {
         double cen[3] = {v.centroid[0], v.centroid[1], v.centroid[2]};
-        int evals = 0;
         for (int k = T::tid(); k < P; k += T::SIZE) {
-            double px = ws->pts[3 * k], py = ws->pts[3 * k + 1], pz = ws->pts[3 * k + 2], far;
-            bool hit = ray_scan(sh.S, n, cen, px, py, pz, &far);
-            unsigned char okf = 0;
-            if (!hit) {
-                double g2, chunk[3];
-                int pos;
-                if (path_scan_thread(sh.S, n, px, py, pz, 1.0, &g2, &pos, chunk, &evals)) {
-                    okf = 1;
-                    ws->knn[k] = g2;
-                }
-            }
-            ws->flag[k] = okf;
+            double far;
+            bool hit = ray_scan(sh.S, n, cen, ws->pts[3 * k], ws->pts[3 * k + 1], ws->pts[3 * k + 2], &far);
+            ws->flag[k] = hit ? 0 : 1;
         }
         T::sync();
         if (T::wave() == 0) {
@@ -1268,7 +1270,32 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                 bool f = k < P && ws->flag[k] != 0;
                 unsigned long long bal = T::ballot(f);
                 int pos = m + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
-                if (f) { ws->surv_k[pos] = k; ws->vals[pos] = ws->knn[k]; }
+                if (f) ws->labels[pos] = k;          // labels[] is free until DBSCAN
+                m += __builtin_popcountll(bal);
+            }
+            if (T::lane() == 0) v.n_surv = m;
+        }
+        T::sync();
+        int ncand = v.n_surv;
+        int evals = 0;
+        for (int j = T::tid(); j < ncand; j += T::SIZE) {
+            int k = ws->labels[j];
+            double g2, chunk[3];
+            int pos;
+            bool ok = path_scan_thread(sh.S, n, ws->pts[3 * k], ws->pts[3 * k + 1], ws->pts[3 * k + 2], 1.0,
+                                       &g2, &pos, chunk, &evals);
+            ws->flag[j] = ok ? 1 : 0;
+            ws->knn[j] = g2;
+        }
+        T::sync();
+        if (T::wave() == 0) {
+            int m = 0;
+            for (int base = 0; base < ncand; base += T::WSIZE) {
+                int j = base + T::lane();
+                bool f = j < ncand && ws->flag[j] != 0;
+                unsigned long long bal = T::ballot(f);
+                int pos = m + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
+                if (f) { ws->surv_k[pos] = ws->labels[j]; ws->vals[pos] = ws->knn[j]; }
                 m += __builtin_popcountll(bal);
             }
             if (T::lane() == 0) { v.n_surv = m; out->n_survivors = m; }
