@@ -107,7 +107,8 @@ PW_NOINLINE PW_HD inline void sincos_dd(double x, DD* s_out, DD* c_out) {
     // sin r = r * (1 - r^2/3! + r^4/5! - ...), cos r = 1 - r^2/2! + r^4/4! - ...
     DD ps = inv_fact(27);
     DD pc = inv_fact(26);
-    for (int n = 25; n >= 3; n -= 2) {
+#pragma unroll
+    for (int n = 25; n >= 3; n -= 2) {   // fully unrolled: the coefficients become immediates
         ps = dd_add(inv_fact(n), dd_neg(dd_mul(ps, r2)));
         pc = dd_add(inv_fact(n - 1), dd_neg(dd_mul(pc, r2)));
     }

@@ -99,6 +99,7 @@ struct UnitVars {
     int opt_atom;
     double shift[3];
     ClassInfo cls;
+    int cls_cnt[PW_KCLS];
     double eps;
     double radius;
     int P;
@@ -111,6 +112,8 @@ struct UnitVars {
     int red_i[16];
     // DBSCAN bitsets: core / unlabelled / frontier / next (PW_P_MAX bits each)
     unsigned long long bits[4][PW_P_MAX / 64];
+    // sampling vector chosen for each cluster (largest 2*gap, first occurrence)
+    double win_vec[PW_W_MAX][3];
     // window results by cluster
     int win_ok[PW_W_MAX];
     double win_d[PW_W_MAX];
@@ -128,7 +131,11 @@ struct UnitShared {
     Frame S;        // shifted coordinates (COM frame, then pore-centre frame)
     Frame R[8];     // per-wave rotated coordinates (window frames)
     PW_LDS void* lb[8];    // per-wave optimiser state
-    size_t rot_words;  // 8-byte words in the rotated-frame region (reused as DBSCAN adjacency)
+    size_t rot_words;  // 8-byte words in the rotated-frame region
+    // everything behind the shifted frame (window frames + optimiser states) is idle until the
+    // windows are fitted and serves as scratch for the sampling stages
+    PW_LDS unsigned char* scratch;
+    size_t scratch_bytes;
     // nrot = rotated window frames, nlb = optimiser states (both 0..nwaves)
     PW_HD static size_t bytes(int nmax, int nrot, int nlb) {
         size_t n = (size_t)((nmax + 1) & ~1);
@@ -153,6 +160,7 @@ struct UnitShared {
         A.x = d; d += n; A.y = d; d += n; A.z = d; d += n; A.xx = d; d += n; A.vdw = vdw; A.perm = perm; A.cls = &v->cls;
         S.x = d; d += n; S.y = d; d += n; S.z = d; d += n; S.xx = d; d += n; S.vdw = vdw; S.perm = perm; S.cls = &v->cls;
         for (int w = 0; w < 8; ++w) { R[w].x = R[w].y = R[w].z = R[w].xx = nullptr; lb[w] = nullptr; }
+        scratch = (PW_LDS unsigned char*)d;
         for (int w = 0; w < nrot; ++w) {
             R[w].x = d; d += n; R[w].y = d; d += n; R[w].z = d; d += n; R[w].xx = d; d += n;
             R[w].vdw = vdw; R[w].perm = perm; R[w].cls = &v->cls;
@@ -163,6 +171,23 @@ struct UnitShared {
             lb[w] = (PW_LDS void*)p;
             p += (sizeof(Lbfgsb<3>) + 15) & ~(size_t)15;
         }
+        scratch_bytes = (size_t)(p - scratch);
+    }
+};
+
+// bump allocator over the idle LDS region; returns generic pointers (LDS aperture) and
+// nullptr when the request does not fit (callers then use the global workspace)
+struct ScratchArena {
+    unsigned char* cur;
+    size_t left;
+    PW_HD void init(const UnitShared& sh) { cur = (unsigned char*)sh.scratch; left = sh.scratch_bytes; }
+    PW_HD void* take(size_t bytes) {
+        bytes = (bytes + 15) & ~(size_t)15;
+        if (bytes > left) return nullptr;
+        void* r = cur;
+        cur += bytes;
+        left -= bytes;
+        return r;
     }
 };
 
@@ -249,6 +274,7 @@ PW_HD inline void wave_gap4(const Frame& F, int n, const double* px, const doubl
         double pp = sq3(qx, qy, qz);
         double best = PW_INF;
         int bi = 0x7fffffff;
+#pragma unroll 4
         for (int i = l; i < n; i += 16) {
             double v = gap_atom(F, i, qx, qy, qz, pp);
             if (v < best) { best = v; bi = i; }
@@ -378,25 +404,52 @@ PW_HD inline double np_sum_serial(const double* a, int n) {
     }
     return total;
 }
-// team version.  The eight strided accumulators of every leaf are independent
-// sequential chains, so (leaf, accumulator) pairs are spread over the threads;
-// one thread per leaf then folds them exactly as numpy does, and thread 0
-// combines the leaves in recursion order.  `tab` needs 2*160 ints, `acc8` 8*160
-// doubles, `leafbuf` 160 doubles (team-shared memory).
+// team version.  Leaves are at least 64 elements long (for n > 128), so every 64-element
+// slot holds at most one leaf start; a thread finds it by walking down the recursion
+// (no tables, no private stacks -- those would live in scratch memory on the GPU).  The
+// eight strided accumulators of a leaf are independent sequential chains, so (leaf,
+// accumulator) pairs are spread over the threads; one thread per leaf folds them exactly
+// as numpy does and thread 0 combines the leaves in recursion order with its stack in
+// team-shared memory.  Scratch: tab 2*128+80 ints, acc8 8*128 doubles, leafbuf 128+32 doubles.
+PW_HD inline void np_descend(int len, int e, int* off_out, int* len_out) {
+    int off = 0, l = len;
+    while (l > 128) {
+        int n2 = l / 2;
+        n2 -= n2 % 8;
+        if (e < off + n2) { l = n2; } else { off += n2; l -= n2; }
+    }
+    *off_out = off;
+    *len_out = l;
+}
 template <class T>
 PW_HD inline double np_sum_team(const double* a, int n, int* tab, double* acc8, double* leafbuf,
                                 double* slot) {
     double total = 0.0;
     bool first = true;
     for (int s = 0; s < n; s += 8192) {
-        int len = n - s < 8192 ? n - s : 8192;
-        if (T::tid() == 0) tab[320] = np_leaves(0, len, tab, tab + 160);
+        const int len = n - s < 8192 ? n - s : 8192;
+        const int nslot = (len + 63) / 64;
+        int* t_off = tab;
+        int* t_len = tab + 128;
+        for (int sl = T::tid(); sl < nslot; sl += T::SIZE) {
+            int e = sl * 64, off, l, start = -1, ln = 0;
+            np_descend(len, e, &off, &l);
+            if (off == e) { start = off; ln = l; }
+            else {
+                int nxt = off + l;
+                int lim = e + 64 < len ? e + 64 : len;
+                if (nxt < lim) { np_descend(len, nxt, &off, &l); start = off; ln = l; }
+            }
+            t_off[sl] = start;
+            t_len[sl] = ln;
+        }
         T::sync();
-        int nl = tab[320];
-        for (int task = T::tid(); task < nl * 8; task += T::SIZE) {
-            int lf = task >> 3, c = task & 7;
-            const double* b = a + s + tab[lf];
-            int ln = tab[160 + lf];
+        for (int task = T::tid(); task < nslot * 8; task += T::SIZE) {
+            int sl = task >> 3, c = task & 7;
+            int start = t_off[sl];
+            if (start < 0) continue;
+            const double* b = a + s + start;
+            int ln = t_len[sl];
             if (ln < 8) {
                 if (c == 0) {
                     double r = 0.0;
@@ -411,10 +464,12 @@ PW_HD inline double np_sum_team(const double* a, int n, int* tab, double* acc8, 
             }
         }
         T::sync();
-        for (int lf = T::tid(); lf < nl; lf += T::SIZE) {
-            const double* b = a + s + tab[lf];
-            int ln = tab[160 + lf];
-            const double* r = acc8 + 8 * lf;
+        for (int sl = T::tid(); sl < nslot; sl += T::SIZE) {
+            int start = t_off[sl];
+            if (start < 0) continue;
+            const double* b = a + s + start;
+            int ln = t_len[sl];
+            const double* r = acc8 + 8 * sl;
             double res;
             if (ln < 8) {
                 res = r[0];
@@ -422,11 +477,41 @@ PW_HD inline double np_sum_team(const double* a, int n, int* tab, double* acc8, 
                 res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
                 for (int i = ln - (ln % 8); i < ln; ++i) res = res + b[i];
             }
-            leafbuf[lf] = res;
+            leafbuf[sl] = res;
         }
         T::sync();
         if (T::tid() == 0) {
-            double part = np_combine(len, leafbuf);
+            // depth-first combine; node stack (off, len, stage) and value stack in shared memory
+            int* st = tab + 256;          // 3 ints per entry, depth <= 8
+            double* vals = leafbuf + 128;
+            int top = 0, vtop = 0;
+            st[0] = 0; st[1] = len; st[2] = 0; top = 1;
+            while (top) {
+                int* c = st + 3 * (top - 1);
+                int coff = c[0], clen = c[1], cst = c[2];
+                if (clen <= 128) {
+                    vals[vtop++] = leafbuf[coff >> 6];
+                    --top;
+                } else {
+                    int n2 = clen / 2;
+                    n2 -= n2 % 8;
+                    if (cst == 0) {
+                        c[2] = 1;
+                        int* d = st + 3 * top;
+                        d[0] = coff; d[1] = n2; d[2] = 0; ++top;
+                    } else if (cst == 1) {
+                        c[2] = 2;
+                        int* d = st + 3 * top;
+                        d[0] = coff + n2; d[1] = clen - n2; d[2] = 0; ++top;
+                    } else {
+                        double r = vals[--vtop];
+                        double l = vals[--vtop];
+                        vals[vtop++] = l + r;
+                        --top;
+                    }
+                }
+            }
+            double part = vals[0];
             total = first ? part : total + part;
         }
         first = false;
@@ -569,7 +654,7 @@ PW_HD inline void load_unit(UnitShared& sh, int n, const double* xyz, const doub
         v.status = 0;
         // group atoms by radius (stable: ascending atom index inside a group)
         auto& C = v.cls;
-        int cnt[PW_KCLS];
+        PW_LDS int* cnt = v.cls_cnt;   // (private arrays with run-time indices live in scratch memory)
         int k = 0;
         bool ok = true;
         for (int i = 0; i < n && ok; ++i) {
@@ -858,13 +943,25 @@ PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, i
     }
     Sphere sp;
     sp.init(radius, P);
+    ScratchArena arena;
+    arena.init(sh);
+    double* vals = (double*)arena.take((size_t)P * 8);
+    if (!vals) vals = ws->vals;
+    double* packed = (double*)arena.take((size_t)P * 8);
+    if (!packed) packed = ws->knn;
+    unsigned char* flag = (unsigned char*)arena.take((size_t)P);
+    if (!flag) flag = ws->flag;
+    int* s_tab = (int*)arena.take(324 * 4);
+    double* s_acc = (double*)arena.take(8 * 160 * 8);
+    double* s_leaf = (double*)arena.take(256 * 8);
+    if (!s_tab || !s_acc || !s_leaf) { s_tab = ws->leaf_tab; s_acc = ws->acc8; s_leaf = ws->leaf; }
     double cen[3] = {v.centroid[0], v.centroid[1], v.centroid[2]};
     for (int k = T::tid(); k < P; k += T::SIZE) {
         double px, py, pz, far;
         sp.point(k, &px, &py, &pz);
         bool hit = ray_scan(sh.S, n, cen, px, py, pz, &far);
-        ws->vals[k] = far;
-        ws->flag[k] = hit ? 1 : 0;
+        vals[k] = far;
+        flag[k] = hit ? 1 : 0;
     }
     T::sync();
     // compact in ray order (thread 0), then the numpy mean
@@ -873,17 +970,17 @@ PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, i
         int m = 0;
         for (int base = 0; base < P; base += T::WSIZE) {
             int k = base + T::lane();
-            bool f = k < P && ws->flag[k] != 0;
+            bool f = k < P && flag[k] != 0;
             unsigned long long bal = T::ballot(f);
             int pos = m + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
-            if (f) ws->knn[pos] = ws->vals[k];
+            if (f) packed[pos] = vals[k];
             m += __builtin_popcountll(bal);
         }
         if (T::lane() == 0) v.n_surv = m;
     }
     T::sync();
     int m = v.n_surv;
-    double sum = np_sum_team<T>(ws->knn, m, ws->leaf_tab, ws->acc8, ws->leaf, &v.red_v[15]);
+    double sum = np_sum_team<T>(packed, m, s_tab, s_acc, s_leaf, &v.red_v[15]);
     if (T::tid() == 0) {
         out->avg_d = (sum / (double)m) * 2.0;
         out->n_points_avg = P;
@@ -897,37 +994,37 @@ PW_NOINLINE PW_HD inline void wave_fmin_xy(const Frame& F, int n, double z, doub
                                double* yo, int* n_eval) {
     const int maxfun = 400, maxiter = 400;
     const double xatol = 1e-4, fatol = 1e-4;
-    double sx[3], sy[3], fs[3];
+    // the simplex lives in named scalars: private arrays indexed at run time would be
+    // placed in scratch (global) memory on the GPU
+    double x0s, y0s, f0s, x1s, y1s, f1s, x2s, y2s, f2s;
     int fcalls = 0;
     auto fun = [&](double x, double y) {
         fcalls += 1;
         return -(wave_gap<T>(F, n, x, y, z, nullptr) * 2.0);
     };
-    sx[0] = x0; sy[0] = y0;
-    sx[1] = (x0 != 0.0) ? (1.0 + 0.05) * x0 : 0.00025; sy[1] = y0;
-    sx[2] = x0; sy[2] = (y0 != 0.0) ? (1.0 + 0.05) * y0 : 0.00025;
-    for (int k = 0; k < 3; ++k) fs[k] = fun(sx[k], sy[k]);
-    auto sort3 = [&]() {  // stable insertion sort by fs
-        for (int i = 1; i < 3; ++i) {
-            double f = fs[i], a = sx[i], b = sy[i];
-            int j = i - 1;
-            while (j >= 0 && fs[j] > f) {
-                fs[j + 1] = fs[j]; sx[j + 1] = sx[j]; sy[j + 1] = sy[j];
-                --j;
-            }
-            fs[j + 1] = f; sx[j + 1] = a; sy[j + 1] = b;
-        }
+    x0s = x0; y0s = y0;
+    x1s = (x0 != 0.0) ? (1.0 + 0.05) * x0 : 0.00025; y1s = y0;
+    x2s = x0; y2s = (y0 != 0.0) ? (1.0 + 0.05) * y0 : 0.00025;
+    f0s = fun(x0s, y0s);
+    f1s = fun(x1s, y1s);
+    f2s = fun(x2s, y2s);
+    // stable insertion sort of three (numpy argsort on 3 elements)
+    auto swap01 = [&]() { double t; t = f0s; f0s = f1s; f1s = t; t = x0s; x0s = x1s; x1s = t; t = y0s; y0s = y1s; y1s = t; };
+    auto swap12 = [&]() { double t; t = f1s; f1s = f2s; f2s = t; t = x1s; x1s = x2s; x2s = t; t = y1s; y1s = y2s; y2s = t; };
+    auto sort3 = [&]() {
+        if (f0s > f1s) swap01();
+        if (f1s > f2s) { swap12(); if (f0s > f1s) swap01(); }
     };
     sort3();
     int iterations = 1;
     while (fcalls < maxfun && iterations < maxiter) {
-        double dx1 = pw_abs(sx[1] - sx[0]), dx2 = pw_abs(sx[2] - sx[0]);
-        double dy1 = pw_abs(sy[1] - sy[0]), dy2 = pw_abs(sy[2] - sy[0]);
+        double dx1 = pw_abs(x1s - x0s), dx2 = pw_abs(x2s - x0s);
+        double dy1 = pw_abs(y1s - y0s), dy2 = pw_abs(y2s - y0s);
         double mx = pw_max(pw_max(dx1, dy1), pw_max(dx2, dy2));
-        double mf = pw_max(pw_abs(fs[0] - fs[1]), pw_abs(fs[0] - fs[2]));
+        double mf = pw_max(pw_abs(f0s - f1s), pw_abs(f0s - f2s));
         if (mx <= xatol && mf <= fatol) break;
-        double bx = (sx[0] + sx[1]) / 2.0, by = (sy[0] + sy[1]) / 2.0;
-        double xr = 2.0 * bx - sx[2], yr = 2.0 * by - sy[2];
+        double bx = (x0s + x1s) / 2.0, by = (y0s + y1s) / 2.0;
+        double xr = 2.0 * bx - x2s, yr = 2.0 * by - y2s;
         bool over = false;  // _MaxFuncCallError
         auto guarded = [&](double x, double y, double* f) {
             if (fcalls >= maxfun) { over = true; return false; }
@@ -937,44 +1034,47 @@ PW_NOINLINE PW_HD inline void wave_fmin_xy(const Frame& F, int n, double z, doub
         double fxr;
         if (guarded(xr, yr, &fxr)) {
             bool doshrink = false;
-            if (fxr < fs[0]) {
-                double xe = 3.0 * bx - 2.0 * sx[2], ye = 3.0 * by - 2.0 * sy[2];
+            if (fxr < f0s) {
+                double xe = 3.0 * bx - 2.0 * x2s, ye = 3.0 * by - 2.0 * y2s;
                 double fxe;
                 if (guarded(xe, ye, &fxe)) {
-                    if (fxe < fxr) { sx[2] = xe; sy[2] = ye; fs[2] = fxe; }
-                    else { sx[2] = xr; sy[2] = yr; fs[2] = fxr; }
+                    if (fxe < fxr) { x2s = xe; y2s = ye; f2s = fxe; }
+                    else { x2s = xr; y2s = yr; f2s = fxr; }
                 }
-            } else if (fxr < fs[1]) {
-                sx[2] = xr; sy[2] = yr; fs[2] = fxr;
-            } else if (fxr < fs[2]) {
-                double xc = 1.5 * bx - 0.5 * sx[2], yc = 1.5 * by - 0.5 * sy[2];
+            } else if (fxr < f1s) {
+                x2s = xr; y2s = yr; f2s = fxr;
+            } else if (fxr < f2s) {
+                double xc = 1.5 * bx - 0.5 * x2s, yc = 1.5 * by - 0.5 * y2s;
                 double fxc;
                 if (guarded(xc, yc, &fxc)) {
-                    if (fxc <= fxr) { sx[2] = xc; sy[2] = yc; fs[2] = fxc; }
+                    if (fxc <= fxr) { x2s = xc; y2s = yc; f2s = fxc; }
                     else doshrink = true;
                 }
             } else {
-                double xcc = 0.5 * bx + 0.5 * sx[2], ycc = 0.5 * by + 0.5 * sy[2];
+                double xcc = 0.5 * bx + 0.5 * x2s, ycc = 0.5 * by + 0.5 * y2s;
                 double fxcc;
                 if (guarded(xcc, ycc, &fxcc)) {
-                    if (fxcc < fs[2]) { sx[2] = xcc; sy[2] = ycc; fs[2] = fxcc; }
+                    if (fxcc < f2s) { x2s = xcc; y2s = ycc; f2s = fxcc; }
                     else doshrink = true;
                 }
             }
             if (doshrink && !over) {
-                for (int j = 1; j < 3 && !over; ++j) {
-                    sx[j] = sx[0] + 0.5 * (sx[j] - sx[0]);
-                    sy[j] = sy[0] + 0.5 * (sy[j] - sy[0]);
-                    double f;
-                    if (guarded(sx[j], sy[j], &f)) fs[j] = f;
+                x1s = x0s + 0.5 * (x1s - x0s);
+                y1s = y0s + 0.5 * (y1s - y0s);
+                double f;
+                if (guarded(x1s, y1s, &f)) f1s = f;
+                if (!over) {
+                    x2s = x0s + 0.5 * (x2s - x0s);
+                    y2s = y0s + 0.5 * (y2s - y0s);
+                    if (guarded(x2s, y2s, &f)) f2s = f;
                 }
             }
             if (!over) iterations += 1;
         }
         sort3();
     }
-    *xo = sx[0];
-    *yo = sy[0];
+    *xo = x0s;
+    *yo = y0s;
     *n_eval += fcalls;
 }
 
@@ -986,18 +1086,8 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     const int w = T::wave();
     Frame& R = sh.R[w];
     int evals = 0;
-    // (i) the vector of the cluster with the largest 2*gap, first occurrence
-    double best = -PW_INF;
-    int bidx = 0x7fffffff;
-    for (int s = T::lane(); s < v.n_surv; s += T::WSIZE) {
-        if (ws->labels[s] == cluster) {
-            double val = ws->vals[s];
-            if (val > best || (val == best && s < bidx)) { best = val; bidx = s; }
-        }
-    }
-    T::wave_argmax(best, bidx);
-    const double* pv = &ws->pts[3 * ws->surv_k[bidx]];
-    double vx = pv[0], vy = pv[1], vz = pv[2];
+    // (i) the cluster's vector with the largest 2*gap was selected by stage_windows
+    double vx = v.win_vec[cluster][0], vy = v.win_vec[cluster][1], vz = v.win_vec[cluster][2];
     PW_T0(t_p);
     // (ii) refined path scan, increment 0.1, lanes over path points
     double nrm = norm3(vx, vy, vz);
@@ -1171,6 +1261,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         for (int w = 0; w < 8; ++w) v.red_i[8 + w] = 0;
     }
     T::sync();
+    PW_T0(t_pre);
     make_shifted<T>(sh, n, v.shift[0], v.shift[1], v.shift[2]);
     double keep_d = v.maxd;
     int keep_i = v.maxd_i, keep_j = v.maxd_j;
@@ -1195,9 +1286,26 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     }
     Sphere sp;
     sp.init(radius, P);
+    // per-unit arrays of the sampling stages: LDS scratch first, global workspace otherwise
+    ScratchArena arena;
+    arena.init(sh);
+    double* pts = (double*)arena.take((size_t)P * 3 * 8);
+    if (!pts) pts = ws->pts;
+    double* vals = (double*)arena.take((size_t)P * 8);
+    if (!vals) vals = ws->vals;
+    double* tmpv = (double*)arena.take((size_t)P * 8);
+    if (!tmpv) tmpv = ws->knn;            // free again once eps is known
+    int* surv_k = (int*)arena.take((size_t)P * 4);
+    if (!surv_k) surv_k = ws->surv_k;
+    int* labels = (int*)arena.take((size_t)P * 4);
+    if (!labels) labels = ws->labels;
+    unsigned char* flag = (unsigned char*)arena.take((size_t)P);
+    if (!flag) flag = ws->flag;
+    ScratchArena arena_mark = arena;      // everything taken below is temporary
     for (int k = T::tid(); k < P; k += T::SIZE)
-        sp.point(k, &ws->pts[3 * k], &ws->pts[3 * k + 1], &ws->pts[3 * k + 2]);
+        sp.point(k, &pts[3 * k], &pts[3 * k + 1], &pts[3 * k + 2]);
     T::sync();
+    if (T::wave() == 0) PW_T1(ws, 26, t_pre);
     // ---- eps: mean of all 10-NN distances (self included), utilities.py:1427-1434 ----
     PW_T0(t_eps);
     {
@@ -1205,23 +1313,16 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         // full scan is done when the window cannot be proven sufficient
         double zstep = pw_abs(sp.step) * radius;
         int W = (int)(4.0 * pw_sqrt((double)P)) + 8;
-        // stage the points in LDS (window frames are idle) when they fit
-        ldouble* lp = ((size_t)P * 3 <= sh.rot_words) ? sh.R[0].x : (ldouble*)nullptr;
-        if (lp) {
-            for (int e = T::tid(); e < 3 * P; e += T::SIZE) lp[e] = ws->pts[e];
-            T::sync();
-        }
+        PW_T0(t_knn);
         for (int k = T::tid(); k < P; k += T::SIZE) {
-            double px = ws->pts[3 * k], py = ws->pts[3 * k + 1], pz = ws->pts[3 * k + 2];
+            double px = pts[3 * k], py = pts[3 * k + 1], pz = pts[3 * k + 2];
             double t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
             int lo = k - W < 0 ? 0 : k - W, hi = k + W > P - 1 ? P - 1 : k + W;
             for (int pass = 0; pass < 2; ++pass) {
                 t0 = t1 = t2 = t3 = t4 = t5 = t6 = t7 = t8 = t9 = PW_INF;
 #pragma unroll 4
                 for (int j = lo; j <= hi; ++j) {
-                    double qx, qy, qz;
-                    if (lp) { qx = lp[3 * j]; qy = lp[3 * j + 1]; qz = lp[3 * j + 2]; }
-                    else { qx = ws->pts[3 * j]; qy = ws->pts[3 * j + 1]; qz = ws->pts[3 * j + 2]; }
+                    double qx = pts[3 * j], qy = pts[3 * j + 1], qz = pts[3 * j + 2];
                     double ax = px - qx, ay = py - qy, az = pz - qz;
                     double d = 0.0;
                     d = d + ax * ax; d = d + ay * ay; d = d + az * az;
@@ -1244,10 +1345,18 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             row[8] = pw_sqrt(t8); row[9] = pw_sqrt(t9);
         }
         T::sync();
-        double sum = np_sum_team<T>(ws->knn, P * 10, ws->leaf_tab, ws->acc8, ws->leaf, &v.red_v[15]);
+        if (T::wave() == 0) PW_T1(ws, 24, t_knn);
+        PW_T0(t_sum);
+        int* s_tab = (int*)arena.take(324 * 4);
+        double* s_acc = (double*)arena.take(8 * 160 * 8);
+        double* s_leaf = (double*)arena.take(256 * 8);
+        if (!s_tab || !s_acc || !s_leaf) { s_tab = ws->leaf_tab; s_acc = ws->acc8; s_leaf = ws->leaf; }
+        double sum = np_sum_team<T>(ws->knn, P * 10, s_tab, s_acc, s_leaf, &v.red_v[15]);
+        arena = arena_mark;
         double m = sum / (double)(P * 10);
         if (T::tid() == 0) { v.eps = m + pw_sqrt(m); out->eps = v.eps; }
         T::sync();
+        if (T::wave() == 0) PW_T1(ws, 25, t_sum);
     }
     if (T::wave() == 0) PW_T1(ws, 8, t_eps);
     PW_T0(t_smp);
@@ -1259,18 +1368,18 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         double cen[3] = {v.centroid[0], v.centroid[1], v.centroid[2]};
         for (int k = T::tid(); k < P; k += T::SIZE) {
             double far;
-            bool hit = ray_scan(sh.S, n, cen, ws->pts[3 * k], ws->pts[3 * k + 1], ws->pts[3 * k + 2], &far);
-            ws->flag[k] = hit ? 0 : 1;
+            bool hit = ray_scan(sh.S, n, cen, pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], &far);
+            flag[k] = hit ? 0 : 1;
         }
         T::sync();
         if (T::wave() == 0) {
             int m = 0;
             for (int base = 0; base < P; base += T::WSIZE) {
                 int k = base + T::lane();
-                bool f = k < P && ws->flag[k] != 0;
+                bool f = k < P && flag[k] != 0;
                 unsigned long long bal = T::ballot(f);
                 int pos = m + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
-                if (f) ws->labels[pos] = k;          // labels[] is free until DBSCAN
+                if (f) labels[pos] = k;          // labels[] is free until DBSCAN
                 m += __builtin_popcountll(bal);
             }
             if (T::lane() == 0) v.n_surv = m;
@@ -1279,23 +1388,23 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         int ncand = v.n_surv;
         int evals = 0;
         for (int j = T::tid(); j < ncand; j += T::SIZE) {
-            int k = ws->labels[j];
+            int k = labels[j];
             double g2, chunk[3];
             int pos;
-            bool ok = path_scan_thread(sh.S, n, ws->pts[3 * k], ws->pts[3 * k + 1], ws->pts[3 * k + 2], 1.0,
+            bool ok = path_scan_thread(sh.S, n, pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], 1.0,
                                        &g2, &pos, chunk, &evals);
-            ws->flag[j] = ok ? 1 : 0;
-            ws->knn[j] = g2;
+            flag[j] = ok ? 1 : 0;
+            tmpv[j] = g2;
         }
         T::sync();
         if (T::wave() == 0) {
             int m = 0;
             for (int base = 0; base < ncand; base += T::WSIZE) {
                 int j = base + T::lane();
-                bool f = j < ncand && ws->flag[j] != 0;
+                bool f = j < ncand && flag[j] != 0;
                 unsigned long long bal = T::ballot(f);
                 int pos = m + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
-                if (f) { ws->surv_k[pos] = ws->labels[j]; ws->vals[pos] = ws->knn[j]; }
+                if (f) { surv_k[pos] = labels[j]; vals[pos] = tmpv[j]; }
                 m += __builtin_popcountll(bal);
             }
             if (T::lane() == 0) { v.n_surv = m; out->n_survivors = m; }
@@ -1326,11 +1435,9 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         PW_LDS unsigned long long* frontier = v.bits[2];
         PW_LDS unsigned long long* next = v.bits[3];
         // adjacency rows live in LDS (the window frames are idle now) when they fit
-        size_t cap_words = sh.rot_words;
-        unsigned long long* adj;
-        int stride;
-        if ((size_t)ns * (size_t)words <= cap_words) { adj = (unsigned long long*)(double*)sh.R[0].x; stride = words; }
-        else { adj = ws->adj; stride = PW_P_MAX / 64; }
+        unsigned long long* adj = (unsigned long long*)arena.take((size_t)ns * (size_t)words * 8);
+        int stride = words;
+        if (!adj) { adj = ws->adj; stride = PW_P_MAX / 64; }
         if (adj == nullptr) {   // launch without a global adjacency buffer and LDS too small
             if (T::tid() == 0) v.status |= PW_ST_POINTS_OVERFLOW;
             T::sync();
@@ -1343,14 +1450,14 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         }
         T::sync();
         for (int i = T::tid(); i < ns; i += T::SIZE) {
-            const double* pi = &ws->pts[3 * ws->surv_k[i]];
+            const double* pi = &pts[3 * surv_k[i]];
             double px = pi[0], py = pi[1], pz = pi[2];
             int cnt = 0;
             for (int wd = 0; wd < words; ++wd) {
                 unsigned long long bits = 0;
                 int jend = (wd * 64 + 64 < ns) ? wd * 64 + 64 : ns;
                 for (int j = wd * 64; j < jend; ++j) {
-                    const double* pj = &ws->pts[3 * ws->surv_k[j]];
+                    const double* pj = &pts[3 * surv_k[j]];
                     double ax = px - pj[0], ay = py - pj[1], az = pz - pj[2];
                     double d = 0.0;
                     d = d + ax * ax; d = d + ay * ay; d = d + az * az;
@@ -1359,7 +1466,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                 adj[(size_t)i * stride + wd] = bits;
             }
             if (cnt >= 5) team_atomic_or(&core[i >> 6], 1ull << (i & 63));
-            ws->labels[i] = -1;
+            labels[i] = -1;
         }
         T::sync();
         int label = 0;
@@ -1377,7 +1484,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                 unsigned long long b = 1ull << (seed & 63);
                 frontier[seed >> 6] = b;
                 unl[seed >> 6] &= ~b;
-                ws->labels[seed] = label;
+                labels[seed] = label;
             }
             T::sync();
             for (;;) {
@@ -1396,7 +1503,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                 for (int wd = 0; wd < words; ++wd) any = any || (next[wd] != 0);
                 if (!any) break;
                 for (int i = T::tid(); i < ns; i += T::SIZE)
-                    if ((next[i >> 6] >> (i & 63)) & 1ull) ws->labels[i] = label;
+                    if ((next[i >> 6] >> (i & 63)) & 1ull) labels[i] = label;
                 T::sync();
                 for (int wd = T::tid(); wd < words; wd += T::SIZE) {
                     unsigned long long nx = next[wd];
@@ -1412,6 +1519,24 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             v.n_clusters = label;
             out->n_clusters = label;
             if (label > PW_W_MAX) v.status |= PW_ST_WINDOW_OVERFLOW;
+        }
+        T::sync();
+        // utilities.py:1221 -- per cluster the vector with the largest 2*gap (first occurrence)
+        int ncl0 = label < PW_W_MAX ? label : PW_W_MAX;
+        for (int c = T::wave(); c < ncl0; c += T::NWAVES) {
+            double best = -PW_INF;
+            int bidx = 0x7fffffff;
+            for (int q = T::lane(); q < ns; q += T::WSIZE) {
+                if (labels[q] == c) {
+                    double val = vals[q];
+                    if (val > best || (val == best && q < bidx)) { best = val; bidx = q; }
+                }
+            }
+            T::wave_argmax(best, bidx);
+            if (T::lane() == 0) {
+                const double* pv = &pts[3 * surv_k[bidx]];
+                v.win_vec[c][0] = pv[0]; v.win_vec[c][1] = pv[1]; v.win_vec[c][2] = pv[2];
+            }
         }
         T::sync();
     }
