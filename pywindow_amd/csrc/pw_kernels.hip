@@ -38,30 +38,97 @@ void set_err(const char* what, hipError_t e) {
         }                                     \
     } while (0)
 
+// Hand-off between the optimiser launch (producer, one wave per unit) and the window
+// launch (consumer, persistent teams): a producer publishes the index of a unit whose pore
+// centre is in its result record, consumers take published units in completion order.
+//   producer: record stores -> s_waitcnt -> agent release fence -> s_waitcnt -> relaxed store
+//   consumer: ONE relaxed poll loop -> agent acquire fence -> s_waitcnt -> team barrier -> loads
+// (MI355X guide, "Inter-workgroup communication").  Every spin is bounded.
+struct UnitQueue {
+    unsigned long long tail;   // next free slot (producers)
+    unsigned long long head;   // next slot to consume
+    int error;                 // set when a consumer gives up waiting
+    int started;               // producer teams that have begun (gate for the other launches)
+};
+enum : int { PW_ROLE_PLAIN = 0, PW_ROLE_PRODUCER = 1, PW_ROLE_CONSUMER = 2 };
+
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, 2)
 pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
                   const double* __restrict__ vdw, const double* __restrict__ mass, unsigned stages,
                   int nmax, int nrot, int nlb, TeamWorkspace* __restrict__ workspaces,
                   unsigned long long* __restrict__ adj_base, unsigned long long* counter,
-                  pw_unit_out* __restrict__ out) {
+                  pw_unit_out* __restrict__ out, int role, UnitQueue* queue, int* __restrict__ slots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ long s_unit;
     using T = DeviceTeam<NW>;
     UnitShared sh;
     sh.carve(lds, nmax, nrot, nlb);
+    // the optimiser chains are latency-bound and on the critical path: when one shares a SIMD
+    // with a bulk wave of another launch it must win the issue arbitration
+    if (role == PW_ROLE_PRODUCER) {
+        __builtin_amdgcn_s_setprio(3);
+        if (threadIdx.x == 0) atomicAdd(&queue->started, 1);
+    }
     TeamWorkspace* ws = workspaces + blockIdx.x;
     if (threadIdx.x == 0) ws->adj = adj_base ? adj_base + (size_t)blockIdx.x * PW_ADJ_WORDS : nullptr;
     __syncthreads();
     for (;;) {
-        if (threadIdx.x == 0) s_unit = (long)atomicAdd(counter, 1ull);
+        if (role == PW_ROLE_CONSUMER) {
+            if (threadIdx.x == 0) {
+                long pos = (long)atomicAdd(&queue->head, 1ull);
+                long u = -1;
+                if (pos < n_units) {
+                    long long t0 = wall_clock64();
+                    for (;;) {
+                        int v = __hip_atomic_load(&slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (v >= 0) { u = v; break; }
+                        __builtin_amdgcn_s_sleep(32);
+                        if (wall_clock64() - t0 > 500000000ll) {   // 5 s at 100 MHz: give up, flag it
+                            atomicExch(&queue->error, 1);
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                s_unit = u;
+            }
+        } else {
+            if (threadIdx.x == 0) {
+                long u = (long)atomicAdd(counter, 1ull);
+                s_unit = u < n_units ? u : -1;
+            }
+        }
         __syncthreads();
         long u = s_unit;
         __syncthreads();
-        if (u >= n_units) break;
+        if (u < 0) break;
         long a0 = atom_offset[u];
         int n = (int)(atom_offset[u + 1] - a0);
         analyse_unit<T>(sh, ws, n, xyz + 3 * a0, vdw + a0, mass + a0, stages, out + u);
+        if (role == PW_ROLE_PRODUCER) {
+            // analyse_unit ended with a team barrier; thread 0 wrote the record
+            if (threadIdx.x == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                long pos = (long)atomicAdd(&queue->tail, 1ull);
+                __hip_atomic_store(&slots[pos], (int)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// Gate: one wave, no LDS.  Holds the stream it is launched on until every team of the
+// optimiser launch is resident, so that launches queued behind it cannot take the LDS those
+// teams need.  It can never block them itself, and its wait is bounded.
+__global__ void pw_gate_kernel(UnitQueue* queue, int expected) {
+    if (threadIdx.x != 0) return;
+    long long t0 = wall_clock64();
+    while (__hip_atomic_load(&queue->started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > 200000000ll) break;   // 2 s
     }
 }
 
@@ -108,6 +175,11 @@ struct pw_context {
     unsigned long long* adj;
     int adj_blocks;
     unsigned long long* counter;   // 4 work counters
+    UnitQueue* queue;
+    int* slots;
+    long slots_cap;
+    hipStream_t prod;        // optimiser launch of the overlapped pipeline
+    hipEvent_t ev_prod, ev_gate;
     hipEvent_t ev0, ev1, ev_fork, ev_join;
     int fused;               // PW_FUSED=1: one launch per analysis instead of the pipeline
 };
@@ -182,7 +254,7 @@ static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool 
 
 template <int NW>
 static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const LaunchPlan& p, hipStream_t st,
-                     int ws_first, bool with_adj, int counter_slot) {
+                     int ws_first, bool with_adj, int counter_slot, int role) {
     auto kern = pw_analyse_kernel<NW>;
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)p.lds));
@@ -190,15 +262,15 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
                        r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb,
                        c->ws + ws_first, with_adj ? c->adj : (unsigned long long*)nullptr,
-                       c->counter + counter_slot, r->d_out);
+                       c->counter + counter_slot, r->d_out, role, c->queue, c->slots);
     HIP_TRY(hipGetLastError());
     return PW_OK;
 }
 static int launch_plan(pw_context* c, pw_resident* r, unsigned stages, const LaunchPlan& p, hipStream_t st,
-                       int ws_first, bool with_adj, int counter_slot) {
-    if (p.nw == 4) return launch_nw<4>(c, r, stages, p, st, ws_first, with_adj, counter_slot);
-    if (p.nw == 2) return launch_nw<2>(c, r, stages, p, st, ws_first, with_adj, counter_slot);
-    return launch_nw<1>(c, r, stages, p, st, ws_first, with_adj, counter_slot);
+                       int ws_first, bool with_adj, int counter_slot, int role = PW_ROLE_PLAIN) {
+    if (p.nw == 4) return launch_nw<4>(c, r, stages, p, st, ws_first, with_adj, counter_slot, role);
+    if (p.nw == 2) return launch_nw<2>(c, r, stages, p, st, ws_first, with_adj, counter_slot, role);
+    return launch_nw<1>(c, r, stages, p, st, ws_first, with_adj, counter_slot, role);
 }
 
 extern "C" {
@@ -231,6 +303,18 @@ int pw_context_create(int device, pw_context** out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIP_TRY(hipMalloc((void**)&c->counter, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&c->queue, sizeof(UnitQueue)));
+    {
+        // the optimiser chains are the critical path: their launch gets the highest priority,
+        // the average-diameter launch the lowest
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&c->prod, hipStreamNonBlocking, hi));
+        (void)hipStreamDestroy(c->aux);
+        HIP_TRY(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, lo));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_prod, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -251,6 +335,11 @@ void pw_context_destroy(pw_context* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->adj) (void)hipFree(c->adj);
+    if (c->queue) (void)hipFree(c->queue);
+    if (c->slots) (void)hipFree(c->slots);
+    if (c->prod) (void)hipStreamDestroy(c->prod);
+    if (c->ev_prod) (void)hipEventDestroy(c->ev_prod);
+    if (c->ev_gate) (void)hipEventDestroy(c->ev_gate);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -277,14 +366,18 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         if (rc != PW_OK) return rc;
         return launch_plan(c, r, stages, p, c->stream, 0, win, 0);
     }
-    // Pipeline: the analysis is split by parallel shape.
-    //   A (main stream): stage_basic + pore-centre optimiser, ONE wave per unit -- the serial
-    //     chain; every unit of a 1000-frame batch runs at once instead of idling 3 waves.
-    //   B (aux stream, concurrent with A): average diameter, 4 waves per unit.
-    //   C (main, after A and B): window search with the pore centre taken from the record.
+    // Pipeline: the analysis is split by parallel shape and the pieces overlap.
+    //   A (producer stream): stage_basic + pore-centre optimiser, ONE wave per unit -- the serial
+    //     chain; every unit of a 1000-frame batch iterates at once.  Chains differ 10x in length;
+    //     each finished unit is published to a queue.
+    //   B (aux stream): average diameter, 4 waves per unit, independent of A.
+    //   C (main stream): window search, persistent teams consuming units as A publishes them.
+    //     A one-wave gate kernel ahead of C (and B) holds them back until every team of A is
+    //     resident, so they can never take the LDS A needs -- no launch-order assumption.
     LaunchPlan pa, pb, pc;
     rc = plan_launch(c, r->n_units, r->nmax, 1, false, 1, &pa);
     if (rc != PW_OK) return rc;
+    pa.grid = (int)r->n_units < pa.grid ? (int)r->n_units : pa.grid;
     bool do_avg = (stages & PW_STAGE_AVG) != 0;
     pb.grid = 0;
     if (do_avg) {
@@ -293,23 +386,39 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     }
     rc = plan_launch(c, r->n_units, r->nmax, 4, true, -1, &pc);
     if (rc != PW_OK) return rc;
-    int need = pa.grid + pb.grid;
-    if (pc.grid > need) need = pc.grid;
+    int need = pc.grid + pa.grid + pb.grid;
     rc = ensure_workspace(c, need, pc.grid);
     if (rc != PW_OK) return rc;
+    if (c->slots_cap < r->n_units) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->slots) HIP_TRY(hipFree(c->slots));
+        HIP_TRY(hipMalloc((void**)&c->slots, sizeof(int) * (size_t)r->n_units));
+        c->slots_cap = r->n_units;
+    }
     HIP_TRY(hipMemsetAsync(r->d_out, 0, sizeof(pw_unit_out) * r->n_units, c->stream));
+    HIP_TRY(hipMemsetAsync(c->queue, 0, sizeof(UnitQueue), c->stream));
+    HIP_TRY(hipMemsetAsync(c->slots, 0xff, sizeof(int) * (size_t)r->n_units, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_fork, 0));
+    rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod, pc.grid, false, 0,
+                     PW_ROLE_PRODUCER);
+    if (rc != PW_OK) return rc;
+    HIP_TRY(hipEventRecord(c->ev_prod, c->prod));
+    hipLaunchKernelGGL(pw_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->queue, pa.grid);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_gate, c->stream));
+    rc = launch_plan(c, r, PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pc,
+                     c->stream, 0, true, 2, PW_ROLE_CONSUMER);
+    if (rc != PW_OK) return rc;
     if (do_avg) {
-        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-        HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-        rc = launch_plan(c, r, PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pb, c->aux, pa.grid, false, 1);
+        HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_gate, 0));
+        rc = launch_plan(c, r, PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pb, c->aux, pc.grid + pa.grid, false, 1);
         if (rc != PW_OK) return rc;
         HIP_TRY(hipEventRecord(c->ev_join, c->aux));
     }
-    rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->stream, 0, false, 0);
-    if (rc != PW_OK) return rc;
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_prod, 0));
     if (do_avg) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    return launch_plan(c, r, PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pc,
-                       c->stream, 0, true, 2);
+    return PW_OK;
 }
 
 int pw_resident_sync(pw_context* c) {
@@ -366,6 +475,12 @@ int pw_resident_download(pw_context* c, pw_resident* r, pw_unit_out* out) {
     HIP_TRY(hipMemcpyAsync(out, r->d_out, sizeof(pw_unit_out) * r->n_units, hipMemcpyDeviceToHost,
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    UnitQueue q;
+    HIP_TRY(hipMemcpy(&q, c->queue, sizeof(q), hipMemcpyDeviceToHost));
+    if (q.error) {
+        snprintf(g_err, sizeof(g_err), "window launch timed out waiting for the optimiser launch");
+        return PW_E_HIP;
+    }
     return PW_OK;
 }
 
