@@ -191,6 +191,13 @@ struct ScratchArena {
     }
 };
 
+PW_HD inline void team_atomic_max(PW_LDS int* p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMax((int*)p, v);
+#else
+    if (v > *p) *p = v;
+#endif
+}
 PW_HD inline void team_atomic_or(PW_LDS unsigned long long* p, unsigned long long v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicOr((unsigned long long*)p, v);
@@ -649,38 +656,51 @@ template <class T>
 PW_HD inline void load_unit(UnitShared& sh, int n, const double* xyz, const double* vdw,
                             const double* mass) {
     auto& v = *sh.v;
-    if (T::tid() == 0) {
-        v.n_eval = 0;
-        v.status = 0;
-        // group atoms by radius (stable: ascending atom index inside a group)
-        auto& C = v.cls;
-        PW_LDS int* cnt = v.cls_cnt;   // (private arrays with run-time indices live in scratch memory)
-        int k = 0;
-        bool ok = true;
-        for (int i = 0; i < n && ok; ++i) {
-            double r = vdw[i];
-            int g = 0;
-            while (g < k && C.vdw[g] != r) ++g;
-            if (g == k) {
-                if (k == PW_KCLS) { ok = false; break; }
-                C.vdw[k] = r; cnt[k] = 0; ++k;
-            }
-            sh.inv[i] = g;          // group id for now
-            cnt[g] += 1;
+    // Group atoms by radius, stable (ascending atom index inside a group), groups in order of
+    // first appearance -- computed by every thread for its own atoms:
+    //   key_i  = index of the first atom with the same radius
+    //   pos_i  = #{j : key_j < key_i} + #{j < i : key_j == key_i}
+    for (int i = T::tid(); i < n; i += T::SIZE) {
+        double r = vdw[i];
+        sh.vdw[i] = r;                 // caller's order for the moment
+        sh.mass[i] = mass[i];
+    }
+    if (T::tid() == 0) { v.n_eval = 0; v.status = 0; v.cls.k = 0; }
+    T::sync();
+    for (int i = T::tid(); i < n; i += T::SIZE) {
+        double r = sh.vdw[i];
+        int key = i;
+        for (int j = 0; j < i; ++j)
+            if (sh.vdw[j] == r) { key = j; break; }
+        sh.perm[i] = key;              // perm[] holds the keys until the scatter below
+    }
+    T::sync();
+    for (int i = T::tid(); i < n; i += T::SIZE) {
+        int key = sh.perm[i];
+        int pos = 0, cid = 0;
+        for (int j = 0; j < n; ++j) {
+            int kj = sh.perm[j];
+            pos += (kj < key) || (kj == key && j < i);
+            cid += (kj == j) && (j < key);      // group leaders before mine
         }
-        if (ok) {
-            C.k = k;
-            int o = 0;
-            for (int g = 0; g < k; ++g) { C.off[g] = o; o += cnt[g]; cnt[g] = C.off[g]; }
-            C.off[k] = o;
-            for (int i = 0; i < n; ++i) { int g = sh.inv[i]; sh.inv[i] = cnt[g]++; }
-        } else {
-            C.k = 0;
-            C.off[0] = 0;
-            for (int i = 0; i < n; ++i) sh.inv[i] = i;
+        sh.inv[i] = pos;
+        if (key == i) {                // group leader: publishes its group
+            if (cid < PW_KCLS) { v.cls.vdw[cid] = sh.vdw[i]; v.cls.off[cid] = pos; }
+            team_atomic_max(&v.cls.k, cid + 1);
         }
     }
     T::sync();
+    const int ngrp = v.cls.k;
+    T::sync();
+    if (ngrp > PW_KCLS) {
+        // too many distinct radii: no grouping (bulk evaluations fall back to per-atom sqrt)
+        for (int i = T::tid(); i < n; i += T::SIZE) sh.inv[i] = i;
+        if (T::tid() == 0) { v.cls.k = 0; v.cls.off[0] = 0; }
+    } else if (T::tid() == 0) {
+        v.cls.off[ngrp] = n;
+    }
+    T::sync();
+    // scatter into stored order (all reads of the caller-order copy of vdw are done)
     for (int i = T::tid(); i < n; i += T::SIZE) {
         int pos = sh.inv[i];
         double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
@@ -688,7 +708,6 @@ PW_HD inline void load_unit(UnitShared& sh, int n, const double* xyz, const doub
         sh.A.xx[pos] = sq3(x, y, z);
         sh.vdw[pos] = vdw[i];
         sh.perm[pos] = i;
-        sh.mass[i] = mass[i];
     }
     T::sync();
 }
@@ -1606,7 +1625,13 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
         }
     }
     load_unit<T>(sh, n, xyz, vdw, mass);
-    stage_basic<T>(sh, ws, n, out, (stages & PW_STAGE_COM_ONLY) != 0);
+    if (reuse_opt) {
+        // the optimiser launch already wrote the centre of mass
+        if (T::tid() == 0) { sh.v->com[0] = out->com[0]; sh.v->com[1] = out->com[1]; sh.v->com[2] = out->com[2]; }
+        T::sync();
+    } else {
+        stage_basic<T>(sh, ws, n, out, (stages & PW_STAGE_COM_ONLY) != 0);
+    }
     if (stages & PW_STAGE_OPT) stage_opt<T>(sh, ws, n, out);
     if (reuse_opt) {
         if (T::tid() == 0) {
