@@ -24,6 +24,7 @@ FRAMES = 1000
 ALGO_BYTES_PER_UNIT = 24 * 168 + 600   # coordinates read once + one result record
 ALGO_FLOP_PER_UNIT = 2.0e7
 HBM_PEAK_GBS = 8000.0
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01b_hbm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 
@@ -102,6 +103,13 @@ def main():
         k_ms = res.time_launches(max(3, min(args.steps, 10)))
         units_per_s = args.frames / (k_ms * 1e-3)
         achieved_gbs = units_per_s * ALGO_BYTES_PER_UNIT / 1e9
+        traffic = None
+        try:
+            with open(TRAFFIC_FILE) as fh:
+                tj = json.load(fh)
+            traffic = tj["per_launch_bytes"] * (args.frames / tj["units_per_launch"])
+        except (OSError, KeyError, ValueError):
+            traffic = None
         line = {
             "metric": "trajectory frames/sec full_analysis (pore+windows), CC3 1k-frame",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -112,8 +120,10 @@ def main():
                        "frames_per_gpu": args.frames, "stages": "all", "results_ok": ok,
                        "windows_eq_4": int((out["n_windows"] == 4).sum())},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "pw_analyse_kernel", "kernel_ms": k_ms,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_note": "fabric bytes per launch from rocprofv3 PMC (profiles/r01b_hbm_traffic.json); "
+                                         "includes Infinity-Cache hits on the re-used per-team workspaces",
+                         "kernel": "pw_analyse_kernel (pipeline: optimiser chains | average diameter | window search)", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_UNIT * args.frames,
                          "fp64_valu": {"achieved_tflops": units_per_s * ALGO_FLOP_PER_UNIT / 1e12,
                                        "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
