@@ -62,25 +62,47 @@ enum LbMsg : int {
 
 constexpr int LB_M = 10;
 
+// The arrays of one optimiser instance: this block lives in team-shared memory (LDS).
 template <int N>
-struct Lbfgsb {
+struct LbMem {
     static constexpr int M = LB_M;
     static constexpr int M2 = 2 * LB_M;
-    // ---- problem ----
     double l[N], u[N];
-    int nbd[N];
-    double x[N], g[N], f;
-    double factr, pgtol;
-    int maxls;
-    // ---- limited-memory matrices ----
+    double x[N], g[N];
     double ws[M * N], wy[M * N];
     double sy[M * M], ss[M * M], wt[M * M];
     double wn[M2 * M2], wn1[M2 * M2];
     double z[N], r[N], d[N], t[N], xp[N];
     double wa[8 * M];
     double acc[2 * M];  // running dot products of the systolic triangular solves
-    unsigned long long* prof;  // stage timers (diagnostic builds only), else null
+    int nbd[N];
     int index[N], iwhere[N], indx2[N];
+};
+
+// The optimiser object itself holds only scalars and pointers into its LbMem block; the
+// kernels keep it in a local variable, i.e. in registers, so the line search does not pay
+// an LDS round trip for every scalar it touches.
+template <int N>
+struct Lbfgsb {
+    static constexpr int M = LB_M;
+    static constexpr int M2 = 2 * LB_M;
+    LbMem<N>* mem;
+    // ---- problem ----
+    double *l, *u;
+    int* nbd;
+    double *x, *g;
+    double f;
+    double factr, pgtol;
+    int maxls;
+    // ---- limited-memory matrices ----
+    double *ws, *wy;
+    double *sy, *ss, *wt;
+    double *wn, *wn1;
+    double *z, *r, *d, *t, *xp;
+    double* wa;
+    double* acc;
+    unsigned long long* prof;  // stage timers (diagnostic builds only), else null
+    int *index, *iwhere, *indx2;
     // ---- scalars kept between calls ----
     int task, msg;
     bool prjctd, cnstnd, boxed, updatd;
@@ -94,9 +116,17 @@ struct Lbfgsb {
     double ginit, gtest, gx, gy, finit, fx, fy, stx, sty, stmin, stmax, width, width1;
 
     // ------------------------------------------------------------------
-    PW_HD void setup(const double* x0, const double* lo, const double* up, const int* nb,
+    PW_HD void bind(LbMem<N>* m) {
+        mem = m;
+        l = m->l; u = m->u; nbd = m->nbd; x = m->x; g = m->g;
+        ws = m->ws; wy = m->wy; sy = m->sy; ss = m->ss; wt = m->wt; wn = m->wn; wn1 = m->wn1;
+        z = m->z; r = m->r; d = m->d; t = m->t; xp = m->xp; wa = m->wa; acc = m->acc;
+        index = m->index; iwhere = m->iwhere; indx2 = m->indx2;
+    }
+    PW_HD void setup(LbMem<N>* m, const double* x0, const double* lo, const double* up, const int* nb,
                      double factr_, double pgtol_, int maxls_) {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(m);
+        bind(m);
         for (int i = 0; i < N; ++i) {
             x[i] = x0[i];
             l[i] = lo[i];
@@ -125,7 +155,7 @@ struct Lbfgsb {
     // ---- team-parallel dense kernels (element-wise identical to pw_blas.hpp) -------------
     template <class T>
     PW_HD int p_dpotrf_u(int n, double* a, int lda) {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         for (int j = 0; j < n; ++j) {
             double* cj = a + (long)j * lda;
             double ajj = cj[j] - b_ddot(j, cj, cj);
@@ -152,7 +182,7 @@ struct Lbfgsb {
     // solve U x = b (no-trans), one right-hand side: level-2 TRSV order
     template <class T>
     PW_HD void p_dtrsv_un(int n, const double* a, int lda, double* x) {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         for (int i = n - 1; i >= 0; --i) {
             const double* ci = a + (long)i * lda;
             double xi = x[i] / ci[i];
@@ -166,7 +196,7 @@ struct Lbfgsb {
     // solve U^T x = b, one right-hand side: DOT order (b_ddot), as a systolic sweep
     template <class T>
     PW_HD void p_dtrsv_ut(int n, const double* a, int lda, double* x) {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         for (int i = T::lane(); i < n; i += T::WSIZE) acc[i] = 0.0;
         T::wave_sync();
         for (int s = 0; s < n; ++s) {
@@ -200,7 +230,7 @@ struct Lbfgsb {
     }
     template <class T>
     PW_HD int p_dtrtrs_u(bool trans, int n, int nrhs, const double* a, int lda, double* b, int ldb) {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         for (int i = 0; i < n; ++i)
             if (a[i + (long)i * lda] == 0.0) return i + 1;
         if (nrhs == 1) {
@@ -215,7 +245,7 @@ struct Lbfgsb {
 
     // ---- projgr: infinity norm of the projected gradient ------------------
     PW_HD void projgr() {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         sbgnrm = 0.0;
         for (int i = 0; i < N; ++i) {
             double gi = g[i];
@@ -232,7 +262,7 @@ struct Lbfgsb {
 
     // ---- active: project x0, classify variables ----------------------------
     PW_HD void active() {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         prjctd = false;
         cnstnd = false;
         boxed = true;
@@ -260,7 +290,7 @@ struct Lbfgsb {
     // ---- bmv: product of the 2m x 2m middle matrix with a vector ----------
     template <class T>
     PW_HD int bmv(const double* v, double* p) {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         if (col == 0) return 0;
         for (int i = T::lane(); i < col; i += T::WSIZE) {
             if (i == 0) {
@@ -337,7 +367,7 @@ struct Lbfgsb {
     // workspace: p = wa[0..2m), c = wa[2m..4m), wbp = wa[4m..6m), v = wa[6m..8m)
     template <class T>
     PW_HD int cauchy() {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         double* p = wa;
         double* c = wa + 2 * M;
         double* wbp = wa + 4 * M;
@@ -523,7 +553,7 @@ struct Lbfgsb {
 
     // ---- freev ---------------------------------------------------------------
     PW_HD bool freev() {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         nenter = 0;
         ileave = N + 1;  // 1-based
         if (iter > 0 && cnstnd) {
@@ -560,7 +590,7 @@ struct Lbfgsb {
     // ---- formk ------------------------------------------------------------------
     template <class T>
     PW_HD int formk() {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         const int nsub = nfree;
         if (updatd) {
             if (iupdat > M) {
@@ -699,7 +729,7 @@ struct Lbfgsb {
     // ---- cmprlb -------------------------------------------------------------------
     template <class T>
     PW_HD int cmprlb() {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         if (!cnstnd && col > 0) {
             for (int i = 0; i < N; ++i) r[i] = -g[i];
         } else {
@@ -727,7 +757,7 @@ struct Lbfgsb {
     // ---- subsm -----------------------------------------------------------------------
     template <class T>
     PW_HD int subsm() {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         const int nsub = nfree;
         double* wv = wa;
         double* dd = r;   // direction / reduced gradient
@@ -916,7 +946,7 @@ struct Lbfgsb {
     // ---- dcsrch ------------------------------------------------------------------------
     PW_HD void dcsrch(double fv, double gv, double& st, double ftol, double gtol, double xtol,
                       double stpmin, double stpmax) {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         const double p5 = 0.5, p66 = 0.66, xtrapl = 1.1, xtrapu = 4.0;
         if (ls_task == 0) {
             if (st < stpmin) ls_task = 4;
@@ -984,7 +1014,7 @@ struct Lbfgsb {
     // search finished (task NEW_X) or failed (info != 0)
     template <class T>
     PW_HD bool lnsrlb(bool reentry) {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         const double big = 1.0e10, ftol = 1.0e-3, gtol = 0.9, xtol = 0.1;
         if (!reentry) {
             dnorm = b_dnrm2(N, d);
@@ -1049,7 +1079,7 @@ struct Lbfgsb {
     // ---- matupd ---------------------------------------------------------------------------
     template <class T>
     PW_HD void matupd(double rr, double dr) {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         if (iupdat <= M) {
             col = iupdat;
             itail = (head + iupdat - 1) % M;
@@ -1107,7 +1137,7 @@ struct Lbfgsb {
     // ---- formt -------------------------------------------------------------------------------
     template <class T>
     PW_HD int formt() {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         for (int e = T::lane(); e < col * col; e += T::WSIZE) {
             int i = e / col, j = e % col;
             if (j < i) continue;
@@ -1140,7 +1170,7 @@ struct Lbfgsb {
     //            otherwise          -> finished (task/msg say why)
     template <class T>
     PW_HD void step() {
-        PW_ASSUME_LDS(this);
+        PW_ASSUME_LDS(mem);
         int entry;  // 0 fresh, 1 after FG_START, 2 after FG_LNSRCH, 3 after NEW_X
         if (task == LB_START) {
             epsmch = 2.220446049250313e-16;

@@ -144,7 +144,7 @@ struct UnitShared {
         b += n * 8 * 2;                       // vdw, mass
         b += n * 4 * 2;                       // perm, inv
         b += n * 8 * 4 * (2 + (size_t)nrot);  // A, S, R[w]
-        b += (size_t)nlb * ((sizeof(Lbfgsb<3>) + 15) & ~(size_t)15);
+        b += (size_t)nlb * ((sizeof(LbMem<3>) + 15) & ~(size_t)15);
         return b;
     }
     PW_HD void carve(unsigned char* base, int nmax, int nrot, int nlb) {
@@ -169,7 +169,7 @@ struct UnitShared {
         p = (PW_LDS unsigned char*)d;
         for (int w = 0; w < nlb; ++w) {
             lb[w] = (PW_LDS void*)p;
-            p += (sizeof(Lbfgsb<3>) + 15) & ~(size_t)15;
+            p += (sizeof(LbMem<3>) + 15) & ~(size_t)15;
         }
         scratch_bytes = (size_t)(p - scratch);
     }
@@ -852,8 +852,10 @@ PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n
     (void)ws;
     auto& v = *sh.v;
     if (T::wave() == 0) {
-        Lbfgsb<3>* S = (Lbfgsb<3>*)sh.lb[0];
-        PW_ASSUME_LDS(S);
+        Lbfgsb<3> opt;                       // scalars in registers, arrays in LDS
+        Lbfgsb<3>* S = &opt;
+        LbMem<3>* Smem = (LbMem<3>*)sh.lb[0];
+        PW_ASSUME_LDS(Smem);
         double r = v.pore_g;  // pore_diameter / 2
         double lo[3], up[3], x0[3];
         int nbd[3] = {2, 2, 2};
@@ -867,7 +869,7 @@ PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n
         bool have_last = false;
         double lx = 0.0, ly = 0.0, lz = 0.0, lf = 0.0, lg[3] = {0.0, 0.0, 0.0};
         if (!bad) {
-            S->setup(x0, lo, up, nbd, 1e7, 1e-5, 20);
+            S->setup(Smem, x0, lo, up, nbd, 1e7, 1e-5, 20);
 #ifdef PW_PROFILE
             S->prof = ws->prof;
 #endif
@@ -915,8 +917,8 @@ PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n
                 }
             }
         }
-        double cx = bad ? v.com[0] : S->x[0], cy = bad ? v.com[1] : S->x[1],
-               cz = bad ? v.com[2] : S->x[2];
+        double cx = v.com[0], cy = v.com[1], cz = v.com[2];
+        if (!bad) { cx = S->x[0]; cy = S->x[1]; cz = S->x[2]; }
         int arg;
         double g = wave_gap<T>(sh.A, n, cx, cy, cz, &arg);
         if (T::lane() == 0) {
@@ -1176,12 +1178,14 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     evals += 1;
     PW_T1(ws, 3, t_r);
     // (v) neck position along z: L-BFGS-B, n = 1, bounds [-new_z, +inf)
-    Lbfgsb<1>* S = (Lbfgsb<1>*)sh.lb[w];
-    PW_ASSUME_LDS(S);
+    Lbfgsb<1> zopt_state;
+    Lbfgsb<1>* S = &zopt_state;
+    LbMem<1>* Smem = (LbMem<1>*)sh.lb[w];
+    PW_ASSUME_LDS(Smem);
     double lo1[1] = {-new_z}, up1[1] = {0.0}, x01[1] = {0.0};
     int nbd1[1] = {1};
     if (x01[0] < lo1[0]) x01[0] = lo1[0];   // np.clip(x0, lb, ub)
-    S->setup(x01, lo1, up1, nbd1, 1e7, 1e-5, 20);
+    S->setup(Smem, x01, lo1, up1, nbd1, 1e7, 1e-5, 20);
     int nit = 0;
     bool have_last = false;
     double lz = 0.0, lf = 0.0, lg = 0.0;

@@ -32,10 +32,12 @@ template <int N> static void dump(Lbfgsb<N>* s, double* wa_out, int* ints, doubl
                                     const int* nbd, double factr, double pgtol, int maxls) { \
         auto* s = new Lbfgsb<N>();                                                           \
         memset((void*)s, 0, sizeof(*s));                                                     \
-        s->setup(x0, l, u, nbd, factr, pgtol, maxls);                                        \
+        auto* m = new LbMem<N>();                                                            \
+        memset((void*)m, 0, sizeof(*m));                                                     \
+        s->setup(m, x0, l, u, nbd, factr, pgtol, maxls);                                        \
         return s;                                                                            \
     }                                                                                        \
-    extern "C" void hs_lb##N##_free(void* h) { delete (Lbfgsb<N>*)h; }                       \
+    extern "C" void hs_lb##N##_free(void* h) { delete ((Lbfgsb<N>*)h)->mem; delete (Lbfgsb<N>*)h; }                       \
     extern "C" void hs_lb##N##_step(void* h, double* x, double f, const double* g,          \
                                     int set_fg) {                                            \
         auto* s = (Lbfgsb<N>*)h;                                                             \
