@@ -82,3 +82,27 @@ def test_dlpoly_batched_analysis(tmp_path):
         assert len(p["windows"]["diameters"]) == g["n_windows"][f]
     with pytest.raises(Exception):
         traj.analysis(frames="bogus")
+
+
+def test_record_gather_over_rccl_single_rank():
+    """The RCCL (nccl backend) path of the only collective, with one rank on the GPU."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from pywindow_amd import _lib
+    from pywindow_amd.trajectory import gather_records
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        local = np.zeros(5, dtype=_lib.UNIT_OUT_DTYPE)
+        local["pore_d"] = np.arange(5) * 1.5
+        local["n_windows"] = 4
+        out = gather_records(local, 5, 0, 1, dist)
+        assert out.tobytes() == local.tobytes()
+    finally:
+        dist.destroy_process_group()
