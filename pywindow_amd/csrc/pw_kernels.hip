@@ -182,6 +182,7 @@ struct pw_context {
     hipEvent_t ev_prod, ev_gate;
     hipEvent_t ev0, ev1, ev_fork, ev_join;
     int fused;               // PW_FUSED=1: one launch per analysis instead of the pipeline
+    int c_waves;             // waves per team in the window launch (PW_C_WAVES, default 4)
 };
 
 struct pw_resident {
@@ -228,8 +229,9 @@ static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool 
     const size_t max_lds = 160 * 1024 - 256;
     int nw = want_nw;
     for (;;) {
-        int nrot = rot ? nw : 0;
-        int nlb = lb_per_team < 0 ? nw : lb_per_team;
+        int nslot = nw < 4 ? nw : 4;
+        int nrot = rot ? nslot : 0;
+        int nlb = lb_per_team < 0 ? nslot : lb_per_team;
         size_t lds = UnitShared::bytes(nmax, nrot, nlb) + 64;
         if (lds <= max_lds || nw == 1) {
             if (lds > max_lds) {
@@ -268,6 +270,7 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
 }
 static int launch_plan(pw_context* c, pw_resident* r, unsigned stages, const LaunchPlan& p, hipStream_t st,
                        int ws_first, bool with_adj, int counter_slot, int role = PW_ROLE_PLAIN) {
+    if (p.nw == 8) return launch_nw<8>(c, r, stages, p, st, ws_first, with_adj, counter_slot, role);
     if (p.nw == 4) return launch_nw<4>(c, r, stages, p, st, ws_first, with_adj, counter_slot, role);
     if (p.nw == 2) return launch_nw<2>(c, r, stages, p, st, ws_first, with_adj, counter_slot, role);
     return launch_nw<1>(c, r, stages, p, st, ws_first, with_adj, counter_slot, role);
@@ -321,6 +324,8 @@ int pw_context_create(int device, pw_context** out) {
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     const char* fz = getenv("PW_FUSED");
     c->fused = (fz && fz[0] == '1') ? 1 : 0;
+    const char* cw = getenv("PW_C_WAVES");
+    c->c_waves = (cw && cw[0] == '8') ? 8 : 4;
     *out = c;
     return PW_OK;
 }
@@ -384,7 +389,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         rc = plan_launch(c, r->n_units, r->nmax, 4, false, 3, &pb);   // 3 state slots = 32 KB of scratch
         if (rc != PW_OK) return rc;
     }
-    rc = plan_launch(c, r->n_units, r->nmax, 4, true, -1, &pc);
+    rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pc);
     if (rc != PW_OK) return rc;
     int need = pc.grid + pa.grid + pb.grid;
     rc = ensure_workspace(c, need, pc.grid);

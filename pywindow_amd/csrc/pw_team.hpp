@@ -31,6 +31,7 @@ struct HostTeam {
     PW_HD static bool wave_all(bool p) { return p; }
     PW_HD static bool wave_any(bool p) { return p; }
     PW_HD static double bcast(double v, int /*src_lane*/) { return v; }
+    PW_HD static double bcast_u(double v, int /*uniform_src_lane*/) { return v; }
     PW_HD static int bcast_i(int v, int /*src_lane*/) { return v; }
 };
 
@@ -112,6 +113,8 @@ struct DeviceTeam {
     __device__ static bool wave_all(bool p) { return __all(p); }
     __device__ static bool wave_any(bool p) { return __any(p); }
     __device__ static double bcast(double v, int src) { return __shfl(v, src, 64); }
+    // source lane known to be the same in every lane: v_readlane, no LDS crossbar
+    __device__ static double bcast_u(double v, int src) { return lane_d(v, __builtin_amdgcn_readfirstlane(src)); }
     __device__ static int bcast_i(int v, int src) { return __shfl(v, src, 64); }
 };
 #endif

@@ -1567,7 +1567,11 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     PW_T0(t_w);
     // ---- one window per cluster, clusters dealt round-robin to the waves -------------------
     int ncl = v.n_clusters < PW_W_MAX ? v.n_clusters : PW_W_MAX;
-    for (int c = T::wave(); c < ncl; c += T::NWAVES) wave_window<T>(sh, ws, n, c, sp);
+    // at most four waves fit windows at a time (one rotated frame + optimiser state each);
+    // in an 8-wave team the upper four only take part in the bulk stages
+    constexpr int NSLOT = T::NWAVES < 4 ? T::NWAVES : 4;
+    if (T::wave() < NSLOT)
+        for (int c = T::wave(); c < ncl; c += NSLOT) wave_window<T>(sh, ws, n, c, sp);
     T::sync();
     if (T::wave() == 0) PW_T1(ws, 12, t_w);
     if (T::tid() == 0) {
