@@ -132,6 +132,30 @@ class DLPOLY:
             raise _FunctionError("Didn't recognise the keyword. (see manual)")
         raise _FunctionError("frames must be an int, a list of ints, a (start, stop) tuple or 'all'")
 
+    def save_analysis(self, filepath=None, **kwargs) -> None:  # noqa: ARG002
+        """Dump ``analysis_output`` as JSON (reference trajectory.py:251-271: arrays become
+        lists, frame numbers become string keys)."""
+        import json
+
+        path = pathlib.Path(filepath) if filepath is not None else pathlib.Path.cwd() / f"{self.system_id}_pywindow_analysis"
+        if path.suffix != ".json":
+            path = path.with_suffix(".json")
+
+        def enc(obj):
+            if isinstance(obj, np.ndarray):
+                return obj.tolist()
+            raise TypeError("Not serializable")
+
+        with path.open("w") as fh:
+            json.dump({str(k): v for k, v in self.analysis_output.items()}, fh, default=enc)
+
+    def analysis_records(self, frames="all", swap_atoms=None, forcefield=None, device=None) -> np.ndarray:
+        """Columnar results: the structured record array (``_lib.UNIT_OUT_DTYPE``) for the
+        selected frames, without building per-frame dicts."""
+        sel = self._select(frames)
+        ids = element_ids(self.elements(swap_atoms, forcefield))
+        return self._run(sel, VDW[ids], MASS[ids], device)
+
     # ---- the hot path -----------------------------------------------------------------------
     def analysis(self, frames="all", ncpus: int = 1, ncpus_analysis: int = 1, override: bool = False,
                  modular: bool = False, rebuild: bool = False, swap_atoms: dict | None = None,

@@ -126,3 +126,59 @@ def test_ragged_batch_and_edge_cases(hip_ctx):
     # empty batch
     empty = hip_ctx.analyse(_lib.Batch(np.zeros(1, np.int64), np.zeros((0, 3)), np.zeros(0), np.zeros(0)))
     assert len(empty) == 0
+
+
+def test_config3_periodic_cell_with_many_cages(hip_ctx):
+    """BASELINE config 3: a periodic cell's worth of discrete cages (the 8 rebuilt cages of
+    tests/data/system_periodic_rebuild.pdb, replicated 1x1x3 = 24 cages) in ONE launch; the
+    replicas (pure translations by lattice vectors) must give translation-consistent results and
+    the originals must match the reference."""
+    from pywindow_amd import _lib
+
+    g = load_group("periodic8")
+    off, xyz, vdw, mass = group_batch(g)
+    cell = 24.8
+    reps = [xyz + np.array([0.0, 0.0, cell * k]) for k in range(3)]
+    n8 = len(off) - 1
+    off24 = np.concatenate([off[:-1] + k * off[-1] for k in range(3)] + [[3 * off[-1]]])
+    out = hip_ctx.analyse(_lib.Batch(off24, np.concatenate(reps), np.tile(vdw, 3), np.tile(mass, 3)))
+    check_records(out[:n8], g, where="config3/cell0")
+    for k in (1, 2):
+        rep = out[k * n8:(k + 1) * n8]
+        assert np.array_equal(rep["n_windows"], g["n_windows"])
+        # translated input: same geometry up to rounding of the shifted coordinates (atom
+        # indices of near-degenerate extrema may legitimately differ on these symmetric cages)
+        assert rel(rep["maxd"], g["maxd"]) < 1e-12 and rel(rep["pore_d"], g["pore_d"]) < 1e-12
+        assert rel(rep["avg_d"], g["avg_d"]) < 1e-9
+        assert np.max(np.abs(rep["com"] - (g["com"] + np.array([0, 0, cell * k])))) < 1e-9
+
+
+def test_config5_screen_sample_against_live_oracle(hip_ctx):
+    """BASELINE config 5 (perturbed cages x frames, throughput mode), sampled: seeds
+    20260000 + 1000*cage + frame; a random sample is checked against the oracle run live."""
+    from oracle import pw_oracle as O
+    from pywindow_amd import _lib, synth
+    from pywindow_amd import element_data as E
+
+    elements, base = synth.load_cc3_base()
+    ids = E.element_ids(elements)
+    vdw, mass = E.VDW[ids], E.MASS[ids]
+    cages, frames = 40, 8
+    coords = np.empty((cages * frames, len(base), 3))
+    for c in range(cages):
+        for f in range(frames):
+            coords[c * frames + f] = synth.quantise_like_history(
+                synth.noisy_frame(base, synth.SEED_BASE + 1000 * c + f, 0.10))
+    out = hip_ctx.analyse(_lib.Batch.uniform(coords, vdw, mass))
+    assert (out["status"] == 0).all()
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for u in rng.choice(len(coords), 6, replace=False):
+        ref = O.full_analysis(coords[u], vdw, mass)
+        r = out[u]
+        for key in ("maxd", "avg_d", "pore_d", "pore_opt_d"):
+            assert float(r[key]) == ref[key], (u, key)
+        assert int(r["n_windows"]) == ref["n_windows"]
+        n = ref["n_windows"]
+        worst = max(worst, rel(np.sort(r["win_d"][:n]), np.sort(ref["win_d"][:n])))
+    assert worst <= 1e-6
