@@ -90,6 +90,16 @@ typedef struct pw_unit_out {
     double sphere_r;       /* sampling sphere radius in find_windows */
 } pw_unit_out;
 
+/* Optional knobs of the reference's free functions.  Defaults are the
+ * values Molecule.full_analysis() uses; a context starts with the defaults. */
+typedef struct pw_params {
+    double adjust_windows;  /* find_windows(adjust=1):           sampling density, utilities.py:1410 */
+    double adjust_average;  /* find_average_diameter(adjust=1):  sampling density, utilities.py:1615 */
+    double increment;       /* find_windows(increment=1.0):      coarse path-scan step, utilities.py:1457 */
+    int32_t pore_opt;       /* find_windows(pore_opt=True): centre on the optimised pore, :1380-1393 */
+    int32_t reserved;
+} pw_params;
+
 typedef struct pw_context pw_context;   /* device, stream, workspace */
 typedef struct pw_resident pw_resident; /* a batch resident in HBM */
 
@@ -99,6 +109,9 @@ const char *pw_last_error(void);
 
 int pw_context_create(int device, pw_context **ctx);
 void pw_context_destroy(pw_context *ctx);
+/* knobs used by every later launch on this context (validated: adjust > 0, increment > 0) */
+void pw_params_default(pw_params *params);
+int pw_context_set_params(pw_context *ctx, const pw_params *params);
 
 /* Host-buffer path: H2D copy, one launch, D2H copy, synchronous.
  * Replaces the per-frame loop `mol.full_analysis()` of trajectory.py:518-522

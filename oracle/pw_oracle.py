@@ -332,19 +332,24 @@ def window_fit(cage: Cage, cluster_rows: np.ndarray, detail=None):
     return diameter, centre
 
 
-def find_windows(cage: Cage, detail=None):
-    """utilities.py:1364-1553 with the default knobs (pore_opt, increment 1.0).
+def find_windows(cage: Cage, detail=None, adjust: float = 1, pore_opt: bool = True,
+                 increment: float = 1.0):
+    """utilities.py:1364-1553 (``adjust``, ``pore_opt``, ``increment`` as there).
 
     Returns ``None`` (no window), or ``(diameters (W,), centres (W,3))``.
     """
     com = centre_of_mass(cage)
-    pore_centre = opt_pore_diameter(cage)[2]
-    shift = com - pore_centre
-    origin_back = com - shift
+    if pore_opt is True:
+        pore_centre = opt_pore_diameter(cage)[2]
+        shift = com - pore_centre
+        origin_back = com - shift
+    else:
+        shift = np.zeros(3)
+        origin_back = com
     # shift_com(elements, coordinates, com_adjust): coords - (COM - adjust)
     moved = cage.moved(cage.xyz - np.array([com - shift] * cage.n))
     radius = max_dim(moved)[2] / 2
-    count = n_sampling_points(radius)
+    count = n_sampling_points(radius, adjust)
     pts = sphere_points(radius, count)
     eps = knn_eps(pts)
     vdw_col = moved.vdw.reshape(-1, 1)
@@ -352,7 +357,7 @@ def find_windows(cage: Cage, detail=None):
     kept = []
     for k, p in enumerate(pts):
         if len(_ray_hits(p, moved.xyz, vdw_col)) == 0:
-            r = path_scan(moved, p, 1.0)
+            r = path_scan(moved, p, increment)
             if r is not None:
                 rows.append(r)
                 kept.append(k)

@@ -44,6 +44,21 @@ class BatchIn(ctypes.Structure):
     ]
 
 
+class Params(ctypes.Structure):
+    """``pw_params``: knobs of find_windows / find_average_diameter (reference defaults)."""
+
+    _fields_ = [
+        ("adjust_windows", ctypes.c_double),
+        ("adjust_average", ctypes.c_double),
+        ("increment", ctypes.c_double),
+        ("pore_opt", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+    def __init__(self, adjust_windows=1.0, adjust_average=1.0, increment=1.0, pore_opt=True):
+        super().__init__(float(adjust_windows), float(adjust_average), float(increment), 1 if pore_opt else 0, 0)
+
+
 #: numpy mirror of ``pw_unit_out`` (natural C alignment)
 UNIT_OUT_DTYPE = np.dtype(
     [
@@ -87,6 +102,8 @@ EXPORTED_SYMBOLS = [
     "pw_last_error",
     "pw_context_create",
     "pw_context_destroy",
+    "pw_params_default",
+    "pw_context_set_params",
     "pw_analysis_batch",
     "pw_point_gaps",
     "pw_resident_upload",
@@ -136,6 +153,9 @@ def load():
     L.pw_context_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
     L.pw_context_destroy.argtypes = [vp]
     L.pw_context_destroy.restype = None
+    L.pw_params_default.argtypes = [ctypes.POINTER(Params)]
+    L.pw_params_default.restype = None
+    L.pw_context_set_params.argtypes = [vp, ctypes.POINTER(Params)]
     L.pw_analysis_batch.argtypes = [vp, ctypes.POINTER(BatchIn), ctypes.c_uint32, vp]
     L.pw_point_gaps.argtypes = [vp, ctypes.POINTER(BatchIn), vp, vp, ctypes.c_int64, vp, vp]
     L.pw_resident_upload.argtypes = [vp, ctypes.POINTER(BatchIn), ctypes.POINTER(vp)]
@@ -227,14 +247,25 @@ class Context:
         except Exception:
             pass
 
-    def analyse(self, batch: Batch, stages: int = STAGE_ALL) -> np.ndarray:
+    def set_params(self, params: "Params | None" = None) -> None:
+        """Knobs used by every later launch on this context (``None`` = reference defaults)."""
+        p = params if params is not None else Params()
+        _check(load().pw_context_set_params(self._h, ctypes.byref(p)), "pw_context_set_params")
+
+    def analyse(self, batch: Batch, stages: int = STAGE_ALL, params: "Params | None" = None) -> np.ndarray:
         out = np.zeros(batch.n_units, dtype=UNIT_OUT_DTYPE)
         if batch.n_units == 0:
             return out
-        _check(
-            load().pw_analysis_batch(self._h, ctypes.byref(batch.c), stages, out.ctypes.data),
-            "pw_analysis_batch",
-        )
+        if params is not None:
+            self.set_params(params)
+        try:
+            _check(
+                load().pw_analysis_batch(self._h, ctypes.byref(batch.c), stages, out.ctypes.data),
+                "pw_analysis_batch",
+            )
+        finally:
+            if params is not None:
+                self.set_params(None)
         return out
 
     def point_gaps(self, batch: Batch, unit_of_point, points):

@@ -58,7 +58,8 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
                   const double* __restrict__ vdw, const double* __restrict__ mass, unsigned stages,
                   int nmax, int nrot, int nlb, TeamWorkspace* __restrict__ workspaces,
                   unsigned long long* __restrict__ adj_base, unsigned long long* counter,
-                  pw_unit_out* __restrict__ out, int role, UnitQueue* queue, int* __restrict__ slots) {
+                  pw_unit_out* __restrict__ out, int role, UnitQueue* queue, int* __restrict__ slots,
+                  pw_params prm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ long s_unit;
     using T = DeviceTeam<NW>;
@@ -106,7 +107,7 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
         if (u < 0) break;
         long a0 = atom_offset[u];
         int n = (int)(atom_offset[u + 1] - a0);
-        analyse_unit<T>(sh, ws, n, xyz + 3 * a0, vdw + a0, mass + a0, stages, out + u);
+        analyse_unit<T>(sh, ws, n, xyz + 3 * a0, vdw + a0, mass + a0, stages, out + u, prm);
         if (role == PW_ROLE_PRODUCER) {
             // analyse_unit ended with a team barrier; thread 0 wrote the record
             if (threadIdx.x == 0) {
@@ -183,6 +184,7 @@ struct pw_context {
     hipEvent_t ev0, ev1, ev_fork, ev_join;
     int fused;               // PW_FUSED=1: one launch per analysis instead of the pipeline
     int c_waves;             // waves per team in the window launch (PW_C_WAVES, default 4)
+    pw_params prm;           // knobs of find_windows / find_average_diameter
 };
 
 struct pw_resident {
@@ -264,7 +266,7 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
                        r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb,
                        c->ws + ws_first, with_adj ? c->adj : (unsigned long long*)nullptr,
-                       c->counter + counter_slot, r->d_out, role, c->queue, c->slots);
+                       c->counter + counter_slot, r->d_out, role, c->queue, c->slots, c->prm);
     HIP_TRY(hipGetLastError());
     return PW_OK;
 }
@@ -326,6 +328,7 @@ int pw_context_create(int device, pw_context** out) {
     c->fused = (fz && fz[0] == '1') ? 1 : 0;
     const char* cw = getenv("PW_C_WAVES");
     c->c_waves = (cw && cw[0] == '8') ? 8 : 4;
+    c->prm = default_params();
     *out = c;
     return PW_OK;
 }
@@ -348,6 +351,21 @@ void pw_context_destroy(pw_context* c) {
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+void pw_params_default(pw_params* p) {
+    if (p) *p = default_params();
+}
+
+int pw_context_set_params(pw_context* c, const pw_params* p) {
+    if (!c || !p) return PW_E_BAD_ARG;
+    if (!(p->adjust_windows > 0.0) || !(p->adjust_average > 0.0) || !(p->increment > 0.0)) {
+        snprintf(g_err, sizeof(g_err), "pw_params: adjust and increment must be positive");
+        return PW_E_BAD_ARG;
+    }
+    c->prm = *p;
+    c->prm.pore_opt = p->pore_opt ? 1 : 0;
+    return PW_OK;
 }
 
 void* pw_context_stream(pw_context* c) { return c ? (void*)c->stream : nullptr; }

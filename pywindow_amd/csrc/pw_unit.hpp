@@ -554,9 +554,15 @@ struct Sphere {
         *pz = z * R;
     }
 };
-PW_HD inline int sampling_count(double radius) {
+PW_HD inline pw_params default_params() {
+    pw_params p;
+    p.adjust_windows = 1.0; p.adjust_average = 1.0; p.increment = 1.0; p.pore_opt = 1; p.reserved = 0;
+    return p;
+}
+// int(np.log10(4*pi*r**2) * 250 * adjust)  (utilities.py:1410, 1615)
+PW_HD inline int sampling_count(double radius, double adjust) {
     double area = FOUR_PI * (radius * radius);
-    return (int)(pw_log10(area) * 250.0);
+    return (int)((pw_log10(area) * 250.0) * adjust);
 }
 
 // Ray from the centroid along (dx,dy,dz) against every atom (utilities.py:1138-1158 /
@@ -945,7 +951,8 @@ PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n
 
 // ---- stage: average diameter ---------------------------------------------------------------
 template <class T>
-PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out) {
+PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
+                                             const pw_params& prm) {
     auto& v = *sh.v;
     make_shifted<T>(sh, n, v.com[0], v.com[1], v.com[2]);
     // preserve the input-frame max_dim: the shifted frame's replaces it only here
@@ -956,7 +963,7 @@ PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, i
     double radius = v.maxd;
     T::sync();
     if (T::tid() == 0) { v.maxd = keep_d; v.maxd_i = keep_i; v.maxd_j = keep_j; }
-    int P = sampling_count(radius);
+    int P = sampling_count(radius, prm.adjust_average);
     if (P > PW_P_MAX) {
         if (T::tid() == 0) { v.status |= PW_ST_POINTS_OVERFLOW; out->avg_d = 0.0; out->n_points_avg = P; }
         T::sync();
@@ -1272,12 +1279,14 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
 
 // ---- stage: windows ----------------------------------------------------------------------------
 template <class T>
-PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out) {
+PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
+                                             const pw_params& prm) {
     auto& v = *sh.v;
-    // shift so that the optimised pore centre is the origin (utilities.py:1388-1390)
+    // shift so that the optimised pore centre (pore_opt) or the centre of mass is the origin
+    // (utilities.py:1380-1393)
     if (T::tid() == 0) {
         for (int c = 0; c < 3; ++c) {
-            double adjust = v.com[c] - v.opt_c[c];
+            double adjust = prm.pore_opt ? v.com[c] - v.opt_c[c] : 0.0;
             v.shift[c] = v.com[c] - adjust;
         }
         for (int c = 0; c < PW_W_MAX; ++c) v.win_ok[c] = 0;
@@ -1293,7 +1302,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     double radius = v.maxd / 2.0;
     T::sync();
     if (T::tid() == 0) { v.maxd = keep_d; v.maxd_i = keep_i; v.maxd_j = keep_j; }
-    int P = sampling_count(radius);
+    int P = sampling_count(radius, prm.adjust_windows);
     if (T::tid() == 0) {
         out->n_points = P;
         out->sphere_r = radius;
@@ -1414,7 +1423,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             int k = labels[j];
             double g2, chunk[3];
             int pos;
-            bool ok = path_scan_thread(sh.S, n, pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], 1.0,
+            bool ok = path_scan_thread(sh.S, n, pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], prm.increment,
                                        &g2, &pos, chunk, &evals);
             flag[j] = ok ? 1 : 0;
             tmpv[j] = g2;
@@ -1613,10 +1622,10 @@ PW_HD inline void record_or_status(pw_unit_out* out, int st, int evals) {
 template <class T>
 PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const double* xyz,
                                const double* vdw, const double* mass, unsigned stages,
-                               pw_unit_out* out) {
+                               pw_unit_out* out, const pw_params& prm) {
     const bool merge = (stages & PW_STAGE_MERGE) != 0;
     const bool reuse_opt = (stages & PW_STAGE_REUSE_OPT) != 0;
-    if ((stages & PW_STAGE_WINDOWS) && !reuse_opt) stages |= PW_STAGE_OPT;
+    if ((stages & PW_STAGE_WINDOWS) && !reuse_opt && prm.pore_opt) stages |= PW_STAGE_OPT;
     if (T::tid() == 0 && !merge) {
         out->status = 0;
         out->n_eval = 0;
@@ -1652,11 +1661,11 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
     }
     if (stages & PW_STAGE_AVG) {
         PW_T0(t_a);
-        stage_average<T>(sh, ws, n, out);
+        stage_average<T>(sh, ws, n, out, prm);
         if (T::wave() == 0) PW_T1(ws, 13, t_a);
     }
-    if ((stages & PW_STAGE_WINDOWS) && !(sh.v->status & PW_ST_NEGATIVE_PORE))
-        stage_windows<T>(sh, ws, n, out);
+    if ((stages & PW_STAGE_WINDOWS) && !(prm.pore_opt && (sh.v->status & PW_ST_NEGATIVE_PORE)))
+        stage_windows<T>(sh, ws, n, out, prm);
     if (T::tid() == 0) {
         if (merge) {
             record_or_status(out, sh.v->status, sh.v->n_eval);

@@ -55,10 +55,11 @@ def make_batch(molecules) -> "_lib.Batch":
     return _lib.Batch(np.array(offs, np.int64), np.concatenate(xyz), np.concatenate(vdw), np.concatenate(mass))
 
 
-def analyse(molecules, stages: int = _lib.STAGE_ALL, device: int | None = None) -> np.ndarray:
+def analyse(molecules, stages: int = _lib.STAGE_ALL, device: int | None = None, params=None) -> np.ndarray:
     """Run the selected stages for a list of molecules in ONE launch; returns the
-    structured record array (``_lib.UNIT_OUT_DTYPE``)."""
-    return context(device).analyse(make_batch(molecules), stages)
+    structured record array (``_lib.UNIT_OUT_DTYPE``).  ``params``: ``_lib.Params`` for
+    non-default find_windows / find_average_diameter knobs."""
+    return context(device).analyse(make_batch(molecules), stages, params)
 
 
 def windows_of(rec):

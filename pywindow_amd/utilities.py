@@ -15,8 +15,8 @@ from . import _lib, engine
 from .element_data import atomic_mass, atomic_vdw_radius  # noqa: F401  (re-exported)
 
 
-def _one(elements, coordinates, stages):
-    return engine.analyse([(elements, coordinates)], stages)[0]
+def _one(elements, coordinates, stages, params=None):
+    return engine.analyse([(elements, coordinates)], stages, params=params)[0]
 
 
 def molecular_weight(elements) -> float:
@@ -69,16 +69,20 @@ def opt_pore_diameter(elements, coordinates, bounds=None, com=None):
 
 
 def find_average_diameter(elements, coordinates, adjust=1, processes=None) -> float:
-    """Reference utilities.py:1586-1650 (``adjust`` fixed at its default 1)."""
-    if adjust != 1:
-        raise NotImplementedError("adjust != 1 is not reachable from Molecule (SURVEY 5.6)")
-    return float(_one(elements, coordinates, _lib.STAGE_AVG)["avg_d"])
+    """Reference utilities.py:1586-1650; ``adjust`` scales the number of sampling rays.
+    ``processes`` is accepted and ignored (there is no CPU pool)."""
+    del processes
+    params = None if adjust == 1 else _lib.Params(adjust_average=adjust)
+    return float(_one(elements, coordinates, _lib.STAGE_AVG, params)["avg_d"])
 
 
 def find_windows(elements, coordinates, processes=None, adjust=1, pore_opt=True, increment=1.0):
-    """Reference utilities.py:1364-1553 with the knobs ``Molecule`` uses."""
-    if adjust != 1 or pore_opt is not True or increment != 1.0:
-        raise NotImplementedError("non-default find_windows knobs are not reachable from Molecule")
-    r = _one(elements, coordinates, _lib.STAGE_WINDOWS)
+    """Reference utilities.py:1364-1553.  ``adjust`` scales the number of sampling vectors,
+    ``pore_opt`` centres the molecule on the optimised pore (``is True``, like the reference)
+    or on its centre of mass, ``increment`` is the step of the coarse path scan."""
+    del processes
+    default = adjust == 1 and pore_opt is True and increment == 1.0
+    params = None if default else _lib.Params(adjust_windows=adjust, pore_opt=pore_opt is True, increment=increment)
+    r = _one(elements, coordinates, _lib.STAGE_WINDOWS, params)
     engine.warn_like_reference(r)
     return engine.windows_of(r)

@@ -464,8 +464,55 @@ def periodic_cases():
     )
 
 
+#: (adjust, pore_opt, increment) for find_windows; adjust for find_average_diameter
+WINDOW_OPTIONS = [(2.0, True, 1.0), (0.5, True, 1.0), (1, False, 1.0), (1, True, 0.5), (1.5, False, 0.7)]
+AVERAGE_OPTIONS = [0.5, 2.0, 1.3]
+
+
+def options_unit(args):
+    """find_windows / find_average_diameter of the reference with non-default knobs
+    (utilities.py:1364-1371, 1586-1591) on one molecule."""
+    elements, coords = args
+    load_reference()
+    from pywindow._internal import utilities as U
+
+    elements = np.array(elements)
+    n_win = np.full(len(WINDOW_OPTIONS), -1, np.int64)
+    win_d = np.zeros((len(WINDOW_OPTIONS), W_MAX))
+    win_c = np.zeros((len(WINDOW_OPTIONS), W_MAX, 3))
+    for k, (adjust, pore_opt, increment) in enumerate(WINDOW_OPTIONS):
+        res = U.find_windows(elements, np.array(coords), adjust=adjust, pore_opt=pore_opt, increment=increment)
+        if res is not None:
+            n_win[k] = len(res[0])
+            win_d[k, : len(res[0])] = res[0]
+            win_c[k, : len(res[0])] = res[1]
+    avg = np.array([U.find_average_diameter(elements, np.array(coords), adjust=a) for a in AVERAGE_OPTIONS])
+    return n_win, win_d, win_c, avg
+
+
+def run_options(pool):
+    n, e, x = static_cases()
+    pick = [n.index(k) for k in ("cc3", "windows_case_2", "windows_case_3", "windows_case_4")]
+    n2, e2, x2 = md20_cases()
+    names = [n[i] for i in pick] + [n2[3]]
+    els = [list(e[i]) for i in pick] + [list(e2[3])]
+    xyz = [np.array(x[i], float) for i in pick] + [np.array(x2[3], float)]
+    res = pool.map(options_unit, list(zip(els, xyz)))
+    off = np.concatenate([[0], np.cumsum([len(q) for q in els])])
+    np.savez_compressed(
+        HERE / "options.npz",
+        names=np.array(names), atom_offset=off, elements=np.concatenate([np.array(q) for q in els]),
+        coordinates=np.concatenate(xyz),
+        window_options=np.array([[a, float(p), i] for a, p, i in WINDOW_OPTIONS]),
+        average_options=np.array(AVERAGE_OPTIONS),
+        n_windows=np.array([r[0] for r in res]), win_d=np.array([r[1] for r in res]),
+        win_c=np.array([r[2] for r in res]), avg_d=np.array([r[3] for r in res]),
+    )
+    print("options:", names, [r[0].tolist() for r in res])
+
+
 def main():
-    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base"}
+    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options"}
     if "cc3base" in which:
         load_reference()
         import tests.test_validate_cc3 as C
@@ -491,6 +538,8 @@ def main():
         if "periodic" in which:
             n, e, x = periodic_cases()
             run_group("periodic8", n, e, x, {0}, pool)
+        if "options" in which:
+            run_options(pool)
     meta = {
         "generator": "tests/golden/make_golden.py",
         "reference": "marcinmiklitz/pywindow @ /root/reference (imported with rdkit stub)",

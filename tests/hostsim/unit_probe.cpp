@@ -8,7 +8,10 @@
 #include <string.h>
 using namespace pw;
 extern "C" int hs_analysis_batch(long n_units, const long* off, const double* xyz, const double* vdw,
-                                 const double* mass, unsigned stages, pw_unit_out* out) {
+                                 const double* mass, unsigned stages, pw_unit_out* out,
+                                 const pw_params* params) {
+    pw_params prm = default_params();
+    if (params) prm = *params;
     int nmax = 0;
     for (long u = 0; u < n_units; ++u) { int n = (int)(off[u + 1] - off[u]); if (n > nmax) nmax = n; }
     size_t bytes = UnitShared::bytes(nmax, 1, 1);
@@ -22,7 +25,7 @@ extern "C" int hs_analysis_batch(long n_units, const long* off, const double* xy
         sh.carve(lds, nmax, 1, 1);
         int n = (int)(off[u + 1] - off[u]);
         memset(&out[u], 0, sizeof(pw_unit_out));
-        analyse_unit<HostTeam>(sh, ws, n, xyz + 3 * off[u], vdw + off[u], mass + off[u], stages, &out[u]);
+        analyse_unit<HostTeam>(sh, ws, n, xyz + 3 * off[u], vdw + off[u], mass + off[u], stages, &out[u], prm);
     }
     free(ws->adj); free(lds); free(ws);
     return 0;

@@ -20,7 +20,7 @@ def run_hostsim(hostsim, g, stages=15):
     rc = L.hs_analysis_batch(ctypes.c_long(len(off) - 1), off.ctypes.data_as(ctypes.c_void_p),
                              xyz.ctypes.data_as(ctypes.c_void_p), vdw.ctypes.data_as(ctypes.c_void_p),
                              mass.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(stages),
-                             out.ctypes.data_as(ctypes.c_void_p))
+                             out.ctypes.data_as(ctypes.c_void_p), None)
     assert rc == 0
     return out
 
