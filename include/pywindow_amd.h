@@ -141,6 +141,49 @@ int64_t pw_resident_units(pw_resident *res);
 /* the HIP stream (hipStream_t) launches are issued on, as an opaque pointer */
 void *pw_context_stream(pw_context *ctx);
 
+/* ---- periodic pre-processing ---------------------------------------------
+ * create_supercell (utilities.py:768-810) + discrete_molecules (utilities.py:820-1085) as
+ * driven by MolecularSystem.rebuild_system / make_modular (molecular.py:672-708, 798-824):
+ * split every frame of a system into discrete molecules; with `rebuild`, molecules wrapped
+ * across the cell faces are re-assembled from the 3x3x3 supercell and the copies whose
+ * centre of mass lies outside the cell are dropped.  Atom order inside each molecule and
+ * the order of the molecules are the reference's.  One topology (covalent radii, masses,
+ * terminal flags) for all frames; coordinates and lattice per frame. */
+typedef struct pw_cell_in {
+    int64_t n_frames;
+    int32_t n_atoms;           /* atoms per frame */
+    int32_t rebuild;           /* 1: rebuild through the periodic boundary (needs lattice) */
+    const double *xyz;         /* n_frames x n_atoms x 3, as loaded (not rounded) */
+    const double *lattice;     /* n_frames x 9 row-major lattice matrices; NULL = non-periodic */
+    const double *lattice_inv; /* n_frames x 9: numpy.linalg.inv(lattice), utilities.py:726 */
+    const double *cov;         /* n_atoms: atomic_covalent_radius[element] (tables.py:200-286) */
+    const double *mass;        /* n_atoms */
+    const uint8_t *terminal;   /* n_atoms: 1 if the element ends a bond path (utilities.py:943) */
+    double max_dist;           /* 2 * max covalent radius present + tol (utilities.py:949-953) */
+    double tol;                /* bond tolerance, 0.4 */
+} pw_cell_in;
+
+#define PW_RB_NB_OVERFLOW 1     /* more than 32 atoms within max_dist of one atom */
+#define PW_RB_SEG_OVERFLOW 2    /* more than 32 bonded neighbours of one atom */
+#define PW_RB_ATOMS_OVERFLOW 4  /* atoms_cap too small (retry with a larger one) */
+#define PW_RB_MOLS_OVERFLOW 8   /* mols_cap too small */
+#define PW_RB_THIN_CELL 16      /* a cell height is below max_dist */
+
+typedef struct pw_cell_out {   /* caller-allocated */
+    int32_t atoms_cap;         /* output atoms per frame */
+    int32_t mols_cap;          /* output molecules per frame */
+    int32_t *n_mol;            /* n_frames */
+    int32_t *status;           /* n_frames: PW_RB_* bits */
+    int32_t *mol_offset;       /* n_frames x (mols_cap + 1): atoms of molecule m are [off[m], off[m+1]) */
+    int32_t *src_atom;         /* n_frames x atoms_cap: index of the input atom */
+    int8_t *src_image;         /* n_frames x atoms_cap: -1 = the input atom itself, else image 0..26
+                                  (a, b, c nested, 13 = the cell) */
+    double *xyz;               /* n_frames x atoms_cap x 3: coordinates rounded to 8 decimals */
+} pw_cell_out;
+
+int pw_discrete_molecules(pw_context *ctx, const pw_cell_in *in, const pw_cell_out *out);
+int pw_context_device(pw_context *ctx);
+
 /* Native DL_POLY HISTORY ingest (trajectory.py:647-766): see pw_history_* in
  * pywindow_amd/csrc/pw_history.cpp */
 typedef struct pw_history pw_history;

@@ -84,3 +84,46 @@ double pwo_max_dim(int64_t n, const double *xyz, const double *xx, const double 
     *oi = bi; *oj = bj;
     return best;
 }
+
+/* ---- periodic pre-processing (oracle/pw_rebuild.py) ------------------------------------ */
+
+/* distances of n atoms to one point (N x 1 call shape), utilities.py:984, 1001 */
+void pwo_dists(int64_t n, const double *xyz, const double *xx, const double *p, double *out) {
+    double pp = sqnorm3(p);
+    for (int64_t i = 0; i < n; ++i) out[i] = dist_point(xyz + 3 * i, xx[i], p, pp);
+}
+
+/* numpy (3,3) matrix times (3,1) column as np.matrix.__mul__ evaluates it through
+ * OpenBLAS (utilities.py:727-729, 738-740): y_i = fma(m_i2, x2, fma(m_i0, x0, m_i1 * x1));
+ * established against numpy on random inputs (tests/test_rebuild.py). */
+void pwo_mat3_apply(const double *m, int64_t n, const double *x, double *y) {
+    for (int64_t k = 0; k < n; ++k) {
+        const double *v = x + 3 * k;
+        for (int i = 0; i < 3; ++i)
+            y[3 * k + i] = fma(m[3 * i + 2], v[2], fma(m[3 * i + 0], v[0], m[3 * i + 1] * v[1]));
+    }
+}
+
+/* Python's round(float, 8) (utilities.py:191-193, 203-205): the decimal expansion of the
+ * double, correctly rounded (half-even) at 8 places, converted back correctly rounded.
+ * p = x * 1e8 is inexact; fma gives its exact residual, which settles the tie cases.
+ * Valid for |x| < 4.5e7 (2^52 / 1e8). */
+double pwo_round8_one(double x) {
+    double p = x * 1e8;
+    if (!(fabs(p) < 4503599627370496.0)) return x;
+    double e = fma(x, 1e8, -p);
+    double f = floor(p);
+    double r = p - f;
+    double k;
+    if (r < 0.5) k = f;
+    else if (r > 0.5) k = f + 1.0;
+    else if (e > 0.0) k = f + 1.0;
+    else if (e < 0.0) k = f;
+    else k = (fmod(f, 2.0) == 0.0) ? f : f + 1.0;
+    /* r < 0.5 but p + e may still cross down to an integer boundary only when r == 0:
+     * p integral and e < 0 means the true value is just below p: still rounds to p */
+    return k / 1e8;
+}
+void pwo_round8(int64_t n, const double *in, double *out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = pwo_round8_one(in[i]);
+}

@@ -59,6 +59,42 @@ class Params(ctypes.Structure):
         super().__init__(float(adjust_windows), float(adjust_average), float(increment), 1 if pore_opt else 0, 0)
 
 
+class CellIn(ctypes.Structure):
+    """``pw_cell_in``: frames of one system for ``pw_discrete_molecules``."""
+
+    _fields_ = [
+        ("n_frames", ctypes.c_int64),
+        ("n_atoms", ctypes.c_int32),
+        ("rebuild", ctypes.c_int32),
+        ("xyz", ctypes.c_void_p),
+        ("lattice", ctypes.c_void_p),
+        ("lattice_inv", ctypes.c_void_p),
+        ("cov", ctypes.c_void_p),
+        ("mass", ctypes.c_void_p),
+        ("terminal", ctypes.c_void_p),
+        ("max_dist", ctypes.c_double),
+        ("tol", ctypes.c_double),
+    ]
+
+
+class CellOut(ctypes.Structure):
+    """``pw_cell_out``: caller-allocated result arrays of ``pw_discrete_molecules``."""
+
+    _fields_ = [
+        ("atoms_cap", ctypes.c_int32),
+        ("mols_cap", ctypes.c_int32),
+        ("n_mol", ctypes.c_void_p),
+        ("status", ctypes.c_void_p),
+        ("mol_offset", ctypes.c_void_p),
+        ("src_atom", ctypes.c_void_p),
+        ("src_image", ctypes.c_void_p),
+        ("xyz", ctypes.c_void_p),
+    ]
+
+
+RB_ATOMS_OVERFLOW = 4
+RB_MOLS_OVERFLOW = 8
+
 #: numpy mirror of ``pw_unit_out`` (natural C alignment)
 UNIT_OUT_DTYPE = np.dtype(
     [
@@ -115,6 +151,8 @@ EXPORTED_SYMBOLS = [
     "pw_resident_device_results",
     "pw_resident_units",
     "pw_context_stream",
+    "pw_context_device",
+    "pw_discrete_molecules",
     "pw_history_open",
     "pw_history_frames",
     "pw_history_atoms",
@@ -171,6 +209,8 @@ def load():
     L.pw_resident_units.restype = ctypes.c_int64
     L.pw_context_stream.argtypes = [vp]
     L.pw_context_stream.restype = vp
+    L.pw_context_device.argtypes = [vp]
+    L.pw_discrete_molecules.argtypes = [vp, ctypes.POINTER(CellIn), ctypes.POINTER(CellOut)]
     L.pw_history_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
     L.pw_history_frames.argtypes = [vp]
     L.pw_history_frames.restype = ctypes.c_int64
@@ -280,6 +320,44 @@ class Context:
             "pw_point_gaps",
         )
         return gap, arg
+
+    def discrete_molecules(self, topology, coords, lattice, lattice_inv, rebuild: bool, atoms_cap=None):
+        """``pw_discrete_molecules`` on F frames of one topology (see pywindow_amd/rebuild.py).
+        Returns ``(n_mol, mol_offset, src_atom, src_image, xyz, status)``; output capacity grows
+        automatically when a frame reports an overflow."""
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        f, n, _ = coords.shape
+        if n != topology.n:
+            raise ValueError("coordinates do not match the topology")
+        cap = int(atoms_cap) if atoms_cap else (2 * n if rebuild else n)
+        mols = min(cap, n)
+        for _attempt in range(6):
+            n_mol = np.zeros(f, np.int32)
+            status = np.zeros(f, np.int32)
+            off = np.zeros((f, mols + 1), np.int32)
+            src = np.zeros((f, cap), np.int32)
+            img = np.zeros((f, cap), np.int8)
+            xyz = np.zeros((f, cap, 3))
+            cin = CellIn(f, n, 1 if rebuild else 0, coords.ctypes.data,
+                         None if lattice is None else lattice.ctypes.data,
+                         None if lattice_inv is None else lattice_inv.ctypes.data,
+                         topology.cov.ctypes.data, topology.mass.ctypes.data, topology.terminal.ctypes.data,
+                         topology.max_dist, topology.tol)
+            cout = CellOut(cap, mols, n_mol.ctypes.data, status.ctypes.data, off.ctypes.data, src.ctypes.data,
+                           img.ctypes.data, xyz.ctypes.data)
+            _check(load().pw_discrete_molecules(self._h, ctypes.byref(cin), ctypes.byref(cout)),
+                   "pw_discrete_molecules")
+            if not (status & (RB_ATOMS_OVERFLOW | RB_MOLS_OVERFLOW)).any():
+                break
+            cap *= 4
+            mols = min(cap, 4 * mols)
+        else:
+            raise PwHipError("pw_discrete_molecules: output does not fit (molecule larger than 2048 x the cell?)")
+        bad = status & ~(RB_ATOMS_OVERFLOW | RB_MOLS_OVERFLOW)
+        if bad.any():
+            raise PwHipError(f"pw_discrete_molecules: unsupported input (status bits {int(np.bitwise_or.reduce(bad))}: "
+                             "1/2 = more than 32 neighbours of one atom, 16 = cell thinner than the bond cut-off)")
+        return n_mol, off, src, img, xyz
 
     def upload(self, batch: Batch) -> "Resident":
         return Resident(self, batch)

@@ -368,6 +368,9 @@ int pw_context_set_params(pw_context* c, const pw_params* p) {
     return PW_OK;
 }
 
+int pw_context_device(pw_context* c) { return c ? c->device : -1; }
+char* pw_internal_error_buffer(void) { return g_err; }
+
 void* pw_context_stream(pw_context* c) { return c ? (void*)c->stream : nullptr; }
 
 int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {

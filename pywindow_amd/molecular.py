@@ -205,6 +205,76 @@ class MolecularSystem:
         obj.system_id = system_id
         return obj
 
+    @classmethod
+    def load_file(cls, filepath) -> "MolecularSystem":
+        """Load an ``.xyz`` or ``.pdb`` file (reference molecular.py:596-623 with the readers of
+        io_tools.py:106-182; CRYST1 becomes ``unit_cell`` and ``lattice``)."""
+        import pathlib
+
+        from .rebuild import unit_cell_to_lattice_array
+
+        path = pathlib.Path(filepath)
+        lines = path.read_text().splitlines(keepends=True)
+        system: dict = {}
+        if path.suffix == ".xyz":
+            body = [ln.split() for ln in lines[2:]]
+            try:
+                system["elements"] = np.array([b[0] for b in body])
+                system["coordinates"] = np.array([[float(b[1]), float(b[2]), float(b[3])] for b in body])
+            except IndexError:
+                raise ValueError("The XYZ file is corrupted in some way (empty line at the end, or a trajectory).") from None
+        elif path.suffix == ".pdb":
+            if sum(ln.count("END ") for ln in lines) > 1:
+                raise ValueError("Multiple 'END' statements were found in this PDB file.")
+            atoms = [ln for ln in lines if ln[:6] in ("HETATM", "ATOM  ")]
+            system["remarks"] = [ln for ln in lines if ln[:6] == "REMARK"]
+            system["unit_cell"] = np.array([
+                float(x) for ln in lines if ln[:6] == "CRYST1"
+                for x in (ln[6:15], ln[15:24], ln[24:33], ln[33:40], ln[40:47], ln[47:54])
+            ])
+            if system["unit_cell"].any():
+                system["lattice"] = unit_cell_to_lattice_array(system["unit_cell"])
+            system["atom_ids"] = np.array([ln[12:16].strip() for ln in atoms], dtype="<U8")
+            system["elements"] = np.array([ln[76:78].strip() for ln in atoms], dtype="<U8")
+            system["coordinates"] = np.array([[float(ln[30:38]), float(ln[38:46]), float(ln[46:54])] for ln in atoms])
+        else:
+            raise ValueError(f"unsupported file type {path.suffix!r} (xyz and pdb are read natively)")
+        obj = cls()
+        obj.system = system
+        obj.filename = path.name
+        obj.system_id = path.name.split(".")[0]
+        return obj
+
+    def rebuild_system(self, override: bool = False) -> "MolecularSystem":
+        """Re-assemble the molecules of a periodic system through the cell faces
+        (reference molecular.py:672-708); the 3x3x3 supercell and the bonded-neighbour walk
+        run on the GPU (csrc/pw_rebuild.hpp)."""
+        from .rebuild import discrete_molecules
+
+        discrete = discrete_molecules(self.system, rebuild=True)
+        coordinates = np.array([], dtype=np.float64).reshape(0, 3)
+        atom_ids = np.array([])
+        elements = np.array([])
+        for mol in discrete:
+            coordinates = np.concatenate([coordinates, mol["coordinates"]], axis=0)
+            atom_ids = np.concatenate([atom_ids, mol["atom_ids"]], axis=0)
+            elements = np.concatenate([elements, mol["elements"]], axis=0)
+        rebuilt = {"coordinates": coordinates, "atom_ids": atom_ids, "elements": elements}
+        if override is True:
+            self.system.update(rebuilt)
+        return self.load_system(rebuilt)
+
+    def make_modular(self, rebuild: bool = False) -> None:
+        """Populate ``self.molecules`` with the discrete molecules of the system
+        (reference molecular.py:798-824)."""
+        from .rebuild import discrete_molecules
+
+        dis = discrete_molecules(self.system, rebuild=True if rebuild is True else None)
+        self.no_of_discrete_molecules = len(dis)
+        self.molecules = {}
+        for i in range(len(dis)):
+            self.molecules[i] = Molecule(dis[i], str(self.system_id), i)
+
     def swap_atom_keys(self, swap_dict: dict, dict_key: str = "atom_ids") -> None:
         """Reference molecular.py:710-749."""
         if "atom_ids" not in self.system:

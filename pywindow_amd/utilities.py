@@ -12,7 +12,8 @@ from __future__ import annotations
 import numpy as np
 
 from . import _lib, engine
-from .element_data import atomic_mass, atomic_vdw_radius  # noqa: F401  (re-exported)
+from .element_data import atomic_covalent_radius, atomic_mass, atomic_vdw_radius  # noqa: F401  (re-exported)
+from .rebuild import discrete_molecules, lattice_array_to_unit_cell, unit_cell_to_lattice_array  # noqa: F401
 
 
 def _one(elements, coordinates, stages, params=None):

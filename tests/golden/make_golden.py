@@ -511,8 +511,77 @@ def run_options(pool):
     print("options:", names, [r[0].tolist() for r in res])
 
 
+def rebuild_case(args):
+    """discrete_molecules / create_supercell of the reference (utilities.py:768-1085) on one system."""
+    name, system = args
+    load_reference()
+    from pywindow._internal import utilities as U
+
+    def flat(mols):
+        off = np.concatenate([[0], np.cumsum([len(m["elements"]) for m in mols])]).astype(np.int64)
+        if not mols:
+            return off, np.zeros((0, 3)), np.array([], dtype="<U8"), np.array([], dtype="<U8")
+        ids = np.concatenate([m["atom_ids"] for m in mols]) if "atom_ids" in mols[0] else np.array([], dtype="<U8")
+        return off, np.concatenate([m["coordinates"] for m in mols]), np.concatenate([m["elements"] for m in mols]), ids
+
+    out = {}
+    off, xyz, el, ids = flat(U.discrete_molecules(system))
+    out.update({"plain_offset": off, "plain_xyz": xyz, "plain_elements": el, "plain_ids": ids})
+    if "lattice" in system:
+        sc = U.create_supercell(system)
+        off, xyz, el, ids = flat(U.discrete_molecules(system, rebuild=sc))
+        out.update({"rebuild_offset": off, "rebuild_xyz": xyz, "rebuild_elements": el, "rebuild_ids": ids})
+    return name, out
+
+
+def run_rebuild(pool):
+    pw = load_reference()
+    cases = []
+
+    def add(name, system):
+        keep = {k: system[k] for k in ("elements", "atom_ids", "coordinates", "unit_cell", "lattice") if k in system}
+        if "unit_cell" in keep and not len(keep["unit_cell"]):
+            del keep["unit_cell"]
+        cases.append((name, keep))
+
+    base = pw.MolecularSystem.load_file(REF / "tests/data/system_periodic.pdb").system
+    add("cc3_cell", base)
+    # unit cell centred on the origin: the <-0.5, 0.5> boundary branch (utilities.py:925-929)
+    centred = dict(base)
+    centred["coordinates"] = base["coordinates"] - 12.4
+    add("cc3_cell_centred", centred)
+    # MD-like frames: Gaussian noise, quantised like a DL_POLY HISTORY record (BASELINE configs 3-4)
+    from pywindow_amd import synth
+
+    rebuilt = pw.MolecularSystem.load_file(REF / "tests/data/system_periodic_rebuild.pdb").system
+    for k in range(2):
+        noisy = dict(base)
+        # whole cages + noise, wrapped back into the cell so that cages cross the faces
+        xyz = synth.quantise_like_history(synth.noisy_frame(rebuilt["coordinates"], synth.SEED_BASE + 700000 + k, 0.10))
+        noisy["coordinates"] = xyz - 24.8 * np.floor(xyz / 24.8)
+        noisy["elements"] = rebuilt["elements"]
+        noisy["atom_ids"] = rebuilt["atom_ids"]
+        add(f"cc3_cell_md{k}", noisy)
+    for f in ("EPIRUR_no_solvent.pdb", "TATVER_no_solvent.pdb", "MIBQAR.pdb"):
+        add(f.split(".")[0].split("_")[0], pw.MolecularSystem.load_file(REF / "examples/data/input" / f).system)
+    add("cc3_molecule", pw.MolecularSystem.load_file(REF / "tests/data/system.pdb").system)
+    add("saygor", pw.MolecularSystem.load_file(REF / "examples/data/input/SAYGOR.pdb").system)
+    xyz_sys = pw.MolecularSystem.load_file(REF / "examples/data/input/PUDXES.xyz").system
+    add("pudxes_xyz", xyz_sys)
+    res = dict(pool.map(rebuild_case, cases))
+    arrays = {"names": np.array([c[0] for c in cases])}
+    for name, system in cases:
+        for k, v in system.items():
+            arrays[f"{name}__in_{k}"] = np.asarray(v)
+        for k, v in res[name].items():
+            arrays[f"{name}__{k}"] = v
+        print("rebuild", name, len(system["elements"]), "->", len(res[name]["plain_offset"]) - 1,
+              len(res[name].get("rebuild_offset", [0])) - 1)
+    np.savez_compressed(HERE / "rebuild.npz", **arrays)
+
+
 def main():
-    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options"}
+    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild"}
     if "cc3base" in which:
         load_reference()
         import tests.test_validate_cc3 as C
@@ -540,6 +609,8 @@ def main():
             run_group("periodic8", n, e, x, {0}, pool)
         if "options" in which:
             run_options(pool)
+        if "rebuild" in which:
+            run_rebuild(pool)
     meta = {
         "generator": "tests/golden/make_golden.py",
         "reference": "marcinmiklitz/pywindow @ /root/reference (imported with rdkit stub)",

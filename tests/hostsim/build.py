@@ -10,6 +10,7 @@ TARGETS = {
     "liblbprobe.so": "lbfgsb_probe.cpp",
     "libmathprobe.so": "math_probe.cpp",
     "libunitprobe.so": "unit_probe.cpp",
+    "librebuildprobe.so": "rebuild_probe.cpp",
 }
 
 

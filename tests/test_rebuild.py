@@ -1,0 +1,155 @@
+"""Periodic pre-processing: create_supercell + discrete_molecules
+(reference utilities.py:768-1085).  Golden outputs were produced by the reference itself
+(tests/golden/make_golden.py rebuild): CC3 cell as in tests/test_molecular.py:4467-4553 (33
+fragments / 8 rebuilt cages), the same cell centred on the origin, two noisy MD-like
+frames, a hexagonal and a triclinic cell, a framework that fills the supercell, and
+non-periodic inputs."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from _util import GOLDEN
+from pywindow_amd import rebuild as RB
+
+
+def load_cases():
+    g = np.load(GOLDEN / "rebuild.npz")
+    cases = {}
+    for name in g["names"]:
+        name = str(name)
+        system = {k.split("__in_")[1]: g[k] for k in g.files if k.startswith(f"{name}__in_")}
+        expect = {k.split("__")[1]: g[k] for k in g.files if k.startswith(f"{name}__") and "__in_" not in k}
+        cases[name] = (system, expect)
+    return cases
+
+
+CASES = load_cases()
+pytestmark = pytest.mark.filterwarnings("ignore::PendingDeprecationWarning")
+SMALL = ["cc3_cell", "cc3_cell_centred", "cc3_cell_md0", "EPIRUR", "TATVER", "cc3_molecule", "saygor", "pudxes_xyz"]
+
+
+def check_molecules(mols, expect, prefix, where):
+    off = expect[f"{prefix}_offset"]
+    assert len(mols) == len(off) - 1, f"{where}: {len(mols)} molecules, reference {len(off) - 1}"
+    for k, m in enumerate(mols):
+        lo, hi = off[k], off[k + 1]
+        assert np.array_equal(m["elements"], expect[f"{prefix}_elements"][lo:hi]), f"{where}: mol {k} elements"
+        assert np.array_equal(m["coordinates"], expect[f"{prefix}_xyz"][lo:hi]), f"{where}: mol {k} coordinates"
+        if "atom_ids" in m:
+            assert np.array_equal(m["atom_ids"], expect[f"{prefix}_ids"][lo:hi]), f"{where}: mol {k} atom ids"
+
+
+@pytest.mark.parametrize("name", SMALL + ["MIBQAR"])
+def test_oracle_matches_reference(name):
+    from oracle import pw_rebuild as R
+
+    system, expect = CASES[name]
+    check_molecules(R.discrete_molecules(system), expect, "plain", f"oracle/{name}")
+    if "rebuild_offset" in expect:
+        check_molecules(R.discrete_molecules(system, rebuild=R.create_supercell(system)), expect, "rebuild",
+                        f"oracle/{name}/rebuild")
+
+
+def test_oracle_primitives():
+    """The two arithmetic restatements the supercell rests on: numpy's 3x3 matrix-vector
+    product and Python's round(x, 8)."""
+    from oracle import pw_rebuild as R
+
+    rng = np.random.default_rng(5)
+    m = rng.normal(size=(3, 3)) * 10
+    pts = rng.normal(size=(400, 3)) * 20
+    ref = np.array([np.array(np.matrix(m) * p.reshape(-1, 1)).reshape(-1) for p in pts])
+    assert np.array_equal(R.mat3_apply(m, pts), ref)
+    k = rng.integers(-5e9, 5e9, 20000)
+    for x in (rng.normal(size=20000) * 30, (k + 0.5) / 1e8, np.nextafter((k + 0.5) / 1e8, np.inf), k / 1e8):
+        assert np.array_equal(R.round8(x), np.array([round(float(v), 8) for v in x]))
+
+
+def run_hostsim(hostsim, system, rebuild):
+    L = ctypes.CDLL(str(hostsim / "librebuildprobe.so"))
+    topo = RB.CellTopology(system["elements"])
+    lattice, periodic = RB.system_lattice(system)
+    if rebuild and lattice is None:
+        lattice = np.asarray(system["lattice"], float)
+    xyz, lat, inv = RB.pack_frames(np.asarray(system["coordinates"], float)[None], None if lattice is None else lattice[None])
+    n = topo.n
+    cap = 30 * n if rebuild else n
+    n_mol = ctypes.c_int()
+    status = ctypes.c_int()
+    off = np.zeros(cap + 1, np.int32)
+    src = np.zeros(cap, np.int32)
+    img = np.zeros(cap, np.int8)
+    oxyz = np.zeros((cap, 3))
+    vp = ctypes.c_void_p
+    rc = L.hs_discrete_molecules(
+        ctypes.c_int(n), xyz.ctypes.data_as(vp), None if lat is None else lat.ctypes.data_as(vp),
+        None if inv is None else inv.ctypes.data_as(vp), topo.cov.ctypes.data_as(vp), topo.mass.ctypes.data_as(vp),
+        topo.terminal.ctypes.data_as(vp), ctypes.c_double(topo.max_dist), ctypes.c_double(topo.tol),
+        ctypes.c_int(1 if rebuild else 0), ctypes.c_int(cap), ctypes.c_int(cap), ctypes.byref(n_mol),
+        ctypes.byref(status), off.ctypes.data_as(vp), src.ctypes.data_as(vp), img.ctypes.data_as(vp),
+        oxyz.ctypes.data_as(vp))
+    assert rc == 0
+    return RB.molecules_from_output(system, n_mol.value, off, src, oxyz), status.value
+
+
+@pytest.mark.parametrize("name", SMALL + ["MIBQAR"])
+def test_host_team_matches_reference(hostsim, name):
+    system, expect = CASES[name]
+    mols, status = run_hostsim(hostsim, system, False)
+    assert status == 0
+    check_molecules(mols, expect, "plain", f"hostsim/{name}")
+    if "rebuild_offset" in expect:
+        mols, status = run_hostsim(hostsim, system, True)
+        assert status == 0
+        check_molecules(mols, expect, "rebuild", f"hostsim/{name}/rebuild")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SMALL + ["cc3_cell_md1", "MIBQAR"])
+def test_hip_matches_reference(hip_ctx, name):
+    system, expect = CASES[name]
+    check_molecules(RB.discrete_molecules(dict(system)), expect, "plain", f"hip/{name}")
+    if "rebuild_offset" in expect:
+        check_molecules(RB.discrete_molecules(dict(system), rebuild=True), expect, "rebuild", f"hip/{name}/rebuild")
+
+
+@pytest.mark.gpu
+def test_hip_many_frames_one_launch(hip_ctx):
+    """Frames of one topology in one launch (BASELINE config 4 shape): each frame's result equals
+    the single-frame result; frame order does not matter."""
+    for names in (["cc3_cell", "cc3_cell_centred"], ["cc3_cell_md0", "cc3_cell_md1"]):
+        systems = [CASES[k][0] for k in names]
+        assert np.array_equal(systems[0]["elements"], systems[1]["elements"])
+        topo = RB.CellTopology(systems[0]["elements"])
+        reps = 300
+        coords = np.array([s["coordinates"] for s in systems] * reps)
+        lat = np.array([s["lattice"] for s in systems] * reps)
+        n_mol, off, src, img, xyz = RB.discrete_molecules_frames(topo, coords, lat, True)
+        for f in range(len(coords)):
+            system, expect = CASES[names[f % len(names)]]
+            mols = RB.molecules_from_output(system, n_mol[f], off[f], src[f], xyz[f])
+            check_molecules(mols, expect, "rebuild", f"hip/frame{f}")
+
+
+@pytest.mark.gpu
+def test_molecular_system_api(hip_ctx):
+    """MolecularSystem.rebuild_system / make_modular as the reference's tests use them
+    (tests/test_molecular.py:4467-4553)."""
+    import pywindow_amd as pw
+
+    system, expect = CASES["cc3_cell"]
+    ms = pw.MolecularSystem.load_system(dict(system), "periodic")
+    ms.make_modular()
+    assert len(ms.molecules) == 33
+    ms.make_modular(rebuild=True)
+    assert len(ms.molecules) == 8 and all(m.no_of_atoms == 168 for m in ms.molecules.values())
+    rebuilt = ms.rebuild_system()
+    assert np.array_equal(rebuilt.system["coordinates"], expect["rebuild_xyz"])
+    assert np.array_equal(rebuilt.system["elements"], expect["rebuild_elements"])
+    assert np.array_equal(rebuilt.system["atom_ids"], expect["rebuild_ids"])
+    rebuilt.make_modular()
+    assert len(rebuilt.molecules) == 8
+    # the rebuilt cages go straight into the analysis
+    props = ms.molecules[0].full_analysis()
+    assert props["windows"]["diameters"] is not None and len(props["windows"]["diameters"]) == 4
