@@ -49,15 +49,25 @@ def history_text(
     frames,
     title: str = "synthetic CC3 trajectory (pywindow_amd.synth)",
     tstep: float = 0.0007,
+    cell=None,
 ) -> str:
-    """Serialise frames (iterable of (N,3) arrays) as a keytrj=0/imcon=0 HISTORY."""
+    """Serialise frames (iterable of (N,3) arrays) as a keytrj=0 HISTORY; ``cell`` (3,3), rows =
+    cell vectors, makes it a periodic (imcon=1 cubic / 3 otherwise) trajectory."""
     elements = list(elements)
     natms = len(elements)
-    out = [title, "%10d%10d%10d" % (0, 0, natms)]
+    imcon = 0
+    if cell is not None:
+        cell = np.asarray(cell, dtype=float)
+        cubic = np.allclose(cell, np.diag(np.diag(cell))) and np.allclose(np.diag(cell), cell[0, 0])
+        imcon = 1 if cubic else 3
+    out = [title, "%10d%10d%10d" % (0, imcon, natms)]
     for k, xyz in enumerate(frames):
         out.append(
-            "timestep%10d%10d%10d%10d%12.6f" % (k + 1, natms, 0, 0, tstep)
+            "timestep%10d%10d%10d%10d%12.6f" % (k + 1, natms, 0, imcon, tstep)
         )
+        if cell is not None:
+            for row in cell:
+                out.append("%20.10f%20.10f%20.10f" % tuple(row))
         for i, el in enumerate(elements):
             out.append("%-8s%10d%12.6f%12.6f" % (el, i + 1, 0.0, 0.0))
             out.append(_fmt_e(xyz[i, 0]) + _fmt_e(xyz[i, 1]) + _fmt_e(xyz[i, 2]))

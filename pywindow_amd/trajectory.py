@@ -82,14 +82,34 @@ class DLPOLY:
             pass
 
     # ---- frame access ---------------------------------------------------------------
-    def read_coordinates(self, first: int, count: int) -> np.ndarray:
-        """(count, natoms, 3) float64, parsed natively."""
+    def read_coordinates(self, first: int, count: int, lattice: np.ndarray | None = None) -> np.ndarray:
+        """(count, natoms, 3) float64, parsed natively; ``lattice`` (count, 3, 3) receives the
+        lattice matrices in the reference's orientation (cell vectors as columns,
+        trajectory.py:724-726)."""
         xyz = np.empty((count, self.no_of_atoms, 3), dtype=np.float64)
         if count:
-            rc = _lib.load().pw_history_read(self._h, first, count, xyz.ctypes.data, None)
+            rc = _lib.load().pw_history_read(self._h, first, count, xyz.ctypes.data,
+                                             None if lattice is None else lattice.ctypes.data)
             if rc != 0:
                 raise _TrajectoryError(f"cannot decode frames {first}..{first + count - 1} (code {rc})")
         return xyz
+
+    @property
+    def periodic(self) -> bool:
+        return self.periodic_boundary in ("cubic", "orthorhombic", "parallelepiped")
+
+    def _read_selected(self, frames: list[int], want_lattice: bool):
+        """Coordinates (and lattices) of arbitrary frames; contiguous runs are one native call."""
+        coords = np.empty((len(frames), self.no_of_atoms, 3))
+        lattice = np.zeros((len(frames), 3, 3)) if want_lattice else None
+        i = 0
+        while i < len(frames):
+            j = i
+            while j + 1 < len(frames) and frames[j + 1] == frames[j] + 1:
+                j += 1
+            coords[i : j + 1] = self.read_coordinates(frames[i], j - i + 1, None if lattice is None else lattice[i : j + 1])
+            i = j + 1
+        return coords, lattice
 
     def elements(self, swap_atoms: dict | None = None, forcefield: str | None = None) -> np.ndarray:
         """Elements for every atom: swap keys, then decipher (reference
@@ -107,8 +127,14 @@ class DLPOLY:
         el = self.elements(swap_atoms, forcefield)
         out = {}
         for f in sel:
-            xyz = self.read_coordinates(f, 1)[0]
+            lat = np.zeros((1, 3, 3)) if self.periodic else None
+            xyz = self.read_coordinates(f, 1, lat)[0]
             sysd = {"atom_ids": self.atom_ids.copy(), "coordinates": xyz, "elements": el.copy()}
+            if lat is not None:
+                from .rebuild import lattice_array_to_unit_cell
+
+                sysd["lattice"] = lat[0]
+                sysd["unit_cell"] = lattice_array_to_unit_cell(lat[0])
             out[f] = MolecularSystem.load_system(sysd, f"{self.system_id}_{f}")
             self.frames[f] = out[f]
         if isinstance(frames, int):
@@ -163,14 +189,16 @@ class DLPOLY:
         """``full_analysis`` of every selected frame in one launch per GPU.
 
         ``ncpus`` / ``ncpus_analysis`` are accepted for API compatibility and
-        ignored (there is no CPU path).  ``modular`` / ``rebuild`` (splitting a
-        periodic cell into molecules) are outside the accelerated path.
-        Results land in ``analysis_output[frame]["0"]`` exactly like the
-        reference's non-modular branch (trajectory.py:515-522).
+        ignored (there is no CPU path).  Results land in ``analysis_output[frame]["0"]``
+        exactly like the reference's non-modular branch (trajectory.py:515-522).  With
+        ``modular=True`` every frame is first split into discrete molecules
+        (``rebuild=True``: re-assembled through the periodic boundary) by
+        ``pw_discrete_molecules`` -- all frames in one launch -- and the results are keyed by
+        the molecule index ``0..k-1`` (trajectory.py:512-514).
         """
         del ncpus, ncpus_analysis
-        if modular or rebuild:
-            raise NotImplementedError("modular/rebuild pre-processing is outside the accelerated path")
+        if modular is True:
+            return self._analysis_modular(frames, override, rebuild is True, swap_atoms, forcefield, device, distributed)
         sel = self._select(frames)
         if not override:
             sel = [f for f in sel if f not in self.analysis_output]
@@ -179,17 +207,7 @@ class DLPOLY:
         el = self.elements(swap_atoms, forcefield)
         ids = element_ids(el)
         vdw, mass = VDW[ids], MASS[ids]
-        rank, world = 0, 1
-        dist = None
-        if distributed is not False:
-            try:
-                import torch.distributed as dist_mod
-
-                if dist_mod.is_available() and dist_mod.is_initialized():
-                    dist = dist_mod
-                    rank, world = dist.get_rank(), dist.get_world_size()
-            except ImportError:
-                dist = None
+        dist, rank, world = _dist_state(distributed)
         lo, hi = shard_range(len(sel), rank, world)
         mine = sel[lo:hi]
         recs = self._run(mine, vdw, mass, device)
@@ -204,17 +222,101 @@ class DLPOLY:
     def _run(self, frames: list[int], vdw, mass, device):
         if not frames:
             return np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE)
-        # contiguous runs are read with one native call each
-        coords = np.empty((len(frames), self.no_of_atoms, 3))
-        i = 0
-        while i < len(frames):
-            j = i
-            while j + 1 < len(frames) and frames[j + 1] == frames[j] + 1:
-                j += 1
-            coords[i : j + 1] = self.read_coordinates(frames[i], j - i + 1)
-            i = j + 1
+        coords, _ = self._read_selected(frames, False)
         batch = _lib.Batch.uniform(coords, vdw, mass)
         return engine.context(device).analyse(batch, _lib.STAGE_ALL)
+
+    # ---- modular analysis: frames -> discrete molecules -> units --------------------------------
+    def modular_records(self, frames="all", rebuild: bool = False, swap_atoms=None, forcefield=None, device=None):
+        """Columnar form of the modular analysis for the selected frames of THIS process:
+        ``(records, unit_frame, unit_molecule)``; ``records[k]`` belongs to molecule
+        ``unit_molecule[k]`` of frame ``unit_frame[k]``."""
+        return self._run_modular(self._select(frames), rebuild, self.elements(swap_atoms, forcefield), device)
+
+    def _run_modular(self, frames: list[int], rebuild: bool, el, device):
+        from . import rebuild as rb
+
+        if not frames:
+            return np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE), np.zeros(0, np.int64), np.zeros(0, np.int64)
+        if rebuild and not self.periodic:
+            raise KeyError("lattice")   # create_supercell needs the cell (utilities.py:776-779)
+        ids = element_ids(el)
+        topo = rb.CellTopology(el)
+        coords, lattice = self._read_selected(frames, self.periodic)
+        n_mol, off, src, _img, xyz = rb.discrete_molecules_frames(topo, coords, lattice, rebuild, device)
+        # every molecule of every frame becomes one unit of ONE analysis launch
+        counts = [np.diff(off[f][: n_mol[f] + 1]) for f in range(len(frames))]
+        sizes = np.concatenate(counts) if counts else np.zeros(0, np.int64)
+        atom_offset = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        take = [slice(0, int(off[f][n_mol[f]])) for f in range(len(frames))]
+        flat_xyz = np.concatenate([xyz[f][take[f]] for f in range(len(frames))])
+        flat_src = np.concatenate([src[f][take[f]] for f in range(len(frames))])
+        batch = _lib.Batch(atom_offset, flat_xyz, VDW[ids][flat_src], MASS[ids][flat_src])
+        recs = engine.context(device).analyse(batch, _lib.STAGE_ALL)
+        unit_frame = np.repeat(np.asarray(frames, np.int64), n_mol)
+        unit_mol = np.concatenate([np.arange(k) for k in n_mol]).astype(np.int64)
+        return recs, unit_frame, unit_mol
+
+    def _analysis_modular(self, frames, override, rebuild, swap_atoms, forcefield, device, distributed):
+        sel = self._select(frames)
+        if not override:
+            sel = [f for f in sel if f not in self.analysis_output]
+        if not sel:
+            return
+        el = self.elements(swap_atoms, forcefield)
+        dist, rank, world = _dist_state(distributed)
+        lo, hi = shard_range(len(sel), rank, world)
+        recs, uframe, umol = self._run_modular(sel[lo:hi], rebuild, el, device)
+        if dist is not None and world > 1:
+            tags = np.stack([uframe, umol], axis=1).astype(np.int64)
+            recs = gather_ragged(recs, rank, world, dist)
+            tags = gather_ragged(tags.reshape(-1), rank, world, dist)
+            if rank != 0:
+                return
+            tags = tags.reshape(-1, 2)
+            uframe, umol = tags[:, 0], tags[:, 1]
+        for f in sel:
+            self.analysis_output[f] = {}
+        for rec, f, m in zip(recs, uframe, umol):
+            engine.warn_like_reference(rec)
+            self.analysis_output[int(f)][int(m)] = engine.record_to_properties(rec)
+
+
+def _dist_state(distributed):
+    """(torch.distributed module or None, rank, world) for an initialised process group."""
+    if distributed is False:
+        return None, 0, 1
+    try:
+        import torch.distributed as dist_mod
+
+        if dist_mod.is_available() and dist_mod.is_initialized():
+            return dist_mod, dist_mod.get_rank(), dist_mod.get_world_size()
+    except ImportError:
+        pass
+    return None, 0, 1
+
+
+def gather_ragged(local: np.ndarray, rank: int, world: int, dist) -> np.ndarray:
+    """Concatenate per-rank arrays of different lengths on rank 0 (rank order): one
+    ``all_gather`` of the lengths, one of the padded payloads."""
+    import torch
+
+    backend = dist.get_backend()
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    raw = np.ascontiguousarray(local).view(np.uint8).reshape(-1)
+    size = torch.tensor([raw.size], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    sizes = [int(s.item()) for s in sizes]
+    buf = np.zeros(max(max(sizes), 1), dtype=np.uint8)
+    buf[: raw.size] = raw
+    send = torch.from_numpy(buf).to(dev)
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send)
+    if rank != 0:
+        return np.zeros(0, dtype=local.dtype)
+    parts = [recv[r].cpu().numpy()[: sizes[r]] for r in range(world)]
+    return np.concatenate(parts).view(local.dtype)
 
 
 def gather_records(local: np.ndarray, n_total: int, rank: int, world: int, dist) -> np.ndarray:

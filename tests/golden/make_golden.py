@@ -580,8 +580,70 @@ def run_rebuild(pool):
     np.savez_compressed(HERE / "rebuild.npz", **arrays)
 
 
+def ptraj_frame(args):
+    """Reference DLPOLY.analysis(modular=True, rebuild=True) on one frame of a periodic
+    HISTORY file (trajectory.py:496-522)."""
+    path, frame = args
+    pw = load_reference()
+    traj = pw.DLPOLY(path)
+    try:
+        traj.analysis(frames=[frame], modular=True, rebuild=True, forcefield="opls")
+    except ValueError as exc:   # a bond stretched by the noise leaves a fragment with a negative pore
+        return frame, str(exc)
+    res = traj.analysis_output[frame]
+    rows = []
+    for m in sorted(res):
+        p = res[m]
+        w = p["windows"]["diameters"]
+        wd = np.zeros(W_MAX)
+        nw = -1
+        if w is not None:
+            nw = len(w)
+            wd[:nw] = np.sort(w)
+        rows.append([m, p["no_of_atoms"], *p["centre_of_mass"], p["maximum_diameter"]["diameter"],
+                     p["average_diameter"], p["pore_diameter"]["diameter"], p["pore_diameter_opt"]["diameter"],
+                     nw, *wd])
+    return frame, np.array(rows, dtype=float)
+
+
+def run_ptraj(pool):
+    """Two MD-like frames of the periodic CC3 cell as a DL_POLY HISTORY (imcon=1)."""
+    import tempfile
+
+    from pywindow_amd import synth
+
+    pwr = load_reference()
+    rebuilt = pwr.MolecularSystem.load_file(REF / "tests/data/system_periodic_rebuild.pdb").system
+    elements = rebuilt["elements"]
+    frames = []
+    for k in range(1, 7):   # same recipe as the rebuild group's MD-like frames
+        xyz = synth.quantise_like_history(synth.noisy_frame(rebuilt["coordinates"], synth.SEED_BASE + 700000 + k, 0.10))
+        frames.append(xyz - 24.8 * np.floor(xyz / 24.8))
+    cell = np.diag([24.8, 24.8, 24.8])
+    text = synth.history_text(elements, frames, title="periodic CC3 cell (pywindow_amd.synth)", cell=cell)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = pathlib.Path(tmp) / "HISTORY_periodic"
+        path.write_text(text)
+        pw = load_reference()
+        traj = pw.DLPOLY(path)
+        res = dict(pool.map(ptraj_frame, [(path, f) for f in range(len(frames))]))
+        good = [f for f in range(len(frames)) if not isinstance(res[f], str)][:2]
+        print("ptraj frames:", {f: (res[f] if isinstance(res[f], str) else res[f].shape) for f in res}, "kept", good)
+        parsed = [traj._get_frame(traj.trajectory_map[f], f, forcefield="opls").system for f in good]
+    frames = [frames[f] for f in good]
+    res = {k: res[f] for k, f in enumerate(good)}
+    np.savez_compressed(
+        HERE / "ptraj.npz", elements=elements, cell=cell, frames=np.array(frames),
+        parsed_coordinates=np.array([p["coordinates"] for p in parsed]), parsed_lattice=np.array([p["lattice"] for p in parsed]),
+        columns=np.array(["mol", "n_atoms", "com_x", "com_y", "com_z", "maxd", "avg_d", "pore_d", "pore_opt_d", "n_windows"]
+                         + [f"win_d{k}" for k in range(W_MAX)]),
+        frame0=res[0], frame1=res[1],
+    )
+    print("ptraj:", res[0].shape, res[1].shape)
+
+
 def main():
-    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild"}
+    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj"}
     if "cc3base" in which:
         load_reference()
         import tests.test_validate_cc3 as C
@@ -611,6 +673,8 @@ def main():
             run_options(pool)
         if "rebuild" in which:
             run_rebuild(pool)
+        if "ptraj" in which:
+            run_ptraj(pool)
     meta = {
         "generator": "tests/golden/make_golden.py",
         "reference": "marcinmiklitz/pywindow @ /root/reference (imported with rdkit stub)",
