@@ -24,7 +24,7 @@ FRAMES = 1000
 ALGO_BYTES_PER_UNIT = 24 * 168 + 600   # coordinates read once + one result record
 ALGO_FLOP_PER_UNIT = 2.0e7
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01b_hbm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01c_hbm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 
@@ -101,6 +101,15 @@ def main():
         value = world * args.frames * args.steps / elapsed
         # kernel duration measured with HIP events on the launch stream
         k_ms = res.time_launches(max(3, min(args.steps, 10)))
+        # one launch on its own (no overlap with a neighbour): the latency of a single batch
+        lat = []
+        for _ in range(3):
+            res.sync()
+            t1 = time.perf_counter()
+            res.launch()
+            res.sync()
+            lat.append(1e3 * (time.perf_counter() - t1))
+        single_ms = min(lat)
         units_per_s = args.frames / (k_ms * 1e-3)
         achieved_gbs = units_per_s * ALGO_BYTES_PER_UNIT / 1e9
         traffic = None
@@ -118,10 +127,11 @@ def main():
             "config": {"workload": "CC3 1000-frame synthetic DL_POLY trajectory (BASELINE configs[1]), "
                                    "per-frame pore+windows, 168 atoms/frame",
                        "frames_per_gpu": args.frames, "stages": "all", "results_ok": ok,
+                       "successive_steps_overlap": True, "single_step_latency_ms": single_ms,
                        "windows_eq_4": int((out["n_windows"] == 4).sum())},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "fabric bytes per launch from rocprofv3 PMC (profiles/r01b_hbm_traffic.json); "
+                         "traffic_note": "fabric bytes per launch from rocprofv3 PMC (profiles/r01c_hbm_traffic.json); "
                                          "includes Infinity-Cache hits on the re-used per-team workspaces",
                          "kernel": "pw_analyse_kernel (pipeline: optimiser chains | average diameter | window search)", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_UNIT * args.frames,

@@ -179,9 +179,17 @@ struct pw_context {
     UnitQueue* queue;
     int* slots;
     long slots_cap;
-    hipStream_t prod;        // optimiser launch of the overlapped pipeline
-    hipEvent_t ev_prod, ev_gate;
-    hipEvent_t ev0, ev1, ev_fork, ev_join;
+    hipStream_t prod;        // optimiser launch of the overlapped pipeline (this launch's of prods[])
+    hipStream_t prods[2];
+    // successive pipeline launches alternate between two sets of (result buffer, queue,
+    // slots, events), so the optimiser chains of launch k+1 run beside the window tail of k
+    hipEvent_t ev_reset[2], ev_prod[2], ev_gate[2], ev_join[2], ev_done[2];
+    int done_valid[2];
+    int flip;                // buffer set of the latest pipeline launch
+    int need_fork;           // main stream carries work the next pipeline launch must wait for
+    UnitQueue* cur_queue;
+    int* cur_slots;
+    hipEvent_t ev0, ev1, ev_fork;
     int fused;               // PW_FUSED=1: one launch per analysis instead of the pipeline
     int c_waves;             // waves per team in the window launch (PW_C_WAVES, default 4)
     pw_params prm;           // knobs of find_windows / find_average_diameter
@@ -195,7 +203,9 @@ struct pw_resident {
     double* d_xyz;
     double* d_vdw;
     double* d_mass;
-    pw_unit_out* d_out;
+    pw_unit_out* d_out;      // result records of the latest launch (= d_outs[cur])
+    pw_unit_out* d_outs[2];
+    int cur;
 };
 
 static int ensure_workspace(pw_context* c, int blocks, int adj_blocks) {
@@ -266,7 +276,7 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
                        r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb,
                        c->ws + ws_first, with_adj ? c->adj : (unsigned long long*)nullptr,
-                       c->counter + counter_slot, r->d_out, role, c->queue, c->slots, c->prm);
+                       c->counter + counter_slot, r->d_out, role, c->cur_queue, c->cur_slots, c->prm);
     HIP_TRY(hipGetLastError());
     return PW_OK;
 }
@@ -308,22 +318,31 @@ int pw_context_create(int device, pw_context** out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIP_TRY(hipMalloc((void**)&c->counter, 4 * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc((void**)&c->queue, sizeof(UnitQueue)));
+    HIP_TRY(hipMalloc((void**)&c->queue, 2 * sizeof(UnitQueue)));
+    HIP_TRY(hipMemset(c->queue, 0, 2 * sizeof(UnitQueue)));
+    c->cur_queue = c->queue;
     {
         // the optimiser chains are the critical path: their launch gets the highest priority,
         // the average-diameter launch the lowest
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIP_TRY(hipStreamCreateWithPriority(&c->prod, hipStreamNonBlocking, hi));
+        HIP_TRY(hipStreamCreateWithPriority(&c->prods[0], hipStreamNonBlocking, hi));
+        HIP_TRY(hipStreamCreateWithPriority(&c->prods[1], hipStreamNonBlocking, hi));
+        c->prod = c->prods[0];
         (void)hipStreamDestroy(c->aux);
         HIP_TRY(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, lo));
     }
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_prod, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming));
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_reset[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_prod[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_gate[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_join[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming));
+    }
+    c->need_fork = 1;
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     const char* fz = getenv("PW_FUSED");
     c->fused = (fz && fz[0] == '1') ? 1 : 0;
     const char* cw = getenv("PW_C_WAVES");
@@ -341,13 +360,18 @@ void pw_context_destroy(pw_context* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (int b = 0; b < 2; ++b) {
+        if (c->ev_reset[b]) (void)hipEventDestroy(c->ev_reset[b]);
+        if (c->ev_prod[b]) (void)hipEventDestroy(c->ev_prod[b]);
+        if (c->ev_gate[b]) (void)hipEventDestroy(c->ev_gate[b]);
+        if (c->ev_join[b]) (void)hipEventDestroy(c->ev_join[b]);
+        if (c->ev_done[b]) (void)hipEventDestroy(c->ev_done[b]);
+    }
     if (c->adj) (void)hipFree(c->adj);
     if (c->queue) (void)hipFree(c->queue);
     if (c->slots) (void)hipFree(c->slots);
-    if (c->prod) (void)hipStreamDestroy(c->prod);
-    if (c->ev_prod) (void)hipEventDestroy(c->ev_prod);
-    if (c->ev_gate) (void)hipEventDestroy(c->ev_gate);
+    if (c->prods[0]) (void)hipStreamDestroy(c->prods[0]);
+    if (c->prods[1]) (void)hipStreamDestroy(c->prods[1]);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -390,6 +414,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         if (rc != PW_OK) return rc;
         rc = ensure_workspace(c, p.grid, win ? p.grid : 0);
         if (rc != PW_OK) return rc;
+        c->need_fork = 1;
         return launch_plan(c, r, stages, p, c->stream, 0, win, 0);
     }
     // Pipeline: the analysis is split by parallel shape and the pieces overlap.
@@ -412,38 +437,64 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     }
     rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pc);
     if (rc != PW_OK) return rc;
-    int need = pc.grid + pa.grid + pb.grid;
+    int need = pc.grid + 2 * pa.grid + pb.grid;
     rc = ensure_workspace(c, need, pc.grid);
     if (rc != PW_OK) return rc;
     if (c->slots_cap < r->n_units) {
         HIP_TRY(hipDeviceSynchronize());
         if (c->slots) HIP_TRY(hipFree(c->slots));
-        HIP_TRY(hipMalloc((void**)&c->slots, sizeof(int) * (size_t)r->n_units));
+        c->slots = nullptr;
+        HIP_TRY(hipMalloc((void**)&c->slots, 2 * sizeof(int) * (size_t)r->n_units));
         c->slots_cap = r->n_units;
+        c->done_valid[0] = c->done_valid[1] = 0;
     }
-    HIP_TRY(hipMemsetAsync(r->d_out, 0, sizeof(pw_unit_out) * r->n_units, c->stream));
-    HIP_TRY(hipMemsetAsync(c->queue, 0, sizeof(UnitQueue), c->stream));
-    HIP_TRY(hipMemsetAsync(c->slots, 0xff, sizeof(int) * (size_t)r->n_units, c->stream));
-    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-    HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_fork, 0));
-    rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod, pc.grid, false, 0,
-                     PW_ROLE_PRODUCER);
+    // this launch's buffer set; the other one may still be in use by the previous launch.
+    // (A batch's result buffer was last used two of its own launches ago, i.e. no later than
+    // the launch that used this set before, whose completion is awaited below.)
+    const int b = c->flip ^ 1;
+    c->flip = b;
+    {
+        const char* ps = getenv("PW_PROD_STREAMS");
+        c->prod = c->prods[(ps && ps[0] == '2') ? b : 0];
+    }
+    r->cur ^= 1;
+    r->d_out = r->d_outs[r->cur];
+    c->cur_queue = c->queue + b;
+    c->cur_slots = c->slots + (size_t)b * c->slots_cap;
+    if (c->need_fork) {
+        // uploads, single-launch analyses and timing marks on the main stream come first
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->prods[0], c->ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(c->prods[1], c->ev_fork, 0));
+        c->need_fork = 0;
+    }
+    if (c->done_valid[b]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_done[b], 0));
+    HIP_TRY(hipMemsetAsync(r->d_out, 0, sizeof(pw_unit_out) * r->n_units, c->prod));
+    HIP_TRY(hipMemsetAsync(c->cur_queue, 0, sizeof(UnitQueue), c->prod));
+    HIP_TRY(hipMemsetAsync(c->cur_slots, 0xff, sizeof(int) * (size_t)r->n_units, c->prod));
+    HIP_TRY(hipEventRecord(c->ev_reset[b], c->prod));
+    // two optimiser launches can be in flight: separate work counters and workspaces
+    rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod,
+                     pc.grid + (b ? pa.grid + pb.grid : 0), false, b ? 3 : 0, PW_ROLE_PRODUCER);
     if (rc != PW_OK) return rc;
-    HIP_TRY(hipEventRecord(c->ev_prod, c->prod));
-    hipLaunchKernelGGL(pw_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->queue, pa.grid);
+    HIP_TRY(hipEventRecord(c->ev_prod[b], c->prod));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_reset[b], 0));
+    hipLaunchKernelGGL(pw_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->cur_queue, pa.grid);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev_gate, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_gate[b], c->stream));
     rc = launch_plan(c, r, PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pc,
                      c->stream, 0, true, 2, PW_ROLE_CONSUMER);
     if (rc != PW_OK) return rc;
     if (do_avg) {
-        HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_gate, 0));
+        HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_gate[b], 0));
         rc = launch_plan(c, r, PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pb, c->aux, pc.grid + pa.grid, false, 1);
         if (rc != PW_OK) return rc;
-        HIP_TRY(hipEventRecord(c->ev_join, c->aux));
+        HIP_TRY(hipEventRecord(c->ev_join[b], c->aux));
     }
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_prod, 0));
-    if (do_avg) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_prod[b], 0));
+    if (do_avg) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join[b], 0));
+    HIP_TRY(hipEventRecord(c->ev_done[b], c->stream));
+    c->done_valid[b] = 1;
     return PW_OK;
 }
 
@@ -478,7 +529,10 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
         HIP_TRY(hipMalloc((void**)&r->d_xyz, sizeof(double) * 3 * natoms));
         HIP_TRY(hipMalloc((void**)&r->d_vdw, sizeof(double) * natoms));
         HIP_TRY(hipMalloc((void**)&r->d_mass, sizeof(double) * natoms));
-        HIP_TRY(hipMalloc((void**)&r->d_out, sizeof(pw_unit_out) * r->n_units));
+        HIP_TRY(hipMalloc((void**)&r->d_outs[0], 2 * sizeof(pw_unit_out) * r->n_units));
+        r->d_outs[1] = r->d_outs[0] + r->n_units;
+        r->d_out = r->d_outs[0];
+        r->cur = 0;
         HIP_TRY(hipMemcpyAsync(r->d_offset, in->atom_offset, sizeof(long) * (r->n_units + 1),
                                hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(r->d_xyz, in->xyz, sizeof(double) * 3 * natoms, hipMemcpyHostToDevice,
@@ -487,7 +541,7 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
                                c->stream));
         HIP_TRY(hipMemcpyAsync(r->d_mass, in->mass, sizeof(double) * natoms, hipMemcpyHostToDevice,
                                c->stream));
-        HIP_TRY(hipMemsetAsync(r->d_out, 0, sizeof(pw_unit_out) * r->n_units, c->stream));
+        HIP_TRY(hipMemsetAsync(r->d_outs[0], 0, 2 * sizeof(pw_unit_out) * r->n_units, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     *out = r;
@@ -501,9 +555,10 @@ int pw_resident_download(pw_context* c, pw_resident* r, pw_unit_out* out) {
     HIP_TRY(hipMemcpyAsync(out, r->d_out, sizeof(pw_unit_out) * r->n_units, hipMemcpyDeviceToHost,
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    UnitQueue q;
-    HIP_TRY(hipMemcpy(&q, c->queue, sizeof(q), hipMemcpyDeviceToHost));
-    if (q.error) {
+    UnitQueue q[2];
+    HIP_TRY(hipMemcpy(q, c->queue, sizeof(q), hipMemcpyDeviceToHost));
+    if (q[0].error || q[1].error) {
+        (void)hipMemset(c->queue, 0, sizeof(q));
         snprintf(g_err, sizeof(g_err), "window launch timed out waiting for the optimiser launch");
         return PW_E_HIP;
     }
@@ -517,7 +572,8 @@ void pw_resident_free(pw_context* c, pw_resident* r) {
     if (r->d_xyz) (void)hipFree(r->d_xyz);
     if (r->d_vdw) (void)hipFree(r->d_vdw);
     if (r->d_mass) (void)hipFree(r->d_mass);
-    if (r->d_out) (void)hipFree(r->d_out);
+    if (c) (void)hipDeviceSynchronize();
+    if (r->d_outs[0]) (void)hipFree(r->d_outs[0]);
     delete r;
 }
 
@@ -531,6 +587,7 @@ int pw_resident_time(pw_context* c, pw_resident* r, uint32_t stages, int iters, 
     if (rc != PW_OK) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    c->need_fork = 1;        // the first timed launch starts after ev0 on every stream
     for (int i = 0; i < iters; ++i) {
         rc = pw_resident_launch(c, r, stages);
         if (rc != PW_OK) return rc;
