@@ -59,7 +59,7 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
                   int nmax, int nrot, int nlb, TeamWorkspace* __restrict__ workspaces,
                   unsigned long long* __restrict__ adj_base, unsigned long long* counter,
                   pw_unit_out* __restrict__ out, int role, UnitQueue* queue, int* __restrict__ slots,
-                  pw_params prm) {
+                  pw_params prm, const unsigned* __restrict__ rsq_tab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ long s_unit;
     using T = DeviceTeam<NW>;
@@ -72,7 +72,10 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
         if (threadIdx.x == 0) atomicAdd(&queue->started, 1);
     }
     TeamWorkspace* ws = workspaces + blockIdx.x;
-    if (threadIdx.x == 0) ws->adj = adj_base ? adj_base + (size_t)blockIdx.x * PW_ADJ_WORDS : nullptr;
+    if (threadIdx.x == 0) {
+        ws->adj = adj_base ? adj_base + (size_t)blockIdx.x * PW_ADJ_WORDS : nullptr;
+        ws->rsq = rsq_tab;
+    }
     __syncthreads();
     for (;;) {
         if (role == PW_ROLE_CONSUMER) {
@@ -193,6 +196,7 @@ struct pw_context {
     int fused;               // PW_FUSED=1: one launch per analysis instead of the pipeline
     int c_waves;             // waves per team in the window launch (PW_C_WAVES, default 4)
     pw_params prm;           // knobs of find_windows / find_average_diameter
+    unsigned* rsq_tab;       // VRSQRT14PD table on the device (numpy's arccos, pw_math.hpp)
 };
 
 struct pw_resident {
@@ -276,7 +280,7 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
                        r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb,
                        c->ws + ws_first, with_adj ? c->adj : (unsigned long long*)nullptr,
-                       c->counter + counter_slot, r->d_out, role, c->cur_queue, c->cur_slots, c->prm);
+                       c->counter + counter_slot, r->d_out, role, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab);
     HIP_TRY(hipGetLastError());
     return PW_OK;
 }
@@ -348,6 +352,17 @@ int pw_context_create(int device, pw_context** out) {
     const char* cw = getenv("PW_C_WAVES");
     c->c_waves = (cw && cw[0] == '8') ? 8 : 4;
     c->prm = default_params();
+    {
+        unsigned* host = new (std::nothrow) unsigned[65536];
+        if (!host) return PW_E_NOMEM;
+        rsqrt14_decode(host);
+        hipError_t e1 = hipMalloc((void**)&c->rsq_tab, 65536 * sizeof(unsigned));
+        hipError_t e2 = e1 == hipSuccess
+                            ? hipMemcpy(c->rsq_tab, host, 65536 * sizeof(unsigned), hipMemcpyHostToDevice)
+                            : e1;
+        delete[] host;
+        if (e2 != hipSuccess) { set_err("rsqrt14 table upload", e2); return PW_E_HIP; }
+    }
     *out = c;
     return PW_OK;
 }
@@ -369,6 +384,7 @@ void pw_context_destroy(pw_context* c) {
     }
     if (c->adj) (void)hipFree(c->adj);
     if (c->queue) (void)hipFree(c->queue);
+    if (c->rsq_tab) (void)hipFree(c->rsq_tab);
     if (c->slots) (void)hipFree(c->slots);
     if (c->prods[0]) (void)hipStreamDestroy(c->prods[0]);
     if (c->prods[1]) (void)hipStreamDestroy(c->prods[1]);

@@ -229,7 +229,8 @@ PW_HD inline void rb_expand(const RebuildFrame& fr, RebuildWs& w, int id, int sl
             double d = rb_dist_sk(X, xx, px, py, pz, pp);
             if (!(d > 0.1 && d < fr.max_dist)) continue;
             double dx = px - X[0], dy = py - X[1], dz = pz - X[2];
-            double r = pw_sqrt((dx * dx + dy * dy) + dz * dz);
+            double r2 = (dx * dx + dy * dy) + dz * dz;
+            double r = r2 >= 2.2250738585072014e-308 ? pw_pow_np(r2, 0.5) : pw_sqrt(r2);   // float ** 0.5: libm pow
             if (!(lo < r && r < hi)) continue;
             int k = rb_atomic_add(&w.seg_cnt[slot], 1);
             if (k < RB_SEG_CAP) w.seg[(size_t)slot * RB_SEG_CAP + k] = key;

@@ -82,6 +82,7 @@ struct TeamWorkspace {
     int stack[PW_P_MAX];
     unsigned long long prof[32];
     unsigned long long* adj;   // PW_P_MAX x PW_P_MAX/64 words, only for launches that run DBSCAN
+    const unsigned* rsq;       // VRSQRT14PD table (pw_math.hpp: rsqrt14_decode), for numpy's arccos
 };
 constexpr size_t PW_ADJ_WORDS = (size_t)PW_P_MAX * (PW_P_MAX / 64);
 
@@ -561,7 +562,7 @@ PW_HD inline pw_params default_params() {
 }
 // int(np.log10(4*pi*r**2) * 250 * adjust)  (utilities.py:1410, 1615)
 PW_HD inline int sampling_count(double radius, double adjust) {
-    double area = FOUR_PI * (radius * radius);
+    double area = FOUR_PI * pw_square_np(radius);    // radius ** 2 on a float scalar: libm pow
     return (int)((pw_log10(area) * 250.0) * adjust);
 }
 
@@ -832,9 +833,7 @@ PW_NOINLINE PW_HD inline void stage_basic(UnitShared& sh, TeamWorkspace* ws, int
         out->pore_d = v.pore_g * 2.0;
         out->pore_atom = v.pore_atom;
         double r = out->pore_d / 2.0;
-        DD r2 = two_prod(r, r);
-        DD r3 = dd_mul_d(r2, r);
-        out->pore_vol = FOUR_THIRDS_PI * (r3.hi + r3.lo);
+        out->pore_vol = FOUR_THIRDS_PI * pw_cube_np(r);
     }
     T::sync();
 }
@@ -937,9 +936,7 @@ PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n
             out->pore_opt_atom = arg;
             out->pore_opt_c[0] = cx; out->pore_opt_c[1] = cy; out->pore_opt_c[2] = cz;
             double rr = out->pore_opt_d / 2.0;
-            DD r2 = two_prod(rr, rr);
-            DD r3 = dd_mul_d(r2, rr);
-            out->pore_vol_opt = FOUR_THIRDS_PI * (r3.hi + r3.lo);
+            out->pore_vol_opt = FOUR_THIRDS_PI * pw_cube_np(rr);
             out->opt_nit = nit;
             out->opt_nfev = nfev;
             out->opt_task = bad ? -1 : S->task;
@@ -1143,11 +1140,13 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     PW_T0(t_r);
     double new_z = norm3(cx * (double)ppos, cy * (double)ppos, cz * (double)ppos);
     // (iii) rotation angles (utilities.py:1235-1259)
+    // angle_between_vectors (utilities.py:1088-1097): x[i] ** 2 on float64 scalars is libm's pow
+    const double vx2 = pw_square_np(vx), vy2 = pw_square_np(vy), vz2 = pw_square_np(vz);
     double c1 = pw_abs(vx * 1.0 + vy * 0.0 + 0.0 * 0.0) /
-                (pw_sqrt(vx * vx + vy * vy + 0.0 * 0.0) * pw_sqrt(1.0 * 1.0 + 0.0 * 0.0 + 0.0 * 0.0));
+                (pw_sqrt(vx2 + vy2 + 0.0) * pw_sqrt(1.0 + 0.0 + 0.0));
     double c2 = pw_abs(vx * 0.0 + vy * 0.0 + vz * 1.0) /
-                (pw_sqrt(vx * vx + vy * vy + vz * vz) * pw_sqrt(0.0 * 0.0 + 0.0 * 0.0 + 1.0 * 1.0));
-    double a1 = pw_acos01(c1), a2 = pw_acos01(c2);
+                (pw_sqrt(vx2 + vy2 + vz2) * pw_sqrt(0.0 + 0.0 + 1.0));
+    double a1 = pw_acos_np(c1, ws->rsq), a2 = pw_acos_np(c2, ws->rsq);
     bool sxp = vx >= 0.0, syp = vy >= 0.0, szp = vz >= 0.0;
     if (szp) {
         if (sxp && syp) { a1 = -a1; a2 = -a2; }
@@ -1386,7 +1385,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         double sum = np_sum_team<T>(ws->knn, P * 10, s_tab, s_acc, s_leaf, &v.red_v[15]);
         arena = arena_mark;
         double m = sum / (double)(P * 10);
-        if (T::tid() == 0) { v.eps = m + pw_sqrt(m); out->eps = v.eps; }
+        if (T::tid() == 0) { v.eps = m + pw_pow_np(m, 0.5); out->eps = v.eps; }
         T::sync();
         if (T::wave() == 0) PW_T1(ws, 25, t_sum);
     }

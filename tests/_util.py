@@ -7,10 +7,26 @@ ROOT = pathlib.Path(__file__).resolve().parents[1]
 GOLDEN = ROOT / "tests" / "golden"
 GROUPS = ("static", "md20", "synth64", "periodic8")
 
-# tolerances (relative) -- SURVEY.md section 8: deterministic quantities are bit-exact;
-# window quantities go through numpy's SIMD arccos, which cannot be reproduced
-# bit for bit, so they carry north_star's 1e-6.
-TOL_WINDOW = 1e-6
+# Tolerance (relative) on window diameters.  north_star allows 1e-6; the kernels restate
+# numpy's arccos (SVML), sin/cos and scalar ** (glibc) operation by operation, so against
+# fixtures produced on the reference platform (glibc 2.35, AVX-512 numpy) EVERYTHING is
+# bit-identical and the golden comparisons use 0.  Comparisons against the oracle run live
+# use LIVE_TOL_WINDOW: 0 on that platform, north_star's 1e-6 elsewhere.
+TOL_WINDOW = 0.0
+
+
+def _reference_platform() -> bool:
+    import platform
+
+    try:
+        from numpy._core._multiarray_umath import __cpu_features__ as feats
+    except ImportError:  # pragma: no cover
+        return False
+    libc = platform.libc_ver()
+    return bool(feats.get("AVX512_SKX")) and libc[0] == "glibc" and libc[1] == "2.35"
+
+
+LIVE_TOL_WINDOW = 0.0 if _reference_platform() else 1e-6
 
 
 def load_group(tag):
@@ -78,6 +94,6 @@ def check_records(recs, g, *, exact_scalars=True, tol_window=TOL_WINDOW, where="
             wc = np.asarray(r["win_c"][:k]).reshape(k, 3)[p]
             gc = g["win_c"][u][:k][q]
             ea = float(np.max(np.abs(wc - gc)))
-            assert ea <= 1e-4, f"{tag}: window centres abs err {ea:.3e}"
+            assert ea <= (0.0 if tol_window == 0.0 else 1e-4), f"{tag}: window centres abs err {ea:.3e}"
             stats["win_c_abs"] = max(stats["win_c_abs"], ea)
     return stats

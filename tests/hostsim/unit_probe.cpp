@@ -19,6 +19,10 @@ extern "C" int hs_analysis_batch(long n_units, const long* off, const double* xy
     TeamWorkspace* ws = (TeamWorkspace*)malloc(sizeof(TeamWorkspace));
     if (!lds || !ws) return -5;
     ws->adj = (unsigned long long*)malloc(sizeof(unsigned long long) * PW_ADJ_WORDS);
+    static unsigned rsq_tab[65536];
+    static bool rsq_ready = false;
+    if (!rsq_ready) { rsqrt14_decode(rsq_tab); rsq_ready = true; }
+    ws->rsq = rsq_tab;
     for (long u = 0; u < n_units; ++u) {
         memset(lds, 0, bytes);
         UnitShared sh;

@@ -58,7 +58,7 @@ def test_function_level_mirror():
     assert pw.pore_diameter(el, xyz, com=c) == (d, a)
     assert pw.find_average_diameter(el, xyz) == g["avg_d"][3]
     wd, wc = pw.find_windows(el, xyz)
-    assert rel(np.sort(wd), np.sort(g["win_d"][3][:4])) < 1e-6
+    assert rel(np.sort(wd), np.sort(g["win_d"][3][:4])) == 0.0
     with pytest.raises(KeyError):
         pw.molecular_weight(np.array(["Qq"]))
 

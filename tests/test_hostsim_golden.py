@@ -30,8 +30,8 @@ def test_host_team_matches_reference(hostsim, tag):
     g = load_group(tag)
     out = run_hostsim(hostsim, g)
     stats = check_records(out, g, where=tag)
-    # window quantities: far inside north_star's 1e-6
-    assert stats["win_d"] < 1e-7
+    # window diameters and centres are bit-identical too
+    assert stats["win_d"] == 0.0 and stats["win_c_abs"] == 0.0
     assert (out["status"] == 0).all()
 
 

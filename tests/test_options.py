@@ -25,7 +25,7 @@ def compare_windows(n, wd, wc, g, u, k, where):
     e = rel(np.asarray(wd[:m])[p], g["win_d"][u][k][:m][q])
     assert e <= TOL_WINDOW, f"{where}: window diameters rel err {e:.3e}"
     ea = np.max(np.abs(np.asarray(wc[:m]).reshape(m, 3)[p] - g["win_c"][u][k][:m][q]))
-    assert ea < 1e-3, f"{where}: window centres {ea:.3e}"
+    assert ea == 0.0, f"{where}: window centres {ea:.3e}"
     return e
 
 

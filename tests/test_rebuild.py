@@ -208,7 +208,7 @@ def test_periodic_trajectory_modular_rebuild(hip_ctx, tmp_path):
             nw = int(row[cols.index("n_windows")])
             assert len(p["windows"]["diameters"]) == nw
             e = rel(np.sort(p["windows"]["diameters"]), row[10:10 + nw])
-            assert e <= 1e-6
+            assert e == 0.0
             worst = max(worst, e)
     print("periodic trajectory: worst window rel err", worst)
     # columnar form, and a frame the reference cannot finish is still analysed here
