@@ -19,6 +19,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the pipeline keeps several kernels in flight on separate streams: ask the HIP runtime for enough
+# hardware queues BEFORE anything (torch included) initialises it
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FRAMES = 1000
 ALGO_BYTES_PER_UNIT = 24 * 168 + 600   # coordinates read once + one result record
@@ -122,10 +125,11 @@ def main():
     res = ctx.upload(_lib.Batch.uniform(frames, vdw, mass))
 
     def barrier():
+        res.sync()                     # the engine's own HIP streams
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        res.sync()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         res.launch()

@@ -6,9 +6,15 @@ gfx950 (``csrc/``), through a C ABI (``include/pywindow_amd.h``) bound with
 ctypes.  There is no CPU implementation in this package.
 """
 
-from .molecular import MolecularSystem, Molecule
-from .trajectory import DLPOLY
-from .utilities import (
+import os as _os
+
+# several kernels of one analysis run side by side on separate HIP streams; the runtime must be
+# told before it initialises (harmless if the host application already set it)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from .molecular import MolecularSystem, Molecule  # noqa: E402
+from .trajectory import DLPOLY  # noqa: E402
+from .utilities import (  # noqa: E402
     center_of_mass,
     find_average_diameter,
     find_windows,
