@@ -131,7 +131,7 @@ PW_HD inline double sc_do_sincos(double a, double da, int n) {
     return (n & 2) ? -r : r;
 }
 // libm sin(x) as numpy.sin sees it
-PW_HD inline double pw_sin_np(double x) {
+PW_NOINLINE PW_HD inline double pw_sin_np(double x) {
     const unsigned k = (unsigned)(pw_d2bits(x) >> 32) & 0x7fffffffu;
     if (k < 0x3e500000u) return x;
     if (k < 0x3feb6000u) return sc_do_sin(x, 0.0);
@@ -144,7 +144,7 @@ PW_HD inline double pw_sin_np(double x) {
     return sc_do_sincos(a, da, n);
 }
 // libm cos(x) as numpy.cos sees it
-PW_HD inline double pw_cos_np(double x) {
+PW_NOINLINE PW_HD inline double pw_cos_np(double x) {
     const unsigned k = (unsigned)(pw_d2bits(x) >> 32) & 0x7fffffffu;
     if (k < 0x3e400000u) return 1.0;
     if (k < 0x3feb6000u) return sc_do_cos(x, 0.0);
@@ -172,7 +172,7 @@ PW_HD inline double pw_cos(double x) { return pw_cos_np(x); }
 // is within 0.52 ulp but not correctly rounded: pow(x, 2.0) != x*x for 0.08 % of the arguments.
 // Main path of the FMA build, operation by operation; x positive and normal, |y log x| moderate
 // (everything on this path), otherwise the caller's plain expression is used.
-PW_HD inline double pw_pow_np(double x, double y) {
+PW_NOINLINE PW_HD inline double pw_pow_np(double x, double y) {
     const uint64_t ix = pw_d2bits(x);
     const uint64_t tmp = ix - 0x3fe6955500000000ull;
     const int i = (int)((tmp >> 45) & 0x7f);
@@ -279,7 +279,7 @@ PW_HD inline double pw_rsqrt14(double y, const unsigned* tab) {
     return pw_bits2d(rb);
 }
 // numpy.arccos(x) for |x| <= 1
-PW_HD inline double pw_acos_np(double x, const unsigned* tab) {
+PW_NOINLINE PW_HD inline double pw_acos_np(double x, const unsigned* tab) {
     const double c4 = pw_bits2d(0xbf918000993b24c3ull), c3 = pw_bits2d(0x3fa400006f70d42dull),
                  c2 = pw_bits2d(0xbfb7fffffffffe97ull), c1 = pw_bits2d(0x3fcfffffffffff9dull);
     const double q12 = pw_bits2d(0x3fa07520c70eb909ull), q11 = pw_bits2d(0xbf90fb17f7dbb0edull),

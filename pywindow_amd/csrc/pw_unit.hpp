@@ -241,14 +241,28 @@ PW_HD inline double point_gap_value(const Frame& F, int n, double px, double py,
     double best = PW_INF;
     for (int g = 0; g < C.k; ++g) {
         double m2 = PW_INF;
-#pragma unroll 8
-        for (int i = C.off[g]; i < C.off[g + 1]; ++i) {
+        int i = C.off[g];
+        const int hi = C.off[g + 1];
+        // blocks of eight: all LDS reads of a block are issued before its arithmetic, so the
+        // (broadcast) read latency is paid once per block, not once per atom
+        for (; i + 8 <= hi; i += 8) {
+            double ax[8], ay[8], az[8], aq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ax[j] = F.x[i + j]; ay[j] = F.y[i + j]; az[j] = F.z[i + j]; aq[j] = F.xx[i + j]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                double gg = pw_fma(az[j], pz, pw_fma(ax[j], px, ay[j] * py));
+                double d2 = ((-2.0 * gg) + aq[j]) + pp;
+                m2 = __builtin_fmin(m2, d2);
+            }
+        }
+        for (; i < hi; ++i) {
             double gg = pw_fma(F.z[i], pz, pw_fma(F.x[i], px, F.y[i] * py));
             double d2 = ((-2.0 * gg) + F.xx[i]) + pp;
-            m2 = pw_min(m2, d2);
+            m2 = __builtin_fmin(m2, d2);
         }
         double d = pw_sqrt(m2 > 0.0 ? m2 : 0.0);
-        best = pw_min(best, d - C.vdw[g]);
+        best = __builtin_fmin(best, d - C.vdw[g]);
     }
     return best;
 }
@@ -582,8 +596,24 @@ PW_NOINLINE PW_HD inline bool ray_scan(const Frame& F, int n, const double* cen,
     for (int blk = 0; blk < n; blk += 64) {
         unsigned long long mask = 0;
         int jend = n - blk < 64 ? n - blk : 64;
-#pragma unroll 8
-        for (int j = 0; j < jend; ++j) {
+        int j = 0;
+        for (; j + 8 <= jend; j += 8) {
+            double ax[8], ay[8], az[8], ar[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                int i = blk + j + t;
+                ax[t] = F.x[i]; ay[t] = F.y[i]; az[t] = F.z[i]; ar[t] = F.vdw[i];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                double rx = ax[t] - cen[0], ry = ay[t] - cen[1], rz = az[t] - cen[2];
+                double along = pw_fma(rz, uz, pw_fma(rx, ux, ry * uy));
+                double q = sq3(rx, ry, rz) - along * along;
+                double r2 = ar[t] * ar[t];
+                if (q >= 0.0 && q <= r2 * (1.0 + 1e-14)) mask |= 1ull << (j + t);
+            }
+        }
+        for (; j < jend; ++j) {
             int i = blk + j;
             double rx = F.x[i] - cen[0], ry = F.y[i] - cen[1], rz = F.z[i] - cen[2];
             double along = pw_fma(rz, uz, pw_fma(rx, ux, ry * uy));
@@ -1351,21 +1381,41 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             int lo = k - W < 0 ? 0 : k - W, hi = k + W > P - 1 ? P - 1 : k + W;
             for (int pass = 0; pass < 2; ++pass) {
                 t0 = t1 = t2 = t3 = t4 = t5 = t6 = t7 = t8 = t9 = PW_INF;
-#pragma unroll 4
-                for (int j = lo; j <= hi; ++j) {
+#define PW_CE(tq) lo_ = __builtin_fmin(tq, v_); v_ = __builtin_fmax(tq, v_); tq = lo_;
+#define PW_KNN_INSERT(dd)                                                  \
+    if ((dd) < t9) {                                                       \
+        /* sorted insertion by a compare-exchange chain (registers only) */ \
+        double lo_, v_ = (dd);                                             \
+        PW_CE(t0) PW_CE(t1) PW_CE(t2) PW_CE(t3) PW_CE(t4)                  \
+        PW_CE(t5) PW_CE(t6) PW_CE(t7) PW_CE(t8) PW_CE(t9)                  \
+    }
+                int j = lo;
+                // blocks of eight candidates: reads first, then the distances, then the insertions
+                for (; j + 7 <= hi; j += 8) {
+                    double qx[8], qy[8], qz[8], dd[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        qx[t] = pts[3 * (j + t)]; qy[t] = pts[3 * (j + t) + 1]; qz[t] = pts[3 * (j + t) + 2];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        double ax = px - qx[t], ay = py - qy[t], az = pz - qz[t];
+                        double d = 0.0;
+                        d = d + ax * ax; d = d + ay * ay; d = d + az * az;
+                        dd[t] = d;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) { PW_KNN_INSERT(dd[t]) }
+                }
+                for (; j <= hi; ++j) {
                     double qx = pts[3 * j], qy = pts[3 * j + 1], qz = pts[3 * j + 2];
                     double ax = px - qx, ay = py - qy, az = pz - qz;
                     double d = 0.0;
                     d = d + ax * ax; d = d + ay * ay; d = d + az * az;
-                    if (d < t9) {
-                        // sorted insertion by a compare-exchange chain (registers only)
-                        double lo_, v_ = d;
-#define PW_CE(tq) lo_ = pw_min(tq, v_); v_ = pw_max(tq, v_); tq = lo_;
-                        PW_CE(t0) PW_CE(t1) PW_CE(t2) PW_CE(t3) PW_CE(t4)
-                        PW_CE(t5) PW_CE(t6) PW_CE(t7) PW_CE(t8) PW_CE(t9)
-#undef PW_CE
-                    }
+                    PW_KNN_INSERT(d)
                 }
+#undef PW_KNN_INSERT
+#undef PW_CE
                 bool full = (lo == 0 && hi == P - 1);
                 if (full || pw_sqrt(t9) < (double)(W - 1) * zstep) break;
                 lo = 0; hi = P - 1;
