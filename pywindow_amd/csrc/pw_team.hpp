@@ -27,6 +27,8 @@ struct HostTeam {
     PW_HD static void row_argmin4(double v, int idx, double* outv, int* outi) {
         for (int r = 0; r < 4; ++r) { outv[r] = v; outi[r] = idx; }
     }
+    PW_HD static double wave_min(double v) { return v; }
+    PW_HD static void row_min4(double v, double* outv) { for (int r = 0; r < 4; ++r) outv[r] = v; }
     PW_HD static unsigned long long ballot(bool p) { return p ? 1ull : 0ull; }
     PW_HD static bool wave_all(bool p) { return p; }
     PW_HD static bool wave_any(bool p) { return p; }
@@ -108,6 +110,28 @@ struct DeviceTeam {
         outv[1] = lane_d(v, 31); outi[1] = __builtin_amdgcn_readlane(idx, 31);
         outv[2] = lane_d(v, 47); outi[2] = __builtin_amdgcn_readlane(idx, 47);
         outv[3] = lane_d(v, 63); outi[3] = __builtin_amdgcn_readlane(idx, 63);
+    }
+    // value-only minimum: the same DPP ladder without the index
+    template <int CTRL, int ROW_MASK, int BANK_MASK>
+    __device__ static void min_step(double& v) {
+        v = __builtin_fmin(v, dpp_d<CTRL, ROW_MASK, BANK_MASK>(v));
+    }
+    __device__ static double wave_min(double v) {
+        min_step<0x111, 0xf, 0xf>(v);
+        min_step<0x112, 0xf, 0xf>(v);
+        min_step<0x114, 0xf, 0xe>(v);
+        min_step<0x118, 0xf, 0xc>(v);
+        min_step<0x142, 0xa, 0xf>(v);
+        min_step<0x143, 0xc, 0xf>(v);
+        return lane_d(v, 63);
+    }
+    // four independent value-only minima, one per row of 16 lanes
+    __device__ static void row_min4(double v, double* outv) {
+        min_step<0x111, 0xf, 0xf>(v);
+        min_step<0x112, 0xf, 0xf>(v);
+        min_step<0x114, 0xf, 0xe>(v);
+        min_step<0x118, 0xf, 0xc>(v);
+        outv[0] = lane_d(v, 15); outv[1] = lane_d(v, 31); outv[2] = lane_d(v, 47); outv[3] = lane_d(v, 63);
     }
     __device__ static unsigned long long ballot(bool p) { return __ballot(p); }
     __device__ static bool wave_all(bool p) { return __all(p); }

@@ -282,6 +282,16 @@ PW_HD inline double wave_gap(const Frame& F, int n, double px, double py, double
     return best;
 }
 
+// one wave, atoms spread over lanes, VALUE only (the simplex and window-diameter evaluations
+// never need the atom): no index bookkeeping, value-only reduction.  Same value as wave_gap.
+template <class T>
+PW_HD inline double wave_gap_value(const Frame& F, int n, double px, double py, double pz) {
+    double pp = sq3(px, py, pz);
+    double best = PW_INF;
+    for (int i = T::lane(); i < n; i += T::WSIZE) best = __builtin_fmin(best, gap_atom(F, i, px, py, pz, pp));
+    return T::wave_min(best);
+}
+
 // Four points at once (the f and the three forward-difference points of one gradient
 // request): each row of 16 lanes takes one point and the atoms are spread over the row.
 // Values only; identical to four wave_gap calls.
@@ -295,14 +305,9 @@ PW_HD inline void wave_gap4(const Frame& F, int n, const double* px, const doubl
         double qz = g == 0 ? pz[0] : (g == 1 ? pz[1] : (g == 2 ? pz[2] : pz[3]));
         double pp = sq3(qx, qy, qz);
         double best = PW_INF;
-        int bi = 0x7fffffff;
 #pragma unroll 4
-        for (int i = l; i < n; i += 16) {
-            double v = gap_atom(F, i, qx, qy, qz, pp);
-            if (v < best) { best = v; bi = i; }
-        }
-        int oi[4];
-        T::row_argmin4(best, bi, out, oi);
+        for (int i = l; i < n; i += 16) best = __builtin_fmin(best, gap_atom(F, i, qx, qy, qz, pp));
+        T::row_min4(best, out);
     } else {
         for (int q = 0; q < 4; ++q) out[q] = wave_gap<T>(F, n, px[q], py[q], pz[q], nullptr);
     }
@@ -1055,7 +1060,7 @@ PW_NOINLINE PW_HD inline void wave_fmin_xy(const Frame& F, int n, double z, doub
     int fcalls = 0;
     auto fun = [&](double x, double y) {
         fcalls += 1;
-        return -(wave_gap<T>(F, n, x, y, z, nullptr) * 2.0);
+        return -(wave_gap_value<T>(F, n, x, y, z) * 2.0);
     };
     x0s = x0; y0s = y0;
     x1s = (x0 != 0.0) ? (1.0 + 0.05) * x0 : 0.00025; y1s = y0;
@@ -1210,7 +1215,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     }
     T::wave_sync();
     // (iv) diameter at the neck
-    double d0 = wave_gap<T>(R, n, 0.0, 0.0, 0.0, nullptr) * 2.0;
+    double d0 = wave_gap_value<T>(R, n, 0.0, 0.0, 0.0) * 2.0;
     evals += 1;
     PW_T1(ws, 3, t_r);
     // (v) neck position along z: L-BFGS-B, n = 1, bounds [-new_z, +inf)
@@ -1281,7 +1286,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     wave_fmin_xy<T>(R, n, zopt, gx0, gy0, &xo, &yo, &evals);
     PW_T1(ws, 7, t_n);
     // (vii) final diameter, (viii) back-rotation
-    double dfin = wave_gap<T>(R, n, xo, yo, zopt, nullptr) * 2.0;
+    double dfin = wave_gap_value<T>(R, n, xo, yo, zopt) * 2.0;
     evals += 1;
     double wx = xo, wy = yo, wz = zopt + new_z;
     double sm2, cm2, sm1, cm1;
