@@ -445,6 +445,16 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     rc = plan_launch(c, r->n_units, r->nmax, 1, false, 1, &pa);
     if (rc != PW_OK) return rc;
     pa.grid = (int)r->n_units < pa.grid ? (int)r->n_units : pa.grid;
+    {
+        // PW_A_LDS_KB: pad the LDS request of the optimiser teams (tuning: keeps the bulk launches
+        // off a CU while its chains are young)
+        const char* al = getenv("PW_A_LDS_KB");
+        if (al && atoi(al) > 0) {
+            size_t want = (size_t)atoi(al) * 1024;
+            if (want > pa.lds && want <= 160 * 1024 - 256) pa.lds = want;
+        }
+        if (getenv("PW_PLAN_DEBUG")) fprintf(stderr, "plan A: grid %d lds %zu\n", pa.grid, pa.lds);
+    }
     bool do_avg = (stages & PW_STAGE_AVG) != 0;
     pb.grid = 0;
     if (do_avg) {
@@ -453,6 +463,13 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     }
     rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pc);
     if (rc != PW_OK) return rc;
+    {
+        // PW_C_TEAMS / PW_B_TEAMS: cap the persistent teams of the window / average launches (tuning)
+        const char* ct = getenv("PW_C_TEAMS");
+        if (ct && atoi(ct) > 0 && atoi(ct) < pc.grid) pc.grid = atoi(ct);
+        const char* bt = getenv("PW_B_TEAMS");
+        if (bt && do_avg && atoi(bt) > 0 && atoi(bt) < pb.grid) pb.grid = atoi(bt);
+    }
     int need = pc.grid + 2 * pa.grid + pb.grid;
     rc = ensure_workspace(c, need, pc.grid);
     if (rc != PW_OK) return rc;
