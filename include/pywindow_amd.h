@@ -97,8 +97,13 @@ typedef struct pw_params {
     double adjust_average;  /* find_average_diameter(adjust=1):  sampling density, utilities.py:1615 */
     double increment;       /* find_windows(increment=1.0):      coarse path-scan step, utilities.py:1457 */
     int32_t pore_opt;       /* find_windows(pore_opt=True): centre on the optimised pore, :1380-1393 */
-    int32_t reserved;
+    int32_t opt_flags;      /* opt_pore_diameter(bounds=, com=), utilities.py:400-426: PW_OPT_* bits */
+    double opt_x0[3];       /* com=: start of the optimisation (default: the centre of mass) */
+    double opt_lo[3];       /* bounds=: lower / upper bound per axis, -/+HUGE_VAL for None */
+    double opt_hi[3];       /*          (default: start -/+ the pore radius at the start) */
 } pw_params;
+#define PW_OPT_CUSTOM_START 1
+#define PW_OPT_CUSTOM_BOUNDS 2
 
 typedef struct pw_context pw_context;   /* device, stream, workspace */
 typedef struct pw_resident pw_resident; /* a batch resident in HBM */

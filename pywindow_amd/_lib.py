@@ -52,11 +52,32 @@ class Params(ctypes.Structure):
         ("adjust_average", ctypes.c_double),
         ("increment", ctypes.c_double),
         ("pore_opt", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("opt_flags", ctypes.c_int32),
+        ("opt_x0", ctypes.c_double * 3),
+        ("opt_lo", ctypes.c_double * 3),
+        ("opt_hi", ctypes.c_double * 3),
     ]
 
-    def __init__(self, adjust_windows=1.0, adjust_average=1.0, increment=1.0, pore_opt=True):
-        super().__init__(float(adjust_windows), float(adjust_average), float(increment), 1 if pore_opt else 0, 0)
+    def __init__(self, adjust_windows=1.0, adjust_average=1.0, increment=1.0, pore_opt=True, opt_start=None,
+                 opt_bounds=None):
+        """``opt_start``: (3,) start of opt_pore_diameter; ``opt_bounds``: three (lo, hi) pairs, ``None``
+        for an open side (scipy.optimize.minimize's ``bounds`` convention)."""
+        flags = 0
+        x0 = (ctypes.c_double * 3)(0.0, 0.0, 0.0)
+        lo = (ctypes.c_double * 3)(-np.inf, -np.inf, -np.inf)
+        hi = (ctypes.c_double * 3)(np.inf, np.inf, np.inf)
+        if opt_start is not None:
+            flags |= 1
+            for k in range(3):
+                x0[k] = float(opt_start[k])
+        if opt_bounds is not None:
+            flags |= 2
+            for k in range(3):
+                a, b = opt_bounds[k]
+                lo[k] = -np.inf if a is None else float(a)
+                hi[k] = np.inf if b is None else float(b)
+        super().__init__(float(adjust_windows), float(adjust_average), float(increment), 1 if pore_opt else 0,
+                         flags, x0, lo, hi)
 
 
 class CellIn(ctypes.Structure):

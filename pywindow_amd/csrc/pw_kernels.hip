@@ -403,6 +403,12 @@ int pw_context_set_params(pw_context* c, const pw_params* p) {
         snprintf(g_err, sizeof(g_err), "pw_params: adjust and increment must be positive");
         return PW_E_BAD_ARG;
     }
+    if (p->opt_flags & PW_OPT_CUSTOM_BOUNDS)
+        for (int k = 0; k < 3; ++k)
+            if (p->opt_lo[k] > p->opt_hi[k]) {   // scipy raises for the same input
+                snprintf(g_err, sizeof(g_err), "pw_params: an upper bound is less than the corresponding lower bound");
+                return PW_E_BAD_ARG;
+            }
     c->prm = *p;
     c->prm.pore_opt = p->pore_opt ? 1 : 0;
     return PW_OK;

@@ -576,7 +576,8 @@ struct Sphere {
 };
 PW_HD inline pw_params default_params() {
     pw_params p;
-    p.adjust_windows = 1.0; p.adjust_average = 1.0; p.increment = 1.0; p.pore_opt = 1; p.reserved = 0;
+    p.adjust_windows = 1.0; p.adjust_average = 1.0; p.increment = 1.0; p.pore_opt = 1; p.opt_flags = 0;
+    for (int c = 0; c < 3; ++c) { p.opt_x0[c] = 0.0; p.opt_lo[c] = -PW_INF; p.opt_hi[c] = PW_INF; }
     return p;
 }
 // int(np.log10(4*pi*r**2) * 250 * adjust)  (utilities.py:1410, 1615)
@@ -877,6 +878,8 @@ PW_NOINLINE PW_HD inline void stage_basic(UnitShared& sh, TeamWorkspace* ws, int
 // abs_step 1e-8, _adjust_scheme_to_bounds '1-sided')
 PW_HD inline double fd_step(double x, double lb, double ub) {
     double h = 1e-8;
+    // "cannot have a zero step": for huge |x| fall back to the relative step sqrt(eps) * sign * max(1, |x|)
+    if ((x + h) - x == 0.0) h = 1.4901161193847656e-08 * (x >= 0.0 ? 1.0 : -1.0) * pw_max(1.0, pw_abs(x));
     double lower = x - lb, upper = ub - x;
     double xh = x + h;
     bool violated = (xh < lb) || (xh > ub);
@@ -888,7 +891,8 @@ PW_HD inline double fd_step(double x, double lb, double ub) {
 
 // ---- stage: optimised pore (wave 0) --------------------------------------------------------
 template <class T>
-PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out) {
+PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
+                                        const pw_params& prm) {
     (void)ws;
     auto& v = *sh.v;
     if (T::wave() == 0) {
@@ -899,12 +903,29 @@ PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n
         double r = v.pore_g;  // pore_diameter / 2
         double lo[3], up[3], x0[3];
         int nbd[3] = {2, 2, 2};
-        for (int c = 0; c < 3; ++c) {
-            lo[c] = v.com[c] - r;
-            up[c] = v.com[c] + r;
-            x0[c] = v.com[c];
+        for (int c = 0; c < 3; ++c) x0[c] = (prm.opt_flags & PW_OPT_CUSTOM_START) ? prm.opt_x0[c] : v.com[c];
+        // user-supplied start: the default box is built around it (utilities.py:412-421)
+        if ((prm.opt_flags & PW_OPT_CUSTOM_START) && !(prm.opt_flags & PW_OPT_CUSTOM_BOUNDS))
+            r = wave_gap<T>(sh.A, n, x0[0], x0[1], x0[2], nullptr);
+        bool bad;
+        if (prm.opt_flags & PW_OPT_CUSTOM_BOUNDS) {
+            bad = false;
+            for (int c = 0; c < 3; ++c) {
+                lo[c] = prm.opt_lo[c];
+                up[c] = prm.opt_hi[c];
+                bool has_lo = lo[c] > -PW_INF, has_up = up[c] < PW_INF;
+                nbd[c] = has_lo ? (has_up ? 2 : 1) : (has_up ? 3 : 0);
+                if (lo[c] > up[c]) bad = true;
+                // scipy clips the start into the box (_lbfgsb_py.py: x0 = np.clip(x0, lb, ub))
+                x0[c] = x0[c] < lo[c] ? lo[c] : (x0[c] > up[c] ? up[c] : x0[c]);
+            }
+        } else {
+            for (int c = 0; c < 3; ++c) {
+                lo[c] = x0[c] - r;
+                up[c] = x0[c] + r;
+            }
+            bad = !(r > 0.0);
         }
-        bool bad = !(r > 0.0);
         int nit = 0, nfev = 0;
         bool have_last = false;
         double lx = 0.0, ly = 0.0, lz = 0.0, lf = 0.0, lg[3] = {0.0, 0.0, 0.0};
@@ -950,8 +971,10 @@ PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n
                     T::wave_sync();
                     PW_T1(ws, 1, t_e);
                 } else if (S->task == LB_NEW_X) {
+                    // scipy's driver: maxiter = maxfun = 15000, both tested at a new iterate only
+                    // (_lbfgsb_py.py: "interruptions due to maxfun are postponed")
                     nit += 1;
-                    if (nit >= 15000) break;
+                    if (nit >= 15000 || nfev > 15000) break;
                 } else {
                     break;
                 }
@@ -1258,7 +1281,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
             PW_T1(ws, 5, t_ze);
         } else if (S->task == LB_NEW_X) {
             nit += 1;
-            if (nit >= 15000) break;
+            if (nit >= 15000) break;      // (a neck search takes a handful of evaluations)
         } else {
             break;
         }
@@ -1703,7 +1726,7 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
     } else {
         stage_basic<T>(sh, ws, n, out, (stages & PW_STAGE_COM_ONLY) != 0);
     }
-    if (stages & PW_STAGE_OPT) stage_opt<T>(sh, ws, n, out);
+    if (stages & PW_STAGE_OPT) stage_opt<T>(sh, ws, n, out, prm);
     if (reuse_opt) {
         if (T::tid() == 0) {
             sh.v->opt_c[0] = out->pore_opt_c[0];

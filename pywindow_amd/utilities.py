@@ -61,11 +61,17 @@ def sphere_volume(sphere_radius: float) -> float:
 
 
 def opt_pore_diameter(elements, coordinates, bounds=None, com=None):
-    """Reference utilities.py:400-426 (default bounds / start only, which is all
-    ``Molecule`` ever uses)."""
+    """Reference utilities.py:400-426.  ``com``: start of the optimisation (default the centre
+    of mass); ``bounds``: three ``(lo, hi)`` pairs as for ``scipy.optimize.minimize`` (default:
+    start -/+ the pore radius at the start)."""
+    params = None
     if bounds is not None or com is not None:
-        raise NotImplementedError("custom bounds / start are not reachable from Molecule (SURVEY 5.6)")
-    r = _one(elements, coordinates, _lib.STAGE_OPT)
+        if bounds is not None:
+            for lo, hi in bounds:
+                if lo is not None and hi is not None and lo > hi:
+                    raise ValueError("An upper bound is less than the corresponding lower bound.")
+        params = _lib.Params(opt_start=com, opt_bounds=bounds)
+    r = _one(elements, coordinates, _lib.STAGE_OPT, params)
     return float(r["pore_opt_d"]), int(r["pore_opt_atom"]), np.array(r["pore_opt_c"])
 
 

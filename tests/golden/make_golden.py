@@ -490,6 +490,47 @@ def options_unit(args):
     return n_win, win_d, win_c, avg
 
 
+OPT_CASES = [  # (com offset or None, bounds offsets relative to the centre of mass or None)
+    ((0.3, -0.2, 0.1), None),
+    (None, ((-1.0, 1.0), (-1.0, None), (None, None))),
+    ((0.2, 0.1, -0.3), ((-0.5, 0.5), (-0.4, 0.9), (None, 0.2))),
+]
+
+
+def optopt_unit(args):
+    """opt_pore_diameter(bounds=, com=) of the reference (utilities.py:400-426)."""
+    elements, coords = args
+    load_reference()
+    from pywindow._internal import utilities as U
+
+    elements = np.array(elements)
+    coords = np.array(coords)
+    com = U.center_of_mass(elements, coords)
+    rows = []
+    for off, bnd in OPT_CASES:
+        start = None if off is None else com + np.array(off)
+        bounds = None
+        if bnd is not None:
+            bounds = tuple((None if a is None else com[k] + a, None if b is None else com[k] + b)
+                           for k, (a, b) in enumerate(bnd))
+        d, atom, c = U.opt_pore_diameter(elements, coords, bounds=bounds, com=start)
+        rows.append([d, atom, *c])
+    return np.array(rows)
+
+
+def run_optopt(pool):
+    n, e, x = static_cases()
+    pick = [n.index(k) for k in ("cc3", "windows_case_2", "windows_case_5", "avgdiam_case_3")]
+    els = [list(e[i]) for i in pick]
+    xyz = [np.array(x[i], float) for i in pick]
+    res = pool.map(optopt_unit, list(zip(els, xyz)))
+    off = np.concatenate([[0], np.cumsum([len(q) for q in els])])
+    np.savez_compressed(HERE / "optopt.npz", names=np.array([n[i] for i in pick]), atom_offset=off,
+                        elements=np.concatenate([np.array(q) for q in els]), coordinates=np.concatenate(xyz),
+                        results=np.array(res))
+    print("optopt:", np.array(res)[:, :, 0])
+
+
 def run_options(pool):
     n, e, x = static_cases()
     pick = [n.index(k) for k in ("cc3", "windows_case_2", "windows_case_3", "windows_case_4")]
@@ -643,7 +684,7 @@ def run_ptraj(pool):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj"}
+    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj", "optopt"}
     if "cc3base" in which:
         load_reference()
         import tests.test_validate_cc3 as C
@@ -675,6 +716,8 @@ def main():
             run_rebuild(pool)
         if "ptraj" in which:
             run_ptraj(pool)
+        if "optopt" in which:
+            run_optopt(pool)
     meta = {
         "generator": "tests/golden/make_golden.py",
         "reference": "marcinmiklitz/pywindow @ /root/reference (imported with rdkit stub)",

@@ -95,3 +95,57 @@ def test_params_validation(hip_ctx):
     with pytest.raises(_lib.PwHipError):
         hip_ctx.set_params(_lib.Params(adjust_windows=-1.0))
     hip_ctx.set_params(None)
+
+
+# ---- opt_pore_diameter(bounds=, com=) ------------------------------------------------------------
+def optopt_cases():
+    import sys
+
+    sys.path.insert(0, str(GOLDEN))
+    from make_golden import OPT_CASES
+
+    return np.load(GOLDEN / "optopt.npz"), OPT_CASES
+
+
+def optopt_args(com, case):
+    off, bnd = case
+    start = None if off is None else com + np.array(off)
+    bounds = None
+    if bnd is not None:
+        bounds = tuple((None if a is None else com[k] + a, None if b is None else com[k] + b)
+                       for k, (a, b) in enumerate(bnd))
+    return start, bounds
+
+
+def test_host_team_custom_start_and_bounds(hostsim):
+    g, cases = optopt_cases()
+    base = run_hostsim(hostsim, g, _lib.STAGE_BASIC, _lib.Params())
+    for k, case in enumerate(cases):
+        for u in range(len(base)):
+            start, bounds = optopt_args(base[u]["com"], case)
+            one = {key: g[key] for key in ("elements", "coordinates")}
+            off = g["atom_offset"]
+            sub = {"atom_offset": np.array([0, off[u + 1] - off[u]]), "elements": one["elements"][off[u]:off[u + 1]],
+                   "coordinates": one["coordinates"][off[u]:off[u + 1]]}
+            out = run_hostsim(hostsim, sub, _lib.STAGE_OPT, _lib.Params(opt_start=start, opt_bounds=bounds))[0]
+            ref = g["results"][u][k]
+            assert float(out["pore_opt_d"]) == ref[0] and int(out["pore_opt_atom"]) == int(ref[1]), (u, k)
+            assert np.array_equal(out["pore_opt_c"], ref[2:5]), (u, k)
+
+
+@pytest.mark.gpu
+def test_hip_custom_start_and_bounds(hip_ctx):
+    from pywindow_amd import utilities as U
+
+    g, cases = optopt_cases()
+    off = g["atom_offset"]
+    for u in range(len(off) - 1):
+        el, xyz = g["elements"][off[u]:off[u + 1]], g["coordinates"][off[u]:off[u + 1]]
+        com = U.center_of_mass(el, xyz)
+        for k, case in enumerate(cases):
+            start, bounds = optopt_args(com, case)
+            d, atom, c = U.opt_pore_diameter(el, xyz, bounds=bounds, com=start)
+            ref = g["results"][u][k]
+            assert d == ref[0] and atom == int(ref[1]) and np.array_equal(c, ref[2:5]), (u, k)
+    with pytest.raises(ValueError):
+        U.opt_pore_diameter(el, xyz, bounds=((1.0, 0.0), (None, None), (None, None)))

@@ -26,6 +26,8 @@ def fd_grad(fun, x, f0, lb, ub, h=1e-8):
     n = len(x); g = np.zeros(n)
     for i in range(n):
         hi = h
+        if (x[i] + hi) - x[i] == 0:
+            hi = 1.4901161193847656e-08 * (1.0 if x[i] >= 0 else -1.0) * max(1.0, abs(x[i]))
         lower = x[i] - lb[i]; upper = ub[i] - x[i]
         xi = x[i] + hi
         violated = xi < lb[i] or xi > ub[i]
