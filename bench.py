@@ -109,11 +109,17 @@ def main():
     import torch
 
     dist = None
+    backend = os.environ.get("PW_BENCH_BACKEND", "nccl")       # "gloo": rehearsal of the multi-rank path
+    if "PW_BENCH_DEVICE" in os.environ:                        # ... with every rank on one GPU
+        local_rank = int(os.environ["PW_BENCH_DEVICE"])
     if world > 1:
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from pywindow_amd import _lib, synth
     from pywindow_amd import element_data as E
@@ -140,7 +146,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     out = res.download()
