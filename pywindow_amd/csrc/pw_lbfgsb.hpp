@@ -82,6 +82,65 @@ struct LbMem {
 // The optimiser object itself holds only scalars and pointers into its LbMem block; the
 // kernels keep it in a local variable, i.e. in registers, so the line search does not pay
 // an LDS round trip for every scalar it touches.
+// ---- triangular solves of one wave with the unknowns in registers ------------------------------
+// One element of x per lane; the pivot travels by v_readlane, so a step costs a division and an
+// fma instead of an LDS round trip and a barrier.  The same operations are applied to every
+// element, in the same order, as in the LDS sweeps of Lbfgsb::p_dtrsv_un / p_dtrsv_ut.  Out of
+// line on purpose: inlined into the optimiser step they raise its register pressure enough to
+// spill inside the hot loops.
+template <class T>
+PW_NOINLINE PW_HD inline void lb_trsv_un_wave(int n, const double* a, int lda, double* x) {
+    PW_ASSUME_LDS(a);
+    PW_ASSUME_LDS(x);
+    const int lane = T::lane();
+    double xk = lane < n ? x[lane] : 0.0;
+    for (int i = n - 1; i >= 0; --i) {
+        const double* ci = a + (long)i * lda;
+        double xi = T::bcast_u(xk, i) / ci[i];
+        if (lane == i) xk = xi;
+        if (lane < i) xk = pw_fma(-xi, ci[lane], xk);
+    }
+    T::wave_sync();
+    if (lane < n) x[lane] = xk;
+    T::wave_sync();
+}
+template <class T>
+PW_NOINLINE PW_HD inline void lb_trsv_ut_wave(int n, const double* a, int lda, double* x) {
+    PW_ASSUME_LDS(a);
+    PW_ASSUME_LDS(x);
+    const int lane = T::lane();
+    const double* ci = a + (long)(lane < n ? lane : 0) * lda;     // my row of U^T = column of U
+    double xk = lane < n ? x[lane] : 0.0;
+    double ak = 0.0;
+    for (int s = 0; s < n; ++s) {
+        double xs = T::bcast_u(xk, s);
+        if (s > 0) xs = xs - T::bcast_u(ak, s);
+        xs = xs / a[s + (long)s * lda];
+        if (lane == s) xk = xs;
+        if (lane > s && lane < n) {
+            if (lane >= 16 && s < 16) {
+                // rows 16.. take their first 16 terms through the SIMD ddot kernel order
+                if (s == 15) {
+                    double sl[4];
+                    for (int l = 0; l < 4; ++l) {
+                        double a0 = ci[l] * T::bcast_u(xk, l);
+                        double a1 = ci[4 + l] * T::bcast_u(xk, 4 + l);
+                        double a2 = ci[8 + l] * T::bcast_u(xk, 8 + l);
+                        double a3 = ci[12 + l] * T::bcast_u(xk, 12 + l);
+                        sl[l] = ((a0 + a1) + a2) + a3;
+                    }
+                    ak = (sl[0] + sl[2]) + (sl[1] + sl[3]);
+                }
+            } else {
+                ak = pw_fma(xs, ci[s], ak);
+            }
+        }
+    }
+    T::wave_sync();
+    if (lane < n) x[lane] = xk;
+    T::wave_sync();
+}
+
 template <int N>
 struct Lbfgsb {
     static constexpr int M = LB_M;
@@ -183,6 +242,7 @@ struct Lbfgsb {
     template <class T>
     PW_HD void p_dtrsv_un(int n, const double* a, int lda, double* x) {
         PW_ASSUME_LDS(mem);
+        if (T::WSIZE == 64 && n <= 64) { lb_trsv_un_wave<T>(n, a, lda, x); return; }
         for (int i = n - 1; i >= 0; --i) {
             const double* ci = a + (long)i * lda;
             double xi = x[i] / ci[i];
@@ -197,6 +257,7 @@ struct Lbfgsb {
     template <class T>
     PW_HD void p_dtrsv_ut(int n, const double* a, int lda, double* x) {
         PW_ASSUME_LDS(mem);
+        if (T::WSIZE == 64 && n <= 64) { lb_trsv_ut_wave<T>(n, a, lda, x); return; }
         for (int i = T::lane(); i < n; i += T::WSIZE) acc[i] = 0.0;
         T::wave_sync();
         for (int s = 0; s < n; ++s) {
