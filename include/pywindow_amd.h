@@ -187,6 +187,13 @@ typedef struct pw_cell_out {   /* caller-allocated */
 } pw_cell_out;
 
 int pw_discrete_molecules(pw_context *ctx, const pw_cell_in *in, const pw_cell_out *out);
+/* The same, but the molecules of all frames stay on the device as ONE resident batch (units in
+ * frame order, then molecule order) ready for pw_resident_launch: the modular branch of
+ * Trajectory._analysis_serial (trajectory.py:512-522) without a host round trip.  `vdw`: van der
+ * Waals radius per input atom.  n_mol / status (n_frames each) are returned to the host; *res is
+ * NULL when no frame has a molecule.  PW_E_TOO_LARGE: a frame needs larger caps (retry). */
+int pw_resident_from_cells(pw_context *ctx, const pw_cell_in *in, const double *vdw, int32_t atoms_cap,
+                           int32_t mols_cap, pw_resident **res, int32_t *n_mol, int32_t *status);
 int pw_context_device(pw_context *ctx);
 
 /* Native DL_POLY HISTORY ingest (trajectory.py:647-766): see pw_history_* in

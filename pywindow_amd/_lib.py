@@ -174,6 +174,7 @@ EXPORTED_SYMBOLS = [
     "pw_context_stream",
     "pw_context_device",
     "pw_discrete_molecules",
+    "pw_resident_from_cells",
     "pw_history_open",
     "pw_history_frames",
     "pw_history_atoms",
@@ -232,6 +233,8 @@ def load():
     L.pw_context_stream.restype = vp
     L.pw_context_device.argtypes = [vp]
     L.pw_discrete_molecules.argtypes = [vp, ctypes.POINTER(CellIn), ctypes.POINTER(CellOut)]
+    L.pw_resident_from_cells.argtypes = [vp, ctypes.POINTER(CellIn), vp, ctypes.c_int32, ctypes.c_int32,
+                                         ctypes.POINTER(vp), vp, vp]
     L.pw_history_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
     L.pw_history_frames.argtypes = [vp]
     L.pw_history_frames.restype = ctypes.c_int64
@@ -380,6 +383,43 @@ class Context:
                              "1/2 = more than 32 neighbours of one atom, 16 = cell thinner than the bond cut-off)")
         return n_mol, off, src, img, xyz
 
+    def resident_from_cells(self, topology, vdw, coords, lattice, lattice_inv, rebuild: bool):
+        """Frames -> discrete molecules -> ONE resident batch, all on the device
+        (``pw_resident_from_cells``).  Returns ``(resident or None, n_mol per frame)``."""
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        vdw = np.ascontiguousarray(vdw, dtype=np.float64)
+        f, n, _ = coords.shape
+        if n != topology.n or len(vdw) != n:
+            raise ValueError("coordinates / radii do not match the topology")
+        cap = 2 * n if rebuild else n
+        mols = min(cap, n)
+        for _attempt in range(6):
+            n_mol = np.zeros(f, np.int32)
+            status = np.zeros(f, np.int32)
+            cin = CellIn(f, n, 1 if rebuild else 0, coords.ctypes.data,
+                         None if lattice is None else lattice.ctypes.data,
+                         None if lattice_inv is None else lattice_inv.ctypes.data,
+                         topology.cov.ctypes.data, topology.mass.ctypes.data, topology.terminal.ctypes.data,
+                         topology.max_dist, topology.tol)
+            h = ctypes.c_void_p()
+            rc = load().pw_resident_from_cells(self._h, ctypes.byref(cin), vdw.ctypes.data, cap, mols,
+                                               ctypes.byref(h), n_mol.ctypes.data, status.ctypes.data)
+            if rc == -4:                 # PW_E_TOO_LARGE: a frame needs more room
+                cap *= 4
+                mols = min(cap, 4 * mols)
+                continue
+            _check(rc, "pw_resident_from_cells")
+            break
+        else:
+            raise PwHipError("pw_resident_from_cells: output does not fit")
+        bad = status & ~(RB_ATOMS_OVERFLOW | RB_MOLS_OVERFLOW)
+        if bad.any():
+            if h:
+                load().pw_resident_free(self._h, h)
+            raise PwHipError(f"pw_resident_from_cells: unsupported input (status bits {int(np.bitwise_or.reduce(bad))})")
+        res = Resident._adopt(self, h, int(n_mol.sum())) if h else None
+        return res, n_mol
+
     def upload(self, batch: Batch) -> "Resident":
         return Resident(self, batch)
 
@@ -397,6 +437,14 @@ class Resident:
         h = ctypes.c_void_p()
         _check(load().pw_resident_upload(ctx._h, ctypes.byref(batch.c), ctypes.byref(h)), "pw_resident_upload")
         self._h = h
+
+    @classmethod
+    def _adopt(cls, ctx: Context, handle, n_units: int) -> "Resident":
+        obj = cls.__new__(cls)
+        obj.ctx = ctx
+        obj.n_units = n_units
+        obj._h = handle
+        return obj
 
     def launch(self, stages: int = STAGE_ALL):
         _check(load().pw_resident_launch(self.ctx._h, self._h, stages), "pw_resident_launch")

@@ -274,6 +274,9 @@ template <int NW>
 static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const LaunchPlan& p, hipStream_t st,
                      int ws_first, bool with_adj, int counter_slot, int role) {
     auto kern = pw_analyse_kernel<NW>;
+    if (getenv("PW_PLAN_DEBUG"))
+        fprintf(stderr, "launch NW=%d grid %d lds %zu nmax %d units %ld atoms %ld\n", NW, p.grid, p.lds, r->nmax,
+                r->n_units, r->n_atoms);
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)p.lds));
     HIP_TRY(hipMemsetAsync(c->counter + counter_slot, 0, sizeof(unsigned long long), st));
@@ -583,6 +586,33 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
         HIP_TRY(hipMemsetAsync(r->d_outs[0], 0, 2 * sizeof(pw_unit_out) * r->n_units, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    *out = r;
+    return PW_OK;
+}
+
+// a batch whose arrays are already on the device (pw_resident_from_cells); takes ownership
+int pw_internal_resident_adopt(pw_context* c, long n_units, long n_atoms, int nmax, long* d_offset, double* d_xyz,
+                               double* d_vdw, double* d_mass, pw_resident** out) {
+    if (!c || !out || n_units <= 0 || nmax <= 0) return PW_E_BAD_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    pw_resident* r = new (std::nothrow) pw_resident();
+    if (!r) return PW_E_NOMEM;
+    memset(r, 0, sizeof(*r));
+    hipError_t e = hipMalloc((void**)&r->d_outs[0], 2 * sizeof(pw_unit_out) * n_units);
+    if (e == hipSuccess) e = hipMemsetAsync(r->d_outs[0], 0, 2 * sizeof(pw_unit_out) * n_units, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        set_err("pw_internal_resident_adopt", e);
+        if (r->d_outs[0]) (void)hipFree(r->d_outs[0]);
+        delete r;
+        return PW_E_HIP;
+    }
+    r->n_units = n_units; r->n_atoms = n_atoms; r->nmax = nmax;
+    r->d_offset = d_offset; r->d_xyz = d_xyz; r->d_vdw = d_vdw; r->d_mass = d_mass;
+    r->d_outs[1] = r->d_outs[0] + n_units;
+    r->d_out = r->d_outs[0];
+    r->cur = 0;
+    c->need_fork = 1;
     *out = r;
     return PW_OK;
 }

@@ -8,6 +8,7 @@
 // launch is sized for many concurrent frames rather than for wide teams.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/pywindow_amd.h"
@@ -68,10 +69,12 @@ pw_rebuild_kernel(pw_cell_in in, pw_cell_out out, unsigned char* __restrict__ sl
 }
 
 struct Buffers {
-    void* p[16];
+    static constexpr int CAP = 32;
+    void* p[CAP];
     int n = 0;
     ~Buffers() { for (int i = 0; i < n; ++i) if (p[i]) (void)hipFree(p[i]); }
     template <class X> hipError_t alloc(X** out, size_t bytes) {
+        if (n >= CAP) return hipErrorOutOfMemory;
         hipError_t e = hipMalloc((void**)out, bytes ? bytes : 8);
         if (e == hipSuccess) p[n++] = *out;
         return e;
@@ -89,17 +92,30 @@ struct Buffers {
         }                                                                                  \
     } while (0)
 
-extern "C" int pw_discrete_molecules(pw_context* ctx, const pw_cell_in* in, const pw_cell_out* out) {
-    if (!ctx || !in || !out || in->n_frames < 0 || in->n_atoms <= 0 || !in->xyz || !in->cov || !in->mass ||
-        !in->terminal || !out->n_mol || !out->status || !out->mol_offset || !out->src_atom ||
-        !out->src_image || !out->xyz || out->atoms_cap <= 0 || out->mols_cap <= 0)
-        return PW_E_BAD_ARG;
+extern "C" int pw_internal_resident_adopt(pw_context* ctx, long n_units, long n_atoms, int nmax, long* d_offset,
+                                          double* d_xyz, double* d_vdw, double* d_mass, pw_resident** out);
+
+namespace {
+
+// device-side result of the rebuild launch (freed with the Buffers object that owns it)
+struct DeviceCells {
+    int *n_mol, *status, *off, *src;
+    signed char* img;
+    double *oxyz, *mass;
+};
+
+bool args_ok(pw_context* ctx, const pw_cell_in* in) {
+    return ctx && in && in->n_frames >= 0 && in->n_atoms > 0 && in->xyz && in->cov && in->mass && in->terminal;
+}
+
+// upload the frames, run the rebuild kernel; outputs stay on the device
+int rebuild_on_device(pw_context* ctx, const pw_cell_in* in, int atoms_cap, int mols_cap, Buffers& buf,
+                      DeviceCells* dev) {
     if (in->rebuild && (!in->lattice || !in->lattice_inv)) {
         snprintf(pw_internal_error_buffer(), 512, "rebuild needs the lattice and its inverse");
         return PW_E_BAD_ARG;
     }
     if (in->lattice && !in->lattice_inv) return PW_E_BAD_ARG;
-    if (in->n_frames == 0) return PW_OK;
     RB_TRY(hipSetDevice(pw_context_device(ctx)));
     hipStream_t st = (hipStream_t)pw_context_stream(ctx);
     const long F = (long)in->n_frames;
@@ -111,53 +127,183 @@ extern "C" int pw_discrete_molecules(pw_context* ctx, const pw_cell_in* in, cons
     if (grid > F) grid = F;
     // keep the slabs within a quarter of the device memory
     while (grid > 1 && (size_t)grid * slab > prop.totalGlobalMem / 4) grid >>= 1;
-    Buffers buf;
     pw_cell_in d_in = *in;
-    pw_cell_out d_out = *out;
-    double *d_xyz, *d_lat = nullptr, *d_inv = nullptr, *d_cov, *d_mass, *d_oxyz;
+    pw_cell_out d_out;
+    double *d_xyz, *d_lat = nullptr, *d_inv = nullptr, *d_cov;
     unsigned char *d_term, *d_slabs;
-    int *d_nmol, *d_status, *d_off, *d_src;
-    signed char* d_img;
     unsigned long long* d_counter;
     RB_TRY(buf.alloc(&d_xyz, sizeof(double) * 3 * n * F));
     RB_TRY(buf.alloc(&d_cov, sizeof(double) * n));
-    RB_TRY(buf.alloc(&d_mass, sizeof(double) * n));
+    RB_TRY(buf.alloc(&dev->mass, sizeof(double) * n));
     RB_TRY(buf.alloc(&d_term, n));
     if (in->lattice) {
         RB_TRY(buf.alloc(&d_lat, sizeof(double) * 9 * F));
         RB_TRY(buf.alloc(&d_inv, sizeof(double) * 9 * F));
     }
-    RB_TRY(buf.alloc(&d_nmol, sizeof(int) * F));
-    RB_TRY(buf.alloc(&d_status, sizeof(int) * F));
-    RB_TRY(buf.alloc(&d_off, sizeof(int) * F * (out->mols_cap + 1)));
-    RB_TRY(buf.alloc(&d_src, sizeof(int) * F * out->atoms_cap));
-    RB_TRY(buf.alloc(&d_img, (size_t)F * out->atoms_cap));
-    RB_TRY(buf.alloc(&d_oxyz, sizeof(double) * 3 * F * out->atoms_cap));
+    RB_TRY(buf.alloc(&dev->n_mol, sizeof(int) * F));
+    RB_TRY(buf.alloc(&dev->status, sizeof(int) * F));
+    RB_TRY(buf.alloc(&dev->off, sizeof(int) * F * (mols_cap + 1)));
+    RB_TRY(buf.alloc(&dev->src, sizeof(int) * F * atoms_cap));
+    RB_TRY(buf.alloc(&dev->img, (size_t)F * atoms_cap));
+    RB_TRY(buf.alloc(&dev->oxyz, sizeof(double) * 3 * F * atoms_cap));
     RB_TRY(buf.alloc(&d_slabs, (size_t)grid * slab));
     RB_TRY(buf.alloc(&d_counter, sizeof(unsigned long long)));
     RB_TRY(hipMemcpyAsync(d_xyz, in->xyz, sizeof(double) * 3 * n * F, hipMemcpyHostToDevice, st));
     RB_TRY(hipMemcpyAsync(d_cov, in->cov, sizeof(double) * n, hipMemcpyHostToDevice, st));
-    RB_TRY(hipMemcpyAsync(d_mass, in->mass, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    RB_TRY(hipMemcpyAsync(dev->mass, in->mass, sizeof(double) * n, hipMemcpyHostToDevice, st));
     RB_TRY(hipMemcpyAsync(d_term, in->terminal, n, hipMemcpyHostToDevice, st));
     if (in->lattice) {
         RB_TRY(hipMemcpyAsync(d_lat, in->lattice, sizeof(double) * 9 * F, hipMemcpyHostToDevice, st));
         RB_TRY(hipMemcpyAsync(d_inv, in->lattice_inv, sizeof(double) * 9 * F, hipMemcpyHostToDevice, st));
     }
     RB_TRY(hipMemsetAsync(d_counter, 0, sizeof(unsigned long long), st));
-    RB_TRY(hipMemsetAsync(d_off, 0, sizeof(int) * F * (out->mols_cap + 1), st));
+    RB_TRY(hipMemsetAsync(dev->off, 0, sizeof(int) * F * (mols_cap + 1), st));
     d_in.xyz = d_xyz; d_in.lattice = d_lat; d_in.lattice_inv = d_inv;
-    d_in.cov = d_cov; d_in.mass = d_mass; d_in.terminal = d_term;
-    d_out.n_mol = d_nmol; d_out.status = d_status; d_out.mol_offset = d_off;
-    d_out.src_atom = d_src; d_out.src_image = (int8_t*)d_img; d_out.xyz = d_oxyz;
+    d_in.cov = d_cov; d_in.mass = dev->mass; d_in.terminal = d_term;
+    d_out.atoms_cap = atoms_cap; d_out.mols_cap = mols_cap;
+    d_out.n_mol = dev->n_mol; d_out.status = dev->status; d_out.mol_offset = dev->off;
+    d_out.src_atom = dev->src; d_out.src_image = (int8_t*)dev->img; d_out.xyz = dev->oxyz;
     hipLaunchKernelGGL(pw_rebuild_kernel, dim3((unsigned)grid), dim3(RB_WAVES * 64), 0, st, d_in, d_out,
                        d_slabs, slab, d_counter);
     RB_TRY(hipGetLastError());
-    RB_TRY(hipMemcpyAsync(out->n_mol, d_nmol, sizeof(int) * F, hipMemcpyDeviceToHost, st));
-    RB_TRY(hipMemcpyAsync(out->status, d_status, sizeof(int) * F, hipMemcpyDeviceToHost, st));
-    RB_TRY(hipMemcpyAsync(out->mol_offset, d_off, sizeof(int) * F * (out->mols_cap + 1), hipMemcpyDeviceToHost, st));
-    RB_TRY(hipMemcpyAsync(out->src_atom, d_src, sizeof(int) * F * out->atoms_cap, hipMemcpyDeviceToHost, st));
-    RB_TRY(hipMemcpyAsync(out->src_image, d_img, (size_t)F * out->atoms_cap, hipMemcpyDeviceToHost, st));
-    RB_TRY(hipMemcpyAsync(out->xyz, d_oxyz, sizeof(double) * 3 * F * out->atoms_cap, hipMemcpyDeviceToHost, st));
+    return PW_OK;
+}
+
+// exclusive scans over the frames: first unit and first atom of every frame (F + 1 entries each)
+__global__ void rb_scan_kernel(long F, int mols_cap, const int* __restrict__ n_mol, const int* __restrict__ off,
+                               long* __restrict__ unit_base, long* __restrict__ atom_base) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long u = 0, a = 0;
+    for (long f = 0; f < F; ++f) {
+        unit_base[f] = u;
+        atom_base[f] = a;
+        int m = n_mol[f];
+        u += m;
+        a += off[f * (mols_cap + 1) + m];
+    }
+    unit_base[F] = u;
+    atom_base[F] = a;
+}
+
+// the molecules of all frames as one ragged batch: offsets, coordinates, radii and masses by source atom
+__global__ void rb_gather_kernel(long F, int atoms_cap, int mols_cap, const int* __restrict__ n_mol,
+                                 const int* __restrict__ off, const int* __restrict__ src,
+                                 const double* __restrict__ oxyz, const double* __restrict__ vdw,
+                                 const double* __restrict__ mass, const long* __restrict__ unit_base,
+                                 const long* __restrict__ atom_base, long* __restrict__ d_offset,
+                                 double* __restrict__ xyz, double* __restrict__ uv, double* __restrict__ um,
+                                 int* __restrict__ nmax) {
+    const long f = blockIdx.x;
+    const int m = n_mol[f];
+    const int* fo = off + f * (mols_cap + 1);
+    const long ub = unit_base[f], ab = atom_base[f];
+    for (int k = threadIdx.x; k < m; k += blockDim.x) {
+        d_offset[ub + k] = ab + fo[k];
+        atomicMax(nmax, fo[k + 1] - fo[k]);
+    }
+    if (f == F - 1 && threadIdx.x == 0) d_offset[ub + m] = ab + fo[m];
+    const int na = fo[m];
+    const int* fs = src + f * atoms_cap;
+    const double* fx = oxyz + 3 * f * atoms_cap;
+    for (int j = threadIdx.x; j < na; j += blockDim.x) {
+        long d = ab + j;
+        xyz[3 * d] = fx[3 * j]; xyz[3 * d + 1] = fx[3 * j + 1]; xyz[3 * d + 2] = fx[3 * j + 2];
+        int q = fs[j];
+        uv[d] = vdw[q];
+        um[d] = mass[q];
+    }
+}
+
+}  // namespace
+
+extern "C" int pw_discrete_molecules(pw_context* ctx, const pw_cell_in* in, const pw_cell_out* out) {
+    if (!args_ok(ctx, in) || !out || !out->n_mol || !out->status || !out->mol_offset || !out->src_atom ||
+        !out->src_image || !out->xyz || out->atoms_cap <= 0 || out->mols_cap <= 0)
+        return PW_E_BAD_ARG;
+    if (in->n_frames == 0) return PW_OK;
+    Buffers buf;
+    DeviceCells dev;
+    int rc = rebuild_on_device(ctx, in, out->atoms_cap, out->mols_cap, buf, &dev);
+    if (rc != PW_OK) return rc;
+    hipStream_t st = (hipStream_t)pw_context_stream(ctx);
+    const long F = (long)in->n_frames;
+    RB_TRY(hipMemcpyAsync(out->n_mol, dev.n_mol, sizeof(int) * F, hipMemcpyDeviceToHost, st));
+    RB_TRY(hipMemcpyAsync(out->status, dev.status, sizeof(int) * F, hipMemcpyDeviceToHost, st));
+    RB_TRY(hipMemcpyAsync(out->mol_offset, dev.off, sizeof(int) * F * (out->mols_cap + 1), hipMemcpyDeviceToHost, st));
+    RB_TRY(hipMemcpyAsync(out->src_atom, dev.src, sizeof(int) * F * out->atoms_cap, hipMemcpyDeviceToHost, st));
+    RB_TRY(hipMemcpyAsync(out->src_image, dev.img, (size_t)F * out->atoms_cap, hipMemcpyDeviceToHost, st));
+    RB_TRY(hipMemcpyAsync(out->xyz, dev.oxyz, sizeof(double) * 3 * F * out->atoms_cap, hipMemcpyDeviceToHost, st));
     RB_TRY(hipStreamSynchronize(st));
     return PW_OK;
+}
+
+extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, const double* vdw, int32_t atoms_cap,
+                                      int32_t mols_cap, pw_resident** res, int32_t* n_mol, int32_t* status) {
+    if (!args_ok(ctx, in) || !vdw || !res || !n_mol || !status || atoms_cap <= 0 || mols_cap <= 0 || in->n_frames <= 0)
+        return PW_E_BAD_ARG;
+    *res = nullptr;
+    Buffers buf;
+    DeviceCells dev;
+    int rc = rebuild_on_device(ctx, in, atoms_cap, mols_cap, buf, &dev);
+    if (rc != PW_OK) return rc;
+    hipStream_t st = (hipStream_t)pw_context_stream(ctx);
+    const long F = (long)in->n_frames;
+    const int n = in->n_atoms;
+    long *d_ubase, *d_abase;
+    double* d_vdw_atom;
+    int* d_nmax;
+    RB_TRY(buf.alloc(&d_ubase, sizeof(long) * (F + 1)));
+    RB_TRY(buf.alloc(&d_abase, sizeof(long) * (F + 1)));
+    RB_TRY(buf.alloc(&d_vdw_atom, sizeof(double) * n));
+    RB_TRY(buf.alloc(&d_nmax, sizeof(int)));
+    RB_TRY(hipMemcpyAsync(d_vdw_atom, vdw, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    RB_TRY(hipMemsetAsync(d_nmax, 0, sizeof(int), st));
+    hipLaunchKernelGGL(rb_scan_kernel, dim3(1), dim3(64), 0, st, F, (int)mols_cap, dev.n_mol, dev.off, d_ubase, d_abase);
+    RB_TRY(hipGetLastError());
+    long totals[2] = {0, 0};
+    RB_TRY(hipMemcpyAsync(n_mol, dev.n_mol, sizeof(int) * F, hipMemcpyDeviceToHost, st));
+    RB_TRY(hipMemcpyAsync(status, dev.status, sizeof(int) * F, hipMemcpyDeviceToHost, st));
+    RB_TRY(hipMemcpyAsync(&totals[0], d_ubase + F, sizeof(long), hipMemcpyDeviceToHost, st));
+    RB_TRY(hipMemcpyAsync(&totals[1], d_abase + F, sizeof(long), hipMemcpyDeviceToHost, st));
+    RB_TRY(hipStreamSynchronize(st));
+    for (long f = 0; f < F; ++f)
+        if (status[f] & (PW_RB_ATOMS_OVERFLOW | PW_RB_MOLS_OVERFLOW)) {
+            snprintf(pw_internal_error_buffer(), 512, "frame %ld needs more than %d atoms / %d molecules", f,
+                     atoms_cap, mols_cap);
+            return PW_E_TOO_LARGE;
+        }
+    const long U = totals[0], A = totals[1];
+    if (U == 0) return PW_OK;      // nothing to analyse: *res stays NULL
+    long* d_offset = nullptr;
+    double *d_xyz = nullptr, *d_uv = nullptr, *d_um = nullptr;
+    auto drop = [&]() {
+        if (d_offset) (void)hipFree(d_offset);
+        if (d_xyz) (void)hipFree(d_xyz);
+        if (d_uv) (void)hipFree(d_uv);
+        if (d_um) (void)hipFree(d_um);
+    };
+#define RBF_TRY(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            snprintf(pw_internal_error_buffer(), 512, "%s: %s", #call, hipGetErrorString(e_)); \
+            drop();                                                                        \
+            return PW_E_HIP;                                                               \
+        }                                                                                  \
+    } while (0)
+    RBF_TRY(hipMalloc((void**)&d_offset, sizeof(long) * (U + 1)));
+    RBF_TRY(hipMalloc((void**)&d_xyz, sizeof(double) * 3 * A));
+    RBF_TRY(hipMalloc((void**)&d_uv, sizeof(double) * A));
+    RBF_TRY(hipMalloc((void**)&d_um, sizeof(double) * A));
+    hipLaunchKernelGGL(rb_gather_kernel, dim3((unsigned)F), dim3(256), 0, st, F, (int)atoms_cap, (int)mols_cap,
+                       dev.n_mol, dev.off, dev.src, dev.oxyz, d_vdw_atom, dev.mass, d_ubase, d_abase, d_offset, d_xyz,
+                       d_uv, d_um, d_nmax);
+    RBF_TRY(hipGetLastError());
+    int nmax = 0;
+    RBF_TRY(hipMemcpyAsync(&nmax, d_nmax, sizeof(int), hipMemcpyDeviceToHost, st));
+    RBF_TRY(hipStreamSynchronize(st));
+#undef RBF_TRY
+    rc = pw_internal_resident_adopt(ctx, U, A, nmax, d_offset, d_xyz, d_uv, d_um, res);
+    if (rc != PW_OK) drop();
+    return rc;
 }

@@ -243,16 +243,18 @@ class DLPOLY:
         ids = element_ids(el)
         topo = rb.CellTopology(el)
         coords, lattice = self._read_selected(frames, self.periodic)
-        n_mol, off, src, _img, xyz = rb.discrete_molecules_frames(topo, coords, lattice, rebuild, device)
-        # every molecule of every frame becomes one unit of ONE analysis launch
-        counts = [np.diff(off[f][: n_mol[f] + 1]) for f in range(len(frames))]
-        sizes = np.concatenate(counts) if counts else np.zeros(0, np.int64)
-        atom_offset = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-        take = [slice(0, int(off[f][n_mol[f]])) for f in range(len(frames))]
-        flat_xyz = np.concatenate([xyz[f][take[f]] for f in range(len(frames))])
-        flat_src = np.concatenate([src[f][take[f]] for f in range(len(frames))])
-        batch = _lib.Batch(atom_offset, flat_xyz, VDW[ids][flat_src], MASS[ids][flat_src])
-        recs = engine.context(device).analyse(batch, _lib.STAGE_ALL)
+        # frames -> molecules -> units without leaving the device: every molecule of every frame is
+        # one unit of ONE analysis launch
+        coords, lat, inv = rb.pack_frames(coords, lattice)
+        ctx = engine.context(device)
+        res, n_mol = ctx.resident_from_cells(topo, VDW[ids], coords, lat, inv, rebuild)
+        if res is None:
+            return np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE), np.zeros(0, np.int64), np.zeros(0, np.int64)
+        try:
+            res.launch(_lib.STAGE_ALL)
+            recs = res.download()
+        finally:
+            res.free()
         unit_frame = np.repeat(np.asarray(frames, np.int64), n_mol)
         unit_mol = np.concatenate([np.arange(k) for k in n_mol]).astype(np.int64)
         return recs, unit_frame, unit_mol
