@@ -214,3 +214,38 @@ def test_periodic_trajectory_modular_rebuild(hip_ctx, tmp_path):
     # columnar form, and a frame the reference cannot finish is still analysed here
     recs, uframe, umol = traj.modular_records(frames=[1], rebuild=True, forcefield="opls")
     assert len(recs) == 8 and (uframe == 1).all() and list(umol) == list(range(8))
+
+
+@pytest.mark.gpu
+def test_resident_hand_over_matches_host_path(hip_ctx):
+    """pw_resident_from_cells: the ragged unit batch built on the device gives the same analysis
+    records as the host-marshalled path; capacity retries (a framework 27x the cell) work."""
+    from pywindow_amd import _lib
+    from pywindow_amd import element_data as E
+
+    for name, rebuild in (("cc3_cell_md1", True), ("cc3_cell", False), ("EPIRUR", True)):
+        system = CASES[name][0]
+        topo = RB.CellTopology(system["elements"])
+        ids = E.element_ids(system["elements"])
+        coords, lat, inv = RB.pack_frames(np.array([system["coordinates"]] * 3), np.array([system["lattice"]] * 3))
+        res, n_mol = hip_ctx.resident_from_cells(topo, E.VDW[ids], coords, lat, inv, rebuild)
+        mols = RB.discrete_molecules(dict(system), rebuild=True if rebuild else None)
+        assert list(n_mol) == [len(mols)] * 3 and res.n_units == 3 * len(mols)
+        if max(len(m["elements"]) for m in mols) >= 20:
+            res.launch(_lib.STAGE_BASIC | _lib.STAGE_AVG)
+            got = res.download()
+            from pywindow_amd import engine
+
+            want = engine.analyse([(m["elements"], m["coordinates"]) for m in mols], _lib.STAGE_BASIC | _lib.STAGE_AVG)
+            for k in range(3):
+                part = got[k * len(mols):(k + 1) * len(mols)]
+                for key in ("n_atoms", "mw", "com", "maxd", "pore_d", "avg_d"):
+                    assert np.array_equal(part[key], want[key]), (name, key)
+        res.free()
+    system = CASES["MIBQAR"][0]
+    topo = RB.CellTopology(system["elements"])
+    ids = E.element_ids(system["elements"])
+    coords, lat, inv = RB.pack_frames(system["coordinates"][None], system["lattice"][None])
+    res, n_mol = hip_ctx.resident_from_cells(topo, E.VDW[ids], coords, lat, inv, True)
+    assert list(n_mol) == [1] and res.n_units == 1
+    res.free()
