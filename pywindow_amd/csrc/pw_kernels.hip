@@ -136,6 +136,18 @@ __global__ void pw_gate_kernel(UnitQueue* queue, int expected) {
     }
 }
 
+// Tail gate: holds the optimiser launch of analysis k+1 until all but the slowest few chains
+// of analysis k have been published, so that the two launches overlap only where the older one
+// leaves most SIMDs idle.  One wave, bounded wait.
+__global__ void pw_tail_gate_kernel(const UnitQueue* prev, unsigned long long need) {
+    if (threadIdx.x != 0) return;
+    long long t0 = wall_clock64();
+    while (__hip_atomic_load(&prev->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(32);
+        if (wall_clock64() - t0 > 200000000ll) break;   // 2 s
+    }
+}
+
 // Fine-grained entry: min_i(|r_i - p| - vdw_i) and its first argmin for arbitrary
 // points p (reference pore_diameter(elements, coordinates, com=p)/2,
 // utilities.py:375-388).  One lane per point, atoms streamed from global memory.
@@ -188,6 +200,11 @@ struct pw_context {
     // slots, events), so the optimiser chains of launch k+1 run beside the window tail of k
     hipEvent_t ev_reset[2], ev_prod[2], ev_gate[2], ev_join[2], ev_done[2];
     int done_valid[2];
+    hipEvent_t ev_tail[2];   // tail gate of the launch using set b has run
+    int tail_valid[2];
+    long last_units[2];
+    int tail_pct;            // PW_TAIL_GATE: start the next optimiser launch at this % published
+                             // (default 97; 0 = strictly one optimiser launch at a time)
     int flip;                // buffer set of the latest pipeline launch
     int need_fork;           // main stream carries work the next pipeline launch must wait for
     UnitQueue* cur_queue;
@@ -345,6 +362,12 @@ int pw_context_create(int device, pw_context** out) {
         HIP_TRY(hipEventCreateWithFlags(&c->ev_gate[b], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_join[b], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_tail[b], hipEventDisableTiming));
+    }
+    {
+        const char* tg = getenv("PW_TAIL_GATE");
+        c->tail_pct = tg ? atoi(tg) : 97;
+        if (c->tail_pct < 0 || c->tail_pct > 100) c->tail_pct = 0;
     }
     c->need_fork = 1;
     HIP_TRY(hipEventCreate(&c->ev0));
@@ -384,6 +407,7 @@ void pw_context_destroy(pw_context* c) {
         if (c->ev_gate[b]) (void)hipEventDestroy(c->ev_gate[b]);
         if (c->ev_join[b]) (void)hipEventDestroy(c->ev_join[b]);
         if (c->ev_done[b]) (void)hipEventDestroy(c->ev_done[b]);
+        if (c->ev_tail[b]) (void)hipEventDestroy(c->ev_tail[b]);
     }
     if (c->adj) (void)hipFree(c->adj);
     if (c->queue) (void)hipFree(c->queue);
@@ -497,7 +521,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     c->flip = b;
     {
         const char* ps = getenv("PW_PROD_STREAMS");
-        c->prod = c->prods[(ps && ps[0] == '2') ? b : 0];
+        c->prod = c->prods[((ps && ps[0] == '2') || c->tail_pct > 0) ? b : 0];
     }
     r->cur ^= 1;
     r->d_out = r->d_outs[r->cur];
@@ -511,10 +535,21 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         c->need_fork = 0;
     }
     if (c->done_valid[b]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_done[b], 0));
+    // the previous launch's tail gate reads the queue that is reset below
+    if (c->tail_valid[b ^ 1]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_tail[b ^ 1], 0));
     HIP_TRY(hipMemsetAsync(r->d_out, 0, sizeof(pw_unit_out) * r->n_units, c->prod));
     HIP_TRY(hipMemsetAsync(c->cur_queue, 0, sizeof(UnitQueue), c->prod));
     HIP_TRY(hipMemsetAsync(c->cur_slots, 0xff, sizeof(int) * (size_t)r->n_units, c->prod));
     HIP_TRY(hipEventRecord(c->ev_reset[b], c->prod));
+    c->tail_valid[b] = 0;
+    if (c->tail_pct > 0 && c->done_valid[b ^ 1] && c->last_units[b ^ 1] > 0) {
+        unsigned long long need = (unsigned long long)((c->last_units[b ^ 1] * c->tail_pct) / 100);
+        hipLaunchKernelGGL(pw_tail_gate_kernel, dim3(1), dim3(64), 0, c->prod, c->queue + (b ^ 1), need);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev_tail[b], c->prod));
+        c->tail_valid[b] = 1;
+    }
+    c->last_units[b] = r->n_units;
     // two optimiser launches can be in flight: separate work counters and workspaces
     rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod,
                      pc.grid + (b ? pa.grid + pb.grid : 0), false, b ? 3 : 0, PW_ROLE_PRODUCER);
