@@ -755,6 +755,24 @@ PW_HD inline void load_unit(UnitShared& sh, int n, const double* xyz, const doub
     T::sync();
 }
 
+// sum_{i<n} term(i), strictly left to right (numpy's axis-0 reduction over rows), with the terms
+// of eight rows fetched before they are added: the additions stay one dependent chain, the LDS
+// reads (two levels through the permutation) no longer sit on it
+template <class F>
+PW_HD inline double seq_sum_blocked(int n, F term) {
+    double s = term(0);
+    int i = 1;
+    for (; i + 8 <= n; i += 8) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = term(i + j);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = s + v[j];
+    }
+    for (; i < n; ++i) s = s + term(i);
+    return s;
+}
+
 // shifted copy S = A - c (elementwise), with |r|^2 and the row-sequential centroid
 template <class T>
 PW_HD inline void make_shifted(UnitShared& sh, int n, double cx, double cy, double cz) {
@@ -767,8 +785,7 @@ PW_HD inline void make_shifted(UnitShared& sh, int n, double cx, double cy, doub
     // centroid: np.sum(coordinates, axis=0) / N -- rows added in the caller's atom order
     auto cen_comp = [&](int c) {
         const ldouble* a = c == 0 ? sh.S.x : (c == 1 ? sh.S.y : sh.S.z);
-        double s = a[sh.inv[0]];
-        for (int i = 1; i < n; ++i) s = s + a[sh.inv[i]];
+        double s = seq_sum_blocked(n, [&](int i) { return a[sh.inv[i]]; });
         sh.v->centroid[c] = s / (double)n;
     };
     if (T::SIZE >= 3) {
@@ -782,45 +799,138 @@ PW_HD inline void make_shifted(UnitShared& sh, int n, double cx, double cy, doub
 // max_dim over frame F (utilities.py:355-372); result in sh.v->maxd*, all threads.
 template <class T>
 PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n) {
+    // max over pairs (diagonal included) of d_ij + (vdw_i + vdw_j), first maximum in row-major
+    // order of the caller's numbering (utilities.py:355-372).  Two passes; a thread owns a
+    // (row, column half) and walks the columns, so the lanes of a wave hold consecutive rows and
+    // read the SAME column at the same time (LDS broadcast, no bank conflicts):
+    //   1. value only -- inside one radius group of the column the maximum of the sum is at the
+    //      maximum squared distance (sqrt and the addition of a common constant are monotone), so
+    //      the tile loop carries squared distances and takes one sqrt per (row, group);
+    //   2. the winner's index: only pairs whose squared distance is within a few ulps of what
+    //      the maximum requires are evaluated exactly and compared by index.
+    const auto& C = *F.cls;
+    const int ngrp = C.k;
+    const int half = (n + 1) / 2;
+    const int ntile = 2 * n;
     double best = -PW_INF;
-    int bidx = 0x7fffffff;
-    // rows paired (i, n-1-i) for balance
-    for (int r = T::tid(); r < n; r += T::SIZE) {
-        int i = (r & 1) ? (n - 1 - (r >> 1)) : (r >> 1);
-        double xi = F.x[i], yi = F.y[i], zi = F.z[i], xxi = F.xx[i], vi = F.vdw[i];
-        int oi = F.perm[i];
-        for (int j = i; j < n; ++j) {
-            double d;
-            if (j == i) {
-                d = 0.0;
-            } else {
-                double g = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
-                // entry (row, column) of the reference's matrix has row < column in the
-                // caller's numbering: the row norm is added first
-                double d2 = (oi < F.perm[j]) ? ((-2.0 * g) + xxi) + F.xx[j]
-                                             : ((-2.0 * g) + F.xx[j]) + xxi;
-                d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
+    if (ngrp > 0) {
+        for (int t = T::tid(); t < ntile; t += T::SIZE) {
+            const int part = t >= n ? 1 : 0;
+            const int i = t - part * n;
+            const int j0 = part * half, j1 = part ? n : half;
+            if (j1 <= i) continue;
+            const double xi = F.x[i], yi = F.y[i], zi = F.z[i], xxi = F.xx[i], vi = F.vdw[i];
+            const int oi = F.perm[i];
+            if (j0 <= i) best = pw_max(best, 0.0 + (vi + vi));          // the diagonal entry
+            for (int g = 0; g < ngrp; ++g) {
+                int lo = C.off[g] > j0 ? C.off[g] : j0;
+                if (lo <= i) lo = i + 1;
+                const int hi = C.off[g + 1] < j1 ? C.off[g + 1] : j1;
+                if (lo >= hi) continue;
+                double m2 = -PW_INF;
+                for (int j = lo; j < hi; ++j) {
+                    double gg = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
+                    // entry (row, column) of the reference's matrix has row < column in the
+                    // caller's numbering: the row norm is added first
+                    double d2 = (oi < F.perm[j]) ? ((-2.0 * gg) + xxi) + F.xx[j] : ((-2.0 * gg) + F.xx[j]) + xxi;
+                    m2 = __builtin_fmax(m2, d2);
+                }
+                double d = pw_sqrt(m2 > 0.0 ? m2 : 0.0);
+                best = pw_max(best, d + (vi + C.vdw[g]));
             }
-            double v = d + (vi + F.vdw[j]);
-            int oj = F.perm[j];
-            int idx = oi < oj ? oi * n + oj : oj * n + oi;
-            if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
         }
     }
-    T::wave_argmax(best, bidx);
-    if (T::lane() == 0) { sh.v->red_v[T::wave()] = best; sh.v->red_i[T::wave()] = bidx; }
+    // team maximum of the values
+    best = -T::wave_min(-best);
+    if (T::lane() == 0) sh.v->red_v[T::wave()] = best;
+    T::sync();
+    double vmax = sh.v->red_v[0];
+    for (int w = 1; w < T::NWAVES; ++w) vmax = pw_max(vmax, sh.v->red_v[w]);
+    T::sync();
+    // pass 2: smallest row-major index among the pairs that reach vmax
+    double bidx = PW_INF;
+    if (ngrp > 0) {
+        for (int t = T::tid(); t < ntile; t += T::SIZE) {
+            const int part = t >= n ? 1 : 0;
+            const int i = t - part * n;
+            const int j0 = part * half, j1 = part ? n : half;
+            if (j1 <= i) continue;
+            const double xi = F.x[i], yi = F.y[i], zi = F.z[i], xxi = F.xx[i], vi = F.vdw[i];
+            const int oi = F.perm[i];
+            if (j0 <= i && 0.0 + (vi + vi) == vmax) bidx = pw_min(bidx, (double)(oi * n + oi));
+            for (int g = 0; g < ngrp; ++g) {
+                int lo = C.off[g] > j0 ? C.off[g] : j0;
+                if (lo <= i) lo = i + 1;
+                const int hi = C.off[g + 1] < j1 ? C.off[g + 1] : j1;
+                if (lo >= hi) continue;
+                const double c = vi + C.vdw[g];
+                // d + c == vmax needs d >= vmax - c - ulp(vmax); squared, with margin
+                const double need = (vmax - c) - 1e-15 * vmax;
+                const double thr = need > 0.0 ? need * need * (1.0 - 1e-15) : -PW_INF;
+                for (int j = lo; j < hi; ++j) {
+                    double gg = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
+                    int oj = F.perm[j];
+                    double d2 = (oi < oj) ? ((-2.0 * gg) + xxi) + F.xx[j] : ((-2.0 * gg) + F.xx[j]) + xxi;
+                    if (d2 >= thr) {
+                        double d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
+                        if (d + c == vmax) {
+                            int idx = oi < oj ? oi * n + oj : oj * n + oi;
+                            bidx = pw_min(bidx, (double)idx);
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        // more radii than groups: plain scan (value and index together)
+        double bv = -PW_INF;
+        for (int r = T::tid(); r < n; r += T::SIZE) {
+            int i = (r & 1) ? (n - 1 - (r >> 1)) : (r >> 1);
+            double xi = F.x[i], yi = F.y[i], zi = F.z[i], xxi = F.xx[i], vi = F.vdw[i];
+            int oi = F.perm[i];
+            for (int j = i; j < n; ++j) {
+                double d = 0.0;
+                int oj = F.perm[j];
+                if (j != i) {
+                    double gg = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
+                    double d2 = (oi < oj) ? ((-2.0 * gg) + xxi) + F.xx[j] : ((-2.0 * gg) + F.xx[j]) + xxi;
+                    d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
+                }
+                double v = d + (vi + F.vdw[j]);
+                double idx = (double)(oi < oj ? oi * n + oj : oj * n + oi);
+                if (v > bv || (v == bv && idx < bidx)) { bv = v; bidx = idx; }
+            }
+        }
+        // two-level reduction on (value, index)
+        int ii = (int)(bidx < 2147483647.0 ? bidx : 2147483647.0);
+        T::wave_argmax(bv, ii);
+        if (T::lane() == 0) { sh.v->red_v[T::wave()] = bv; sh.v->red_i[T::wave()] = ii; }
+        T::sync();
+        if (T::tid() == 0) {
+            double bb = sh.v->red_v[0];
+            int bi = sh.v->red_i[0];
+            for (int w = 1; w < T::NWAVES; ++w) {
+                double v = sh.v->red_v[w];
+                int vi2 = sh.v->red_i[w];
+                if (v > bb || (v == bb && vi2 < bi)) { bb = v; bi = vi2; }
+            }
+            sh.v->maxd = bb;
+            sh.v->maxd_i = bi / n;
+            sh.v->maxd_j = bi % n;
+        }
+        T::sync();
+        return;
+    }
+    bidx = T::wave_min(bidx);
+    if (T::lane() == 0) sh.v->red_v[T::wave()] = bidx;
     T::sync();
     if (T::tid() == 0) {
-        double b = sh.v->red_v[0];
-        int bi = sh.v->red_i[0];
-        for (int w = 1; w < T::NWAVES; ++w) {
-            double v = sh.v->red_v[w];
-            int vi = sh.v->red_i[w];
-            if (v > b || (v == b && vi < bi)) { b = v; bi = vi; }
-        }
-        sh.v->maxd = b;
-        sh.v->maxd_i = bi / n;
-        sh.v->maxd_j = bi % n;
+        double bi = sh.v->red_v[0];
+        for (int w = 1; w < T::NWAVES; ++w) bi = pw_min(bi, sh.v->red_v[w]);
+        int idx = (int)bi;
+        sh.v->maxd = vmax;
+        sh.v->maxd_i = idx / n;
+        sh.v->maxd_j = idx % n;
     }
     T::sync();
 }
@@ -843,8 +953,7 @@ PW_NOINLINE PW_HD inline void stage_basic(UnitShared& sh, TeamWorkspace* ws, int
     // centre of mass: per component the row-sequential sum of x_i*m_i over the mass
     auto com_comp = [&](int c) {
         const ldouble* a = c == 0 ? sh.A.x : (c == 1 ? sh.A.y : sh.A.z);
-        double s = a[sh.inv[0]] * sh.mass[0];
-        for (int i = 1; i < n; ++i) s = s + a[sh.inv[i]] * sh.mass[i];
+        double s = seq_sum_blocked(n, [&](int i) { return a[sh.inv[i]] * sh.mass[i]; });
         v.com[c] = s / v.mw;
     };
     if (T::SIZE >= 3) {
@@ -1009,6 +1118,7 @@ template <class T>
 PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
                                              const pw_params& prm) {
     auto& v = *sh.v;
+    PW_T0(t_a0);
     make_shifted<T>(sh, n, v.com[0], v.com[1], v.com[2]);
     // preserve the input-frame max_dim: the shifted frame's replaces it only here
     double keep_d = v.maxd;
@@ -1039,6 +1149,8 @@ PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, i
     double* s_leaf = (double*)arena.take(256 * 8);
     if (!s_tab || !s_acc || !s_leaf) { s_tab = ws->leaf_tab; s_acc = ws->acc8; s_leaf = ws->leaf; }
     double cen[3] = {v.centroid[0], v.centroid[1], v.centroid[2]};
+    if (T::wave() == 0) PW_T1(ws, 27, t_a0);
+    PW_T0(t_a1);
     for (int k = T::tid(); k < P; k += T::SIZE) {
         double px, py, pz, far;
         sp.point(k, &px, &py, &pz);
@@ -1047,6 +1159,8 @@ PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, i
         flag[k] = hit ? 1 : 0;
     }
     T::sync();
+    if (T::wave() == 0) PW_T1(ws, 28, t_a1);
+    PW_T0(t_a2);
     // compact in ray order (thread 0), then the numpy mean
     // order-preserving compaction by wave 0 (ballot + prefix popcount)
     if (T::wave() == 0) {
@@ -1064,6 +1178,7 @@ PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, i
     T::sync();
     int m = v.n_surv;
     double sum = np_sum_team<T>(packed, m, s_tab, s_acc, s_leaf, &v.red_v[15]);
+    if (T::wave() == 0) PW_T1(ws, 29, t_a2);
     if (T::tid() == 0) {
         out->avg_d = (sum / (double)m) * 2.0;
         out->n_points_avg = P;
