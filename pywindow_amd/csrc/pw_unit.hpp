@@ -507,12 +507,12 @@ PW_HD inline double np_sum_team(const double* a, int n, int* tab, double* acc8, 
             leafbuf[sl] = res;
         }
         T::sync();
-        if (T::tid() == 0) {
-            // depth-first combine; node stack (off, len, stage) and value stack in shared memory
-            int* st = tab + 256;          // 3 ints per entry, depth <= 8
-            double* vals = leafbuf + 128;
+        // depth-first combine of the leaf sums in recursion order; node stack (off, len, stage)
+        // and value stack in team-shared memory.  For long arrays the four depth-2 subtrees are
+        // walked by four waves at once (the walk is a chain of dependent LDS operations).
+        auto walk = [&](int off0, int len0, int* st, double* vals) -> double {
             int top = 0, vtop = 0;
-            st[0] = 0; st[1] = len; st[2] = 0; top = 1;
+            st[0] = off0; st[1] = len0; st[2] = 0; top = 1;
             while (top) {
                 int* c = st + 3 * (top - 1);
                 int coff = c[0], clen = c[1], cst = c[2];
@@ -538,7 +538,26 @@ PW_HD inline double np_sum_team(const double* a, int n, int* tab, double* acc8, 
                     }
                 }
             }
-            double part = vals[0];
+            return vals[0];
+        };
+        if (len > 512 && T::NWAVES >= 4) {
+            int h = len / 2; h -= h % 8;                    // root: [0, h) + [h, len)
+            int hl = h / 2; hl -= hl % 8;                   // left child: [0, hl) + [hl, h)
+            int hr = (len - h) / 2; hr -= hr % 8;           // right child: [h, h + hr) + [h + hr, len)
+            int w = T::wave();
+            if (w < 4 && T::lane() == 0) {
+                int so = w == 0 ? 0 : (w == 1 ? hl : (w == 2 ? h : h + hr));
+                int sl = w == 0 ? hl : (w == 1 ? h - hl : (w == 2 ? hr : len - h - hr));
+                int* st = (int*)(acc8 + 64) + 32 * w;       // acc8 is free again after the leaf folds
+                acc8[w] = walk(so, sl, st, leafbuf + 128 + 8 * w);
+            }
+            T::sync();
+            if (T::tid() == 0) {
+                double part = (acc8[0] + acc8[1]) + (acc8[2] + acc8[3]);
+                total = first ? part : total + part;
+            }
+        } else if (T::tid() == 0) {
+            double part = walk(0, len, tab + 256, leafbuf + 128);
             total = first ? part : total + part;
         }
         first = false;
@@ -828,10 +847,25 @@ PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n
                 const int hi = C.off[g + 1] < j1 ? C.off[g + 1] : j1;
                 if (lo >= hi) continue;
                 double m2 = -PW_INF;
-                for (int j = lo; j < hi; ++j) {
+                int j = lo;
+                // entry (row, column) of the reference's matrix has row < column in the caller's
+                // numbering: the row norm is added first
+                for (; j + 8 <= hi; j += 8) {
+                    double ax[8], ay[8], az[8], aq[8];
+                    int ap[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        ax[u] = F.x[j + u]; ay[u] = F.y[j + u]; az[u] = F.z[j + u]; aq[u] = F.xx[j + u]; ap[u] = F.perm[j + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        double gg = pw_fma(zi, az[u], pw_fma(yi, ay[u], xi * ax[u]));
+                        double d2 = (oi < ap[u]) ? ((-2.0 * gg) + xxi) + aq[u] : ((-2.0 * gg) + aq[u]) + xxi;
+                        m2 = __builtin_fmax(m2, d2);
+                    }
+                }
+                for (; j < hi; ++j) {
                     double gg = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
-                    // entry (row, column) of the reference's matrix has row < column in the
-                    // caller's numbering: the row norm is added first
                     double d2 = (oi < F.perm[j]) ? ((-2.0 * gg) + xxi) + F.xx[j] : ((-2.0 * gg) + F.xx[j]) + xxi;
                     m2 = __builtin_fmax(m2, d2);
                 }
@@ -867,17 +901,33 @@ PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n
                 // d + c == vmax needs d >= vmax - c - ulp(vmax); squared, with margin
                 const double need = (vmax - c) - 1e-15 * vmax;
                 const double thr = need > 0.0 ? need * need * (1.0 - 1e-15) : -PW_INF;
-                for (int j = lo; j < hi; ++j) {
+                auto candidate = [&](double d2, int oj) {
+                    double d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
+                    if (d + c == vmax) {
+                        int idx = oi < oj ? oi * n + oj : oj * n + oi;
+                        bidx = pw_min(bidx, (double)idx);
+                    }
+                };
+                int j = lo;
+                for (; j + 8 <= hi; j += 8) {
+                    double ax[8], ay[8], az[8], aq[8];
+                    int ap[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        ax[u] = F.x[j + u]; ay[u] = F.y[j + u]; az[u] = F.z[j + u]; aq[u] = F.xx[j + u]; ap[u] = F.perm[j + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        double gg = pw_fma(zi, az[u], pw_fma(yi, ay[u], xi * ax[u]));
+                        double d2 = (oi < ap[u]) ? ((-2.0 * gg) + xxi) + aq[u] : ((-2.0 * gg) + aq[u]) + xxi;
+                        if (d2 >= thr) candidate(d2, ap[u]);
+                    }
+                }
+                for (; j < hi; ++j) {
                     double gg = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
                     int oj = F.perm[j];
                     double d2 = (oi < oj) ? ((-2.0 * gg) + xxi) + F.xx[j] : ((-2.0 * gg) + F.xx[j]) + xxi;
-                    if (d2 >= thr) {
-                        double d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
-                        if (d + c == vmax) {
-                            int idx = oi < oj ? oi * n + oj : oj * n + oi;
-                            bidx = pw_min(bidx, (double)idx);
-                        }
-                    }
+                    if (d2 >= thr) candidate(d2, oj);
                 }
             }
         }
