@@ -1723,6 +1723,16 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             unl[wd] = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
         }
         T::sync();
+        // the survivors' end points, compacted: every thread then reads the same point at the same
+        // time (broadcast) and eight of them are fetched ahead of the arithmetic
+        double* cp = (double*)arena.take((size_t)ns * 24);
+        if (cp) {
+            for (int i = T::tid(); i < ns; i += T::SIZE) {
+                const double* pi = &pts[3 * surv_k[i]];
+                cp[3 * i] = pi[0]; cp[3 * i + 1] = pi[1]; cp[3 * i + 2] = pi[2];
+            }
+            T::sync();
+        }
         for (int i = T::tid(); i < ns; i += T::SIZE) {
             const double* pi = &pts[3 * surv_k[i]];
             double px = pi[0], py = pi[1], pz = pi[2];
@@ -1730,7 +1740,22 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             for (int wd = 0; wd < words; ++wd) {
                 unsigned long long bits = 0;
                 int jend = (wd * 64 + 64 < ns) ? wd * 64 + 64 : ns;
-                for (int j = wd * 64; j < jend; ++j) {
+                int j = wd * 64;
+                if (cp) {
+                    for (; j + 8 <= jend; j += 8) {
+                        double qx[8], qy[8], qz[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) { qx[t] = cp[3 * (j + t)]; qy[t] = cp[3 * (j + t) + 1]; qz[t] = cp[3 * (j + t) + 2]; }
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            double ax = px - qx[t], ay = py - qy[t], az = pz - qz[t];
+                            double d = 0.0;
+                            d = d + ax * ax; d = d + ay * ay; d = d + az * az;
+                            if (d <= e2) { bits |= 1ull << (j + t - wd * 64); ++cnt; }
+                        }
+                    }
+                }
+                for (; j < jend; ++j) {
                     const double* pj = &pts[3 * surv_k[j]];
                     double ax = px - pj[0], ay = py - pj[1], az = pz - pj[2];
                     double d = 0.0;
