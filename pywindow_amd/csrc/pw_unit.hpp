@@ -1661,7 +1661,11 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         T::sync();
         int ncand = v.n_surv;
         int evals = 0;
-        for (int j = T::tid(); j < ncand; j += T::SIZE) {
+        // whole rounds: one path per thread.  The last, partial round would keep a handful of
+        // lanes busy for a full path each, so its paths are cut into points instead: one
+        // (path, point) per thread, then one thread per path folds its points.
+        const int whole = T::SIZE > 1 ? (ncand / T::SIZE) * T::SIZE : ncand;
+        for (int j = T::tid(); j < whole; j += T::SIZE) {
             int k = labels[j];
             double g2, chunk[3];
             int pos;
@@ -1669,6 +1673,47 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                                        &g2, &pos, chunk, &evals);
             flag[j] = ok ? 1 : 0;
             tmpv[j] = g2;
+        }
+        const int left = ncand - whole;
+        if (left > 0) {
+            constexpr int PCAP = 64;                       // points per path handled this way
+            double* pm = ws->knn + PW_P_MAX;               // free since the DBSCAN radius is known (the first
+                                                           // PW_P_MAX entries may hold tmpv)
+            bool fits = true;
+            for (int item = T::tid(); item < left * PCAP; item += T::SIZE) {
+                int j = whole + item / PCAP, q = item % PCAP;
+                int k = labels[j];
+                double vx = pts[3 * k], vy = pts[3 * k + 1], vz = pts[3 * k + 2];
+                int chunks = (int)np_floordiv(norm3(vx, vy, vz), prm.increment);
+                if (chunks + 1 > PCAP) { fits = false; continue; }
+                if (q > chunks) continue;
+                double cx = vx / (double)chunks, cy = vy / (double)chunks, cz = vz / (double)chunks;
+                pm[(size_t)(j - whole) * PCAP + q] = point_gap_value(sh.S, n, cx * (double)q, cy * (double)q, cz * (double)q);
+            }
+            T::sync();
+            for (int j = whole + T::tid(); j < ncand; j += T::SIZE) {
+                int k = labels[j];
+                double vx = pts[3 * k], vy = pts[3 * k + 1], vz = pts[3 * k + 2];
+                int chunks = (int)np_floordiv(norm3(vx, vy, vz), prm.increment);
+                double g2 = 0.0;
+                bool ok = true;
+                if (chunks + 1 > PCAP) {                   // very fine increments: the plain walk
+                    double chunk[3];
+                    int pos;
+                    ok = path_scan_thread(sh.S, n, vx, vy, vz, prm.increment, &g2, &pos, chunk, &evals);
+                } else {
+                    double best = PW_INF;
+                    for (int q = 0; q <= chunks; ++q) {
+                        double m = pm[(size_t)(j - whole) * PCAP + q];
+                        if (!(m > 0.0)) { ok = false; break; }
+                        if (m < best) best = m;
+                    }
+                    g2 = best * 2.0;
+                }
+                flag[j] = ok ? 1 : 0;
+                tmpv[j] = g2;
+            }
+            (void)fits;
         }
         T::sync();
         if (T::wave() == 0) {
