@@ -144,7 +144,18 @@ __global__ void pw_tail_gate_kernel(const UnitQueue* prev, unsigned long long ne
     long long t0 = wall_clock64();
     while (__hip_atomic_load(&prev->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
         __builtin_amdgcn_s_sleep(32);
-        if (wall_clock64() - t0 > 200000000ll) break;   // 2 s
+        if (wall_clock64() - t0 > 2000000ll) break;     // 20 ms: only an optimisation, never a dependency
+    }
+}
+
+// The same for the window launch: analysis k+1's consumers start when all but the last few
+// units of analysis k have been TAKEN by a team (its queue head has advanced that far).
+__global__ void pw_head_gate_kernel(const UnitQueue* prev, unsigned long long need) {
+    if (threadIdx.x != 0) return;
+    long long t0 = wall_clock64();
+    while (__hip_atomic_load(&prev->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(32);
+        if (wall_clock64() - t0 > 2000000ll) break;     // 20 ms: only an optimisation, never a dependency
     }
 }
 
@@ -200,6 +211,10 @@ struct pw_context {
     // slots, events), so the optimiser chains of launch k+1 run beside the window tail of k
     hipEvent_t ev_reset[2], ev_prod[2], ev_gate[2], ev_join[2], ev_done[2];
     int done_valid[2];
+    hipStream_t cons[2];     // gate + window launch of the pipeline, one stream per buffer set
+    hipEvent_t ev_head[2];   // head gate of the launch using set b has run
+    int head_valid[2];
+    int head_pct;            // PW_HEAD_GATE (default 97; 0 = window launches strictly one after another)
     hipEvent_t ev_tail[2];   // tail gate of the launch using set b has run
     int tail_valid[2];
     long last_units[2];
@@ -289,7 +304,7 @@ static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool 
 
 template <int NW>
 static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const LaunchPlan& p, hipStream_t st,
-                     int ws_first, bool with_adj, int counter_slot, int role) {
+                     int ws_first, int adj_first, int counter_slot, int role) {
     auto kern = pw_analyse_kernel<NW>;
     if (getenv("PW_PLAN_DEBUG"))
         fprintf(stderr, "launch NW=%d grid %d lds %zu nmax %d units %ld atoms %ld\n", NW, p.grid, p.lds, r->nmax,
@@ -299,17 +314,26 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
     HIP_TRY(hipMemsetAsync(c->counter + counter_slot, 0, sizeof(unsigned long long), st));
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
                        r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb,
-                       c->ws + ws_first, with_adj ? c->adj : (unsigned long long*)nullptr,
+                       c->ws + ws_first,
+                       adj_first >= 0 ? c->adj + (size_t)adj_first * PW_ADJ_WORDS : (unsigned long long*)nullptr,
                        c->counter + counter_slot, r->d_out, role, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab);
     HIP_TRY(hipGetLastError());
     return PW_OK;
 }
 static int launch_plan(pw_context* c, pw_resident* r, unsigned stages, const LaunchPlan& p, hipStream_t st,
-                       int ws_first, bool with_adj, int counter_slot, int role = PW_ROLE_PLAIN) {
-    if (p.nw == 8) return launch_nw<8>(c, r, stages, p, st, ws_first, with_adj, counter_slot, role);
-    if (p.nw == 4) return launch_nw<4>(c, r, stages, p, st, ws_first, with_adj, counter_slot, role);
-    if (p.nw == 2) return launch_nw<2>(c, r, stages, p, st, ws_first, with_adj, counter_slot, role);
-    return launch_nw<1>(c, r, stages, p, st, ws_first, with_adj, counter_slot, role);
+                       int ws_first, int adj_first, int counter_slot, int role = PW_ROLE_PLAIN) {
+    if (p.nw == 8) return launch_nw<8>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
+    if (p.nw == 4) return launch_nw<4>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
+    if (p.nw == 2) return launch_nw<2>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
+    return launch_nw<1>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
+}
+
+// the API stream (uploads, downloads, single-launch analyses, timing marks) follows every
+// pipeline launch issued so far
+static int join_pipeline(pw_context* c) {
+    for (int b = 0; b < 2; ++b)
+        if (c->done_valid[b]) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done[b], 0));
+    return PW_OK;
 }
 
 extern "C" {
@@ -341,7 +365,7 @@ int pw_context_create(int device, pw_context** out) {
     c->lds_per_cu = 160 * 1024;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc((void**)&c->counter, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&c->counter, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void**)&c->queue, 2 * sizeof(UnitQueue)));
     HIP_TRY(hipMemset(c->queue, 0, 2 * sizeof(UnitQueue)));
     c->cur_queue = c->queue;
@@ -363,6 +387,13 @@ int pw_context_create(int device, pw_context** out) {
         HIP_TRY(hipEventCreateWithFlags(&c->ev_join[b], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_tail[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_head[b], hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&c->cons[b], hipStreamNonBlocking));
+    }
+    {
+        const char* hg = getenv("PW_HEAD_GATE");
+        c->head_pct = hg ? atoi(hg) : 97;
+        if (c->head_pct < 0 || c->head_pct > 100) c->head_pct = 0;
     }
     {
         const char* tg = getenv("PW_TAIL_GATE");
@@ -408,6 +439,8 @@ void pw_context_destroy(pw_context* c) {
         if (c->ev_join[b]) (void)hipEventDestroy(c->ev_join[b]);
         if (c->ev_done[b]) (void)hipEventDestroy(c->ev_done[b]);
         if (c->ev_tail[b]) (void)hipEventDestroy(c->ev_tail[b]);
+        if (c->ev_head[b]) (void)hipEventDestroy(c->ev_head[b]);
+        if (c->cons[b]) (void)hipStreamDestroy(c->cons[b]);
     }
     if (c->adj) (void)hipFree(c->adj);
     if (c->queue) (void)hipFree(c->queue);
@@ -464,7 +497,9 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         rc = ensure_workspace(c, p.grid, win ? p.grid : 0);
         if (rc != PW_OK) return rc;
         c->need_fork = 1;
-        return launch_plan(c, r, stages, p, c->stream, 0, win, 0);
+        rc = join_pipeline(c);
+        if (rc != PW_OK) return rc;
+        return launch_plan(c, r, stages, p, c->stream, 0, win ? 0 : -1, 0);
     }
     // Pipeline: the analysis is split by parallel shape and the pieces overlap.
     //   A (producer stream): stage_basic + pore-centre optimiser, ONE wave per unit -- the serial
@@ -503,8 +538,9 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         const char* bt = getenv("PW_B_TEAMS");
         if (bt && do_avg && atoi(bt) > 0 && atoi(bt) < pb.grid) pb.grid = atoi(bt);
     }
-    int need = pc.grid + 2 * pa.grid + pb.grid;
-    rc = ensure_workspace(c, need, pc.grid);
+    // teams: C0 | A0 | B | A1 | C1 (two window and two optimiser launches can be in flight)
+    int need = 2 * pc.grid + 2 * pa.grid + pb.grid;
+    rc = ensure_workspace(c, need, 2 * pc.grid);
     if (rc != PW_OK) return rc;
     if (c->slots_cap < r->n_units) {
         HIP_TRY(hipDeviceSynchronize());
@@ -513,6 +549,8 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         HIP_TRY(hipMalloc((void**)&c->slots, 2 * sizeof(int) * (size_t)r->n_units));
         c->slots_cap = r->n_units;
         c->done_valid[0] = c->done_valid[1] = 0;
+        c->tail_valid[0] = c->tail_valid[1] = 0;
+        c->head_valid[0] = c->head_valid[1] = 0;
     }
     // this launch's buffer set; the other one may still be in use by the previous launch.
     // (A batch's result buffer was last used two of its own launches ago, i.e. no later than
@@ -532,11 +570,15 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
         HIP_TRY(hipStreamWaitEvent(c->prods[0], c->ev_fork, 0));
         HIP_TRY(hipStreamWaitEvent(c->prods[1], c->ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(c->cons[0], c->ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(c->cons[1], c->ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
         c->need_fork = 0;
     }
     if (c->done_valid[b]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_done[b], 0));
     // the previous launch's tail gate reads the queue that is reset below
     if (c->tail_valid[b ^ 1]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_tail[b ^ 1], 0));
+    if (c->head_valid[b ^ 1]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_head[b ^ 1], 0));
     HIP_TRY(hipMemsetAsync(r->d_out, 0, sizeof(pw_unit_out) * r->n_units, c->prod));
     HIP_TRY(hipMemsetAsync(c->cur_queue, 0, sizeof(UnitQueue), c->prod));
     HIP_TRY(hipMemsetAsync(c->cur_slots, 0xff, sizeof(int) * (size_t)r->n_units, c->prod));
@@ -552,31 +594,47 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     c->last_units[b] = r->n_units;
     // two optimiser launches can be in flight: separate work counters and workspaces
     rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod,
-                     pc.grid + (b ? pa.grid + pb.grid : 0), false, b ? 3 : 0, PW_ROLE_PRODUCER);
+                     pc.grid + (b ? pa.grid + pb.grid : 0), -1, b ? 3 : 0, PW_ROLE_PRODUCER);
     if (rc != PW_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev_prod[b], c->prod));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_reset[b], 0));
-    hipLaunchKernelGGL(pw_gate_kernel, dim3(1), dim3(64), 0, c->stream, c->cur_queue, pa.grid);
+    hipStream_t cs = c->cons[b];
+    HIP_TRY(hipStreamWaitEvent(cs, c->ev_reset[b], 0));
+    hipLaunchKernelGGL(pw_gate_kernel, dim3(1), dim3(64), 0, cs, c->cur_queue, pa.grid);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev_gate[b], c->stream));
-    rc = launch_plan(c, r, PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pc,
-                     c->stream, 0, true, 2, PW_ROLE_CONSUMER);
+    HIP_TRY(hipEventRecord(c->ev_gate[b], cs));
+    c->head_valid[b] = 0;
+    if (c->done_valid[b ^ 1] && c->last_units[b ^ 1] > 0) {
+        if (c->head_pct > 0) {
+            // start beside the tail of the previous window launch, not behind it
+            unsigned long long need_h = (unsigned long long)((c->last_units[b ^ 1] * c->head_pct) / 100);
+            hipLaunchKernelGGL(pw_head_gate_kernel, dim3(1), dim3(64), 0, cs, c->queue + (b ^ 1), need_h);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->ev_head[b], cs));
+            c->head_valid[b] = 1;
+        } else {
+            HIP_TRY(hipStreamWaitEvent(cs, c->ev_done[b ^ 1], 0));
+        }
+    }
+    rc = launch_plan(c, r, PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pc, cs,
+                     b ? pc.grid + 2 * pa.grid + pb.grid : 0, b ? pc.grid : 0, b ? 4 : 2, PW_ROLE_CONSUMER);
     if (rc != PW_OK) return rc;
     if (do_avg) {
         HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_gate[b], 0));
-        rc = launch_plan(c, r, PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pb, c->aux, pc.grid + pa.grid, false, 1);
+        rc = launch_plan(c, r, PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pb, c->aux, pc.grid + pa.grid, -1, 1);
         if (rc != PW_OK) return rc;
         HIP_TRY(hipEventRecord(c->ev_join[b], c->aux));
     }
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_prod[b], 0));
-    if (do_avg) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join[b], 0));
-    HIP_TRY(hipEventRecord(c->ev_done[b], c->stream));
+    HIP_TRY(hipStreamWaitEvent(cs, c->ev_prod[b], 0));
+    if (do_avg) HIP_TRY(hipStreamWaitEvent(cs, c->ev_join[b], 0));
+    HIP_TRY(hipEventRecord(c->ev_done[b], cs));
     c->done_valid[b] = 1;
     return PW_OK;
 }
 
 int pw_resident_sync(pw_context* c) {
     if (!c) return PW_E_BAD_ARG;
+    int rcj = join_pipeline(c);
+    if (rcj != PW_OK) return rcj;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PW_OK;
 }
@@ -656,6 +714,8 @@ int pw_resident_download(pw_context* c, pw_resident* r, pw_unit_out* out) {
     if (!c || !r || !out) return PW_E_BAD_ARG;
     if (r->n_units == 0) return PW_OK;
     HIP_TRY(hipSetDevice(c->device));
+    int rcj = join_pipeline(c);
+    if (rcj != PW_OK) return rcj;
     HIP_TRY(hipMemcpyAsync(out, r->d_out, sizeof(pw_unit_out) * r->n_units, hipMemcpyDeviceToHost,
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -689,13 +749,16 @@ int pw_resident_time(pw_context* c, pw_resident* r, uint32_t stages, int iters, 
     HIP_TRY(hipSetDevice(c->device));
     int rc = pw_resident_launch(c, r, stages);  // warm-up, also sizes the workspace
     if (rc != PW_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = pw_resident_sync(c);
+    if (rc != PW_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     c->need_fork = 1;        // the first timed launch starts after ev0 on every stream
     for (int i = 0; i < iters; ++i) {
         rc = pw_resident_launch(c, r, stages);
         if (rc != PW_OK) return rc;
     }
+    rc = join_pipeline(c);
+    if (rc != PW_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     float total = 0.f;
