@@ -52,8 +52,10 @@ struct UnitQueue {
 };
 enum : int { PW_ROLE_PLAIN = 0, PW_ROLE_PRODUCER = 1, PW_ROLE_CONSUMER = 2 };
 
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, 2)
+// MASK: the stage bits this instantiation can execute (the run-time mask is ANDed with it), so
+// the launches of the pipeline carry only the code -- and the registers -- of their own stages
+template <int NW, unsigned MASK>
+__global__ void __launch_bounds__(NW * 64, MASK == PW_KERNEL_AVERAGE ? 3 : 2)
 pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
                   const double* __restrict__ vdw, const double* __restrict__ mass, unsigned stages,
                   int nmax, int nrot, int nlb, TeamWorkspace* __restrict__ workspaces,
@@ -110,7 +112,7 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
         if (u < 0) break;
         long a0 = atom_offset[u];
         int n = (int)(atom_offset[u + 1] - a0);
-        analyse_unit<T>(sh, ws, n, xyz + 3 * a0, vdw + a0, mass + a0, stages, out + u, prm);
+        analyse_unit<T, MASK>(sh, ws, n, xyz + 3 * a0, vdw + a0, mass + a0, stages & MASK, out + u, prm);
         if (role == PW_ROLE_PRODUCER) {
             // analyse_unit ended with a team barrier; thread 0 wrote the record
             if (threadIdx.x == 0) {
@@ -302,13 +304,18 @@ static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool 
     return PW_OK;
 }
 
-template <int NW>
+constexpr unsigned MASK_ANY = 0xffffffffu;
+constexpr unsigned MASK_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE;
+constexpr unsigned MASK_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
+constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
+
+template <int NW, unsigned MASK>
 static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const LaunchPlan& p, hipStream_t st,
                      int ws_first, int adj_first, int counter_slot, int role) {
-    auto kern = pw_analyse_kernel<NW>;
+    auto kern = pw_analyse_kernel<NW, MASK>;
     if (getenv("PW_PLAN_DEBUG"))
-        fprintf(stderr, "launch NW=%d grid %d lds %zu nmax %d units %ld atoms %ld\n", NW, p.grid, p.lds, r->nmax,
-                r->n_units, r->n_atoms);
+        fprintf(stderr, "launch NW=%d mask %x grid %d lds %zu nmax %d units %ld atoms %ld\n", NW, MASK, p.grid, p.lds,
+                r->nmax, r->n_units, r->n_atoms);
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)p.lds));
     HIP_TRY(hipMemsetAsync(c->counter + counter_slot, 0, sizeof(unsigned long long), st));
@@ -322,10 +329,17 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
 }
 static int launch_plan(pw_context* c, pw_resident* r, unsigned stages, const LaunchPlan& p, hipStream_t st,
                        int ws_first, int adj_first, int counter_slot, int role = PW_ROLE_PLAIN) {
-    if (p.nw == 8) return launch_nw<8>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
-    if (p.nw == 4) return launch_nw<4>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
-    if (p.nw == 2) return launch_nw<2>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
-    return launch_nw<1>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
+    // the three launches of the pipeline have kernels of their own
+    if (stages == MASK_CHAINS && p.nw == 1)
+        return launch_nw<1, MASK_CHAINS>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
+    if (stages == MASK_AVERAGE && p.nw == 4)
+        return launch_nw<4, MASK_AVERAGE>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
+    if (stages == MASK_WINDOWS && p.nw == 4)
+        return launch_nw<4, MASK_WINDOWS>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
+    if (p.nw == 8) return launch_nw<8, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
+    if (p.nw == 4) return launch_nw<4, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
+    if (p.nw == 2) return launch_nw<2, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
+    return launch_nw<1, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
 }
 
 // the API stream (uploads, downloads, single-launch analyses, timing marks) follows every

@@ -607,7 +607,7 @@ PW_HD inline int sampling_count(double radius, double adjust) {
 
 // Ray from the centroid along (dx,dy,dz) against every atom (utilities.py:1138-1158 /
 // 1561-1578).  Returns whether any atom is "in the way" and the largest |p_out|.
-PW_NOINLINE PW_HD inline bool ray_scan(const Frame& F, int n, const double* cen, double dx, double dy,
+PW_HD inline __attribute__((always_inline)) bool ray_scan_impl(const Frame& F, int n, const double* cen, double dx, double dy,
                            double dz, double* farthest) {
     double nrm = norm3(dx, dy, dz);
     double ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
@@ -670,6 +670,11 @@ PW_NOINLINE PW_HD inline bool ray_scan(const Frame& F, int n, const double* cen,
     }
     *farthest = far;
     return any;
+}
+
+PW_NOINLINE PW_HD inline bool ray_scan(const Frame& F, int n, const double* cen, double dx, double dy, double dz,
+                                       double* farthest) {
+    return ray_scan_impl(F, n, cen, dx, dy, dz, farthest);
 }
 
 // numpy floor division a // b for positive doubles (npy_divmod)
@@ -817,7 +822,7 @@ PW_HD inline void make_shifted(UnitShared& sh, int n, double cx, double cy, doub
 
 // max_dim over frame F (utilities.py:355-372); result in sh.v->maxd*, all threads.
 template <class T>
-PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n) {
+PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& sh, const Frame& F, int n) {
     // max over pairs (diagonal included) of d_ij + (vdw_i + vdw_j), first maximum in row-major
     // order of the caller's numbering (utilities.py:355-372).  Two passes; a thread owns a
     // (row, column half) and walks the columns, so the lanes of a wave hold consecutive rows and
@@ -985,10 +990,15 @@ PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n
     T::sync();
 }
 
+template <class T>
+PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n) {
+    team_max_dim_impl<T>(sh, F, n);
+}
+
 // ---- stage: basic -------------------------------------------------------------------------
 template <class T>
-PW_NOINLINE PW_HD inline void stage_basic(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
-                                           bool com_only) {
+PW_HD inline __attribute__((always_inline)) void stage_basic_impl(UnitShared& sh, TeamWorkspace* ws, int n,
+                                                                  pw_unit_out* out, bool com_only) {
     auto& v = *sh.v;
     (void)ws;
     if (T::tid() == 0) {
@@ -1031,6 +1041,12 @@ PW_NOINLINE PW_HD inline void stage_basic(UnitShared& sh, TeamWorkspace* ws, int
         out->pore_vol = FOUR_THIRDS_PI * pw_cube_np(r);
     }
     T::sync();
+}
+
+template <class T>
+PW_NOINLINE PW_HD inline void stage_basic(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
+                                           bool com_only) {
+    stage_basic_impl<T>(sh, ws, n, out, com_only);
 }
 
 // forward-difference gradient step exactly as scipy.optimize._numdiff (2-point,
@@ -1164,9 +1180,11 @@ PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n
 }
 
 // ---- stage: average diameter ---------------------------------------------------------------
-template <class T>
-PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
-                                             const pw_params& prm) {
+// INL: everything inlined into the caller (the average-diameter launch has a kernel of its own,
+// whose register budget then covers the whole stage: three waves per SIMD instead of two)
+template <class T, bool INL>
+PW_HD inline __attribute__((always_inline)) void stage_average_impl(UnitShared& sh, TeamWorkspace* ws, int n,
+                                                                    pw_unit_out* out, const pw_params& prm) {
     auto& v = *sh.v;
     PW_T0(t_a0);
     make_shifted<T>(sh, n, v.com[0], v.com[1], v.com[2]);
@@ -1174,7 +1192,7 @@ PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, i
     double keep_d = v.maxd;
     int keep_i = v.maxd_i, keep_j = v.maxd_j;
     T::sync();
-    team_max_dim<T>(sh, sh.S, n);
+    if (INL) team_max_dim_impl<T>(sh, sh.S, n); else team_max_dim<T>(sh, sh.S, n);
     double radius = v.maxd;
     T::sync();
     if (T::tid() == 0) { v.maxd = keep_d; v.maxd_i = keep_i; v.maxd_j = keep_j; }
@@ -1204,7 +1222,7 @@ PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, i
     for (int k = T::tid(); k < P; k += T::SIZE) {
         double px, py, pz, far;
         sp.point(k, &px, &py, &pz);
-        bool hit = ray_scan(sh.S, n, cen, px, py, pz, &far);
+        bool hit = INL ? ray_scan_impl(sh.S, n, cen, px, py, pz, &far) : ray_scan(sh.S, n, cen, px, py, pz, &far);
         vals[k] = far;
         flag[k] = hit ? 1 : 0;
     }
@@ -1234,6 +1252,12 @@ PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, i
         out->n_points_avg = P;
     }
     T::sync();
+}
+
+template <class T>
+PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
+                                             const pw_params& prm) {
+    stage_average_impl<T, false>(sh, ws, n, out, prm);
 }
 
 // ---- Nelder-Mead in the window plane (scipy.optimize.fmin defaults, N = 2) ------------------
@@ -1931,7 +1955,9 @@ PW_HD inline void record_or_status(pw_unit_out* out, int st, int evals) {
 #endif
 }
 
-template <class T>
+constexpr unsigned PW_KERNEL_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
+
+template <class T, unsigned KMASK = 0xffffffffu>
 PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const double* xyz,
                                const double* vdw, const double* mass, unsigned stages,
                                pw_unit_out* out, const pw_params& prm) {
@@ -1958,6 +1984,8 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
         // the optimiser launch already wrote the centre of mass
         if (T::tid() == 0) { sh.v->com[0] = out->com[0]; sh.v->com[1] = out->com[1]; sh.v->com[2] = out->com[2]; }
         T::sync();
+    } else if (KMASK == PW_KERNEL_AVERAGE) {
+        stage_basic_impl<T>(sh, ws, n, out, true);
     } else {
         stage_basic<T>(sh, ws, n, out, (stages & PW_STAGE_COM_ONLY) != 0);
     }
@@ -1973,7 +2001,8 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
     }
     if (stages & PW_STAGE_AVG) {
         PW_T0(t_a);
-        stage_average<T>(sh, ws, n, out, prm);
+        if (KMASK == PW_KERNEL_AVERAGE) stage_average_impl<T, true>(sh, ws, n, out, prm);
+        else stage_average<T>(sh, ws, n, out, prm);
         if (T::wave() == 0) PW_T1(ws, 13, t_a);
     }
     if ((stages & PW_STAGE_WINDOWS) && !(prm.pore_opt && (sh.v->status & PW_ST_NEGATIVE_PORE)))
