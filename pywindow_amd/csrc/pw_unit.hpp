@@ -266,6 +266,50 @@ PW_HD inline double point_gap_value(const Frame& F, int n, double px, double py,
     }
     return best;
 }
+// NP points at once by ONE thread (register blocking): every atom is read from LDS once and
+// used for all NP points, so the loop is bound by arithmetic instead of LDS reads.  Each value is
+// bit-identical to point_gap_value of that point.
+template <int NP>
+PW_HD inline void points_gap_values(const Frame& F, int n, const double* px, const double* py, const double* pz,
+                                    double* out) {
+    const auto& C = *F.cls;
+    if (C.k == 0) {
+        for (int p = 0; p < NP; ++p) out[p] = point_gap(F, n, px[p], py[p], pz[p], nullptr);
+        return;
+    }
+    double qx[NP], qy[NP], qz[NP], pp[NP], best[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        qx[p] = px[p]; qy[p] = py[p]; qz[p] = pz[p];
+        pp[p] = sq3(qx[p], qy[p], qz[p]);
+        best[p] = PW_INF;
+    }
+    for (int g = 0; g < C.k; ++g) {
+        double m2[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) m2[p] = PW_INF;
+        const int hi = C.off[g + 1];
+#pragma unroll 2
+        for (int i = C.off[g]; i < hi; ++i) {
+            const double x = F.x[i], y = F.y[i], z = F.z[i], xx = F.xx[i];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                double gg = pw_fma(z, qz[p], pw_fma(x, qx[p], y * qy[p]));
+                double d2 = ((-2.0 * gg) + xx) + pp[p];
+                m2[p] = __builtin_fmin(m2[p], d2);
+            }
+        }
+        const double r = C.vdw[g];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            double d = pw_sqrt(m2[p] > 0.0 ? m2[p] : 0.0);
+            best[p] = __builtin_fmin(best[p], d - r);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) out[p] = best[p];
+}
+
 // one wave, atoms spread over lanes; value and first argmin (caller's numbering) in every lane
 template <class T>
 PW_HD inline double wave_gap(const Frame& F, int n, double px, double py, double pz, int* arg) {
@@ -705,10 +749,24 @@ PW_NOINLINE PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx,
     double best = PW_INF;
     int pos = 0;
     bool ok = true;
-    for (int k = 0; k <= chunks; ++k) {
-        double m = point_gap_value(F, n, cx * (double)k, cy * (double)k, cz * (double)k);
-        if (!(m > 0.0)) { ok = false; break; }
-        if (m < best) { best = m; pos = k; }
+    // six path points per pass over the atoms (the reference stops at the first point inside a
+    // sphere; evaluating the rest changes nothing: the vector is rejected either way)
+    constexpr int NP = 6;
+    for (int k0 = 0; k0 <= chunks && ok; k0 += NP) {
+        double qx[NP], qy[NP], qz[NP], m[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            int k = k0 + p <= chunks ? k0 + p : chunks;
+            qx[p] = cx * (double)k; qy[p] = cy * (double)k; qz[p] = cz * (double)k;
+        }
+        points_gap_values<NP>(F, n, qx, qy, qz, m);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (k0 + p <= chunks && ok) {
+                if (!(m[p] > 0.0)) ok = false;
+                else if (m[p] < best) { best = m[p]; pos = k0 + p; }
+            }
+        }
     }
     if (n_eval) *n_eval += chunks + 1;
     if (!ok) return false;
