@@ -1426,10 +1426,28 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     double pbest = PW_INF;
     int ppos = 0x7fffffff;
     bool ok = true;
-    for (int k = T::lane(); k <= chunks; k += T::WSIZE) {
-        double m = point_gap_value(sh.S, n, cx * (double)k, cy * (double)k, cz * (double)k);
-        if (!(m > 0.0)) ok = false;
-        if (m < pbest) { pbest = m; ppos = k; }
+    if (T::WSIZE == 64) {
+        // two path points per lane and pass over the atoms
+        for (int k0 = T::lane(); k0 <= chunks; k0 += 2 * T::WSIZE) {
+            int k1 = k0 + T::WSIZE <= chunks ? k0 + T::WSIZE : k0;
+            double qx[2] = {cx * (double)k0, cx * (double)k1};
+            double qy[2] = {cy * (double)k0, cy * (double)k1};
+            double qz[2] = {cz * (double)k0, cz * (double)k1};
+            double m[2];
+            points_gap_values<2>(sh.S, n, qx, qy, qz, m);
+            if (!(m[0] > 0.0)) ok = false;
+            if (m[0] < pbest) { pbest = m[0]; ppos = k0; }
+            if (k1 != k0) {
+                if (!(m[1] > 0.0)) ok = false;
+                if (m[1] < pbest) { pbest = m[1]; ppos = k1; }
+            }
+        }
+    } else {
+        for (int k = T::lane(); k <= chunks; k += T::WSIZE) {
+            double m = point_gap_value(sh.S, n, cx * (double)k, cy * (double)k, cz * (double)k);
+            if (!(m > 0.0)) ok = false;
+            if (m < pbest) { pbest = m; ppos = k; }
+        }
     }
     evals += chunks + 1;
     ok = T::wave_all(ok);
@@ -1541,11 +1559,32 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     double gstep = (hlf - gstart) / 19.0;
     double gbest = PW_INF;
     int gidx = 0x7fffffff;
-    for (int q = T::lane(); q < 400; q += T::WSIZE) {
-        int ix = q / 20, iy = q % 20;
-        double gx = (double)ix * gstep + gstart, gy = (double)iy * gstep + gstart;
-        double f = -(point_gap_value(R, n, gx, gy, zopt) * 2.0);
-        if (f < gbest) { gbest = f; gidx = q; }
+    if (T::WSIZE == 64) {
+        // a lane's (up to) seven grid points share one pass over the atoms
+        constexpr int NP = 7;
+        double qx[NP], qy[NP], qz[NP], m[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            int q = T::lane() + 64 * p;
+            if (q >= 400) q = T::lane();
+            qx[p] = (double)(q / 20) * gstep + gstart;
+            qy[p] = (double)(q % 20) * gstep + gstart;
+            qz[p] = zopt;
+        }
+        points_gap_values<NP>(R, n, qx, qy, qz, m);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            int q = T::lane() + 64 * p;
+            double f = -(m[p] * 2.0);
+            if (q < 400 && f < gbest) { gbest = f; gidx = q; }
+        }
+    } else {
+        for (int q = T::lane(); q < 400; q += T::WSIZE) {
+            int ix = q / 20, iy = q % 20;
+            double gx = (double)ix * gstep + gstart, gy = (double)iy * gstep + gstart;
+            double f = -(point_gap_value(R, n, gx, gy, zopt) * 2.0);
+            if (f < gbest) { gbest = f; gidx = q; }
+        }
     }
     evals += 400;
     T::wave_argmin(gbest, gidx);
