@@ -721,6 +721,76 @@ PW_NOINLINE PW_HD inline bool ray_scan(const Frame& F, int n, const double* cen,
     return ray_scan_impl(F, n, cen, dx, dy, dz, farthest);
 }
 
+// NR rays of one thread at once: the screen reads every atom once for all of them (register
+// blocking); the exact part per flagged (ray, atom) is the one of ray_scan_impl.  Results are
+// identical to NR calls of ray_scan.
+template <int NR>
+PW_HD inline __attribute__((always_inline)) void ray_scan_multi_impl(const Frame& F, int n, const double* cen,
+                                                                     const double* dx, const double* dy,
+                                                                     const double* dz, bool* hit, double* farthest) {
+    double ux[NR], uy[NR], uz[NR], far[NR];
+    bool any[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        double nrm = norm3(dx[r], dy[r], dz[r]);
+        ux[r] = dx[r] / nrm; uy[r] = dy[r] / nrm; uz[r] = dz[r] / nrm;
+        far[r] = -1.0;
+        any[r] = false;
+    }
+    const double c0 = cen[0], c1 = cen[1], c2 = cen[2];
+    for (int blk = 0; blk < n; blk += 64) {
+        unsigned long long mask[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) mask[r] = 0;
+        int jend = n - blk < 64 ? n - blk : 64;
+#pragma unroll 2
+        for (int j = 0; j < jend; ++j) {
+            int i = blk + j;
+            double rx = F.x[i] - c0, ry = F.y[i] - c1, rz = F.z[i] - c2;
+            double rr = sq3(rx, ry, rz);
+            double lim = (F.vdw[i] * F.vdw[i]) * (1.0 + 1e-14);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                double along = pw_fma(rz, uz[r], pw_fma(rx, ux[r], ry * uy[r]));
+                double q = rr - along * along;
+                if (q >= 0.0 && q <= lim) mask[r] |= 1ull << j;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            unsigned long long m = mask[r];
+            while (m) {
+                int j = __builtin_ctzll(m);
+                m &= m - 1;
+                int i = blk + j;
+                double rx = F.x[i] - c0, ry = F.y[i] - c1, rz = F.z[i] - c2;
+                double along = pw_fma(rz, uz[r], pw_fma(rx, ux[r], ry * uy[r]));
+                double sq = sq3(rx, ry, rz);
+                double perp = pw_sqrt(sq - along * along);
+                double radicand = F.vdw[i] * F.vdw[i] - perp * perp;
+                if (radicand > 0.0) {
+                    double half = pw_sqrt(radicand);
+                    double tin = along - half, tout = along + half;
+                    double ix = c0 + tin * ux[r], iy = c1 + tin * uy[r], iz = c2 + tin * uz[r];
+                    double ox = c0 + tout * ux[r], oy = c1 + tout * uy[r], oz = c2 + tout * uz[r];
+                    double nin = norm3(ix, iy, iz), nout = norm3(ox, oy, oz);
+                    if (nin < nout) {
+                        any[r] = true;
+                        if (nout > far[r]) far[r] = nout;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { hit[r] = any[r]; farthest[r] = far[r]; }
+}
+template <int NR>
+PW_NOINLINE PW_HD inline void ray_scan_multi(const Frame& F, int n, const double* cen, const double* dx,
+                                             const double* dy, const double* dz, bool* hit, double* farthest) {
+    ray_scan_multi_impl<NR>(F, n, cen, dx, dy, dz, hit, farthest);
+}
+
 // numpy floor division a // b for positive doubles (npy_divmod)
 PW_HD inline double np_floordiv(double a, double b) {
     double mod = __builtin_fmod(a, b);
@@ -1277,12 +1347,33 @@ PW_HD inline __attribute__((always_inline)) void stage_average_impl(UnitShared& 
     double cen[3] = {v.centroid[0], v.centroid[1], v.centroid[2]};
     if (T::wave() == 0) PW_T1(ws, 27, t_a0);
     PW_T0(t_a1);
-    for (int k = T::tid(); k < P; k += T::SIZE) {
-        double px, py, pz, far;
-        sp.point(k, &px, &py, &pz);
-        bool hit = INL ? ray_scan_impl(sh.S, n, cen, px, py, pz, &far) : ray_scan(sh.S, n, cen, px, py, pz, &far);
-        vals[k] = far;
-        flag[k] = hit ? 1 : 0;
+    if (T::SIZE > 1) {
+        // four rays per thread and pass over the atoms
+        constexpr int NR = 4;
+        for (int k0 = T::tid(); k0 < P; k0 += NR * T::SIZE) {
+            double dx[NR], dy[NR], dz[NR], far[NR];
+            bool hit[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                int k = k0 + r * T::SIZE < P ? k0 + r * T::SIZE : k0;
+                sp.point(k, &dx[r], &dy[r], &dz[r]);
+            }
+            if (INL) ray_scan_multi_impl<NR>(sh.S, n, cen, dx, dy, dz, hit, far);
+            else ray_scan_multi<NR>(sh.S, n, cen, dx, dy, dz, hit, far);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                int k = k0 + r * T::SIZE;
+                if (k < P) { vals[k] = far[r]; flag[k] = hit[r] ? 1 : 0; }
+            }
+        }
+    } else {
+        for (int k = T::tid(); k < P; k += T::SIZE) {
+            double px, py, pz, far;
+            sp.point(k, &px, &py, &pz);
+            bool hit = ray_scan(sh.S, n, cen, px, py, pz, &far);
+            vals[k] = far;
+            flag[k] = hit ? 1 : 0;
+        }
     }
     T::sync();
     if (T::wave() == 0) PW_T1(ws, 28, t_a1);
@@ -1763,10 +1854,29 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     //      neighbours walk a path.
     {
         double cen[3] = {v.centroid[0], v.centroid[1], v.centroid[2]};
-        for (int k = T::tid(); k < P; k += T::SIZE) {
-            double far;
-            bool hit = ray_scan(sh.S, n, cen, pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], &far);
-            flag[k] = hit ? 0 : 1;
+        if (T::SIZE > 1) {
+            constexpr int NR = 4;
+            for (int k0 = T::tid(); k0 < P; k0 += NR * T::SIZE) {
+                double dx[NR], dy[NR], dz[NR], far[NR];
+                bool hit[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    int k = k0 + r * T::SIZE < P ? k0 + r * T::SIZE : k0;
+                    dx[r] = pts[3 * k]; dy[r] = pts[3 * k + 1]; dz[r] = pts[3 * k + 2];
+                }
+                ray_scan_multi<NR>(sh.S, n, cen, dx, dy, dz, hit, far);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    int k = k0 + r * T::SIZE;
+                    if (k < P) flag[k] = hit[r] ? 0 : 1;
+                }
+            }
+        } else {
+            for (int k = T::tid(); k < P; k += T::SIZE) {
+                double far;
+                bool hit = ray_scan(sh.S, n, cen, pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], &far);
+                flag[k] = hit ? 0 : 1;
+            }
         }
         T::sync();
         if (T::wave() == 0) {
