@@ -1782,55 +1782,61 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         // a window of 0.118*P + 6 indices either side proves itself for every point (checked below)
         int W = (int)(0.118 * (double)P) + 6;
         PW_T0(t_knn);
-        for (int k = T::tid(); k < P; k += T::SIZE) {
-            double px = pts[3 * k], py = pts[3 * k + 1], pz = pts[3 * k + 2];
-            double t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
-            int lo = k - W < 0 ? 0 : k - W, hi = k + W > P - 1 ? P - 1 : k + W;
+        // A thread takes FOUR consecutive points: their index windows overlap almost completely, so
+        // every candidate is read once and measured against all four (register blocking); the
+        // ten smallest squared distances of each point live in registers (sorted insertion by a
+        // compare-exchange chain).
+        constexpr int NK = 4;
+        const int ngroups = (P + NK - 1) / NK;
+        for (int grp = T::tid(); grp < ngroups; grp += T::SIZE) {
+            const int k0 = grp * NK;
+            double px[NK], py[NK], pz[NK], t[NK][10];
+#pragma unroll
+            for (int p = 0; p < NK; ++p) {
+                int k = k0 + p < P ? k0 + p : P - 1;
+                px[p] = pts[3 * k]; py[p] = pts[3 * k + 1]; pz[p] = pts[3 * k + 2];
+            }
+            const int klast = k0 + NK - 1 < P ? k0 + NK - 1 : P - 1;
+            int lo = k0 - W < 0 ? 0 : k0 - W, hi = klast + W > P - 1 ? P - 1 : klast + W;
             for (int pass = 0; pass < 2; ++pass) {
-                t0 = t1 = t2 = t3 = t4 = t5 = t6 = t7 = t8 = t9 = PW_INF;
-#define PW_CE(tq) lo_ = __builtin_fmin(tq, v_); v_ = __builtin_fmax(tq, v_); tq = lo_;
-#define PW_KNN_INSERT(dd)                                                  \
-    if ((dd) < t9) {                                                       \
-        /* sorted insertion by a compare-exchange chain (registers only) */ \
-        double lo_, v_ = (dd);                                             \
-        PW_CE(t0) PW_CE(t1) PW_CE(t2) PW_CE(t3) PW_CE(t4)                  \
-        PW_CE(t5) PW_CE(t6) PW_CE(t7) PW_CE(t8) PW_CE(t9)                  \
-    }
-                int j = lo;
-                // blocks of eight candidates: reads first, then the distances, then the insertions
-                for (; j + 7 <= hi; j += 8) {
-                    double qx[8], qy[8], qz[8], dd[8];
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        qx[t] = pts[3 * (j + t)]; qy[t] = pts[3 * (j + t) + 1]; qz[t] = pts[3 * (j + t) + 2];
-                    }
+                for (int p = 0; p < NK; ++p)
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        double ax = px - qx[t], ay = py - qy[t], az = pz - qz[t];
+                    for (int q = 0; q < 10; ++q) t[p][q] = PW_INF;
+#pragma unroll 2
+                for (int j = lo; j <= hi; ++j) {
+                    const double qx = pts[3 * j], qy = pts[3 * j + 1], qz = pts[3 * j + 2];
+#pragma unroll
+                    for (int p = 0; p < NK; ++p) {
+                        double ax = px[p] - qx, ay = py[p] - qy, az = pz[p] - qz;
                         double d = 0.0;
                         d = d + ax * ax; d = d + ay * ay; d = d + az * az;
-                        dd[t] = d;
-                    }
+                        if (d < t[p][9]) {
+                            double v_ = d;
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) { PW_KNN_INSERT(dd[t]) }
+                            for (int q = 0; q < 10; ++q) {
+                                double lo_ = __builtin_fmin(t[p][q], v_);
+                                v_ = __builtin_fmax(t[p][q], v_);
+                                t[p][q] = lo_;
+                            }
+                        }
+                    }
                 }
-                for (; j <= hi; ++j) {
-                    double qx = pts[3 * j], qy = pts[3 * j + 1], qz = pts[3 * j + 2];
-                    double ax = px - qx, ay = py - qy, az = pz - qz;
-                    double d = 0.0;
-                    d = d + ax * ax; d = d + ay * ay; d = d + az * az;
-                    PW_KNN_INSERT(d)
-                }
-#undef PW_KNN_INSERT
-#undef PW_CE
                 bool full = (lo == 0 && hi == P - 1);
-                if (full || pw_sqrt(t9) < (double)(W - 1) * zstep) break;
+                bool proven = true;
+#pragma unroll
+                for (int p = 0; p < NK; ++p) proven = proven && (pw_sqrt(t[p][9]) < (double)(W - 1) * zstep);
+                if (full || proven) break;
                 lo = 0; hi = P - 1;
             }
-            double* row = &ws->knn[k * 10];
-            row[0] = pw_sqrt(t0); row[1] = pw_sqrt(t1); row[2] = pw_sqrt(t2); row[3] = pw_sqrt(t3);
-            row[4] = pw_sqrt(t4); row[5] = pw_sqrt(t5); row[6] = pw_sqrt(t6); row[7] = pw_sqrt(t7);
-            row[8] = pw_sqrt(t8); row[9] = pw_sqrt(t9);
+#pragma unroll
+            for (int p = 0; p < NK; ++p) {
+                if (k0 + p < P) {
+                    double* row = &ws->knn[(k0 + p) * 10];
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) row[q] = pw_sqrt(t[p][q]);
+                }
+            }
         }
         T::sync();
         if (T::wave() == 0) PW_T1(ws, 24, t_knn);
