@@ -182,3 +182,26 @@ def test_config5_screen_sample_against_live_oracle(hip_ctx):
         n = ref["n_windows"]
         worst = max(worst, rel(np.sort(r["win_d"][:n]), np.sort(ref["win_d"][:n])))
     assert worst <= LIVE_TOL_WINDOW
+
+
+def test_many_distinct_radii_on_the_gpu(hip_ctx):
+    """More distinct radii than the kernels group by (ungrouped fall-back loops), against the oracle."""
+    from oracle import pw_oracle as O
+    from pywindow_amd import _lib, synth
+    from pywindow_amd import element_data as E
+
+    elements, base = synth.load_cc3_base()
+    pool = ["C", "H", "N", "O", "S", "P", "F", "CL", "BR", "I", "SI", "SE", "ZN", "CU", "LI"]
+    swapped = np.array([pool[i % len(pool)] if elements[i] == "H" else elements[i] for i in range(len(elements))])
+    ids = E.element_ids(swapped)
+    vdw, mass = E.VDW[ids], E.MASS[ids]
+    frames = np.array([synth.quantise_like_history(synth.noisy_frame(base, 777 + k, 0.05)) for k in range(3)])
+    out = hip_ctx.analyse(_lib.Batch.uniform(frames, vdw, mass))
+    for k in range(3):
+        ref = O.full_analysis(frames[k], vdw, mass)
+        r = out[k]
+        for key in ("mw", "maxd", "avg_d", "pore_d", "pore_opt_d"):
+            assert float(r[key]) == ref[key], (k, key)
+        assert int(r["n_windows"]) == ref["n_windows"]
+        n = max(ref["n_windows"], 0)
+        assert rel(np.sort(r["win_d"][:n]), np.sort(ref["win_d"][:n])) <= LIVE_TOL_WINDOW

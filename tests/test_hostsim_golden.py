@@ -67,3 +67,36 @@ def test_stage_selection(hostsim):
     assert np.array_equal(basic["pore_d"], g["pore_d"])
     opt = run_hostsim(hostsim, g, stages=4)
     assert np.array_equal(opt["pore_opt_d"], g["pore_opt_d"])
+
+
+def test_many_distinct_radii_fall_back_to_ungrouped_loops(hostsim):
+    """More distinct van der Waals radii than the kernels group by: the ungrouped code paths
+    (per-atom square roots) must give the oracle's results too."""
+    from oracle import pw_oracle as O
+    from pywindow_amd import element_data as E
+    from pywindow_amd import synth
+
+    elements, base = synth.load_cc3_base()
+    pool = ["C", "H", "N", "O", "S", "P", "F", "CL", "BR", "I", "SI", "SE", "ZN", "CU", "LI"]
+    assert len({E.atomic_vdw_radius[e] for e in pool}) > 8
+    keep = np.array([e for e in elements])
+    swapped = np.array([pool[i % len(pool)] if keep[i] == "H" else keep[i] for i in range(len(keep))])
+    ids = E.element_ids(swapped)
+    vdw, mass = np.ascontiguousarray(E.VDW[ids]), np.ascontiguousarray(E.MASS[ids])
+    g = {"atom_offset": np.array([0, len(base)], np.int64)}
+    L = ctypes.CDLL(str(hostsim / "libunitprobe.so"))
+    out = np.zeros(1, dtype=_lib.UNIT_OUT_DTYPE)
+    xyz = np.ascontiguousarray(base)
+    vp = ctypes.c_void_p
+    rc = L.hs_analysis_batch(ctypes.c_long(1), g["atom_offset"].ctypes.data_as(vp), xyz.ctypes.data_as(vp),
+                             vdw.ctypes.data_as(vp), mass.ctypes.data_as(vp), ctypes.c_uint(15),
+                             out.ctypes.data_as(vp), None)
+    assert rc == 0
+    ref = O.full_analysis(xyz, vdw, mass)
+    r = out[0]
+    for key in ("mw", "maxd", "avg_d", "pore_d", "pore_opt_d"):
+        assert float(r[key]) == ref[key], key
+    assert (int(r["maxd_i"]), int(r["maxd_j"])) == (ref["maxd_i"], ref["maxd_j"])
+    assert int(r["n_windows"]) == ref["n_windows"]
+    n = max(ref["n_windows"], 0)
+    assert np.array_equal(np.sort(r["win_d"][:n]), np.sort(ref["win_d"][:n]))
