@@ -106,3 +106,12 @@ def test_record_gather_over_rccl_single_rank():
         assert out.tobytes() == local.tobytes()
     finally:
         dist.destroy_process_group()
+
+
+def test_contexts_batches_and_overlapped_launches(hip_ctx):
+    """Odd batch sizes on fresh contexts, two resident batches alternating on one context
+    (overlapped pipeline launches), single-stage launches in between."""
+    import runpy
+    import pathlib
+
+    runpy.run_path(str(pathlib.Path(__file__).resolve().parent / "tools" / "stress.py"), run_name="__main__")
