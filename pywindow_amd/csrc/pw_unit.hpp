@@ -950,7 +950,8 @@ PW_HD inline void make_shifted(UnitShared& sh, int n, double cx, double cy, doub
 
 // max_dim over frame F (utilities.py:355-372); result in sh.v->maxd*, all threads.
 template <class T>
-PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& sh, const Frame& F, int n) {
+PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& sh, const Frame& F, int n,
+                                                                   double* item_best = nullptr) {
     // max over pairs (diagonal included) of d_ij + (vdw_i + vdw_j), first maximum in row-major
     // order of the caller's numbering (utilities.py:355-372).  Two passes; a thread owns a
     // (row, column half) and walks the columns, so the lanes of a wave hold consecutive rows and
@@ -973,7 +974,8 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
             if (j1 <= i) continue;
             const double xi = F.x[i], yi = F.y[i], zi = F.z[i], xxi = F.xx[i], vi = F.vdw[i];
             const int oi = F.perm[i];
-            if (j0 <= i) best = pw_max(best, 0.0 + (vi + vi));          // the diagonal entry
+            double ibest = -PW_INF;                                     // this item's maximum
+            if (j0 <= i) ibest = 0.0 + (vi + vi);                       // the diagonal entry
             for (int g = 0; g < ngrp; ++g) {
                 int lo = C.off[g] > j0 ? C.off[g] : j0;
                 if (lo <= i) lo = i + 1;
@@ -1003,8 +1005,10 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
                     m2 = __builtin_fmax(m2, d2);
                 }
                 double d = pw_sqrt(m2 > 0.0 ? m2 : 0.0);
-                best = pw_max(best, d + (vi + C.vdw[g]));
+                ibest = pw_max(ibest, d + (vi + C.vdw[g]));
             }
+            best = pw_max(best, ibest);
+            if (item_best) item_best[t] = ibest;
         }
     }
     // team maximum of the values
@@ -1022,6 +1026,7 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
             const int i = t - part * n;
             const int j0 = part * half, j1 = part ? n : half;
             if (j1 <= i) continue;
+            if (item_best && item_best[t] != vmax) continue;            // (written by this very thread)
             const double xi = F.x[i], yi = F.y[i], zi = F.z[i], xxi = F.xx[i], vi = F.vdw[i];
             const int oi = F.perm[i];
             if (j0 <= i && 0.0 + (vi + vi) == vmax) bidx = pw_min(bidx, (double)(oi * n + oi));
@@ -1119,8 +1124,8 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
 }
 
 template <class T>
-PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n) {
-    team_max_dim_impl<T>(sh, F, n);
+PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n, double* item_best = nullptr) {
+    team_max_dim_impl<T>(sh, F, n, item_best);
 }
 
 // ---- stage: basic -------------------------------------------------------------------------
@@ -1151,7 +1156,7 @@ PW_HD inline __attribute__((always_inline)) void stage_basic_impl(UnitShared& sh
     }
     T::sync();
     if (com_only) return;
-    team_max_dim<T>(sh, sh.A, n);
+    team_max_dim<T>(sh, sh.A, n, 2 * n <= PW_P_MAX ? ws->vals : nullptr);
     if (T::wave() == 0) {
         int arg;
         double g = wave_gap<T>(sh.A, n, v.com[0], v.com[1], v.com[2], &arg);
@@ -1320,7 +1325,10 @@ PW_HD inline __attribute__((always_inline)) void stage_average_impl(UnitShared& 
     double keep_d = v.maxd;
     int keep_i = v.maxd_i, keep_j = v.maxd_j;
     T::sync();
-    if (INL) team_max_dim_impl<T>(sh, sh.S, n); else team_max_dim<T>(sh, sh.S, n);
+    {
+        double* ib = 2 * n <= PW_P_MAX ? ws->vals : nullptr;     // per-item maxima (free until the rays)
+        if (INL) team_max_dim_impl<T>(sh, sh.S, n, ib); else team_max_dim<T>(sh, sh.S, n, ib);
+    }
     double radius = v.maxd;
     T::sync();
     if (T::tid() == 0) { v.maxd = keep_d; v.maxd_i = keep_i; v.maxd_j = keep_j; }
@@ -1732,7 +1740,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     double keep_d = v.maxd;
     int keep_i = v.maxd_i, keep_j = v.maxd_j;
     T::sync();
-    team_max_dim<T>(sh, sh.S, n);
+    team_max_dim<T>(sh, sh.S, n, 2 * n <= PW_P_MAX ? ws->vals : nullptr);
     double radius = v.maxd / 2.0;
     T::sync();
     if (T::tid() == 0) { v.maxd = keep_d; v.maxd_i = keep_i; v.maxd_j = keep_j; }
