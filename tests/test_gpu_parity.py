@@ -205,3 +205,26 @@ def test_many_distinct_radii_on_the_gpu(hip_ctx):
         assert int(r["n_windows"]) == ref["n_windows"]
         n = max(ref["n_windows"], 0)
         assert rel(np.sort(r["win_d"][:n]), np.sort(ref["win_d"][:n])) <= LIVE_TOL_WINDOW
+
+
+@pytest.mark.parametrize("copies", [3, 6])
+def test_large_molecules_against_the_oracle(hip_ctx, copies):
+    """Hundreds to a thousand atoms per unit (narrower teams, arrays spilling from LDS to the
+    workspace): several CC3 cages side by side treated as one molecule, against the oracle."""
+    from oracle import pw_oracle as O
+    from pywindow_amd import _lib, synth
+    from pywindow_amd import element_data as E
+
+    elements, base = synth.load_cc3_base()
+    ids1 = E.element_ids(elements)
+    xyz = np.concatenate([synth.quantise_like_history(synth.noisy_frame(base, 4242 + k, 0.05)) + np.array([26.0 * k, 0.0, 0.0])
+                          for k in range(copies)])
+    vdw, mass = np.tile(E.VDW[ids1], copies), np.tile(E.MASS[ids1], copies)
+    out = hip_ctx.analyse(_lib.Batch(np.array([0, len(xyz)], np.int64), xyz, vdw, mass))[0]
+    ref = O.full_analysis(xyz, vdw, mass)
+    for key in ("mw", "maxd", "avg_d", "pore_d", "pore_opt_d"):
+        assert float(out[key]) == ref[key], key
+    assert (int(out["maxd_i"]), int(out["maxd_j"])) == (ref["maxd_i"], ref["maxd_j"])
+    assert int(out["n_windows"]) == ref["n_windows"]
+    n = max(ref["n_windows"], 0)
+    assert rel(np.sort(out["win_d"][:n]), np.sort(ref["win_d"][:n])) <= LIVE_TOL_WINDOW
