@@ -21,6 +21,7 @@
 
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pywindow_amd.h"
@@ -52,23 +53,70 @@ inline bool first_token_is(const char* p, const char* e, const char* tok) {
     const char* q = p + n;
     return q == e || *q == ' ' || *q == '\t' || *q == '\r';
 }
+// One decimal token -> double.  Fast path (Clinger): a mantissa below 2^53 and a power of ten up
+// to 10^22 are both exact doubles, so one multiplication or division is correctly rounded --
+// the value strtod / Python's float() give.  Anything else goes to strtod.
+inline bool parse_one(const char* p, const char* q, double* out) {
+    static const double P10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                   1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const char* c = p;
+    bool neg = false;
+    if (c < q && (*c == '+' || *c == '-')) { neg = *c == '-'; ++c; }
+    uint64_t m = 0;
+    int digits = 0, frac = 0;
+    bool seen_dot = false, any = false, fast = true;
+    for (; c < q; ++c) {
+        if (*c >= '0' && *c <= '9') {
+            any = true;
+            if (digits < 18) { m = m * 10 + (uint64_t)(*c - '0'); if (m) ++digits; if (seen_dot) ++frac; }
+            else fast = false;
+        } else if (*c == '.' && !seen_dot) {
+            seen_dot = true;
+        } else {
+            break;
+        }
+    }
+    int e10 = 0;
+    if (any && c < q && (*c == 'e' || *c == 'E' || *c == 'd' || *c == 'D')) {
+        if (*c == 'd' || *c == 'D') fast = false;        // Fortran exponent: let strtod reject it like float()
+        ++c;
+        bool eneg = false;
+        if (c < q && (*c == '+' || *c == '-')) { eneg = *c == '-'; ++c; }
+        int ev = 0, nd = 0;
+        for (; c < q && *c >= '0' && *c <= '9'; ++c, ++nd) if (ev < 10000) ev = ev * 10 + (*c - '0');
+        if (nd == 0) fast = false;
+        e10 = eneg ? -ev : ev;
+    }
+    if (any && fast && c == q && m < (1ull << 53)) {
+        int e = e10 - frac;
+        if (e >= -22 && e <= 22) {
+            double v = (double)m;
+            v = e >= 0 ? v * P10[e] : v / P10[-e];
+            *out = neg ? -v : v;
+            return true;
+        }
+    }
+    char buf[64];
+    size_t n = (size_t)(q - p);
+    if (n >= sizeof(buf)) return false;
+    memcpy(buf, p, n);
+    buf[n] = 0;
+    char* endp = nullptr;
+    double v = strtod(buf, &endp);
+    if (endp == buf || *endp != 0) return false;
+    *out = v;
+    return true;
+}
 // parse up to `want` whitespace separated doubles from [p, e)
 inline int parse_doubles(const char* p, const char* e, double* out, int want) {
-    char buf[64];
     int got = 0;
     while (got < want) {
         p = skip_ws(p, e);
         if (p >= e) break;
         const char* q = p;
         while (q < e && *q != ' ' && *q != '\t' && *q != '\r') ++q;
-        size_t n = (size_t)(q - p);
-        if (n >= sizeof(buf)) return -1;
-        memcpy(buf, p, n);
-        buf[n] = 0;
-        char* endp = nullptr;
-        double v = strtod(buf, &endp);
-        if (endp == buf || *endp != 0) return -1;
-        out[got++] = v;
+        if (!parse_one(p, q, &out[got])) return -1;
+        ++got;
         p = q;
     }
     return got;
@@ -186,11 +234,9 @@ int64_t pw_history_atom_keys(const pw_history* h, char* buf, int64_t buflen) {
     return (int64_t)keys.size();
 }
 
-int pw_history_read(const pw_history* h, int64_t first, int64_t count, double* xyz, double* lattice) {
-    if (!h || !xyz || first < 0 || count < 0 || first + count > (int64_t)h->frame_start.size())
-        return PW_E_BAD_ARG;
+static int read_range(const pw_history* h, int64_t first, int64_t f0, int64_t f1, double* xyz, double* lattice) {
     const int64_t n = h->natoms;
-    for (int64_t f = 0; f < count; ++f) {
+    for (int64_t f = f0; f < f1; ++f) {
         double* dst = xyz + (size_t)f * (size_t)n * 3;
         double* lat = lattice ? lattice + (size_t)f * 9 : nullptr;
         int64_t seen = 0;
@@ -211,6 +257,26 @@ int pw_history_read(const pw_history* h, int64_t first, int64_t count, double* x
         });
         if (rc != PW_OK || seen != n) return PW_E_BAD_ARG;
     }
+    return PW_OK;
+}
+
+int pw_history_read(const pw_history* h, int64_t first, int64_t count, double* xyz, double* lattice) {
+    if (!h || !xyz || first < 0 || count < 0 || first + count > (int64_t)h->frame_start.size())
+        return PW_E_BAD_ARG;
+    // frames are independent: decode them on several host threads
+    unsigned hw = std::thread::hardware_concurrency();
+    int64_t nthreads = hw ? (int64_t)hw : 1;
+    if (nthreads > 16) nthreads = 16;
+    if (nthreads > count / 16) nthreads = count / 16;
+    if (nthreads <= 1) return read_range(h, first, 0, count, xyz, lattice);
+    std::vector<std::thread> pool;
+    std::vector<int> rcs((size_t)nthreads, PW_OK);
+    for (int64_t t = 0; t < nthreads; ++t) {
+        int64_t f0 = count * t / nthreads, f1 = count * (t + 1) / nthreads;
+        pool.emplace_back([&, t, f0, f1]() { rcs[(size_t)t] = read_range(h, first, f0, f1, xyz, lattice); });
+    }
+    for (auto& th : pool) th.join();
+    for (int rc : rcs) if (rc != PW_OK) return rc;
     return PW_OK;
 }
 

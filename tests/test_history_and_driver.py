@@ -74,3 +74,36 @@ def test_frame_selection_and_sharding(tmp_path):
         parts = [shard_range(n, r, w) for r in range(w)]
         assert parts[0][0] == 0 and parts[-1][1] == n
         assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+
+
+def test_number_decoding_equals_python_float(tmp_path):
+    """The reference decodes every field with float(); the parser's fast path (short mantissa x
+    exact power of ten) and its strtod fallback must give the same double for every spelling,
+    and the threaded frame decode must keep the frame order."""
+    rng = np.random.default_rng(17)
+    toks = ["0", "-0.0", "+1.5", ".5", "5.", "1e5", "1E-5", "-2.5000E+00", "1.2345E+01",
+            "9007199254740993", "9007199254740992.0", "0.1", "1e22", "1e23", "1e-22", "1e-23",
+            "123456789012345678", "1234567890123456789012", "0.000000000000000000000001",
+            "4.9406564584124654e-324", "1.7976931348623157e308", "2.2250738585072011e-308",
+            "3.141592653589793238462643", "-7.0E-01", "6.02214076E+23", "1e+0", "00012.5e-3"]
+    toks += ["%.4E" % v for v in rng.normal(0, 30, 40)]
+    toks += ["%.17g" % v for v in rng.normal(0, 1e-3, 40)]
+    toks += ["%.10f" % v for v in rng.normal(0, 1e3, 40)]
+    while len(toks) % 3:
+        toks.append("1.0")
+    natms, nframes = len(toks) // 3, 40
+    lines = ["title", "%10d%10d%10d" % (0, 0, natms)]
+    for k in range(nframes):
+        lines.append("timestep%10d%10d%10d%10d%12.6f" % (k + 1, natms, 0, 0, 0.001))
+        for i in range(natms):
+            lines.append("%-8s%10d%12.6f%12.6f" % ("C", i + 1, 12.0, 0.0))
+            a, b, c = toks[3 * i: 3 * i + 3]
+            # a different spelling of frame k's first field marks the frame
+            lines.append("%s %s %s" % (a if i else "%d.0" % k, b, c))
+    path = tmp_path / "HISTORY"
+    path.write_text("\n".join(lines) + "\n")
+    got = DLPOLY(path).read_coordinates(0, nframes)
+    want = np.array([float(t) for t in toks]).reshape(natms, 3)
+    for k in range(nframes):
+        want[0, 0] = float(k)
+        assert got[k].tobytes() == want.tobytes(), k
