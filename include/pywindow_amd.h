@@ -50,6 +50,7 @@ extern "C" {
 #define PW_ST_POINTS_OVERFLOW 4    /* more than PW_P_MAX sampling vectors */
 #define PW_ST_WINDOW_DROPPED 8     /* a cluster's refined path scan failed (reference: None + warning) */
 #define PW_ST_WINDOW_NEGATIVE 16   /* a window diameter < 0 (reference: warning) */
+#define PW_ST_Z_BOUNDS 32          /* z_bounds upper < -new_z with lb_z (reference: scipy raises ValueError) */
 
 /* Input batch: ragged molecules, atoms of unit u are [atom_offset[u], atom_offset[u+1]). */
 typedef struct pw_batch_in {
@@ -101,6 +102,11 @@ typedef struct pw_params {
     double opt_x0[3];       /* com=: start of the optimisation (default: the centre of mass) */
     double opt_lo[3];       /* bounds=: lower / upper bound per axis, -/+HUGE_VAL for None */
     double opt_hi[3];       /*          (default: start -/+ the pore radius at the start) */
+    /* window_analysis(increment2=0.1, z_bounds=None, lb_z=True, z_second_mini=False), utilities.py:1191-1200 */
+    double increment2;      /* refined path-scan step along the chosen vector, :1221-1224 */
+    double z_lo, z_hi;      /* z_bounds: -/+HUGE_VAL for None; z_lo is replaced by -new_z when lb_z, :1296-1297 */
+    int32_t lb_z;           /* lower bound of the neck search = -new_z (default 1) */
+    int32_t z_second_mini;  /* second neck search after the in-plane optimisation, :1326-1334 (default 0) */
 } pw_params;
 #define PW_OPT_CUSTOM_START 1
 #define PW_OPT_CUSTOM_BOUNDS 2

@@ -293,10 +293,12 @@ def _rot_y(a):
     return np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
 
 
-def window_fit(cage: Cage, cluster_rows: np.ndarray, detail=None):
+def window_fit(cage: Cage, cluster_rows: np.ndarray, detail=None, increment2: float = 0.1,
+               z_bounds=None, lb_z: bool = True, z_second_mini: bool = False):
     """utilities.py:1191-1361 -- measure one window from its cluster of vectors."""
+    z_bounds = [None, None] if z_bounds is None else list(z_bounds)
     best = cluster_rows[cluster_rows.argmax(axis=0)[1]][5:8]
-    fine = path_scan(cage, best, 0.1)
+    fine = path_scan(cage, best, increment2)
     if fine is None:
         return None
     v = fine[5:8]
@@ -312,7 +314,9 @@ def window_fit(cage: Cage, cluster_rows: np.ndarray, detail=None):
     def along_z(z):
         return local.gap(np.array([centre[0], centre[1], z[0]]))[0] * 2
 
-    zres = minimize(along_z, x0=centre[2], bounds=[[-neck, None]])
+    if lb_z:
+        z_bounds[0] = -neck
+    zres = minimize(along_z, x0=centre[2], bounds=[z_bounds])
     centre[2] = zres.x[0]
 
     def in_plane(xy):
@@ -322,6 +326,9 @@ def window_fit(cage: Cage, cluster_rows: np.ndarray, detail=None):
     xyres = brute(in_plane, box, full_output=True, finish=fmin)
     centre[0] = xyres[0][0]
     centre[1] = xyres[0][1]
+    if z_second_mini is not False:
+        zres = minimize(along_z, x0=centre[2], bounds=[z_bounds])
+        centre[2] = zres.x[0]
     diameter = pore_diameter(local, centre)[0]
     centre[2] = centre[2] + neck
     centre = np.dot(_rot_y(-a2), centre)
@@ -333,8 +340,10 @@ def window_fit(cage: Cage, cluster_rows: np.ndarray, detail=None):
 
 
 def find_windows(cage: Cage, detail=None, adjust: float = 1, pore_opt: bool = True,
-                 increment: float = 1.0):
-    """utilities.py:1364-1553 (``adjust``, ``pore_opt``, ``increment`` as there).
+                 increment: float = 1.0, **window_options):
+    """utilities.py:1364-1553 (``adjust``, ``pore_opt``, ``increment`` as there);
+    ``window_options`` are window_analysis's keywords (increment2, z_bounds, lb_z,
+    z_second_mini), which the reference's find_windows leaves at their defaults.
 
     Returns ``None`` (no window), or ``(diameters (W,), centres (W,3))``.
     """
@@ -380,7 +389,7 @@ def find_windows(cage: Cage, detail=None, adjust: float = 1, pore_opt: bool = Tr
         if lab == -1:
             continue
         found.append(window_fit(moved, np.array(groups[lab]),
-                                None if detail is None else detail["windows"]))
+                                None if detail is None else detail["windows"], **window_options))
     diam = np.array([w[0] for w in found if w is not None])
     cen = np.array([np.add(w[1], origin_back) for w in found if w is not None])
     return diam, cen

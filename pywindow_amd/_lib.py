@@ -25,6 +25,7 @@ ST_WINDOW_OVERFLOW = 2
 ST_POINTS_OVERFLOW = 4
 ST_WINDOW_DROPPED = 8
 ST_WINDOW_NEGATIVE = 16
+ST_Z_BOUNDS = 32
 
 _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libpywindow_hip.so"
@@ -56,12 +57,19 @@ class Params(ctypes.Structure):
         ("opt_x0", ctypes.c_double * 3),
         ("opt_lo", ctypes.c_double * 3),
         ("opt_hi", ctypes.c_double * 3),
+        ("increment2", ctypes.c_double),
+        ("z_lo", ctypes.c_double),
+        ("z_hi", ctypes.c_double),
+        ("lb_z", ctypes.c_int32),
+        ("z_second_mini", ctypes.c_int32),
     ]
 
     def __init__(self, adjust_windows=1.0, adjust_average=1.0, increment=1.0, pore_opt=True, opt_start=None,
-                 opt_bounds=None):
+                 opt_bounds=None, increment2=0.1, z_bounds=None, lb_z=True, z_second_mini=False):
         """``opt_start``: (3,) start of opt_pore_diameter; ``opt_bounds``: three (lo, hi) pairs, ``None``
-        for an open side (scipy.optimize.minimize's ``bounds`` convention)."""
+        for an open side (scipy.optimize.minimize's ``bounds`` convention).  ``increment2``,
+        ``z_bounds`` (a (lo, hi) pair), ``lb_z``, ``z_second_mini``: window_analysis's keywords
+        (utilities.py:1191-1200)."""
         flags = 0
         x0 = (ctypes.c_double * 3)(0.0, 0.0, 0.0)
         lo = (ctypes.c_double * 3)(-np.inf, -np.inf, -np.inf)
@@ -76,8 +84,11 @@ class Params(ctypes.Structure):
                 a, b = opt_bounds[k]
                 lo[k] = -np.inf if a is None else float(a)
                 hi[k] = np.inf if b is None else float(b)
+        z_lo, z_hi = (None, None) if z_bounds is None else z_bounds
         super().__init__(float(adjust_windows), float(adjust_average), float(increment), 1 if pore_opt else 0,
-                         flags, x0, lo, hi)
+                         flags, x0, lo, hi, float(increment2),
+                         -np.inf if z_lo is None else float(z_lo), np.inf if z_hi is None else float(z_hi),
+                         1 if lb_z else 0, 0 if z_second_mini is False else 1)
 
 
 class CellIn(ctypes.Structure):

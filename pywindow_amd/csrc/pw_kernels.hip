@@ -473,7 +473,7 @@ void pw_params_default(pw_params* p) {
 
 int pw_context_set_params(pw_context* c, const pw_params* p) {
     if (!c || !p) return PW_E_BAD_ARG;
-    if (!(p->adjust_windows > 0.0) || !(p->adjust_average > 0.0) || !(p->increment > 0.0)) {
+    if (!(p->adjust_windows > 0.0) || !(p->adjust_average > 0.0) || !(p->increment > 0.0) || !(p->increment2 > 0.0)) {
         snprintf(g_err, sizeof(g_err), "pw_params: adjust and increment must be positive");
         return PW_E_BAD_ARG;
     }
@@ -483,8 +483,14 @@ int pw_context_set_params(pw_context* c, const pw_params* p) {
                 snprintf(g_err, sizeof(g_err), "pw_params: an upper bound is less than the corresponding lower bound");
                 return PW_E_BAD_ARG;
             }
+    if (!p->lb_z && p->z_lo > p->z_hi) {
+        snprintf(g_err, sizeof(g_err), "pw_params: an upper bound is less than the corresponding lower bound");
+        return PW_E_BAD_ARG;
+    }
     c->prm = *p;
     c->prm.pore_opt = p->pore_opt ? 1 : 0;
+    c->prm.lb_z = p->lb_z ? 1 : 0;
+    c->prm.z_second_mini = p->z_second_mini ? 1 : 0;
     return PW_OK;
 }
 

@@ -641,6 +641,7 @@ PW_HD inline pw_params default_params() {
     pw_params p;
     p.adjust_windows = 1.0; p.adjust_average = 1.0; p.increment = 1.0; p.pore_opt = 1; p.opt_flags = 0;
     for (int c = 0; c < 3; ++c) { p.opt_x0[c] = 0.0; p.opt_lo[c] = -PW_INF; p.opt_hi[c] = PW_INF; }
+    p.increment2 = 0.1; p.z_lo = -PW_INF; p.z_hi = PW_INF; p.lb_z = 1; p.z_second_mini = 0;
     return p;
 }
 // int(np.log10(4*pi*r**2) * 250 * adjust)  (utilities.py:1410, 1615)
@@ -1510,7 +1511,7 @@ PW_NOINLINE PW_HD inline void wave_fmin_xy(const Frame& F, int n, double z, doub
 // ---- one window (utilities.py:1191-1361), executed by ONE wave -------------------------------
 template <class T>
 PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int n, int cluster,
-                              const Sphere& sp) {
+                              const Sphere& sp, const pw_params& prm) {
     auto& v = *sh.v;
     const int w = T::wave();
     Frame& R = sh.R[w];
@@ -1518,9 +1519,9 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     // (i) the cluster's vector with the largest 2*gap was selected by stage_windows
     double vx = v.win_vec[cluster][0], vy = v.win_vec[cluster][1], vz = v.win_vec[cluster][2];
     PW_T0(t_p);
-    // (ii) refined path scan, increment 0.1, lanes over path points
+    // (ii) refined path scan, increment2 (0.1), lanes over path points
     double nrm = norm3(vx, vy, vz);
-    int chunks = (int)np_floordiv(nrm, 0.1);
+    int chunks = (int)np_floordiv(nrm, prm.increment2);
     double cx = vx / (double)chunks, cy = vy / (double)chunks, cz = vz / (double)chunks;
     double pbest = PW_INF;
     int ppos = 0x7fffffff;
@@ -1605,94 +1606,117 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     double d0 = wave_gap_value<T>(R, n, 0.0, 0.0, 0.0) * 2.0;
     evals += 1;
     PW_T1(ws, 3, t_r);
-    // (v) neck position along z: L-BFGS-B, n = 1, bounds [-new_z, +inf)
+    // (v) neck position along z: L-BFGS-B, n = 1, bounds [-new_z, +inf) by default
+    // (lb_z / z_bounds: utilities.py:1296-1303); (vi) in-plane optimisation; optionally the neck
+    // search once more from the in-plane optimum (z_second_mini, :1326-1334)
     Lbfgsb<1> zopt_state;
     Lbfgsb<1>* S = &zopt_state;
     LbMem<1>* Smem = (LbMem<1>*)sh.lb[w];
     PW_ASSUME_LDS(Smem);
-    double lo1[1] = {-new_z}, up1[1] = {0.0}, x01[1] = {0.0};
-    int nbd1[1] = {1};
-    if (x01[0] < lo1[0]) x01[0] = lo1[0];   // np.clip(x0, lb, ub)
-    S->setup(Smem, x01, lo1, up1, nbd1, 1e7, 1e-5, 20);
-    int nit = 0;
-    bool have_last = false;
-    double lz = 0.0, lf = 0.0, lg = 0.0;
-    for (;;) {
-        PW_T0(t_zs);
-        S->template step<T>();
-        T::wave_sync();
-        PW_T1(ws, 4, t_zs);
-        if (S->task == LB_FG) {
-            PW_T0(t_ze);
-            double zc = S->x[0];
-            if (!(have_last && zc == lz)) {
-                double h = fd_step(zc, lo1[0], PW_INF);
-                double z1 = zc + h;
-                double dz = z1 - zc;
-                double zx[4] = {0.0, 0.0, 0.0, 0.0}, zz[4] = {zc, z1, zc, z1}, gv[4];
-                wave_gap4<T>(R, n, zx, zx, zz, gv);
-                double f0 = gv[0] * 2.0;
-                double f1 = gv[1] * 2.0;
-                evals += 2;
-                lf = f0;
-                lg = (f1 - f0) / dz;
-                lz = zc;
-                have_last = true;
-            }
-            S->f = lf;
-            S->g[0] = lg;
-            T::wave_sync();
-            PW_T1(ws, 5, t_ze);
-        } else if (S->task == LB_NEW_X) {
-            nit += 1;
-            if (nit >= 15000) break;      // (a neck search takes a handful of evaluations)
+    double lo1[1] = {prm.lb_z ? -new_z : prm.z_lo}, up1[1] = {prm.z_hi};
+    int nbd1[1];
+    {
+        bool has_lo = lo1[0] > -PW_INF, has_up = up1[0] < PW_INF;
+        nbd1[0] = has_lo ? (has_up ? 2 : 1) : (has_up ? 3 : 0);
+    }
+    if (lo1[0] > up1[0]) {                       // scipy: ValueError -- reported through the status
+        if (T::lane() == 0) {
+            v.win_ok[cluster] = -1;              // "bounds", not "path scan failed"
+            v.red_i[8 + w] += evals;
+        }
+        return;
+    }
+    double xo = 0.0, yo = 0.0, zopt = 0.0;
+    for (int phase = 0; phase < 2; ++phase) {
+        if (lo1[0] == up1[0]) {
+            zopt = lo1[0];                       // a fixed variable: scipy returns the bound itself
         } else {
-            break;
+            double x01[1] = {zopt};
+            // np.clip(x0, lb, ub)
+            x01[0] = x01[0] < lo1[0] ? lo1[0] : (x01[0] > up1[0] ? up1[0] : x01[0]);
+            S->setup(Smem, x01, lo1, up1, nbd1, 1e7, 1e-5, 20);
+            int nit = 0;
+            bool have_last = false;
+            double lz = 0.0, lf = 0.0, lg = 0.0;
+            for (;;) {
+                PW_T0(t_zs);
+                S->template step<T>();
+                T::wave_sync();
+                PW_T1(ws, 4, t_zs);
+                if (S->task == LB_FG) {
+                    PW_T0(t_ze);
+                    double zc = S->x[0];
+                    if (!(have_last && zc == lz)) {
+                        double h = fd_step(zc, lo1[0], up1[0]);
+                        double z1 = zc + h;
+                        double dz = z1 - zc;
+                        double zx[4] = {xo, xo, xo, xo}, zy[4] = {yo, yo, yo, yo}, zz[4] = {zc, z1, zc, z1}, gv[4];
+                        wave_gap4<T>(R, n, zx, zy, zz, gv);
+                        double f0 = gv[0] * 2.0;
+                        double f1 = gv[1] * 2.0;
+                        evals += 2;
+                        lf = f0;
+                        lg = (f1 - f0) / dz;
+                        lz = zc;
+                        have_last = true;
+                    }
+                    S->f = lf;
+                    S->g[0] = lg;
+                    T::wave_sync();
+                    PW_T1(ws, 5, t_ze);
+                } else if (S->task == LB_NEW_X) {
+                    nit += 1;
+                    if (nit >= 15000) break;      // (a neck search takes a handful of evaluations)
+                } else {
+                    break;
+                }
+            }
+            zopt = S->x[0];
         }
-    }
-    double zopt = S->x[0];
-    PW_T0(t_b);
-    // (vi) brute 20 x 20 grid over +-d0/2, lanes over grid points, first minimum
-    double hlf = d0 / 2.0;
-    double gstart = -hlf;
-    double gstep = (hlf - gstart) / 19.0;
-    double gbest = PW_INF;
-    int gidx = 0x7fffffff;
-    if (T::WSIZE == 64) {
-        // a lane's (up to) seven grid points share one pass over the atoms
-        constexpr int NP = 7;
-        double qx[NP], qy[NP], qz[NP], m[NP];
+        if (phase == 1) break;
+        PW_T0(t_b);
+        // (vi) brute 20 x 20 grid over +-d0/2, lanes over grid points, first minimum
+        double hlf = d0 / 2.0;
+        double gstart = -hlf;
+        double gstep = (hlf - gstart) / 19.0;
+        double gbest = PW_INF;
+        int gidx = 0x7fffffff;
+        if (T::WSIZE == 64) {
+            // a lane's (up to) seven grid points share one pass over the atoms
+            constexpr int NP = 7;
+            double qx[NP], qy[NP], qz[NP], m[NP];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            int q = T::lane() + 64 * p;
-            if (q >= 400) q = T::lane();
-            qx[p] = (double)(q / 20) * gstep + gstart;
-            qy[p] = (double)(q % 20) * gstep + gstart;
-            qz[p] = zopt;
-        }
-        points_gap_values<NP>(R, n, qx, qy, qz, m);
+            for (int p = 0; p < NP; ++p) {
+                int q = T::lane() + 64 * p;
+                if (q >= 400) q = T::lane();
+                qx[p] = (double)(q / 20) * gstep + gstart;
+                qy[p] = (double)(q % 20) * gstep + gstart;
+                qz[p] = zopt;
+            }
+            points_gap_values<NP>(R, n, qx, qy, qz, m);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            int q = T::lane() + 64 * p;
-            double f = -(m[p] * 2.0);
-            if (q < 400 && f < gbest) { gbest = f; gidx = q; }
+            for (int p = 0; p < NP; ++p) {
+                int q = T::lane() + 64 * p;
+                double f = -(m[p] * 2.0);
+                if (q < 400 && f < gbest) { gbest = f; gidx = q; }
+            }
+        } else {
+            for (int q = T::lane(); q < 400; q += T::WSIZE) {
+                int ix = q / 20, iy = q % 20;
+                double gx = (double)ix * gstep + gstart, gy = (double)iy * gstep + gstart;
+                double f = -(point_gap_value(R, n, gx, gy, zopt) * 2.0);
+                if (f < gbest) { gbest = f; gidx = q; }
+            }
         }
-    } else {
-        for (int q = T::lane(); q < 400; q += T::WSIZE) {
-            int ix = q / 20, iy = q % 20;
-            double gx = (double)ix * gstep + gstart, gy = (double)iy * gstep + gstart;
-            double f = -(point_gap_value(R, n, gx, gy, zopt) * 2.0);
-            if (f < gbest) { gbest = f; gidx = q; }
-        }
+        evals += 400;
+        T::wave_argmin(gbest, gidx);
+        double gx0 = (double)(gidx / 20) * gstep + gstart, gy0 = (double)(gidx % 20) * gstep + gstart;
+        PW_T1(ws, 6, t_b);
+        PW_T0(t_n);
+        wave_fmin_xy<T>(R, n, zopt, gx0, gy0, &xo, &yo, &evals);
+        PW_T1(ws, 7, t_n);
+        if (!prm.z_second_mini) break;
     }
-    evals += 400;
-    T::wave_argmin(gbest, gidx);
-    double gx0 = (double)(gidx / 20) * gstep + gstart, gy0 = (double)(gidx % 20) * gstep + gstart;
-    PW_T1(ws, 6, t_b);
-    PW_T0(t_n);
-    double xo, yo;
-    wave_fmin_xy<T>(R, n, zopt, gx0, gy0, &xo, &yo, &evals);
-    PW_T1(ws, 7, t_n);
     // (vii) final diameter, (viii) back-rotation
     double dfin = wave_gap_value<T>(R, n, xo, yo, zopt) * 2.0;
     evals += 1;
@@ -1707,7 +1731,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     double uy = row(sm1, cm1, 0.0, tx, ty, tz);
     double uz = row(0.0, 0.0, 1.0, tx, ty, tz);
 #ifdef PW_HOST_DEBUG
-    printf("DBG cluster %d vec %.17g %.17g %.17g a1 %.17g a2 %.17g new_z %.17g d0 %.17g zopt %.17g g0 %.17g %.17g xy %.17g %.17g dfin %.17g\n", cluster, vx, vy, vz, a1, a2, new_z, d0, zopt, gx0, gy0, xo, yo, dfin);
+    printf("DBG cluster %d vec %.17g %.17g %.17g a1 %.17g a2 %.17g new_z %.17g d0 %.17g zopt %.17g xy %.17g %.17g dfin %.17g\n", cluster, vx, vy, vz, a1, a2, new_z, d0, zopt, xo, yo, dfin);
 #endif
     if (T::lane() == 0) {
         v.win_ok[cluster] = 1;
@@ -2139,19 +2163,21 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     // in an 8-wave team the upper four only take part in the bulk stages
     constexpr int NSLOT = T::NWAVES < 4 ? T::NWAVES : 4;
     if (T::wave() < NSLOT)
-        for (int c = T::wave(); c < ncl; c += NSLOT) wave_window<T>(sh, ws, n, c, sp);
+        for (int c = T::wave(); c < ncl; c += NSLOT) wave_window<T>(sh, ws, n, c, sp, prm);
     T::sync();
     if (T::wave() == 0) PW_T1(ws, 12, t_w);
     if (T::tid() == 0) {
         int m = 0;
         for (int c = 0; c < ncl; ++c) {
-            if (v.win_ok[c]) {
+            if (v.win_ok[c] > 0) {
                 out->win_d[m] = v.win_d[c];
                 out->win_c[m][0] = v.win_c[c][0];
                 out->win_c[m][1] = v.win_c[c][1];
                 out->win_c[m][2] = v.win_c[c][2];
                 if (v.win_d[c] < 0.0) v.status |= PW_ST_WINDOW_NEGATIVE;
                 ++m;
+            } else if (v.win_ok[c] < 0) {
+                v.status |= PW_ST_Z_BOUNDS;
             } else {
                 v.status |= PW_ST_WINDOW_DROPPED;
             }

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes
 import pathlib
+import sys
 
 import numpy as np
 
@@ -288,13 +289,11 @@ def _dist_state(distributed):
     """(torch.distributed module or None, rank, world) for an initialised process group."""
     if distributed is False:
         return None, 0, 1
-    try:
-        import torch.distributed as dist_mod
-
-        if dist_mod.is_available() and dist_mod.is_initialized():
-            return dist_mod, dist_mod.get_rank(), dist_mod.get_world_size()
-    except ImportError:
-        pass
+    # a process group can only exist if the application imported torch.distributed already:
+    # never pay the torch import (about a second) for a single-process analysis
+    dist_mod = sys.modules.get("torch.distributed")
+    if dist_mod is not None and dist_mod.is_available() and dist_mod.is_initialized():
+        return dist_mod, dist_mod.get_rank(), dist_mod.get_world_size()
     return None, 0, 1
 
 

@@ -83,13 +83,26 @@ def find_average_diameter(elements, coordinates, adjust=1, processes=None) -> fl
     return float(_one(elements, coordinates, _lib.STAGE_AVG, params)["avg_d"])
 
 
-def find_windows(elements, coordinates, processes=None, adjust=1, pore_opt=True, increment=1.0):
+def find_windows(elements, coordinates, processes=None, adjust=1, pore_opt=True, increment=1.0,
+                 increment2=0.1, z_bounds=None, lb_z=True, z_second_mini=False):
     """Reference utilities.py:1364-1553.  ``adjust`` scales the number of sampling vectors,
     ``pore_opt`` centres the molecule on the optimised pore (``is True``, like the reference)
-    or on its centre of mass, ``increment`` is the step of the coarse path scan."""
+    or on its centre of mass, ``increment`` is the step of the coarse path scan.
+
+    The last four keywords are those of the reference's ``window_analysis``
+    (utilities.py:1191-1200), which its ``find_windows`` always calls with the defaults: the
+    refined path-scan step, the bounds of the neck search along the window axis (``lb_z``: the
+    lower bound is the distance back to the pore centre), and the optional second neck search.
+    """
     del processes
-    default = adjust == 1 and pore_opt is True and increment == 1.0
-    params = None if default else _lib.Params(adjust_windows=adjust, pore_opt=pore_opt is True, increment=increment)
+    default = (adjust == 1 and pore_opt is True and increment == 1.0 and increment2 == 0.1
+               and z_bounds is None and lb_z is True and z_second_mini is False)
+    params = None if default else _lib.Params(
+        adjust_windows=adjust, pore_opt=pore_opt is True, increment=increment, increment2=increment2,
+        z_bounds=z_bounds, lb_z=bool(lb_z), z_second_mini=z_second_mini)
     r = _one(elements, coordinates, _lib.STAGE_WINDOWS, params)
+    if int(r["status"]) & _lib.ST_Z_BOUNDS:
+        # scipy.optimize.minimize raises this from inside the reference's window_analysis
+        raise ValueError("An upper bound is less than the corresponding lower bound.")
     engine.warn_like_reference(r)
     return engine.windows_of(r)

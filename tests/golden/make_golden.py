@@ -490,6 +490,67 @@ def options_unit(args):
     return n_win, win_d, win_c, avg
 
 
+#: window_analysis keywords (increment2, z_bounds, lb_z, z_second_mini), utilities.py:1191-1200
+WINDOW_FIT_OPTIONS = [
+    (0.1, None, True, True),
+    (0.1, None, False, False),
+    (0.05, None, True, False),
+    (0.25, (None, 0.5), True, True),
+    (0.1, (-1.0, 1.0), False, True),
+    (0.1, (0.2, 3.0), False, False),
+]
+
+
+def winopt_unit(args):
+    """find_windows of the reference with window_analysis's keywords set: find_windows passes
+    none of them (utilities.py:1497-1523), so the defaults of the callee are bound instead."""
+    import functools
+
+    elements, coords = args
+    load_reference()
+    from pywindow._internal import utilities as U
+
+    elements = np.array(elements)
+    n_win = np.full(len(WINDOW_FIT_OPTIONS), -1, np.int64)
+    win_d = np.zeros((len(WINDOW_FIT_OPTIONS), W_MAX))
+    win_c = np.zeros((len(WINDOW_FIT_OPTIONS), W_MAX, 3))
+    plain = U.window_analysis
+    try:
+        for k, (inc2, zb, lb_z, second) in enumerate(WINDOW_FIT_OPTIONS):
+            U.window_analysis = functools.partial(
+                plain, increment2=inc2, z_bounds=None if zb is None else list(zb), lb_z=lb_z, z_second_mini=second)
+            res = U.find_windows(elements, np.array(coords))
+            if res is not None:
+                n_win[k] = len(res[0])
+                win_d[k, : len(res[0])] = res[0]
+                win_c[k, : len(res[0])] = res[1]
+    finally:
+        U.window_analysis = plain
+    return n_win, win_d, win_c
+
+
+def run_winopt(pool):
+    n, e, x = static_cases()
+    pick = [n.index(k) for k in ("cc3", "windows_case_2", "windows_case_3", "windows_case_4")]
+    n2, e2, x2 = md20_cases()
+    names = [n[i] for i in pick] + [n2[3]]
+    els = [list(e[i]) for i in pick] + [list(e2[3])]
+    xyz = [np.array(x[i], float) for i in pick] + [np.array(x2[3], float)]
+    res = pool.map(winopt_unit, list(zip(els, xyz)))
+    off = np.concatenate([[0], np.cumsum([len(q) for q in els])])
+    opts = np.array([[i2, -np.inf if zb is None or zb[0] is None else zb[0],
+                      np.inf if zb is None or zb[1] is None else zb[1], float(lb), float(sec)]
+                     for i2, zb, lb, sec in WINDOW_FIT_OPTIONS])
+    np.savez_compressed(
+        HERE / "winopt.npz",
+        names=np.array(names), atom_offset=off, elements=np.concatenate([np.array(q) for q in els]),
+        coordinates=np.concatenate(xyz), window_fit_options=opts,
+        n_windows=np.array([r[0] for r in res]), win_d=np.array([r[1] for r in res]),
+        win_c=np.array([r[2] for r in res]),
+    )
+    print("winopt:", names, [r[0].tolist() for r in res])
+
+
 OPT_CASES = [  # (com offset or None, bounds offsets relative to the centre of mass or None)
     ((0.3, -0.2, 0.1), None),
     (None, ((-1.0, 1.0), (-1.0, None), (None, None))),
@@ -684,7 +745,7 @@ def run_ptraj(pool):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj", "optopt"}
+    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj", "optopt", "winopt"}
     if "cc3base" in which:
         load_reference()
         import tests.test_validate_cc3 as C
@@ -718,6 +779,8 @@ def main():
             run_ptraj(pool)
         if "optopt" in which:
             run_optopt(pool)
+        if "winopt" in which:
+            run_winopt(pool)
     meta = {
         "generator": "tests/golden/make_golden.py",
         "reference": "marcinmiklitz/pywindow @ /root/reference (imported with rdkit stub)",

@@ -149,3 +149,56 @@ def test_hip_custom_start_and_bounds(hip_ctx):
             assert d == ref[0] and atom == int(ref[1]) and np.array_equal(c, ref[2:5]), (u, k)
     with pytest.raises(ValueError):
         U.opt_pore_diameter(el, xyz, bounds=((1.0, 0.0), (None, None), (None, None)))
+
+
+# ---- window_analysis(increment2=, z_bounds=, lb_z=, z_second_mini=) --------------------------------
+def winopt_kwargs(row):
+    inc2, lo, hi, lb_z, second = (float(x) for x in row)
+    zb = None if (np.isinf(lo) and np.isinf(hi)) else (None if np.isinf(lo) else lo, None if np.isinf(hi) else hi)
+    return {"increment2": inc2, "z_bounds": zb, "lb_z": bool(lb_z), "z_second_mini": bool(second)}
+
+
+def test_oracle_window_fit_options_match_reference():
+    from oracle import pw_oracle as O
+
+    g = np.load(GOLDEN / "winopt.npz")
+    off, xyz, vdw, mass = group_batch(g)
+    u = 1                    # the oracle is slow: one molecule, every keyword set
+    cage = O.Cage(xyz[off[u]:off[u + 1]], vdw[off[u]:off[u + 1]], mass[off[u]:off[u + 1]])
+    for k, row in enumerate(g["window_fit_options"]):
+        res = O.find_windows(cage, **winopt_kwargs(row))
+        assert np.array_equal(np.sort(res[0]), np.sort(g["win_d"][u][k][: len(res[0])])), k
+
+
+def test_host_team_window_fit_options_match_reference(hostsim):
+    g = np.load(GOLDEN / "winopt.npz")
+    default = np.load(GOLDEN / "options.npz")
+    for k, row in enumerate(g["window_fit_options"]):
+        out = run_hostsim(hostsim, g, _lib.STAGE_WINDOWS, _lib.Params(**winopt_kwargs(row)))
+        for u in range(len(out)):
+            compare_windows(out[u]["n_windows"], out[u]["win_d"], out[u]["win_c"], g, u, k, f"hostsim u{u} fit{k}")
+    # the keywords matter: the results differ from the defaults' somewhere
+    assert default["names"].tolist() == g["names"].tolist()
+
+
+@pytest.mark.gpu
+def test_hip_window_fit_options_match_reference(hip_ctx):
+    from pywindow_amd import utilities as U
+
+    g = np.load(GOLDEN / "winopt.npz")
+    off = g["atom_offset"]
+    changed = 0
+    for u in range(len(off) - 1):
+        el, xyz = g["elements"][off[u]:off[u + 1]], g["coordinates"][off[u]:off[u + 1]]
+        plain = U.find_windows(el, xyz)
+        for k, row in enumerate(g["window_fit_options"]):
+            res = U.find_windows(el, xyz, **winopt_kwargs(row))
+            compare_windows(len(res[0]), res[0], res[1], g, u, k, f"hip u{u} fit{k}")
+            changed += int(not np.array_equal(np.sort(res[0]), np.sort(plain[0])))
+    assert changed > 0
+    # an upper bound below -new_z: scipy raises inside the reference's window_analysis
+    with pytest.raises(ValueError):
+        U.find_windows(el, xyz, z_bounds=(None, -1000.0))
+    with pytest.raises(_lib.PwHipError):
+        hip_ctx.set_params(_lib.Params(z_bounds=(1.0, 0.0), lb_z=False))
+    hip_ctx.set_params(None)
