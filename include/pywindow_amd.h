@@ -202,6 +202,26 @@ int pw_resident_from_cells(pw_context *ctx, const pw_cell_in *in, const double *
                            int32_t mols_cap, pw_resident **res, int32_t *n_mol, int32_t *status);
 int pw_context_device(pw_context *ctx);
 
+/* ---- shape descriptors and circumcircles --------------------------------------
+ * get_gyration_tensor / get_inertia_tensor / get_tensor_eigenvalues(sort=True) / calc_asphericity /
+ * calc_acylidricity / calc_relative_shape_anisotropy (utilities.py:434-650) of every unit of a batch
+ * in one launch.  The tensors are bit-identical to the reference's (numpy's summation orders are
+ * reproduced, including the N x N broadcast of utilities.py:511-522); the eigenvalues come from a
+ * Jacobi iteration instead of LAPACK dgeev and agree to a few ulps of the largest one. */
+typedef struct pw_shape_out {
+    double gyration[3][3];
+    double inertia[3][3];
+    double eigenvalues[3];             /* of the inertia tensor, descending */
+    double asphericity;
+    double acylidricity;
+    double relative_shape_anisotropy;
+} pw_shape_out;
+int pw_shape_batch(pw_context *ctx, const pw_batch_in *in, pw_shape_out *out);
+/* circumcircle(coordinates, atom_sets) (utilities.py:1653-1691) for one molecule: n_sets triples of
+ * atom indices -> diameters (n_sets) and centres (n_sets x 3). */
+int pw_circumcircle(pw_context *ctx, const double *xyz, int64_t n_atoms, const int32_t *atom_sets,
+                    int64_t n_sets, double *diameter, double *centre);
+
 /* Native DL_POLY HISTORY ingest (trajectory.py:647-766): see pw_history_* in
  * pywindow_amd/csrc/pw_history.cpp */
 typedef struct pw_history pw_history;

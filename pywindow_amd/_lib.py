@@ -163,6 +163,19 @@ UNIT_OUT_DTYPE = np.dtype(
     align=True,
 )
 
+#: numpy mirror of ``pw_shape_out``
+SHAPE_OUT_DTYPE = np.dtype(
+    [
+        ("gyration", np.float64, (3, 3)),
+        ("inertia", np.float64, (3, 3)),
+        ("eigenvalues", np.float64, (3,)),
+        ("asphericity", np.float64),
+        ("acylidricity", np.float64),
+        ("relative_shape_anisotropy", np.float64),
+    ],
+    align=True,
+)
+
 #: every symbol include/pywindow_amd.h declares (checked by the CPU test-suite)
 EXPORTED_SYMBOLS = [
     "pw_device_count",
@@ -186,6 +199,8 @@ EXPORTED_SYMBOLS = [
     "pw_context_device",
     "pw_discrete_molecules",
     "pw_resident_from_cells",
+    "pw_shape_batch",
+    "pw_circumcircle",
     "pw_history_open",
     "pw_history_frames",
     "pw_history_atoms",
@@ -246,6 +261,8 @@ def load():
     L.pw_discrete_molecules.argtypes = [vp, ctypes.POINTER(CellIn), ctypes.POINTER(CellOut)]
     L.pw_resident_from_cells.argtypes = [vp, ctypes.POINTER(CellIn), vp, ctypes.c_int32, ctypes.c_int32,
                                          ctypes.POINTER(vp), vp, vp]
+    L.pw_shape_batch.argtypes = [vp, ctypes.POINTER(BatchIn), vp]
+    L.pw_circumcircle.argtypes = [vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, vp]
     L.pw_history_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
     L.pw_history_frames.argtypes = [vp]
     L.pw_history_frames.restype = ctypes.c_int64
@@ -355,6 +372,28 @@ class Context:
             "pw_point_gaps",
         )
         return gap, arg
+
+    def shape(self, batch: Batch) -> np.ndarray:
+        """``pw_shape_batch``: gyration / inertia tensors, sorted eigenvalues and the three shape
+        descriptors of every unit (``SHAPE_OUT_DTYPE`` records)."""
+        out = np.zeros(batch.n_units, dtype=SHAPE_OUT_DTYPE)
+        if batch.n_units:
+            _check(load().pw_shape_batch(self._h, ctypes.byref(batch.c), out.ctypes.data), "pw_shape_batch")
+        return out
+
+    def circumcircle(self, coordinates, atom_sets):
+        """``pw_circumcircle``: (diameters (K,), centres (K, 3)) for K atom triples of one molecule."""
+        xyz = np.ascontiguousarray(coordinates, dtype=np.float64).reshape(-1, 3)
+        sets = np.array(atom_sets, dtype=np.int32).reshape(-1, 3)
+        sets = np.ascontiguousarray(np.where((sets < 0) & (sets >= -len(xyz)), sets + len(xyz), sets))   # Python indexing
+        d = np.zeros(len(sets))
+        c = np.zeros((len(sets), 3))
+        rc = load().pw_circumcircle(self._h, xyz.ctypes.data, len(xyz), sets.ctypes.data, len(sets),
+                                    d.ctypes.data, c.ctypes.data)
+        if rc == -2 and len(sets) and ((sets < 0) | (sets >= len(xyz))).any():
+            raise IndexError("atom index out of range")      # what indexing the array raises in the reference
+        _check(rc, "pw_circumcircle")
+        return d, c
 
     def discrete_molecules(self, topology, coords, lattice, lattice_inv, rebuild: bool, atoms_cap=None):
         """``pw_discrete_molecules`` on F frames of one topology (see pywindow_amd/rebuild.py).

@@ -12,7 +12,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _lib, engine
-from .element_data import atomic_covalent_radius, atomic_mass, atomic_vdw_radius  # noqa: F401  (re-exported)
+from .element_data import MASS, VDW, atomic_covalent_radius, atomic_mass, atomic_vdw_radius, element_ids  # noqa: F401  (re-exported)
 from .rebuild import discrete_molecules, lattice_array_to_unit_cell, unit_cell_to_lattice_array  # noqa: F401
 
 
@@ -106,3 +106,57 @@ def find_windows(elements, coordinates, processes=None, adjust=1, pore_opt=True,
         raise ValueError("An upper bound is less than the corresponding lower bound.")
     engine.warn_like_reference(r)
     return engine.windows_of(r)
+
+
+# ---- shape descriptors and circumcircles (reference utilities.py:434-650, 1653-1691) ---------------
+def _shape(elements, coordinates):
+    ids = element_ids(elements)
+    xyz = np.ascontiguousarray(coordinates, dtype=np.float64)
+    batch = _lib.Batch(np.array([0, len(xyz)], dtype=np.int64), xyz, VDW[ids], MASS[ids])
+    return engine.context().shape(batch)[0]
+
+
+def get_gyration_tensor(elements, coordinates) -> np.ndarray:
+    """Reference utilities.py:461-495 (bit-identical)."""
+    return np.array(_shape(elements, coordinates)["gyration"])
+
+
+def get_inertia_tensor(elements, coordinates) -> np.ndarray:
+    """Reference utilities.py:498-529, including its (N, 1) x (N,) broadcast (bit-identical)."""
+    return np.array(_shape(elements, coordinates)["inertia"])
+
+
+def calc_asphericity(elements, coordinates) -> float:
+    """Reference utilities.py:626-632 (eigenvalues: Jacobi instead of LAPACK, a few ulps)."""
+    return float(_shape(elements, coordinates)["asphericity"])
+
+
+def calc_acylidricity(elements, coordinates) -> float:
+    """Reference utilities.py:635-641."""
+    return float(_shape(elements, coordinates)["acylidricity"])
+
+
+def calc_relative_shape_anisotropy(elements, coordinates) -> float:
+    """Reference utilities.py:644-650."""
+    return float(_shape(elements, coordinates)["relative_shape_anisotropy"])
+
+
+def inertia_eigenvalues(elements, coordinates) -> np.ndarray:
+    """``get_tensor_eigenvalues(get_inertia_tensor(...), sort=True)`` (utilities.py:449-458)."""
+    return np.array(_shape(elements, coordinates)["eigenvalues"])
+
+
+def circumcircle_window(coordinates, atom_set):
+    """Reference utilities.py:1653-1676: ``(radius, centre)`` of the circle through three atoms,
+    less a carbon van der Waals radius."""
+    d, c = engine.context().circumcircle(coordinates, [list(atom_set)[:3]])
+    return float(d[0]) / 2, c[0]
+
+
+def circumcircle(coordinates, atom_sets):
+    """Reference utilities.py:1679-1691: ``(diameters, centres)`` lists for atom triples."""
+    sets = [[int(i) for i in list(t)[:3]] for t in atom_sets]
+    if not sets:
+        return [], []
+    d, c = engine.context().circumcircle(coordinates, sets)
+    return [float(x) for x in d], [np.array(x) for x in c]

@@ -551,6 +551,44 @@ def run_winopt(pool):
     print("winopt:", names, [r[0].tolist() for r in res])
 
 
+def shape_unit(args):
+    """Shape descriptors and circumcircles of the reference (utilities.py:434-650, 1653-1691)."""
+    elements, coords, triples = args
+    load_reference()
+    from pywindow._internal import utilities as U
+
+    elements = np.array(elements)
+    coords = np.array(coords, float)
+    gyr = U.get_gyration_tensor(elements, coords)
+    ine = U.get_inertia_tensor(elements, coords)
+    eig = U.get_tensor_eigenvalues(ine, sort=True)
+    desc = np.array([U.calc_asphericity(elements, coords), U.calc_acylidricity(elements, coords),
+                     U.calc_relative_shape_anisotropy(elements, coords)])
+    d, c = U.circumcircle(coords, [list(t) for t in triples])
+    return gyr, ine, eig, desc, np.array(d), np.array(c)
+
+
+def run_shape(pool):
+    n, e, x = static_cases()
+    n2, e2, x2 = md20_cases()
+    names = list(n) + list(n2[:5])
+    els = [list(q) for q in e] + [list(q) for q in e2[:5]]
+    xyz = [np.array(q, float) for q in x] + [np.array(q, float) for q in x2[:5]]
+    rng = np.random.default_rng(5)
+    triples = [np.array([rng.choice(len(q), 3, replace=False) for _ in range(4)]) for q in els]
+    res = pool.map(shape_unit, list(zip(els, xyz, triples)))
+    off = np.concatenate([[0], np.cumsum([len(q) for q in els])])
+    np.savez_compressed(
+        HERE / "shape.npz",
+        names=np.array(names), atom_offset=off, elements=np.concatenate([np.array(q) for q in els]),
+        coordinates=np.concatenate(xyz), atom_sets=np.array(triples),
+        gyration=np.array([r[0] for r in res]), inertia=np.array([r[1] for r in res]),
+        eigenvalues=np.array([r[2] for r in res]), descriptors=np.array([r[3] for r in res]),
+        circum_d=np.array([r[4] for r in res]), circum_c=np.array([r[5] for r in res]),
+    )
+    print("shape:", np.array([r[3] for r in res])[:4])
+
+
 OPT_CASES = [  # (com offset or None, bounds offsets relative to the centre of mass or None)
     ((0.3, -0.2, 0.1), None),
     (None, ((-1.0, 1.0), (-1.0, None), (None, None))),
@@ -745,7 +783,7 @@ def run_ptraj(pool):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj", "optopt", "winopt"}
+    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj", "optopt", "winopt", "shape"}
     if "cc3base" in which:
         load_reference()
         import tests.test_validate_cc3 as C
@@ -781,6 +819,8 @@ def main():
             run_optopt(pool)
         if "winopt" in which:
             run_winopt(pool)
+        if "shape" in which:
+            run_shape(pool)
     meta = {
         "generator": "tests/golden/make_golden.py",
         "reference": "marcinmiklitz/pywindow @ /root/reference (imported with rdkit stub)",

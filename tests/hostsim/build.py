@@ -11,6 +11,7 @@ TARGETS = {
     "libmathprobe.so": "math_probe.cpp",
     "libunitprobe.so": "unit_probe.cpp",
     "librebuildprobe.so": "rebuild_probe.cpp",
+    "libshapeprobe.so": "shape_probe.cpp",
 }
 
 

@@ -1,0 +1,109 @@
+"""Shape descriptors and circumcircles (reference utilities.py:434-650,
+1653-1691).  Golden values come from the reference itself (tests/golden/make_golden.py shape).
+
+Bars: tensors, circumcircle diameters and centres bit-identical; eigenvalues (the reference:
+LAPACK dgeev, here: Jacobi) within EIG_TOL of the largest eigenvalue; descriptors accordingly."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from _util import GOLDEN, group_batch
+from pywindow_amd import _lib
+
+EIG_TOL = 1e-12      # relative to the largest |eigenvalue| of the tensor
+
+
+def load():
+    g = np.load(GOLDEN / "shape.npz")
+    return g, group_batch(g)
+
+
+def check(out, g, where):
+    for u in range(len(out)):
+        assert np.array_equal(out[u]["gyration"], g["gyration"][u]), f"{where} u{u}: gyration tensor"
+        assert np.array_equal(out[u]["inertia"], g["inertia"][u]), f"{where} u{u}: inertia tensor"
+        scale = np.max(np.abs(g["eigenvalues"][u]))
+        assert np.max(np.abs(out[u]["eigenvalues"] - g["eigenvalues"][u])) <= EIG_TOL * scale, f"{where} u{u}"
+        a, b, k = g["descriptors"][u]
+        assert abs(out[u]["asphericity"] - a) <= 2 * EIG_TOL * scale, f"{where} u{u}: asphericity"
+        assert abs(out[u]["acylidricity"] - b) <= 2 * EIG_TOL * scale, f"{where} u{u}: acylidricity"
+        assert abs(out[u]["relative_shape_anisotropy"] - k) <= 10 * EIG_TOL, f"{where} u{u}: anisotropy"
+
+
+def test_oracle_shape_matches_reference():
+    from oracle import pw_shape as S
+
+    g, (off, xyz, _, mass) = load()
+    for u in range(len(off) - 1):
+        x, m = xyz[off[u]:off[u + 1]], mass[off[u]:off[u + 1]]
+        inertia = S.inertia_tensor(x, m)
+        assert np.array_equal(S.gyration_tensor(x, m), g["gyration"][u])
+        assert np.array_equal(inertia, g["inertia"][u])
+        eig = S.sorted_eigenvalues(inertia)
+        assert np.array_equal(eig, g["eigenvalues"][u])
+        assert np.array_equal(S.descriptors(eig), g["descriptors"][u])
+        d, c = S.circumcircle(x, g["atom_sets"][u])
+        assert np.array_equal(d, g["circum_d"][u]) and np.array_equal(np.array(c), g["circum_c"][u])
+
+
+def test_host_team_shape_matches_reference(hostsim):
+    g, (off, xyz, _, mass) = load()
+    L = ctypes.CDLL(str(hostsim / "libshapeprobe.so"))
+    vp = ctypes.c_void_p
+    mass = np.ascontiguousarray(mass)
+    out = np.zeros(len(off) - 1, dtype=_lib.SHAPE_OUT_DTYPE)
+    assert L.hs_shape_batch(ctypes.c_long(len(out)), off.ctypes.data_as(vp), xyz.ctypes.data_as(vp),
+                            mass.ctypes.data_as(vp), out.ctypes.data_as(vp)) == 0
+    check(out, g, "hostsim")
+    for u in range(len(out)):
+        sets = np.ascontiguousarray(g["atom_sets"][u].astype(np.int32))
+        x = np.ascontiguousarray(xyz[off[u]:off[u + 1]])
+        d, c = np.zeros(len(sets)), np.zeros((len(sets), 3))
+        L.hs_circumcircle(x.ctypes.data_as(vp), sets.ctypes.data_as(vp), ctypes.c_long(len(sets)),
+                          d.ctypes.data_as(vp), c.ctypes.data_as(vp))
+        assert np.array_equal(d, g["circum_d"][u]) and np.array_equal(c, g["circum_c"][u]), u
+
+
+@pytest.mark.gpu
+def test_hip_shape_matches_reference(hip_ctx):
+    from pywindow_amd import utilities as U
+
+    g, (off, xyz, vdw, mass) = load()
+    out = hip_ctx.shape(_lib.Batch(off, xyz, vdw, mass))          # ragged batch, one launch
+    check(out, g, "hip")
+    for u in (0, 1, 5):
+        el, x = g["elements"][off[u]:off[u + 1]], g["coordinates"][off[u]:off[u + 1]]
+        assert np.array_equal(U.get_gyration_tensor(el, x), g["gyration"][u])
+        assert np.array_equal(U.get_inertia_tensor(el, x), g["inertia"][u])
+        assert U.calc_asphericity(el, x) == out[u]["asphericity"]
+        assert U.calc_acylidricity(el, x) == out[u]["acylidricity"]
+        assert U.calc_relative_shape_anisotropy(el, x) == out[u]["relative_shape_anisotropy"]
+        d, c = U.circumcircle(x, g["atom_sets"][u])
+        assert np.array_equal(d, g["circum_d"][u]) and np.array_equal(np.array(c), g["circum_c"][u])
+        r, c0 = U.circumcircle_window(x, g["atom_sets"][u][0])
+        assert 2 * r == g["circum_d"][u][0] and np.array_equal(c0, g["circum_c"][u][0])
+        # Python's negative indices address the same atoms
+        dn, _ = U.circumcircle(x, [g["atom_sets"][u][0] - len(x)])
+        assert dn[0] == g["circum_d"][u][0]
+    with pytest.raises(IndexError):
+        U.circumcircle(x, [[0, 1, len(x)]])
+    assert U.circumcircle(x, []) == ([], [])
+
+
+@pytest.mark.gpu
+def test_hip_shape_large_unit_matches_oracle(hip_ctx):
+    """A 1008-atom unit: the inertia sums run over a million terms (124 numpy buffers)."""
+    from oracle import pw_shape as S
+    from pywindow_amd import element_data as E
+    from pywindow_amd import synth
+
+    el, frames = synth.synthetic_units(6)
+    x = np.concatenate([frames[k] + np.array([30.0 * k, 0, 0]) for k in range(6)])
+    ids = E.element_ids(list(el) * 6)
+    out = hip_ctx.shape(_lib.Batch(np.array([0, len(x)]), x, E.VDW[ids], E.MASS[ids]))[0]
+    assert np.array_equal(out["gyration"], S.gyration_tensor(x, E.MASS[ids]))
+    inertia = S.inertia_tensor(x, E.MASS[ids])
+    assert np.array_equal(out["inertia"], inertia)
+    eig = S.sorted_eigenvalues(inertia)
+    assert np.max(np.abs(out["eigenvalues"] - eig)) <= EIG_TOL * np.max(np.abs(eig))
