@@ -52,6 +52,11 @@ struct UnitQueue {
 };
 enum : int { PW_ROLE_PLAIN = 0, PW_ROLE_PRODUCER = 1, PW_ROLE_CONSUMER = 2 };
 
+constexpr unsigned MASK_ANY = 0xffffffffu;
+constexpr unsigned MASK_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE;
+constexpr unsigned MASK_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
+constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
+
 // MASK: the stage bits this instantiation can execute (the run-time mask is ANDed with it), so
 // the launches of the pipeline carry only the code -- and the registers -- of their own stages
 template <int NW, unsigned MASK>
@@ -66,7 +71,7 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
     __shared__ long s_unit;
     using T = DeviceTeam<NW>;
     UnitShared sh;
-    sh.carve(lds, nmax, nrot, nlb);
+    sh.carve(lds, nmax, nrot, nlb, MASK == MASK_CHAINS ? 1 : 2);
     // the optimiser chains are latency-bound and on the critical path: when one shares a SIMD
     // with a bulk wave of another launch it must win the issue arbitration
     if (role == PW_ROLE_PRODUCER) {
@@ -275,14 +280,14 @@ struct LaunchPlan {
 // team width, LDS carve and grid for one launch.  want_nw: preferred waves per team;
 // rot/lb: whether window frames / optimiser states are needed (per wave).
 static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool rot, int lb_per_team,
-                       LaunchPlan* p) {
+                       LaunchPlan* p, int nframes = 2) {
     const size_t max_lds = 160 * 1024 - 256;
     int nw = want_nw;
     for (;;) {
         int nslot = nw < 4 ? nw : 4;
         int nrot = rot ? nslot : 0;
         int nlb = lb_per_team < 0 ? nslot : lb_per_team;
-        size_t lds = UnitShared::bytes(nmax, nrot, nlb) + 64;
+        size_t lds = UnitShared::bytes(nmax, nrot, nlb, nframes) + 64;
         if (lds <= max_lds || nw == 1) {
             if (lds > max_lds) {
                 snprintf(g_err, sizeof(g_err), "molecule with %d atoms does not fit in LDS", nmax);
@@ -303,11 +308,6 @@ static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool 
     p->grid = (int)grid;
     return PW_OK;
 }
-
-constexpr unsigned MASK_ANY = 0xffffffffu;
-constexpr unsigned MASK_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE;
-constexpr unsigned MASK_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
-constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 
 template <int NW, unsigned MASK>
 static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const LaunchPlan& p, hipStream_t st,
@@ -530,7 +530,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     //     A one-wave gate kernel ahead of C (and B) holds them back until every team of A is
     //     resident, so they can never take the LDS A needs -- no launch-order assumption.
     LaunchPlan pa, pb, pc;
-    rc = plan_launch(c, r->n_units, r->nmax, 1, false, 1, &pa);
+    rc = plan_launch(c, r->n_units, r->nmax, 1, false, 1, &pa, 1);   // chains: no shifted frame
     if (rc != PW_OK) return rc;
     pa.grid = (int)r->n_units < pa.grid ? (int)r->n_units : pa.grid;
     {
@@ -546,7 +546,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     bool do_avg = (stages & PW_STAGE_AVG) != 0;
     pb.grid = 0;
     if (do_avg) {
-        rc = plan_launch(c, r->n_units, r->nmax, 4, false, 3, &pb);   // 3 state slots = 32 KB of scratch
+        rc = plan_launch(c, r->n_units, r->nmax, 4, false, 2, &pb);   // 2 state slots = 20 KB of scratch
         if (rc != PW_OK) return rc;
     }
     rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pc);

@@ -111,6 +111,8 @@ struct UnitVars {
     // cross-wave reduction scratch
     double red_v[16];
     int red_i[16];
+    // ---- window search only: everything from here on is NOT allocated for the optimiser-chain
+    // launch (UnitShared::bytes with nframes == 1) ----
     // DBSCAN bitsets: core / unlabelled / frontier / next (PW_P_MAX bits each)
     unsigned long long bits[4][PW_P_MAX / 64];
     // sampling vector chosen for each cluster (largest 2*gap, first occurrence)
@@ -138,28 +140,31 @@ struct UnitShared {
     PW_LDS unsigned char* scratch;
     size_t scratch_bytes;
     // nrot = rotated window frames, nlb = optimiser states (both 0..nwaves)
-    PW_HD static size_t bytes(int nmax, int nrot, int nlb) {
+    // nframes = 1: no shifted frame (the optimiser-chain launch works on the input frame only)
+    PW_HD static size_t bytes(int nmax, int nrot, int nlb, int nframes = 2) {
         size_t n = (size_t)((nmax + 1) & ~1);
-        size_t b = sizeof(UnitVars);
+        size_t b = nframes > 1 ? sizeof(UnitVars) : offsetof(UnitVars, bits);
         b = (b + 15) & ~(size_t)15;
         b += n * 8 * 2;                       // vdw, mass
         b += n * 4 * 2;                       // perm, inv
-        b += n * 8 * 4 * (2 + (size_t)nrot);  // A, S, R[w]
+        b += n * 8 * 4 * ((size_t)nframes + (size_t)nrot);  // A, S, R[w]
         b += (size_t)nlb * ((sizeof(LbMem<3>) + 15) & ~(size_t)15);
         return b;
     }
-    PW_HD void carve(unsigned char* base, int nmax, int nrot, int nlb) {
+    PW_HD void carve(unsigned char* base, int nmax, int nrot, int nlb, int nframes = 2) {
         size_t n = (size_t)((nmax + 1) & ~1);
         PW_LDS unsigned char* p = (PW_LDS unsigned char*)base;
         v = (PW_LDS UnitVars*)p;
-        p += (sizeof(UnitVars) + 15) & ~(size_t)15;
+        p += ((nframes > 1 ? sizeof(UnitVars) : offsetof(UnitVars, bits)) + 15) & ~(size_t)15;
         ldouble* d = (ldouble*)p;
         vdw = d; d += n;
         mass = d; d += n;
         perm = (lint*)d; d += n / 2;
         inv = (lint*)d; d += n / 2;
         A.x = d; d += n; A.y = d; d += n; A.z = d; d += n; A.xx = d; d += n; A.vdw = vdw; A.perm = perm; A.cls = &v->cls;
-        S.x = d; d += n; S.y = d; d += n; S.z = d; d += n; S.xx = d; d += n; S.vdw = vdw; S.perm = perm; S.cls = &v->cls;
+        if (nframes > 1) { S.x = d; d += n; S.y = d; d += n; S.z = d; d += n; S.xx = d; d += n; }
+        else { S.x = S.y = S.z = S.xx = nullptr; }
+        S.vdw = vdw; S.perm = perm; S.cls = &v->cls;
         for (int w = 0; w < 8; ++w) { R[w].x = R[w].y = R[w].z = R[w].xx = nullptr; lb[w] = nullptr; }
         scratch = (PW_LDS unsigned char*)d;
         for (int w = 0; w < nrot; ++w) {
@@ -1350,7 +1355,11 @@ PW_HD inline __attribute__((always_inline)) void stage_average_impl(UnitShared& 
     unsigned char* flag = (unsigned char*)arena.take((size_t)P);
     if (!flag) flag = ws->flag;
     int* s_tab = (int*)arena.take(324 * 4);
-    double* s_acc = (double*)arena.take(8 * 160 * 8);
+    // np_sum_team: eight accumulators per 64-element slot of (at most) P values, and never less
+    // than the 128 words its tree walk borrows
+    size_t acc_words = 8 * (size_t)(((P < 8192 ? P : 8192) + 63) / 64);
+    if (acc_words < 128) acc_words = 128;
+    double* s_acc = (double*)arena.take(acc_words * 8);
     double* s_leaf = (double*)arena.take(256 * 8);
     if (!s_tab || !s_acc || !s_leaf) { s_tab = ws->leaf_tab; s_acc = ws->acc8; s_leaf = ws->leaf; }
     double cen[3] = {v.centroid[0], v.centroid[1], v.centroid[2]};
