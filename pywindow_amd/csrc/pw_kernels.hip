@@ -546,7 +546,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     bool do_avg = (stages & PW_STAGE_AVG) != 0;
     pb.grid = 0;
     if (do_avg) {
-        rc = plan_launch(c, r->n_units, r->nmax, 4, false, 2, &pb);   // 2 state slots = 20 KB of scratch
+        rc = plan_launch(c, r->n_units, r->nmax, 4, false, 3, &pb);   // 3 state slots = 21 KB of scratch
         if (rc != PW_OK) return rc;
     }
     rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pc);

@@ -71,7 +71,10 @@ struct LbMem {
     double x[N], g[N];
     double ws[M * N], wy[M * N];
     double sy[M * M], ss[M * M], wt[M * M];
-    double wn[M2 * M2], wn1[M2 * M2];
+    // WN (the factorised middle matrix) only ever uses its upper triangle and WN1 (the running
+    // inner products it is rebuilt from) only its lower one: they share one 2m x 2m array; the
+    // diagonal of WN1 lives in wn1d
+    double wn[M2 * M2], wn1d[M2];
     double z[N], r[N], d[N], t[N], xp[N];
     double wa[8 * M];
     double acc[2 * M];  // running dot products of the systolic triangular solves
@@ -156,7 +159,7 @@ struct Lbfgsb {
     // ---- limited-memory matrices ----
     double *ws, *wy;
     double *sy, *ss, *wt;
-    double *wn, *wn1;
+    double *wn, *wn1d;
     double *z, *r, *d, *t, *xp;
     double* wa;
     double* acc;
@@ -178,7 +181,7 @@ struct Lbfgsb {
     PW_HD void bind(LbMem<N>* m) {
         mem = m;
         l = m->l; u = m->u; nbd = m->nbd; x = m->x; g = m->g;
-        ws = m->ws; wy = m->wy; sy = m->sy; ss = m->ss; wt = m->wt; wn = m->wn; wn1 = m->wn1;
+        ws = m->ws; wy = m->wy; sy = m->sy; ss = m->ss; wt = m->wt; wn = m->wn; wn1d = m->wn1d;
         z = m->z; r = m->r; d = m->d; t = m->t; xp = m->xp; wa = m->wa; acc = m->acc;
         index = m->index; iwhere = m->iwhere; indx2 = m->indx2;
     }
@@ -206,7 +209,7 @@ struct Lbfgsb {
     PW_HD double& SS(int i, int j) { return ss[i + M * j]; }
     PW_HD double& WT(int i, int j) { return wt[i + M * j]; }
     PW_HD double& WN(int i, int j) { return wn[i + M2 * j]; }
-    PW_HD double& WN1(int i, int j) { return wn1[i + M2 * j]; }
+    PW_HD double& WN1(int i, int j) { return i == j ? wn1d[i] : wn[i + M2 * j]; }   // i >= j only
     PW_HD double* WS(int j) { return ws + j * N; }
     PW_HD double* WY(int j) { return wy + j * N; }
 
@@ -656,28 +659,44 @@ struct Lbfgsb {
         if (updatd) {
             if (iupdat > M) {
                 // shift the old part of WN1 up-left by one: every target reads a cell of the
-                // next column, so the whole shift is "read all, then write all"
-                for (int pass = 0; pass < 2; ++pass) {
-                    // block (1,1) and (2,2): element (r, jy) <- (r+1, jy+1), r = jy..M-2
-                    // block (2,1): element (M+r, jy) <- (M+r+1, jy+1), r = 0..M-2
-                    // values staged through the (unused here) snd-sized scratch: wn
-                    for (int e = T::lane(); e < (M - 1) * (M - 1); e += T::WSIZE) {
-                        int jy = e / (M - 1), r = e % (M - 1);
-                        if (pass == 0) {
-                            if (r >= jy) {
-                                WN(r, jy) = WN1(r + 1, jy + 1);
-                                WN(M + r, M + jy) = WN1(M + r + 1, M + jy + 1);
-                            }
-                            WN(M + r, jy) = WN1(M + r + 1, jy + 1);
-                        } else {
-                            if (r >= jy) {
-                                WN1(r, jy) = WN(r, jy);
-                                WN1(M + r, M + jy) = WN(M + r, M + jy);
-                            }
-                            WN1(M + r, jy) = WN(M + r, jy);
+                // next column, so the whole shift is "read all, then write all" -- staged in
+                // registers (two cells of each block per lane)
+                // block (1,1) and (2,2): element (r, jy) <- (r+1, jy+1), r = jy..M-2
+                // block (2,1): element (M+r, jy) <- (M+r+1, jy+1), r = 0..M-2
+                constexpr int CELLS = (M - 1) * (M - 1);
+                constexpr int PER = (CELLS + T::WSIZE - 1) / T::WSIZE;
+                if (PER <= 2) {
+                    double s11[2] = {0.0, 0.0}, s22[2] = {0.0, 0.0}, s21[2] = {0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        int e = T::lane() + q * T::WSIZE;
+                        if (e < CELLS) {
+                            int jy = e / (M - 1), r = e % (M - 1);
+                            if (r >= jy) { s11[q] = WN1(r + 1, jy + 1); s22[q] = WN1(M + r + 1, M + jy + 1); }
+                            s21[q] = WN1(M + r + 1, jy + 1);
                         }
                     }
                     T::wave_sync();
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        int e = T::lane() + q * T::WSIZE;
+                        if (e < CELLS) {
+                            int jy = e / (M - 1), r = e % (M - 1);
+                            if (r >= jy) { WN1(r, jy) = s11[q]; WN1(M + r, M + jy) = s22[q]; }
+                            WN1(M + r, jy) = s21[q];
+                        }
+                    }
+                    T::wave_sync();
+                } else {
+                    // one-thread team: in place, in an order that never overwrites a pending source
+                    // (targets ascend column by column, sources lie one column to the right)
+                    for (int jy = 0; jy < M - 1; ++jy) {
+                        for (int r = jy; r < M - 1; ++r) {
+                            WN1(r, jy) = WN1(r + 1, jy + 1);
+                            WN1(M + r, M + jy) = WN1(M + r + 1, M + jy + 1);
+                        }
+                        for (int r = 0; r < M - 1; ++r) WN1(M + r, jy) = WN1(M + r + 1, jy + 1);
+                    }
                 }
             }
             int ipntr = head + col - 1;

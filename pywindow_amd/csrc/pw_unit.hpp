@@ -1800,15 +1800,15 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     if (!pts) pts = ws->pts;
     double* vals = (double*)arena.take((size_t)P * 8);
     if (!vals) vals = ws->vals;
-    double* tmpv = (double*)arena.take((size_t)P * 8);
-    if (!tmpv) tmpv = ws->knn;            // free again once eps is known
     int* surv_k = (int*)arena.take((size_t)P * 4);
     if (!surv_k) surv_k = ws->surv_k;
     int* labels = (int*)arena.take((size_t)P * 4);
     if (!labels) labels = ws->labels;
     unsigned char* flag = (unsigned char*)arena.take((size_t)P);
     if (!flag) flag = ws->flag;
-    ScratchArena arena_mark = arena;      // everything taken below is temporary
+    // everything taken below is temporary: the scratch of the k-NN mean, then the path-scan values
+    // of the sampling stage, then the adjacency rows of DBSCAN occupy the same bytes in turn
+    ScratchArena arena_mark = arena;
     for (int k = T::tid(); k < P; k += T::SIZE)
         sp.point(k, &pts[3 * k], &pts[3 * k + 1], &pts[3 * k + 2]);
     T::sync();
@@ -1895,6 +1895,9 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     }
     if (T::wave() == 0) PW_T1(ws, 8, t_eps);
     PW_T0(t_smp);
+    arena = arena_mark;
+    double* tmpv = (double*)arena.take((size_t)P * 8);
+    if (!tmpv) tmpv = ws->knn;            // (the k-NN rows are not needed once eps is known)
     // ---- sampling vectors (utilities.py:1457-1467): ray pre-analysis for every vector,
     //      then the coarse path scan for the vectors that hit nothing.  Two dense phases
     //      with an order-preserving compaction in between, so no lane idles while its
@@ -2020,6 +2023,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         return;
     }
     PW_T0(t_db);
+    arena = arena_mark;                   // tmpv is dead: its values were compacted into vals
     // ---- DBSCAN(eps, min_samples = 5) on the survivors' end points -----------------------
     // sklearn labels (sklearn/cluster/_dbscan_inner.pyx): core points = connected components
     // of the eps-graph numbered by their smallest member index; a border point takes the

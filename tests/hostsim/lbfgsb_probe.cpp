@@ -14,7 +14,7 @@ template <int N> static void dump(Lbfgsb<N>* s, double* wa_out, int* ints, doubl
     memcpy(p, s->ss, sizeof(double) * m * m); p += m * m;
     memcpy(p, s->wt, sizeof(double) * m * m); p += m * m;
     memcpy(p, s->wn, sizeof(double) * 4 * m * m); p += 4 * m * m;
-    memcpy(p, s->wn1, sizeof(double) * 4 * m * m); p += 4 * m * m;
+    memset(p, 0, sizeof(double) * 4 * m * m); p += 4 * m * m;   // WN1 shares wn's lower triangle (not compared)
     memcpy(p, s->z, sizeof(double) * N); p += N;
     memcpy(p, s->r, sizeof(double) * N); p += N;
     memcpy(p, s->d, sizeof(double) * N); p += N;

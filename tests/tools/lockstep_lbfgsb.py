@@ -75,8 +75,8 @@ def lockstep(fun, x0, lb, ub, nbd, verbose=False, maxcalls=5000):
             if k in ("snd", "wa", "xp", "t"): continue
             sa = wa[a:b]; sb = mwa[a:b]
             if k == "wn":
-                # only the upper triangle (column-major) is ever read; pw::Lbfgsb uses the
-                # strict lower triangle as staging space when it shifts WN1
+                # only the upper triangle (column-major) is ever read; pw::Lbfgsb keeps WN1 in the
+                # strict lower triangle of the same array
                 keep = np.tril(np.ones((2 * M, 2 * M), bool)).ravel()
                 sa = np.where(keep, sa, 0.0); sb = np.where(keep, sb, 0.0)
             if not np.array_equal(sa, sb):
