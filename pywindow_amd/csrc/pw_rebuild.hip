@@ -26,11 +26,13 @@ constexpr int RB_WAVES = 4;
 
 __global__ void __launch_bounds__(RB_WAVES * 64)
 pw_rebuild_kernel(pw_cell_in in, pw_cell_out out, unsigned char* __restrict__ slabs, size_t slab_bytes,
-                  unsigned long long* counter) {
+                  unsigned long long* counter, int with_bits) {
     using T = DeviceTeam<RB_WAVES>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fast[];   // RebuildWs::fast_bytes
     __shared__ long s_frame;
     const int n = in.n_atoms;
     RebuildWs* w = RebuildWs::carve(slabs + (size_t)blockIdx.x * slab_bytes, n, in.rebuild, T::SIZE);
+    w->attach_fast(fast, n, in.rebuild, with_bits != 0);
     __syncthreads();
     for (;;) {
         if (threadIdx.x == 0) {
@@ -163,8 +165,12 @@ int rebuild_on_device(pw_context* ctx, const pw_cell_in* in, int atoms_cap, int 
     d_out.atoms_cap = atoms_cap; d_out.mols_cap = mols_cap;
     d_out.n_mol = dev->n_mol; d_out.status = dev->status; d_out.mol_offset = dev->off;
     d_out.src_atom = dev->src; d_out.src_image = (int8_t*)dev->img; d_out.xyz = dev->oxyz;
-    hipLaunchKernelGGL(pw_rebuild_kernel, dim3((unsigned)grid), dim3(RB_WAVES * 64), 0, st, d_in, d_out,
-                       d_slabs, slab, d_counter);
+    // team-shared memory: the hit segments, and the two visit bit sets when they fit beside them
+    int with_bits = RebuildWs::fast_bytes(n, in->rebuild, true) <= 96 * 1024 ? 1 : 0;
+    size_t lds = RebuildWs::fast_bytes(n, in->rebuild, with_bits != 0);
+    RB_TRY(hipFuncSetAttribute((const void*)pw_rebuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(pw_rebuild_kernel, dim3((unsigned)grid), dim3(RB_WAVES * 64), lds, st, d_in, d_out,
+                       d_slabs, slab, d_counter, with_bits);
     RB_TRY(hipGetLastError());
     return PW_OK;
 }

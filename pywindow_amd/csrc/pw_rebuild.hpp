@@ -33,7 +33,7 @@ namespace pw {
 
 constexpr int RB_NB_CAP = 32;      // conservative neighbour candidates kept per heavy atom
 constexpr int RB_SEG_CAP = 32;     // bonded neighbours one atom can contribute per layer
-constexpr int RB_CHUNK = 256;      // atoms of a layer expanded between two merges
+constexpr int RB_CHUNK = 64;       // atoms of a layer expanded between two merges
 constexpr int RB_CENTRAL = 13;     // image (0,0,0) in the a,b,c-nested 3x3x3 enumeration
 
 // status bits of one frame (pw_cell_out.status)
@@ -53,6 +53,13 @@ PW_HD inline int rb_atomic_add(int* p, int v) {
 #endif
 }
 PW_HD inline void rb_atomic_or(int* p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicOr(p, v);
+#else
+    *p |= v;
+#endif
+}
+PW_HD inline void rb_atomic_or64(unsigned long long* p, unsigned long long v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicOr(p, v);
 #else
@@ -92,13 +99,20 @@ PW_HD inline double rb_dist_sk(const double* x, double xx, double px, double py,
     return pw_sqrt(d2 > 0.0 ? d2 : 0.0);
 }
 
+// scalars and small arrays every phase of the walk passes through: team-shared memory
+struct RebuildShared {
+    double red_v[8];
+    double com[3], origin[3], bound[2];
+    double box[27 * 6];
+    int red_i[8];
+    int n_work, n_next, n_final, start;
+};
+
 struct RebuildWs {
     double* V;            // n x 3   value coordinates of the cell atoms
     double* Vxx;          // n
     double* S;            // 27n x 3 value coordinates of the supercell atoms (rebuild only)
     double* msum;         // 28n     masses of the molecule being closed (numpy pairwise sum)
-    double* red_v;        // team size: reduction slots
-    int* red_i;           // team size
     int* nb_cnt;          // n
     int* nb;              // n x RB_NB_CAP: image * n + atom
     int* stamp_final;     // ids: molecule serial
@@ -106,21 +120,44 @@ struct RebuildWs {
     int* work;            // ids
     int* work_next;       // ids
     int* final_;          // ids
+    // ---- team-shared fast memory (LDS on the device), attach_fast() ----
     int* seg_cnt;         // RB_CHUNK
     long long* seg;       // RB_CHUNK x RB_SEG_CAP: position key << 32 | canonical id
+    double* terms;        // 4 x term_cap: x, y, z moments and masses of a molecule being closed (same bytes as seg)
+    unsigned long long* bits_final;   // ids bits: "in the current molecule"; null -> stamp_final is used
+    unsigned long long* bits_temp;    // ids bits: "seen in the current layer"; null -> stamp_temp is used
+    RebuildShared* sh;
+    int term_cap, bit_words;
     unsigned char* remaining;   // n
     unsigned char* alias;       // n
-    double box[27 * 6];
-    double com[3], origin[3], bound[2];
-    int n_work, n_next, n_final, start, status, n_mol, n_out;
+    int status, n_mol, n_out;
 
     PW_HD static size_t ids(int n, int rebuild) { return rebuild ? (size_t)28 * n : (size_t)n; }
     PW_HD static size_t bytes(int n, int rebuild, int team) {
         size_t id = ids(n, rebuild);
-        size_t d = (size_t)3 * n + n + (rebuild ? (size_t)81 * n : 0) + id + team;
-        size_t i = (size_t)team + n + (size_t)n * RB_NB_CAP + 5 * id + RB_CHUNK;
-        size_t l = (size_t)RB_CHUNK * RB_SEG_CAP;
-        return sizeof(RebuildWs) + 64 + d * 8 + l * 8 + i * 4 + 2 * (size_t)n + 64;
+        (void)team;
+        size_t d = (size_t)3 * n + n + (rebuild ? (size_t)81 * n : 0) + id;
+        size_t i = (size_t)n + (size_t)n * RB_NB_CAP + 5 * id;
+        return sizeof(RebuildWs) + 64 + d * 8 + i * 4 + 2 * (size_t)n + 64;
+    }
+    // fast memory: the hit segments always, the two bit sets when `with_bits`
+    PW_HD static size_t fast_bytes(int n, int rebuild, bool with_bits) {
+        size_t words = (ids(n, rebuild) + 63) / 64;
+        return (size_t)RB_CHUNK * RB_SEG_CAP * 8 + (size_t)RB_CHUNK * 4 + (with_bits ? 2 * words * 8 : 0) +
+               ((sizeof(RebuildShared) + 15) & ~(size_t)15);
+    }
+    PW_HD void attach_fast(unsigned char* base, int n, int rebuild, bool with_bits) {
+        sh = (RebuildShared*)base;
+        base += (sizeof(RebuildShared) + 15) & ~(size_t)15;
+        seg = (long long*)base;
+        terms = (double*)base;
+        term_cap = RB_CHUNK * RB_SEG_CAP / 4;
+        base += (size_t)RB_CHUNK * RB_SEG_CAP * 8;
+        bit_words = (int)((ids(n, rebuild) + 63) / 64);
+        bits_final = with_bits ? (unsigned long long*)base : nullptr;
+        bits_temp = with_bits ? (unsigned long long*)base + bit_words : nullptr;
+        base += with_bits ? 2 * (size_t)bit_words * 8 : 0;
+        seg_cnt = (int*)base;
     }
     // `base` -> [RebuildWs header][arrays]; returns the header
     PW_HD static RebuildWs* carve(unsigned char* base, int n, int rebuild, int team) {
@@ -131,9 +168,6 @@ struct RebuildWs {
         w->Vxx = (double*)p; p += (size_t)n * 8;
         w->S = (double*)p; p += rebuild ? (size_t)81 * n * 8 : 0;
         w->msum = (double*)p; p += id * 8;
-        w->red_v = (double*)p; p += (size_t)team * 8;
-        w->seg = (long long*)p; p += (size_t)RB_CHUNK * RB_SEG_CAP * 8;
-        w->red_i = (int*)p; p += (size_t)team * 4;
         w->nb_cnt = (int*)p; p += (size_t)n * 4;
         w->nb = (int*)p; p += (size_t)n * RB_NB_CAP * 4;
         w->stamp_final = (int*)p; p += id * 4;
@@ -141,7 +175,6 @@ struct RebuildWs {
         w->work = (int*)p; p += id * 4;
         w->work_next = (int*)p; p += id * 4;
         w->final_ = (int*)p; p += id * 4;
-        w->seg_cnt = (int*)p; p += (size_t)RB_CHUNK * 4;
         w->remaining = p; p += n;
         w->alias = p; p += n;
         return w;
@@ -187,8 +220,10 @@ PW_HD inline void rb_decode(const RebuildWs& w, int n, int id, int* q, int* ax, 
 
 // one wave expands one atom of the current layer: lanes over its candidate list
 template <class T>
-PW_HD inline void rb_expand(const RebuildFrame& fr, RebuildWs& w, int id, int slot) {
+PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, int* status, int id, int slot) {
     const int n = fr.n;
+    PW_ASSUME_LDS(w.seg);
+    PW_ASSUME_LDS(w.seg_cnt);
     int q0, ax, ay, az;
     const double* P;
     rb_decode(w, n, id, &q0, &ax, &ay, &az, &P);
@@ -234,13 +269,36 @@ PW_HD inline void rb_expand(const RebuildFrame& fr, RebuildWs& w, int id, int sl
             if (!(lo < r && r < hi)) continue;
             int k = rb_atomic_add(&w.seg_cnt[slot], 1);
             if (k < RB_SEG_CAP) w.seg[(size_t)slot * RB_SEG_CAP + k] = key;
-            else rb_atomic_or(&w.status, RB_ST_SEG_OVERFLOW);
+            else rb_atomic_or(status, RB_ST_SEG_OVERFLOW);
         }
     }
 }
 
+// -DPW_RB_PROFILE: team 0 prints the wall time of its phases per frame (tests/tools/rebuild_profile.py)
+#if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define RB_TICK(k) do { if (T::tid() == 0) { long long t_ = wall_clock64(); rb_prof[k] += t_ - rb_last; rb_last = t_; } } while (0)
+#else
+#define RB_TICK(k) do { } while (0)
+#endif
 template <class T>
 PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const RebuildOut& out) {
+#if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    long long rb_prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long rb_last = wall_clock64();
+    int rb_layers = 0, rb_mols = 0, rb_rounds = 0, rb_heavy = 0, rb_imgs = 0;
+#endif
+    // the array pointers of the workspace header, copied once: the header itself lives in global
+    // memory, and reading a pointer through it costs a dependent load after every store
+    const RebuildWs WS = w;
+    // team-shared arrays through address-space-qualified pointers (ds_read / ds_write, not flat)
+    PW_LDS RebuildShared& sh = *(PW_LDS RebuildShared*)WS.sh;
+    PW_LDS long long* const seg = (PW_LDS long long*)WS.seg;
+    PW_LDS int* const seg_cnt = (PW_LDS int*)WS.seg_cnt;
+    PW_LDS double* const terms = (PW_LDS double*)WS.terms;
+    PW_LDS unsigned long long* const bits_final = (PW_LDS unsigned long long*)WS.bits_final;
+    PW_LDS unsigned long long* const bits_temp = (PW_LDS unsigned long long*)WS.bits_temp;
+    int* work = WS.work;
+    int* work_next = WS.work_next;
     const int n = fr.n;
     const int n_ids = (int)RebuildWs::ids(n, fr.rebuild);
     const int tid = T::tid();
@@ -251,13 +309,18 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
     // ---- value coordinates ------------------------------------------------------------
     for (int i = tid; i < n; i += T::SIZE) {
         double x = rb_round8(fr.xyz[3 * i]), y = rb_round8(fr.xyz[3 * i + 1]), z = rb_round8(fr.xyz[3 * i + 2]);
-        w.V[3 * i] = x; w.V[3 * i + 1] = y; w.V[3 * i + 2] = z;
-        w.Vxx[i] = sq3(x, y, z);
-        w.remaining[i] = 1;
-        w.alias[i] = 0;
-        w.nb_cnt[i] = 0;
+        WS.V[3 * i] = x; WS.V[3 * i + 1] = y; WS.V[3 * i + 2] = z;
+        WS.Vxx[i] = sq3(x, y, z);
+        WS.remaining[i] = 1;
+        WS.alias[i] = 0;
+        WS.nb_cnt[i] = 0;
     }
-    for (int i = tid; i < n_ids; i += T::SIZE) { w.stamp_final[i] = 0; w.stamp_temp[i] = 0; }
+    const bool use_bits = WS.bits_final != nullptr;
+    if (use_bits) {
+        for (int i = tid; i < WS.bit_words; i += T::SIZE) { bits_final[i] = 0; bits_temp[i] = 0; }
+    } else {
+        for (int i = tid; i < n_ids; i += T::SIZE) { WS.stamp_final[i] = 0; WS.stamp_temp[i] = 0; }
+    }
     if (fr.rebuild) {
         // create_supercell: frac = M^-1 x; images a, b, c nested; cart = M (frac + shift)
         for (int i = tid; i < n; i += T::SIZE) {
@@ -268,149 +331,203 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                 double c[3];
                 rb_mat3(fr.lattice, fq[0] + sa, fq[1] + sb, fq[2] + sc, c);
                 size_t s = (size_t)img * n + i;
-                w.S[3 * s] = rb_round8(c[0]); w.S[3 * s + 1] = rb_round8(c[1]); w.S[3 * s + 2] = rb_round8(c[2]);
+                WS.S[3 * s] = rb_round8(c[0]); WS.S[3 * s + 1] = rb_round8(c[1]); WS.S[3 * s + 2] = rb_round8(c[2]);
             }
             size_t s0 = (size_t)RB_CENTRAL * n + i;
-            w.alias[i] = (w.S[3 * s0] == w.V[3 * i] && w.S[3 * s0 + 1] == w.V[3 * i + 1] &&
-                          w.S[3 * s0 + 2] == w.V[3 * i + 2]) ? 1 : 0;
+            WS.alias[i] = (WS.S[3 * s0] == WS.V[3 * i] && WS.S[3 * s0 + 1] == WS.V[3 * i + 1] &&
+                          WS.S[3 * s0 + 2] == WS.V[3 * i + 2]) ? 1 : 0;
         }
     }
     T::sync();
+    RB_TICK(0);
     // ---- system centre of mass (utilities.py:127-148 on the unrounded input) -----------
     constexpr int SUM_THREAD = T::SIZE > 3 ? 3 : 0;
-    for (int col = tid; col < 3; col += T::SIZE) {
-        double acc = 0.0;
-        for (int r = 0; r < n; ++r) {
-            double t = fr.xyz[3 * r + col] * fr.mass[r];
-            acc = r == 0 ? t : acc + t;
-        }
-        w.com[col] = acc;
-    }
-    if (tid == SUM_THREAD) w.red_v[0] = np_sum_serial(fr.mass, n);
+    for (int col = tid; col < 3; col += T::SIZE)
+        sh.com[col] = seq_sum_blocked(n, [&](int r) { return fr.xyz[3 * r + col] * fr.mass[r]; });
+    if (tid == SUM_THREAD) sh.red_v[0] = np_sum_serial(fr.mass, n);
     if (fr.rebuild) {
-        // bounding box of every image (candidate culling only)
-        for (int img = tid; img < 27; img += T::SIZE) {
+        // bounding box of every image (candidate culling only; min / max are exact in any order):
+        // one wave per image, lanes over the atoms
+        for (int img = T::wave(); img < 27; img += T::NWAVES) {
             double lo[3] = {PW_INF, PW_INF, PW_INF}, hi[3] = {-PW_INF, -PW_INF, -PW_INF};
-            for (int i = 0; i < n; ++i)
+            for (int i = T::lane(); i < n; i += T::WSIZE)
                 for (int c = 0; c < 3; ++c) {
-                    double v = w.S[3 * ((size_t)img * n + i) + c];
+                    double v = WS.S[3 * ((size_t)img * n + i) + c];
                     lo[c] = pw_min(lo[c], v); hi[c] = pw_max(hi[c], v);
                 }
-            for (int c = 0; c < 3; ++c) { w.box[6 * img + c] = lo[c]; w.box[6 * img + 3 + c] = hi[c]; }
+            for (int c = 0; c < 3; ++c) {
+                double l = T::wave_min(lo[c]), h = -T::wave_min(-hi[c]);
+                if (T::lane() == 0) { sh.box[6 * img + c] = l; sh.box[6 * img + 3 + c] = h; }
+            }
         }
     }
     T::sync();
     if (tid == 0) {
-        double total = w.red_v[0];
-        for (int c = 0; c < 3; ++c) w.com[c] = w.com[c] / total;
+        double total = sh.red_v[0];
+        for (int c = 0; c < 3; ++c) sh.com[c] = sh.com[c] / total;
         if (fr.periodic) {
             // origin skewed by 0.01 along x; pseudo origin at fractional (0.26, 0.25, 0.25)
             // (utilities.py:889-899); <-0.5, 0.5> cell when the system COM is at the origin
-            rb_mat3(fr.lattice, 0.26, 0.25, 0.25, w.origin);
-            bool centred = pw_abs(w.com[0] - 0.01) <= 1.0 + 1e-5 * 0.01 && pw_abs(w.com[1]) <= 1.0 &&
-                           pw_abs(w.com[2]) <= 1.0;
-            w.bound[0] = centred ? -0.5 : 0.0;
-            w.bound[1] = centred ? 0.5 : 1.0;
+            rb_mat3(fr.lattice, 0.26, 0.25, 0.25, (double*)sh.origin);
+            bool centred = pw_abs(sh.com[0] - 0.01) <= 1.0 + 1e-5 * 0.01 && pw_abs(sh.com[1]) <= 1.0 &&
+                           pw_abs(sh.com[2]) <= 1.0;
+            sh.bound[0] = centred ? -0.5 : 0.0;
+            sh.bound[1] = centred ? 0.5 : 1.0;
             // candidate lists assume a bond never spans two images
             double h[3];
             for (int c = 0; c < 3; ++c) h[c] = pw_abs(fr.lattice[3 * c + c]);
             if (fr.rebuild && (h[0] < fr.max_dist || h[1] < fr.max_dist || h[2] < fr.max_dist))
                 w.status |= RB_ST_THIN_CELL;
         } else {
-            w.origin[0] = w.com[0] + 0.01; w.origin[1] = w.com[1] + 0.0; w.origin[2] = w.com[2] + 0.0;
+            sh.origin[0] = sh.com[0] + 0.01; sh.origin[1] = sh.com[1] + 0.0; sh.origin[2] = sh.com[2] + 0.0;
         }
     }
+    RB_TICK(1);
     // ---- conservative candidate lists around every heavy atom ----------------------------
     {
         const double reach = fr.max_dist + 1e-3;
         const double reach2 = reach * reach;
-        for (int p = tid; p < n; p += T::SIZE) {
+        // one wave per heavy atom, lanes over the atoms of an image (coalesced reads); the hits of a
+        // pass keep their (image, atom) order through a ballot prefix
+        // lane i < 27 keeps the (widened) box of image i: one comparison pass per atom gives the
+        // set of images worth scanning
+        double bx0 = 0.0, bx1 = 0.0, by0 = 0.0, by1 = 0.0, bz0 = 0.0, bz1 = 0.0;
+        if (fr.rebuild && T::WSIZE >= 32 && T::lane() < 27) {
+            const PW_LDS double* b = &sh.box[6 * T::lane()];
+            bx0 = b[0] - reach; by0 = b[1] - reach; bz0 = b[2] - reach;
+            bx1 = b[3] + reach; by1 = b[4] + reach; bz1 = b[5] + reach;
+        }
+        for (int p = T::wave(); p < n; p += T::NWAVES) {
             if (fr.terminal[p]) continue;
-            const double* C = fr.rebuild ? &w.S[3 * ((size_t)RB_CENTRAL * n + p)] : &w.V[3 * p];
+            const double* C = fr.rebuild ? &WS.S[3 * ((size_t)RB_CENTRAL * n + p)] : &WS.V[3 * p];
             double cx = C[0], cy = C[1], cz = C[2];
             int cnt = 0;
-            for (int img = fr.rebuild ? 0 : RB_CENTRAL; img < (fr.rebuild ? 27 : RB_CENTRAL + 1); ++img) {
-                const double* X;
-                if (fr.rebuild) {
-                    const double* b = &w.box[6 * img];
-                    if (cx < b[0] - reach || cx > b[3] + reach || cy < b[1] - reach || cy > b[4] + reach ||
-                        cz < b[2] - reach || cz > b[5] + reach)
-                        continue;
-                    X = &w.S[3 * (size_t)img * n];
+            unsigned long long images = 1ull << RB_CENTRAL;
+            if (fr.rebuild) {
+                if (T::WSIZE >= 32) {
+                    images = T::ballot(T::lane() < 27 && !(cx < bx0 || cx > bx1 || cy < by0 || cy > by1 ||
+                                                            cz < bz0 || cz > bz1));
                 } else {
-                    X = w.V;
-                }
-                for (int q = 0; q < n; ++q) {
-                    double dx = X[3 * q] - cx, dy = X[3 * q + 1] - cy, dz = X[3 * q + 2] - cz;
-                    double d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 < reach2 && !(img == RB_CENTRAL && q == p)) {
-                        if (cnt < RB_NB_CAP) w.nb[(size_t)p * RB_NB_CAP + cnt] = img * n + q;
-                        ++cnt;
+                    images = 0;
+                    for (int img = 0; img < 27; ++img) {
+                        const PW_LDS double* b = &sh.box[6 * img];
+                        if (!(cx < b[0] - reach || cx > b[3] + reach || cy < b[1] - reach || cy > b[4] + reach ||
+                              cz < b[2] - reach || cz > b[5] + reach))
+                            images |= 1ull << img;
                     }
                 }
             }
-            w.nb_cnt[p] = cnt;
-            if (cnt > RB_NB_CAP) rb_atomic_or(&w.status, RB_ST_NB_OVERFLOW);
+            for (; images; images &= images - 1) {        // ascending image order
+                const int img = __builtin_ctzll(images);
+                const double* X = fr.rebuild ? &WS.S[3 * (size_t)img * n] : WS.V;
+                constexpr int UN = 8;        // blocks of candidates whose loads are in flight together
+#if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+                ++rb_imgs;
+#endif
+                for (int q0 = 0; q0 < n; q0 += UN * T::WSIZE) {
+#if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+                    ++rb_rounds;
+#endif
+                    bool hit[UN];
+                    double vx[UN], vy[UN], vz[UN];
+                    // unconditional (clamped) loads, so that all of them are issued before the first use
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        int q = q0 + u * T::WSIZE + T::lane();
+                        int qq = q < n ? q : n - 1;
+                        vx[u] = X[3 * qq]; vy[u] = X[3 * qq + 1]; vz[u] = X[3 * qq + 2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        int q = q0 + u * T::WSIZE + T::lane();
+                        double dx = vx[u] - cx, dy = vy[u] - cy, dz = vz[u] - cz;
+                        double d2 = dx * dx + dy * dy + dz * dz;
+                        hit[u] = q < n && d2 < reach2 && !(img == RB_CENTRAL && q == p);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        unsigned long long bal = T::ballot(hit[u]);
+                        if (bal) {
+                            int q = q0 + u * T::WSIZE + T::lane();
+                            int pos = cnt + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
+                            if (hit[u] && pos < RB_NB_CAP) WS.nb[(size_t)p * RB_NB_CAP + pos] = img * n + q;
+                            cnt += __builtin_popcountll(bal);
+                        }
+                    }
+                }
+            }
+            if (T::lane() == 0) {
+                WS.nb_cnt[p] = cnt;
+                if (cnt > RB_NB_CAP) rb_atomic_or(&w.status, RB_ST_NB_OVERFLOW);
+            }
         }
     }
     T::sync();
+    RB_TICK(2);
     // ---- molecules, one at a time ------------------------------------------------------------
     int mol_serial = 0, layer_serial = 0;
     for (;;) {
         // start: the remaining heavy atom closest to the pseudo origin (utilities.py:955-972)
         {
-            double ox = w.origin[0], oy = w.origin[1], oz = w.origin[2];
+            double ox = sh.origin[0], oy = sh.origin[1], oz = sh.origin[2];
             double oo = sq3(ox, oy, oz);
             double best = PW_INF;
             int bi = -1;
             for (int q = tid; q < n; q += T::SIZE) {
-                if (!w.remaining[q] || fr.terminal[q]) continue;
-                double d = rb_dist_sk(&w.V[3 * q], w.Vxx[q], ox, oy, oz, oo);
+                if (!WS.remaining[q] || fr.terminal[q]) continue;
+                double d = rb_dist_sk(&WS.V[3 * q], WS.Vxx[q], ox, oy, oz, oo);
                 if (d < best || bi < 0) { best = d; bi = q; }
             }
-            w.red_v[tid] = best;
-            w.red_i[tid] = bi;
+            if (bi < 0) { best = PW_INF; bi = 0x7fffffff; }
+            T::wave_argmin(best, bi);            // smallest distance, smallest index on ties
+            if (T::lane() == 0) { sh.red_v[T::wave()] = best; sh.red_i[T::wave()] = bi; }
             T::sync();
             if (tid == 0) {
                 double b = PW_INF;
                 int i0 = -1;
-                for (int t = 0; t < T::SIZE; ++t) {
-                    int it = w.red_i[t];
-                    if (it < 0) continue;
-                    double bt = w.red_v[t];
+                for (int t = 0; t < T::NWAVES; ++t) {
+                    int it = sh.red_i[t];
+                    if (it == 0x7fffffff) continue;
+                    double bt = sh.red_v[t];
                     if (i0 < 0 || bt < b || (bt == b && it < i0)) { b = bt; i0 = it; }
                 }
-                w.start = i0;
+                sh.start = i0;
             }
             T::sync();
         }
-        if (w.start < 0) break;
+        RB_TICK(3);
+        if (sh.start < 0) break;
         ++mol_serial;
-        if (tid == 0) { w.work[0] = w.start; w.n_work = 1; w.n_final = 0; }
+        if (tid == 0) { work[0] = sh.start; sh.n_work = 1; sh.n_final = 0; }
+        if (use_bits)
+            for (int i = tid; i < WS.bit_words; i += T::SIZE) bits_final[i] = 0;
         T::sync();
         // breadth-first layers (utilities.py:982-1055)
         for (;;) {
-            const int nw = w.n_work;
+            const int nw = sh.n_work;
             if (nw == 0) break;
             ++layer_serial;
-            if (tid == 0) w.n_next = 0;
+            if (tid == 0) sh.n_next = 0;
             // the atoms of this layer join the molecule in list order
             for (int k = tid; k < nw; k += T::SIZE) {
-                int id = w.work[k];
-                w.final_[w.n_final + k] = id;
-                w.stamp_final[id] = mol_serial;
+                int id = work[k];
+                WS.final_[sh.n_final + k] = id;
+                if (use_bits) rb_atomic_or64((unsigned long long*)&bits_final[id >> 6], 1ull << (id & 63));
+                else WS.stamp_final[id] = mol_serial;
             }
             T::sync();
+            RB_TICK(4);
             for (int c0 = 0; c0 < nw; c0 += RB_CHUNK) {
                 const int cn = nw - c0 < RB_CHUNK ? nw - c0 : RB_CHUNK;
-                for (int k = tid; k < cn; k += T::SIZE) w.seg_cnt[k] = 0;
+                for (int k = tid; k < cn; k += T::SIZE) seg_cnt[k] = 0;
                 T::sync();
-                for (int k = T::wave(); k < cn; k += T::NWAVES) rb_expand<T>(fr, w, w.work[c0 + k], k);
+                for (int k = T::wave(); k < cn; k += T::NWAVES) rb_expand<T>(fr, WS, &w.status, work[c0 + k], k);
                 T::sync();
+                RB_TICK(5);
                 // every atom's hits in list-position order
                 for (int k = tid; k < cn; k += T::SIZE) {
-                    int m = w.seg_cnt[k] < RB_SEG_CAP ? w.seg_cnt[k] : RB_SEG_CAP;
-                    long long* sgm = &w.seg[(size_t)k * RB_SEG_CAP];
+                    int m = seg_cnt[k] < RB_SEG_CAP ? seg_cnt[k] : RB_SEG_CAP;
+                    PW_LDS long long* sgm = &seg[(size_t)k * RB_SEG_CAP];
                     for (int a = 1; a < m; ++a) {
                         long long v = sgm[a];
                         int b = a - 1;
@@ -419,78 +536,111 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                     }
                 }
                 T::sync();
+                RB_TICK(6);
                 // unique(working_list_temp), then "not in final_molecule" (utilities.py:1044-1055)
                 if (tid == 0) {
-                    int nn = w.n_next;
+                    int nn = sh.n_next;
                     for (int k = 0; k < cn; ++k) {
-                        int m = w.seg_cnt[k] < RB_SEG_CAP ? w.seg_cnt[k] : RB_SEG_CAP;
-                        const long long* sgm = &w.seg[(size_t)k * RB_SEG_CAP];
+                        int m = seg_cnt[k] < RB_SEG_CAP ? seg_cnt[k] : RB_SEG_CAP;
+                        const PW_LDS long long* sgm = &seg[(size_t)k * RB_SEG_CAP];
                         for (int a = 0; a < m; ++a) {
                             int id = (int)(sgm[a] & 0xffffffffll);
-                            if (w.stamp_temp[id] == layer_serial) continue;
-                            w.stamp_temp[id] = layer_serial;
-                            if (w.stamp_final[id] == mol_serial) continue;
-                            w.work_next[nn++] = id;
+                            if (use_bits) {
+                                unsigned long long bit = 1ull << (id & 63);
+                                unsigned long long seen = bits_temp[id >> 6];
+                                if (seen & bit) continue;
+                                bits_temp[id >> 6] = seen | bit;
+                                if (bits_final[id >> 6] & bit) continue;
+                            } else {
+                                if (WS.stamp_temp[id] == layer_serial) continue;
+                                WS.stamp_temp[id] = layer_serial;
+                                if (WS.stamp_final[id] == mol_serial) continue;
+                            }
+                            work_next[nn++] = id;
                         }
                     }
-                    w.n_next = nn;
+                    sh.n_next = nn;
                 }
                 T::sync();
+                RB_TICK(7);
             }
             // atom_list.remove(i) for the atoms of this layer (utilities.py:1037-1039)
             for (int k = tid; k < nw; k += T::SIZE) {
-                int id = w.work[k];
-                if (id < n) w.remaining[id] = 0;
+                int id = work[k];
+                if (id < n) WS.remaining[id] = 0;
             }
+            if (use_bits)
+                for (int i = tid; i < WS.bit_words; i += T::SIZE) bits_temp[i] = 0;
             T::sync();
             if (tid == 0) {
-                w.n_final += nw;
-                w.n_work = w.n_next;
-                int* t = w.work; w.work = w.work_next; w.work_next = t;
+                sh.n_final += nw;
+                sh.n_work = sh.n_next;
             }
+            { int* t = work; work = work_next; work_next = t; }     // every thread, its own copies
             T::sync();
+            RB_TICK(8);
+#if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+            ++rb_layers;
+#endif
         }
         // ---- close the molecule ------------------------------------------------------------
-        const int m = w.n_final;
+        const int m = sh.n_final;
         bool keep = true;
         if (fr.rebuild) {
             // centre of mass of the molecule in fractional coordinates, rounded to 8 places
             // (np.around: x * 1e8 -> rint -> / 1e8), inside [bound0, bound1) on all three axes
-            for (int k = tid; k < m; k += T::SIZE) {
-                int q, ax, ay, az;
-                const double* P;
-                rb_decode(w, n, w.final_[k], &q, &ax, &ay, &az, &P);
-                w.msum[k] = fr.mass[q];
-            }
-            T::sync();
-            for (int col = tid; col < 3; col += T::SIZE) {
-                double acc = 0.0;
-                for (int k = 0; k < m; ++k) {
+            if (m <= WS.term_cap) {
+                // terms staged in team-shared memory by all threads, then summed in list order
+                PW_LDS double* tx = terms;
+                const int tc = WS.term_cap;
+                for (int k = tid; k < m; k += T::SIZE) {
                     int q, ax, ay, az;
                     const double* P;
-                    rb_decode(w, n, w.final_[k], &q, &ax, &ay, &az, &P);
-                    double t = P[col] * fr.mass[q];
-                    acc = k == 0 ? t : acc + t;
+                    rb_decode(WS, n, WS.final_[k], &q, &ax, &ay, &az, &P);
+                    double mq = fr.mass[q];
+                    tx[k] = P[0] * mq; tx[tc + k] = P[1] * mq; tx[2 * tc + k] = P[2] * mq; tx[3 * tc + k] = mq;
                 }
-                w.com[col] = acc;
+                T::sync();
+                for (int col = tid; col < 3; col += T::SIZE)
+                    sh.com[col] = seq_sum_blocked(m, [&](int k) { return tx[col * tc + k]; });
+                if (tid == SUM_THREAD) sh.red_v[0] = np_sum_serial((const double*)(tx + 3 * tc), m);
+            } else {
+                for (int k = tid; k < m; k += T::SIZE) {
+                    int q, ax, ay, az;
+                    const double* P;
+                    rb_decode(WS, n, WS.final_[k], &q, &ax, &ay, &az, &P);
+                    WS.msum[k] = fr.mass[q];
+                }
+                T::sync();
+                for (int col = tid; col < 3; col += T::SIZE)
+                    sh.com[col] = seq_sum_blocked(m, [&](int k) {
+                        int q, ax, ay, az;
+                        const double* P;
+                        rb_decode(WS, n, WS.final_[k], &q, &ax, &ay, &az, &P);
+                        return P[col] * fr.mass[q];
+                    });
+                if (tid == SUM_THREAD) sh.red_v[0] = np_sum_serial(WS.msum, m);
             }
-            if (tid == SUM_THREAD) w.red_v[0] = np_sum_serial(w.msum, m);
             T::sync();
             if (tid == 0) {
-                double total = w.red_v[0];
+                double total = sh.red_v[0];
                 double cf[3];
-                rb_mat3(fr.lattice_inv, w.com[0] / total, w.com[1] / total, w.com[2] / total, cf);
+                rb_mat3(fr.lattice_inv, sh.com[0] / total, sh.com[1] / total, sh.com[2] / total, cf);
                 bool in = true;
                 for (int c = 0; c < 3; ++c) {
                     double r = __builtin_rint(cf[c] * 1e8) / 1e8;
-                    in = in && (r >= w.bound[0]) && (r < w.bound[1]);
+                    in = in && (r >= sh.bound[0]) && (r < sh.bound[1]);
                 }
-                w.red_i[0] = in ? 1 : 0;
+                sh.red_i[0] = in ? 1 : 0;
             }
             T::sync();
-            keep = w.red_i[0] != 0;
+            keep = sh.red_i[0] != 0;
             T::sync();
         }
+        RB_TICK(9);
+#if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        ++rb_mols;
+#endif
         if (keep) {
             const int base = w.n_out;
             const bool fits = base + m <= out.atoms_cap && w.n_mol < out.mols_cap;
@@ -498,8 +648,8 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                 for (int k = tid; k < m; k += T::SIZE) {
                     int q, ax, ay, az;
                     const double* P;
-                    int id = w.final_[k];
-                    rb_decode(w, n, id, &q, &ax, &ay, &az, &P);
+                    int id = WS.final_[k];
+                    rb_decode(WS, n, id, &q, &ax, &ay, &az, &P);
                     out.src_atom[base + k] = q;
                     out.src_image[base + k] = id < n ? (signed char)-1 : (signed char)((id - n) / n);
                     out.xyz[3 * (size_t)(base + k)] = P[0];
@@ -520,11 +670,21 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
             T::sync();
         }
     }
+    RB_TICK(10);
     if (tid == 0) {
         *out.n_mol = w.n_mol;
         *out.status = w.status;
     }
     T::sync();
+#if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    if (tid == 0 && blockIdx.x == 0)
+        printf("RBPROF us: setup %lld pre %lld cand %lld start %lld append %lld expand %lld sort %lld unique %lld "
+               "layer_end %lld close %lld emit %lld | layers %d walks %d kept %d\n",
+               rb_prof[0] / 100, rb_prof[1] / 100, rb_prof[2] / 100, rb_prof[3] / 100, rb_prof[4] / 100, rb_prof[5] / 100,
+               rb_prof[6] / 100, rb_prof[7] / 100, rb_prof[8] / 100, rb_prof[9] / 100, rb_prof[10] / 100, rb_layers, rb_mols,
+               w.n_mol);
+    if (tid == 0 && blockIdx.x == 0) printf("RBPROF wave 0 candidate scan: %d images, %d rounds\n", rb_imgs, rb_rounds);
+#endif
 }
 
 }  // namespace pw

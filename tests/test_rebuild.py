@@ -66,7 +66,7 @@ def test_oracle_primitives():
         assert np.array_equal(R.round8(x), np.array([round(float(v), 8) for v in x]))
 
 
-def run_hostsim(hostsim, system, rebuild):
+def run_hostsim(hostsim, system, rebuild, with_bits=True):
     L = ctypes.CDLL(str(hostsim / "librebuildprobe.so"))
     topo = RB.CellTopology(system["elements"])
     lattice, periodic = RB.system_lattice(system)
@@ -88,7 +88,7 @@ def run_hostsim(hostsim, system, rebuild):
         topo.terminal.ctypes.data_as(vp), ctypes.c_double(topo.max_dist), ctypes.c_double(topo.tol),
         ctypes.c_int(1 if rebuild else 0), ctypes.c_int(cap), ctypes.c_int(cap), ctypes.byref(n_mol),
         ctypes.byref(status), off.ctypes.data_as(vp), src.ctypes.data_as(vp), img.ctypes.data_as(vp),
-        oxyz.ctypes.data_as(vp))
+        oxyz.ctypes.data_as(vp), ctypes.c_int(1 if with_bits else 0))
     assert rc == 0
     return RB.molecules_from_output(system, n_mol.value, off, src, oxyz), status.value
 
@@ -103,6 +103,10 @@ def test_host_team_matches_reference(hostsim, name):
         mols, status = run_hostsim(hostsim, system, True)
         assert status == 0
         check_molecules(mols, expect, "rebuild", f"hostsim/{name}/rebuild")
+        # cells too large for the visit bit sets in team-shared memory use the stamp arrays
+        mols, status = run_hostsim(hostsim, system, True, with_bits=False)
+        assert status == 0
+        check_molecules(mols, expect, "rebuild", f"hostsim/{name}/rebuild/stamps")
 
 
 @pytest.mark.gpu

@@ -22,3 +22,10 @@ for rebuild in (True, False):
     dt = time.time() - t
     print(f"rebuild={rebuild}: {frames} frames x {topo.n} atoms in {dt * 1e3:.1f} ms wall (H2D+kernel+D2H) "
           f"-> {frames / dt:.0f} frames/s; molecules per frame {n_mol[0]}")
+# latency of one frame on its own (kernel + copies)
+for rebuild in (True, False):
+    RB.discrete_molecules_frames(topo, coords[:1], lat[:1], rebuild)
+    t = time.time()
+    for _ in range(10):
+        RB.discrete_molecules_frames(topo, coords[:1], lat[:1], rebuild)
+    print(f"rebuild={rebuild}: one frame alone {(time.time() - t) * 100:.2f} ms")
