@@ -34,6 +34,7 @@ namespace pw {
 constexpr int RB_NB_CAP = 32;      // conservative neighbour candidates kept per heavy atom
 constexpr int RB_SEG_CAP = 32;     // bonded neighbours one atom can contribute per layer
 constexpr int RB_CHUNK = 64;       // atoms of a layer expanded between two merges
+constexpr int RB_LWORK = 512;      // layer width kept in team-shared memory (wider layers: global lists)
 constexpr int RB_CENTRAL = 13;     // image (0,0,0) in the a,b,c-nested 3x3x3 enumeration
 
 // status bits of one frame (pw_cell_out.status)
@@ -106,6 +107,7 @@ struct RebuildShared {
     double box[27 * 6];
     int red_i[8];
     int n_work, n_next, n_final, start;
+    int lwork[2][RB_LWORK];        // the current and the next layer (layers up to RB_LWORK atoms)
 };
 
 struct RebuildWs {
@@ -220,58 +222,79 @@ PW_HD inline void rb_decode(const RebuildWs& w, int n, int id, int* q, int* ax, 
 
 // one wave expands one atom of the current layer: lanes over its candidate list
 template <class T>
-PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, int* status, int id, int slot) {
+PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, int* status, int id, int slot,
+                            long long* xprof = nullptr) {
+#if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    long long xt = wall_clock64();
+#define RB_XT(k) do { if (xprof && T::lane() == 0) { long long t_ = wall_clock64(); xprof[k] += t_ - xt; xt = t_; } } while (0)
+#else
+#define RB_XT(k) do { } while (0)
+#endif
     const int n = fr.n;
     PW_ASSUME_LDS(w.seg);
     PW_ASSUME_LDS(w.seg_cnt);
     int q0, ax, ay, az;
     const double* P;
     rb_decode(w, n, id, &q0, &ax, &ay, &az, &P);
-    if (fr.terminal[q0]) return;
-    const double px = P[0], py = P[1], pz = P[2];
-    const double pp = sq3(px, py, pz);
+    // everything that depends on q0 only is requested at once (one memory round trip, not four)
+    const unsigned char term0 = fr.terminal[q0];
     const double ri = fr.cov[q0];
-    const int cnt = w.nb_cnt[q0] < RB_NB_CAP ? w.nb_cnt[q0] : RB_NB_CAP;
+    const int cnt0 = w.nb_cnt[q0];
+    const int first = w.nb[(size_t)q0 * RB_NB_CAP + (T::lane() < RB_NB_CAP ? T::lane() : 0)];
+    const double px = P[0], py = P[1], pz = P[2];
+    RB_XT(0);
+    if (term0) return;
+    const double pp = sq3(px, py, pz);
+    const int cnt = cnt0 < RB_NB_CAP ? cnt0 : RB_NB_CAP;
     for (int e = T::lane(); e < cnt; e += T::WSIZE) {
-        int packed = w.nb[(size_t)q0 * RB_NB_CAP + e];
+        int packed = e == T::lane() ? first : w.nb[(size_t)q0 * RB_NB_CAP + e];
         int dimg = packed / n;
         int q = packed - dimg * n;
         int bx = ax + dimg / 9 - 1, by = ay + (dimg / 3) % 3 - 1, bz = az + dimg % 3 - 1;
         bool central = bx == 0 && by == 0 && bz == 0;
         double rc = ri + fr.cov[q];
         double lo = rc - fr.tol, hi = rc + fr.tol;
-        for (int part = 0; part < 2; ++part) {
-            const double* X;
-            double xx;
-            long long key;
-            if (part == 0) {
-                // remaining cell atoms (utilities.py:996-1013)
-                if (!central || !w.remaining[q]) continue;
-                X = &w.V[3 * q];
-                xx = w.Vxx[q];
-                key = ((long long)q << 32) | (unsigned)q;
-            } else {
-                // supercell atoms that are not (by value) in the remaining atom list (:1014-1036)
-                if (!fr.rebuild) continue;
-                if (bx < -1 || bx > 1 || by < -1 || by > 1 || bz < -1 || bz > 1) continue;
-                bool same_item = central && w.alias[q];
-                if (same_item && w.remaining[q]) continue;
-                int s = ((bx + 1) * 9 + (by + 1) * 3 + (bz + 1)) * n + q;
-                X = &w.S[3 * (size_t)s];
-                xx = sq3(X[0], X[1], X[2]);
-                key = ((long long)(n + s) << 32) | (unsigned)(same_item ? q : n + s);
-            }
-            double d = rb_dist_sk(X, xx, px, py, pz, pp);
+        // a candidate is tested as a remaining cell atom (utilities.py:996-1013) and / or as a
+        // supercell atom that is not, by value, in the remaining atom list (:1014-1036); nearly
+        // always exactly one of the two applies, so the lanes pick theirs first and share one
+        // pass through the distance code (a second pass only if some lane needs both)
+        const unsigned char rem = central ? w.remaining[q] : (unsigned char)0;
+        const bool same_item = central && w.alias[q];
+        const bool do0 = central && rem;
+        const bool do1 = fr.rebuild && !(bx < -1 || bx > 1 || by < -1 || by > 1 || bz < -1 || bz > 1) &&
+                         !(same_item && rem);
+        const int s1 = ((bx + 1) * 9 + (by + 1) * 3 + (bz + 1)) * n + q;
+        RB_XT(1);
+        for (int pass = 0; pass < 2; ++pass) {
+            const bool as_cell = pass == 0 ? do0 : false;
+            const bool as_image = pass == 0 ? (!do0 && do1) : (do0 && do1);
+            if (pass == 1 && !T::wave_any(as_image)) break;
+            if (!as_cell && !as_image) continue;
+            const double* X = as_cell ? &w.V[3 * q] : &w.S[3 * (size_t)s1];
+            const double x0 = X[0], x1 = X[1], x2 = X[2];
+            RB_XT(2);
+            const double xx = sq3(x0, x1, x2);          // == Vxx[q] for a cell atom
+            const long long key = as_cell ? (((long long)q << 32) | (unsigned)q)
+                                          : (((long long)(n + s1) << 32) | (unsigned)(same_item ? q : n + s1));
+            const double xv[3] = {x0, x1, x2};
+            double d = rb_dist_sk(xv, xx, px, py, pz, pp);
             if (!(d > 0.1 && d < fr.max_dist)) continue;
-            double dx = px - X[0], dy = py - X[1], dz = pz - X[2];
+            double dx = px - x0, dy = py - x1, dz = pz - x2;
             double r2 = (dx * dx + dy * dy) + dz * dz;
-            double r = r2 >= 2.2250738585072014e-308 ? pw_pow_np(r2, 0.5) : pw_sqrt(r2);   // float ** 0.5: libm pow
+            // distance(): (...) ** 0.5 on a float is libm pow, which is within one ulp of the correctly
+            // rounded square root: only a comparison that close to a limit needs the libm value
+            double r = pw_sqrt(r2);
+            const double margin = r * 1.0e-15;
+            if ((pw_abs(r - lo) <= margin || pw_abs(r - hi) <= margin) && r2 >= 2.2250738585072014e-308)
+                r = pw_pow_np(r2, 0.5);
             if (!(lo < r && r < hi)) continue;
             int k = rb_atomic_add(&w.seg_cnt[slot], 1);
             if (k < RB_SEG_CAP) w.seg[(size_t)slot * RB_SEG_CAP + k] = key;
             else rb_atomic_or(status, RB_ST_SEG_OVERFLOW);
         }
+        RB_XT(3);
     }
+    RB_XT(4);
 }
 
 // -DPW_RB_PROFILE: team 0 prints the wall time of its phases per frame (tests/tools/rebuild_profile.py)
@@ -286,6 +309,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
     long long rb_prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long rb_last = wall_clock64();
     int rb_layers = 0, rb_mols = 0, rb_rounds = 0, rb_heavy = 0, rb_imgs = 0;
+    long long rb_xp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     // the array pointers of the workspace header, copied once: the header itself lives in global
     // memory, and reading a pointer through it costs a dependent load after every store
@@ -498,53 +522,73 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
         RB_TICK(3);
         if (sh.start < 0) break;
         ++mol_serial;
-        if (tid == 0) { work[0] = sh.start; sh.n_work = 1; sh.n_final = 0; }
+        if (tid == 0) { work[0] = sh.start; sh.lwork[0][0] = sh.start; sh.n_work = 1; sh.n_final = 0; sh.n_next = 0; }
         if (use_bits)
             for (int i = tid; i < WS.bit_words; i += T::SIZE) bits_final[i] = 0;
         T::sync();
-        // breadth-first layers (utilities.py:982-1055)
+        // breadth-first layers (utilities.py:982-1055).  Two team barriers per chunk of a layer:
+        //   A  the layer's atoms join the molecule; one wave per atom finds and orders its bonded
+        //      neighbours (rb_expand + sort);
+        //   C  thread 0 merges the hits in list order (unique, then "not in the molecule") into the
+        //      next layer while the other threads retire the layer's atoms from the atom list.
+        int cur = 0;                       // which team-shared copy holds the current layer
         for (;;) {
             const int nw = sh.n_work;
             if (nw == 0) break;
             ++layer_serial;
-            if (tid == 0) sh.n_next = 0;
-            // the atoms of this layer join the molecule in list order
+            const int nf = sh.n_final;
+            const bool lw = nw <= RB_LWORK;
+            const PW_LDS int* wl = sh.lwork[cur];
+            PW_LDS int* wl_next = sh.lwork[cur ^ 1];
             for (int k = tid; k < nw; k += T::SIZE) {
-                int id = work[k];
-                WS.final_[sh.n_final + k] = id;
+                int id = lw ? wl[k] : work[k];
+                WS.final_[nf + k] = id;
                 if (use_bits) rb_atomic_or64((unsigned long long*)&bits_final[id >> 6], 1ull << (id & 63));
                 else WS.stamp_final[id] = mol_serial;
             }
-            T::sync();
-            RB_TICK(4);
+            if (use_bits)
+                for (int i = tid; i < WS.bit_words; i += T::SIZE) bits_temp[i] = 0;
             for (int c0 = 0; c0 < nw; c0 += RB_CHUNK) {
                 const int cn = nw - c0 < RB_CHUNK ? nw - c0 : RB_CHUNK;
-                for (int k = tid; k < cn; k += T::SIZE) seg_cnt[k] = 0;
-                T::sync();
-                for (int k = T::wave(); k < cn; k += T::NWAVES) rb_expand<T>(fr, WS, &w.status, work[c0 + k], k);
-                T::sync();
-                RB_TICK(5);
-                // every atom's hits in list-position order
-                for (int k = tid; k < cn; k += T::SIZE) {
-                    int m = seg_cnt[k] < RB_SEG_CAP ? seg_cnt[k] : RB_SEG_CAP;
-                    PW_LDS long long* sgm = &seg[(size_t)k * RB_SEG_CAP];
-                    for (int a = 1; a < m; ++a) {
-                        long long v = sgm[a];
-                        int b = a - 1;
-                        while (b >= 0 && sgm[b] > v) { sgm[b + 1] = sgm[b]; --b; }
-                        sgm[b + 1] = v;
+                const bool last = c0 + RB_CHUNK >= nw;
+                for (int k = T::wave(); k < cn; k += T::NWAVES) {
+                    if (T::lane() == 0) seg_cnt[k] = 0;
+                    T::wave_sync();
+#if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+                    rb_expand<T>(fr, WS, &w.status, lw ? wl[c0 + k] : work[c0 + k], k, T::wave() == 0 ? rb_xp : nullptr);
+#else
+                    rb_expand<T>(fr, WS, &w.status, lw ? wl[c0 + k] : work[c0 + k], k);
+#endif
+                    T::wave_sync();
+                    if (T::lane() == 0) {
+                        // the atom's hits in list-position order
+                        int m = seg_cnt[k] < RB_SEG_CAP ? seg_cnt[k] : RB_SEG_CAP;
+                        PW_LDS long long* sgm = &seg[(size_t)k * RB_SEG_CAP];
+                        for (int a2 = 1; a2 < m; ++a2) {
+                            long long v = sgm[a2];
+                            int b2 = a2 - 1;
+                            while (b2 >= 0 && sgm[b2] > v) { sgm[b2 + 1] = sgm[b2]; --b2; }
+                            sgm[b2 + 1] = v;
+                        }
                     }
                 }
                 T::sync();
-                RB_TICK(6);
+                RB_TICK(5);
+                // atom_list.remove(i) for the atoms of this layer (utilities.py:1037-1039), after
+                // the last of them has been expanded
+                if (last)
+                    for (int k = tid; k < nw; k += T::SIZE) {
+                        int id = lw ? wl[k] : work[k];
+                        if (id < n) WS.remaining[id] = 0;
+                    }
                 // unique(working_list_temp), then "not in final_molecule" (utilities.py:1044-1055)
                 if (tid == 0) {
                     int nn = sh.n_next;
                     for (int k = 0; k < cn; ++k) {
                         int m = seg_cnt[k] < RB_SEG_CAP ? seg_cnt[k] : RB_SEG_CAP;
                         const PW_LDS long long* sgm = &seg[(size_t)k * RB_SEG_CAP];
-                        for (int a = 0; a < m; ++a) {
-                            int id = (int)(sgm[a] & 0xffffffffll);
+                        for (int a2 = 0; a2 < m; ++a2) {
+                            int id = (int)(sgm[a2] & 0xffffffffll);
                             if (use_bits) {
                                 unsigned long long bit = 1ull << (id & 63);
                                 unsigned long long seen = bits_temp[id >> 6];
@@ -556,29 +600,23 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                                 WS.stamp_temp[id] = layer_serial;
                                 if (WS.stamp_final[id] == mol_serial) continue;
                             }
+                            if (nn < RB_LWORK) wl_next[nn] = id;
                             work_next[nn++] = id;
                         }
                     }
-                    sh.n_next = nn;
+                    if (last) {
+                        sh.n_final = nf + nw;
+                        sh.n_work = nn;
+                        sh.n_next = 0;
+                    } else {
+                        sh.n_next = nn;
+                    }
                 }
                 T::sync();
                 RB_TICK(7);
             }
-            // atom_list.remove(i) for the atoms of this layer (utilities.py:1037-1039)
-            for (int k = tid; k < nw; k += T::SIZE) {
-                int id = work[k];
-                if (id < n) WS.remaining[id] = 0;
-            }
-            if (use_bits)
-                for (int i = tid; i < WS.bit_words; i += T::SIZE) bits_temp[i] = 0;
-            T::sync();
-            if (tid == 0) {
-                sh.n_final += nw;
-                sh.n_work = sh.n_next;
-            }
             { int* t = work; work = work_next; work_next = t; }     // every thread, its own copies
-            T::sync();
-            RB_TICK(8);
+            cur ^= 1;
 #if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
             ++rb_layers;
 #endif
@@ -684,6 +722,9 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                rb_prof[6] / 100, rb_prof[7] / 100, rb_prof[8] / 100, rb_prof[9] / 100, rb_prof[10] / 100, rb_layers, rb_mols,
                w.n_mol);
     if (tid == 0 && blockIdx.x == 0) printf("RBPROF wave 0 candidate scan: %d images, %d rounds\n", rb_imgs, rb_rounds);
+    if (tid == 0 && blockIdx.x == 0)
+        printf("RBPROF expand (wave 0) us: q0 loads %lld, candidate flags %lld, coordinates %lld, test+append %lld, tail %lld\n",
+               rb_xp[0] / 100, rb_xp[1] / 100, rb_xp[2] / 100, rb_xp[3] / 100, rb_xp[4] / 100);
 #endif
 }
 
