@@ -12,6 +12,7 @@
 // Built with:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (fused
 // multiply-adds only where the source writes pw_fma).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -316,8 +317,17 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
     if (getenv("PW_PLAN_DEBUG"))
         fprintf(stderr, "launch NW=%d mask %x grid %d lds %zu nmax %d units %ld atoms %ld\n", NW, MASK, p.grid, p.lds,
                 r->nmax, r->n_units, r->n_atoms);
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)p.lds));
+    // the limit, not a request: set once per kernel and device to the most a launch may ask for, so
+    // that concurrent launches from several host threads never lower it under each other
+    {
+        static std::atomic<unsigned long long> done{0};
+        unsigned long long bit = 1ull << (c->device & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024 - 256));
+            done.fetch_or(bit, std::memory_order_release);
+        }
+    }
     HIP_TRY(hipMemsetAsync(c->counter + counter_slot, 0, sizeof(unsigned long long), st));
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
                        r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb,

@@ -7,6 +7,7 @@
 // lists, visit stamps); the traversal itself is a chain of short dependent steps, so the
 // launch is sized for many concurrent frames rather than for wide teams.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -125,7 +126,9 @@ int rebuild_on_device(pw_context* ctx, const pw_cell_in* in, int atoms_cap, int 
     hipDeviceProp_t prop;
     RB_TRY(hipGetDeviceProperties(&prop, pw_context_device(ctx)));
     size_t slab = (RebuildWs::bytes(n, in->rebuild, RB_WAVES * 64) + 255) & ~(size_t)255;
-    long grid = (long)prop.multiProcessorCount * 4;
+    int per_cu = 4;
+    if (const char* e = getenv("PW_RB_TEAMS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
+    long grid = (long)prop.multiProcessorCount * per_cu;
     if (grid > F) grid = F;
     // keep the slabs within a quarter of the device memory
     while (grid > 1 && (size_t)grid * slab > prop.totalGlobalMem / 4) grid >>= 1;
@@ -168,7 +171,16 @@ int rebuild_on_device(pw_context* ctx, const pw_cell_in* in, int atoms_cap, int 
     // team-shared memory: the hit segments, and the two visit bit sets when they fit beside them
     int with_bits = RebuildWs::fast_bytes(n, in->rebuild, true) <= 96 * 1024 ? 1 : 0;
     size_t lds = RebuildWs::fast_bytes(n, in->rebuild, with_bits != 0);
-    RB_TRY(hipFuncSetAttribute((const void*)pw_rebuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        // the limit, not a request: set once per device (host threads may launch concurrently)
+        static std::atomic<unsigned long long> done{0};
+        unsigned long long bit = 1ull << (pw_context_device(ctx) & 63);
+        if (!(done.load(std::memory_order_acquire) & bit)) {
+            RB_TRY(hipFuncSetAttribute((const void*)pw_rebuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       128 * 1024));
+            done.fetch_or(bit, std::memory_order_release);
+        }
+    }
     hipLaunchKernelGGL(pw_rebuild_kernel, dim3((unsigned)grid), dim3(RB_WAVES * 64), lds, st, d_in, d_out,
                        d_slabs, slab, d_counter, with_bits);
     RB_TRY(hipGetLastError());

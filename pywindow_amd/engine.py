@@ -23,14 +23,16 @@ def set_default_device(device: int) -> None:
     _default_device = int(device)
 
 
-def context(device: int | None = None) -> "_lib.Context":
-    """Lazily created per-device context (stream + workspace)."""
+def context(device: int | None = None, lane: int = 0) -> "_lib.Context":
+    """Lazily created per-device context (streams + workspaces).  ``lane`` > 0 gives further
+    contexts on the same device for host threads that keep their own launches in flight."""
     dev = _default_device if device is None else int(device)
+    key = dev if lane == 0 else (dev, int(lane))
     with _lock:
-        ctx = _contexts.get(dev)
+        ctx = _contexts.get(key)
         if ctx is None:
             ctx = _lib.Context(dev)
-            _contexts[dev] = ctx
+            _contexts[key] = ctx
         return ctx
 
 

@@ -24,6 +24,9 @@ from . import _lib, engine
 from .element_data import MASS, VDW, element_ids
 from .molecular import MolecularSystem, decipher_atom_key
 
+#: frames per launch pair of a long modular analysis (see Trajectory._run_modular)
+MODULAR_CHUNK = 512
+
 
 class _FunctionError(Exception):
     def __init__(self, message: str) -> None:
@@ -243,21 +246,61 @@ class DLPOLY:
             raise KeyError("lattice")   # create_supercell needs the cell (utilities.py:776-779)
         ids = element_ids(el)
         topo = rb.CellTopology(el)
-        coords, lattice = self._read_selected(frames, self.periodic)
-        # frames -> molecules -> units without leaving the device: every molecule of every frame is
-        # one unit of ONE analysis launch
-        coords, lat, inv = rb.pack_frames(coords, lattice)
-        ctx = engine.context(device)
-        res, n_mol = ctx.resident_from_cells(topo, VDW[ids], coords, lat, inv, rebuild)
-        if res is None:
-            return np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE), np.zeros(0, np.int64), np.zeros(0, np.int64)
-        try:
-            res.launch(_lib.STAGE_ALL)
-            recs = res.download()
-        finally:
-            res.free()
+        vdw = VDW[ids]
+        dev = engine._default_device if device is None else int(device)
+
+        def one_chunk(ctx, chunk):
+            # frames -> molecules -> units without leaving the device: every molecule of every frame of
+            # the chunk is one unit of ONE analysis launch
+            coords, lattice = self._read_selected(chunk, self.periodic)
+            coords, lat, inv = rb.pack_frames(coords, lattice)
+            res, n_mol = ctx.resident_from_cells(topo, vdw, coords, lat, inv, rebuild)
+            if res is None:
+                return np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE), n_mol
+            try:
+                res.launch(_lib.STAGE_ALL)
+                return res.download(), n_mol
+            finally:
+                res.free()
+
+        if len(frames) <= 2 * MODULAR_CHUNK:
+            parts = [one_chunk(engine.context(dev), frames)]
+        else:
+            # long trajectories: chunks of frames on two host threads with a context (streams,
+            # workspaces) each, so that the re-assembly launch of one chunk runs beside the analysis
+            # launches of another (both are latency-bound and leave most of the GPU idle on their own)
+            import itertools
+            import threading
+
+            chunks = [frames[i:i + MODULAR_CHUNK] for i in range(0, len(frames), MODULAR_CHUNK)]
+            parts = [None] * len(chunks)
+            take = itertools.count()
+            lock = threading.Lock()
+            errors = []
+
+            def worker(ctx):            # a thread owns its context; chunks are handed out in order
+                try:
+                    while not errors:
+                        with lock:
+                            k = next(take)
+                        if k >= len(chunks):
+                            return
+                        parts[k] = one_chunk(ctx, chunks[k])
+                except BaseException as exc:  # noqa: BLE001 - re-raised on the calling thread
+                    errors.append(exc)
+
+            threads = [threading.Thread(target=worker, args=(engine.context(dev, lane=k),)) for k in range(2)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if errors:
+                raise errors[0]
+        recs = np.concatenate([p[0] for p in parts])
+        n_mol = np.concatenate([p[1] for p in parts])
         unit_frame = np.repeat(np.asarray(frames, np.int64), n_mol)
-        unit_mol = np.concatenate([np.arange(k) for k in n_mol]).astype(np.int64)
+        unit_mol = (np.concatenate([np.arange(k) for k in n_mol]).astype(np.int64) if len(n_mol)
+                    else np.zeros(0, np.int64))
         return recs, unit_frame, unit_mol
 
     def _analysis_modular(self, frames, override, rebuild, swap_atoms, forcefield, device, distributed):

@@ -221,6 +221,29 @@ def test_periodic_trajectory_modular_rebuild(hip_ctx, tmp_path):
 
 
 @pytest.mark.gpu
+def test_long_modular_analysis_in_chunks_on_two_contexts(hip_ctx, tmp_path, monkeypatch):
+    """A long periodic trajectory is analysed in chunks of frames by two host threads with a
+    context each (re-assembly of one chunk beside the analysis of another): same records, same
+    order as the one-piece analysis."""
+    import pywindow_amd as pw
+    from pywindow_amd import synth, trajectory
+
+    g = np.load(GOLDEN / "ptraj.npz")
+    rng = np.random.default_rng(11)
+    base = np.asarray(g["frames"][0], float)
+    frames = [base + rng.normal(0.0, 0.01, size=base.shape) for _ in range(11)]
+    path = tmp_path / "HISTORY_periodic_long"
+    path.write_text(synth.history_text(g["elements"], frames, cell=g["cell"]))
+    traj = pw.DLPOLY(path)
+    whole = traj.modular_records(rebuild=True, forcefield="opls")
+    monkeypatch.setattr(trajectory, "MODULAR_CHUNK", 2)
+    parts = traj.modular_records(rebuild=True, forcefield="opls")
+    assert len(whole[0]) >= 11 * 8
+    assert whole[0].tobytes() == parts[0].tobytes()
+    assert np.array_equal(whole[1], parts[1]) and np.array_equal(whole[2], parts[2])
+
+
+@pytest.mark.gpu
 def test_resident_hand_over_matches_host_path(hip_ctx):
     """pw_resident_from_cells: the ragged unit batch built on the device gives the same analysis
     records as the host-marshalled path; capacity retries (a framework 27x the cell) work."""
