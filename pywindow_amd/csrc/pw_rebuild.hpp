@@ -35,6 +35,9 @@ constexpr int RB_NB_CAP = 32;      // conservative neighbour candidates kept per
 constexpr int RB_SEG_CAP = 32;     // bonded neighbours one atom can contribute per layer
 constexpr int RB_CHUNK = 64;       // atoms of a layer expanded between two merges
 constexpr int RB_LWORK = 512;      // layer width kept in team-shared memory (wider layers: global lists)
+constexpr int RB_WF_TRUNCATED = 1;  // a neighbour candidate lay outside the 3x3x3 supercell
+constexpr int RB_WF_MARGINAL = 2;   // a distance within 1e-6 of a threshold of the bond test
+constexpr int RB_WF_REPEAT = 4;     // the same atom met in two images (or twice by value): not a finite molecule
 constexpr int RB_CENTRAL = 13;     // image (0,0,0) in the a,b,c-nested 3x3x3 enumeration
 
 // status bits of one frame (pw_cell_out.status)
@@ -107,6 +110,10 @@ struct RebuildShared {
     double box[27 * 6];
     int red_i[8];
     int n_work, n_next, n_final, start;
+    double cf[3];                  // unrounded fractional centre of mass of the molecule being closed
+    int wflags;                    // RB_WF_* of the walk in progress
+    int off_lo[3], off_hi[3];      // image offsets it reached
+    int skip, skip_cage, skip_off; // the walk from `start` is predicted (see rebuild_frame)
     int lwork[2][RB_LWORK];        // the current and the next layer (layers up to RB_LWORK atoms)
 };
 
@@ -132,15 +139,21 @@ struct RebuildWs {
     int term_cap, bit_words;
     unsigned char* remaining;   // n
     unsigned char* alias;       // n
+    // what the first walk through a molecule learned (rebuild only; see "walks that can be predicted")
+    int* cage_of;         // n: serial of the first walk that visited the atom, 0 = none yet
+    unsigned char* cage_off;    // n: image (0..26) in which that walk met the atom
+    unsigned char* cage_ok;     // n + 1, by walk serial: the walk was clean (no truncation / marginal bond / repeat)
+    int* cage_rng;        // n + 1: lowest and highest image offset per axis (2 bits each)
+    double* cage_f;       // (n + 1) x 3: fractional centre of mass of that walk's molecule
     int status, n_mol, n_out;
 
     PW_HD static size_t ids(int n, int rebuild) { return rebuild ? (size_t)28 * n : (size_t)n; }
     PW_HD static size_t bytes(int n, int rebuild, int team) {
         size_t id = ids(n, rebuild);
         (void)team;
-        size_t d = (size_t)3 * n + n + (rebuild ? (size_t)81 * n : 0) + id;
-        size_t i = (size_t)n + (size_t)n * RB_NB_CAP + 5 * id;
-        return sizeof(RebuildWs) + 64 + d * 8 + i * 4 + 2 * (size_t)n + 64;
+        size_t d = (size_t)3 * n + n + (rebuild ? (size_t)81 * n : 0) + id + 3 * ((size_t)n + 1);
+        size_t i = (size_t)n + (size_t)n * RB_NB_CAP + 5 * id + 2 * ((size_t)n + 1);
+        return sizeof(RebuildWs) + 64 + d * 8 + i * 4 + 4 * (size_t)n + 64 + 64;
     }
     // fast memory: the hit segments always, the two bit sets when `with_bits`
     PW_HD static size_t fast_bytes(int n, int rebuild, bool with_bits) {
@@ -170,6 +183,7 @@ struct RebuildWs {
         w->Vxx = (double*)p; p += (size_t)n * 8;
         w->S = (double*)p; p += rebuild ? (size_t)81 * n * 8 : 0;
         w->msum = (double*)p; p += id * 8;
+        w->cage_f = (double*)p; p += 3 * ((size_t)n + 1) * 8;
         w->nb_cnt = (int*)p; p += (size_t)n * 4;
         w->nb = (int*)p; p += (size_t)n * RB_NB_CAP * 4;
         w->stamp_final = (int*)p; p += id * 4;
@@ -177,8 +191,12 @@ struct RebuildWs {
         w->work = (int*)p; p += id * 4;
         w->work_next = (int*)p; p += id * 4;
         w->final_ = (int*)p; p += id * 4;
+        w->cage_of = (int*)p; p += ((size_t)n + 1) * 4;
+        w->cage_rng = (int*)p; p += ((size_t)n + 1) * 4;
         w->remaining = p; p += n;
         w->alias = p; p += n;
+        w->cage_off = p; p += n;
+        w->cage_ok = p; p += (size_t)n + 1;
         return w;
     }
 };
@@ -222,7 +240,7 @@ PW_HD inline void rb_decode(const RebuildWs& w, int n, int id, int* q, int* ax, 
 
 // one wave expands one atom of the current layer: lanes over its candidate list
 template <class T>
-PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, int* status, int id, int slot,
+PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, int* status, int* wflags, int id, int slot,
                             long long* xprof = nullptr) {
 #if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     long long xt = wall_clock64();
@@ -261,8 +279,9 @@ PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, int* sta
         const unsigned char rem = central ? w.remaining[q] : (unsigned char)0;
         const bool same_item = central && w.alias[q];
         const bool do0 = central && rem;
-        const bool do1 = fr.rebuild && !(bx < -1 || bx > 1 || by < -1 || by > 1 || bz < -1 || bz > 1) &&
-                         !(same_item && rem);
+        const bool outside = bx < -1 || bx > 1 || by < -1 || by > 1 || bz < -1 || bz > 1;
+        if (fr.rebuild && outside) rb_atomic_or(wflags, RB_WF_TRUNCATED);
+        const bool do1 = fr.rebuild && !outside && !(same_item && rem);
         const int s1 = ((bx + 1) * 9 + (by + 1) * 3 + (bz + 1)) * n + q;
         RB_XT(1);
         for (int pass = 0; pass < 2; ++pass) {
@@ -278,6 +297,7 @@ PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, int* sta
                                           : (((long long)(n + s1) << 32) | (unsigned)(same_item ? q : n + s1));
             const double xv[3] = {x0, x1, x2};
             double d = rb_dist_sk(xv, xx, px, py, pz, pp);
+            if (pw_abs(d - 0.1) < 1e-6 || pw_abs(d - fr.max_dist) < 1e-6) rb_atomic_or(wflags, RB_WF_MARGINAL);
             if (!(d > 0.1 && d < fr.max_dist)) continue;
             double dx = px - x0, dy = py - x1, dz = pz - x2;
             double r2 = (dx * dx + dy * dy) + dz * dz;
@@ -287,6 +307,7 @@ PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, int* sta
             const double margin = r * 1.0e-15;
             if ((pw_abs(r - lo) <= margin || pw_abs(r - hi) <= margin) && r2 >= 2.2250738585072014e-308)
                 r = pw_pow_np(r2, 0.5);
+            if (pw_abs(r - lo) < 1e-6 || pw_abs(r - hi) < 1e-6) rb_atomic_or(wflags, RB_WF_MARGINAL);
             if (!(lo < r && r < hi)) continue;
             int k = rb_atomic_add(&w.seg_cnt[slot], 1);
             if (k < RB_SEG_CAP) w.seg[(size_t)slot * RB_SEG_CAP + k] = key;
@@ -308,7 +329,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
 #if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     long long rb_prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long rb_last = wall_clock64();
-    int rb_layers = 0, rb_mols = 0, rb_rounds = 0, rb_heavy = 0, rb_imgs = 0;
+    int rb_layers = 0, rb_mols = 0, rb_rounds = 0, rb_heavy = 0, rb_imgs = 0, rb_skipped = 0;
     long long rb_xp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     // the array pointers of the workspace header, copied once: the header itself lives in global
@@ -338,6 +359,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
         WS.remaining[i] = 1;
         WS.alias[i] = 0;
         WS.nb_cnt[i] = 0;
+        WS.cage_of[i] = 0;
     }
     const bool use_bits = WS.bits_final != nullptr;
     if (use_bits) {
@@ -521,8 +543,52 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
         }
         RB_TICK(3);
         if (sh.start < 0) break;
+        // ---- walks that can be predicted -----------------------------------------------------
+        // A molecule wrapped through the cell faces is walked once from every fragment: each walk
+        // finds the same molecule shifted by a lattice vector, and all but one are dropped by the
+        // centre-of-mass test.  After the first (clean) walk the others are known in advance: the
+        // shift is the image in which the first walk met the new start atom, the walk would retire
+        // exactly the atoms it met in that image, and its centre of mass is the first one minus the
+        // shift.  A walk predicted to be dropped - with 1e-6 to spare, against 1e-8 of coordinate
+        // rounding - is not made.
+        if (fr.rebuild) {
+            if (tid == 0) {
+                int s0 = sh.start, c = WS.cage_of[s0], skip = 0;
+                if (c != 0 && WS.cage_ok[c]) {
+                    int o = WS.cage_off[s0], rng = WS.cage_rng[c];
+                    int os[3] = {o / 9 - 1, (o / 3) % 3 - 1, o % 3 - 1};
+                    bool in_range = true, inside = true, sure = true;
+                    for (int a = 0; a < 3; ++a) {
+                        int lo = ((rng >> (4 * a)) & 3) - 1, hi = ((rng >> (4 * a + 2)) & 3) - 1;
+                        if (lo - os[a] < -1 || hi - os[a] > 1) in_range = false;
+                        double f = WS.cage_f[3 * (size_t)c + a] - (double)os[a];
+                        if (pw_abs(f - sh.bound[0]) < 1e-6 || pw_abs(f - sh.bound[1]) < 1e-6) sure = false;
+                        if (!(f >= sh.bound[0] && f < sh.bound[1])) inside = false;
+                    }
+                    if (in_range && sure && !inside) { skip = 1; sh.skip_cage = c; sh.skip_off = o; }
+                }
+                sh.skip = skip;
+            }
+            T::sync();
+            if (sh.skip) {
+                const int c = sh.skip_cage, o = sh.skip_off;
+                for (int q = tid; q < n; q += T::SIZE)
+                    if (WS.cage_of[q] == c && WS.cage_off[q] == o) WS.remaining[q] = 0;
+                T::sync();
+#if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+                ++rb_skipped;
+#endif
+                continue;
+            }
+        }
         ++mol_serial;
-        if (tid == 0) { work[0] = sh.start; sh.lwork[0][0] = sh.start; sh.n_work = 1; sh.n_final = 0; sh.n_next = 0; }
+        // (read before anybody records anything: the molecule's atoms are entered at its end)
+        const bool first_walk = fr.rebuild && WS.cage_of[sh.start] == 0;
+        if (tid == 0) {
+            work[0] = sh.start; sh.lwork[0][0] = sh.start; sh.n_work = 1; sh.n_final = 0; sh.n_next = 0;
+            sh.wflags = 0;
+            for (int a = 0; a < 3; ++a) { sh.off_lo[a] = 1; sh.off_hi[a] = -1; }
+        }
         if (use_bits)
             for (int i = tid; i < WS.bit_words; i += T::SIZE) bits_final[i] = 0;
         T::sync();
@@ -555,9 +621,9 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                     if (T::lane() == 0) seg_cnt[k] = 0;
                     T::wave_sync();
 #if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-                    rb_expand<T>(fr, WS, &w.status, lw ? wl[c0 + k] : work[c0 + k], k, T::wave() == 0 ? rb_xp : nullptr);
+                    rb_expand<T>(fr, WS, &w.status, (int*)&sh.wflags, lw ? wl[c0 + k] : work[c0 + k], k, T::wave() == 0 ? rb_xp : nullptr);
 #else
-                    rb_expand<T>(fr, WS, &w.status, lw ? wl[c0 + k] : work[c0 + k], k);
+                    rb_expand<T>(fr, WS, &w.status, (int*)&sh.wflags, lw ? wl[c0 + k] : work[c0 + k], k);
 #endif
                     T::wave_sync();
                     if (T::lane() == 0) {
@@ -668,12 +734,51 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                 for (int c = 0; c < 3; ++c) {
                     double r = __builtin_rint(cf[c] * 1e8) / 1e8;
                     in = in && (r >= sh.bound[0]) && (r < sh.bound[1]);
+                    sh.cf[c] = cf[c];
                 }
                 sh.red_i[0] = in ? 1 : 0;
             }
             T::sync();
             keep = sh.red_i[0] != 0;
             T::sync();
+            // first walk through this molecule: remember where it met every atom
+            if (first_walk) {
+                for (int k = tid; k < m; k += T::SIZE) {
+                    int q, ax, ay, az;
+                    const double* P;
+                    rb_decode(WS, n, WS.final_[k], &q, &ax, &ay, &az, &P);
+#if defined(__HIP_DEVICE_COMPILE__)
+                    int old = atomicExch(&WS.cage_of[q], mol_serial);
+#else
+                    int old = WS.cage_of[q];
+                    WS.cage_of[q] = mol_serial;
+#endif
+                    if (old != 0) rb_atomic_or((int*)&sh.wflags, RB_WF_REPEAT);
+                    WS.cage_off[q] = (unsigned char)((ax + 1) * 9 + (ay + 1) * 3 + (az + 1));
+                    int ao[3] = {ax, ay, az};
+                    for (int a = 0; a < 3; ++a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                        atomicMin((int*)&sh.off_lo[a], ao[a]);
+                        atomicMax((int*)&sh.off_hi[a], ao[a]);
+#else
+                        if (ao[a] < sh.off_lo[a]) sh.off_lo[a] = ao[a];
+                        if (ao[a] > sh.off_hi[a]) sh.off_hi[a] = ao[a];
+#endif
+                    }
+                }
+                T::sync();
+                if (tid == 0) {
+                    int rng = 0;
+                    for (int a = 0; a < 3; ++a) {
+                        rng |= (sh.off_lo[a] + 1) << (4 * a);
+                        rng |= (sh.off_hi[a] + 1) << (4 * a + 2);
+                        WS.cage_f[3 * (size_t)mol_serial + a] = sh.cf[a];
+                    }
+                    WS.cage_rng[mol_serial] = rng;
+                    WS.cage_ok[mol_serial] = sh.wflags == 0 ? 1 : 0;
+                }
+                T::sync();
+            }
         }
         RB_TICK(9);
 #if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -721,7 +826,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                rb_prof[0] / 100, rb_prof[1] / 100, rb_prof[2] / 100, rb_prof[3] / 100, rb_prof[4] / 100, rb_prof[5] / 100,
                rb_prof[6] / 100, rb_prof[7] / 100, rb_prof[8] / 100, rb_prof[9] / 100, rb_prof[10] / 100, rb_layers, rb_mols,
                w.n_mol);
-    if (tid == 0 && blockIdx.x == 0) printf("RBPROF wave 0 candidate scan: %d images, %d rounds\n", rb_imgs, rb_rounds);
+    if (tid == 0 && blockIdx.x == 0) printf("RBPROF wave 0 candidate scan: %d images, %d rounds; walks predicted and skipped: %d\n", rb_imgs, rb_rounds, rb_skipped);
     if (tid == 0 && blockIdx.x == 0)
         printf("RBPROF expand (wave 0) us: q0 loads %lld, candidate flags %lld, coordinates %lld, test+append %lld, tail %lld\n",
                rb_xp[0] / 100, rb_xp[1] / 100, rb_xp[2] / 100, rb_xp[3] / 100, rb_xp[4] / 100);
