@@ -466,7 +466,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
             for (; images; images &= images - 1) {        // ascending image order
                 const int img = __builtin_ctzll(images);
                 const double* X = fr.rebuild ? &WS.S[3 * (size_t)img * n] : WS.V;
-                constexpr int UN = 8;        // blocks of candidates whose loads are in flight together
+                constexpr int UN = 11;       // blocks of candidates whose loads are in flight together
 #if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
                 ++rb_imgs;
 #endif
