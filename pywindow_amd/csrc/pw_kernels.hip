@@ -61,7 +61,7 @@ constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STA
 // MASK: the stage bits this instantiation can execute (the run-time mask is ANDed with it), so
 // the launches of the pipeline carry only the code -- and the registers -- of their own stages
 template <int NW, unsigned MASK>
-__global__ void __launch_bounds__(NW * 64, MASK == PW_KERNEL_AVERAGE ? 3 : 2)
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (MASK == PW_KERNEL_AVERAGE ? 3 : 2))
 pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
                   const double* __restrict__ vdw, const double* __restrict__ mass, unsigned stages,
                   int nmax, int nrot, int nlb, TeamWorkspace* __restrict__ workspaces,
@@ -300,7 +300,7 @@ static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool 
         nw >>= 1;
     }
     int per_cu = (int)(c->lds_per_cu / p->lds);
-    int wave_cap = 16 / p->nw;  // kernels are built for 2 waves per SIMD
+    int wave_cap = p->nw == 8 ? 1 : 16 / p->nw;  // kernels are built for 2 waves per SIMD (8-wave teams: one team per CU)
     if (per_cu > wave_cap) per_cu = wave_cap;
     if (per_cu < 1) per_cu = 1;
     long grid = (long)c->n_cu * per_cu;

@@ -1947,7 +1947,10 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         // whole rounds: one path per thread.  The last, partial round would keep a handful of
         // lanes busy for a full path each, so its paths are cut into points instead: one
         // (path, point) per thread, then one thread per path folds its points.
-        const int whole = T::SIZE > 1 ? (ncand / T::SIZE) * T::SIZE : ncand;
+        // (a last round that still fills a quarter of the team stays with one path per thread: a
+        // thread's six points share every atom read, a (path, point) item reads all atoms for one)
+        int whole = T::SIZE > 1 ? (ncand / T::SIZE) * T::SIZE : ncand;
+        if ((ncand - whole) * 4 >= T::SIZE) whole = ncand;
         for (int j = T::tid(); j < whole; j += T::SIZE) {
             int k = labels[j];
             double g2, chunk[3];
