@@ -34,6 +34,7 @@ namespace pw {
 constexpr int RB_NB_CAP = 32;      // conservative neighbour candidates kept per heavy atom
 constexpr int RB_SEG_CAP = 32;     // bonded neighbours one atom can contribute per layer
 constexpr int RB_CHUNK = 64;       // atoms of a layer expanded between two merges
+constexpr int RB_LFINAL = 1024;    // atoms of the molecule being walked kept in team-shared memory
 constexpr int RB_LWORK = 512;      // layer width kept in team-shared memory (wider layers: global lists)
 constexpr int RB_WF_TRUNCATED = 1;  // a neighbour candidate lay outside the 3x3x3 supercell
 constexpr int RB_WF_MARGINAL = 2;   // a distance within 1e-6 of a threshold of the bond test
@@ -114,7 +115,8 @@ struct RebuildShared {
     int wflags;                    // RB_WF_* of the walk in progress
     int off_lo[3], off_hi[3];      // image offsets it reached
     int skip, skip_cage, skip_off; // the walk from `start` is predicted (see rebuild_frame)
-    int lwork[2][RB_LWORK];        // the current and the next layer (layers up to RB_LWORK atoms)
+    int lwork[2][RB_LWORK];        // the first RB_LWORK atoms of the current and of the next layer
+    int lfinal[RB_LFINAL];         // the first RB_LFINAL atoms of the molecule
 };
 
 struct RebuildWs {
@@ -159,7 +161,7 @@ struct RebuildWs {
     PW_HD static size_t fast_bytes(int n, int rebuild, bool with_bits) {
         size_t words = (ids(n, rebuild) + 63) / 64;
         return (size_t)RB_CHUNK * RB_SEG_CAP * 8 + (size_t)RB_CHUNK * 4 + (with_bits ? 2 * words * 8 : 0) +
-               ((sizeof(RebuildShared) + 15) & ~(size_t)15);
+               ((sizeof(RebuildShared) + 15) & ~(size_t)15) + (with_bits ? (((size_t)n + 15) & ~(size_t)15) : 0);
     }
     PW_HD void attach_fast(unsigned char* base, int n, int rebuild, bool with_bits) {
         sh = (RebuildShared*)base;
@@ -173,6 +175,10 @@ struct RebuildWs {
         bits_temp = with_bits ? (unsigned long long*)base + bit_words : nullptr;
         base += with_bits ? 2 * (size_t)bit_words * 8 : 0;
         seg_cnt = (int*)base;
+        base += (size_t)RB_CHUNK * 4;
+        // the atom list ("remaining") is read and written at every step of the walk: with the bit sets
+        // it moves into team-shared memory (carve() pointed it into the slab)
+        if (with_bits) remaining = base;
     }
     // `base` -> [RebuildWs header][arrays]; returns the header
     PW_HD static RebuildWs* carve(unsigned char* base, int n, int rebuild, int team) {
@@ -585,7 +591,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
         // (read before anybody records anything: the molecule's atoms are entered at its end)
         const bool first_walk = fr.rebuild && WS.cage_of[sh.start] == 0;
         if (tid == 0) {
-            work[0] = sh.start; sh.lwork[0][0] = sh.start; sh.n_work = 1; sh.n_final = 0; sh.n_next = 0;
+            sh.lwork[0][0] = sh.start; sh.n_work = 1; sh.n_final = 0; sh.n_next = 0;
             sh.wflags = 0;
             for (int a = 0; a < 3; ++a) { sh.off_lo[a] = 1; sh.off_hi[a] = -1; }
         }
@@ -603,12 +609,12 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
             if (nw == 0) break;
             ++layer_serial;
             const int nf = sh.n_final;
-            const bool lw = nw <= RB_LWORK;
             const PW_LDS int* wl = sh.lwork[cur];
             PW_LDS int* wl_next = sh.lwork[cur ^ 1];
             for (int k = tid; k < nw; k += T::SIZE) {
-                int id = lw ? wl[k] : work[k];
-                WS.final_[nf + k] = id;
+                int id = k < RB_LWORK ? wl[k] : work[k];
+                if (nf + k < RB_LFINAL) sh.lfinal[nf + k] = id;
+                else WS.final_[nf + k] = id;
                 if (use_bits) rb_atomic_or64((unsigned long long*)&bits_final[id >> 6], 1ull << (id & 63));
                 else WS.stamp_final[id] = mol_serial;
             }
@@ -621,9 +627,9 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                     if (T::lane() == 0) seg_cnt[k] = 0;
                     T::wave_sync();
 #if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-                    rb_expand<T>(fr, WS, &w.status, (int*)&sh.wflags, lw ? wl[c0 + k] : work[c0 + k], k, T::wave() == 0 ? rb_xp : nullptr);
+                    rb_expand<T>(fr, WS, &w.status, (int*)&sh.wflags, c0 + k < RB_LWORK ? wl[c0 + k] : work[c0 + k], k, T::wave() == 0 ? rb_xp : nullptr);
 #else
-                    rb_expand<T>(fr, WS, &w.status, (int*)&sh.wflags, lw ? wl[c0 + k] : work[c0 + k], k);
+                    rb_expand<T>(fr, WS, &w.status, (int*)&sh.wflags, c0 + k < RB_LWORK ? wl[c0 + k] : work[c0 + k], k);
 #endif
                     T::wave_sync();
                     if (T::lane() == 0) {
@@ -644,7 +650,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                 // the last of them has been expanded
                 if (last)
                     for (int k = tid; k < nw; k += T::SIZE) {
-                        int id = lw ? wl[k] : work[k];
+                        int id = k < RB_LWORK ? wl[k] : work[k];
                         if (id < n) WS.remaining[id] = 0;
                     }
                 // unique(working_list_temp), then "not in final_molecule" (utilities.py:1044-1055)
@@ -667,7 +673,8 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                                 if (WS.stamp_final[id] == mol_serial) continue;
                             }
                             if (nn < RB_LWORK) wl_next[nn] = id;
-                            work_next[nn++] = id;
+                            else work_next[nn] = id;
+                            ++nn;
                         }
                     }
                     if (last) {
@@ -700,7 +707,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                 for (int k = tid; k < m; k += T::SIZE) {
                     int q, ax, ay, az;
                     const double* P;
-                    rb_decode(WS, n, WS.final_[k], &q, &ax, &ay, &az, &P);
+                    rb_decode(WS, n, (k < RB_LFINAL ? sh.lfinal[k] : WS.final_[k]), &q, &ax, &ay, &az, &P);
                     double mq = fr.mass[q];
                     tx[k] = P[0] * mq; tx[tc + k] = P[1] * mq; tx[2 * tc + k] = P[2] * mq; tx[3 * tc + k] = mq;
                 }
@@ -712,7 +719,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                 for (int k = tid; k < m; k += T::SIZE) {
                     int q, ax, ay, az;
                     const double* P;
-                    rb_decode(WS, n, WS.final_[k], &q, &ax, &ay, &az, &P);
+                    rb_decode(WS, n, (k < RB_LFINAL ? sh.lfinal[k] : WS.final_[k]), &q, &ax, &ay, &az, &P);
                     WS.msum[k] = fr.mass[q];
                 }
                 T::sync();
@@ -720,7 +727,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                     sh.com[col] = seq_sum_blocked(m, [&](int k) {
                         int q, ax, ay, az;
                         const double* P;
-                        rb_decode(WS, n, WS.final_[k], &q, &ax, &ay, &az, &P);
+                        rb_decode(WS, n, (k < RB_LFINAL ? sh.lfinal[k] : WS.final_[k]), &q, &ax, &ay, &az, &P);
                         return P[col] * fr.mass[q];
                     });
                 if (tid == SUM_THREAD) sh.red_v[0] = np_sum_serial(WS.msum, m);
@@ -746,7 +753,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                 for (int k = tid; k < m; k += T::SIZE) {
                     int q, ax, ay, az;
                     const double* P;
-                    rb_decode(WS, n, WS.final_[k], &q, &ax, &ay, &az, &P);
+                    rb_decode(WS, n, (k < RB_LFINAL ? sh.lfinal[k] : WS.final_[k]), &q, &ax, &ay, &az, &P);
 #if defined(__HIP_DEVICE_COMPILE__)
                     int old = atomicExch(&WS.cage_of[q], mol_serial);
 #else
@@ -791,7 +798,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                 for (int k = tid; k < m; k += T::SIZE) {
                     int q, ax, ay, az;
                     const double* P;
-                    int id = WS.final_[k];
+                    int id = (k < RB_LFINAL ? sh.lfinal[k] : WS.final_[k]);
                     rb_decode(WS, n, id, &q, &ax, &ay, &az, &P);
                     out.src_atom[base + k] = q;
                     out.src_image[base + k] = id < n ? (signed char)-1 : (signed char)((id - n) / n);

@@ -1944,6 +1944,8 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         T::sync();
         int ncand = v.n_surv;
         int evals = 0;
+        if (T::wave() == 0) PW_T1(ws, 30, t_smp);     // rays + compaction
+        PW_T0(t_path);
         // whole rounds: one path per thread.  The last, partial round would keep a handful of
         // lanes busy for a full path each, so its paths are cut into points instead: one
         // (path, point) per thread, then one thread per path folds its points.
@@ -2002,6 +2004,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             (void)fits;
         }
         T::sync();
+        if (T::wave() == 0) PW_T1(ws, 31, t_path);    // path scans
         if (T::wave() == 0) {
             int m = 0;
             for (int base = 0; base < ncand; base += T::WSIZE) {
