@@ -142,6 +142,8 @@ struct RebuildWs {
     unsigned char* remaining;   // n
     unsigned char* alias;       // n
     // what the first walk through a molecule learned (rebuild only; see "walks that can be predicted")
+    float* scan;          // 3 x (27n | n): x, y, z of every (image, atom) in single precision, for the
+                          // conservative candidate scan only (coalesced 4-byte reads)
     int* cage_of;         // n: serial of the first walk that visited the atom, 0 = none yet
     unsigned char* cage_off;    // n: image (0..26) in which that walk met the atom
     unsigned char* cage_ok;     // n + 1, by walk serial: the walk was clean (no truncation / marginal bond / repeat)
@@ -155,7 +157,8 @@ struct RebuildWs {
         (void)team;
         size_t d = (size_t)3 * n + n + (rebuild ? (size_t)81 * n : 0) + id + 3 * ((size_t)n + 1);
         size_t i = (size_t)n + (size_t)n * RB_NB_CAP + 5 * id + 2 * ((size_t)n + 1);
-        return sizeof(RebuildWs) + 64 + d * 8 + i * 4 + 4 * (size_t)n + 64 + 64;
+        return sizeof(RebuildWs) + 64 + d * 8 + i * 4 + 4 * (size_t)n + 64 + 64 +
+               3 * (rebuild ? (size_t)27 * n : (size_t)n) * 4 + 64;
     }
     // fast memory: the hit segments always, the two bit sets when `with_bits`
     PW_HD static size_t fast_bytes(int n, int rebuild, bool with_bits) {
@@ -203,6 +206,8 @@ struct RebuildWs {
         w->alias = p; p += n;
         w->cage_off = p; p += n;
         w->cage_ok = p; p += (size_t)n + 1;
+        p = (unsigned char*)(((size_t)p + 63) & ~(size_t)63);
+        w->scan = (float*)p; p += 3 * (rebuild ? (size_t)27 * n : (size_t)n) * 4;
         return w;
     }
 };
@@ -362,6 +367,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
         double x = rb_round8(fr.xyz[3 * i]), y = rb_round8(fr.xyz[3 * i + 1]), z = rb_round8(fr.xyz[3 * i + 2]);
         WS.V[3 * i] = x; WS.V[3 * i + 1] = y; WS.V[3 * i + 2] = z;
         WS.Vxx[i] = sq3(x, y, z);
+        if (!fr.rebuild) { WS.scan[i] = (float)x; WS.scan[(size_t)n + i] = (float)y; WS.scan[2 * (size_t)n + i] = (float)z; }
         WS.remaining[i] = 1;
         WS.alias[i] = 0;
         WS.nb_cnt[i] = 0;
@@ -384,6 +390,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                 rb_mat3(fr.lattice, fq[0] + sa, fq[1] + sb, fq[2] + sc, c);
                 size_t s = (size_t)img * n + i;
                 WS.S[3 * s] = rb_round8(c[0]); WS.S[3 * s + 1] = rb_round8(c[1]); WS.S[3 * s + 2] = rb_round8(c[2]);
+                WS.scan[s] = (float)c[0]; WS.scan[(size_t)27 * n + s] = (float)c[1]; WS.scan[(size_t)54 * n + s] = (float)c[2];
             }
             size_t s0 = (size_t)RB_CENTRAL * n + i;
             WS.alias[i] = (WS.S[3 * s0] == WS.V[3 * i] && WS.S[3 * s0 + 1] == WS.V[3 * i + 1] &&
@@ -438,7 +445,6 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
     // ---- conservative candidate lists around every heavy atom ----------------------------
     {
         const double reach = fr.max_dist + 1e-3;
-        const double reach2 = reach * reach;
         // one wave per heavy atom, lanes over the atoms of an image (coalesced reads); the hits of a
         // pass keep their (image, atom) order through a ballot prefix
         // lane i < 27 keeps the (widened) box of image i: one comparison pass per atom gives the
@@ -453,6 +459,10 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
             if (fr.terminal[p]) continue;
             const double* C = fr.rebuild ? &WS.S[3 * ((size_t)RB_CENTRAL * n + p)] : &WS.V[3 * p];
             double cx = C[0], cy = C[1], cz = C[2];
+            const float fcx = (float)cx, fcy = (float)cy, fcz = (float)cz;
+            // single precision moves a coordinate by at most 6e-8 of its size: the slack grows with it
+            const double reach_f = fr.max_dist + 2e-3 + 5e-7 * (pw_abs(cx) + pw_abs(cy) + pw_abs(cz));
+            const float reach2f = (float)(reach_f * reach_f);
             int cnt = 0;
             unsigned long long images = 1ull << RB_CENTRAL;
             if (fr.rebuild) {
@@ -471,7 +481,10 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
             }
             for (; images; images &= images - 1) {        // ascending image order
                 const int img = __builtin_ctzll(images);
-                const double* X = fr.rebuild ? &WS.S[3 * (size_t)img * n] : WS.V;
+                // single-precision copies, one array per component: the test only has to be conservative
+                // (reach carries 2e-3 of slack, single precision moves a distance here by < 1e-4)
+                const size_t comp = fr.rebuild ? (size_t)27 * n : (size_t)n;
+                const float* X = WS.scan + (fr.rebuild ? (size_t)img * n : 0);
                 constexpr int UN = 11;       // blocks of candidates whose loads are in flight together
 #if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
                 ++rb_imgs;
@@ -481,20 +494,20 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                     ++rb_rounds;
 #endif
                     bool hit[UN];
-                    double vx[UN], vy[UN], vz[UN];
+                    float vx[UN], vy[UN], vz[UN];
                     // unconditional (clamped) loads, so that all of them are issued before the first use
 #pragma unroll
                     for (int u = 0; u < UN; ++u) {
                         int q = q0 + u * T::WSIZE + T::lane();
                         int qq = q < n ? q : n - 1;
-                        vx[u] = X[3 * qq]; vy[u] = X[3 * qq + 1]; vz[u] = X[3 * qq + 2];
+                        vx[u] = X[qq]; vy[u] = X[comp + qq]; vz[u] = X[2 * comp + qq];
                     }
 #pragma unroll
                     for (int u = 0; u < UN; ++u) {
                         int q = q0 + u * T::WSIZE + T::lane();
-                        double dx = vx[u] - cx, dy = vy[u] - cy, dz = vz[u] - cz;
-                        double d2 = dx * dx + dy * dy + dz * dz;
-                        hit[u] = q < n && d2 < reach2 && !(img == RB_CENTRAL && q == p);
+                        float dx = vx[u] - fcx, dy = vy[u] - fcy, dz = vz[u] - fcz;
+                        float d2 = dx * dx + dy * dy + dz * dz;
+                        hit[u] = q < n && d2 < reach2f && !(img == RB_CENTRAL && q == p);
                     }
 #pragma unroll
                     for (int u = 0; u < UN; ++u) {
