@@ -23,16 +23,14 @@ def set_default_device(device: int) -> None:
     _default_device = int(device)
 
 
-def context(device: int | None = None, lane: int = 0) -> "_lib.Context":
-    """Lazily created per-device context (streams + workspaces).  ``lane`` > 0 gives further
-    contexts on the same device for host threads that keep their own launches in flight."""
+def context(device: int | None = None) -> "_lib.Context":
+    """Lazily created per-device context (streams + workspaces)."""
     dev = _default_device if device is None else int(device)
-    key = dev if lane == 0 else (dev, int(lane))
     with _lock:
-        ctx = _contexts.get(key)
+        ctx = _contexts.get(dev)
         if ctx is None:
             ctx = _lib.Context(dev)
-            _contexts[key] = ctx
+            _contexts[dev] = ctx
         return ctx
 
 

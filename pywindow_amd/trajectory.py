@@ -24,8 +24,8 @@ from . import _lib, engine
 from .element_data import MASS, VDW, element_ids
 from .molecular import MolecularSystem, decipher_atom_key
 
-#: frames per launch pair of a long modular analysis (see Trajectory._run_modular)
-MODULAR_CHUNK = 512
+#: most frames a modular analysis pushes through the device in one piece (see Trajectory._run_modular)
+MODULAR_CHUNK = 8192
 
 
 class _FunctionError(Exception):
@@ -263,39 +263,10 @@ class DLPOLY:
             finally:
                 res.free()
 
-        if len(frames) <= 2 * MODULAR_CHUNK:
-            parts = [one_chunk(engine.context(dev), frames)]
-        else:
-            # long trajectories: chunks of frames on two host threads with a context (streams,
-            # workspaces) each, so that the re-assembly launch of one chunk runs beside the analysis
-            # launches of another (both are latency-bound and leave most of the GPU idle on their own)
-            import itertools
-            import threading
-
-            chunks = [frames[i:i + MODULAR_CHUNK] for i in range(0, len(frames), MODULAR_CHUNK)]
-            parts = [None] * len(chunks)
-            take = itertools.count()
-            lock = threading.Lock()
-            errors = []
-
-            def worker(ctx):            # a thread owns its context; chunks are handed out in order
-                try:
-                    while not errors:
-                        with lock:
-                            k = next(take)
-                        if k >= len(chunks):
-                            return
-                        parts[k] = one_chunk(ctx, chunks[k])
-                except BaseException as exc:  # noqa: BLE001 - re-raised on the calling thread
-                    errors.append(exc)
-
-            threads = [threading.Thread(target=worker, args=(engine.context(dev, lane=k),)) for k in range(2)]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-            if errors:
-                raise errors[0]
+        # very long trajectories go through in pieces (the frames and the re-assembled molecules of a
+        # piece are resident on the device at once); each piece is still two launches
+        ctx = engine.context(dev)
+        parts = [one_chunk(ctx, frames[i:i + MODULAR_CHUNK]) for i in range(0, len(frames), MODULAR_CHUNK)]
         recs = np.concatenate([p[0] for p in parts])
         n_mol = np.concatenate([p[1] for p in parts])
         unit_frame = np.repeat(np.asarray(frames, np.int64), n_mol)

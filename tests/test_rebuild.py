@@ -221,9 +221,8 @@ def test_periodic_trajectory_modular_rebuild(hip_ctx, tmp_path):
 
 
 @pytest.mark.gpu
-def test_long_modular_analysis_in_chunks_on_two_contexts(hip_ctx, tmp_path, monkeypatch):
-    """A long periodic trajectory is analysed in chunks of frames by two host threads with a
-    context each (re-assembly of one chunk beside the analysis of another): same records, same
+def test_long_modular_analysis_in_pieces(hip_ctx, tmp_path, monkeypatch):
+    """A very long periodic trajectory goes through the device in pieces: same records, same
     order as the one-piece analysis."""
     import pywindow_amd as pw
     from pywindow_amd import synth, trajectory

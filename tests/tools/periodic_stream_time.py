@@ -1,5 +1,4 @@
-"""Long periodic trajectory through DLPOLY.modular_records (GPU box): one piece against chunks on
-two contexts.  python tests/tools/periodic_stream_time.py [frames]"""
+"""Long periodic trajectory through DLPOLY.modular_records (GPU box): one piece against several.  python tests/tools/periodic_stream_time.py [frames]"""
 import pathlib
 import sys
 import tempfile
@@ -24,7 +23,7 @@ with tempfile.TemporaryDirectory() as tmp:
     print(f"wrote {n} frames in {time.perf_counter() - t0:.1f} s", flush=True)
     traj = pw.DLPOLY(path)
     traj.modular_records(frames=list(range(8)), rebuild=True, forcefield="opls")      # warm-up
-    for chunk in (10 ** 9, 1024, 512, 256):
+    for chunk in (10 ** 9, 1024):
         trajectory.MODULAR_CHUNK = chunk
         t0 = time.perf_counter()
         recs, uf, um = traj.modular_records(rebuild=True, forcefield="opls")
