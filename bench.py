@@ -29,6 +29,7 @@ ALGO_FLOP_PER_UNIT = 2.0e7
 HBM_PEAK_GBS = 8000.0
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01h_hbm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary
 FP64_VECTOR_PEAK_TFLOPS = 78.6
+COUNTER_FILE = os.path.join(ROOT, "profiles", "r01i_instruction_counters.json")    # rocprofv3 --pmc SQ_INSTS_* summary
 
 
 def cpu_baseline(elements, frames, vdw, mass, budget_s=20.0):
@@ -177,6 +178,20 @@ def main():
             traffic = tj["per_launch_bytes"] * (args.frames / tj["units_per_launch"])
         except (OSError, KeyError, ValueError):
             traffic = None
+        # VALU issue utilisation from the profiled wave-level instruction count (committed summary) and
+        # the kernel time measured in this run: instructions x 4 SIMD cycles / (SIMDs x clock x time)
+        valu_issue = None
+        try:
+            with open(COUNTER_FILE) as fh:
+                cj = json.load(fh)
+            per_unit = cj["per_launch"]["SQ_INSTS_VALU"] / cj["units_per_launch"]
+            vi = cj["valu_issue"]
+            valu_issue = {"wave_instructions_per_launch": per_unit * args.frames,
+                          "frac": per_unit * args.frames * vi["simd_cycles_per_wave_instruction"]
+                                  / (vi["simds"] * vi["clock_ghz"] * 1e9 * k_ms * 1e-3),
+                          "source": "profiles/r01i_instruction_counters.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
+        except (OSError, KeyError, ValueError):
+            valu_issue = None
         line = {
             "metric": "trajectory frames/sec full_analysis (pore+windows), CC3 1k-frame",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -195,7 +210,8 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_UNIT * args.frames,
                          "fp64_valu": {"achieved_tflops": units_per_s * ALGO_FLOP_PER_UNIT / 1e12,
                                        "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                                       "frac": units_per_s * ALGO_FLOP_PER_UNIT / 1e12 / FP64_VECTOR_PEAK_TFLOPS}},
+                                       "frac": units_per_s * ALGO_FLOP_PER_UNIT / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                       "valu_issue_measured": valu_issue}},
         }
         if not args.no_secondary and world == 1:
             line["secondary"] = secondary(ctx, elements, vdw, mass)
