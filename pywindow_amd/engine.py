@@ -83,6 +83,48 @@ def warn_like_reference(rec) -> None:
         logger.warning("pywindow_amd: workspace limit hit (status=%d); results truncated.", st)
 
 
+def records_to_properties(recs: np.ndarray, stages: int = _lib.STAGE_ALL) -> list:
+    """Many records -> the nested dicts of ``record_to_properties``, column-wise: every field is
+    converted to Python objects once for the whole array (the per-record route spends its time in
+    numpy scalar look-ups), and the conditions the reference logs are reported on the way."""
+    n = len(recs)
+    if n == 0:
+        return []
+    for rec in recs[recs["status"] != 0]:
+        warn_like_reference(rec)
+    n_atoms = recs["n_atoms"].tolist()
+    com = recs["com"].copy()
+    maxd, maxd_i, maxd_j = recs["maxd"].tolist(), recs["maxd_i"].tolist(), recs["maxd_j"].tolist()
+    avg = recs["avg_d"].tolist()
+    pore_d, pore_atom, pore_vol = recs["pore_d"].tolist(), recs["pore_atom"].tolist(), recs["pore_vol"].tolist()
+    opt_d, opt_atom = recs["pore_opt_d"].tolist(), recs["pore_opt_atom"].tolist()
+    opt_c, opt_vol = recs["pore_opt_c"].copy(), recs["pore_vol_opt"].tolist()
+    n_win = recs["n_windows"].tolist()
+    win_d, win_c = recs["win_d"], recs["win_c"]
+    with_avg = bool(stages & _lib.STAGE_AVG)
+    with_opt = bool(stages & (_lib.STAGE_OPT | _lib.STAGE_WINDOWS))
+    with_win = bool(stages & _lib.STAGE_WINDOWS)
+    out = []
+    for i in range(n):
+        props = {"no_of_atoms": n_atoms[i], "centre_of_mass": com[i],
+                 "maximum_diameter": {"diameter": maxd[i], "atom_1": maxd_i[i], "atom_2": maxd_j[i]}}
+        if with_avg:
+            props["average_diameter"] = avg[i]
+        props["pore_diameter"] = {"diameter": pore_d[i], "atom": pore_atom[i]}
+        props["pore_volume"] = pore_vol[i]
+        if with_opt:
+            props["pore_diameter_opt"] = {"diameter": opt_d[i], "atom_1": opt_atom[i], "centre_of_mass": opt_c[i]}
+            props["pore_volume_opt"] = opt_vol[i]
+        if with_win:
+            k = n_win[i]
+            if k < 0:
+                props["windows"] = {"diameters": None, "centre_of_mass": None}
+            else:
+                props["windows"] = {"diameters": win_d[i, :k].copy(), "centre_of_mass": win_c[i, :k].copy()}
+        out.append(props)
+    return out
+
+
 def record_to_properties(rec, stages: int = _lib.STAGE_ALL) -> dict:
     """One result record -> the nested dict ``Molecule.full_analysis()`` returns."""
     props: dict = {"no_of_atoms": int(rec["n_atoms"])}

@@ -219,9 +219,8 @@ class DLPOLY:
             recs = gather_records(recs, len(sel), rank, world, dist)
             if rank != 0:
                 return
-        for f, rec in zip(sel, recs):
-            engine.warn_like_reference(rec)
-            self.analysis_output[f] = {"0": engine.record_to_properties(rec)}
+        for f, props in zip(sel, engine.records_to_properties(recs)):
+            self.analysis_output[f] = {"0": props}
 
     def _run(self, frames: list[int], vdw, mass, device):
         if not frames:
@@ -294,9 +293,8 @@ class DLPOLY:
             uframe, umol = tags[:, 0], tags[:, 1]
         for f in sel:
             self.analysis_output[f] = {}
-        for rec, f, m in zip(recs, uframe, umol):
-            engine.warn_like_reference(rec)
-            self.analysis_output[int(f)][int(m)] = engine.record_to_properties(rec)
+        for props, f, m in zip(engine.records_to_properties(recs), uframe.tolist(), umol.tolist()):
+            self.analysis_output[f][m] = props
 
 
 def _dist_state(distributed):

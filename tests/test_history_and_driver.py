@@ -107,3 +107,38 @@ def test_number_decoding_equals_python_float(tmp_path):
     for k in range(nframes):
         want[0, 0] = float(k)
         assert got[k].tobytes() == want.tobytes(), k
+
+
+def test_bulk_record_conversion_equals_the_per_record_one():
+    """engine.records_to_properties (column-wise) builds the same nested dicts, value for value and
+    type for type, as record_to_properties does record by record."""
+    from pywindow_amd import engine
+
+    g = load_group("synth64")
+    recs = np.zeros(6, dtype=_lib.UNIT_OUT_DTYPE)
+    rng = np.random.default_rng(2)
+    for name in recs.dtype.names:
+        col = recs[name]
+        if col.dtype.kind == "f":
+            recs[name] = rng.normal(size=col.shape)
+        else:
+            recs[name] = rng.integers(0, 5, size=col.shape)
+    recs["status"] = 0
+    recs["n_windows"] = [4, 0, -1, 16, 2, 1]
+    del g
+
+    def same(a, b):
+        assert type(a) is type(b), (type(a), type(b))
+        if isinstance(a, dict):
+            assert list(a) == list(b)
+            for k in a:
+                same(a[k], b[k])
+        elif isinstance(a, np.ndarray):
+            assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b)
+        else:
+            assert a == b
+
+    for stages in (_lib.STAGE_ALL, _lib.STAGE_BASIC, _lib.STAGE_BASIC | _lib.STAGE_AVG, _lib.STAGE_OPT):
+        bulk = engine.records_to_properties(recs, stages)
+        for rec, props in zip(recs, bulk):
+            same(props, engine.record_to_properties(rec, stages))
