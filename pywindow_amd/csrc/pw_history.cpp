@@ -186,26 +186,55 @@ int pw_history_open(const char* path, pw_history** out) {
     h->keytrj = 0;
     h->imcon = 0;
     h->natoms = 0;
-    const char* p = h->data;
     const char* end = h->data + h->size;
-    int line = 0;
-    while (p < end) {
-        const char* le = line_end(p, end);
-        ++line;
-        if (line == 2 && h->frame_start.empty()) {
+    {
+        // header: the second line carries keytrj, imcon, natms
+        const char* l1 = line_end(h->data, end);
+        if (l1 < end) {
+            const char* p2 = l1 + 1;
+            const char* l2 = line_end(p2, end);
             double v[3];
-            if (parse_doubles(p, le, v, 3) == 3) {
+            if (!first_token_is(p2, l2, "timestep") && parse_doubles(p2, l2, v, 3) == 3) {
                 h->keytrj = (int)v[0];
                 h->imcon = (int)v[1];
                 h->natoms = (int64_t)v[2];
             }
         }
-        if (first_token_is(p, le, "timestep")) {
-            if (!h->frame_start.empty()) h->frame_end.push_back((size_t)(p - h->data));
-            h->frame_start.push_back((size_t)(p - h->data));
-        }
-        p = le < end ? le + 1 : end;
     }
+    // frame starts: lines whose first token is "timestep".  The file is cut into byte ranges, one
+    // host thread each; a range begins at the first line start at or after its first byte.
+    unsigned hw = std::thread::hardware_concurrency();
+    int nthreads = hw ? (int)hw : 1;
+    if (nthreads > 16) nthreads = 16;
+    if ((size_t)nthreads > h->size / (1u << 20)) nthreads = (int)(h->size / (1u << 20));
+    if (nthreads < 1) nthreads = 1;
+    std::vector<std::vector<size_t>> found((size_t)nthreads);
+    auto scan = [&](int t) {
+        const char* lo = h->data + h->size * (size_t)t / (size_t)nthreads;
+        const char* hi = h->data + h->size * (size_t)(t + 1) / (size_t)nthreads;
+        const char* p = lo;
+        if (t > 0 && p[-1] != '\n') {                      // not at a line start: skip the partial line
+            p = line_end(p, end);
+            p = p < end ? p + 1 : end;
+        }
+        while (p < hi) {
+            const char* le = line_end(p, end);
+            if (first_token_is(p, le, "timestep")) found[(size_t)t].push_back((size_t)(p - h->data));
+            p = le < end ? le + 1 : end;
+        }
+    };
+    if (nthreads == 1) {
+        scan(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t) pool.emplace_back(scan, t);
+        for (auto& th : pool) th.join();
+    }
+    for (auto& part : found)
+        for (size_t off : part) {
+            if (!h->frame_start.empty()) h->frame_end.push_back(off);
+            h->frame_start.push_back(off);
+        }
     if (!h->frame_start.empty()) h->frame_end.push_back(h->size);
     *out = h;
     return PW_OK;
