@@ -176,8 +176,8 @@ class DLPOLY:
                 return obj.tolist()
             raise TypeError("Not serializable")
 
-        with path.open("w") as fh:
-            json.dump({str(k): v for k, v in self.analysis_output.items()}, fh, default=enc)
+        # (dumps, not dump: one pass of the C encoder instead of the chunk-by-chunk Python iterator)
+        path.write_text(json.dumps({str(k): v for k, v in self.analysis_output.items()}, default=enc))
 
     def analysis_records(self, frames="all", swap_atoms=None, forcefield=None, device=None) -> np.ndarray:
         """Columnar results: the structured record array (``_lib.UNIT_OUT_DTYPE``) for the
