@@ -169,7 +169,7 @@ int pw_history_open(const char* path, pw_history** out) {
         close(fd);
         return PW_E_BAD_ARG;
     }
-    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);   // page tables in one go
     if (m == MAP_FAILED) {
         close(fd);
         return PW_E_NOMEM;
