@@ -27,7 +27,7 @@ FRAMES = 1000
 ALGO_BYTES_PER_UNIT = 24 * 168 + 600   # coordinates read once + one result record
 ALGO_FLOP_PER_UNIT = 2.0e7
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01h_hbm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01i_hbm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 COUNTER_FILE = os.path.join(ROOT, "profiles", "r01i_instruction_counters.json")    # rocprofv3 --pmc SQ_INSTS_* summary
 
@@ -204,7 +204,7 @@ def main():
                        "windows_eq_4": int((out["n_windows"] == 4).sum())},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "fabric bytes per launch from rocprofv3 PMC (profiles/r01h_hbm_traffic.json); "
+                         "traffic_note": "fabric bytes per launch from rocprofv3 PMC (profiles/r01i_hbm_traffic.json); "
                                          "includes Infinity-Cache hits on the re-used per-team workspaces",
                          "kernel": "pw_analyse_kernel (pipeline: optimiser chains | average diameter | window search)", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_UNIT * args.frames,
