@@ -207,6 +207,11 @@ def main():
                          "traffic_note": "fabric bytes per launch from rocprofv3 PMC (profiles/r01i_hbm_traffic.json); "
                                          "includes Infinity-Cache hits on the re-used per-team workspaces",
                          "kernel": "pw_analyse_kernel (pipeline: optimiser chains | average diameter | window search)", "kernel_ms": k_ms,
+                         "kernel_ms_note": "HIP events around back-to-back analyses / their number: the steady-state period of "
+                                           "the pipeline, whose three launches per analysis overlap each other and the next "
+                                           "analysis; rocprofv3 therefore reports longer per-launch durations "
+                                           "(profiles/r01i_pipeline_kernel_stats.csv: chains 3.8 ms, window search 3.7 ms, "
+                                           "average diameter 1.9 ms, all inside config.single_step_latency_ms)",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_UNIT * args.frames,
                          "fp64_valu": {"achieved_tflops": units_per_s * ALGO_FLOP_PER_UNIT / 1e12,
                                        "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
