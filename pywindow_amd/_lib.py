@@ -214,6 +214,32 @@ EXPORTED_SYMBOLS = [
 _lib = None
 
 
+def _share_torch_hip_runtime() -> None:
+    """One HIP / HSA runtime per process.  PyTorch-ROCm ships its own ``libamdhip64`` (same SONAME as
+    the system one this library links to).  If torch is imported first the loader gives this library
+    torch's copy; the other way round the process would end up with two runtimes, and the second
+    (torch's) finds no GPU.  So when torch is installed its copy is loaded first, without importing
+    torch.  ``PW_SYSTEM_HIP=1`` keeps the system runtime."""
+    import importlib.util
+    import os
+    import sys
+
+    if os.environ.get("PW_SYSTEM_HIP") == "1" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = pathlib.Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            ctypes.CDLL(str(cand), mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libpywindow_hip.so (built by ``__graft_entry__.build()``)."""
     global _lib
@@ -228,6 +254,7 @@ def load():
     import os
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    _share_torch_hip_runtime()
     try:
         L = ctypes.CDLL(str(LIB_PATH))
     except OSError as exc:  # pragma: no cover - depends on the machine

@@ -115,3 +115,16 @@ def test_contexts_batches_and_overlapped_launches(hip_ctx):
     import pathlib
 
     runpy.run_path(str(pathlib.Path(__file__).resolve().parent / "tools" / "stress.py"), run_name="__main__")
+
+
+def test_torch_can_start_after_the_library():
+    """A process that analyses first and touches torch.cuda afterwards (the library loads before
+    torch): both must end up on one HIP runtime, or torch finds no GPU."""
+    import pathlib
+    import subprocess
+    import sys
+
+    tool = pathlib.Path(__file__).resolve().parent / "tools" / "torch_after.py"
+    out = subprocess.run([sys.executable, str(tool), "both"], capture_output=True, text=True, timeout=300,
+                         cwd=str(tool.parents[2]))
+    assert out.returncode == 0 and "torch ok" in out.stdout, out.stdout[-500:] + out.stderr[-1500:]
