@@ -64,7 +64,7 @@ template <int NW, unsigned MASK>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (MASK == PW_KERNEL_AVERAGE ? 3 : 2))
 pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
                   const double* __restrict__ vdw, const double* __restrict__ mass, unsigned stages,
-                  int nmax, int nrot, int nlb, TeamWorkspace* __restrict__ workspaces,
+                  int nmax, int nrot, int nlb, int nframes, int lean, TeamWorkspace* __restrict__ workspaces,
                   unsigned long long* __restrict__ adj_base, unsigned long long* counter,
                   pw_unit_out* __restrict__ out, int role, UnitQueue* queue, int* __restrict__ slots,
                   pw_params prm, const unsigned* __restrict__ rsq_tab) {
@@ -72,7 +72,7 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
     __shared__ long s_unit;
     using T = DeviceTeam<NW>;
     UnitShared sh;
-    sh.carve(lds, nmax, nrot, nlb, MASK == MASK_CHAINS ? 1 : 2);
+    sh.carve(lds, nmax, nrot, nlb, nframes, lean != 0);     // as planned by the host (plan_launch)
     // the optimiser chains are latency-bound and on the critical path: when one shares a SIMD
     // with a bulk wave of another launch it must win the issue arbitration
     if (role == PW_ROLE_PRODUCER) {
@@ -274,27 +274,27 @@ static int ensure_workspace(pw_context* c, int blocks, int adj_blocks) {
 }
 
 struct LaunchPlan {
-    int nw, nrot, nlb, grid;
+    int nw, nrot, nlb, grid, nframes, lean;
     size_t lds;
 };
 
 // team width, LDS carve and grid for one launch.  want_nw: preferred waves per team;
 // rot/lb: whether window frames / optimiser states are needed (per wave).
 static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool rot, int lb_per_team,
-                       LaunchPlan* p, int nframes = 2) {
+                       LaunchPlan* p, int nframes = 2, bool lean = false) {
     const size_t max_lds = 160 * 1024 - 256;
     int nw = want_nw;
     for (;;) {
         int nslot = nw < 4 ? nw : 4;
         int nrot = rot ? nslot : 0;
         int nlb = lb_per_team < 0 ? nslot : lb_per_team;
-        size_t lds = UnitShared::bytes(nmax, nrot, nlb, nframes) + 64;
+        size_t lds = UnitShared::bytes(nmax, nrot, nlb, nframes, lean) + 64;
         if (lds <= max_lds || nw == 1) {
             if (lds > max_lds) {
                 snprintf(g_err, sizeof(g_err), "molecule with %d atoms does not fit in LDS", nmax);
                 return PW_E_TOO_LARGE;
             }
-            p->nw = nw; p->nrot = nrot; p->nlb = nlb; p->lds = lds;
+            p->nw = nw; p->nrot = nrot; p->nlb = nlb; p->lds = lds; p->nframes = nframes; p->lean = lean ? 1 : 0;
             break;
         }
         nw >>= 1;
@@ -330,7 +330,7 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
     }
     HIP_TRY(hipMemsetAsync(c->counter + counter_slot, 0, sizeof(unsigned long long), st));
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
-                       r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb,
+                       r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb, p.nframes, p.lean,
                        c->ws + ws_first,
                        adj_first >= 0 ? c->adj + (size_t)adj_first * PW_ADJ_WORDS : (unsigned long long*)nullptr,
                        c->counter + counter_slot, r->d_out, role, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab);
@@ -540,7 +540,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     //     A one-wave gate kernel ahead of C (and B) holds them back until every team of A is
     //     resident, so they can never take the LDS A needs -- no launch-order assumption.
     LaunchPlan pa, pb, pc;
-    rc = plan_launch(c, r->n_units, r->nmax, 1, false, 1, &pa, 1);   // chains: no shifted frame
+    rc = plan_launch(c, r->n_units, r->nmax, 1, false, 1, &pa, 1, true);   // chains: no shifted frame
     if (rc != PW_OK) return rc;
     pa.grid = (int)r->n_units < pa.grid ? (int)r->n_units : pa.grid;
     {
@@ -556,10 +556,10 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     bool do_avg = (stages & PW_STAGE_AVG) != 0;
     pb.grid = 0;
     if (do_avg) {
-        rc = plan_launch(c, r->n_units, r->nmax, 4, false, 3, &pb);   // 3 state slots = 21 KB of scratch
+        rc = plan_launch(c, r->n_units, r->nmax, 4, false, 2, &pb, 1, true);   // one frame; 2 state slots = 14 KB of scratch
         if (rc != PW_OK) return rc;
     }
-    rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pc);
+    rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pc, 1);      // one frame, shifted in place
     if (rc != PW_OK) return rc;
     // A batch of up to a few units per SIMD is latency-bound by its optimiser chains: one window team
     // per CU keeps LDS free for the chains of the next launch (measured on 1000 units: 2.56 -> 2.45 ms);
@@ -569,7 +569,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         // PW_C_TEAMS / PW_B_TEAMS: cap the persistent teams of the window / average launches (tuning)
         const char* ct = getenv("PW_C_TEAMS");
         if (ct && atoi(ct) > 0) {
-            rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pc);
+            rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pc, 1);      // one frame, shifted in place
             if (rc != PW_OK) return rc;
             if (atoi(ct) < pc.grid) pc.grid = atoi(ct);
         }

@@ -140,10 +140,11 @@ struct UnitShared {
     PW_LDS unsigned char* scratch;
     size_t scratch_bytes;
     // nrot = rotated window frames, nlb = optimiser states (both 0..nwaves)
-    // nframes = 1: no shifted frame (the optimiser-chain launch works on the input frame only)
-    PW_HD static size_t bytes(int nmax, int nrot, int nlb, int nframes = 2) {
+    // nframes = 1: one frame - the optimiser-chain launch works on the input frame only, the other two
+    // launches of the pipeline shift it in place; lean = without the window-search variables
+    PW_HD static size_t bytes(int nmax, int nrot, int nlb, int nframes = 2, bool lean = false) {
         size_t n = (size_t)((nmax + 1) & ~1);
-        size_t b = nframes > 1 ? sizeof(UnitVars) : offsetof(UnitVars, bits);
+        size_t b = lean ? offsetof(UnitVars, bits) : sizeof(UnitVars);
         b = (b + 15) & ~(size_t)15;
         b += n * 8 * 2;                       // vdw, mass
         b += n * 4 * 2;                       // perm, inv
@@ -151,11 +152,11 @@ struct UnitShared {
         b += (size_t)nlb * ((sizeof(LbMem<3>) + 15) & ~(size_t)15);
         return b;
     }
-    PW_HD void carve(unsigned char* base, int nmax, int nrot, int nlb, int nframes = 2) {
+    PW_HD void carve(unsigned char* base, int nmax, int nrot, int nlb, int nframes = 2, bool lean = false) {
         size_t n = (size_t)((nmax + 1) & ~1);
         PW_LDS unsigned char* p = (PW_LDS unsigned char*)base;
         v = (PW_LDS UnitVars*)p;
-        p += ((nframes > 1 ? sizeof(UnitVars) : offsetof(UnitVars, bits)) + 15) & ~(size_t)15;
+        p += ((lean ? offsetof(UnitVars, bits) : sizeof(UnitVars)) + 15) & ~(size_t)15;
         ldouble* d = (ldouble*)p;
         vdw = d; d += n;
         mass = d; d += n;
@@ -163,7 +164,7 @@ struct UnitShared {
         inv = (lint*)d; d += n / 2;
         A.x = d; d += n; A.y = d; d += n; A.z = d; d += n; A.xx = d; d += n; A.vdw = vdw; A.perm = perm; A.cls = &v->cls;
         if (nframes > 1) { S.x = d; d += n; S.y = d; d += n; S.z = d; d += n; S.xx = d; d += n; }
-        else { S.x = S.y = S.z = S.xx = nullptr; }
+        else { S.x = A.x; S.y = A.y; S.z = A.z; S.xx = A.xx; }   // one frame: a shift happens in place
         S.vdw = vdw; S.perm = perm; S.cls = &v->cls;
         for (int w = 0; w < 8; ++w) { R[w].x = R[w].y = R[w].z = R[w].xx = nullptr; lb[w] = nullptr; }
         scratch = (PW_LDS unsigned char*)d;
@@ -1350,8 +1351,7 @@ PW_HD inline __attribute__((always_inline)) void stage_average_impl(UnitShared& 
     arena.init(sh);
     double* vals = (double*)arena.take((size_t)P * 8);
     if (!vals) vals = ws->vals;
-    double* packed = (double*)arena.take((size_t)P * 8);
-    if (!packed) packed = ws->knn;
+    double* packed = vals;     // the hits are compacted in place (a slot never moves to a later one)
     unsigned char* flag = (unsigned char*)arena.take((size_t)P);
     if (!flag) flag = ws->flag;
     int* s_tab = (int*)arena.take(324 * 4);
