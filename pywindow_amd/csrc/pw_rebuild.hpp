@@ -666,8 +666,51 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                         int id = k < RB_LWORK ? wl[k] : work[k];
                         if (id < n) WS.remaining[id] = 0;
                     }
-                // unique(working_list_temp), then "not in final_molecule" (utilities.py:1044-1055)
-                if (tid == 0) {
+                // unique(working_list_temp), then "not in final_molecule" (utilities.py:1044-1055): the
+                // hits of the chunk in (atom, position) order; the first occurrence of an id survives
+                bool merged = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (T::WSIZE == 64 && use_bits && T::wave() == 0) {
+                    // wave 0, one hit per lane (chunks with up to 64 hits; anything larger goes the serial way)
+                    const int lane = T::lane();
+                    int mk = 0;
+                    if (lane < cn) { int c = seg_cnt[lane]; mk = c < RB_SEG_CAP ? c : RB_SEG_CAP; }
+                    int incl = mk;                                   // inclusive prefix of the hit counts
+                    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+                    const int H = __shfl(incl, 63);
+                    if (H <= 64) {
+                        int k = 0;                                   // the atom lane's hit belongs to
+                        for (int j = 0; j < cn; ++j) k += (__shfl(incl, j) <= lane) ? 1 : 0;
+                        const bool act = lane < H;
+                        const int first = __shfl(incl - mk, act ? k : 0);
+                        int id = -1 - lane;                          // (distinct dummies for idle lanes)
+                        if (act) id = (int)(seg[(size_t)k * RB_SEG_CAP + (lane - first)] & 0xffffffffll);
+                        bool dup = false;
+                        for (int j = 0; j < H; ++j) { int idj = __shfl(id, j); dup = dup || (j < lane && idj == id); }
+                        bool fresh = false, keep = false;
+                        if (act && !dup) {
+                            unsigned long long bit = 1ull << (id & 63);
+                            fresh = !(bits_temp[id >> 6] & bit);
+                            keep = fresh && !(bits_final[id >> 6] & bit);
+                            if (fresh) rb_atomic_or64((unsigned long long*)&bits_temp[id >> 6], bit);
+                        }
+                        const unsigned long long bal = T::ballot(keep);
+                        const int nn0 = sh.n_next;
+                        const int pos = nn0 + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                        if (keep) {
+                            if (pos < RB_LWORK) wl_next[pos] = id;
+                            else work_next[pos] = id;
+                        }
+                        if (lane == 0) {
+                            const int nn = nn0 + __builtin_popcountll(bal);
+                            if (last) { sh.n_final = nf + nw; sh.n_work = nn; sh.n_next = 0; }
+                            else sh.n_next = nn;
+                        }
+                        merged = true;
+                    }
+                }
+#endif
+                if (tid == 0 && !merged) {
                     int nn = sh.n_next;
                     for (int k = 0; k < cn; ++k) {
                         int m = seg_cnt[k] < RB_SEG_CAP ? seg_cnt[k] : RB_SEG_CAP;
