@@ -113,8 +113,8 @@ struct UnitVars {
     int red_i[16];
     // ---- window search only: everything from here on is NOT allocated for the optimiser-chain
     // launch (UnitShared::bytes with nframes == 1) ----
-    // DBSCAN bitsets: core / unlabelled / frontier / next (PW_P_MAX bits each)
-    unsigned long long bits[4][PW_P_MAX / 64];
+    // DBSCAN bitsets: core / unlabelled / frontier / next (two, used in turn) (PW_P_MAX bits each)
+    unsigned long long bits[5][PW_P_MAX / 64];
     // sampling vector chosen for each cluster (largest 2*gap, first occurrence)
     double win_vec[PW_W_MAX][3];
     // window results by cluster
@@ -2043,6 +2043,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         PW_LDS unsigned long long* unl = v.bits[1];
         PW_LDS unsigned long long* frontier = v.bits[2];
         PW_LDS unsigned long long* next = v.bits[3];
+        PW_LDS unsigned long long* next2 = v.bits[4];
         // adjacency rows live in LDS (the window frames are idle now) when they fit
         unsigned long long* adj = (unsigned long long*)arena.take((size_t)ns * (size_t)words * 8);
         int stride = words;
@@ -2111,38 +2112,40 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                 if (m) { seed = wd * 64 + __builtin_ctzll(m); break; }
             }
             if (seed < 0) break;
-            T::sync();
-            for (int wd = T::tid(); wd < words; wd += T::SIZE) frontier[wd] = 0;
-            T::sync();
-            if (T::tid() == 0) {
-                unsigned long long b = 1ull << (seed & 63);
-                frontier[seed >> 6] = b;
-                unl[seed >> 6] &= ~b;
-                labels[seed] = label;
+            T::sync();                       // everybody has found the seed before anybody edits the sets
+            for (int wd = T::tid(); wd < words; wd += T::SIZE) {
+                unsigned long long b = (wd == (seed >> 6)) ? (1ull << (seed & 63)) : 0ull;
+                frontier[wd] = b;
+                unl[wd] &= ~b;
+                next[wd] = 0;
+                next2[wd] = 0;
             }
+            if (T::tid() == 0) labels[seed] = label;
             T::sync();
-            for (;;) {
-                for (int wd = T::tid(); wd < words; wd += T::SIZE) next[wd] = 0;
-                T::sync();
+            // breadth-first levels, two barriers each: the members of the frontier mark their
+            // unlabelled neighbours in one of two "next" sets (the other is cleared meanwhile)
+            for (int lv = 0;; ++lv) {
+                PW_LDS unsigned long long* nx = (lv & 1) ? next2 : next;
+                PW_LDS unsigned long long* nz = (lv & 1) ? next : next2;
                 for (int i = T::tid(); i < ns; i += T::SIZE) {
                     if ((frontier[i >> 6] >> (i & 63)) & 1ull) {
                         for (int wd = 0; wd < words; ++wd) {
                             unsigned long long b = adj[(size_t)i * stride + wd] & unl[wd];
-                            if (b) team_atomic_or(&next[wd], b);
+                            if (b) team_atomic_or(&nx[wd], b);
                         }
                     }
                 }
                 T::sync();
                 bool any = false;
-                for (int wd = 0; wd < words; ++wd) any = any || (next[wd] != 0);
+                for (int wd = 0; wd < words; ++wd) any = any || (nx[wd] != 0);
                 if (!any) break;
                 for (int i = T::tid(); i < ns; i += T::SIZE)
-                    if ((next[i >> 6] >> (i & 63)) & 1ull) labels[i] = label;
-                T::sync();
+                    if ((nx[i >> 6] >> (i & 63)) & 1ull) labels[i] = label;
                 for (int wd = T::tid(); wd < words; wd += T::SIZE) {
-                    unsigned long long nx = next[wd];
-                    unl[wd] &= ~nx;
-                    frontier[wd] = nx & core[wd];
+                    unsigned long long u = nx[wd];
+                    unl[wd] &= ~u;
+                    frontier[wd] = u & core[wd];
+                    nz[wd] = 0;
                 }
                 T::sync();
             }
