@@ -2104,6 +2104,8 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             labels[i] = -1;
         }
         T::sync();
+        if (T::wave() == 0) PW_T1(ws, 11, t_db);      // adjacency rows + core points
+        PW_T0(t_bfs);
         int label = 0;
         for (;;) {
             int seed = -1;
@@ -2152,6 +2154,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             label += 1;
         }
         T::sync();
+        if (T::wave() == 0) PW_T1(ws, 23, t_bfs);     // cluster growth
         if (T::tid() == 0) {
             v.n_clusters = label;
             out->n_clusters = label;
