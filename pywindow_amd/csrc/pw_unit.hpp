@@ -1796,8 +1796,14 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     // per-unit arrays of the sampling stages: LDS scratch first, global workspace otherwise
     ScratchArena arena;
     arena.init(sh);
-    double* pts = (double*)arena.take((size_t)P * 3 * 8);
+    // The sampling vectors, one array per component, each cut into the four residue classes of the
+    // point index: point k sits at [component][k & 3][k >> 2].  Threads of a wave that hold
+    // consecutive groups of four points and walk their index windows in step (the k-NN loop) then
+    // read consecutive doubles -- no LDS bank conflicts -- and everybody else just uses PT().
+    const int Q4 = (P + 3) >> 2;
+    double* pts = (double*)arena.take((size_t)Q4 * 12 * 8);
     if (!pts) pts = ws->pts;
+    auto PT = [Q4](int k, int c) { return (c * 4 + (k & 3)) * Q4 + (k >> 2); };
     double* vals = (double*)arena.take((size_t)P * 8);
     if (!vals) vals = ws->vals;
     int* surv_k = (int*)arena.take((size_t)P * 4);
@@ -1810,7 +1816,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     // of the sampling stage, then the adjacency rows of DBSCAN occupy the same bytes in turn
     ScratchArena arena_mark = arena;
     for (int k = T::tid(); k < P; k += T::SIZE)
-        sp.point(k, &pts[3 * k], &pts[3 * k + 1], &pts[3 * k + 2]);
+        sp.point(k, &pts[PT(k, 0)], &pts[PT(k, 1)], &pts[PT(k, 2)]);
     T::sync();
     if (T::wave() == 0) PW_T1(ws, 26, t_pre);
     // ---- eps: mean of all 10-NN distances (self included), utilities.py:1427-1434 ----
@@ -1835,7 +1841,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
 #pragma unroll
             for (int p = 0; p < NK; ++p) {
                 int k = k0 + p < P ? k0 + p : P - 1;
-                px[p] = pts[3 * k]; py[p] = pts[3 * k + 1]; pz[p] = pts[3 * k + 2];
+                px[p] = pts[PT(k, 0)]; py[p] = pts[PT(k, 1)]; pz[p] = pts[PT(k, 2)];
             }
             const int klast = k0 + NK - 1 < P ? k0 + NK - 1 : P - 1;
             int lo = k0 - W < 0 ? 0 : k0 - W, hi = klast + W > P - 1 ? P - 1 : klast + W;
@@ -1844,15 +1850,31 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                 for (int p = 0; p < NK; ++p)
 #pragma unroll
                     for (int q = 0; q < 10; ++q) t[p][q] = PW_INF;
+                // pass 0: every thread walks the same offsets t relative to its first point (k0 = 4 * grp),
+                // so the lanes of a wave read consecutive doubles of one residue class; pass 1 (the whole
+                // sphere, only if the window did not prove itself) uses plain indices
+                const int t_lo = pass == 0 ? -W : -k0, t_hi = pass == 0 ? NK - 1 + W : P - 1 - k0;
+                // Candidates further than twice the expected tenth-neighbour distance are never entered
+                // (pass 0): the lanes walk the same offsets and a spiral lattice has its neighbours at the
+                // same offsets everywhere, so for most offsets no lane of the wave inserts anything and the
+                // whole insertion chain is skipped.  A list that is not full afterwards (t[9] still
+                // infinite) fails the proof below and the point is redone without a threshold.
+                const double tau = pass == 0 ? 80.0 * radius * radius / (double)P : PW_INF;
+                double thr[NK];
+#pragma unroll
+                for (int p = 0; p < NK; ++p) thr[p] = tau;
 #pragma unroll 2
-                for (int j = lo; j <= hi; ++j) {
-                    const double qx = pts[3 * j], qy = pts[3 * j + 1], qz = pts[3 * j + 2];
+                for (int tt = t_lo; tt <= t_hi; ++tt) {
+                    const int j = k0 + tt;
+                    if (j < lo || j > hi) continue;
+                    const int at = ((tt & 3) * Q4) + grp + (tt >> 2);      // == PT(j, 0): j = 4 * grp + tt
+                    const double qx = pts[at], qy = pts[4 * Q4 + at], qz = pts[8 * Q4 + at];
 #pragma unroll
                     for (int p = 0; p < NK; ++p) {
                         double ax = px[p] - qx, ay = py[p] - qy, az = pz[p] - qz;
                         double d = 0.0;
                         d = d + ax * ax; d = d + ay * ay; d = d + az * az;
-                        if (d < t[p][9]) {
+                        if (d < thr[p]) {
                             double v_ = d;
 #pragma unroll
                             for (int q = 0; q < 10; ++q) {
@@ -1860,6 +1882,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                                 v_ = __builtin_fmax(t[p][q], v_);
                                 t[p][q] = lo_;
                             }
+                            thr[p] = __builtin_fmin(tau, t[p][9]);
                         }
                     }
                 }
@@ -1912,7 +1935,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     int k = k0 + r * T::SIZE < P ? k0 + r * T::SIZE : k0;
-                    dx[r] = pts[3 * k]; dy[r] = pts[3 * k + 1]; dz[r] = pts[3 * k + 2];
+                    dx[r] = pts[PT(k, 0)]; dy[r] = pts[PT(k, 1)]; dz[r] = pts[PT(k, 2)];
                 }
                 ray_scan_multi<NR>(sh.S, n, cen, dx, dy, dz, hit, far);
 #pragma unroll
@@ -1924,7 +1947,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         } else {
             for (int k = T::tid(); k < P; k += T::SIZE) {
                 double far;
-                bool hit = ray_scan(sh.S, n, cen, pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], &far);
+                bool hit = ray_scan(sh.S, n, cen, pts[PT(k, 0)], pts[PT(k, 1)], pts[PT(k, 2)], &far);
                 flag[k] = hit ? 0 : 1;
             }
         }
@@ -1957,7 +1980,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             int k = labels[j];
             double g2, chunk[3];
             int pos;
-            bool ok = path_scan_thread(sh.S, n, pts[3 * k], pts[3 * k + 1], pts[3 * k + 2], prm.increment,
+            bool ok = path_scan_thread(sh.S, n, pts[PT(k, 0)], pts[PT(k, 1)], pts[PT(k, 2)], prm.increment,
                                        &g2, &pos, chunk, &evals);
             flag[j] = ok ? 1 : 0;
             tmpv[j] = g2;
@@ -1971,7 +1994,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             for (int item = T::tid(); item < left * PCAP; item += T::SIZE) {
                 int j = whole + item / PCAP, q = item % PCAP;
                 int k = labels[j];
-                double vx = pts[3 * k], vy = pts[3 * k + 1], vz = pts[3 * k + 2];
+                double vx = pts[PT(k, 0)], vy = pts[PT(k, 1)], vz = pts[PT(k, 2)];
                 int chunks = (int)np_floordiv(norm3(vx, vy, vz), prm.increment);
                 if (chunks + 1 > PCAP) { fits = false; continue; }
                 if (q > chunks) continue;
@@ -1981,7 +2004,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             T::sync();
             for (int j = whole + T::tid(); j < ncand; j += T::SIZE) {
                 int k = labels[j];
-                double vx = pts[3 * k], vy = pts[3 * k + 1], vz = pts[3 * k + 2];
+                double vx = pts[PT(k, 0)], vy = pts[PT(k, 1)], vz = pts[PT(k, 2)];
                 int chunks = (int)np_floordiv(norm3(vx, vy, vz), prm.increment);
                 double g2 = 0.0;
                 bool ok = true;
@@ -2064,13 +2087,15 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         double* cp = (double*)arena.take((size_t)ns * 24);
         if (cp) {
             for (int i = T::tid(); i < ns; i += T::SIZE) {
-                const double* pi = &pts[3 * surv_k[i]];
+                const int pik = surv_k[i];
+                const double pi[3] = {pts[PT(pik, 0)], pts[PT(pik, 1)], pts[PT(pik, 2)]};
                 cp[3 * i] = pi[0]; cp[3 * i + 1] = pi[1]; cp[3 * i + 2] = pi[2];
             }
             T::sync();
         }
         for (int i = T::tid(); i < ns; i += T::SIZE) {
-            const double* pi = &pts[3 * surv_k[i]];
+            const int pik = surv_k[i];
+                const double pi[3] = {pts[PT(pik, 0)], pts[PT(pik, 1)], pts[PT(pik, 2)]};
             double px = pi[0], py = pi[1], pz = pi[2];
             int cnt = 0;
             for (int wd = 0; wd < words; ++wd) {
@@ -2092,7 +2117,8 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                     }
                 }
                 for (; j < jend; ++j) {
-                    const double* pj = &pts[3 * surv_k[j]];
+                    const int pjk = surv_k[j];
+                const double pj[3] = {pts[PT(pjk, 0)], pts[PT(pjk, 1)], pts[PT(pjk, 2)]};
                     double ax = px - pj[0], ay = py - pj[1], az = pz - pj[2];
                     double d = 0.0;
                     d = d + ax * ax; d = d + ay * ay; d = d + az * az;
@@ -2174,7 +2200,8 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             }
             T::wave_argmax(best, bidx);
             if (T::lane() == 0) {
-                const double* pv = &pts[3 * surv_k[bidx]];
+                const int pvk = surv_k[bidx];
+                const double pv[3] = {pts[PT(pvk, 0)], pts[PT(pvk, 1)], pts[PT(pvk, 2)]};
                 v.win_vec[c][0] = pv[0]; v.win_vec[c][1] = pv[1]; v.win_vec[c][2] = pv[2];
             }
         }

@@ -125,6 +125,6 @@ def test_torch_can_start_after_the_library():
     import sys
 
     tool = pathlib.Path(__file__).resolve().parent / "tools" / "torch_after.py"
-    out = subprocess.run([sys.executable, str(tool), "both"], capture_output=True, text=True, timeout=300,
+    out = subprocess.run([sys.executable, str(tool), "both"], capture_output=True, text=True, timeout=1200,   # (a fresh box pages torch in for minutes)
                          cwd=str(tool.parents[2]))
     assert out.returncode == 0 and "torch ok" in out.stdout, out.stdout[-500:] + out.stderr[-1500:]
