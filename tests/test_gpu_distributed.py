@@ -50,9 +50,9 @@ def _run(path, periodic):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, str(path), periodic, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=300) for _ in procs]
+    got = [q.get(timeout=900) for _ in procs]      # (spawned ranks import torch afresh: minutes on a cold box)
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=300)
         assert p.exitcode == 0
     assert [g for g in got if not isinstance(g, dict)] == [0]
     return [g for g in got if isinstance(g, dict)][0]
