@@ -49,9 +49,9 @@ def test_gather_records_world2(n_total):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in procs]
+    got = [q.get(timeout=600) for _ in procs]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     full = [g for g in got if isinstance(g, tuple)][0]
     assert full[0] == list(range(n_total))
@@ -91,9 +91,9 @@ def test_gather_ragged_world2(counts):
     procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, counts, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = {g[0]: g for g in (q.get(timeout=120) for _ in procs)}
+    got = {g[0]: g for g in (q.get(timeout=600) for _ in procs)}
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     total = sum(counts)
     assert got[0][1] == list(range(total)) and got[0][2] == list(range(2 * total))
