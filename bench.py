@@ -27,9 +27,9 @@ FRAMES = 1000
 ALGO_BYTES_PER_UNIT = 24 * 168 + 600   # coordinates read once + one result record
 ALGO_FLOP_PER_UNIT = 2.0e7
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01i_hbm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01j_hbm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary
 FP64_VECTOR_PEAK_TFLOPS = 78.6
-COUNTER_FILE = os.path.join(ROOT, "profiles", "r01i_instruction_counters.json")    # rocprofv3 --pmc SQ_INSTS_* summary
+COUNTER_FILE = os.path.join(ROOT, "profiles", "r01j_instruction_counters.json")    # rocprofv3 --pmc SQ_INSTS_* summary
 
 
 def cpu_baseline(elements, frames, vdw, mass, budget_s=20.0):
@@ -189,7 +189,7 @@ def main():
             valu_issue = {"wave_instructions_per_launch": per_unit * args.frames,
                           "frac": per_unit * args.frames * vi["simd_cycles_per_wave_instruction"]
                                   / (vi["simds"] * vi["clock_ghz"] * 1e9 * k_ms * 1e-3),
-                          "source": "profiles/r01i_instruction_counters.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
+                          "source": "profiles/r01j_instruction_counters.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
         except (OSError, KeyError, ValueError):
             valu_issue = None
         line = {
@@ -204,14 +204,14 @@ def main():
                        "windows_eq_4": int((out["n_windows"] == 4).sum())},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "fabric bytes per launch from rocprofv3 PMC (profiles/r01i_hbm_traffic.json); "
+                         "traffic_note": "fabric bytes per launch from rocprofv3 PMC (profiles/r01j_hbm_traffic.json); "
                                          "includes Infinity-Cache hits on the re-used per-team workspaces",
                          "kernel": "pw_analyse_kernel (pipeline: optimiser chains | average diameter | window search)", "kernel_ms": k_ms,
                          "kernel_ms_note": "HIP events around back-to-back analyses / their number: the steady-state period of "
                                            "the pipeline, whose three launches per analysis overlap each other and the next "
                                            "analysis; rocprofv3 therefore reports longer per-launch durations "
-                                           "(profiles/r01i_pipeline_kernel_stats.csv: chains 3.8 ms, window search 3.7 ms, "
-                                           "average diameter 1.9 ms, all inside config.single_step_latency_ms)",
+                                           "(profiles/r01j_pipeline_kernel_stats.csv: chains 3.8 ms, window search 3.6 ms, "
+                                           "average diameter 1.8 ms, all inside config.single_step_latency_ms)",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_UNIT * args.frames,
                          "fp64_valu": {"achieved_tflops": units_per_s * ALGO_FLOP_PER_UNIT / 1e12,
                                        "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
