@@ -534,9 +534,19 @@ PW_HD inline double np_sum_team(const double* a, int n, int* tab, double* acc8, 
                     acc8[task] = r;
                 }
             } else {
-                double r = b[c];
+                // a leaf has at most 128 elements, i.e. at most 16 per accumulator: all loads first
+                // (they are independent), then the additions in order
                 int lim = ln - (ln % 8);
-                for (int i = 8 + c; i < lim; i += 8) r = r + b[i];
+                double vv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    int i = c + 8 * u;
+                    vv[u] = b[i < lim ? i : c];
+                }
+                double r = vv[0];
+#pragma unroll
+                for (int u = 1; u < 16; ++u)
+                    if (c + 8 * u < lim) r = r + vv[u];
                 acc8[task] = r;
             }
         }
