@@ -3,15 +3,25 @@
 1000-frame synthetic CC3 trajectory (BASELINE.json config 2), N GPUs of one node.
 
 One *step* = one pass of the whole hot path (all stages) over the rank's batch
-of 1000 frames, inputs already resident in HBM.  Weak scaling: every rank
-analyses its own 1000 frames (frames rank*1000 .. rank*1000+999 of the synthetic
-generator); no data-path collective.  Prints ONE JSON line on rank 0.
+of frames, inputs already resident in HBM.  ``--gpus N``:
+
+* under ``torchrun`` (RANK / WORLD_SIZE set) this process is one rank, bound to GPU LOCAL_RANK;
+* started plainly with ``--gpus N > 1`` the process starts ``torch.distributed.run`` with N ranks as a
+  CHILD (before anything here touches a GPU) and passes its output through.
+
+Weak scaling is the headline (every rank analyses its own 1000 frames per step); with more than one
+rank every step ends with the path's only collective, the RCCL all-gather of the result records,
+read straight from the engine's device buffer, inside the timed region.  The same run then times
+strong scaling (ONE 1000-frame trajectory split over the ranks) and reports it beside the headline.
+Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,34 +34,141 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FRAMES = 1000
-ALGO_BYTES_PER_UNIT = 24 * 168 + 600   # coordinates read once + one result record
-ALGO_FLOP_PER_UNIT = 2.0e7             # SURVEY.md section 8d
+N_ATOMS = 168
+ALGO_BYTES_PER_UNIT = 24 * N_ATOMS + 600   # coordinates read once + one result record
+ALGO_FLOP_PER_UNIT = 2.0e7                 # SURVEY.md section 8d
+# the per-unit flop of section 8d by launch: evaluations x 168 atoms x 15 flop
+ALGO_FLOP_BY_KERNEL = {
+    "chains": (500 * N_ATOMS + N_ATOMS * (N_ATOMS + 1) // 2) * 15.0,            # F_opt evaluations + max_dim pairs
+    "average": (947 * N_ATOMS + N_ATOMS * (N_ATOMS + 1) // 2) * 15.0,           # P_avg ray tests + max_dim pairs
+    "windows": ((3100 + 2400 + 797) * N_ATOMS + N_ATOMS * (N_ATOMS + 1) // 2) * 15.0,   # paths, window fits, rays
+}
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01j_hbm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary
 FP64_VECTOR_PEAK_TFLOPS = 78.6
-COUNTER_FILE = os.path.join(ROOT, "profiles", "r01j_instruction_counters.json")    # rocprofv3 --pmc SQ_INSTS_* summary
+# static inputs measured with rocprofv3 --pmc (separate passes; committed summaries), NOT by this run
+TRAFFIC_FILES = ("r02_hbm_traffic.json", "r01j_hbm_traffic.json")
+COUNTER_FILES = ("r02_instruction_counters.json", "r01j_instruction_counters.json")
+# the only figure for this metric the reference's repository holds: 715-frame CC3 trajectory,
+# traj.analysis(ncpus=8) in 286.5 s (examples/Example7_AnalysingTrajectorySingleMol.ipynb:569-575)
+REFERENCE_NOTEBOOK_FPS = 715 / 286.5
+REFERENCE_SURVEY_FPS_PER_CORE = 0.54       # the reference itself, survey container, one core
 
 
-def cpu_baseline(elements, frames, vdw, mass, budget_s=20.0):
-    """The oracle (numpy/scipy/sklearn restatement of the reference's path,
-    bit-identical to it on the golden inputs) timed on this host, one core."""
-    from oracle import pw_oracle as O
+# ---------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1).  They run BEFORE this process initialises the GPU: their worker
+# processes are fresh interpreters, and nothing here may start one once HIP is up.
+def _cpu_worker(args):
+    """One worker process: analyse frames wid, wid + stride, ... until the budget is spent."""
+    kind, wid, stride, budget_s, n_frames = args
+    os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    sys.path.insert(0, ROOT)
+    from pywindow_amd import element_data as E
+    from pywindow_amd import synth
 
-    O.build()
-    t0 = time.perf_counter()
+    elements, base = synth.load_cc3_base()
+    ids = E.element_ids(elements)
+    vdw, mass = np.ascontiguousarray(E.VDW[ids]), np.ascontiguousarray(E.MASS[ids])
+
+    def frame(k):
+        return synth.quantise_like_history(synth.noisy_frame(base, synth.SEED_BASE + k))
+
+    if kind == "oracle":
+        from oracle import pw_oracle as O
+
+        O.build()
+
+        def run(xyz):
+            O.full_analysis(xyz, vdw, mass)
+    else:
+        import ctypes
+
+        L = ctypes.CDLL(os.path.join(ROOT, "tests", "hostsim", "libunitprobe.so"))
+        rec = np.zeros(4096, dtype=np.uint8)
+        off = np.array([0, len(vdw)], dtype=np.int64)
+
+        def run(xyz):
+            xyz = np.ascontiguousarray(xyz)
+            rc = L.hs_analysis_batch(ctypes.c_long(1), off.ctypes.data_as(ctypes.c_void_p),
+                                     xyz.ctypes.data_as(ctypes.c_void_p), vdw.ctypes.data_as(ctypes.c_void_p),
+                                     mass.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(15),
+                                     rec.ctypes.data_as(ctypes.c_void_p), None)
+            assert rc == 0
+
+    run(frame(wid))                      # warm-up (imports, first-call costs), untimed
     n = 0
-    while n < len(frames) and (n < 2 or time.perf_counter() - t0 < budget_s):
-        O.full_analysis(frames[n], vdw, mass)
+    t0 = time.perf_counter()
+    k = wid
+    while k < n_frames and (n < 1 or time.perf_counter() - t0 < budget_s):
+        run(frame(k))
         n += 1
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} frames of the same synthetic trajectory, oracle/pw_oracle.py, 1 process"}
+        k += stride
+    return n, time.perf_counter() - t0
 
 
-def secondary(ctx, elements, vdw, mass):
-    """BASELINE.json's secondary shapes, reported beside the headline (not part of `value`):
-    a large throughput batch (configs 4-5: tens of thousands of independent units) and the
-    periodic pipeline of configs 3-4 (cell -> rebuilt cages -> analysis)."""
+def _cpu_rate(kind, workers, budget_s):
+    import multiprocessing as mp
+
+    jobs = [(kind, w, workers, budget_s, 100000) for w in range(workers)]
+    if workers == 1:
+        res = [_cpu_worker(jobs[0])]
+    else:
+        with mp.get_context("spawn").Pool(workers) as pool:
+            res = pool.map(_cpu_worker, jobs)
+    frames = sum(r[0] for r in res)
+    return frames, sum(r[0] / r[1] for r in res)      # workers run side by side: rates add
+
+
+def cpu_baseline(budget_s=8.0):
+    """The oracle (numpy/scipy/sklearn restatement of the reference's path, bit-identical to it on the
+    golden inputs) timed on this host: one core and all cores; and the kernel SOURCE compiled for the
+    host with a one-lane team (tests/hostsim), the "same source" CPU figure."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    workers = min(cores, 128)
+    n1, r1 = _cpu_rate("oracle", 1, budget_s)
+    out = {"value": r1, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"{n1} frames of the same synthetic trajectory, oracle/pw_oracle.py, 1 process, {budget_s:.0f} s",
+           "host_cpu_count": os.cpu_count(), "host_cores_usable": cores}
+    try:
+        na, ra = _cpu_rate("oracle", workers, budget_s)
+        out["all_core"] = {"value": ra, "unit": "frames/s", "cores": workers, "kind": "port",
+                           "sample": f"{na} frames, one oracle process per core ({workers} processes), {budget_s:.0f} s each"}
+    except Exception as exc:  # pragma: no cover - depends on the host
+        out["all_core"] = {"error": repr(exc)}
+    if os.path.exists(os.path.join(ROOT, "tests", "hostsim", "libunitprobe.so")):
+        try:
+            ns, rs = _cpu_rate("hostsim", 1, budget_s / 2)
+            nsa, rsa = _cpu_rate("hostsim", workers, budget_s / 2)
+            out["same_source"] = {"value": rs, "unit": "frames/s", "cores": 1, "kind": "port",
+                                  "what": "pywindow_amd/csrc/pw_unit.hpp compiled with g++ for a one-lane team (tests/hostsim)",
+                                  "sample": f"{ns} frames", "all_core": {"value": rsa, "cores": workers, "sample": f"{nsa} frames"}}
+        except Exception as exc:  # pragma: no cover
+            out["same_source"] = {"error": repr(exc)}
+    out["reference_itself"] = {"value": REFERENCE_SURVEY_FPS_PER_CORE, "unit": "frames/s", "cores": 1,
+                               "where": "survey container (BASELINE.md section 2); the reference's Python cannot travel to the GPU box"}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+def _median_ms(fn, reps=5, warm=1):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    return float(np.median(ts)), [round(t, 3) for t in ts]
+
+
+def secondary(ctx, vdw, mass):
+    """BASELINE.json's other shapes, reported beside the headline (not part of `value`), each the
+    median of five repetitions after a warm-up."""
+    import tempfile
+
+    import pywindow_amd as pw
     from pywindow_amd import _lib, synth
     from pywindow_amd import rebuild as rb
 
@@ -61,6 +178,17 @@ def secondary(ctx, elements, vdw, mass):
     ms = res.time_launches(3)
     res.free()
     out["throughput_batch"] = {"units": 4000, "ms_per_launch": ms, "units_per_s": 4000 / (ms * 1e-3)}
+    # HISTORY file -> records: native parse, H2D, the launch, D2H (DLPOLY.analysis_records)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = synth.write_synthetic_history(os.path.join(tmp, "HISTORY"), FRAMES)
+        traj = pw.DLPOLY(path)
+
+        def e2e():
+            return traj.analysis_records(forcefield="opls", swap_atoms={"he": "H"})
+
+        med, reps = _median_ms(e2e)
+        out["e2e_history_to_records"] = {"frames": FRAMES, "ms": med, "frames_per_s": FRAMES / (med * 1e-3), "reps_ms": reps,
+                                         "includes": "tokenising the HISTORY text, H2D, all launches, D2H of the records"}
     cell = os.path.join(ROOT, "tests", "golden", "rebuild.npz")
     if os.path.exists(cell):
         g = np.load(cell)
@@ -74,25 +202,50 @@ def secondary(ctx, elements, vdw, mass):
 
         ids = E.element_ids(el)
         cc, ll, inv = rb.pack_frames(coords, lats)
+        state = {}
 
         def run():
             res, n_mol = ctx.resident_from_cells(topo, E.VDW[ids], cc, ll, inv, True)
             res.launch()
-            recs = res.download()
+            state["recs"] = res.download()
+            state["n_mol"] = n_mol
             res.free()
-            return n_mol, recs
 
-        run()
-        t0 = time.perf_counter()
-        n_mol, recs = run()
-        dt = time.perf_counter() - t0
+        med, reps = _median_ms(run)
+        n_mol, recs = state["n_mol"], state["recs"]
         out["periodic_cell"] = {
             "workload": "cubic cell, 8 CC3 cages / 1344 atoms per frame (tests/data/system_periodic.pdb + 0.02 A noise)",
-            "frames": frames, "cages": int(n_mol.sum()), "ms": 1e3 * dt,
-            "frames_per_s": frames / dt, "cages_per_s": float(n_mol.sum()) / dt,
+            "frames": frames, "cages": int(n_mol.sum()), "ms": med, "reps_ms": reps,
+            "frames_per_s": frames / (med * 1e-3), "cages_per_s": float(n_mol.sum()) / (med * 1e-3),
             "includes": "H2D of the frames, rebuild launch, on-device hand-over, analysis launch, D2H of the records",
             "all_cages_have_windows": bool((recs["n_windows"] > 0).all())}
     return out
+
+
+def _load_profile(names):
+    for name in names:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                return json.load(fh), name
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` without torchrun: start the N ranks as a child process (this
+    process has not touched the GPU and never will) and hand its output and exit code on."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -103,57 +256,137 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-strong", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+
+    cpu = None
+    if rank == 0 and world_env == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()              # before the GPU is initialised (see above)
 
     import torch
 
     dist = None
     backend = os.environ.get("PW_BENCH_BACKEND", "nccl")       # "gloo": rehearsal of the multi-rank path
+    device_index = local_rank
     if "PW_BENCH_DEVICE" in os.environ:                        # ... with every rank on one GPU
-        local_rank = int(os.environ["PW_BENCH_DEVICE"])
-    if world > 1:
+        device_index = int(os.environ["PW_BENCH_DEVICE"])
+    world = 1
+    if world_env > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(device_index)
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend=backend)
+        world = dist.get_world_size()     # what the process group reports, not what the flag asked for
+        rank = dist.get_rank()
 
-    from pywindow_amd import _lib, synth
+    from pywindow_amd import _lib, engine, synth
     from pywindow_amd import element_data as E
+    from pywindow_amd import trajectory as T
 
-    elements, frames = synth.synthetic_units(args.frames, first=rank * args.frames)
+    elements, _ = synth.load_cc3_base()
     ids = E.element_ids(elements)
     vdw, mass = E.VDW[ids], E.MASS[ids]
-    ctx = _lib.Context(local_rank)
-    res = ctx.upload(_lib.Batch.uniform(frames, vdw, mass))
+    ctx = engine.context(device_index)
+    tdev = torch.device("cuda", device_index)
+    rec_bytes = _lib.UNIT_OUT_DTYPE.itemsize
 
-    def barrier():
+    def barrier(res):
         res.sync()                     # the engine's own HIP streams
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res.launch()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res.launch()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    class StepGather:
+        """The all-gather of one step's records, queued behind the launch without a host wait."""
+
+        def __init__(self, res, per):
+            self.res, self.per = res, per
+            self.views = {}
+            self.out = [torch.empty(world * per * rec_bytes, dtype=torch.uint8, device=tdev) for _ in range(2)] \
+                if backend == "nccl" else None
+            self.k = 0
+            self.last_host = None
+
+        def __call__(self):
+            if backend == "nccl":
+                stream = torch.cuda.current_stream(tdev).cuda_stream
+                ptr = self.res.results_ready(stream)
+                view = self.views.get(ptr)
+                if view is None:
+                    view = self.views[ptr] = T.device_bytes_tensor(ptr, self.per * rec_bytes, tdev)
+                dist.all_gather_into_tensor(self.out[self.k & 1], view)
+                self.res.results_release(stream)
+                self.k += 1
+            else:                                              # gloo rehearsal: host records
+                self.last_host = T.gather_records(self.res.download(), self.per * world, rank, world, dist)
+
+        def records(self):
+            """Gathered records of the latest step (all ranks' blocks, rank order) on the host."""
+            if backend == "nccl":
+                raw = self.out[(self.k - 1) & 1].cpu().numpy()
+                return raw.view(_lib.UNIT_OUT_DTYPE)
+            return self.last_host
+
+    def timed(res, steps, warmup, gather):
+        for _ in range(warmup):
+            res.launch()
+            if gather:
+                gather()
+        barrier(res)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res.launch()
+            if gather:
+                gather()
+        barrier(res)
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=tdev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    # ---- weak scaling (headline): every rank its own `frames` frames --------------------------------
+    _, frames = synth.synthetic_units(args.frames, first=rank * args.frames)
+    res = ctx.upload(_lib.Batch.uniform(frames, vdw, mass))
+    gather = StepGather(res, args.frames) if world > 1 else None
+    elapsed = timed(res, args.steps, args.warmup, gather)
     out = res.download()
     ok = bool((out["status"] == 0).all())
+    gather_ok = None
+    if gather is not None:
+        allrec = gather.records()
+        if rank == 0:
+            mine = allrec[: args.frames]
+            gather_ok = bool(len(allrec) == world * args.frames and mine.tobytes() == out.tobytes()
+                             and (allrec["status"] == 0).all() and (allrec["n_atoms"] == N_ATOMS).all())
+
+    # ---- strong scaling: ONE trajectory of `frames` frames split over the ranks -----------------------
+    strong = None
+    if world > 1 and not args.no_strong:
+        per = -(-args.frames // world)
+        lo, hi = T.shard_range(args.frames, rank, world)
+        if hi - lo == per:
+            _, mine = synth.synthetic_units(hi - lo, first=lo)
+            res_s = ctx.upload(_lib.Batch.uniform(mine, vdw, mass))
+            el_s = timed(res_s, args.steps, args.warmup, StepGather(res_s, per))
+            strong = {"frames_total": args.frames, "frames_per_gpu": per, "ms_per_step": 1e3 * el_s / args.steps,
+                      "value": args.frames * args.steps / el_s, "unit": "frames/s", "scaling": "strong",
+                      "includes_gather": True}
+            res_s.free()
+        else:
+            strong = {"skipped": f"{args.frames} frames do not split evenly over {world} ranks"}
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
@@ -162,66 +395,106 @@ def main():
         k_ms = res.time_launches(max(3, min(args.steps, 10)))
         # one launch on its own (no overlap with a neighbour): the latency of a single batch
         lat = []
-        for _ in range(3):
+        for _ in range(5):
             res.sync()
             t1 = time.perf_counter()
             res.launch()
             res.sync()
             lat.append(1e3 * (time.perf_counter() - t1))
-        single_ms = min(lat)
+        single_ms = float(np.median(lat))
         units_per_s = args.frames / (k_ms * 1e-3)
         achieved_gbs = units_per_s * ALGO_BYTES_PER_UNIT / 1e9
+        achieved_tf = units_per_s * ALGO_FLOP_PER_UNIT / 1e12
+        tj, tname = _load_profile(TRAFFIC_FILES)
         traffic = None
-        try:
-            with open(TRAFFIC_FILE) as fh:
-                tj = json.load(fh)
-            traffic = tj["per_launch_bytes"] * (args.frames / tj["units_per_launch"])
-        except (OSError, KeyError, ValueError):
-            traffic = None
+        if tj is not None:
+            try:
+                traffic = tj["per_launch_bytes"] * (args.frames / tj["units_per_launch"])
+            except (KeyError, TypeError, ZeroDivisionError):
+                traffic = None
         # VALU issue utilisation from the profiled wave-level instruction count (committed summary) and
         # the kernel time measured in this run: instructions x 4 SIMD cycles / (SIMDs x clock x time)
+        cj, cname = _load_profile(COUNTER_FILES)
         valu_issue = None
+        if cj is not None:
+            try:
+                per_unit = cj["per_launch"]["SQ_INSTS_VALU"] / cj["units_per_launch"]
+                vi = cj["valu_issue"]
+                valu_issue = {"wave_instructions_per_launch": per_unit * args.frames,
+                              "frac": per_unit * args.frames * vi["simd_cycles_per_wave_instruction"]
+                                      / (vi["simds"] * vi["clock_ghz"] * 1e9 * k_ms * 1e-3),
+                              "source": f"static: profiles/{cname} (rocprofv3 --pmc SQ_INSTS_VALU), not measured by this run"}
+            except (KeyError, TypeError, ZeroDivisionError):
+                valu_issue = None
+        # per launch of the pipeline, each on its own (no other launch in flight): HIP events on the
+        # stream the kernel runs on; profiles/r02_serial_kernel_stats.csv is rocprofv3's view of the same
+        per_kernel = None
         try:
-            with open(COUNTER_FILE) as fh:
-                cj = json.load(fh)
-            per_unit = cj["per_launch"]["SQ_INSTS_VALU"] / cj["units_per_launch"]
-            vi = cj["valu_issue"]
-            valu_issue = {"wave_instructions_per_launch": per_unit * args.frames,
-                          "frac": per_unit * args.frames * vi["simd_cycles_per_wave_instruction"]
-                                  / (vi["simds"] * vi["clock_ghz"] * 1e9 * k_ms * 1e-3),
-                          "source": "profiles/r01j_instruction_counters.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
-        except (OSError, KeyError, ValueError):
-            valu_issue = None
+            st = res.stage_times()
+            per_kernel = []
+            for name, ms in st.items():
+                fl = ALGO_FLOP_BY_KERNEL[name] * args.frames
+                per_kernel.append({"kernel": name, "ms": ms, "algorithmic_flop_per_launch": fl,
+                                   "achieved_tflops": fl / (ms * 1e-3) / 1e12,
+                                   "frac_fp64_valu": fl / (ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS})
+        except AttributeError:
+            per_kernel = None
         line = {
             "metric": "trajectory frames/sec full_analysis (pore+windows), CC3 1k-frame",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": value / REFERENCE_NOTEBOOK_FPS, "dtype": "f64", "data": "synthetic",
+            "vs_baseline_note": "BASELINE.md holds no published benchmark; the denominator is the only figure for this metric in the "
+                                "reference's repository: 715-frame CC3 trajectory, analysis(ncpus=8), 286.5 s = 2.50 frames/s "
+                                "(examples/Example7_AnalysingTrajectorySingleMol.ipynb:569-575, unknown 2018 hardware)",
             "config": {"workload": "CC3 1000-frame synthetic DL_POLY trajectory (BASELINE configs[1]), "
                                    "per-frame pore+windows, 168 atoms/frame",
                        "frames_per_gpu": args.frames, "stages": "all", "results_ok": ok,
                        "successive_steps_overlap": True, "single_step_latency_ms": single_ms,
-                       "windows_eq_4": int((out["n_windows"] == 4).sum())},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "fabric bytes per launch from rocprofv3 PMC (profiles/r01j_hbm_traffic.json); "
-                                         "includes Infinity-Cache hits on the re-used per-team workspaces",
-                         "kernel": "pw_analyse_kernel (pipeline: optimiser chains | average diameter | window search)", "kernel_ms": k_ms,
-                         "kernel_ms_note": "HIP events around back-to-back analyses / their number: the steady-state period of "
-                                           "the pipeline, whose three launches per analysis overlap each other and the next "
-                                           "analysis; rocprofv3 therefore reports longer per-launch durations "
-                                           "(profiles/r01j_pipeline_kernel_stats.csv: chains 3.8 ms, window search 3.6 ms, "
-                                           "average diameter 1.8 ms, all inside config.single_step_latency_ms)",
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_UNIT * args.frames,
-                         "fp64_valu": {"achieved_tflops": units_per_s * ALGO_FLOP_PER_UNIT / 1e12,
-                                       "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                                       "frac": units_per_s * ALGO_FLOP_PER_UNIT / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                                       "valu_issue_measured": valu_issue}},
+                       "windows_eq_4": int((out["n_windows"] == 4).sum()),
+                       "gather_in_timed_region": world > 1, "gather_ok": gather_ok,
+                       "backend": backend if world > 1 else None},
+            "roofline": {"bound": "fp64_valu", "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS,
+                         "algorithmic_flop_per_launch": ALGO_FLOP_PER_UNIT * args.frames,
+                         "kernel": "pw_analyse_kernel x 3 (one analysis = optimiser chains | average diameter | window search, concurrent)",
+                         "kernel_ms": k_ms,
+                         "kernel_ms_note": "HIP events on the launch streams around back-to-back analyses / their number: the steady-state "
+                                           "period (successive analyses overlap); config.single_step_latency_ms is one analysis on its own",
+                         "frac_single_analysis": (args.frames * ALGO_FLOP_PER_UNIT / (single_ms * 1e-3) / 1e12) / FP64_VECTOR_PEAK_TFLOPS,
+                         "per_kernel": per_kernel,
+                         "hbm": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": achieved_gbs / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_UNIT * args.frames},
+                         "traffic": traffic,
+                         "traffic_note": None if tname is None else
+                         f"static: fabric bytes per launch from rocprofv3 PMC (profiles/{tname}), not measured by this run; "
+                         "includes Infinity-Cache hits on the re-used per-team workspaces",
+                         "valu_issue_measured": valu_issue},
         }
+        if strong is not None:
+            line["strong"] = strong
+        if world == 1:
+            # what strong scaling of the 1000-frame trajectory can reach: a rank's share analysed on this
+            # GPU (ranks are independent; the gather is not in these numbers)
+            model = {}
+            for n in (2, 4, 8):
+                if args.frames % n:
+                    continue
+                _, part = synth.synthetic_units(args.frames // n)
+                r2 = ctx.upload(_lib.Batch.uniform(part, vdw, mass))
+                ms = r2.time_launches(10)
+                r2.free()
+                model[str(n)] = {"frames_per_gpu": args.frames // n, "ms_per_step": ms,
+                                 "predicted_frames_per_s": args.frames / (ms * 1e-3)}
+            line["strong_scaling_model_1gpu"] = model
         if not args.no_secondary and world == 1:
-            line["secondary"] = secondary(ctx, elements, vdw, mass)
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(elements, frames, vdw, mass)
+            line["secondary"] = secondary(ctx, vdw, mass)
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+            line["vs_cpu_baseline"] = {"one_core": value / cpu["value"],
+                                       "all_core": (value / cpu["all_core"]["value"]) if "value" in cpu.get("all_core", {}) else None,
+                                       "target": "north_star: >= 10x reference-CPU frames/s at 1 GPU"}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

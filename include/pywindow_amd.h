@@ -59,6 +59,10 @@ typedef struct pw_batch_in {
     const double *xyz;          /* sum(N) x 3, row-major as numpy (N,3) */
     const double *vdw;          /* per atom: atomic_vdw_radius[element] (tables.py:111-197) */
     const double *mass;         /* per atom: atomic_mass[element]      (tables.py:22-108)  */
+    int64_t template_atoms;     /* 0: vdw / mass have one entry per atom of the batch (sum(N));
+                                   T > 0: every unit has T atoms and vdw / mass are ONE template of T
+                                   entries -- the frames of a trajectory share their elements
+                                   (trajectory.py:245-248), so the constants travel once */
 } pw_batch_in;
 
 /* Fixed-size result record of one unit == Molecule.properties (molecular.py:215-352). */
@@ -90,6 +94,20 @@ typedef struct pw_unit_out {
     double eps;            /* DBSCAN radius */
     double sphere_r;       /* sampling sphere radius in find_windows */
 } pw_unit_out;
+
+/* Stage-level capture of find_windows for one unit (pw_analysis_debug; the parity tests compare it
+ * with the reference's intermediate results). */
+typedef struct pw_unit_debug {
+    int32_t n_survivors;            /* sampling vectors that pass vector_analysis (utilities.py:1457-1467) */
+    int32_t n_clusters;
+    int32_t pass_idx[PW_P_MAX];     /* their indices on the sampling sphere, ascending */
+    int32_t labels[PW_P_MAX];       /* DBSCAN label of each (utilities.py:1478-1487) */
+    double gap2[PW_P_MAX];          /* vector_analysis result [1]: 2 * narrowest gap along the path */
+    double win[PW_W_MAX][12];       /* window_analysis per cluster (utilities.py:1191-1361): chosen vector (3),
+                                       angle_1, angle_2 (as angle_between_vectors returns them), new_z,
+                                       diameter at the neck point, z optimum,
+                                       x, y optimum, final diameter, evaluations */
+} pw_unit_debug;
 
 /* Optional knobs of the reference's free functions.  Defaults are the
  * values Molecule.full_analysis() uses; a context starts with the defaults. */
@@ -130,6 +148,11 @@ int pw_context_set_params(pw_context *ctx, const pw_params *params);
  * (pore_diameter, max_dim, ... ) the parity tests exercise one by one. */
 int pw_analysis_batch(pw_context *ctx, const pw_batch_in *in, uint32_t stages, pw_unit_out *out);
 
+/* The same analysis with the intermediate results of find_windows captured per unit (dbg: n_units
+ * records, caller-allocated).  Test instrumentation: one launch at a time, no overlap. */
+int pw_analysis_debug(pw_context *ctx, const pw_batch_in *in, uint32_t stages, pw_unit_out *out,
+                      pw_unit_debug *dbg);
+
 /* Fine-grained: min_i(|r_i - p| - vdw_i) and its first argmin at arbitrary points,
  * point q belonging to unit unit_of_point[q]  (pore_diameter(.., com=p)[0]/2 and [1],
  * utilities.py:375-388; the objective of every optimiser on the path). */
@@ -146,8 +169,20 @@ void pw_resident_free(pw_context *ctx, pw_resident *res);
 /* `iters` back-to-back launches bracketed by HIP events on the launch stream;
  * writes the average milliseconds per launch. */
 int pw_resident_time(pw_context *ctx, pw_resident *res, uint32_t stages, int iters, float *ms_per_launch);
+/* one analysis on its own, timed per launch of the pipeline with HIP events on the launch's own
+ * stream: ms[0] optimiser chains, ms[1] average diameter, ms[2] window search (measurement only) */
+int pw_resident_stage_times(pw_context *ctx, pw_resident *res, float *ms3);
 /* raw device pointer of the result records (for RCCL gathers by the host side) */
 void *pw_resident_device_results(pw_resident *res);
+/* Stream-ordered hand-over of the latest launch's records to a stream of the caller (hipStream_t as
+ * an opaque pointer; NULL = the legacy default stream): work queued on `stream` afterwards sees the
+ * finished records at *results (device pointer), without a host synchronisation.  This is how the
+ * one collective of a multi-GPU run -- the gather of the records, Trajectory._analysis_parallel's
+ * pool.get() (trajectory.py:553-586) -- reads them: no host bounce. */
+int pw_resident_results_ready(pw_context *ctx, pw_resident *res, void *stream, void **results);
+/* ... and the way back: the launch that next overwrites those records waits for everything queued
+ * on `stream` so far (call it after queueing the gather). */
+int pw_resident_results_release(pw_context *ctx, pw_resident *res, void *stream);
 int64_t pw_resident_units(pw_resident *res);
 /* the HIP stream (hipStream_t) launches are issued on, as an opaque pointer */
 void *pw_context_stream(pw_context *ctx);

@@ -42,6 +42,7 @@ class BatchIn(ctypes.Structure):
         ("xyz", ctypes.POINTER(ctypes.c_double)),
         ("vdw", ctypes.POINTER(ctypes.c_double)),
         ("mass", ctypes.POINTER(ctypes.c_double)),
+        ("template_atoms", ctypes.c_int64),
     ]
 
 
@@ -163,6 +164,21 @@ UNIT_OUT_DTYPE = np.dtype(
     align=True,
 )
 
+#: numpy mirror of ``pw_unit_debug`` (stage capture of find_windows, ``Context.analyse_debug``)
+UNIT_DEBUG_DTYPE = np.dtype(
+    [
+        ("n_survivors", np.int32),
+        ("n_clusters", np.int32),
+        ("pass_idx", np.int32, (P_MAX,)),
+        ("labels", np.int32, (P_MAX,)),
+        ("gap2", np.float64, (P_MAX,)),
+        ("win", np.float64, (W_MAX, 12)),
+    ],
+    align=True,
+)
+#: columns of ``UNIT_DEBUG_DTYPE["win"]``
+DEBUG_WIN_COLS = ("vx", "vy", "vz", "angle_1", "angle_2", "new_z", "d0", "z_x", "xy_x", "xy_y", "diam", "n_eval")
+
 #: numpy mirror of ``pw_shape_out``
 SHAPE_OUT_DTYPE = np.dtype(
     [
@@ -186,6 +202,7 @@ EXPORTED_SYMBOLS = [
     "pw_params_default",
     "pw_context_set_params",
     "pw_analysis_batch",
+    "pw_analysis_debug",
     "pw_point_gaps",
     "pw_resident_upload",
     "pw_resident_launch",
@@ -193,7 +210,10 @@ EXPORTED_SYMBOLS = [
     "pw_resident_download",
     "pw_resident_free",
     "pw_resident_time",
+    "pw_resident_stage_times",
     "pw_resident_device_results",
+    "pw_resident_results_ready",
+    "pw_resident_results_release",
     "pw_resident_units",
     "pw_context_stream",
     "pw_context_device",
@@ -270,6 +290,7 @@ def load():
     L.pw_params_default.restype = None
     L.pw_context_set_params.argtypes = [vp, ctypes.POINTER(Params)]
     L.pw_analysis_batch.argtypes = [vp, ctypes.POINTER(BatchIn), ctypes.c_uint32, vp]
+    L.pw_analysis_debug.argtypes = [vp, ctypes.POINTER(BatchIn), ctypes.c_uint32, vp, vp]
     L.pw_point_gaps.argtypes = [vp, ctypes.POINTER(BatchIn), vp, vp, ctypes.c_int64, vp, vp]
     L.pw_resident_upload.argtypes = [vp, ctypes.POINTER(BatchIn), ctypes.POINTER(vp)]
     L.pw_resident_launch.argtypes = [vp, vp, ctypes.c_uint32]
@@ -278,8 +299,11 @@ def load():
     L.pw_resident_free.argtypes = [vp, vp]
     L.pw_resident_free.restype = None
     L.pw_resident_time.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+    L.pw_resident_stage_times.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.pw_resident_device_results.argtypes = [vp]
     L.pw_resident_device_results.restype = vp
+    L.pw_resident_results_ready.argtypes = [vp, vp, vp, ctypes.POINTER(vp)]
+    L.pw_resident_results_release.argtypes = [vp, vp, vp]
     L.pw_resident_units.argtypes = [vp]
     L.pw_resident_units.restype = ctypes.c_int64
     L.pw_context_stream.argtypes = [vp]
@@ -319,30 +343,36 @@ def _dptr(a):
 class Batch:
     """Host-side description of a ragged batch of molecules (keeps arrays alive)."""
 
-    def __init__(self, atom_offset, xyz, vdw, mass):
+    def __init__(self, atom_offset, xyz, vdw, mass, template_atoms: int = 0):
+        """``template_atoms`` = T > 0: every unit has T atoms and ``vdw`` / ``mass`` are one template
+        of T entries (``pw_batch_in.template_atoms``); 0: one entry per atom of the batch."""
         self.atom_offset = np.ascontiguousarray(atom_offset, dtype=np.int64)
         self.xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
         self.vdw = np.ascontiguousarray(vdw, dtype=np.float64)
         self.mass = np.ascontiguousarray(mass, dtype=np.float64)
         n_atoms = int(self.atom_offset[-1]) if len(self.atom_offset) else 0
-        if len(self.xyz) != n_atoms or len(self.vdw) != n_atoms or len(self.mass) != n_atoms:
+        n_const = int(template_atoms) if template_atoms else n_atoms
+        if len(self.xyz) != n_atoms or len(self.vdw) != n_const or len(self.mass) != n_const:
             raise ValueError("atom_offset does not match the per-atom arrays")
         self.n_units = len(self.atom_offset) - 1
+        self.template_atoms = int(template_atoms)
         self.c = BatchIn(
             self.n_units,
             self.atom_offset.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
             _dptr(self.xyz),
             _dptr(self.vdw),
             _dptr(self.mass),
+            self.template_atoms,
         )
 
     @classmethod
     def uniform(cls, coords, vdw, mass):
-        """``coords`` (U, N, 3) of one molecule type; ``vdw``/``mass`` (N,)."""
+        """``coords`` (U, N, 3) of one molecule type; ``vdw``/``mass`` (N,): the constants of the
+        trajectory travel once, as a template."""
         coords = np.ascontiguousarray(coords, dtype=np.float64)
         u, n, _ = coords.shape
         off = np.arange(u + 1, dtype=np.int64) * n
-        return cls(off, coords.reshape(-1, 3), np.tile(vdw, u), np.tile(mass, u))
+        return cls(off, coords.reshape(-1, 3), vdw, mass, template_atoms=n)
 
 
 class Context:
@@ -354,6 +384,10 @@ class Context:
         _check(L.pw_context_create(device, ctypes.byref(h)), "pw_context_create")
         self._h = h
         self.device = device
+        # params live on the context between set and reset: one analysis with params at a time
+        import threading
+
+        self._params_lock = threading.Lock()
 
     def close(self):
         if self._h:
@@ -375,17 +409,29 @@ class Context:
         out = np.zeros(batch.n_units, dtype=UNIT_OUT_DTYPE)
         if batch.n_units == 0:
             return out
-        if params is not None:
-            self.set_params(params)
-        try:
-            _check(
-                load().pw_analysis_batch(self._h, ctypes.byref(batch.c), stages, out.ctypes.data),
-                "pw_analysis_batch",
-            )
-        finally:
+        with self._params_lock:
             if params is not None:
-                self.set_params(None)
+                self.set_params(params)
+            try:
+                _check(
+                    load().pw_analysis_batch(self._h, ctypes.byref(batch.c), stages, out.ctypes.data),
+                    "pw_analysis_batch",
+                )
+            finally:
+                if params is not None:
+                    self.set_params(None)
         return out
+
+    def analyse_debug(self, batch: Batch, stages: int = STAGE_ALL):
+        """``pw_analysis_debug``: ``(records, stage captures)`` -- the intermediate results of
+        find_windows per unit (``UNIT_DEBUG_DTYPE``), for the parity tests."""
+        out = np.zeros(batch.n_units, dtype=UNIT_OUT_DTYPE)
+        dbg = np.zeros(batch.n_units, dtype=UNIT_DEBUG_DTYPE)
+        if batch.n_units:
+            with self._params_lock:
+                _check(load().pw_analysis_debug(self._h, ctypes.byref(batch.c), stages, out.ctypes.data,
+                                                dbg.ctypes.data), "pw_analysis_debug")
+        return out, dbg
 
     def point_gaps(self, batch: Batch, unit_of_point, points):
         """min_i(|r_i - p| - vdw_i), argmin for each point (objective of the optimisers)."""
@@ -540,9 +586,29 @@ class Resident:
         _check(load().pw_resident_time(self.ctx._h, self._h, stages, iters, ctypes.byref(ms)), "pw_resident_time")
         return float(ms.value)
 
+    def stage_times(self) -> dict:
+        """Milliseconds of the three launches of ONE analysis run on its own (HIP events on each
+        launch's stream): ``{"chains", "average", "windows"}``."""
+        ms = (ctypes.c_float * 3)()
+        _check(load().pw_resident_stage_times(self.ctx._h, self._h, ms), "pw_resident_stage_times")
+        return {"chains": float(ms[0]), "average": float(ms[1]), "windows": float(ms[2])}
+
     @property
     def device_results_ptr(self) -> int:
         return load().pw_resident_device_results(self._h) or 0
+
+    def results_ready(self, stream: int = 0) -> int:
+        """Make HIP stream ``stream`` (a ``hipStream_t`` as an integer; 0 = the default stream) wait
+        for the latest launch; returns the device address of its records."""
+        ptr = ctypes.c_void_p()
+        _check(load().pw_resident_results_ready(self.ctx._h, self._h, ctypes.c_void_p(stream or None),
+                                                ctypes.byref(ptr)), "pw_resident_results_ready")
+        return ptr.value or 0
+
+    def results_release(self, stream: int = 0) -> None:
+        """The launch that next overwrites the records waits for what ``stream`` holds so far."""
+        _check(load().pw_resident_results_release(self.ctx._h, self._h, ctypes.c_void_p(stream or None)),
+               "pw_resident_results_release")
 
     def free(self):
         if self._h:

@@ -20,6 +20,7 @@
 #include <new>
 
 #include "../../include/pywindow_amd.h"
+#include "pw_host.hpp"
 #include "pw_unit.hpp"
 
 using namespace pw;
@@ -38,6 +39,12 @@ void set_err(const char* what, hipError_t e) {
             return PW_E_HIP;                  \
         }                                     \
     } while (0)
+
+// first statement of every entry point that touches the device: work on the context's device, give
+// the calling thread its own device back on every return path
+#define PW_ON_DEVICE(dev)                     \
+    DeviceScope dev_scope_;                   \
+    HIP_TRY(dev_scope_.enter(dev))
 
 // Hand-off between the optimiser launch (producer, one wave per unit) and the window
 // launch (consumer, persistent teams): a producer publishes the index of a unit whose pore
@@ -67,7 +74,7 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
                   int nmax, int nrot, int nlb, int nframes, int lean, TeamWorkspace* __restrict__ workspaces,
                   unsigned long long* __restrict__ adj_base, unsigned long long* counter,
                   pw_unit_out* __restrict__ out, int role, UnitQueue* queue, int* __restrict__ slots,
-                  pw_params prm, const unsigned* __restrict__ rsq_tab) {
+                  pw_params prm, const unsigned* __restrict__ rsq_tab, int vstride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ long s_unit;
     using T = DeviceTeam<NW>;
@@ -118,7 +125,10 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
         if (u < 0) break;
         long a0 = atom_offset[u];
         int n = (int)(atom_offset[u + 1] - a0);
-        analyse_unit<T, MASK>(sh, ws, n, xyz + 3 * a0, vdw + a0, mass + a0, stages & MASK, out + u, prm);
+        // vstride 0: one molecule type, vdw / mass hold a single template (per-trajectory constants)
+        const long v0 = a0 * vstride;
+        if (threadIdx.x == 0) ws->unit = u;     // (read by the debug capture only; ordered by load_unit's barrier)
+        analyse_unit<T, MASK>(sh, ws, n, xyz + 3 * a0, vdw + v0, mass + v0, stages & MASK, out + u, prm);
         if (role == PW_ROLE_PRODUCER) {
             // analyse_unit ended with a team barrier; thread 0 wrote the record
             if (threadIdx.x == 0) {
@@ -174,7 +184,7 @@ __global__ void pw_point_gap_kernel(long n_points, const long* __restrict__ unit
                                     const double* __restrict__ points,
                                     const long* __restrict__ atom_offset,
                                     const double* __restrict__ xyz, const double* __restrict__ vdw,
-                                    double* __restrict__ gap, int* __restrict__ arg) {
+                                    double* __restrict__ gap, int* __restrict__ arg, int vstride) {
     long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_points) return;
     long u = unit_of_point[q];
@@ -190,11 +200,17 @@ __global__ void pw_point_gap_kernel(long n_points, const long* __restrict__ unit
         double g = pw_fma(z, pz, pw_fma(x, px, y * py));
         double d2 = ((-2.0 * g) + xx) + pp;
         double d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
-        double v = d - vdw[a0 + i];
+        double v = d - vdw[a0 * vstride + i];
         if (v < best) { best = v; bi = i; }
     }
     gap[q] = best;
     arg[q] = bi;
+}
+
+// pw_analysis_debug: point every team workspace at the capture buffer (or away from it)
+__global__ void pw_set_debug_kernel(TeamWorkspace* ws, int blocks, pw_unit_debug* dbg) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < blocks) ws[b].dbg_base = dbg;
 }
 
 }  // namespace
@@ -237,12 +253,22 @@ struct pw_context {
     int c_waves;             // waves per team in the window launch (PW_C_WAVES, default 4)
     pw_params prm;           // knobs of find_windows / find_average_diameter
     unsigned* rsq_tab;       // VRSQRT14PD table on the device (numpy's arccos, pw_math.hpp)
+    // team workspaces of the pipeline: C0 | A0 | B | A1 | C1, each region sized for the largest grid
+    // any launch on this context has asked for so far.  The layout only changes when a maximum
+    // grows, and growing synchronises the device first, so two launches in flight -- which may have
+    // different plans (other batch size, other stage mask) -- never share a team workspace.
+    int max_a, max_b, max_c;
+    hipEvent_t ev_ext;       // ordering against a caller's stream (pw_resident_results_ready)
+    hipEvent_t ev_t[3][2];   // pw_resident_stage_times: start / stop of the chains, average and window launches
+    int timing;              // record them during the next pipeline launch
+    pw_unit_debug* dbg;      // per-unit stage capture of the current debug analysis, else null
 };
 
 struct pw_resident {
     long n_units;
     long n_atoms;
     int nmax;
+    int vstride;             // 1: d_vdw / d_mass per atom; 0: one template of nmax atoms for every unit
     long* d_offset;
     double* d_xyz;
     double* d_vdw;
@@ -250,6 +276,8 @@ struct pw_resident {
     pw_unit_out* d_out;      // result records of the latest launch (= d_outs[cur])
     pw_unit_out* d_outs[2];
     int cur;
+    hipEvent_t ev_read[2];   // a caller's stream has finished reading d_outs[k] (pw_resident_results_release)
+    int read_valid[2];
 };
 
 static int ensure_workspace(pw_context* c, int blocks, int adj_blocks) {
@@ -333,7 +361,8 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
                        r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb, p.nframes, p.lean,
                        c->ws + ws_first,
                        adj_first >= 0 ? c->adj + (size_t)adj_first * PW_ADJ_WORDS : (unsigned long long*)nullptr,
-                       c->counter + counter_slot, r->d_out, role, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab);
+                       c->counter + counter_slot, r->d_out, role, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab,
+                       r->vstride);
     HIP_TRY(hipGetLastError());
     return PW_OK;
 }
@@ -373,46 +402,55 @@ int pw_device_count(void) {
 
 int pw_context_create(int device, pw_context** out) {
     if (!out) return PW_E_BAD_ARG;
+    *out = nullptr;
     int n = pw_device_count();
     if (n <= 0 || device < 0 || device >= n) {
         snprintf(g_err, sizeof(g_err), "no usable HIP device (count=%d, requested %d)", n, device);
         return PW_E_NO_DEVICE;
     }
-    HIP_TRY(hipSetDevice(device));
+    PW_ON_DEVICE(device);
     pw_context* c = new (std::nothrow) pw_context();
     if (!c) return PW_E_NOMEM;
     memset(c, 0, sizeof(*c));
     c->device = device;
+    // any failure below: release what exists so far (pw_context_destroy takes a half-built object)
+#define CTX_TRY(call)                         \
+    do {                                      \
+        hipError_t e_ = (call);               \
+        if (e_ != hipSuccess) {               \
+            set_err(#call, e_);               \
+            pw_context_destroy(c);            \
+            return PW_E_HIP;                  \
+        }                                     \
+    } while (0)
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    CTX_TRY(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount;
     c->lds_per_cu = 160 * 1024;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc((void**)&c->counter, 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc((void**)&c->queue, 2 * sizeof(UnitQueue)));
-    HIP_TRY(hipMemset(c->queue, 0, 2 * sizeof(UnitQueue)));
+    CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CTX_TRY(hipMalloc((void**)&c->counter, 8 * sizeof(unsigned long long)));
+    CTX_TRY(hipMalloc((void**)&c->queue, 2 * sizeof(UnitQueue)));
+    CTX_TRY(hipMemset(c->queue, 0, 2 * sizeof(UnitQueue)));
     c->cur_queue = c->queue;
     {
         // the optimiser chains are the critical path: their launch gets the highest priority,
         // the average-diameter launch the lowest
         int lo = 0, hi = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIP_TRY(hipStreamCreateWithPriority(&c->prods[0], hipStreamNonBlocking, hi));
-        HIP_TRY(hipStreamCreateWithPriority(&c->prods[1], hipStreamNonBlocking, hi));
+        CTX_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        CTX_TRY(hipStreamCreateWithPriority(&c->prods[0], hipStreamNonBlocking, hi));
+        CTX_TRY(hipStreamCreateWithPriority(&c->prods[1], hipStreamNonBlocking, hi));
         c->prod = c->prods[0];
-        (void)hipStreamDestroy(c->aux);
-        HIP_TRY(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, lo));
+        CTX_TRY(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, lo));
     }
     for (int b = 0; b < 2; ++b) {
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_reset[b], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_prod[b], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_gate[b], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_join[b], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_tail[b], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_head[b], hipEventDisableTiming));
-        HIP_TRY(hipStreamCreateWithFlags(&c->cons[b], hipStreamNonBlocking));
+        CTX_TRY(hipEventCreateWithFlags(&c->ev_reset[b], hipEventDisableTiming));
+        CTX_TRY(hipEventCreateWithFlags(&c->ev_prod[b], hipEventDisableTiming));
+        CTX_TRY(hipEventCreateWithFlags(&c->ev_gate[b], hipEventDisableTiming));
+        CTX_TRY(hipEventCreateWithFlags(&c->ev_join[b], hipEventDisableTiming));
+        CTX_TRY(hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming));
+        CTX_TRY(hipEventCreateWithFlags(&c->ev_tail[b], hipEventDisableTiming));
+        CTX_TRY(hipEventCreateWithFlags(&c->ev_head[b], hipEventDisableTiming));
+        CTX_TRY(hipStreamCreateWithFlags(&c->cons[b], hipStreamNonBlocking));
     }
     {
         const char* hg = getenv("PW_HEAD_GATE");
@@ -425,9 +463,10 @@ int pw_context_create(int device, pw_context** out) {
         if (c->tail_pct < 0 || c->tail_pct > 100) c->tail_pct = 0;
     }
     c->need_fork = 1;
-    HIP_TRY(hipEventCreate(&c->ev0));
-    HIP_TRY(hipEventCreate(&c->ev1));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    CTX_TRY(hipEventCreate(&c->ev0));
+    CTX_TRY(hipEventCreate(&c->ev1));
+    CTX_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    CTX_TRY(hipEventCreateWithFlags(&c->ev_ext, hipEventDisableTiming));
     const char* fz = getenv("PW_FUSED");
     c->fused = (fz && fz[0] == '1') ? 1 : 0;
     const char* cw = getenv("PW_C_WAVES");
@@ -435,23 +474,30 @@ int pw_context_create(int device, pw_context** out) {
     c->prm = default_params();
     {
         unsigned* host = new (std::nothrow) unsigned[65536];
-        if (!host) return PW_E_NOMEM;
+        if (!host) { pw_context_destroy(c); return PW_E_NOMEM; }
         rsqrt14_decode(host);
         hipError_t e1 = hipMalloc((void**)&c->rsq_tab, 65536 * sizeof(unsigned));
         hipError_t e2 = e1 == hipSuccess
                             ? hipMemcpy(c->rsq_tab, host, 65536 * sizeof(unsigned), hipMemcpyHostToDevice)
                             : e1;
         delete[] host;
-        if (e2 != hipSuccess) { set_err("rsqrt14 table upload", e2); return PW_E_HIP; }
+        if (e2 != hipSuccess) { set_err("rsqrt14 table upload", e2); pw_context_destroy(c); return PW_E_HIP; }
     }
+#undef CTX_TRY
     *out = c;
     return PW_OK;
 }
 
 void pw_context_destroy(pw_context* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceScope scope;
+    (void)scope.enter(c->device);
+    (void)hipDeviceSynchronize();
     if (c->ws) (void)hipFree(c->ws);
+    if (c->ev_ext) (void)hipEventDestroy(c->ev_ext);
+    for (int k = 0; k < 3; ++k)
+        for (int e = 0; e < 2; ++e)
+            if (c->ev_t[k][e]) (void)hipEventDestroy(c->ev_t[k][e]);
     if (c->counter) (void)hipFree(c->counter);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -512,7 +558,7 @@ void* pw_context_stream(pw_context* c) { return c ? (void*)c->stream : nullptr; 
 int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     if (!c || !r) return PW_E_BAD_ARG;
     if (r->n_units == 0) return PW_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    PW_ON_DEVICE(c->device);
     stages &= PW_STAGE_ALL;
     const bool pipeline = !c->fused && (stages & PW_STAGE_WINDOWS) != 0;
     int rc;
@@ -529,6 +575,10 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         c->need_fork = 1;
         rc = join_pipeline(c);
         if (rc != PW_OK) return rc;
+        if (r->read_valid[r->cur]) {
+            HIP_TRY(hipStreamWaitEvent(c->stream, r->ev_read[r->cur], 0));
+            r->read_valid[r->cur] = 0;
+        }
         return launch_plan(c, r, stages, p, c->stream, 0, win ? 0 : -1, 0);
     }
     // Pipeline: the analysis is split by parallel shape and the pieces overlap.
@@ -576,9 +626,16 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         const char* bt = getenv("PW_B_TEAMS");
         if (bt && do_avg && atoi(bt) > 0 && atoi(bt) < pb.grid) pb.grid = atoi(bt);
     }
-    // teams: C0 | A0 | B | A1 | C1 (two window and two optimiser launches can be in flight)
-    int need = 2 * pc.grid + 2 * pa.grid + pb.grid;
-    rc = ensure_workspace(c, need, 2 * pc.grid);
+    // teams: C0 | A0 | B | A1 | C1 (two window and two optimiser launches can be in flight), every
+    // region as large as the largest grid seen so far -- see pw_context::max_a
+    if (pa.grid > c->max_a || pb.grid > c->max_b || pc.grid > c->max_c) {
+        HIP_TRY(hipDeviceSynchronize());         // nothing is in flight while the layout changes
+        if (pa.grid > c->max_a) c->max_a = pa.grid;
+        if (pb.grid > c->max_b) c->max_b = pb.grid;
+        if (pc.grid > c->max_c) c->max_c = pc.grid;
+    }
+    const int ws_c0 = 0, ws_a0 = c->max_c, ws_b = ws_a0 + c->max_a, ws_a1 = ws_b + c->max_b, ws_c1 = ws_a1 + c->max_a;
+    rc = ensure_workspace(c, ws_c1 + c->max_c, 2 * c->max_c);
     if (rc != PW_OK) return rc;
     if (c->slots_cap < r->n_units) {
         HIP_TRY(hipDeviceSynchronize());
@@ -614,6 +671,10 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         c->need_fork = 0;
     }
     if (c->done_valid[b]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_done[b], 0));
+    if (r->read_valid[r->cur]) {     // a gather on the caller's stream may still be reading this buffer
+        HIP_TRY(hipStreamWaitEvent(c->prod, r->ev_read[r->cur], 0));
+        r->read_valid[r->cur] = 0;
+    }
     // the previous launch's tail gate reads the queue that is reset below
     if (c->tail_valid[b ^ 1]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_tail[b ^ 1], 0));
     if (c->head_valid[b ^ 1]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_head[b ^ 1], 0));
@@ -631,9 +692,11 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     }
     c->last_units[b] = r->n_units;
     // two optimiser launches can be in flight: separate work counters and workspaces
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][0], c->prod));
     rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod,
-                     pc.grid + (b ? pa.grid + pb.grid : 0), -1, b ? 3 : 0, PW_ROLE_PRODUCER);
+                     b ? ws_a1 : ws_a0, -1, b ? 3 : 0, PW_ROLE_PRODUCER);
     if (rc != PW_OK) return rc;
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][1], c->prod));
     HIP_TRY(hipEventRecord(c->ev_prod[b], c->prod));
     hipStream_t cs = c->cons[b];
     HIP_TRY(hipStreamWaitEvent(cs, c->ev_reset[b], 0));
@@ -653,13 +716,17 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
             HIP_TRY(hipStreamWaitEvent(cs, c->ev_done[b ^ 1], 0));
         }
     }
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][0], cs));
     rc = launch_plan(c, r, PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pc, cs,
-                     b ? pc.grid + 2 * pa.grid + pb.grid : 0, b ? pc.grid : 0, b ? 4 : 2, PW_ROLE_CONSUMER);
+                     b ? ws_c1 : ws_c0, b ? c->max_c : 0, b ? 4 : 2, PW_ROLE_CONSUMER);
     if (rc != PW_OK) return rc;
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][1], cs));
     if (do_avg) {
         HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_gate[b], 0));
-        rc = launch_plan(c, r, PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pb, c->aux, pc.grid + pa.grid, -1, 1);
+        if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[1][0], c->aux));
+        rc = launch_plan(c, r, PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pb, c->aux, ws_b, -1, 1);
         if (rc != PW_OK) return rc;
+        if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[1][1], c->aux));
         HIP_TRY(hipEventRecord(c->ev_join[b], c->aux));
     }
     HIP_TRY(hipStreamWaitEvent(cs, c->ev_prod[b], 0));
@@ -669,17 +736,33 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     return PW_OK;
 }
 
-int pw_resident_sync(pw_context* c) {
-    if (!c) return PW_E_BAD_ARG;
-    int rcj = join_pipeline(c);
-    if (rcj != PW_OK) return rcj;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+// a consumer team that gave up waiting for the optimiser launch sets its queue's error flag: every
+// call that waits for results reports it (and clears it), so a timed-out analysis is never mistaken
+// for a finished one -- neither downloaded nor timed
+static int check_queue_error(pw_context* c) {
+    UnitQueue q[2];
+    HIP_TRY(hipMemcpy(q, c->queue, sizeof(q), hipMemcpyDeviceToHost));
+    if (q[0].error || q[1].error) {
+        (void)hipMemset(c->queue, 0, sizeof(q));
+        snprintf(g_err, sizeof(g_err), "window launch timed out waiting for the optimiser launch");
+        return PW_E_HIP;
+    }
     return PW_OK;
 }
 
+int pw_resident_sync(pw_context* c) {
+    if (!c) return PW_E_BAD_ARG;
+    PW_ON_DEVICE(c->device);
+    int rcj = join_pipeline(c);
+    if (rcj != PW_OK) return rcj;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return check_queue_error(c);
+}
+
 int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) {
-    if (!c || !in || !out || in->n_units < 0) return PW_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    if (!c || !in || !out || in->n_units < 0 || in->template_atoms < 0) return PW_E_BAD_ARG;
+    *out = nullptr;
+    PW_ON_DEVICE(c->device);
     pw_resident* r = new (std::nothrow) pw_resident();
     if (!r) return PW_E_NOMEM;
     memset(r, 0, sizeof(*r));
@@ -689,34 +772,49 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
     int nmax = 0;
     for (long u = 0; u < r->n_units; ++u) {
         long n = (long)(in->atom_offset[u + 1] - in->atom_offset[u]);
-        if (n <= 0) {
+        if (n <= 0 || (in->template_atoms > 0 && n != in->template_atoms)) {
             delete r;
-            snprintf(g_err, sizeof(g_err), "unit %ld has %ld atoms", u, n);
+            if (n <= 0) snprintf(g_err, sizeof(g_err), "unit %ld has %ld atoms", u, n);
+            else snprintf(g_err, sizeof(g_err), "unit %ld has %ld atoms, the template %ld", u, n, (long)in->template_atoms);
             return PW_E_BAD_ARG;
         }
         if (n > nmax) nmax = (int)n;
     }
     r->nmax = nmax;
+    r->vstride = in->template_atoms > 0 ? 0 : 1;
+    // radii and masses: per atom, or ONE template for a batch of one molecule type (a trajectory)
+    const long nconst = in->template_atoms > 0 ? (long)in->template_atoms : natoms;
+#define UP_TRY(call)                          \
+    do {                                      \
+        hipError_t e_ = (call);               \
+        if (e_ != hipSuccess) {               \
+            set_err(#call, e_);               \
+            pw_resident_free(c, r);           \
+            return PW_E_HIP;                  \
+        }                                     \
+    } while (0)
     if (r->n_units) {
-        HIP_TRY(hipMalloc((void**)&r->d_offset, sizeof(long) * (r->n_units + 1)));
-        HIP_TRY(hipMalloc((void**)&r->d_xyz, sizeof(double) * 3 * natoms));
-        HIP_TRY(hipMalloc((void**)&r->d_vdw, sizeof(double) * natoms));
-        HIP_TRY(hipMalloc((void**)&r->d_mass, sizeof(double) * natoms));
-        HIP_TRY(hipMalloc((void**)&r->d_outs[0], 2 * sizeof(pw_unit_out) * r->n_units));
+        UP_TRY(hipMalloc((void**)&r->d_offset, sizeof(long) * (r->n_units + 1)));
+        UP_TRY(hipMalloc((void**)&r->d_xyz, sizeof(double) * 3 * natoms));
+        UP_TRY(hipMalloc((void**)&r->d_vdw, sizeof(double) * nconst));
+        UP_TRY(hipMalloc((void**)&r->d_mass, sizeof(double) * nconst));
+        UP_TRY(hipMalloc((void**)&r->d_outs[0], 2 * sizeof(pw_unit_out) * r->n_units));
         r->d_outs[1] = r->d_outs[0] + r->n_units;
         r->d_out = r->d_outs[0];
         r->cur = 0;
-        HIP_TRY(hipMemcpyAsync(r->d_offset, in->atom_offset, sizeof(long) * (r->n_units + 1),
-                               hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(r->d_xyz, in->xyz, sizeof(double) * 3 * natoms, hipMemcpyHostToDevice,
-                               c->stream));
-        HIP_TRY(hipMemcpyAsync(r->d_vdw, in->vdw, sizeof(double) * natoms, hipMemcpyHostToDevice,
-                               c->stream));
-        HIP_TRY(hipMemcpyAsync(r->d_mass, in->mass, sizeof(double) * natoms, hipMemcpyHostToDevice,
-                               c->stream));
-        HIP_TRY(hipMemsetAsync(r->d_outs[0], 0, 2 * sizeof(pw_unit_out) * r->n_units, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        UP_TRY(hipMemcpyAsync(r->d_offset, in->atom_offset, sizeof(long) * (r->n_units + 1),
+                              hipMemcpyHostToDevice, c->stream));
+        UP_TRY(hipMemcpyAsync(r->d_xyz, in->xyz, sizeof(double) * 3 * natoms, hipMemcpyHostToDevice,
+                              c->stream));
+        UP_TRY(hipMemcpyAsync(r->d_vdw, in->vdw, sizeof(double) * nconst, hipMemcpyHostToDevice,
+                              c->stream));
+        UP_TRY(hipMemcpyAsync(r->d_mass, in->mass, sizeof(double) * nconst, hipMemcpyHostToDevice,
+                              c->stream));
+        UP_TRY(hipMemsetAsync(r->d_outs[0], 0, 2 * sizeof(pw_unit_out) * r->n_units, c->stream));
+        UP_TRY(hipStreamSynchronize(c->stream));
     }
+#undef UP_TRY
+    c->need_fork = 1;
     *out = r;
     return PW_OK;
 }
@@ -725,7 +823,7 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
 int pw_internal_resident_adopt(pw_context* c, long n_units, long n_atoms, int nmax, long* d_offset, double* d_xyz,
                                double* d_vdw, double* d_mass, pw_resident** out) {
     if (!c || !out || n_units <= 0 || nmax <= 0) return PW_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    PW_ON_DEVICE(c->device);
     pw_resident* r = new (std::nothrow) pw_resident();
     if (!r) return PW_E_NOMEM;
     memset(r, 0, sizeof(*r));
@@ -738,7 +836,7 @@ int pw_internal_resident_adopt(pw_context* c, long n_units, long n_atoms, int nm
         delete r;
         return PW_E_HIP;
     }
-    r->n_units = n_units; r->n_atoms = n_atoms; r->nmax = nmax;
+    r->n_units = n_units; r->n_atoms = n_atoms; r->nmax = nmax; r->vstride = 1;
     r->d_offset = d_offset; r->d_xyz = d_xyz; r->d_vdw = d_vdw; r->d_mass = d_mass;
     r->d_outs[1] = r->d_outs[0] + n_units;
     r->d_out = r->d_outs[0];
@@ -751,40 +849,63 @@ int pw_internal_resident_adopt(pw_context* c, long n_units, long n_atoms, int nm
 int pw_resident_download(pw_context* c, pw_resident* r, pw_unit_out* out) {
     if (!c || !r || !out) return PW_E_BAD_ARG;
     if (r->n_units == 0) return PW_OK;
-    HIP_TRY(hipSetDevice(c->device));
+    PW_ON_DEVICE(c->device);
     int rcj = join_pipeline(c);
     if (rcj != PW_OK) return rcj;
     HIP_TRY(hipMemcpyAsync(out, r->d_out, sizeof(pw_unit_out) * r->n_units, hipMemcpyDeviceToHost,
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    UnitQueue q[2];
-    HIP_TRY(hipMemcpy(q, c->queue, sizeof(q), hipMemcpyDeviceToHost));
-    if (q[0].error || q[1].error) {
-        (void)hipMemset(c->queue, 0, sizeof(q));
-        snprintf(g_err, sizeof(g_err), "window launch timed out waiting for the optimiser launch");
-        return PW_E_HIP;
-    }
-    return PW_OK;
+    return check_queue_error(c);
 }
 
 void pw_resident_free(pw_context* c, pw_resident* r) {
     if (!r) return;
-    if (c) (void)hipSetDevice(c->device);
+    DeviceScope scope;
+    if (c) (void)scope.enter(c->device);
     if (r->d_offset) (void)hipFree(r->d_offset);
     if (r->d_xyz) (void)hipFree(r->d_xyz);
     if (r->d_vdw) (void)hipFree(r->d_vdw);
     if (r->d_mass) (void)hipFree(r->d_mass);
     if (c) (void)hipDeviceSynchronize();
     if (r->d_outs[0]) (void)hipFree(r->d_outs[0]);
+    for (int k = 0; k < 2; ++k)
+        if (r->ev_read[k]) (void)hipEventDestroy(r->ev_read[k]);
     delete r;
 }
 
 void* pw_resident_device_results(pw_resident* r) { return r ? (void*)r->d_out : nullptr; }
 int64_t pw_resident_units(pw_resident* r) { return r ? r->n_units : 0; }
 
+// Stream-ordered hand-over of the latest results to a caller's stream (the RCCL gather of a
+// one-process-per-GPU job runs on PyTorch's stream): no host synchronisation on either side.
+int pw_resident_results_ready(pw_context* c, pw_resident* r, void* stream, void** results) {
+    if (!c || !r) return PW_E_BAD_ARG;
+    PW_ON_DEVICE(c->device);
+    hipStream_t ext = (hipStream_t)stream;
+    for (int b = 0; b < 2; ++b)
+        if (c->done_valid[b]) HIP_TRY(hipStreamWaitEvent(ext, c->ev_done[b], 0));
+    // single-launch analyses, uploads and downloads go through the API stream
+    HIP_TRY(hipEventRecord(c->ev_ext, c->stream));
+    HIP_TRY(hipStreamWaitEvent(ext, c->ev_ext, 0));
+    if (results) *results = (void*)r->d_out;
+    return PW_OK;
+}
+
+int pw_resident_results_release(pw_context* c, pw_resident* r, void* stream) {
+    if (!c || !r) return PW_E_BAD_ARG;
+    PW_ON_DEVICE(c->device);
+    // the launch that next writes this result buffer (two launches of this batch from now) waits for
+    // what the caller's stream has been given so far; launches in between are not held back
+    const int k = r->cur;
+    if (!r->ev_read[k]) HIP_TRY(hipEventCreateWithFlags(&r->ev_read[k], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(r->ev_read[k], (hipStream_t)stream));
+    r->read_valid[k] = 1;
+    return PW_OK;
+}
+
 int pw_resident_time(pw_context* c, pw_resident* r, uint32_t stages, int iters, float* ms) {
     if (!c || !r || !ms || iters < 1) return PW_E_BAD_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    PW_ON_DEVICE(c->device);
     int rc = pw_resident_launch(c, r, stages);  // warm-up, also sizes the workspace
     if (rc != PW_OK) return rc;
     rc = pw_resident_sync(c);
@@ -802,6 +923,29 @@ int pw_resident_time(pw_context* c, pw_resident* r, uint32_t stages, int iters, 
     float total = 0.f;
     HIP_TRY(hipEventElapsedTime(&total, c->ev0, c->ev1));
     *ms = total / (float)iters;
+    return check_queue_error(c);     // a timed-out launch must not be reported as a time
+}
+
+// One analysis on its own (nothing else in flight), HIP events on the stream of each of its three
+// launches: ms[0] optimiser chains, ms[1] average diameter, ms[2] window search (a consumer: it runs
+// from the moment the chains are resident until the last published unit is fitted).
+int pw_resident_stage_times(pw_context* c, pw_resident* r, float* ms) {
+    if (!c || !r || !ms) return PW_E_BAD_ARG;
+    if (c->fused) { snprintf(g_err, sizeof(g_err), "PW_FUSED=1: the analysis is one launch"); return PW_E_BAD_ARG; }
+    PW_ON_DEVICE(c->device);
+    for (int k = 0; k < 3; ++k)
+        for (int e = 0; e < 2; ++e)
+            if (!c->ev_t[k][e]) HIP_TRY(hipEventCreate(&c->ev_t[k][e]));
+    int rc = pw_resident_launch(c, r, PW_STAGE_ALL);     // warm-up, sizes the workspaces
+    if (rc == PW_OK) rc = pw_resident_sync(c);
+    if (rc != PW_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    c->timing = 1;
+    rc = pw_resident_launch(c, r, PW_STAGE_ALL);
+    c->timing = 0;
+    if (rc == PW_OK) rc = pw_resident_sync(c);
+    if (rc != PW_OK) return rc;
+    for (int k = 0; k < 3; ++k) HIP_TRY(hipEventElapsedTime(&ms[k], c->ev_t[k][0], c->ev_t[k][1]));
     return PW_OK;
 }
 
@@ -816,12 +960,54 @@ int pw_analysis_batch(pw_context* c, const pw_batch_in* in, uint32_t stages, pw_
     return rc;
 }
 
+int pw_analysis_debug(pw_context* c, const pw_batch_in* in, uint32_t stages, pw_unit_out* out, pw_unit_debug* dbg) {
+    if (!c || !in || !out || !dbg) return PW_E_BAD_ARG;
+    if (in->n_units == 0) return PW_OK;
+    PW_ON_DEVICE(c->device);
+    pw_resident* r = nullptr;
+    int rc = pw_resident_upload(c, in, &r);
+    if (rc != PW_OK) return rc;
+    pw_unit_debug* d_dbg = nullptr;
+    const size_t bytes = sizeof(pw_unit_debug) * (size_t)in->n_units;
+    auto set_debug = [&](pw_unit_debug* p) -> int {
+        // (after a sync: no team is running while the pointers change)
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->ws_blocks > 0) {
+            hipLaunchKernelGGL(pw_set_debug_kernel, dim3((c->ws_blocks + 255) / 256), dim3(256), 0, c->stream, c->ws,
+                               c->ws_blocks, p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        return PW_OK;
+    };
+    hipError_t e = hipMalloc((void**)&d_dbg, bytes);
+    if (e == hipSuccess) e = hipMemset(d_dbg, 0, bytes);
+    if (e != hipSuccess) { set_err("pw_analysis_debug", e); pw_resident_free(c, r); return PW_E_HIP; }
+    // a first launch sizes the workspaces (they are re-allocated, zeroed, when they grow); the capture
+    // run follows with every workspace pointing at the buffer
+    rc = pw_resident_launch(c, r, stages);
+    if (rc == PW_OK) rc = pw_resident_sync(c);
+    if (rc == PW_OK) rc = set_debug(d_dbg);
+    if (rc == PW_OK) rc = pw_resident_launch(c, r, stages);
+    if (rc == PW_OK) rc = pw_resident_download(c, r, out);
+    int rc2 = set_debug(nullptr);
+    if (rc == PW_OK) rc = rc2;
+    if (rc == PW_OK) {
+        e = hipMemcpy(dbg, d_dbg, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_err("pw_analysis_debug download", e); rc = PW_E_HIP; }
+    }
+    (void)hipFree(d_dbg);
+    pw_resident_free(c, r);
+    return rc;
+}
+
 int pw_point_gaps(pw_context* c, const pw_batch_in* in, const int64_t* unit_of_point,
                   const double* points, int64_t n_points, double* gap, int32_t* argmin) {
     if (!c || !in || !unit_of_point || !points || !gap || !argmin || n_points < 0) return PW_E_BAD_ARG;
     if (n_points == 0) return PW_OK;
     for (int64_t q = 0; q < n_points; ++q)
         if (unit_of_point[q] < 0 || unit_of_point[q] >= in->n_units) return PW_E_BAD_ARG;
+    PW_ON_DEVICE(c->device);
     pw_resident* r = nullptr;
     int rc = pw_resident_upload(c, in, &r);
     if (rc != PW_OK) return rc;
@@ -853,7 +1039,7 @@ int pw_point_gaps(pw_context* c, const pw_batch_in* in, const int64_t* unit_of_p
     int block = 256;
     long grid = (n_points + block - 1) / block;
     hipLaunchKernelGGL(pw_point_gap_kernel, dim3((unsigned)grid), dim3(block), 0, c->stream,
-                       (long)n_points, d_u, d_p, r->d_offset, r->d_xyz, r->d_vdw, d_g, d_a);
+                       (long)n_points, d_u, d_p, r->d_offset, r->d_xyz, r->d_vdw, d_g, d_a, r->vstride);
     PG_TRY(hipGetLastError());
     PG_TRY(hipMemcpyAsync(gap, d_g, sizeof(double) * n_points, hipMemcpyDeviceToHost, c->stream));
     PG_TRY(hipMemcpyAsync(argmin, d_a, sizeof(int) * n_points, hipMemcpyDeviceToHost, c->stream));

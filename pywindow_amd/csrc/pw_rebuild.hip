@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include "../../include/pywindow_amd.h"
+#include "pw_host.hpp"
 #include "pw_rebuild.hpp"
 #include "pw_team.hpp"
 
@@ -119,7 +120,7 @@ int rebuild_on_device(pw_context* ctx, const pw_cell_in* in, int atoms_cap, int 
         return PW_E_BAD_ARG;
     }
     if (in->lattice && !in->lattice_inv) return PW_E_BAD_ARG;
-    RB_TRY(hipSetDevice(pw_context_device(ctx)));
+    // (the callers -- the two entry points below -- have made the context's device current)
     hipStream_t st = (hipStream_t)pw_context_stream(ctx);
     const long F = (long)in->n_frames;
     const int n = in->n_atoms;
@@ -239,6 +240,8 @@ extern "C" int pw_discrete_molecules(pw_context* ctx, const pw_cell_in* in, cons
         !out->src_image || !out->xyz || out->atoms_cap <= 0 || out->mols_cap <= 0)
         return PW_E_BAD_ARG;
     if (in->n_frames == 0) return PW_OK;
+    DeviceScope dev_scope_;
+    RB_TRY(dev_scope_.enter(pw_context_device(ctx)));
     Buffers buf;
     DeviceCells dev;
     int rc = rebuild_on_device(ctx, in, out->atoms_cap, out->mols_cap, buf, &dev);
@@ -260,6 +263,8 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
     if (!args_ok(ctx, in) || !vdw || !res || !n_mol || !status || atoms_cap <= 0 || mols_cap <= 0 || in->n_frames <= 0)
         return PW_E_BAD_ARG;
     *res = nullptr;
+    DeviceScope dev_scope_;
+    RB_TRY(dev_scope_.enter(pw_context_device(ctx)));
     Buffers buf;
     DeviceCells dev;
     int rc = rebuild_on_device(ctx, in, atoms_cap, mols_cap, buf, &dev);

@@ -7,6 +7,7 @@
 #include <stdio.h>
 
 #include "../../include/pywindow_amd.h"
+#include "pw_host.hpp"
 #include "pw_shape.hpp"
 #include "pw_team.hpp"
 
@@ -21,12 +22,12 @@ constexpr int SH_WAVES = 4;
 
 __global__ void __launch_bounds__(SH_WAVES * 64)
 pw_shape_kernel(long n_units, const long* __restrict__ off, const double* __restrict__ xyz,
-                const double* __restrict__ mass, pw_shape_out* __restrict__ out) {
+                const double* __restrict__ mass, pw_shape_out* __restrict__ out, int mstride) {
     using T = DeviceTeam<SH_WAVES>;
     __shared__ ShapeScratch sc;
     for (long u = blockIdx.x; u < n_units; u += gridDim.x) {
         long a0 = off[u];
-        shape_unit<T>(sc, xyz + 3 * a0, mass + a0, (int)(off[u + 1] - a0), out + u);
+        shape_unit<T>(sc, xyz + 3 * a0, mass + a0 * mstride, (int)(off[u + 1] - a0), out + u);
     }
 }
 
@@ -67,12 +68,17 @@ extern "C" int pw_shape_batch(pw_context* ctx, const pw_batch_in* in, pw_shape_o
     const long U = (long)in->n_units;
     if (U == 0) return PW_OK;
     const long A = (long)in->atom_offset[U];
-    for (long u = 0; u < U; ++u)
-        if (in->atom_offset[u + 1] <= in->atom_offset[u] || in->atom_offset[u + 1] - in->atom_offset[u] > 46340) {
-            snprintf(pw_internal_error_buffer(), 512, "pw_shape_batch: unit %ld is empty or too large", u);
+    const long TA = (long)in->template_atoms;       // > 0: one mass template for every unit
+    if (TA < 0) return PW_E_BAD_ARG;
+    for (long u = 0; u < U; ++u) {
+        long nu = (long)(in->atom_offset[u + 1] - in->atom_offset[u]);
+        if (nu <= 0 || nu > 46340 || (TA > 0 && nu != TA)) {
+            snprintf(pw_internal_error_buffer(), 512, "pw_shape_batch: unit %ld is empty, too large or not the template's size", u);
             return PW_E_BAD_ARG;
         }
-    SH_TRY(hipSetDevice(pw_context_device(ctx)));
+    }
+    DeviceScope dev_scope_;
+    SH_TRY(dev_scope_.enter(pw_context_device(ctx)));
     hipStream_t st = (hipStream_t)pw_context_stream(ctx);
     Buffers buf;
     long* d_off;
@@ -80,13 +86,14 @@ extern "C" int pw_shape_batch(pw_context* ctx, const pw_batch_in* in, pw_shape_o
     pw_shape_out* d_out;
     SH_TRY(buf.alloc(&d_off, sizeof(long) * (U + 1)));
     SH_TRY(buf.alloc(&d_xyz, sizeof(double) * 3 * A));
-    SH_TRY(buf.alloc(&d_mass, sizeof(double) * A));
+    SH_TRY(buf.alloc(&d_mass, sizeof(double) * (TA > 0 ? TA : A)));
     SH_TRY(buf.alloc(&d_out, sizeof(pw_shape_out) * U));
     SH_TRY(hipMemcpyAsync(d_off, in->atom_offset, sizeof(long) * (U + 1), hipMemcpyHostToDevice, st));
     SH_TRY(hipMemcpyAsync(d_xyz, in->xyz, sizeof(double) * 3 * A, hipMemcpyHostToDevice, st));
-    SH_TRY(hipMemcpyAsync(d_mass, in->mass, sizeof(double) * A, hipMemcpyHostToDevice, st));
+    SH_TRY(hipMemcpyAsync(d_mass, in->mass, sizeof(double) * (TA > 0 ? TA : A), hipMemcpyHostToDevice, st));
     long grid = U < 4096 ? U : 4096;
-    hipLaunchKernelGGL(pw_shape_kernel, dim3((unsigned)grid), dim3(SH_WAVES * 64), 0, st, U, d_off, d_xyz, d_mass, d_out);
+    hipLaunchKernelGGL(pw_shape_kernel, dim3((unsigned)grid), dim3(SH_WAVES * 64), 0, st, U, d_off, d_xyz, d_mass, d_out,
+                       TA > 0 ? 0 : 1);
     SH_TRY(hipGetLastError());
     SH_TRY(hipMemcpyAsync(out, d_out, sizeof(pw_shape_out) * U, hipMemcpyDeviceToHost, st));
     SH_TRY(hipStreamSynchronize(st));
@@ -103,7 +110,8 @@ extern "C" int pw_circumcircle(pw_context* ctx, const double* xyz, int64_t n_ato
             snprintf(pw_internal_error_buffer(), 512, "pw_circumcircle: atom index %d out of range", atom_sets[k]);
             return PW_E_BAD_ARG;       // the reference: IndexError
         }
-    SH_TRY(hipSetDevice(pw_context_device(ctx)));
+    DeviceScope dev_scope_;
+    SH_TRY(dev_scope_.enter(pw_context_device(ctx)));
     hipStream_t st = (hipStream_t)pw_context_stream(ctx);
     Buffers buf;
     double *d_xyz, *d_d, *d_c;

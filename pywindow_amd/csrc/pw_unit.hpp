@@ -83,6 +83,8 @@ struct TeamWorkspace {
     unsigned long long prof[32];
     unsigned long long* adj;   // PW_P_MAX x PW_P_MAX/64 words, only for launches that run DBSCAN
     const unsigned* rsq;       // VRSQRT14PD table (pw_math.hpp: rsqrt14_decode), for numpy's arccos
+    pw_unit_debug* dbg_base;   // stage capture of pw_analysis_debug (one record per unit), else null
+    long unit;                 // index of the unit this team is working on
 };
 constexpr size_t PW_ADJ_WORDS = (size_t)PW_P_MAX * (PW_P_MAX / 64);
 
@@ -1589,6 +1591,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     double c2 = pw_abs(vx * 0.0 + vy * 0.0 + vz * 1.0) /
                 (pw_sqrt(vx2 + vy2 + vz2) * pw_sqrt(0.0 + 0.0 + 1.0));
     double a1 = pw_acos_np(c1, ws->rsq), a2 = pw_acos_np(c2, ws->rsq);
+    const double a1_raw = a1, a2_raw = a2;       // what angle_between_vectors returned (stage capture)
     bool sxp = vx >= 0.0, syp = vy >= 0.0, szp = vz >= 0.0;
     if (szp) {
         if (sxp && syp) { a1 = -a1; a2 = -a2; }
@@ -1753,6 +1756,11 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     printf("DBG cluster %d vec %.17g %.17g %.17g a1 %.17g a2 %.17g new_z %.17g d0 %.17g zopt %.17g xy %.17g %.17g dfin %.17g\n", cluster, vx, vy, vz, a1, a2, new_z, d0, zopt, xo, yo, dfin);
 #endif
     if (T::lane() == 0) {
+        if (pw_unit_debug* dbg = ws->dbg_base ? ws->dbg_base + ws->unit : nullptr) {
+            double* wd = dbg->win[cluster];
+            wd[0] = vx; wd[1] = vy; wd[2] = vz; wd[3] = a1_raw; wd[4] = a2_raw; wd[5] = new_z; wd[6] = d0;
+            wd[7] = zopt; wd[8] = xo; wd[9] = yo; wd[10] = dfin; wd[11] = (double)evals;
+        }
         v.win_ok[cluster] = 1;
         v.win_d[cluster] = dfin;
         v.win_c[cluster][0] = ux + v.shift[0];
@@ -2216,6 +2224,15 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             }
         }
         T::sync();
+        // stage capture (pw_analysis_debug): survivors in pass order, their labels and path minima
+        if (pw_unit_debug* dbg = ws->dbg_base ? ws->dbg_base + ws->unit : nullptr) {
+            for (int i = T::tid(); i < ns; i += T::SIZE) {
+                dbg->pass_idx[i] = surv_k[i];
+                dbg->labels[i] = labels[i];
+                dbg->gap2[i] = vals[i];
+            }
+            if (T::tid() == 0) { dbg->n_survivors = ns; dbg->n_clusters = label; }
+        }
     }
     if (T::wave() == 0) PW_T1(ws, 10, t_db);
     PW_T0(t_w);
@@ -2316,8 +2333,10 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
         else stage_average<T>(sh, ws, n, out, prm);
         if (T::wave() == 0) PW_T1(ws, 13, t_a);
     }
-    if ((stages & PW_STAGE_WINDOWS) && !(prm.pore_opt && (sh.v->status & PW_ST_NEGATIVE_PORE)))
-        stage_windows<T>(sh, ws, n, out, prm);
+    if (stages & PW_STAGE_WINDOWS) {
+        if (!(prm.pore_opt && (sh.v->status & PW_ST_NEGATIVE_PORE))) stage_windows<T>(sh, ws, n, out, prm);
+        else if (T::tid() == 0) out->n_windows = -1;     // no window search: None, whichever launch shape
+    }
     if (T::tid() == 0) {
         if (merge) {
             record_or_status(out, sh.v->status, sh.v->n_eval);

@@ -15,17 +15,49 @@ logger = logging.getLogger("pywindow_amd")
 
 _contexts: dict[int, "_lib.Context"] = {}
 _lock = threading.Lock()
-_default_device = 0
+_default_device: int | None = None
 
 
-def set_default_device(device: int) -> None:
+def set_default_device(device: int | None) -> None:
+    """Pin the device used when none is given (``None``: back to automatic selection)."""
     global _default_device
-    _default_device = int(device)
+    _default_device = None if device is None else int(device)
+
+
+def resolve_device(device: int | None = None) -> int:
+    """The HIP ordinal an analysis runs on when the caller names none.
+
+    One process per GPU is the design point (reference: one worker per core,
+    trajectory.py:553-586), so the choice follows what the process already said about its GPU,
+    in this order: an explicit ``device`` argument; :func:`set_default_device`; the device PyTorch
+    has made current (``torch.cuda.set_device(local_rank)`` of a ``torchrun`` job -- only consulted
+    when the application has imported torch and initialised its GPU runtime); ``LOCAL_RANK`` (set by
+    ``torchrun``) modulo the number of visible devices; device 0.
+    """
+    if device is not None:
+        return int(device)
+    if _default_device is not None:
+        return _default_device
+    import os
+    import sys
+
+    torch = sys.modules.get("torch")
+    if torch is not None:
+        try:
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                return int(torch.cuda.current_device())
+        except Exception:  # pragma: no cover - a broken torch install must not break the engine
+            pass
+    lr = os.environ.get("LOCAL_RANK")
+    if lr is not None and lr.isdigit():
+        n = _lib.load().pw_device_count()
+        return int(lr) % n if n > 0 else int(lr)
+    return 0
 
 
 def context(device: int | None = None) -> "_lib.Context":
-    """Lazily created per-device context (streams + workspaces)."""
-    dev = _default_device if device is None else int(device)
+    """Lazily created per-device context (streams + workspaces); ``device=None``: :func:`resolve_device`."""
+    dev = resolve_device(device)
     with _lock:
         ctx = _contexts.get(dev)
         if ctx is None:
@@ -70,9 +102,28 @@ def windows_of(rec):
     return np.array(rec["win_d"][:n]), np.array(rec["win_c"][:n]).reshape(n, 3)
 
 
+#: what scipy.optimize.minimize raises inside the reference's opt_pore_diameter / find_windows when the
+#: pore radius at the start is negative: the box ``start -/+ r`` is inverted (utilities.py:412-424)
+NEGATIVE_PORE_MESSAGE = "An upper bound is less than the corresponding lower bound."
+
+
+def raise_like_reference(rec) -> None:
+    """Single-molecule calls fail where the reference fails: a non-porous molecule makes
+    ``opt_pore_diameter`` / ``find_windows(pore_opt=True)`` / ``full_analysis`` raise ``ValueError``
+    from inside SciPy (bounds ``com -/+ r`` with ``r < 0``)."""
+    if int(rec["status"]) & _lib.ST_NEGATIVE_PORE:
+        raise ValueError(NEGATIVE_PORE_MESSAGE)
+
+
 def warn_like_reference(rec) -> None:
-    """The reference only logs these conditions (utilities.py:1538-1551)."""
+    """The reference only logs these conditions (utilities.py:1538-1551).  Batched drivers also log
+    a non-porous unit here (the reference would have stopped the whole trajectory with a ValueError;
+    the unit carries ``PW_ST_NEGATIVE_PORE``, no optimised pore and ``None`` windows)."""
     st = int(rec["status"])
+    if st & _lib.ST_NEGATIVE_PORE:
+        logger.warning("pywindow_amd: pore radius at the centre of mass is not positive; the reference raises "
+                       "ValueError('%s') here -- pore_diameter_opt and windows of this molecule are not computed.",
+                       NEGATIVE_PORE_MESSAGE)
     if st & _lib.ST_WINDOW_DROPPED:
         logger.warning("Warning. One of the analysed windows has returned as None. See manual.")
     if st & _lib.ST_WINDOW_NEGATIVE:

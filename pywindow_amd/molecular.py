@@ -103,6 +103,15 @@ class Molecule:
     def full_analysis(self, ncpus: int = 1) -> dict:  # noqa: ARG002
         """All nine properties in ONE kernel launch (reference molecular.py:156-202)."""
         rec = self._record(_lib.STAGE_ALL)
+        if int(rec["status"]) & _lib.ST_NEGATIVE_PORE:
+            # the reference fills the dict in order and SciPy stops it at pore_diameter_opt
+            # (molecular.py:196-199 -> utilities.py:422): same entries, same exception
+            self.calculate_centre_of_mass()
+            self.calculate_maximum_diameter()
+            self.calculate_average_diameter()
+            self.calculate_pore_diameter()
+            self.calculate_pore_volume()
+            engine.raise_like_reference(rec)
         self._fill_from(rec)
         return self.properties
 
@@ -160,6 +169,7 @@ class Molecule:
 
     def calculate_pore_diameter_opt(self) -> float:
         r = self._record(_lib.STAGE_OPT)
+        engine.raise_like_reference(r)
         self.pore_diameter_opt = float(r["pore_opt_d"])
         self.pore_opt_closest_atom = int(r["pore_opt_atom"])
         self.pore_opt_COM = np.array(r["pore_opt_c"])
@@ -176,6 +186,7 @@ class Molecule:
 
     def calculate_windows(self, ncpus: int = 1):  # noqa: ARG002
         r = self._record(_lib.STAGE_WINDOWS)
+        engine.raise_like_reference(r)
         engine.warn_like_reference(r)
         win = engine.windows_of(r)
         if win is not None:

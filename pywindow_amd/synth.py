@@ -74,6 +74,32 @@ def history_text(
     return "\n".join(out) + "\n"
 
 
+def write_history(path, elements, frames, title: str = "synthetic trajectory (pywindow_amd.synth)",
+                  tstep: float = 0.0007, cell=None) -> pathlib.Path:
+    """Stream frames (an iterable of (N,3) arrays) into a keytrj=0 HISTORY file, one frame's text at a
+    time -- the same bytes as ``history_text``, without holding a long trajectory's text in memory."""
+    elements = list(elements)
+    natms = len(elements)
+    imcon = 0
+    cell_lines = ""
+    if cell is not None:
+        cell = np.asarray(cell, dtype=float)
+        cubic = np.allclose(cell, np.diag(np.diag(cell))) and np.allclose(np.diag(cell), cell[0, 0])
+        imcon = 1 if cubic else 3
+        cell_lines = "".join("%20.10f%20.10f%20.10f\n" % tuple(row) for row in cell)
+    keys = ["%-8s%10d%12.6f%12.6f\n" % (el, i + 1, 0.0, 0.0) for i, el in enumerate(elements)]
+    path = pathlib.Path(path)
+    with path.open("w") as fh:
+        fh.write(title + "\n" + "%10d%10d%10d\n" % (0, imcon, natms))
+        for k, xyz in enumerate(frames):
+            rows = np.asarray(xyz, dtype=float).tolist()
+            body = [None] * (2 * natms)
+            body[0::2] = keys
+            body[1::2] = ["%12.4E%12.4E%12.4E\n" % (r[0], r[1], r[2]) for r in rows]
+            fh.write("timestep%10d%10d%10d%10d%12.6f\n" % (k + 1, natms, 0, imcon, tstep) + cell_lines + "".join(body))
+    return path
+
+
 def write_synthetic_history(
     path,
     n_frames: int,

@@ -214,11 +214,16 @@ class DLPOLY:
         dist, rank, world = _dist_state(distributed)
         lo, hi = shard_range(len(sel), rank, world)
         mine = sel[lo:hi]
-        recs = self._run(mine, vdw, mass, device)
-        if dist is not None and world > 1:
-            recs = gather_records(recs, len(sel), rank, world, dist)
-            if rank != 0:
-                return
+        if dist is not None and world > 1 and dist.get_backend() == "nccl":
+            # one process per GPU: the records go from this rank's result buffer straight into the
+            # RCCL gather (device pointer -> tensor view, stream-ordered, no host copy on the way)
+            recs = self._run_and_gather_on_device(mine, vdw, mass, device, len(sel), rank, world, dist)
+        else:
+            recs = self._run(mine, vdw, mass, device)
+            if dist is not None and world > 1:
+                recs = gather_records(recs, len(sel), rank, world, dist)
+        if rank != 0:
+            return
         for f, props in zip(sel, engine.records_to_properties(recs)):
             self.analysis_output[f] = {"0": props}
 
@@ -228,6 +233,21 @@ class DLPOLY:
         coords, _ = self._read_selected(frames, False)
         batch = _lib.Batch.uniform(coords, vdw, mass)
         return engine.context(device).analyse(batch, _lib.STAGE_ALL)
+
+    def _run_and_gather_on_device(self, frames, vdw, mass, device, n_total, rank, world, dist):
+        import torch
+
+        dev = engine.resolve_device(device)
+        res = None
+        if frames:
+            coords, _ = self._read_selected(frames, False)
+            res = engine.context(dev).upload(_lib.Batch.uniform(coords, vdw, mass))
+            res.launch(_lib.STAGE_ALL)
+        try:
+            return gather_records_device(res, n_total, rank, world, dist, torch.device("cuda", dev))
+        finally:
+            if res is not None:
+                res.free()
 
     # ---- modular analysis: frames -> discrete molecules -> units --------------------------------
     def modular_records(self, frames="all", rebuild: bool = False, swap_atoms=None, forcefield=None, device=None):
@@ -246,7 +266,7 @@ class DLPOLY:
         ids = element_ids(el)
         topo = rb.CellTopology(el)
         vdw = VDW[ids]
-        dev = engine._default_device if device is None else int(device)
+        dev = engine.resolve_device(device)
 
         def one_chunk(ctx, chunk):
             # frames -> molecules -> units without leaving the device: every molecule of every frame of
@@ -285,8 +305,9 @@ class DLPOLY:
         recs, uframe, umol = self._run_modular(sel[lo:hi], rebuild, el, device)
         if dist is not None and world > 1:
             tags = np.stack([uframe, umol], axis=1).astype(np.int64)
-            recs = gather_ragged(recs, rank, world, dist)
-            tags = gather_ragged(tags.reshape(-1), rank, world, dist)
+            dev = engine.resolve_device(device)
+            recs = gather_ragged(recs, rank, world, dist, dev)
+            tags = gather_ragged(tags.reshape(-1), rank, world, dist, dev)
             if rank != 0:
                 return
             tags = tags.reshape(-1, 2)
@@ -309,13 +330,21 @@ def _dist_state(distributed):
     return None, 0, 1
 
 
-def gather_ragged(local: np.ndarray, rank: int, world: int, dist) -> np.ndarray:
+def _collective_device(dist, device: int | None):
+    """Where the tensors of a collective live: this rank's GPU for RCCL (``nccl``), the host for gloo."""
+    import torch
+
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", engine.resolve_device(device))
+    return torch.device("cpu")
+
+
+def gather_ragged(local: np.ndarray, rank: int, world: int, dist, device: int | None = None) -> np.ndarray:
     """Concatenate per-rank arrays of different lengths on rank 0 (rank order): one
     ``all_gather`` of the lengths, one of the padded payloads."""
     import torch
 
-    backend = dist.get_backend()
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    dev = _collective_device(dist, device)
     raw = np.ascontiguousarray(local).view(np.uint8).reshape(-1)
     size = torch.tensor([raw.size], dtype=torch.int64, device=dev)
     sizes = [torch.zeros_like(size) for _ in range(world)]
@@ -332,13 +361,13 @@ def gather_ragged(local: np.ndarray, rank: int, world: int, dist) -> np.ndarray:
     return np.concatenate(parts).view(local.dtype)
 
 
-def gather_records(local: np.ndarray, n_total: int, rank: int, world: int, dist) -> np.ndarray:
-    """The only collective on the path: every rank contributes its block of
-    fixed-size result records, rank 0 receives all of them in frame order.
+def gather_records(local: np.ndarray, n_total: int, rank: int, world: int, dist, device: int | None = None) -> np.ndarray:
+    """Host-record form of the path's only collective (used with gloo, and by callers that already
+    hold their records on the host): every rank contributes its block of fixed-size result records,
+    rank 0 receives all of them in frame order.
 
     Blocks are padded to ``ceil(n/world)`` records so a single equal-size
-    ``all_gather`` (RCCL over xGMI with the nccl backend; gloo on CPU in tests)
-    suffices: a few hundred bytes per unit, once per trajectory.
+    ``all_gather`` suffices: a few hundred bytes per unit, once per trajectory.
     """
     import torch
 
@@ -347,17 +376,68 @@ def gather_records(local: np.ndarray, n_total: int, rank: int, world: int, dist)
     buf = np.zeros(per * rec_bytes, dtype=np.uint8)
     raw = local.view(np.uint8).reshape(-1)
     buf[: raw.size] = raw
-    backend = dist.get_backend()
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    dev = _collective_device(dist, device)
     send = torch.from_numpy(buf).to(dev)
     recv = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(recv, send)
     if rank != 0:
         return np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE)
+    return _unpack_blocks([recv[r].cpu().numpy() for r in range(world)], n_total, world)
+
+
+def _unpack_blocks(blocks, n_total: int, world: int) -> np.ndarray:
+    rec_bytes = _lib.UNIT_OUT_DTYPE.itemsize
     out = np.zeros(n_total, dtype=_lib.UNIT_OUT_DTYPE)
     for r in range(world):
         lo, hi = shard_range(n_total, r, world)
         if hi > lo:
-            chunk = recv[r].cpu().numpy()[: (hi - lo) * rec_bytes]
-            out[lo:hi] = chunk.view(_lib.UNIT_OUT_DTYPE)
+            out[lo:hi] = np.ascontiguousarray(blocks[r][: (hi - lo) * rec_bytes]).view(_lib.UNIT_OUT_DTYPE)
     return out
+
+
+class _DeviceBytes:
+    """``__cuda_array_interface__`` over a raw device address: lets ``torch.as_tensor`` wrap the
+    engine's result buffer without a copy."""
+
+    def __init__(self, ptr: int, nbytes: int) -> None:
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def device_bytes_tensor(ptr: int, nbytes: int, device):
+    """uint8 torch tensor that aliases ``nbytes`` of device memory at ``ptr`` (no copy)."""
+    import torch
+
+    return torch.as_tensor(_DeviceBytes(ptr, nbytes), device=device)
+
+
+def gather_records_device(res, n_total: int, rank: int, world: int, dist, device, out=None):
+    """The path's only collective, device to device: ``res`` (a ``_lib.Resident`` with a launch in
+    flight, or ``None`` for a rank without frames) hands its record buffer to PyTorch's current stream
+    (``pw_resident_results_ready``: a stream wait, no host synchronisation), RCCL's all-gather reads
+    it in place over xGMI, and only rank 0 copies the gathered block to the host.  Returns the
+    records in frame order on rank 0, an empty array elsewhere.  ``out``: optional preallocated
+    (world * per * record) uint8 device tensor, for callers that gather every step."""
+    import torch
+
+    per = -(-n_total // world)
+    rec_bytes = _lib.UNIT_OUT_DTYPE.itemsize
+    stream = torch.cuda.current_stream(device)
+    mine = 0 if res is None else res.n_units
+    if mine == per:
+        send = device_bytes_tensor(res.results_ready(stream.cuda_stream), per * rec_bytes, device)
+    else:
+        # a short (last) or empty block: pad on the device
+        send = torch.zeros(per * rec_bytes, dtype=torch.uint8, device=device)
+        if mine:
+            send[: mine * rec_bytes].copy_(device_bytes_tensor(res.results_ready(stream.cuda_stream),
+                                                                mine * rec_bytes, device))
+    if out is None:
+        out = torch.empty(world * per * rec_bytes, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(out, send)
+    if res is not None:
+        res.results_release(stream.cuda_stream)
+    if rank != 0:
+        return np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE)
+    host = out.cpu().numpy().reshape(world, per * rec_bytes)
+    return _unpack_blocks([host[r] for r in range(world)], n_total, world)

@@ -72,6 +72,7 @@ def opt_pore_diameter(elements, coordinates, bounds=None, com=None):
                     raise ValueError("An upper bound is less than the corresponding lower bound.")
         params = _lib.Params(opt_start=com, opt_bounds=bounds)
     r = _one(elements, coordinates, _lib.STAGE_OPT, params)
+    engine.raise_like_reference(r)      # non-porous molecule: scipy's ValueError (inverted default box)
     return float(r["pore_opt_d"]), int(r["pore_opt_atom"]), np.array(r["pore_opt_c"])
 
 
@@ -104,6 +105,7 @@ def find_windows(elements, coordinates, processes=None, adjust=1, pore_opt=True,
     if int(r["status"]) & _lib.ST_Z_BOUNDS:
         # scipy.optimize.minimize raises this from inside the reference's window_analysis
         raise ValueError("An upper bound is less than the corresponding lower bound.")
+    engine.raise_like_reference(r)
     engine.warn_like_reference(r)
     return engine.windows_of(r)
 

@@ -82,6 +82,11 @@ def check_records(recs, g, *, exact_scalars=True, tol_window=TOL_WINDOW, where="
             if npass:
                 assert float(r["eps"]) == float(g["st_eps"][u]), f"{tag}: eps"
         k = int(g["n_windows"][u])
+        if k > 0 and tol_window == 0.0:
+            # the ORDER of the windows is part of the result: ascending cluster label, which is what
+            # iterating the reference's set of labels yields (utilities.py:1481-1523)
+            assert np.array_equal(np.asarray(r["win_d"][:k]), g["win_d"][u][:k]), f"{tag}: window order / diameters"
+            assert np.array_equal(np.asarray(r["win_c"][:k]).reshape(k, 3), g["win_c"][u][:k]), f"{tag}: window order / centres"
         if k > 0:
             # the reference's tests compare after sorting by diameter (tests/test_validate_cc3.py:423-439)
             p = np.argsort(np.asarray(r["win_d"][:k]))
@@ -97,3 +102,41 @@ def check_records(recs, g, *, exact_scalars=True, tol_window=TOL_WINDOW, where="
             assert ea <= (0.0 if tol_window == 0.0 else 1e-4), f"{tag}: window centres abs err {ea:.3e}"
             stats["win_c_abs"] = max(stats["win_c_abs"], ea)
     return stats
+
+
+def check_stage_capture(dbg, g, where=""):
+    """Stage-level parity: the capture of find_windows (``_lib.UNIT_DEBUG_DTYPE`` records, from the GPU
+    through ``pw_analysis_debug`` or from the host build of the kernel source) against what the
+    reference computed on the way (tests/golden/make_golden.py monkey-patches the reference's
+    vector_analysis / DBSCAN / angle_between_vectors / minimize / brute): surviving sampling vectors,
+    DBSCAN labels, and per window the chosen vector, the two rotation angles, the neck position,
+    the z optimum, the in-plane optimum and the diameter.  Everything bit for bit."""
+    n = len(g["atom_offset"]) - 1
+    assert len(dbg) == n
+    poff = g["st_pass_offset"]
+    cols = {c: i for i, c in enumerate(g["win_table_cols"])}
+    traced = {int(u) for u in g["trace_units"]} if "trace_units" in g.files else set()
+    n_win = 0
+    for u in range(n):
+        tag = f"{where} unit {u} ({g['names'][u]})"
+        d = dbg[u]
+        ns = int(poff[u + 1] - poff[u])
+        assert int(d["n_survivors"]) == ns, f"{tag}: survivors"
+        assert np.array_equal(d["pass_idx"][:ns], g["st_pass_idx"][poff[u]:poff[u + 1]]), f"{tag}: pass_idx"
+        assert np.array_equal(d["labels"][:ns], g["st_labels"][poff[u]:poff[u + 1]]), f"{tag}: DBSCAN labels"
+        if u in traced and ns:
+            res = g[f"tr{u}_pass_res"]                  # vector_analysis results [dist, 2m, p(3), v(3)]
+            assert np.array_equal(d["gap2"][:ns], res[:, 1]), f"{tag}: path minima"
+        rows = g["win_table"][g["win_unit"] == u]
+        for c, row in enumerate(rows):
+            if row[cols["ok"]] != 1.0:
+                continue
+            w = d["win"][c]
+            assert np.array_equal(w[0:3], row[[cols["vx"], cols["vy"], cols["vz"]]]), f"{tag} window {c}: vector"
+            assert w[3] == row[cols["angle_1"]] and w[4] == row[cols["angle_2"]], f"{tag} window {c}: angles"
+            assert w[5] == -row[cols["z_lb"]], f"{tag} window {c}: neck position"
+            assert w[7] == row[cols["z_x"]], f"{tag} window {c}: z optimum"
+            assert w[8] == row[cols["xy_x"]] and w[9] == row[cols["xy_y"]], f"{tag} window {c}: in-plane optimum"
+            assert w[10] == row[cols["diam"]], f"{tag} window {c}: diameter"
+            n_win += 1
+    return n_win

@@ -782,8 +782,66 @@ def run_ptraj(pool):
     print("ptraj:", res[0].shape, res[1].shape)
 
 
+def run_tables():
+    """The per-element constants of the path as the reference holds them (tables.py:22-286: mass,
+    van der Waals and covalent radius, 85 upper-case keys each) and its OPLS atom-key table
+    (tables.py:290-640), as arrays plus one checksum over a canonical text of all of them."""
+    import hashlib
+
+    load_reference()
+    from pywindow._internal import tables as Tb
+
+    keys = sorted(Tb.atomic_mass)
+    assert keys == sorted(Tb.atomic_vdw_radius) == sorted(Tb.atomic_covalent_radius)
+    mass = np.array([Tb.atomic_mass[k] for k in keys], float)
+    vdw = np.array([Tb.atomic_vdw_radius[k] for k in keys], float)
+    cov = np.array([Tb.atomic_covalent_radius[k] for k in keys], float)
+    # OPLS keys -> element with the reference's search order (decipher_atom_key, utilities.py:298-322:
+    # the first element whose list holds the key)
+    opls_k, opls_e = [], []
+    for element, klist in Tb.opls_atom_keys.items():
+        for k in klist:
+            if k not in opls_k:
+                opls_k.append(k)
+                opls_e.append(element)
+    order = np.argsort(np.array(opls_k))
+    opls_k = [opls_k[i] for i in order]
+    opls_e = [opls_e[i] for i in order]
+    text = "\n".join(f"{k} {m!r} {v!r} {c!r}" for k, m, v, c in zip(keys, mass.tolist(), vdw.tolist(), cov.tolist()))
+    text += "\n" + "\n".join(f"{k} {e}" for k, e in zip(opls_k, opls_e))
+    np.savez_compressed(HERE / "tables.npz", symbols=np.array(keys), mass=mass, vdw=vdw, covalent=cov,
+                        opls_keys=np.array(opls_k), opls_elements=np.array(opls_e),
+                        sha256=np.array(hashlib.sha256(text.encode()).hexdigest()))
+
+
+def run_history20():
+    """The reference's 20-frame DL_POLY data file (examples/data/input/HISTORY_singlemol_short: a data
+    file, 270 KB of numbers and force-field keys) byte for byte, with what the REFERENCE's reader
+    makes of it: frame count, atom keys, elements after swap_atoms / decipher_atom_keys, and the
+    coordinates of every frame (trajectory.py:217-249, 647-766; molecular.py:710-796)."""
+    pw = load_reference()
+    path = REF / "examples/data/input/HISTORY_singlemol_short"
+    traj = pw.DLPOLY(path)
+    raw_keys, els, xyz = None, None, []
+    for f in range(traj.no_of_frames):
+        plain = traj._get_frame(traj.trajectory_map[f], f)
+        ms = traj._get_frame(traj.trajectory_map[f], f, swap_atoms={"he": "H"}, forcefield="opls")
+        if f == 0:
+            raw_keys = np.array(plain.system["atom_ids"])
+            els = np.array(ms.system["elements"])
+        assert np.array_equal(np.array(ms.system["elements"]), els)
+        xyz.append(np.array(ms.system["coordinates"], float))
+    np.savez_compressed(HERE / "history20.npz", file_bytes=np.frombuffer(path.read_bytes(), dtype=np.uint8),
+                        no_of_frames=np.array(traj.no_of_frames), atom_ids=raw_keys, elements=els,
+                        coordinates=np.array(xyz))
+
+
 def main():
-    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj", "optopt", "winopt", "shape"}
+    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj", "optopt", "winopt", "shape", "tables", "history20"}
+    if "tables" in which:
+        run_tables()
+    if "history20" in which:
+        run_history20()
     if "cc3base" in which:
         load_reference()
         import tests.test_validate_cc3 as C

@@ -7,9 +7,22 @@
 #include <stdlib.h>
 #include <string.h>
 using namespace pw;
+static int run_batch(long n_units, const long* off, const double* xyz, const double* vdw, const double* mass,
+                     unsigned stages, pw_unit_out* out, const pw_params* params, pw_unit_debug* dbg);
 extern "C" int hs_analysis_batch(long n_units, const long* off, const double* xyz, const double* vdw,
                                  const double* mass, unsigned stages, pw_unit_out* out,
                                  const pw_params* params) {
+    return run_batch(n_units, off, xyz, vdw, mass, stages, out, params, nullptr);
+}
+// the same with the stage capture of find_windows (pw_unit_debug, one record per unit)
+extern "C" int hs_analysis_debug(long n_units, const long* off, const double* xyz, const double* vdw,
+                                 const double* mass, unsigned stages, pw_unit_out* out, pw_unit_debug* dbg) {
+    memset(dbg, 0, sizeof(pw_unit_debug) * (size_t)n_units);
+    return run_batch(n_units, off, xyz, vdw, mass, stages, out, nullptr, dbg);
+}
+extern "C" int hs_sizeof_unit_debug() { return (int)sizeof(pw_unit_debug); }
+static int run_batch(long n_units, const long* off, const double* xyz, const double* vdw, const double* mass,
+                     unsigned stages, pw_unit_out* out, const pw_params* params, pw_unit_debug* dbg) {
     pw_params prm = default_params();
     if (params) prm = *params;
     int nmax = 0;
@@ -23,7 +36,9 @@ extern "C" int hs_analysis_batch(long n_units, const long* off, const double* xy
     static bool rsq_ready = false;
     if (!rsq_ready) { rsqrt14_decode(rsq_tab); rsq_ready = true; }
     ws->rsq = rsq_tab;
+    ws->dbg_base = dbg;
     for (long u = 0; u < n_units; ++u) {
+        ws->unit = u;
         memset(lds, 0, bytes);
         UnitShared sh;
         sh.carve(lds, nmax, 1, 1);

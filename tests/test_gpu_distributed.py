@@ -85,3 +85,107 @@ def test_two_ranks_modular_rebuild(hip_ctx, tmp_path):
         assert sorted(both[f]) == sorted(one.analysis_output[f])
         for m, v in one.analysis_output[f].items():
             assert both[f][m] == (v["pore_diameter_opt"]["diameter"], tuple(np.sort(v["windows"]["diameters"])))
+
+
+def _nccl_worker(port, path, q):
+    """One rank, RCCL backend, on its own GPU: device binding and the device-to-device gather."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    dev = torch.cuda.device_count() - 1          # the last GPU of the box: not simply "0" when there are several
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev))
+    import pywindow_amd as pw
+    from pywindow_amd import _lib, engine, synth
+    from pywindow_amd import element_data as E
+    from pywindow_amd import trajectory as T
+
+    assert engine.resolve_device() == dev        # what torch made current, not a hard-wired 0
+    before = torch.cuda.current_device()
+    traj = pw.DLPOLY(path)
+    traj.analysis(forcefield="opls", swap_atoms={"he": "H"})     # nccl -> _run_and_gather_on_device
+    assert torch.cuda.current_device() == before                 # the library gave the device back
+    assert engine.context().device == dev
+    got = {f: v["0"]["pore_diameter_opt"]["diameter"] for f, v in traj.analysis_output.items()}
+    # the stream-ordered gather of a launch that is still in flight equals a synchronous download
+    elements, frames = synth.synthetic_units(48)
+    ids = E.element_ids(elements)
+    res = engine.context().upload(_lib.Batch.uniform(frames, E.VDW[ids], E.MASS[ids]))
+    ok = True
+    for _ in range(3):
+        res.launch()
+        recs = T.gather_records_device(res, 48, 0, 1, dist, torch.device("cuda", dev))
+        ok = ok and recs.tobytes() == res.download().tobytes()
+    res.free()
+    q.put((got, ok, dev))
+    dist.destroy_process_group()
+
+
+def test_nccl_rank_binds_its_gpu_and_gathers_on_device(hip_ctx, tmp_path):
+    import torch.multiprocessing as mp
+
+    import pywindow_amd as pw
+    from pywindow_amd import synth
+
+    path = synth.write_synthetic_history(tmp_path / "HISTORY", 9)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), str(path), q))
+    p.start()
+    got, ok, dev = q.get(timeout=900)
+    p.join(timeout=300)
+    assert p.exitcode == 0
+    one = pw.DLPOLY(path)
+    one.analysis(forcefield="opls", swap_atoms={"he": "H"}, distributed=False)
+    assert got == {f: v["0"]["pore_diameter_opt"]["diameter"] for f, v in one.analysis_output.items()}
+    assert ok
+
+
+def _two_gpu_worker(rank, world, port, path, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = str(rank)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    import pywindow_amd as pw
+    from pywindow_amd import engine
+
+    traj = pw.DLPOLY(path)
+    traj.analysis(forcefield="opls", swap_atoms={"he": "H"})
+    q.put((rank, engine.context().device,
+           {f: v["0"]["pore_diameter_opt"]["diameter"] for f, v in traj.analysis_output.items()}))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_two_gpus_over_rccl(hip_ctx, tmp_path):
+    """Two ranks on two DIFFERENT GPUs, RCCL gather over xGMI (skipped on a one-GPU box)."""
+    import torch
+    import torch.multiprocessing as mp
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import pywindow_amd as pw
+    from pywindow_amd import synth
+
+    path = synth.write_synthetic_history(tmp_path / "HISTORY", 9)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_gpu_worker, args=(r, 2, port, str(path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {g[0]: g for g in (q.get(timeout=900) for _ in procs)}
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert got[0][1] == 0 and got[1][1] == 1
+    one = pw.DLPOLY(path)
+    one.analysis(forcefield="opls", swap_atoms={"he": "H"}, distributed=False)
+    assert got[0][2] == {f: v["0"]["pore_diameter_opt"]["diameter"] for f, v in one.analysis_output.items()}
+    assert got[1][2] == {}

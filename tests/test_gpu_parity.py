@@ -228,3 +228,159 @@ def test_large_molecules_against_the_oracle(hip_ctx, copies):
     assert int(out["n_windows"]) == ref["n_windows"]
     n = max(ref["n_windows"], 0)
     assert rel(np.sort(out["win_d"][:n]), np.sort(ref["win_d"][:n])) <= LIVE_TOL_WINDOW
+
+
+@pytest.mark.parametrize("tag", GROUPS)
+def test_stage_capture_matches_reference(hip_ctx, tag):
+    """Where a mismatch would come from: the intermediate results of find_windows read back from the
+    GPU (pw_analysis_debug) against what the reference computed on the way -- surviving sampling
+    vectors, DBSCAN labels, path minima, and per window the chosen vector, both rotation angles, the
+    neck position, the z optimum, the in-plane optimum and the diameter, bit for bit."""
+    from _util import check_stage_capture
+    from pywindow_amd import _lib
+
+    g = load_group(tag)
+    off, xyz, vdw, mass = group_batch(g)
+    out, dbg = hip_ctx.analyse_debug(_lib.Batch(off, xyz, vdw, mass))
+    check_records(out, g, where=f"hip-debug/{tag}")
+    n_win = check_stage_capture(dbg, g, where=f"hip/{tag}")
+    assert n_win == int(np.maximum(g["n_windows"], 0).sum())
+    # the capture does not disturb the analysis, and a later plain analysis is not captured
+    plain = hip_ctx.analyse(_lib.Batch(off, xyz, vdw, mass))
+    assert plain.tobytes() == out.tobytes()
+
+
+def test_window_order_is_the_reference_order(hip_ctx):
+    """Windows come out in ascending cluster label -- the order in which the reference's set of labels
+    iterates (utilities.py:1481-1523) -- not merely as the same set: unsorted comparison."""
+    for tag in GROUPS:
+        g = load_group(tag)
+        out = analyse_group(hip_ctx, g)
+        for u in range(len(out)):
+            k = int(g["n_windows"][u])
+            if k > 0:
+                assert np.array_equal(out["win_d"][u][:k], g["win_d"][u][:k]), (tag, u)
+                assert np.array_equal(out["win_c"][u][:k], g["win_c"][u][:k]), (tag, u)
+
+
+def _methane():
+    el = np.array(["C", "H", "H", "H", "H"])
+    xyz = np.array([[0, 0, 0], [0.63, 0.63, 0.63], [-0.63, -0.63, 0.63], [-0.63, 0.63, -0.63], [0.63, -0.63, -0.63]], float)
+    return el, xyz
+
+
+def test_non_porous_molecule_fails_where_the_reference_fails(hip_ctx, monkeypatch):
+    """A molecule whose centre of mass lies inside an atom: pore_diameter is negative (reference:
+    (-3.4, 0)), the default box of opt_pore_diameter is inverted and SciPy raises ValueError from
+    opt_pore_diameter / find_windows / full_analysis (values from the reference run in the development
+    container).  The single-molecule API raises the same; batches flag the unit instead and go on --
+    identically in the pipelined and the one-launch shape of the analysis."""
+    import pywindow_amd as pw
+    from pywindow_amd import _lib, engine
+
+    el, xyz = _methane()
+    assert pw.pore_diameter(el, xyz) == (-3.4, 0)
+    msg = "An upper bound is less than the corresponding lower bound."
+    for call in (lambda: pw.opt_pore_diameter(el, xyz), lambda: pw.find_windows(el, xyz)):
+        with pytest.raises(ValueError, match=msg):
+            call()
+    assert pw.find_windows(el, xyz, pore_opt=False) is None       # no optimisation, no bounds: the reference returns None
+    mol = pw.MolecularSystem.load_system({"elements": el, "coordinates": xyz}).system_to_molecule()
+    with pytest.raises(ValueError, match=msg):
+        mol.full_analysis()
+    # what the reference had filled in before SciPy stopped it
+    assert list(mol.properties) == ["no_of_atoms", "centre_of_mass", "maximum_diameter", "average_diameter",
+                                    "pore_diameter", "pore_volume"]
+    assert mol.properties["maximum_diameter"] == {"diameter": 3.9619090885901, "atom_1": 1, "atom_2": 2}
+    assert mol.properties["average_diameter"] == 3.247643917158653
+    assert mol.properties["pore_diameter"] == {"diameter": -3.4, "atom": 0}
+    assert mol.properties["pore_volume"] == -20.579526276115534
+    # in a batch: flagged, None windows, neighbours unaffected
+    g = load_group("md20")
+    cage = molecules(g)[2]
+    recs = engine.analyse([cage, (el, xyz), cage])
+    assert int(recs[1]["status"]) & _lib.ST_NEGATIVE_PORE and int(recs[1]["n_windows"]) == -1
+    assert engine.windows_of(recs[1]) is None
+    assert recs[0].tobytes() == recs[2].tobytes() and float(recs[0]["pore_opt_d"]) == g["pore_opt_d"][2]
+    # one-launch shape of the same analysis (PW_FUSED=1): same record
+    monkeypatch.setenv("PW_FUSED", "1")
+    fused = _lib.Context(0)
+    try:
+        again = fused.analyse(engine.make_batch([cage, (el, xyz), cage]))
+    finally:
+        fused.close()
+    assert again.tobytes() == recs.tobytes()
+
+
+def test_interleaved_batches_of_different_shapes(hip_ctx):
+    """Launches of different plans in flight on one context (another batch size, another stage mask)
+    must not share team workspaces: interleaved asynchronous launches give the bytes of launches run
+    one at a time."""
+    from pywindow_amd import _lib, synth
+    from pywindow_amd import element_data as E
+
+    elements, frames = synth.synthetic_units(64)
+    ids = E.element_ids(elements)
+    vdw, mass = E.VDW[ids], E.MASS[ids]
+    big = hip_ctx.upload(_lib.Batch.uniform(frames[:40], vdw, mass))
+    small = hip_ctx.upload(_lib.Batch.uniform(frames[40:64], vdw, mass))
+    WIN, ALL = _lib.STAGE_WINDOWS, _lib.STAGE_ALL
+    plan = [(big, ALL), (small, WIN), (big, WIN), (small, ALL), (big, ALL), (small, ALL), (big, WIN), (small, WIN)]
+    want = []
+    for res, st in plan:                 # one at a time
+        res.launch(st)
+        want.append(res.download().tobytes())
+    for rep in range(3):                 # all in flight, download only what is still current
+        for i, (res, st) in enumerate(plan):
+            res.launch(st)
+            if i >= len(plan) - 2:
+                pass
+        got_small = small.download().tobytes()
+        got_big = big.download().tobytes()
+        assert got_small == want[7] and got_big == want[6], rep
+    # pairwise: launch A then B without waiting, check both
+    for (ra, sa), (rb_, sb) in zip(plan[:-1], plan[1:]):
+        if ra is rb_:
+            continue
+        ra.launch(sa)
+        rb_.launch(sb)
+        a = ra.download().tobytes()
+        b = rb_.download().tobytes()
+        assert a == want[plan.index((ra, sa))] and b == want[plan.index((rb_, sb))]
+    big.free()
+    small.free()
+
+
+def test_uniform_batch_constants_travel_once(hip_ctx):
+    """``pw_batch_in.template_atoms``: one vdw / mass template for a batch of one molecule type gives the
+    bytes of the per-atom form."""
+    from pywindow_amd import _lib, synth
+    from pywindow_amd import element_data as E
+
+    elements, frames = synth.synthetic_units(12)
+    ids = E.element_ids(elements)
+    vdw, mass = E.VDW[ids], E.MASS[ids]
+    tmpl = _lib.Batch.uniform(frames, vdw, mass)
+    assert tmpl.template_atoms == 168 and len(tmpl.vdw) == 168
+    off = np.arange(13, dtype=np.int64) * 168
+    per_atom = _lib.Batch(off, frames.reshape(-1, 3), np.tile(vdw, 12), np.tile(mass, 12))
+    assert hip_ctx.analyse(tmpl).tobytes() == hip_ctx.analyse(per_atom).tobytes()
+    units = np.arange(12) % 12
+    pts = frames.mean(axis=1)
+    ga, ia = hip_ctx.point_gaps(tmpl, units, pts)
+    gb, ib = hip_ctx.point_gaps(per_atom, units, pts)
+    assert np.array_equal(ga, gb) and np.array_equal(ia, ib)
+    sa, sb = hip_ctx.shape(tmpl), hip_ctx.shape(per_atom)
+    assert sa.tobytes() == sb.tobytes()
+    with pytest.raises(_lib.PwHipError):
+        bad = _lib.Batch(np.array([0, 100, 268], np.int64), frames[:2].reshape(-1, 3)[:268], vdw, mass, template_atoms=168)
+        hip_ctx.analyse(bad)
+
+
+def test_reference_platform_branch_is_reported():
+    """Which tolerance the live-oracle comparisons used on this box (0 on the reference platform:
+    glibc 2.35 + AVX-512 numpy; north_star's 1e-6 elsewhere)."""
+    import platform
+
+    print("LIVE_TOL_WINDOW =", LIVE_TOL_WINDOW, "| libc", platform.libc_ver(), "| machine", platform.machine())
+    assert LIVE_TOL_WINDOW in (0.0, 1e-6)

@@ -142,3 +142,61 @@ def test_bulk_record_conversion_equals_the_per_record_one():
         bulk = engine.records_to_properties(recs, stages)
         for rec, props in zip(recs, bulk):
             same(props, engine.record_to_properties(rec, stages))
+
+
+def test_real_md_trajectory_through_the_native_reader(tmp_path):
+    """The reference's own 20-frame DL_POLY data file (examples/data/input/HISTORY_singlemol_short, kept
+    byte for byte in tests/golden/history20.npz) through pw_history_*: frame count, the real OPLS key
+    strings, the elements after swap + decipher and every coordinate equal what the reference's
+    reader produced (trajectory.py:217-249, 647-766; generated by tests/golden/make_golden.py)."""
+    g = np.load(_util_golden() / "history20.npz")
+    path = tmp_path / "HISTORY_singlemol_short"
+    path.write_bytes(g["file_bytes"].tobytes())
+    traj = DLPOLY(path)
+    assert traj.no_of_frames == int(g["no_of_frames"]) == 20
+    assert traj.no_of_atoms == 168 and traj.periodic_boundary == "nonperiodic"
+    assert list(traj.atom_ids) == list(g["atom_ids"])
+    assert "he" in set(traj.atom_ids)                      # the conflicting OPLS key the example swaps
+    with pytest.raises(_AtomKeyConflictError):
+        traj.elements(forcefield="opls")
+    assert list(traj.elements(swap_atoms={"he": "H"}, forcefield="opls")) == list(g["elements"])
+    assert np.array_equal(traj.read_coordinates(0, 20), g["coordinates"])
+    assert np.array_equal(traj.read_coordinates(7, 3), g["coordinates"][7:10])
+    # ... and they are the inputs of the md20 golden group
+    md = load_group("md20")
+    assert np.array_equal(g["coordinates"].reshape(-1, 3), md["coordinates"])
+    assert list(np.tile(g["elements"], 20)) == list(md["elements"])
+
+
+def _util_golden():
+    from _util import GOLDEN
+
+    return GOLDEN
+
+
+def test_element_tables_equal_the_reference():
+    """tables.py:22-286 (mass, van der Waals and covalent radii, 85 keys each, 'X' included) and the
+    OPLS key table (tables.py:290-640) against the checksum fixture generated from the reference."""
+    import hashlib
+
+    from pywindow_amd import element_data as E
+
+    g = np.load(_util_golden() / "tables.npz")
+    keys = sorted(E.atomic_mass)
+    assert keys == list(g["symbols"]) and len(keys) == 85 and "X" in keys
+    assert keys == sorted(E.atomic_vdw_radius) == sorted(E.atomic_covalent_radius)
+    mass = [E.atomic_mass[k] for k in keys]
+    vdw = [E.atomic_vdw_radius[k] for k in keys]
+    cov = [E.atomic_covalent_radius[k] for k in keys]
+    assert np.array_equal(mass, g["mass"]) and np.array_equal(vdw, g["vdw"]) and np.array_equal(cov, g["covalent"])
+    ids = E.element_ids(keys)
+    assert np.array_equal(E.MASS[ids], g["mass"]) and np.array_equal(E.VDW[ids], g["vdw"])
+    assert np.array_equal(E.COVALENT[ids], g["covalent"])
+    opls = sorted(E.OPLS_KEY_TO_ELEMENT)
+    assert opls == list(g["opls_keys"])
+    assert [E.OPLS_KEY_TO_ELEMENT[k] for k in opls] == list(g["opls_elements"])
+    text = "\n".join(f"{k} {m!r} {v!r} {c!r}" for k, m, v, c in zip(keys, mass, vdw, cov))
+    text += "\n" + "\n".join(f"{k} {E.OPLS_KEY_TO_ELEMENT[k]}" for k in opls)
+    assert hashlib.sha256(text.encode()).hexdigest() == str(g["sha256"])
+    assert (E.atomic_mass["C"], E.atomic_vdw_radius["C"]) == (12.011, 1.7)
+    assert (E.atomic_mass["H"], E.atomic_vdw_radius["H"]) == (1.008, 1.09)

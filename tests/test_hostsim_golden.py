@@ -25,6 +25,34 @@ def run_hostsim(hostsim, g, stages=15):
     return out
 
 
+def run_hostsim_debug(hostsim, g, stages=15):
+    L = ctypes.CDLL(str(hostsim / "libunitprobe.so"))
+    assert L.hs_sizeof_unit_debug() == _lib.UNIT_DEBUG_DTYPE.itemsize
+    off, xyz, vdw, mass = group_batch(g)
+    vdw = np.ascontiguousarray(vdw)
+    mass = np.ascontiguousarray(mass)
+    out = np.zeros(len(off) - 1, dtype=_lib.UNIT_OUT_DTYPE)
+    dbg = np.zeros(len(off) - 1, dtype=_lib.UNIT_DEBUG_DTYPE)
+    rc = L.hs_analysis_debug(ctypes.c_long(len(off) - 1), off.ctypes.data_as(ctypes.c_void_p),
+                             xyz.ctypes.data_as(ctypes.c_void_p), vdw.ctypes.data_as(ctypes.c_void_p),
+                             mass.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint(stages),
+                             out.ctypes.data_as(ctypes.c_void_p), dbg.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    return out, dbg
+
+
+@pytest.mark.parametrize("tag", ["static", "md20", "periodic8"])
+def test_host_team_stage_capture_matches_reference(hostsim, tag):
+    """Intermediate results of find_windows (survivors, DBSCAN labels, per-window angles / neck /
+    optima) of the kernel source against the reference's, bit for bit."""
+    from _util import check_stage_capture
+
+    g = load_group(tag)
+    out, dbg = run_hostsim_debug(hostsim, g)
+    check_records(out, g, where=tag)
+    assert check_stage_capture(dbg, g, where=tag) == int(np.maximum(g["n_windows"], 0).sum())
+
+
 @pytest.mark.parametrize("tag", GROUPS)
 def test_host_team_matches_reference(hostsim, tag):
     g = load_group(tag)
