@@ -105,8 +105,11 @@ def find_windows(elements, coordinates, processes=None, adjust=1, pore_opt=True,
     if int(r["status"]) & _lib.ST_Z_BOUNDS:
         # scipy.optimize.minimize raises this from inside the reference's window_analysis
         raise ValueError("An upper bound is less than the corresponding lower bound.")
-    engine.raise_like_reference(r)
-    engine.warn_like_reference(r)
+    if pore_opt is True:
+        engine.raise_like_reference(r)      # (without the pore optimisation there are no bounds to invert)
+        engine.warn_like_reference(r)
+    else:
+        engine.warn_like_reference(np.array(int(r["status"]) & ~_lib.ST_NEGATIVE_PORE, dtype=[("status", np.int32)]))
     return engine.windows_of(r)
 
 
