@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # the pipeline keeps several kernels in flight on separate streams: ask the HIP runtime for enough
 # hardware queues BEFORE anything (torch included) initialises it
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 FRAMES = 1000
 N_ATOMS = 168
@@ -109,6 +109,9 @@ def _cpu_rate(kind, workers, budget_s):
     import multiprocessing as mp
 
     jobs = [(kind, w, workers, budget_s, 100000) for w in range(workers)]
+    # one thread per worker process: the BLAS / OpenMP pools of numpy, scipy and scikit-learn read these
+    # at import, so they are set before the workers start
+    os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = "1"
     if workers == 1:
         res = [_cpu_worker(jobs[0])]
     else:
@@ -126,7 +129,7 @@ def cpu_baseline(budget_s=8.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    workers = min(cores, 128)
+    workers = min(cores, 256)
     n1, r1 = _cpu_rate("oracle", 1, budget_s)
     out = {"value": r1, "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": f"{n1} frames of the same synthetic trajectory, oracle/pw_oracle.py, 1 process, {budget_s:.0f} s",

@@ -10,7 +10,7 @@ import os as _os
 
 # several kernels of one analysis run side by side on separate HIP streams; the runtime must be
 # told before it initialises (harmless if the host application already set it)
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 from .molecular import MolecularSystem, Molecule  # noqa: E402
 from .trajectory import DLPOLY  # noqa: E402

@@ -273,7 +273,7 @@ def load():
     # the pipeline runs several kernels side by side: give the runtime enough hardware queues
     import os
 
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
     _share_torch_hip_runtime()
     try:
         L = ctypes.CDLL(str(LIB_PATH))

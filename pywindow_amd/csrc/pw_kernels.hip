@@ -59,6 +59,10 @@ struct UnitQueue {
     int started;               // producer teams that have begun (gate for the other launches)
 };
 enum : int { PW_ROLE_PLAIN = 0, PW_ROLE_PRODUCER = 1, PW_ROLE_CONSUMER = 2 };
+// Successive analyses rotate through up to PW_SETS sets of (result buffer, queue, slots, streams,
+// events, team workspaces): that many analyses can be in flight, the optimiser chains of the later
+// ones filling the SIMDs that the long tails of the earlier ones leave idle.
+constexpr int PW_SETS = 4;      // (2 + 2 x PW_SETS streams, each needs a hardware queue of its own: GPU_MAX_HW_QUEUES = 12)
 
 constexpr unsigned MASK_ANY = 0xffffffffu;
 constexpr unsigned MASK_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE;
@@ -67,6 +71,12 @@ constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STA
 
 // MASK: the stage bits this instantiation can execute (the run-time mask is ANDed with it), so
 // the launches of the pipeline carry only the code -- and the registers -- of their own stages
+// Register budget: two waves per SIMD (three for the average-diameter launch).  A one-wave-per-SIMD
+// build (amdgpu_waves_per_eu(1, 1): 256 VGPRs + AGPRs, no VGPR spills) was tried for the optimiser
+// chains and rejected: such a wave owns more than half of its SIMD's register file, so no wave of the
+// window launch (256 VGPRs) can share the SIMD with it, and sharing SIMDs between the launches is
+// what the pipeline lives on.  The spills that remain are outside the hot loops (0.2 % of the
+// chains' instructions, profiles/r02_*).
 template <int NW, unsigned MASK>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (MASK == PW_KERNEL_AVERAGE ? 3 : 2))
 pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
@@ -230,21 +240,23 @@ struct pw_context {
     int* slots;
     long slots_cap;
     hipStream_t prod;        // optimiser launch of the overlapped pipeline (this launch's of prods[])
-    hipStream_t prods[2];
+    hipStream_t prods[PW_SETS];
     // successive pipeline launches alternate between two sets of (result buffer, queue,
     // slots, events), so the optimiser chains of launch k+1 run beside the window tail of k
-    hipEvent_t ev_reset[2], ev_prod[2], ev_gate[2], ev_join[2], ev_done[2];
-    int done_valid[2];
-    hipStream_t cons[2];     // gate + window launch of the pipeline, one stream per buffer set
-    hipEvent_t ev_head[2];   // head gate of the launch using set b has run
-    int head_valid[2];
+    hipEvent_t ev_reset[PW_SETS], ev_prod[PW_SETS], ev_gate[PW_SETS], ev_join[PW_SETS], ev_done[PW_SETS];
+    int done_valid[PW_SETS];
+    hipStream_t cons[PW_SETS];   // gate + window launch of the pipeline, one stream per buffer set
+    hipEvent_t ev_head[PW_SETS]; // head gate of the launch using set b has run
+    int head_valid[PW_SETS];
+    int nsets;               // analyses in flight at most (PW_SETS_IN_FLIGHT, 2..PW_SETS), 0: chosen per batch size
+    int cur_sets;            // ... of the current layout of the team workspaces
     int head_pct;            // PW_HEAD_GATE (default 85; 0 = window launches strictly one after another)
-    hipEvent_t ev_tail[2];   // tail gate of the launch using set b has run
-    int tail_valid[2];
-    long last_units[2];
+    hipEvent_t ev_tail[PW_SETS];   // tail gate of the launch using set b has run
+    int tail_valid[PW_SETS];
+    long last_units[PW_SETS];
     int tail_pct;            // PW_TAIL_GATE: start the next optimiser launch at this % published
                              // (default 80; 0 = strictly one optimiser launch at a time)
-    int flip;                // buffer set of the latest pipeline launch
+    int flip;                // buffer set of the latest pipeline launch (-1: none yet)
     int need_fork;           // main stream carries work the next pipeline launch must wait for
     UnitQueue* cur_queue;
     int* cur_slots;
@@ -274,10 +286,12 @@ struct pw_resident {
     double* d_vdw;
     double* d_mass;
     pw_unit_out* d_out;      // result records of the latest launch (= d_outs[cur])
-    pw_unit_out* d_outs[2];
+    pw_unit_out* d_outs[PW_SETS];
+    int nbuf;                // result buffers in rotation (= the context's sets in flight at upload)
     int cur;
-    hipEvent_t ev_read[2];   // a caller's stream has finished reading d_outs[k] (pw_resident_results_release)
-    int read_valid[2];
+    hipEvent_t ev_read[PW_SETS];   // a caller's stream has finished reading d_outs[k] (pw_resident_results_release)
+    int read_valid[PW_SETS];
+    int written_set[PW_SETS];      // pipeline set of the launch that last wrote d_outs[k], -1: none / not a pipeline launch
 };
 
 static int ensure_workspace(pw_context* c, int blocks, int adj_blocks) {
@@ -384,7 +398,7 @@ static int launch_plan(pw_context* c, pw_resident* r, unsigned stages, const Lau
 // the API stream (uploads, downloads, single-launch analyses, timing marks) follows every
 // pipeline launch issued so far
 static int join_pipeline(pw_context* c) {
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < PW_SETS; ++b)
         if (c->done_valid[b]) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done[b], 0));
     return PW_OK;
 }
@@ -428,21 +442,29 @@ int pw_context_create(int device, pw_context** out) {
     c->n_cu = prop.multiProcessorCount;
     c->lds_per_cu = 160 * 1024;
     CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CTX_TRY(hipMalloc((void**)&c->counter, 8 * sizeof(unsigned long long)));
-    CTX_TRY(hipMalloc((void**)&c->queue, 2 * sizeof(UnitQueue)));
-    CTX_TRY(hipMemset(c->queue, 0, 2 * sizeof(UnitQueue)));
+    CTX_TRY(hipMalloc((void**)&c->counter, (2 * PW_SETS + 2) * sizeof(unsigned long long)));
+    CTX_TRY(hipMalloc((void**)&c->queue, PW_SETS * sizeof(UnitQueue)));
+    CTX_TRY(hipMemset(c->queue, 0, PW_SETS * sizeof(UnitQueue)));
+    c->flip = -1;
+    {
+        const char* ns = getenv("PW_SETS_IN_FLIGHT");
+        c->nsets = ns ? atoi(ns) : 0;
+        if (c->nsets != 0 && c->nsets < 2) c->nsets = 2;
+        if (c->nsets > PW_SETS) c->nsets = PW_SETS;
+        c->cur_sets = 2;
+    }
     c->cur_queue = c->queue;
     {
         // the optimiser chains are the critical path: their launch gets the highest priority,
         // the average-diameter launch the lowest
         int lo = 0, hi = 0;
         CTX_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        CTX_TRY(hipStreamCreateWithPriority(&c->prods[0], hipStreamNonBlocking, hi));
-        CTX_TRY(hipStreamCreateWithPriority(&c->prods[1], hipStreamNonBlocking, hi));
+        for (int b = 0; b < PW_SETS; ++b)
+            CTX_TRY(hipStreamCreateWithPriority(&c->prods[b], hipStreamNonBlocking, hi));
         c->prod = c->prods[0];
         CTX_TRY(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, lo));
     }
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < PW_SETS; ++b) {
         CTX_TRY(hipEventCreateWithFlags(&c->ev_reset[b], hipEventDisableTiming));
         CTX_TRY(hipEventCreateWithFlags(&c->ev_prod[b], hipEventDisableTiming));
         CTX_TRY(hipEventCreateWithFlags(&c->ev_gate[b], hipEventDisableTiming));
@@ -454,12 +476,12 @@ int pw_context_create(int device, pw_context** out) {
     }
     {
         const char* hg = getenv("PW_HEAD_GATE");
-        c->head_pct = hg ? atoi(hg) : 85;
+        c->head_pct = hg ? atoi(hg) : 50;
         if (c->head_pct < 0 || c->head_pct > 100) c->head_pct = 0;
     }
     {
         const char* tg = getenv("PW_TAIL_GATE");
-        c->tail_pct = tg ? atoi(tg) : 80;
+        c->tail_pct = tg ? atoi(tg) : 50;
         if (c->tail_pct < 0 || c->tail_pct > 100) c->tail_pct = 0;
     }
     c->need_fork = 1;
@@ -502,7 +524,7 @@ void pw_context_destroy(pw_context* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < PW_SETS; ++b) {
         if (c->ev_reset[b]) (void)hipEventDestroy(c->ev_reset[b]);
         if (c->ev_prod[b]) (void)hipEventDestroy(c->ev_prod[b]);
         if (c->ev_gate[b]) (void)hipEventDestroy(c->ev_gate[b]);
@@ -516,8 +538,8 @@ void pw_context_destroy(pw_context* c) {
     if (c->queue) (void)hipFree(c->queue);
     if (c->rsq_tab) (void)hipFree(c->rsq_tab);
     if (c->slots) (void)hipFree(c->slots);
-    if (c->prods[0]) (void)hipStreamDestroy(c->prods[0]);
-    if (c->prods[1]) (void)hipStreamDestroy(c->prods[1]);
+    for (int b = 0; b < PW_SETS; ++b)
+        if (c->prods[b]) (void)hipStreamDestroy(c->prods[b]);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -579,7 +601,8 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
             HIP_TRY(hipStreamWaitEvent(c->stream, r->ev_read[r->cur], 0));
             r->read_valid[r->cur] = 0;
         }
-        return launch_plan(c, r, stages, p, c->stream, 0, win ? 0 : -1, 0);
+        r->written_set[r->cur] = -1;       // (the API stream joins every pipeline launch: nothing to remember)
+        return launch_plan(c, r, stages, p, c->stream, 0, win ? 0 : -1, 2 * PW_SETS + 1);
     }
     // Pipeline: the analysis is split by parallel shape and the pieces overlap.
     //   A (producer stream): stage_basic + pore-centre optimiser, ONE wave per unit -- the serial
@@ -626,75 +649,99 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         const char* bt = getenv("PW_B_TEAMS");
         if (bt && do_avg && atoi(bt) > 0 && atoi(bt) < pb.grid) pb.grid = atoi(bt);
     }
-    // teams: C0 | A0 | B | A1 | C1 (two window and two optimiser launches can be in flight), every
-    // region as large as the largest grid seen so far -- see pw_context::max_a
-    if (pa.grid > c->max_a || pb.grid > c->max_b || pc.grid > c->max_c) {
+    // teams: C[0..n) | A[0..n) | B (n = sets in flight: that many window and optimiser launches can be
+    // running at once; the average-diameter launches follow each other on one stream), every region
+    // as large as the largest grid seen so far -- see pw_context::max_a
+    // How many analyses may be in flight.  A small batch leaves most of the chip idle while its few long
+    // optimiser chains finish (the slowest of 1000 takes 3.4 ms, the mean 1 ms), so the period of
+    // back-to-back analyses is their latency divided by the number in flight until the window teams
+    // saturate: measured on MI355X, 125 frames: 2.13 ms with two sets, 1.19 with four; 1000 frames:
+    // 2.29 -> 2.22.  Large batches fill the chip on their own and only pay for the extra workspaces.
+    // (More than four would need more than 2 + 2 x 4 streams; beyond the hardware queues the runtime
+    // grants, streams share queues and a gate kernel then blocks the launch it is waiting for until its
+    // time-out -- measured: 8 sets, 2 s per step.)
+    int ns = c->nsets;
+    if (ns == 0) ns = r->n_units <= 1500 ? 4 : (r->n_units <= 6000 ? 3 : 2);
+    if (ns > r->nbuf) ns = r->nbuf;
+    if (pa.grid > c->max_a || pb.grid > c->max_b || pc.grid > c->max_c || ns != c->cur_sets) {
         HIP_TRY(hipDeviceSynchronize());         // nothing is in flight while the layout changes
         if (pa.grid > c->max_a) c->max_a = pa.grid;
         if (pb.grid > c->max_b) c->max_b = pb.grid;
         if (pc.grid > c->max_c) c->max_c = pc.grid;
+        if (ns != c->cur_sets) {
+            c->cur_sets = ns;
+            c->flip = -1;
+            for (int k = 0; k < PW_SETS; ++k) c->done_valid[k] = c->tail_valid[k] = c->head_valid[k] = 0;
+        }
     }
-    const int ws_c0 = 0, ws_a0 = c->max_c, ws_b = ws_a0 + c->max_a, ws_a1 = ws_b + c->max_b, ws_c1 = ws_a1 + c->max_a;
-    rc = ensure_workspace(c, ws_c1 + c->max_c, 2 * c->max_c);
+    const int ws_b = ns * (c->max_c + c->max_a);
+    rc = ensure_workspace(c, ws_b + c->max_b, ns * c->max_c);
     if (rc != PW_OK) return rc;
     if (c->slots_cap < r->n_units) {
         HIP_TRY(hipDeviceSynchronize());
         if (c->slots) HIP_TRY(hipFree(c->slots));
         c->slots = nullptr;
-        HIP_TRY(hipMalloc((void**)&c->slots, 2 * sizeof(int) * (size_t)r->n_units));
+        HIP_TRY(hipMalloc((void**)&c->slots, PW_SETS * sizeof(int) * (size_t)r->n_units));
         c->slots_cap = r->n_units;
-        c->done_valid[0] = c->done_valid[1] = 0;
-        c->tail_valid[0] = c->tail_valid[1] = 0;
-        c->head_valid[0] = c->head_valid[1] = 0;
+        for (int k = 0; k < PW_SETS; ++k) c->done_valid[k] = c->tail_valid[k] = c->head_valid[k] = 0;
     }
-    // this launch's buffer set; the other one may still be in use by the previous launch.
-    // (A batch's result buffer was last used two of its own launches ago, i.e. no later than
-    // the launch that used this set before, whose completion is awaited below.)
-    const int b = c->flip ^ 1;
+    // this launch's set; the others may still be in use by the launches before it.  p: the set of the
+    // launch just before this one (its queue is what this launch's gates watch); nx: the set after
+    // this one, i.e. the launch that watched the queue this launch is about to reset
+    const int p = c->flip;
+    const int b = (c->flip + 1) % ns;
+    const int nx = (b + 1) % ns;
     c->flip = b;
+    const int ws_a = ns * c->max_c + b * c->max_a, ws_c = b * c->max_c;
     {
         const char* ps = getenv("PW_PROD_STREAMS");
         c->prod = c->prods[((ps && ps[0] == '2') || c->tail_pct > 0) ? b : 0];
     }
-    r->cur ^= 1;
+    r->cur = (r->cur + 1) % r->nbuf;
     r->d_out = r->d_outs[r->cur];
     c->cur_queue = c->queue + b;
     c->cur_slots = c->slots + (size_t)b * c->slots_cap;
     if (c->need_fork) {
         // uploads, single-launch analyses and timing marks on the main stream come first
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-        HIP_TRY(hipStreamWaitEvent(c->prods[0], c->ev_fork, 0));
-        HIP_TRY(hipStreamWaitEvent(c->prods[1], c->ev_fork, 0));
-        HIP_TRY(hipStreamWaitEvent(c->cons[0], c->ev_fork, 0));
-        HIP_TRY(hipStreamWaitEvent(c->cons[1], c->ev_fork, 0));
+        for (int k = 0; k < PW_SETS; ++k) {
+            HIP_TRY(hipStreamWaitEvent(c->prods[k], c->ev_fork, 0));
+            HIP_TRY(hipStreamWaitEvent(c->cons[k], c->ev_fork, 0));
+        }
         HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
         c->need_fork = 0;
     }
+    // the launch that used this set before has finished (it is `ns` launches back) ...
     if (c->done_valid[b]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_done[b], 0));
+    // ... and so has the launch that last wrote this result buffer (the same one unless several
+    // batches alternate on the context)
+    if (r->written_set[r->cur] >= 0 && r->written_set[r->cur] != b && c->done_valid[r->written_set[r->cur]])
+        HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_done[r->written_set[r->cur]], 0));
+    r->written_set[r->cur] = b;
     if (r->read_valid[r->cur]) {     // a gather on the caller's stream may still be reading this buffer
         HIP_TRY(hipStreamWaitEvent(c->prod, r->ev_read[r->cur], 0));
         r->read_valid[r->cur] = 0;
     }
-    // the previous launch's tail gate reads the queue that is reset below
-    if (c->tail_valid[b ^ 1]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_tail[b ^ 1], 0));
-    if (c->head_valid[b ^ 1]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_head[b ^ 1], 0));
+    // the gates of the launch after this set's previous user read the queue that is reset below
+    if (c->tail_valid[nx]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_tail[nx], 0));
+    if (c->head_valid[nx]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_head[nx], 0));
     HIP_TRY(hipMemsetAsync(r->d_out, 0, sizeof(pw_unit_out) * r->n_units, c->prod));
     HIP_TRY(hipMemsetAsync(c->cur_queue, 0, sizeof(UnitQueue), c->prod));
     HIP_TRY(hipMemsetAsync(c->cur_slots, 0xff, sizeof(int) * (size_t)r->n_units, c->prod));
     HIP_TRY(hipEventRecord(c->ev_reset[b], c->prod));
     c->tail_valid[b] = 0;
-    if (c->tail_pct > 0 && c->done_valid[b ^ 1] && c->last_units[b ^ 1] > 0) {
-        unsigned long long need = (unsigned long long)((c->last_units[b ^ 1] * c->tail_pct) / 100);
-        hipLaunchKernelGGL(pw_tail_gate_kernel, dim3(1), dim3(64), 0, c->prod, c->queue + (b ^ 1), need);
+    const bool have_prev = p >= 0 && p != b && c->done_valid[p] && c->last_units[p] > 0;
+    if (c->tail_pct > 0 && have_prev) {
+        unsigned long long need = (unsigned long long)((c->last_units[p] * c->tail_pct) / 100);
+        hipLaunchKernelGGL(pw_tail_gate_kernel, dim3(1), dim3(64), 0, c->prod, c->queue + p, need);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_tail[b], c->prod));
         c->tail_valid[b] = 1;
     }
     c->last_units[b] = r->n_units;
-    // two optimiser launches can be in flight: separate work counters and workspaces
+    // several optimiser launches can be in flight: separate work counters and workspaces
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][0], c->prod));
-    rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod,
-                     b ? ws_a1 : ws_a0, -1, b ? 3 : 0, PW_ROLE_PRODUCER);
+    rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod, ws_a, -1, b, PW_ROLE_PRODUCER);
     if (rc != PW_OK) return rc;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][1], c->prod));
     HIP_TRY(hipEventRecord(c->ev_prod[b], c->prod));
@@ -704,27 +751,27 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_gate[b], cs));
     c->head_valid[b] = 0;
-    if (c->done_valid[b ^ 1] && c->last_units[b ^ 1] > 0) {
+    if (have_prev) {
         if (c->head_pct > 0) {
             // start beside the tail of the previous window launch, not behind it
-            unsigned long long need_h = (unsigned long long)((c->last_units[b ^ 1] * c->head_pct) / 100);
-            hipLaunchKernelGGL(pw_head_gate_kernel, dim3(1), dim3(64), 0, cs, c->queue + (b ^ 1), need_h);
+            unsigned long long need_h = (unsigned long long)((c->last_units[p] * c->head_pct) / 100);
+            hipLaunchKernelGGL(pw_head_gate_kernel, dim3(1), dim3(64), 0, cs, c->queue + p, need_h);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev_head[b], cs));
             c->head_valid[b] = 1;
         } else {
-            HIP_TRY(hipStreamWaitEvent(cs, c->ev_done[b ^ 1], 0));
+            HIP_TRY(hipStreamWaitEvent(cs, c->ev_done[p], 0));
         }
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][0], cs));
     rc = launch_plan(c, r, PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pc, cs,
-                     b ? ws_c1 : ws_c0, b ? c->max_c : 0, b ? 4 : 2, PW_ROLE_CONSUMER);
+                     ws_c, b * c->max_c, PW_SETS + b, PW_ROLE_CONSUMER);
     if (rc != PW_OK) return rc;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][1], cs));
     if (do_avg) {
         HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_gate[b], 0));
         if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[1][0], c->aux));
-        rc = launch_plan(c, r, PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pb, c->aux, ws_b, -1, 1);
+        rc = launch_plan(c, r, PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pb, c->aux, ws_b, -1, 2 * PW_SETS);
         if (rc != PW_OK) return rc;
         if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[1][1], c->aux));
         HIP_TRY(hipEventRecord(c->ev_join[b], c->aux));
@@ -740,9 +787,11 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
 // call that waits for results reports it (and clears it), so a timed-out analysis is never mistaken
 // for a finished one -- neither downloaded nor timed
 static int check_queue_error(pw_context* c) {
-    UnitQueue q[2];
+    UnitQueue q[PW_SETS];
     HIP_TRY(hipMemcpy(q, c->queue, sizeof(q), hipMemcpyDeviceToHost));
-    if (q[0].error || q[1].error) {
+    bool any = false;
+    for (int b = 0; b < PW_SETS; ++b) any = any || q[b].error != 0;
+    if (any) {
         (void)hipMemset(c->queue, 0, sizeof(q));
         snprintf(g_err, sizeof(g_err), "window launch timed out waiting for the optimiser launch");
         return PW_E_HIP;
@@ -798,8 +847,10 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
         UP_TRY(hipMalloc((void**)&r->d_xyz, sizeof(double) * 3 * natoms));
         UP_TRY(hipMalloc((void**)&r->d_vdw, sizeof(double) * nconst));
         UP_TRY(hipMalloc((void**)&r->d_mass, sizeof(double) * nconst));
-        UP_TRY(hipMalloc((void**)&r->d_outs[0], 2 * sizeof(pw_unit_out) * r->n_units));
-        r->d_outs[1] = r->d_outs[0] + r->n_units;
+        r->nbuf = c->nsets ? c->nsets : (r->n_units <= 1500 ? 4 : (r->n_units <= 6000 ? 3 : 2));
+        UP_TRY(hipMalloc((void**)&r->d_outs[0], r->nbuf * sizeof(pw_unit_out) * r->n_units));
+        for (int k = 1; k < r->nbuf; ++k) r->d_outs[k] = r->d_outs[0] + (size_t)k * r->n_units;
+        for (int k = 0; k < PW_SETS; ++k) r->written_set[k] = -1;
         r->d_out = r->d_outs[0];
         r->cur = 0;
         UP_TRY(hipMemcpyAsync(r->d_offset, in->atom_offset, sizeof(long) * (r->n_units + 1),
@@ -810,7 +861,7 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
                               c->stream));
         UP_TRY(hipMemcpyAsync(r->d_mass, in->mass, sizeof(double) * nconst, hipMemcpyHostToDevice,
                               c->stream));
-        UP_TRY(hipMemsetAsync(r->d_outs[0], 0, 2 * sizeof(pw_unit_out) * r->n_units, c->stream));
+        UP_TRY(hipMemsetAsync(r->d_outs[0], 0, r->nbuf * sizeof(pw_unit_out) * r->n_units, c->stream));
         UP_TRY(hipStreamSynchronize(c->stream));
     }
 #undef UP_TRY
@@ -827,8 +878,9 @@ int pw_internal_resident_adopt(pw_context* c, long n_units, long n_atoms, int nm
     pw_resident* r = new (std::nothrow) pw_resident();
     if (!r) return PW_E_NOMEM;
     memset(r, 0, sizeof(*r));
-    hipError_t e = hipMalloc((void**)&r->d_outs[0], 2 * sizeof(pw_unit_out) * n_units);
-    if (e == hipSuccess) e = hipMemsetAsync(r->d_outs[0], 0, 2 * sizeof(pw_unit_out) * n_units, c->stream);
+    r->nbuf = c->nsets ? c->nsets : (n_units <= 1500 ? 4 : (n_units <= 6000 ? 3 : 2));
+    hipError_t e = hipMalloc((void**)&r->d_outs[0], r->nbuf * sizeof(pw_unit_out) * n_units);
+    if (e == hipSuccess) e = hipMemsetAsync(r->d_outs[0], 0, r->nbuf * sizeof(pw_unit_out) * n_units, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         set_err("pw_internal_resident_adopt", e);
@@ -838,7 +890,8 @@ int pw_internal_resident_adopt(pw_context* c, long n_units, long n_atoms, int nm
     }
     r->n_units = n_units; r->n_atoms = n_atoms; r->nmax = nmax; r->vstride = 1;
     r->d_offset = d_offset; r->d_xyz = d_xyz; r->d_vdw = d_vdw; r->d_mass = d_mass;
-    r->d_outs[1] = r->d_outs[0] + n_units;
+    for (int k = 1; k < r->nbuf; ++k) r->d_outs[k] = r->d_outs[0] + (size_t)k * n_units;
+    for (int k = 0; k < PW_SETS; ++k) r->written_set[k] = -1;
     r->d_out = r->d_outs[0];
     r->cur = 0;
     c->need_fork = 1;
@@ -868,7 +921,7 @@ void pw_resident_free(pw_context* c, pw_resident* r) {
     if (r->d_mass) (void)hipFree(r->d_mass);
     if (c) (void)hipDeviceSynchronize();
     if (r->d_outs[0]) (void)hipFree(r->d_outs[0]);
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < PW_SETS; ++k)
         if (r->ev_read[k]) (void)hipEventDestroy(r->ev_read[k]);
     delete r;
 }
@@ -882,7 +935,7 @@ int pw_resident_results_ready(pw_context* c, pw_resident* r, void* stream, void*
     if (!c || !r) return PW_E_BAD_ARG;
     PW_ON_DEVICE(c->device);
     hipStream_t ext = (hipStream_t)stream;
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < PW_SETS; ++b)
         if (c->done_valid[b]) HIP_TRY(hipStreamWaitEvent(ext, c->ev_done[b], 0));
     // single-launch analyses, uploads and downloads go through the API stream
     HIP_TRY(hipEventRecord(c->ev_ext, c->stream));
