@@ -158,11 +158,62 @@ PW_HD inline double ext_to_double(Ext64 a) {
     return c.d;
 }
 
-// dnrm2 for short unit-stride vectors: one extended accumulator, sequential.
-PW_NOINLINE PW_HD inline double b_dnrm2(int n, const double* x) {
+// dnrm2 for short unit-stride vectors: one extended accumulator, sequential.  The integer emulation,
+// always right and about a thousand instructions on the GPU.
+PW_NOINLINE PW_HD inline double b_dnrm2_exact(int n, const double* x) {
     Ext64 s; s.m = 0; s.e = 0;
     for (int i = 0; i < n; ++i) s = ext_add(s, ext_square(x[i]));
     return ext_to_double(ext_sqrt(s));
+}
+
+// The same value by a short floating-point route whenever that is provably safe (it is for 99 % of
+// the arguments), the emulation otherwise.  The x87 result is RN53(RN64(sqrt(S))) with S the sum of
+// squares accumulated with a rounding to 64 bits after every operation: at most n squares, n - 1
+// additions and one square root, each off by at most 2^-64 relative, so that value lies within
+// (n + 1) * 2^-63 (relative) of y = sqrt(x_1^2 + ... + x_n^2) exactly.  y is computed here to about
+// 2^-100 in double-double arithmetic (error-free products and sums through fma); when y is farther
+// than 2^-58 * y from every midpoint between neighbouring doubles -- n <= 8 keeps (n + 1) 2^-63
+// below 2^-59 -- every number that close to y rounds to the same double, which is therefore the
+// x87 result.  Checked against the emulation on random and on adversarial (near-midpoint) arguments
+// (tests/test_blas_emulation.py); the L-BFGS-B lockstep tests run through it as well.
+PW_HD inline double b_dnrm2(int n, const double* x) {
+    if (n > 8) return b_dnrm2_exact(n, x);
+    // exact sum of the squares as hi + lo
+    double hi = 0.0, lo = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double a = x[i];
+        const double ph = a * a;
+        const double pl = pw_fma(a, a, -ph);          // a * a = ph + pl exactly
+        const double s = hi + ph;                      // two-sum of hi and ph
+        const double bb = s - hi;
+        const double err = (hi - (s - bb)) + (ph - bb);
+        lo = (lo + pl) + err;
+        hi = s;
+    }
+    if (!(hi > 0.0) || !(hi < 1e300) || hi < 1e-290) return b_dnrm2_exact(n, x);   // zeros, specials, extremes
+    {
+        const double s = hi + lo;                      // renormalise (|lo| << hi)
+        lo = lo - (s - hi);
+        hi = s;
+    }
+    // y = sqrt(hi + lo) = yh + yl: yh the rounded root of hi, yl from the exact residual
+    const double yh = pw_sqrt(hi);
+    const double qh = yh * yh;
+    const double ql = pw_fma(yh, yh, -qh);
+    const double res = ((hi - qh) - ql) + lo;          // (hi - qh is exact: both are within an ulp of each other)
+    const double yl = res / (yh + yh);
+    // r = RN53(yh + yl) and the exact rounding error e of that sum
+    const double r = yh + yl;
+    const double e = yl - (r - yh);
+    // half an ulp of r, from its exponent; powers of two (different ulps on the two sides) go the slow way
+    union { double d; uint64_t u; } c;
+    c.d = r;
+    if ((c.u & 0x000fffffffffffffull) == 0) return b_dnrm2_exact(n, x);
+    c.u = (c.u & 0x7ff0000000000000ull) - (53ull << 52);   // 2^(E - 53)
+    const double half_ulp = c.d;
+    if (half_ulp - pw_abs(e) > r * 3.469446951953614e-18)  // 2^-58
+        return r;
+    return b_dnrm2_exact(n, x);
 }
 
 }  // namespace pw

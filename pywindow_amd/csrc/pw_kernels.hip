@@ -274,6 +274,8 @@ struct pw_context {
     hipEvent_t ev_t[3][2];   // pw_resident_stage_times: start / stop of the chains, average and window launches
     int timing;              // record them during the next pipeline launch
     pw_unit_debug* dbg;      // per-unit stage capture of the current debug analysis, else null
+    void* pool;              // device scratch kept between calls (the team slabs of the periodic re-assembly)
+    size_t pool_bytes;
 };
 
 struct pw_resident {
@@ -535,6 +537,7 @@ void pw_context_destroy(pw_context* c) {
         if (c->cons[b]) (void)hipStreamDestroy(c->cons[b]);
     }
     if (c->adj) (void)hipFree(c->adj);
+    if (c->pool) (void)hipFree(c->pool);
     if (c->queue) (void)hipFree(c->queue);
     if (c->rsq_tab) (void)hipFree(c->rsq_tab);
     if (c->slots) (void)hipFree(c->slots);
@@ -573,6 +576,24 @@ int pw_context_set_params(pw_context* c, const pw_params* p) {
 }
 
 int pw_context_device(pw_context* c) { return c ? c->device : -1; }
+
+// Device scratch owned by the context and kept between calls: the periodic re-assembly needs a few
+// megabytes per team (gigabytes per launch), and allocating and freeing that around every call cost more
+// than the launch itself -- and made its time depend on the state of the allocator.  Work that uses
+// the buffer is ordered on the API stream; growing it waits for the device.
+int pw_internal_pool(pw_context* c, size_t bytes, void** out) {
+    if (!c || !out) return PW_E_BAD_ARG;
+    if (c->pool_bytes < bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->pool) HIP_TRY(hipFree(c->pool));
+        c->pool = nullptr;
+        c->pool_bytes = 0;
+        HIP_TRY(hipMalloc(&c->pool, bytes));
+        c->pool_bytes = bytes;
+    }
+    *out = c->pool;
+    return PW_OK;
+}
 char* pw_internal_error_buffer(void) { return g_err; }
 
 void* pw_context_stream(pw_context* c) { return c ? (void*)c->stream : nullptr; }

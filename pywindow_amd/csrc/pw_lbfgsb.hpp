@@ -374,6 +374,10 @@ struct Lbfgsb {
         for (int i = T::lane(); i < col; i += T::WSIZE) {
             double pi = -p[i] / pw_sqrt(SY(i, i));
             double sum = 0.0;
+            // (forming these quotients on one lane each and adding them up afterwards was measured:
+            // the optimiser launch got 25 % SLOWER -- the line search, which does not even call this,
+            // went from 190 to 460 us per unit; the register allocation of the inlined step is that
+            // fragile.  The same transformation in subsm, below, is a gain.)
             for (int k = i + 1; k < col; ++k) sum = sum + SY(k, i) * p[col + k] / SY(i, i);
             p[i] = pi + sum;
         }
@@ -863,14 +867,36 @@ struct Lbfgsb {
         T::wave_sync();
         inf = p_dtrtrs_u<T>(false, col2, 1, wn, M2, wv, col2);
         if (inf != 0) return inf;
-        int pointr = head;
-        for (int jy = 0; jy < col; ++jy) {
-            int js = col + jy;
-            for (int i = 0; i < nsub; ++i) {
-                int k = index[i];
-                dd[i] = dd[i] + WY(pointr)[k] * wv[jy] / theta + WS(pointr)[k] * wv[js];
+        if (T::WSIZE == 64 && col * nsub <= T::WSIZE) {
+            // the col x nsub terms by one lane each (a division apiece), then every lane adds them to
+            // its copy of dd in the reference's order, fetching them with v_readlane
+            const int t = T::lane();
+            const int jy_ = t / nsub, i_ = t - jy_ * nsub;
+            double t1 = 0.0, t2 = 0.0;
+            if (jy_ < col) {
+                const int pj = (head + jy_) % M, k = index[i_];
+                t1 = WY(pj)[k] * wv[jy_] / theta;
+                t2 = WS(pj)[k] * wv[col + jy_];
             }
-            pointr = (pointr + 1) % M;
+            double acc_[N];
+            for (int i = 0; i < N; ++i) acc_[i] = i < nsub ? dd[i] : 0.0;
+            for (int jy = 0; jy < col; ++jy)
+                for (int i = 0; i < N; ++i)
+                    if (i < nsub) acc_[i] = acc_[i] + T::bcast_u(t1, jy * nsub + i) + T::bcast_u(t2, jy * nsub + i);
+            T::wave_sync();
+            for (int i = 0; i < N; ++i)
+                if (i < nsub) dd[i] = acc_[i];
+            T::wave_sync();
+        } else {
+            int pointr = head;
+            for (int jy = 0; jy < col; ++jy) {
+                int js = col + jy;
+                for (int i = 0; i < nsub; ++i) {
+                    int k = index[i];
+                    dd[i] = dd[i] + WY(pointr)[k] * wv[jy] / theta + WS(pointr)[k] * wv[js];
+                }
+                pointr = (pointr + 1) % M;
+            }
         }
         b_dscal(nsub, 1.0 / theta, dd);
         // projected-search safeguard (Morales & Nocedal)

@@ -21,6 +21,7 @@ using namespace pw;
 
 extern "C" char* pw_internal_error_buffer(void);   // pw_kernels.hip (512 bytes, thread local)
 extern "C" int pw_context_device(pw_context* ctx);
+extern "C" int pw_internal_pool(pw_context* ctx, size_t bytes, void** out);   // pw_kernels.hip
 
 namespace {
 
@@ -152,7 +153,13 @@ int rebuild_on_device(pw_context* ctx, const pw_cell_in* in, int atoms_cap, int 
     RB_TRY(buf.alloc(&dev->src, sizeof(int) * F * atoms_cap));
     RB_TRY(buf.alloc(&dev->img, (size_t)F * atoms_cap));
     RB_TRY(buf.alloc(&dev->oxyz, sizeof(double) * 3 * F * atoms_cap));
-    RB_TRY(buf.alloc(&d_slabs, (size_t)grid * slab));
+    {
+        // the team slabs come from the context's pool (kept between calls)
+        void* pool = nullptr;
+        int rcp = pw_internal_pool(ctx, (size_t)grid * slab, &pool);
+        if (rcp != PW_OK) return rcp;
+        d_slabs = (unsigned char*)pool;
+    }
     RB_TRY(buf.alloc(&d_counter, sizeof(unsigned long long)));
     RB_TRY(hipMemcpyAsync(d_xyz, in->xyz, sizeof(double) * 3 * n * F, hipMemcpyHostToDevice, st));
     RB_TRY(hipMemcpyAsync(d_cov, in->cov, sizeof(double) * n, hipMemcpyHostToDevice, st));

@@ -500,6 +500,136 @@ PW_HD inline void np_descend(int len, int e, int* off_out, int* len_out) {
     *off_out = off;
     *len_out = l;
 }
+// Leaf sums of ONE 8192-element chunk (length len) for the leaves that start in [e_lo, e_hi) --
+// whole leaves by construction: both bounds are leaf starts (or the chunk's end).  `src` holds the
+// elements from e_lo on: element e of the chunk is src[e - e_lo].  leafbuf[slot of the leaf's
+// start] receives the sum.  acc8 needs 8 doubles per 64-element slot of the range, plus one slot.
+template <class T>
+PW_HD inline void np_leaf_phase(const double* src, int len, int e_lo, int e_hi, int* tab, double* acc8,
+                                double* leafbuf) {
+    const int sl_lo = e_lo >> 6;
+    const int sl_hi = (e_hi + 63) >> 6;          // exclusive
+    const int nslot = sl_hi - sl_lo;
+    int* t_off = tab;
+    int* t_len = tab + 128;
+    for (int s_ = T::tid(); s_ < nslot; s_ += T::SIZE) {
+        const int sl = sl_lo + s_;
+        int e = sl * 64, off, l, start = -1, ln = 0;
+        np_descend(len, e, &off, &l);
+        if (off == e) { start = off; ln = l; }
+        else {
+            int nxt = off + l;
+            int lim = e + 64 < len ? e + 64 : len;
+            if (nxt < lim) { np_descend(len, nxt, &off, &l); start = off; ln = l; }
+        }
+        if (start < e_lo || start >= e_hi) { start = -1; ln = 0; }     // a leaf of another tile
+        t_off[sl] = start;
+        t_len[sl] = ln;
+    }
+    T::sync();
+    for (int task = T::tid(); task < nslot * 8; task += T::SIZE) {
+        int sl = sl_lo + (task >> 3), c = task & 7;
+        int start = t_off[sl];
+        if (start < 0) continue;
+        const double* b = src + (start - e_lo);
+        int ln = t_len[sl];
+        if (ln < 8) {
+            if (c == 0) {
+                double r = 0.0;
+                for (int i = 0; i < ln; ++i) r = r + b[i];
+                acc8[task] = r;
+            }
+        } else {
+            // a leaf has at most 128 elements, i.e. at most 16 per accumulator: all loads first
+            // (they are independent), then the additions in order
+            int lim = ln - (ln % 8);
+            double vv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                int i = c + 8 * u;
+                vv[u] = b[i < lim ? i : c];
+            }
+            double r = vv[0];
+#pragma unroll
+            for (int u = 1; u < 16; ++u)
+                if (c + 8 * u < lim) r = r + vv[u];
+            acc8[task] = r;
+        }
+    }
+    T::sync();
+    for (int s_ = T::tid(); s_ < nslot; s_ += T::SIZE) {
+        const int sl = sl_lo + s_;
+        int start = t_off[sl];
+        if (start < 0) continue;
+        const double* b = src + (start - e_lo);
+        int ln = t_len[sl];
+        const double* r = acc8 + 8 * s_;
+        double res;
+        if (ln < 8) {
+            res = r[0];
+        } else {
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            for (int i = ln - (ln % 8); i < ln; ++i) res = res + b[i];
+        }
+        leafbuf[sl] = res;
+    }
+    T::sync();
+}
+// Combine the leaf sums of one chunk in recursion order (depth first; node stack (off, len, stage)
+// and value stack in team-shared memory).  For long arrays the four depth-2 subtrees are walked by
+// four waves at once (the walk is a chain of dependent LDS operations).  The result is valid on
+// thread 0.  acc8: at least 128 doubles; tab: 324 ints; leafbuf: 256 doubles.
+template <class T>
+PW_HD inline double np_walk_phase(int len, int* tab, double* acc8, double* leafbuf) {
+    auto walk = [&](int off0, int len0, int* st, double* vals) -> double {
+        int top = 0, vtop = 0;
+        st[0] = off0; st[1] = len0; st[2] = 0; top = 1;
+        while (top) {
+            int* c = st + 3 * (top - 1);
+            int coff = c[0], clen = c[1], cst = c[2];
+            if (clen <= 128) {
+                vals[vtop++] = leafbuf[coff >> 6];
+                --top;
+            } else {
+                int n2 = clen / 2;
+                n2 -= n2 % 8;
+                if (cst == 0) {
+                    c[2] = 1;
+                    int* d = st + 3 * top;
+                    d[0] = coff; d[1] = n2; d[2] = 0; ++top;
+                } else if (cst == 1) {
+                    c[2] = 2;
+                    int* d = st + 3 * top;
+                    d[0] = coff + n2; d[1] = clen - n2; d[2] = 0; ++top;
+                } else {
+                    double r = vals[--vtop];
+                    double l = vals[--vtop];
+                    vals[vtop++] = l + r;
+                    --top;
+                }
+            }
+        }
+        return vals[0];
+    };
+    double part = 0.0;
+    if (len > 512 && T::NWAVES >= 4) {
+        int h = len / 2; h -= h % 8;                    // root: [0, h) + [h, len)
+        int hl = h / 2; hl -= hl % 8;                   // left child: [0, hl) + [hl, h)
+        int hr = (len - h) / 2; hr -= hr % 8;           // right child: [h, h + hr) + [h + hr, len)
+        int w = T::wave();
+        if (w < 4 && T::lane() == 0) {
+            int so = w == 0 ? 0 : (w == 1 ? hl : (w == 2 ? h : h + hr));
+            int sl = w == 0 ? hl : (w == 1 ? h - hl : (w == 2 ? hr : len - h - hr));
+            int* st = (int*)(acc8 + 64) + 32 * w;       // acc8 is free again after the leaf folds
+            acc8[w] = walk(so, sl, st, leafbuf + 128 + 8 * w);
+        }
+        T::sync();
+        if (T::tid() == 0) part = (acc8[0] + acc8[1]) + (acc8[2] + acc8[3]);
+    } else if (T::tid() == 0) {
+        part = walk(0, len, tab + 256, leafbuf + 128);
+    }
+    return part;
+}
 template <class T>
 PW_HD inline double np_sum_team(const double* a, int n, int* tab, double* acc8, double* leafbuf,
                                 double* slot) {
@@ -507,121 +637,9 @@ PW_HD inline double np_sum_team(const double* a, int n, int* tab, double* acc8, 
     bool first = true;
     for (int s = 0; s < n; s += 8192) {
         const int len = n - s < 8192 ? n - s : 8192;
-        const int nslot = (len + 63) / 64;
-        int* t_off = tab;
-        int* t_len = tab + 128;
-        for (int sl = T::tid(); sl < nslot; sl += T::SIZE) {
-            int e = sl * 64, off, l, start = -1, ln = 0;
-            np_descend(len, e, &off, &l);
-            if (off == e) { start = off; ln = l; }
-            else {
-                int nxt = off + l;
-                int lim = e + 64 < len ? e + 64 : len;
-                if (nxt < lim) { np_descend(len, nxt, &off, &l); start = off; ln = l; }
-            }
-            t_off[sl] = start;
-            t_len[sl] = ln;
-        }
-        T::sync();
-        for (int task = T::tid(); task < nslot * 8; task += T::SIZE) {
-            int sl = task >> 3, c = task & 7;
-            int start = t_off[sl];
-            if (start < 0) continue;
-            const double* b = a + s + start;
-            int ln = t_len[sl];
-            if (ln < 8) {
-                if (c == 0) {
-                    double r = 0.0;
-                    for (int i = 0; i < ln; ++i) r = r + b[i];
-                    acc8[task] = r;
-                }
-            } else {
-                // a leaf has at most 128 elements, i.e. at most 16 per accumulator: all loads first
-                // (they are independent), then the additions in order
-                int lim = ln - (ln % 8);
-                double vv[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    int i = c + 8 * u;
-                    vv[u] = b[i < lim ? i : c];
-                }
-                double r = vv[0];
-#pragma unroll
-                for (int u = 1; u < 16; ++u)
-                    if (c + 8 * u < lim) r = r + vv[u];
-                acc8[task] = r;
-            }
-        }
-        T::sync();
-        for (int sl = T::tid(); sl < nslot; sl += T::SIZE) {
-            int start = t_off[sl];
-            if (start < 0) continue;
-            const double* b = a + s + start;
-            int ln = t_len[sl];
-            const double* r = acc8 + 8 * sl;
-            double res;
-            if (ln < 8) {
-                res = r[0];
-            } else {
-                res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-                for (int i = ln - (ln % 8); i < ln; ++i) res = res + b[i];
-            }
-            leafbuf[sl] = res;
-        }
-        T::sync();
-        // depth-first combine of the leaf sums in recursion order; node stack (off, len, stage)
-        // and value stack in team-shared memory.  For long arrays the four depth-2 subtrees are
-        // walked by four waves at once (the walk is a chain of dependent LDS operations).
-        auto walk = [&](int off0, int len0, int* st, double* vals) -> double {
-            int top = 0, vtop = 0;
-            st[0] = off0; st[1] = len0; st[2] = 0; top = 1;
-            while (top) {
-                int* c = st + 3 * (top - 1);
-                int coff = c[0], clen = c[1], cst = c[2];
-                if (clen <= 128) {
-                    vals[vtop++] = leafbuf[coff >> 6];
-                    --top;
-                } else {
-                    int n2 = clen / 2;
-                    n2 -= n2 % 8;
-                    if (cst == 0) {
-                        c[2] = 1;
-                        int* d = st + 3 * top;
-                        d[0] = coff; d[1] = n2; d[2] = 0; ++top;
-                    } else if (cst == 1) {
-                        c[2] = 2;
-                        int* d = st + 3 * top;
-                        d[0] = coff + n2; d[1] = clen - n2; d[2] = 0; ++top;
-                    } else {
-                        double r = vals[--vtop];
-                        double l = vals[--vtop];
-                        vals[vtop++] = l + r;
-                        --top;
-                    }
-                }
-            }
-            return vals[0];
-        };
-        if (len > 512 && T::NWAVES >= 4) {
-            int h = len / 2; h -= h % 8;                    // root: [0, h) + [h, len)
-            int hl = h / 2; hl -= hl % 8;                   // left child: [0, hl) + [hl, h)
-            int hr = (len - h) / 2; hr -= hr % 8;           // right child: [h, h + hr) + [h + hr, len)
-            int w = T::wave();
-            if (w < 4 && T::lane() == 0) {
-                int so = w == 0 ? 0 : (w == 1 ? hl : (w == 2 ? h : h + hr));
-                int sl = w == 0 ? hl : (w == 1 ? h - hl : (w == 2 ? hr : len - h - hr));
-                int* st = (int*)(acc8 + 64) + 32 * w;       // acc8 is free again after the leaf folds
-                acc8[w] = walk(so, sl, st, leafbuf + 128 + 8 * w);
-            }
-            T::sync();
-            if (T::tid() == 0) {
-                double part = (acc8[0] + acc8[1]) + (acc8[2] + acc8[3]);
-                total = first ? part : total + part;
-            }
-        } else if (T::tid() == 0) {
-            double part = walk(0, len, tab + 256, leafbuf + 128);
-            total = first ? part : total + part;
-        }
+        np_leaf_phase<T>(a + s, len, 0, len, tab, acc8, leafbuf);
+        double part = np_walk_phase<T>(len, tab, acc8, leafbuf);
+        if (T::tid() == 0) total = first ? part : total + part;
         first = false;
         T::sync();
     }
@@ -1822,17 +1840,9 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     double* pts = (double*)arena.take((size_t)Q4 * 12 * 8);
     if (!pts) pts = ws->pts;
     auto PT = [Q4](int k, int c) { return (c * 4 + (k & 3)) * Q4 + (k >> 2); };
-    double* vals = (double*)arena.take((size_t)P * 8);
-    if (!vals) vals = ws->vals;
-    int* surv_k = (int*)arena.take((size_t)P * 4);
-    if (!surv_k) surv_k = ws->surv_k;
-    int* labels = (int*)arena.take((size_t)P * 4);
-    if (!labels) labels = ws->labels;
-    unsigned char* flag = (unsigned char*)arena.take((size_t)P);
-    if (!flag) flag = ws->flag;
-    // everything taken below is temporary: the scratch of the k-NN mean, then the path-scan values
-    // of the sampling stage, then the adjacency rows of DBSCAN occupy the same bytes in turn
-    ScratchArena arena_mark = arena;
+    // (the per-vector arrays of the later stages are taken after the DBSCAN radius is known: until then
+    // everything behind the sampling points belongs to the k-NN mean)
+    ScratchArena arena_pts = arena;
     for (int k = T::tid(); k < P; k += T::SIZE)
         sp.point(k, &pts[PT(k, 0)], &pts[PT(k, 1)], &pts[PT(k, 2)]);
     T::sync();
@@ -1853,6 +1863,42 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         // compare-exchange chain).
         constexpr int NK = 4;
         const int ngroups = (P + NK - 1) / NK;
+        // scratch of the mean: leaf tables, accumulators, and -- when every thread has at most one
+        // group of points, i.e. its distances fit its registers -- a tile for the streamed sum, so that
+        // the P x 10 distances never leave the CU (they were 64 KB per unit written to and read back
+        // from the global workspace)
+        int* s_tab = (int*)arena.take(324 * 4);
+        double* s_leaf = (double*)arena.take(256 * 8);
+        double* s_acc = nullptr;
+        double* tile = nullptr;
+        int tile_cap = 0;
+        if (s_tab && s_leaf && T::SIZE > 1 && ngroups <= T::SIZE) {
+            // as large a tile as the arena allows (in 64-element slots, at most 4096 elements), with
+            // eight accumulators per slot beside it
+            long words = (long)(arena.left / 8) - 160;
+            int slots = (int)(words / (64 + 8)) - 2;
+            if (slots > 64) slots = 64;
+            if (slots >= 4) {
+                size_t acc_words = 8 * (size_t)(slots + 2);
+                if (acc_words < 128) acc_words = 128;
+                s_acc = (double*)arena.take(acc_words * 8);
+                tile = (double*)arena.take((size_t)slots * 64 * 8);
+                tile_cap = slots * 64 - 128;          // a tile ends at a leaf start at or before lo + tile_cap + 127
+            }
+        }
+        const bool streamed = tile != nullptr && s_acc != nullptr && tile_cap >= 128;
+        if (!streamed) {
+            arena = arena_pts;
+            s_tab = (int*)arena.take(324 * 4);
+            s_acc = (double*)arena.take(8 * 160 * 8);
+            s_leaf = (double*)arena.take(256 * 8);
+            if (!s_tab || !s_acc || !s_leaf) { s_tab = ws->leaf_tab; s_acc = ws->acc8; s_leaf = ws->leaf; }
+        }
+        double dist[NK][10];
+#pragma unroll
+        for (int p = 0; p < NK; ++p)
+#pragma unroll
+            for (int q = 0; q < 10; ++q) dist[p][q] = 0.0;
         for (int grp = T::tid(); grp < ngroups; grp += T::SIZE) {
             const int k0 = grp * NK;
             double px[NK], py[NK], pz[NK], t[NK][10];
@@ -1911,24 +1957,71 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                 if (full || proven) break;
                 lo = 0; hi = P - 1;
             }
+            if (streamed) {
+                // this thread's 40 distances stay in registers; they go to the tiles below
 #pragma unroll
-            for (int p = 0; p < NK; ++p) {
-                if (k0 + p < P) {
-                    double* row = &ws->knn[(k0 + p) * 10];
+                for (int p = 0; p < NK; ++p)
 #pragma unroll
-                    for (int q = 0; q < 10; ++q) row[q] = pw_sqrt(t[p][q]);
+                    for (int q = 0; q < 10; ++q) dist[p][q] = pw_sqrt(t[p][q]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < NK; ++p) {
+                    if (k0 + p < P) {
+                        double* row = &ws->knn[(k0 + p) * 10];
+#pragma unroll
+                        for (int q = 0; q < 10; ++q) row[q] = pw_sqrt(t[p][q]);
+                    }
                 }
             }
         }
         T::sync();
         if (T::wave() == 0) PW_T1(ws, 24, t_knn);
         PW_T0(t_sum);
-        int* s_tab = (int*)arena.take(324 * 4);
-        double* s_acc = (double*)arena.take(8 * 160 * 8);
-        double* s_leaf = (double*)arena.take(256 * 8);
-        if (!s_tab || !s_acc || !s_leaf) { s_tab = ws->leaf_tab; s_acc = ws->acc8; s_leaf = ws->leaf; }
-        double sum = np_sum_team<T>(ws->knn, P * 10, s_tab, s_acc, s_leaf, &v.red_v[15]);
-        arena = arena_mark;
+        double sum;
+        if (streamed) {
+            // numpy's pairwise sum over the flattened (P, 10) array without the array: the distances go
+            // through a tile of team-shared memory, a run of whole leaves of the recursion at a time (a
+            // leaf -- at most 128 consecutive elements -- is all a leaf sum needs); the leaf sums are
+            // kept and combined in recursion order at the end, chunk by chunk of 8192 elements.
+            const int n_el = P * 10;
+            const int e_first = T::tid() * NK * 10;         // flattened position of this thread's first distance
+            double total = 0.0;
+            bool first = true;
+            for (int s0 = 0; s0 < n_el; s0 += 8192) {
+                const int len = n_el - s0 < 8192 ? n_el - s0 : 8192;
+                int lo = 0;
+                while (lo < len) {
+                    // the tile ends at the start of the leaf that holds element lo + tile_cap (leaf starts
+                    // are at most 128 apart, so the tile makes progress), or at the end of the chunk
+                    int hi = len;
+                    if (lo + tile_cap < len) {
+                        int off, l;
+                        np_descend(len, lo + tile_cap, &off, &l);
+                        hi = off;
+                    }
+#pragma unroll
+                    for (int p = 0; p < NK; ++p)
+#pragma unroll
+                        for (int q = 0; q < 10; ++q) {
+                            const int e = e_first + p * 10 + q - s0;      // position inside this chunk
+                            if (e >= lo && e < hi && e_first + p * 10 + q < n_el) tile[e - lo] = dist[p][q];
+                        }
+                    T::sync();
+                    np_leaf_phase<T>(tile, len, lo, hi, s_tab, s_acc, s_leaf);
+                    lo = hi;
+                }
+                double part = np_walk_phase<T>(len, s_tab, s_acc, s_leaf);
+                if (T::tid() == 0) total = first ? part : total + part;
+                first = false;
+                T::sync();
+            }
+            if (T::tid() == 0) v.red_v[15] = total;
+            T::sync();
+            sum = v.red_v[15];
+            T::sync();
+        } else {
+            sum = np_sum_team<T>(ws->knn, P * 10, s_tab, s_acc, s_leaf, &v.red_v[15]);
+        }
         double m = sum / (double)(P * 10);
         if (T::tid() == 0) { v.eps = m + pw_pow_np(m, 0.5); out->eps = v.eps; }
         T::sync();
@@ -1936,7 +2029,18 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     }
     if (T::wave() == 0) PW_T1(ws, 8, t_eps);
     PW_T0(t_smp);
-    arena = arena_mark;
+    arena = arena_pts;
+    double* vals = (double*)arena.take((size_t)P * 8);
+    if (!vals) vals = ws->vals;
+    int* surv_k = (int*)arena.take((size_t)P * 4);
+    if (!surv_k) surv_k = ws->surv_k;
+    int* labels = (int*)arena.take((size_t)P * 4);
+    if (!labels) labels = ws->labels;
+    unsigned char* flag = (unsigned char*)arena.take((size_t)P);
+    if (!flag) flag = ws->flag;
+    // everything taken below is temporary: the path-scan values of the sampling stage, then the
+    // adjacency rows of DBSCAN occupy the same bytes in turn
+    ScratchArena arena_mark = arena;
     double* tmpv = (double*)arena.take((size_t)P * 8);
     if (!tmpv) tmpv = ws->knn;            // (the k-NN rows are not needed once eps is known)
     // ---- sampling vectors (utilities.py:1457-1467): ray pre-analysis for every vector,

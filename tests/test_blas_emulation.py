@@ -44,6 +44,30 @@ def test_dnrm2_x87(L):
         assert blas.dnrm2(x) == L.hs_dnrm2(n, P(x))
 
 
+def test_dnrm2_short_route_equals_the_emulation(L):
+    """b_dnrm2 takes a double-double route when its result is provably the x87 one and the integer
+    emulation otherwise: both on random vectors and on vectors whose norm sits within 1e-9 ulp of a
+    midpoint between two doubles (where the three roundings of the x87 code decide the result)."""
+    L.hs_dnrm2_exact.restype = ctypes.c_double
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 3, 5, 8):
+        m = 100000
+        x = np.ascontiguousarray(rng.normal(size=(m, n)) * 10 ** rng.uniform(-8, 3, size=(m, n)))
+        fast, exact = np.zeros(m), np.zeros(m)
+        L.hs_dnrm2_many(ctypes.c_long(m), n, P(x), P(fast), P(exact))
+        assert np.array_equal(fast, exact), n
+    m = 100000
+    y = rng.uniform(1, 2, size=m)
+    x1 = np.sqrt(y * np.spacing(y) * (1 + rng.uniform(-1e-9, 1e-9, size=m)))
+    x = np.ascontiguousarray(np.stack([y, x1, np.zeros(m)], axis=1))
+    fast, exact = np.zeros(m), np.zeros(m)
+    L.hs_dnrm2_many(ctypes.c_long(m), 3, P(x), P(fast), P(exact))
+    assert np.array_equal(fast, exact)
+    for i in range(2000):
+        assert blas.dnrm2(x[i]) == fast[i]
+    assert L.hs_dnrm2(3, P(np.zeros(3))) == 0.0
+
+
 def test_dpotrf(L):
     rng = np.random.default_rng(2)
     for n in range(1, 11):

@@ -10,6 +10,8 @@ sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 from pywindow_amd import _lib, synth  # noqa: E402
 from pywindow_amd import element_data as E  # noqa: E402
 
+if os.environ.get("PW_LIB"):          # a variant build (tests/tools/build_variant.sh)
+    _lib.LIB_PATH = pathlib.Path(os.environ["PW_LIB"])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 elements, frames = synth.synthetic_units(n)
