@@ -129,11 +129,29 @@ def cpu_baseline(budget_s=8.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    # a container may see every CPU of the host and still be allowed only a share of them (cgroup CPU
+    # quota): more worker processes than that only add overhead
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fa, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fb:
+                q, per = float(fa.read()), float(fb.read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            quota = None
     workers = min(cores, 256)
+    if quota is not None:
+        workers = max(1, min(workers, int(quota + 0.5)))
     n1, r1 = _cpu_rate("oracle", 1, budget_s)
     out = {"value": r1, "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": f"{n1} frames of the same synthetic trajectory, oracle/pw_oracle.py, 1 process, {budget_s:.0f} s",
-           "host_cpu_count": os.cpu_count(), "host_cores_usable": cores}
+           "host_cpu_count": os.cpu_count(), "host_cores_usable": cores, "cgroup_cpu_quota": quota}
     try:
         na, ra = _cpu_rate("oracle", workers, budget_s)
         out["all_core"] = {"value": ra, "unit": "frames/s", "cores": workers, "kind": "port",

@@ -195,6 +195,20 @@ class Molecule:
         self.properties["windows"] = {"diameters": None, "centre_of_mass": None}
         return None
 
+    def _align_to_principal_axes(self, align_molsys: bool = False) -> None:
+        """Reference molecular.py:204-213.  There the result -- a ``(coordinates, rotations)`` tuple -- is
+        assigned to ``self.coordinates[0]``, which numpy refuses; here the molecule takes the aligned
+        coordinates (what the method's name promises) and keeps the rotations."""
+        if align_molsys:
+            raise NotImplementedError
+        from .utilities import align_principal_ax
+
+        aligned, self.principal_axes_rotations = align_principal_ax(self.elements, self.coordinates)
+        self.coordinates = aligned
+        self.mol["coordinates"] = aligned
+        self.aligned_to_principal_axes = True
+        self._invalidate()
+
     def shift_to_origin(self) -> None:
         com = self.calculate_centre_of_mass()
         self.coordinates = np.asarray(self.coordinates, float) - np.array([com] * self.no_of_atoms)

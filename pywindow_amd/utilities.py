@@ -165,3 +165,53 @@ def circumcircle(coordinates, atom_sets):
         return [], []
     d, c = engine.context().circumcircle(coordinates, sets)
     return [float(x) for x in d], [np.array(x) for x in c]
+
+
+# ---- principal axes (reference utilities.py:532-623; only used by Molecule._align_to_principal_axes) ----
+def principal_axes(elements, coordinates) -> np.ndarray:
+    """Reference utilities.py:532-536: the eigenvectors of the inertia tensor, one per ROW.
+
+    The tensor (the O(N^2) part, with the reference's accidental N x N broadcast) comes from the GPU
+    bit for bit; the 3 x 3 eigen-decomposition is the same ``numpy.linalg.eig`` call the reference
+    makes, so order and signs are LAPACK ``dgeev``'s, as there: eigenvalues in the order the QR
+    iteration deflates them (NOT sorted), every vector of unit length with the sign ``dgeev`` leaves
+    it with.  Pinned by tests/golden/axes.npz.
+    """
+    return np.linalg.eig(get_inertia_tensor(elements, coordinates))[1].T
+
+
+def normalize_vector(vector) -> np.ndarray:
+    """Reference utilities.py:539-556: unit vector, ROUNDED to four decimals (so the rotation below is
+    about a slightly different axis than the one asked for -- reproduced)."""
+    return np.round(np.divide(vector, np.linalg.norm(vector)), decimals=4)
+
+
+def rotation_matrix_arbitrary_axis(angle, axis) -> np.ndarray:
+    """Reference utilities.py:559-591: rotation by ``angle`` about ``axis`` from the unit quaternion
+    (w, x, y, z) = (cos(angle/2), sin(angle/2) * axis / |axis|), sums taken left to right as there."""
+    w = np.cos(angle / 2)
+    x, y, z = normalize_vector(axis) * np.sin(angle / 2)
+    ww, xx, yy, zz = np.square(w), np.square(x), np.square(y), np.square(z)
+    return np.array([
+        [ww + xx - yy - zz, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), ww + yy - xx - zz, 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), ww + zz - xx - yy],
+    ])
+
+
+def align_principal_ax(elements, coordinates):
+    """Reference utilities.py:594-623: three successive rotations that turn principal axes 2, 1, 0
+    onto x, y, z.  Returns ``(coordinates, [rotation matrices])``.  As in the reference the axes are
+    those of the ORIGINAL coordinates in all three steps (it never recomputes them from the rotated
+    copy), and every atom is rotated by its own 3 x 3 by 3 x 1 product."""
+    moved = np.array(coordinates, dtype=float)
+    rotations = []
+    axes = principal_axes(elements, coordinates)        # (the reference recomputes the same thing three times)
+    for which, target in ((2, (1, 0, 0)), (1, (0, 1, 0)), (0, (0, 0, 1))):
+        target = np.array(target)
+        normal = np.cross(axes[which], target)
+        angle = np.arctan2(np.linalg.norm(normal), np.dot(axes[which], target))
+        rot = np.matrix(rotation_matrix_arbitrary_axis(angle, normal))
+        rotations.append(rot)
+        moved = np.array([np.array((rot * row.reshape(-1, 1)).reshape(1, -1))[0] for row in moved])
+    return moved, rotations

@@ -782,6 +782,47 @@ def run_ptraj(pool):
     print("ptraj:", res[0].shape, res[1].shape)
 
 
+def axes_unit(args):
+    """principal_axes / align_principal_ax of the reference (utilities.py:532-623) for one molecule."""
+    elements, coords = args
+    load_reference()
+    from pywindow._internal import utilities as U
+
+    elements = np.array(elements)
+    coords = np.array(coords, float)
+    pa = np.array(U.principal_axes(elements, coords))
+    aligned, rots = U.align_principal_ax(elements, coords)
+    return pa, np.array(aligned, float), np.array([np.asarray(r) for r in rots])
+
+
+def run_axes(pool):
+    """principal_axes, align_principal_ax (first 6 static + 3 MD units) and rotation_matrix_arbitrary_axis
+    (random angles / axes, including axes that normalize_vector rounds to 4 decimals) of the reference."""
+    load_reference()
+    from pywindow._internal import utilities as U
+
+    n, e, x = static_cases()
+    n2, e2, x2 = md20_cases()
+    pick = [0, 1, 2, 3, 4, 5]
+    names = [n[i] for i in pick] + list(n2[:3])
+    els = [list(e[i]) for i in pick] + [list(q) for q in e2[:3]]
+    xyz = [np.array(x[i], float) for i in pick] + [np.array(q, float) for q in x2[:3]]
+    res = pool.map(axes_unit, list(zip(els, xyz)))
+    off = np.concatenate([[0], np.cumsum([len(q) for q in els])])
+    rng = np.random.default_rng(8)
+    angles = rng.uniform(-2 * np.pi, 2 * np.pi, 40)
+    axes = rng.normal(size=(40, 3)) * 10 ** rng.uniform(-3, 2, size=(40, 1))
+    mats = np.array([U.rotation_matrix_arbitrary_axis(a, v) for a, v in zip(angles, axes)])
+    np.savez_compressed(
+        HERE / "axes.npz",
+        names=np.array(names), atom_offset=off, elements=np.concatenate([np.array(q) for q in els]),
+        coordinates=np.concatenate(xyz), principal_axes=np.array([r[0] for r in res]),
+        aligned=np.concatenate([r[1] for r in res]), rotations=np.array([r[2] for r in res]),
+        rot_angles=angles, rot_axes=axes, rot_matrices=mats,
+    )
+    print("axes:", np.array([r[0] for r in res])[0])
+
+
 def run_tables():
     """The per-element constants of the path as the reference holds them (tables.py:22-286: mass,
     van der Waals and covalent radius, 85 upper-case keys each) and its OPLS atom-key table
@@ -837,7 +878,7 @@ def run_history20():
 
 
 def main():
-    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj", "optopt", "winopt", "shape", "tables", "history20"}
+    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj", "optopt", "winopt", "shape", "tables", "history20", "axes"}
     if "tables" in which:
         run_tables()
     if "history20" in which:
@@ -879,6 +920,8 @@ def main():
             run_winopt(pool)
         if "shape" in which:
             run_shape(pool)
+        if "axes" in which:
+            run_axes(pool)
     meta = {
         "generator": "tests/golden/make_golden.py",
         "reference": "marcinmiklitz/pywindow @ /root/reference (imported with rdkit stub)",

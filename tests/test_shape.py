@@ -107,3 +107,39 @@ def test_hip_shape_large_unit_matches_oracle(hip_ctx):
     assert np.array_equal(out["inertia"], inertia)
     eig = S.sorted_eigenvalues(inertia)
     assert np.max(np.abs(out["eigenvalues"] - eig)) <= EIG_TOL * np.max(np.abs(eig))
+
+
+def test_rotation_matrix_matches_reference():
+    """rotation_matrix_arbitrary_axis / normalize_vector (reference utilities.py:539-591) are host
+    arithmetic: 40 reference-generated matrices, bit for bit (axis rounded to four decimals included)."""
+    from pywindow_amd import utilities as U
+
+    g = np.load(GOLDEN / "axes.npz")
+    for a, v, m in zip(g["rot_angles"], g["rot_axes"], g["rot_matrices"]):
+        assert np.array_equal(U.rotation_matrix_arbitrary_axis(a, v), m)
+    assert np.array_equal(U.normalize_vector(np.array([3.0, 4.0, 0.0])), [0.6, 0.8, 0.0])
+    assert np.array_equal(U.normalize_vector(np.array([1.0, 1.0, 1.0])), [0.5774, 0.5774, 0.5774])
+
+
+@pytest.mark.gpu
+@pytest.mark.filterwarnings("ignore:the matrix subclass")
+def test_principal_axes_and_alignment_match_reference(hip_ctx):
+    """principal_axes / align_principal_ax (reference utilities.py:532-623): inertia tensor from the GPU,
+    eigenvector order and signs as LAPACK dgeev leaves them -- equal to the reference's on every
+    fixture molecule; the aligned coordinates and the three rotation matrices likewise."""
+    import pywindow_amd as pw
+    from pywindow_amd import utilities as U
+
+    g = np.load(GOLDEN / "axes.npz")
+    off = g["atom_offset"]
+    for u in range(len(off) - 1):
+        el, xyz = g["elements"][off[u]:off[u + 1]], g["coordinates"][off[u]:off[u + 1]]
+        assert np.array_equal(U.principal_axes(el, xyz), g["principal_axes"][u]), g["names"][u]
+        moved, rots = U.align_principal_ax(el, xyz)
+        assert np.array_equal(np.array([np.asarray(r) for r in rots]), g["rotations"][u]), g["names"][u]
+        assert np.array_equal(moved, g["aligned"][off[u]:off[u + 1]]), g["names"][u]
+        assert np.array_equal(xyz, g["coordinates"][off[u]:off[u + 1]])          # the input is not touched
+    el, xyz = g["elements"][off[0]:off[1]], g["coordinates"][off[0]:off[1]]
+    mol = pw.Molecule({"elements": el, "coordinates": xyz.copy()}, "cc3", 0)
+    mol._align_to_principal_axes()
+    assert mol.aligned_to_principal_axes is True

@@ -1,0 +1,31 @@
+"""rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU counter CSV -> <tag>_instruction_counters.json
+   python tests/tools/counter_summary.py counters.csv units out.json
+Wave-level instruction counts per launch, averaged over the dispatches of each of the three launches of
+the pipeline (told apart by grid and workgroup size)."""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+path, units, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+acc = defaultdict(lambda: defaultdict(list))
+for r in csv.DictReader(open(path)):
+    if "pw_analyse_kernel" not in r["Kernel_Name"]:
+        continue
+    acc[(int(r["Grid_Size"]), int(r["Workgroup_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+big = sorted(k for k in acc if k[1] != 64)
+kernels, total = {}, defaultdict(float)
+for key, vals in sorted(acc.items()):
+    name = ("A optimiser chains (1 wave/unit)" if key[1] == 64 else
+            "C window search" if key == big[0] else "B average diameter")
+    row = {"grid": key[0], "workgroup": key[1]}
+    for c, v in vals.items():
+        row[c] = sum(v) / len(v)
+        if c != "SQ_WAVES":
+            total[c] += row[c]
+    kernels[name] = row
+json.dump({"note": "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU over tests/tools/run_stage.py 15 %d 4; "
+                   "wave-level instruction counts per launch, averaged over dispatches" % units,
+           "kernels": kernels, "per_launch": dict(total), "units_per_launch": units,
+           "valu_issue": {"simd_cycles_per_wave_instruction": 4, "simds": 1024, "clock_ghz": 2.4}}, open(out, "w"), indent=1)
+print(json.dumps(kernels, indent=1))

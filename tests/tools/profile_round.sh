@@ -1,0 +1,35 @@
+#!/bin/bash
+# All profile passes of a round on the GPU box; writes gpurun_out/<tag>/ (copy the summaries to profiles/).
+#   tests/tools/profile_round.sh <tag>
+# Passes (each its own rocprofv3 run; counters never together with tracing):
+#   1. bench.py itself (the judged line)                                  -> bench.json
+#   2. kernel trace + stats of that same bench command (overlapped mode)  -> overlapped_kernel_stats.csv
+#   3. kernel trace + stats, ONE analysis at a time (PW_TAIL_GATE=0 PW_HEAD_GATE=0, two sets): every
+#      kernel duration is inside its step                                  -> serial_kernel_stats.csv, serial_timeline.txt
+#   4. kernel trace of four overlapped analyses                           -> overlapped_timeline.txt
+#   5. --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes)               -> hbm_traffic.json
+#   6. --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU            -> instruction_counters.json
+tag=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+O=$R/gpurun_out/$tag
+mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+T=$R/tests/tools
+python3 $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/ov -o ov --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/ov.log 2>&1
+cp $(find $O/ov -name "*kernel_stats.csv" | head -1) $O/overlapped_kernel_stats.csv
+( export PW_TAIL_GATE=0 PW_HEAD_GATE=0 PW_SETS_IN_FLIGHT=2
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/se -o se --output-format csv -- python3 $T/timeline.py 1000 20 > $O/se.log 2>&1 )
+cp $(find $O/se -name "*kernel_stats.csv" | head -1) $O/serial_kernel_stats.csv
+python3 $T/timeline_report.py $(find $O/se -name "*kernel_trace.csv" | head -1) | tail -40 > $O/serial_timeline.txt
+timeout 300 rocprofv3 --kernel-trace -d $O/tl -o tl --output-format csv -- python3 $T/timeline.py 1000 6 > $O/tl.log 2>&1
+python3 $T/timeline_report.py $(find $O/tl -name "*kernel_trace.csv" | head -1) | tail -60 > $O/overlapped_timeline.txt
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/pf -o pf --output-format csv -- python3 $T/run_stage.py 15 1000 4 > $O/pf.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/pw -o pw --output-format csv -- python3 $T/run_stage.py 15 1000 4 > $O/pw.log 2>&1
+python3 $T/traffic_summary.py $(find $O/pf -name "*counter_collection.csv" | head -1) $(find $O/pw -name "*counter_collection.csv" | head -1) 1000 $O/hbm_traffic.json > /dev/null
+cp $(find $O/pf -name "*counter_collection.csv" | head -1) $O/pmc_fetch_size.csv
+cp $(find $O/pw -name "*counter_collection.csv" | head -1) $O/pmc_write_size.csv
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU -d $O/pv -o pv --output-format csv -- python3 $T/run_stage.py 15 1000 4 > $O/pv.log 2>&1
+python3 $T/counter_summary.py $(find $O/pv -name "*counter_collection.csv" | head -1) 1000 $O/instruction_counters.json > /dev/null
+rm -rf $O/ov $O/se $O/tl $O/pf $O/pw $O/pv
+ls -la $O
