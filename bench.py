@@ -299,7 +299,7 @@ def main():
     if "PW_BENCH_DEVICE" in os.environ:                        # ... with every rank on one GPU
         device_index = int(os.environ["PW_BENCH_DEVICE"])
     world = 1
-    if world_env > 1:
+    if world_env > 1 or os.environ.get("PW_BENCH_FORCE_DIST") == "1":      # (forced: one-rank rehearsal of the RCCL path)
         import torch.distributed as dist
 
         torch.cuda.set_device(device_index)
@@ -381,7 +381,7 @@ def main():
     # ---- weak scaling (headline): every rank its own `frames` frames --------------------------------
     _, frames = synth.synthetic_units(args.frames, first=rank * args.frames)
     res = ctx.upload(_lib.Batch.uniform(frames, vdw, mass))
-    gather = StepGather(res, args.frames) if world > 1 else None
+    gather = StepGather(res, args.frames) if dist is not None else None
     elapsed = timed(res, args.steps, args.warmup, gather)
     out = res.download()
     ok = bool((out["status"] == 0).all())
@@ -395,7 +395,7 @@ def main():
 
     # ---- strong scaling: ONE trajectory of `frames` frames split over the ranks -----------------------
     strong = None
-    if world > 1 and not args.no_strong:
+    if dist is not None and not args.no_strong:
         per = -(-args.frames // world)
         lo, hi = T.shard_range(args.frames, rank, world)
         if hi - lo == per:
@@ -473,8 +473,8 @@ def main():
                        "frames_per_gpu": args.frames, "stages": "all", "results_ok": ok,
                        "successive_steps_overlap": True, "single_step_latency_ms": single_ms,
                        "windows_eq_4": int((out["n_windows"] == 4).sum()),
-                       "gather_in_timed_region": world > 1, "gather_ok": gather_ok,
-                       "backend": backend if world > 1 else None},
+                       "gather_in_timed_region": dist is not None, "gather_ok": gather_ok,
+                       "backend": backend if dist is not None else None},
             "roofline": {"bound": "fp64_valu", "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS,
                          "algorithmic_flop_per_launch": ALGO_FLOP_PER_UNIT * args.frames,

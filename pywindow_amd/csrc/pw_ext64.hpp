@@ -177,6 +177,9 @@ PW_NOINLINE PW_HD inline double b_dnrm2_exact(int n, const double* x) {
 // x87 result.  Checked against the emulation on random and on adversarial (near-midpoint) arguments
 // (tests/test_blas_emulation.py); the L-BFGS-B lockstep tests run through it as well.
 PW_HD inline double b_dnrm2(int n, const double* x) {
+#ifdef PW_NO_FAST_NRM2
+    return b_dnrm2_exact(n, x);
+#endif
     if (n > 8) return b_dnrm2_exact(n, x);
     // exact sum of the squares as hi + lo
     double hi = 0.0, lo = 0.0;

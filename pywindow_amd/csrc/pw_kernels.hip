@@ -217,6 +217,22 @@ __global__ void pw_point_gap_kernel(long n_points, const long* __restrict__ unit
     arg[q] = bi;
 }
 
+// Start of a pipeline launch: the record buffer, the hand-off queue with its slots and the three work
+// counters of the launch's set, all in ONE small kernel (six hipMemsetAsync calls took 50 us of
+// stream time each -- a tenth of the step of a small batch).
+__global__ void pw_reset_kernel(unsigned long long* __restrict__ out8, long n8, UnitQueue* queue, int* __restrict__ slots,
+                                long n_units, unsigned long long* ca, unsigned long long* cb,
+                                unsigned long long* cc) {
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = i0; i < n8; i += stride) out8[i] = 0ull;
+    for (long i = i0; i < n_units; i += stride) slots[i] = -1;
+    if (i0 == 0) {
+        queue->tail = 0; queue->head = 0; queue->error = 0; queue->started = 0;
+        *ca = 0; *cb = 0; *cc = 0;
+    }
+}
+
 // pw_analysis_debug: point every team workspace at the capture buffer (or away from it)
 __global__ void pw_set_debug_kernel(TeamWorkspace* ws, int blocks, pw_unit_debug* dbg) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -356,7 +372,7 @@ static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool 
 
 template <int NW, unsigned MASK>
 static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const LaunchPlan& p, hipStream_t st,
-                     int ws_first, int adj_first, int counter_slot, int role) {
+                     int ws_first, int adj_first, int counter_slot, int role, bool reset_counter) {
     auto kern = pw_analyse_kernel<NW, MASK>;
     if (getenv("PW_PLAN_DEBUG"))
         fprintf(stderr, "launch NW=%d mask %x grid %d lds %zu nmax %d units %ld atoms %ld\n", NW, MASK, p.grid, p.lds,
@@ -372,7 +388,7 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
             done.fetch_or(bit, std::memory_order_release);
         }
     }
-    HIP_TRY(hipMemsetAsync(c->counter + counter_slot, 0, sizeof(unsigned long long), st));
+    if (reset_counter) HIP_TRY(hipMemsetAsync(c->counter + counter_slot, 0, sizeof(unsigned long long), st));
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
                        r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb, p.nframes, p.lean,
                        c->ws + ws_first,
@@ -383,18 +399,19 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
     return PW_OK;
 }
 static int launch_plan(pw_context* c, pw_resident* r, unsigned stages, const LaunchPlan& p, hipStream_t st,
-                       int ws_first, int adj_first, int counter_slot, int role = PW_ROLE_PLAIN) {
+                       int ws_first, int adj_first, int counter_slot, int role = PW_ROLE_PLAIN,
+                       bool reset_counter = true) {
     // the three launches of the pipeline have kernels of their own
     if (stages == MASK_CHAINS && p.nw == 1)
-        return launch_nw<1, MASK_CHAINS>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
+        return launch_nw<1, MASK_CHAINS>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
     if (stages == MASK_AVERAGE && p.nw == 4)
-        return launch_nw<4, MASK_AVERAGE>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
+        return launch_nw<4, MASK_AVERAGE>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
     if (stages == MASK_WINDOWS && p.nw == 4)
-        return launch_nw<4, MASK_WINDOWS>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
-    if (p.nw == 8) return launch_nw<8, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
-    if (p.nw == 4) return launch_nw<4, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
-    if (p.nw == 2) return launch_nw<2, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
-    return launch_nw<1, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role);
+        return launch_nw<4, MASK_WINDOWS>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
+    if (p.nw == 8) return launch_nw<8, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
+    if (p.nw == 4) return launch_nw<4, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
+    if (p.nw == 2) return launch_nw<2, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
+    return launch_nw<1, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
 }
 
 // the API stream (uploads, downloads, single-launch analyses, timing marks) follows every
@@ -444,7 +461,7 @@ int pw_context_create(int device, pw_context** out) {
     c->n_cu = prop.multiProcessorCount;
     c->lds_per_cu = 160 * 1024;
     CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CTX_TRY(hipMalloc((void**)&c->counter, (2 * PW_SETS + 2) * sizeof(unsigned long long)));
+    CTX_TRY(hipMalloc((void**)&c->counter, (3 * PW_SETS + 2) * sizeof(unsigned long long)));
     CTX_TRY(hipMalloc((void**)&c->queue, PW_SETS * sizeof(UnitQueue)));
     CTX_TRY(hipMemset(c->queue, 0, PW_SETS * sizeof(UnitQueue)));
     c->flip = -1;
@@ -623,7 +640,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
             r->read_valid[r->cur] = 0;
         }
         r->written_set[r->cur] = -1;       // (the API stream joins every pipeline launch: nothing to remember)
-        return launch_plan(c, r, stages, p, c->stream, 0, win ? 0 : -1, 2 * PW_SETS + 1);
+        return launch_plan(c, r, stages, p, c->stream, 0, win ? 0 : -1, 3 * PW_SETS + 1);
     }
     // Pipeline: the analysis is split by parallel shape and the pieces overlap.
     //   A (producer stream): stage_basic + pore-centre optimiser, ONE wave per unit -- the serial
@@ -748,9 +765,16 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     // the gates of the launch after this set's previous user read the queue that is reset below
     if (c->tail_valid[nx]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_tail[nx], 0));
     if (c->head_valid[nx]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_head[nx], 0));
-    HIP_TRY(hipMemsetAsync(r->d_out, 0, sizeof(pw_unit_out) * r->n_units, c->prod));
-    HIP_TRY(hipMemsetAsync(c->cur_queue, 0, sizeof(UnitQueue), c->prod));
-    HIP_TRY(hipMemsetAsync(c->cur_slots, 0xff, sizeof(int) * (size_t)r->n_units, c->prod));
+    {
+        static_assert(sizeof(pw_unit_out) % 8 == 0, "records are cleared in 8-byte words");
+        const long n8 = (long)(sizeof(pw_unit_out) / 8) * r->n_units;
+        long blocks = (n8 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(pw_reset_kernel, dim3((unsigned)blocks), dim3(256), 0, c->prod, (unsigned long long*)r->d_out, n8,
+                           c->cur_queue, c->cur_slots, r->n_units, c->counter + b, c->counter + PW_SETS + b,
+                           c->counter + 2 * PW_SETS + b);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(c->ev_reset[b], c->prod));
     c->tail_valid[b] = 0;
     const bool have_prev = p >= 0 && p != b && c->done_valid[p] && c->last_units[p] > 0;
@@ -764,7 +788,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     c->last_units[b] = r->n_units;
     // several optimiser launches can be in flight: separate work counters and workspaces
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][0], c->prod));
-    rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod, ws_a, -1, b, PW_ROLE_PRODUCER);
+    rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod, ws_a, -1, b, PW_ROLE_PRODUCER, false);
     if (rc != PW_OK) return rc;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][1], c->prod));
     HIP_TRY(hipEventRecord(c->ev_prod[b], c->prod));
@@ -788,13 +812,15 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][0], cs));
     rc = launch_plan(c, r, PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pc, cs,
-                     ws_c, b * c->max_c, PW_SETS + b, PW_ROLE_CONSUMER);
+                     ws_c, b * c->max_c, PW_SETS + b, PW_ROLE_CONSUMER, false);
     if (rc != PW_OK) return rc;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][1], cs));
     if (do_avg) {
         HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_gate[b], 0));
         if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[1][0], c->aux));
-        rc = launch_plan(c, r, PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pb, c->aux, ws_b, -1, 2 * PW_SETS);
+        // (the launch's own counter: the previous average-diameter launch may still be running)
+        rc = launch_plan(c, r, PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pb, c->aux, ws_b, -1, 2 * PW_SETS + b,
+                         PW_ROLE_PLAIN, false);
         if (rc != PW_OK) return rc;
         if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[1][1], c->aux));
         HIP_TRY(hipEventRecord(c->ev_join[b], c->aux));

@@ -185,9 +185,22 @@ struct Lbfgsb {
         z = m->z; r = m->r; d = m->d; t = m->t; xp = m->xp; wa = m->wa; acc = m->acc;
         index = m->index; iwhere = m->iwhere; indx2 = m->indx2;
     }
+    // The arrays start from ZERO, as SciPy's workspace does (_lbfgsb_py.py: wa = zeros(...), iwa =
+    // zeros(...)) -- and the algorithm does read entries it never wrote: when an iteration ends with
+    // every variable on a bound, formk is skipped and the row of WN1 that belongs to the newest
+    // correction pair is never formed; the next formk "modifies the old parts" and reads it.  Team-shared
+    // memory holds whatever the previous workgroup left, so without this the result of such a unit
+    // depended on its predecessor on the CU (found as a 1-in-8192 run-to-run difference).
+    template <class T>
     PW_HD void setup(LbMem<N>* m, const double* x0, const double* lo, const double* up, const int* nb,
                      double factr_, double pgtol_, int maxls_) {
         PW_ASSUME_LDS(m);
+        {
+            static_assert(sizeof(LbMem<N>) % 4 == 0, "LbMem is cleared in 32-bit words");
+            PW_LDS int* w = (PW_LDS int*)m;
+            for (int i = T::lane(); i < (int)(sizeof(LbMem<N>) / 4); i += T::WSIZE) w[i] = 0;
+            T::wave_sync();
+        }
         bind(m);
         for (int i = 0; i < N; ++i) {
             x[i] = x0[i];
@@ -867,7 +880,11 @@ struct Lbfgsb {
         T::wave_sync();
         inf = p_dtrtrs_u<T>(false, col2, 1, wn, M2, wv, col2);
         if (inf != 0) return inf;
+#ifdef PW_NO_SPREAD_SUBSM
+        if (false) {
+#else
         if (T::WSIZE == 64 && col * nsub <= T::WSIZE) {
+#endif
             // the col x nsub terms by one lane each (a division apiece), then every lane adds them to
             // its copy of dd in the reference's order, fetching them with v_readlane
             const int t = T::lane();

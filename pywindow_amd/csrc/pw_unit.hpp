@@ -1275,7 +1275,7 @@ PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n
         bool have_last = false;
         double lx = 0.0, ly = 0.0, lz = 0.0, lf = 0.0, lg[3] = {0.0, 0.0, 0.0};
         if (!bad) {
-            S->setup(Smem, x0, lo, up, nbd, 1e7, 1e-5, 20);
+            S->template setup<T>(Smem, x0, lo, up, nbd, 1e7, 1e-5, 20);
 #ifdef PW_PROFILE
             S->prof = ws->prof;
 #endif
@@ -1674,7 +1674,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
             double x01[1] = {zopt};
             // np.clip(x0, lb, ub)
             x01[0] = x01[0] < lo1[0] ? lo1[0] : (x01[0] > up1[0] ? up1[0] : x01[0]);
-            S->setup(Smem, x01, lo1, up1, nbd1, 1e7, 1e-5, 20);
+            S->template setup<T>(Smem, x01, lo1, up1, nbd1, 1e7, 1e-5, 20);
             int nit = 0;
             bool have_last = false;
             double lz = 0.0, lf = 0.0, lg = 0.0;

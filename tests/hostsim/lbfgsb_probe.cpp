@@ -33,8 +33,8 @@ template <int N> static void dump(Lbfgsb<N>* s, double* wa_out, int* ints, doubl
         auto* s = new Lbfgsb<N>();                                                           \
         memset((void*)s, 0, sizeof(*s));                                                     \
         auto* m = new LbMem<N>();                                                            \
-        memset((void*)m, 0, sizeof(*m));                                                     \
-        s->setup(m, x0, l, u, nbd, factr, pgtol, maxls);                                        \
+        memset((void*)m, 0xff, sizeof(*m));   /* setup() must not rely on what the block held */  \
+        s->template setup<HostTeam>(m, x0, l, u, nbd, factr, pgtol, maxls);                     \
         return s;                                                                            \
     }                                                                                        \
     extern "C" void hs_lb##N##_free(void* h) { delete ((Lbfgsb<N>*)h)->mem; delete (Lbfgsb<N>*)h; }                       \

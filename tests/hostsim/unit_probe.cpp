@@ -37,9 +37,23 @@ static int run_batch(long n_units, const long* off, const double* xyz, const dou
     if (!rsq_ready) { rsqrt14_decode(rsq_tab); rsq_ready = true; }
     ws->rsq = rsq_tab;
     ws->dbg_base = dbg;
+    // HS_LDS_FILL=<byte>: what team-shared memory holds before a unit starts (on the GPU: whatever the
+    // previous workgroup left).  Results must not depend on it.
+    const char* fill_env = getenv("HS_LDS_FILL");
+    const int fill = fill_env ? (int)strtol(fill_env, nullptr, 0) : 0xff;    // NaNs / -1 by default
+    const char* fa_ = getenv("HS_LDS_FILL_FROM");
+    const char* fb_ = getenv("HS_LDS_FILL_TO");
     for (long u = 0; u < n_units; ++u) {
         ws->unit = u;
-        memset(lds, 0, bytes);
+        memset(lds, (fa_ || fb_) ? 0 : fill, bytes);
+        {
+            // HS_LDS_FILL_FROM / HS_LDS_FILL_TO: poison only that byte range (to locate a dependence)
+            const char* fa = getenv("HS_LDS_FILL_FROM");
+            const char* fb = getenv("HS_LDS_FILL_TO");
+            size_t a = fa ? (size_t)strtol(fa, nullptr, 0) : 0, b = fb ? (size_t)strtol(fb, nullptr, 0) : bytes;
+            if (b > bytes) b = bytes;
+            if ((fa || fb) && a < b) memset(lds + a, fill, b - a);
+        }
         UnitShared sh;
         sh.carve(lds, nmax, 1, 1);
         int n = (int)(off[u + 1] - off[u]);
@@ -50,3 +64,23 @@ static int run_batch(long n_units, const long* off, const double* xyz, const dou
     return 0;
 }
 extern "C" int hs_sizeof_unit_out() { return (int)sizeof(pw_unit_out); }
+extern "C" long hs_lds_bytes(int nmax) { return (long)UnitShared::bytes(nmax, 1, 1); }
+extern "C" long hs_lds_offset(int nmax, int what) {
+    // byte offsets of the parts of the team-shared block (for the poison tests)
+    static unsigned char dummy[1];
+    UnitShared sh;
+    sh.carve(dummy, nmax, 1, 1);
+    const unsigned char* base = dummy;
+    switch (what) {
+        case 0: return (long)((const unsigned char*)sh.v - base);
+        case 1: return (long)((const unsigned char*)sh.vdw - base);
+        case 2: return (long)((const unsigned char*)sh.mass - base);
+        case 3: return (long)((const unsigned char*)sh.perm - base);
+        case 4: return (long)((const unsigned char*)sh.inv - base);
+        case 5: return (long)((const unsigned char*)sh.A.x - base);
+        case 6: return (long)((const unsigned char*)sh.S.x - base);
+        case 7: return (long)((const unsigned char*)sh.R[0].x - base);
+        case 8: return (long)((const unsigned char*)sh.lb[0] - base);
+        default: return (long)UnitShared::bytes(nmax, 1, 1);
+    }
+}
