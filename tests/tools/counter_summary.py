@@ -12,12 +12,12 @@ acc = defaultdict(lambda: defaultdict(list))
 for r in csv.DictReader(open(path)):
     if "pw_analyse_kernel" not in r["Kernel_Name"]:
         continue
-    acc[(int(r["Grid_Size"]), int(r["Workgroup_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
-big = sorted(k for k in acc if k[1] != 64)
+    m = __import__("re").search(r"pw_analyse_kernel<(\d+), (\d+)u?>", r["Kernel_Name"])
+    acc[(int(r["Grid_Size"]), int(r["Workgroup_Size"]), int(m.group(2)) if m else -1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 kernels, total = {}, defaultdict(float)
 for key, vals in sorted(acc.items()):
     name = ("A optimiser chains (1 wave/unit)" if key[1] == 64 else
-            "C window search" if key == big[0] else "B average diameter")
+            "C window search" if key[2] == 120 else "B average diameter" if key[2] == 98 else f"<{key[1] // 64}, {key[2]}>")
     row = {"grid": key[0], "workgroup": key[1]}
     for c, v in vals.items():
         row[c] = sum(v) / len(v)

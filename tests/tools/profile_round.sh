@@ -30,6 +30,7 @@ python3 $T/traffic_summary.py $(find $O/pf -name "*counter_collection.csv" | hea
 cp $(find $O/pf -name "*counter_collection.csv" | head -1) $O/pmc_fetch_size.csv
 cp $(find $O/pw -name "*counter_collection.csv" | head -1) $O/pmc_write_size.csv
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU -d $O/pv -o pv --output-format csv -- python3 $T/run_stage.py 15 1000 4 > $O/pv.log 2>&1
-python3 $T/counter_summary.py $(find $O/pv -name "*counter_collection.csv" | head -1) 1000 $O/instruction_counters.json > /dev/null
+cp $(find $O/pv -name "*counter_collection.csv" | head -1) $O/pmc_instruction_counters.csv
+python3 $T/counter_summary.py $O/pmc_instruction_counters.csv 1000 $O/instruction_counters.json > /dev/null
 rm -rf $O/ov $O/se $O/tl $O/pf $O/pw $O/pv
 ls -la $O

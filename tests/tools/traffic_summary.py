@@ -14,18 +14,21 @@ for path in (fetch, write):
     for r in csv.DictReader(open(path)):
         if "pw_analyse_kernel" not in r["Kernel_Name"]:
             continue
-        key = (int(r["Grid_Size"]), int(r["Workgroup_Size"]))
+        # the launches are told apart by the template arguments in the kernel name (<waves, stage mask>)
+        m = __import__("re").search(r"pw_analyse_kernel<(\d+), (\d+)u?>", r["Kernel_Name"])
+        key = (int(r["Grid_Size"]), int(r["Workgroup_Size"]), int(m.group(2)) if m else -1)
         acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 kernels = {}
 total = 0.0
-big = sorted(k for k in acc if k[1] != 64)
 for key, vals in sorted(acc.items()):
     if key[1] == 64:
         name = roles[64]
-    elif key == big[0]:
+    elif key[2] == 120:
         name = "C window search (4 waves/unit, persistent consumer)"
-    else:
+    elif key[2] == 98:
         name = "B average diameter (4 waves/unit)"
+    else:
+        name = f"pw_analyse_kernel<{key[1] // 64}, {key[2]}>"
     f = 2.0 * sum(vals["FETCH_SIZE"]) / max(len(vals["FETCH_SIZE"]), 1)
     w = sum(vals["WRITE_SIZE"]) / max(len(vals["WRITE_SIZE"]), 1)
     kernels[name] = {"grid": key[0], "workgroup": key[1], "FETCH_SIZE_KB_x2": f, "WRITE_SIZE_KB": w,
