@@ -689,6 +689,22 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         const char* bt = getenv("PW_B_TEAMS");
         if (bt && do_avg && atoi(bt) > 0 && atoi(bt) < pb.grid) pb.grid = atoi(bt);
     }
+    if (const char* cslots = getenv("PW_C_SLOTS")) {
+        // experiment: fewer window-fit slots than waves (less LDS per team, windows fitted in rounds);
+        // PW_C_TEAMS then sets the number of teams (up to what the smaller request admits per CU)
+        int k = atoi(cslots);
+        if (k >= 1 && k < 4 && pc.nw == 4) {
+            pc.nrot = pc.nlb = k;
+            pc.lds = UnitShared::bytes(r->nmax, k, k, 1, false) + 64;
+            int per_cu = (int)(c->lds_per_cu / pc.lds);
+            if (per_cu > 4) per_cu = 4;
+            long g = (long)c->n_cu * per_cu;
+            const char* ct = getenv("PW_C_TEAMS");
+            if (ct && atoi(ct) > 0 && atoi(ct) < g) g = atoi(ct);
+            pc.grid = (int)(g < r->n_units ? g : r->n_units);
+            if (getenv("PW_PLAN_DEBUG")) fprintf(stderr, "plan C: slots %d lds %zu grid %d\n", k, pc.lds, pc.grid);
+        }
+    }
     // teams: C[0..n) | A[0..n) | B (n = sets in flight: that many window and optimiser launches can be
     // running at once; the average-diameter launches follow each other on one stream), every region
     // as large as the largest grid seen so far -- see pw_context::max_a

@@ -137,6 +137,7 @@ struct UnitShared {
     Frame R[8];     // per-wave rotated coordinates (window frames)
     PW_LDS void* lb[8];    // per-wave optimiser state
     size_t rot_words;  // 8-byte words in the rotated-frame region
+    int nslots;        // waves that can fit a window at a time (rotated frames = optimiser states carved)
     // everything behind the shifted frame (window frames + optimiser states) is idle until the
     // windows are fitted and serves as scratch for the sampling stages
     PW_LDS unsigned char* scratch;
@@ -175,6 +176,7 @@ struct UnitShared {
             R[w].vdw = vdw; R[w].perm = perm; R[w].cls = &v->cls;
         }
         rot_words = (size_t)nrot * 4 * n;
+        nslots = nrot < nlb ? nrot : nlb;
         p = (PW_LDS unsigned char*)d;
         for (int w = 0; w < nlb; ++w) {
             lb[w] = (PW_LDS void*)p;
@@ -2344,9 +2346,10 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     int ncl = v.n_clusters < PW_W_MAX ? v.n_clusters : PW_W_MAX;
     // at most four waves fit windows at a time (one rotated frame + optimiser state each);
     // in an 8-wave team the upper four only take part in the bulk stages
-    constexpr int NSLOT = T::NWAVES < 4 ? T::NWAVES : 4;
-    if (T::wave() < NSLOT)
-        for (int c = T::wave(); c < ncl; c += NSLOT) wave_window<T>(sh, ws, n, c, sp, prm);
+    int nslot = T::NWAVES < 4 ? T::NWAVES : 4;
+    if (sh.nslots < nslot) nslot = sh.nslots;       // (a launch may carve fewer slots than waves to save LDS)
+    if (T::wave() < nslot)
+        for (int c = T::wave(); c < ncl; c += nslot) wave_window<T>(sh, ws, n, c, sp, prm);
     T::sync();
     if (T::wave() == 0) PW_T1(ws, 12, t_w);
     if (T::tid() == 0) {

@@ -98,3 +98,78 @@ def test_gather_ragged_world2(counts):
     total = sum(counts)
     assert got[0][1] == list(range(total)) and got[0][2] == list(range(2 * total))
     assert got[1][1] == [] and got[1][2] == []
+
+
+def _driver_worker(rank, world, port, path, modular, q):
+    """``DLPOLY.analysis`` under a two-rank gloo group with the device work replaced by a stand-in that
+    encodes (frame, molecule) in the records: what is tested is the host logic of the N > 1 path --
+    which frames a rank takes, what it contributes to the gather, what rank 0 assembles."""
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pywindow_amd import _lib
+    from pywindow_amd import trajectory as T
+
+    seen = []
+
+    def fake_run(self, frames, vdw, mass, device):
+        seen.extend(frames)
+        recs = np.zeros(len(frames), dtype=_lib.UNIT_OUT_DTYPE)
+        recs["n_atoms"] = 168
+        recs["pore_d"] = np.asarray(frames, float) + 0.5
+        recs["n_windows"] = 2
+        recs["win_d"][:, 0] = np.asarray(frames, float)
+        recs["win_d"][:, 1] = rank
+        return recs
+
+    def fake_run_modular(self, frames, rebuild, el, device):
+        seen.extend(frames)
+        n_mol = [2 + (f % 3) for f in frames]                 # ragged: 2..4 molecules per frame
+        uf = np.repeat(np.asarray(frames, np.int64), n_mol)
+        um = np.concatenate([np.arange(k) for k in n_mol]).astype(np.int64) if frames else np.zeros(0, np.int64)
+        recs = np.zeros(len(uf), dtype=_lib.UNIT_OUT_DTYPE)
+        recs["n_atoms"] = 100 + um
+        recs["pore_d"] = uf * 10.0 + um
+        recs["n_windows"] = -1
+        return recs, uf, um
+
+    T.DLPOLY._run = fake_run
+    T.DLPOLY._run_modular = fake_run_modular
+    traj = T.DLPOLY(path)
+    traj.analysis(modular=modular, rebuild=False)
+    out = {f: {m: (p["no_of_atoms"], p["pore_diameter"]["diameter"]) for m, p in mols.items()}
+           for f, mols in traj.analysis_output.items()}
+    q.put((rank, sorted(seen), out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("modular", [False, True])
+def test_trajectory_driver_shards_and_gathers_world2(tmp_path, modular):
+    import torch.multiprocessing as mp
+
+    from pywindow_amd import synth
+
+    path = synth.write_synthetic_history(tmp_path / "HISTORY", 7)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_driver_worker, args=(r, 2, port, str(path), modular, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {g[0]: g for g in (q.get(timeout=600) for _ in procs)}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # contiguous blocks of ceil(7 / 2) = 4 frames: rank 0 analyses 0..3, rank 1 analyses 4..6
+    assert got[0][1] == [0, 1, 2, 3] and got[1][1] == [4, 5, 6]
+    assert got[1][2] == {}                                     # only rank 0 holds the result
+    out = got[0][2]
+    assert sorted(out) == list(range(7))
+    if not modular:
+        assert all(list(out[f]) == ["0"] and out[f]["0"] == (168, f + 0.5) for f in range(7))
+    else:
+        for f in range(7):
+            assert sorted(out[f]) == list(range(2 + f % 3))
+            assert all(out[f][m] == (100 + m, f * 10.0 + m) for m in out[f])

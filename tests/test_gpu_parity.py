@@ -381,8 +381,12 @@ def test_reference_platform_branch_is_reported():
     """Which tolerance the live-oracle comparisons used on this box (0 on the reference platform:
     glibc 2.35 + AVX-512 numpy; north_star's 1e-6 elsewhere)."""
     import platform
+    import warnings
 
-    print("LIVE_TOL_WINDOW =", LIVE_TOL_WINDOW, "| libc", platform.libc_ver(), "| machine", platform.machine())
+    # (a warning, so that it shows in the summary of a quiet run as well)
+    warnings.warn(f"live-oracle window tolerance used on this box: {LIVE_TOL_WINDOW} "
+                  f"(libc {platform.libc_ver()}, {platform.machine()}; 0 = reference platform, bit-identical)",
+                  UserWarning, stacklevel=1)
     assert LIVE_TOL_WINDOW in (0.0, 1e-6)
 
 
