@@ -13,7 +13,7 @@ ids = E.element_ids(elements)
 vdw, mass = E.VDW[ids], E.MASS[ids]
 ref = _lib.Context(0).analyse(_lib.Batch.uniform(frames, vdw, mass))
 for n in (1, 2, 3, 5, 17, 64):
-    for rep in range(3):
+    for rep in range(2 if n == 3 else 1):     # (every context creates a dozen streams: keep their number modest)
         ctx = _lib.Context(0)
         out = ctx.analyse(_lib.Batch.uniform(frames[:n], vdw, mass))
         assert out.tobytes() == ref[:n].tobytes(), (n, rep)
