@@ -647,7 +647,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     //     chain; every unit of a 1000-frame batch iterates at once.  Chains differ 10x in length;
     //     each finished unit is published to a queue.
     //   B (aux stream): average diameter, 4 waves per unit, independent of A.
-    //   C (main stream): window search, persistent teams consuming units as A publishes them.
+    //   C (the set's consumer stream): window search, persistent teams consuming units as A publishes them.
     //     A one-wave gate kernel ahead of C (and B) holds them back until every team of A is
     //     resident, so they can never take the LDS A needs -- no launch-order assumption.
     LaunchPlan pa, pb, pc;
