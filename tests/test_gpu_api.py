@@ -82,6 +82,17 @@ def test_dlpoly_batched_analysis(tmp_path):
         assert len(p["windows"]["diameters"]) == g["n_windows"][f]
     with pytest.raises(Exception):
         traj.analysis(frames="bogus")
+    # a long selection is analysed in pieces (parsing overlaps the kernels): same records, same order
+    from pywindow_amd import trajectory
+
+    whole = traj.analysis_records()
+    old = trajectory.RUN_PIECE_MIN, trajectory.RUN_PIECE
+    trajectory.RUN_PIECE_MIN, trajectory.RUN_PIECE = 2, 4
+    try:
+        assert traj.analysis_records().tobytes() == whole.tobytes()       # 12 frames -> 3 pieces of 4
+        assert traj.analysis_records(frames=list(range(11))).tobytes() == whole[:11].tobytes()
+    finally:
+        trajectory.RUN_PIECE_MIN, trajectory.RUN_PIECE = old
 
 
 def test_record_gather_over_rccl_single_rank():
