@@ -968,8 +968,15 @@ int pw_resident_download(pw_context* c, pw_resident* r, pw_unit_out* out) {
     if (!c || !r || !out) return PW_E_BAD_ARG;
     if (r->n_units == 0) return PW_OK;
     PW_ON_DEVICE(c->device);
-    int rcj = join_pipeline(c);
-    if (rcj != PW_OK) return rcj;
+    // wait for the launch that wrote these records -- not for launches of other batches issued since
+    // (a trajectory analysed in pieces downloads piece k while piece k + 1 is still running)
+    const int ws = r->written_set[r->cur];
+    if (ws >= 0 && c->done_valid[ws]) {
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done[ws], 0));
+    } else {
+        int rcj = join_pipeline(c);
+        if (rcj != PW_OK) return rcj;
+    }
     HIP_TRY(hipMemcpyAsync(out, r->d_out, sizeof(pw_unit_out) * r->n_units, hipMemcpyDeviceToHost,
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -26,6 +26,10 @@ from .molecular import MolecularSystem, decipher_atom_key
 
 #: most frames a modular analysis pushes through the device in one piece (see Trajectory._run_modular)
 MODULAR_CHUNK = 8192
+#: ... a long one in pieces of MODULAR_PIECE frames, up to MODULAR_IN_FLIGHT of them analysed while the next is
+#: being read and re-assembled
+MODULAR_PIECE = 512
+MODULAR_IN_FLIGHT = 2
 #: a plain analysis of many frames is cut into pieces of about RUN_PIECE frames (never smaller than
 #: RUN_PIECE_MIN) so that parsing overlaps the kernels (see DLPOLY._run)
 RUN_PIECE = 4096
@@ -291,24 +295,40 @@ class DLPOLY:
         vdw = VDW[ids]
         dev = engine.resolve_device(device)
 
-        def one_chunk(ctx, chunk):
-            # frames -> molecules -> units without leaving the device: every molecule of every frame of
-            # the chunk is one unit of ONE analysis launch
-            coords, lattice = self._read_selected(chunk, self.periodic)
-            coords, lat, inv = rb.pack_frames(coords, lattice)
-            res, n_mol = ctx.resident_from_cells(topo, vdw, coords, lat, inv, rebuild)
-            if res is None:
-                return np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE), n_mol
-            try:
-                res.launch(_lib.STAGE_ALL)
-                return res.download(), n_mol
-            finally:
-                res.free()
-
-        # very long trajectories go through in pieces (the frames and the re-assembled molecules of a
-        # piece are resident on the device at once); each piece is still two launches
+        # frames -> molecules -> units without leaving the device: every molecule of every frame of a
+        # piece is one unit of ONE analysis launch.  Long trajectories go through in pieces (the frames
+        # and the re-assembled molecules of a piece are resident on the device at once; each piece is two
+        # launches); the analysis launch of a piece is asynchronous, so the next piece is tokenised on the
+        # host -- and re-assembled on the device -- while the previous one is still being analysed.  At most
+        # MODULAR_IN_FLIGHT pieces wait for their download.
         ctx = engine.context(dev)
-        parts = [one_chunk(ctx, frames[i:i + MODULAR_CHUNK]) for i in range(0, len(frames), MODULAR_CHUNK)]
+        n = len(frames)
+        piece = MODULAR_CHUNK if n < 2 * MODULAR_PIECE else min(MODULAR_CHUNK, MODULAR_PIECE)
+        parts, waiting, spent = [], [], []
+
+        def collect(entry):
+            res, n_mol = entry
+            recs = res.download() if res is not None else np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE)
+            if res is not None:
+                spent.append(res)          # (released at the end: freeing device memory waits for the whole device)
+            parts.append((recs, n_mol))
+
+        try:
+            for i in range(0, n, piece):
+                coords, lattice = self._read_selected(frames[i:i + piece], self.periodic)
+                coords, lat, inv = rb.pack_frames(coords, lattice)
+                res, n_mol = ctx.resident_from_cells(topo, vdw, coords, lat, inv, rebuild)
+                if res is not None:
+                    res.launch(_lib.STAGE_ALL)
+                waiting.append((res, n_mol))
+                if len(waiting) > MODULAR_IN_FLIGHT:
+                    collect(waiting.pop(0))
+            while waiting:
+                collect(waiting.pop(0))
+        finally:
+            for res in spent + [w[0] for w in waiting]:
+                if res is not None:
+                    res.free()
         recs = np.concatenate([p[0] for p in parts])
         n_mol = np.concatenate([p[1] for p in parts])
         unit_frame = np.repeat(np.asarray(frames, np.int64), n_mol)

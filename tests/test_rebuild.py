@@ -236,6 +236,7 @@ def test_long_modular_analysis_in_pieces(hip_ctx, tmp_path, monkeypatch):
     traj = pw.DLPOLY(path)
     whole = traj.modular_records(rebuild=True, forcefield="opls")
     monkeypatch.setattr(trajectory, "MODULAR_CHUNK", 2)
+    monkeypatch.setattr(trajectory, "MODULAR_PIECE", 2)      # 11 frames -> six pieces, three of them in flight at a time
     parts = traj.modular_records(rebuild=True, forcefield="opls")
     assert len(whole[0]) >= 11 * 8
     assert whole[0].tobytes() == parts[0].tobytes()
