@@ -86,8 +86,9 @@ def pack_frames(coords, lattices):
     if lattices is None:
         return coords, None, None
     lat = np.ascontiguousarray(lattices, dtype=np.float64).reshape(-1, 3, 3)
-    # fractional_from_cartesian inverts the lattice with numpy for every call (utilities.py:726)
-    inv = np.ascontiguousarray([np.linalg.inv(m) for m in lat])
+    # fractional_from_cartesian inverts the lattice with numpy for every call (utilities.py:726); the
+    # stacked call runs the same LAPACK routine on every 3 x 3 matrix
+    inv = np.ascontiguousarray(np.linalg.inv(lat))
     return coords, lat, inv
 
 

@@ -28,7 +28,7 @@ from .molecular import MolecularSystem, decipher_atom_key
 MODULAR_CHUNK = 8192
 #: ... a long one in pieces of MODULAR_PIECE frames, up to MODULAR_IN_FLIGHT of them analysed while the next is
 #: being read and re-assembled
-MODULAR_PIECE = 512
+MODULAR_PIECE = 1024
 MODULAR_IN_FLIGHT = 2
 #: a plain analysis of many frames is cut into pieces of about RUN_PIECE frames (never smaller than
 #: RUN_PIECE_MIN) so that parsing overlaps the kernels (see DLPOLY._run)
@@ -313,10 +313,26 @@ class DLPOLY:
                 spent.append(res)          # (released at the end: freeing device memory waits for the whole device)
             parts.append((recs, n_mol))
 
+        def read_piece(i):
+            coords, lattice = self._read_selected(frames[i:i + piece], self.periodic)
+            return rb.pack_frames(coords, lattice)
+
+        # the next piece is tokenised by a helper thread (the native reader releases the interpreter lock)
+        # while this thread waits for the re-assembly launch of the current one
+        starts = list(range(0, n, piece))
+        pool = None
+        if len(starts) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+
+            pool = ThreadPoolExecutor(max_workers=1)
         try:
-            for i in range(0, n, piece):
-                coords, lattice = self._read_selected(frames[i:i + piece], self.periodic)
-                coords, lat, inv = rb.pack_frames(coords, lattice)
+            ahead = pool.submit(read_piece, starts[0]) if pool else None
+            for k, i in enumerate(starts):
+                if pool:
+                    coords, lat, inv = ahead.result()
+                    ahead = pool.submit(read_piece, starts[k + 1]) if k + 1 < len(starts) else None
+                else:
+                    coords, lat, inv = read_piece(i)
                 res, n_mol = ctx.resident_from_cells(topo, vdw, coords, lat, inv, rebuild)
                 if res is not None:
                     res.launch(_lib.STAGE_ALL)
@@ -326,6 +342,8 @@ class DLPOLY:
             while waiting:
                 collect(waiting.pop(0))
         finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
             for res in spent + [w[0] for w in waiting]:
                 if res is not None:
                     res.free()
