@@ -36,7 +36,7 @@ def periodic_history(tmp_path_factory):
     return path
 
 
-def test_config4_periodic_trajectory_end_to_end(hip_ctx, periodic_history):
+def test_config4_periodic_trajectory_end_to_end(hip_ctx, periodic_history, monkeypatch):
     import pywindow_amd as pw
     from oracle import pw_oracle as O
     from oracle import pw_rebuild as R
@@ -53,9 +53,15 @@ def test_config4_periodic_trajectory_end_to_end(hip_ctx, periodic_history):
     assert (recs["status"] == 0).all()
     assert (recs["n_atoms"] == 168).all()
     assert (recs["n_windows"] > 0).all() and (recs["n_windows"] == 4).sum() > 0.99 * len(recs)
-    # run to run: byte-identical
-    again, _, _ = traj.modular_records("all", rebuild=True)
+    # run to run: byte-identical -- the second time in four pieces of 256 frames (the pipelined form long
+    # trajectories take: the next piece is read and re-assembled while the previous ones are analysed)
+    from pywindow_amd import trajectory
+
+    monkeypatch.setattr(trajectory, "MODULAR_PIECE", 256)
+    again, uf2, um2 = traj.modular_records("all", rebuild=True)
+    monkeypatch.undo()
     assert again.tobytes() == recs.tobytes()
+    assert np.array_equal(uf2, uframe) and np.array_equal(um2, umol)
     # frame order does not matter (a permuted selection gives the permuted records)
     perm = np.random.default_rng(1).permutation(N_FRAMES)[:96].tolist()
     sub, sf, sm = traj.modular_records(perm, rebuild=True)
