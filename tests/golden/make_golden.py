@@ -823,6 +823,44 @@ def run_axes(pool):
     print("axes:", np.array([r[0] for r in res])[0])
 
 
+def run_nonporous():
+    """What the reference does with a molecule whose centre of mass lies inside an atom (methane): the
+    values it still computes, the exception SciPy raises from opt_pore_diameter / find_windows /
+    full_analysis, and the properties full_analysis had filled in by then."""
+    pw = load_reference()
+    from pywindow._internal import utilities as U
+
+    el = np.array(["C", "H", "H", "H", "H"])
+    xyz = np.array([[0, 0, 0], [0.63, 0.63, 0.63], [-0.63, -0.63, 0.63], [-0.63, 0.63, -0.63], [0.63, -0.63, -0.63]], float)
+    out = {"elements": el, "coordinates": xyz}
+    d, a = U.pore_diameter(el, xyz)
+    out["pore_d"], out["pore_atom"] = np.array(d), np.array(a)
+    msgs = []
+    for f in (U.opt_pore_diameter, U.find_windows):
+        try:
+            f(el, xyz)
+            msgs.append("")
+        except ValueError as exc:
+            msgs.append(str(exc))
+    out["find_windows_no_pore_opt_is_none"] = np.array(U.find_windows(el, xyz, pore_opt=False) is None)
+    mol = pw.MolecularSystem.load_system({"elements": el, "coordinates": xyz}).system_to_molecule()
+    try:
+        mol.full_analysis()
+        msgs.append("")
+    except ValueError as exc:
+        msgs.append(str(exc))
+    out["messages"] = np.array(msgs)
+    p = mol.properties
+    out["property_keys"] = np.array(list(p))
+    out["maxd"] = np.array(p["maximum_diameter"]["diameter"])
+    out["maxd_atoms"] = np.array([p["maximum_diameter"]["atom_1"], p["maximum_diameter"]["atom_2"]])
+    out["avg_d"] = np.array(p["average_diameter"])
+    out["pore_vol"] = np.array(p["pore_volume"])
+    out["com"] = np.array(p["centre_of_mass"])
+    np.savez_compressed(HERE / "nonporous.npz", **out)
+    print("nonporous:", msgs, list(p))
+
+
 def run_tables():
     """The per-element constants of the path as the reference holds them (tables.py:22-286: mass,
     van der Waals and covalent radius, 85 upper-case keys each) and its OPLS atom-key table
@@ -878,11 +916,13 @@ def run_history20():
 
 
 def main():
-    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj", "optopt", "winopt", "shape", "tables", "history20", "axes"}
+    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj", "optopt", "winopt", "shape", "tables", "history20", "axes", "nonporous"}
     if "tables" in which:
         run_tables()
     if "history20" in which:
         run_history20()
+    if "nonporous" in which:
+        run_nonporous()
     if "cc3base" in which:
         load_reference()
         import tests.test_validate_cc3 as C

@@ -4,7 +4,7 @@ benchmark's full size -- through size-independent properties."""
 import numpy as np
 import pytest
 
-from _util import GROUPS, LIVE_TOL_WINDOW, check_records, group_batch, load_group, molecules, rel
+from _util import GOLDEN, GROUPS, LIVE_TOL_WINDOW, check_records, group_batch, load_group, molecules, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -264,9 +264,8 @@ def test_window_order_is_the_reference_order(hip_ctx):
 
 
 def _methane():
-    el = np.array(["C", "H", "H", "H", "H"])
-    xyz = np.array([[0, 0, 0], [0.63, 0.63, 0.63], [-0.63, -0.63, 0.63], [-0.63, 0.63, -0.63], [0.63, -0.63, -0.63]], float)
-    return el, xyz
+    g = np.load(GOLDEN / "nonporous.npz")       # inputs and the reference's behaviour (make_golden.py: run_nonporous)
+    return g["elements"], g["coordinates"], g
 
 
 def test_non_porous_molecule_fails_where_the_reference_fails(hip_ctx, monkeypatch):
@@ -278,9 +277,11 @@ def test_non_porous_molecule_fails_where_the_reference_fails(hip_ctx, monkeypatc
     import pywindow_amd as pw
     from pywindow_amd import _lib, engine
 
-    el, xyz = _methane()
-    assert pw.pore_diameter(el, xyz) == (-3.4, 0)
-    msg = "An upper bound is less than the corresponding lower bound."
+    el, xyz, ref = _methane()
+    assert pw.pore_diameter(el, xyz) == (float(ref["pore_d"]), int(ref["pore_atom"])) == (-3.4, 0)
+    assert len(set(ref["messages"])) == 1 and bool(ref["find_windows_no_pore_opt_is_none"])
+    msg = str(ref["messages"][0])
+    assert msg == engine.NEGATIVE_PORE_MESSAGE
     for call in (lambda: pw.opt_pore_diameter(el, xyz), lambda: pw.find_windows(el, xyz)):
         with pytest.raises(ValueError, match=msg):
             call()
@@ -289,16 +290,18 @@ def test_non_porous_molecule_fails_where_the_reference_fails(hip_ctx, monkeypatc
     with pytest.raises(ValueError, match=msg):
         mol.full_analysis()
     # what the reference had filled in before SciPy stopped it
-    assert list(mol.properties) == ["no_of_atoms", "centre_of_mass", "maximum_diameter", "average_diameter",
-                                    "pore_diameter", "pore_volume"]
-    assert mol.properties["maximum_diameter"] == {"diameter": 3.9619090885901, "atom_1": 1, "atom_2": 2}
-    assert mol.properties["average_diameter"] == 3.247643917158653
-    assert mol.properties["pore_diameter"] == {"diameter": -3.4, "atom": 0}
-    assert mol.properties["pore_volume"] == -20.579526276115534
+    assert list(mol.properties) == list(ref["property_keys"])
+    assert mol.properties["maximum_diameter"] == {"diameter": float(ref["maxd"]), "atom_1": int(ref["maxd_atoms"][0]),
+                                                  "atom_2": int(ref["maxd_atoms"][1])}
+    assert mol.properties["average_diameter"] == float(ref["avg_d"])
+    assert mol.properties["pore_diameter"] == {"diameter": float(ref["pore_d"]), "atom": int(ref["pore_atom"])}
+    assert mol.properties["pore_volume"] == float(ref["pore_vol"])
+    assert np.array_equal(mol.properties["centre_of_mass"], ref["com"])
     # in a batch: flagged, None windows, neighbours unaffected
     g = load_group("md20")
     cage = molecules(g)[2]
     recs = engine.analyse([cage, (el, xyz), cage])
+    assert float(recs[1]["pore_d"]) == float(ref["pore_d"]) and float(recs[1]["avg_d"]) == float(ref["avg_d"])
     assert int(recs[1]["status"]) & _lib.ST_NEGATIVE_PORE and int(recs[1]["n_windows"]) == -1
     assert engine.windows_of(recs[1]) is None
     assert recs[0].tobytes() == recs[2].tobytes() and float(recs[0]["pore_opt_d"]) == g["pore_opt_d"][2]
