@@ -38,6 +38,10 @@ typedef PW_LDS double ldouble;
 typedef PW_LDS int lint;
 
 PW_HD inline double pw_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// (-2 * g) + a in ONE instruction: the product by two is exact, so the fused form rounds once exactly
+// where the two-instruction form of the distance primitive rounds -- the same bits, one VALU operation
+// less in every atom-point distance
+PW_HD inline double pw_m2add(double g, double a) { return __builtin_fma(-2.0, g, a); }
 PW_HD inline double pw_sqrt(double a) { return __builtin_sqrt(a); }
 PW_HD inline double pw_abs(double a) { return __builtin_fabs(a); }
 PW_HD inline double pw_max(double a, double b) { return a > b ? a : b; }   // no NaNs on this path

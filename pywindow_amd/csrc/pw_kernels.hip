@@ -208,7 +208,7 @@ __global__ void pw_point_gap_kernel(long n_points, const long* __restrict__ unit
         double x = xyz[3 * (a0 + i)], y = xyz[3 * (a0 + i) + 1], z = xyz[3 * (a0 + i) + 2];
         double xx = sq3(x, y, z);
         double g = pw_fma(z, pz, pw_fma(x, px, y * py));
-        double d2 = ((-2.0 * g) + xx) + pp;
+        double d2 = pw_m2add(g, xx) + pp;
         double d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
         double v = d - vdw[a0 * vstride + i];
         if (v < best) { best = v; bi = i; }

@@ -100,7 +100,7 @@ PW_HD inline double rb_round8(double x) {
 // scikit-learn euclidean_distances, N x 1 call shape: row x (with |x|^2 = xx) against point p
 PW_HD inline double rb_dist_sk(const double* x, double xx, double px, double py, double pz, double pp) {
     double g = pw_fma(x[2], pz, pw_fma(x[0], px, x[1] * py));
-    double d2 = ((-2.0 * g) + xx) + pp;
+    double d2 = pw_m2add(g, xx) + pp;
     return pw_sqrt(d2 > 0.0 ? d2 : 0.0);
 }
 

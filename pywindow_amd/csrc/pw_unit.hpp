@@ -225,7 +225,7 @@ PW_HD inline double norm3(double a, double b, double c) {
 }
 PW_HD inline double gap_atom(const Frame& F, int i, double px, double py, double pz, double pp) {
     double g = pw_fma(F.z[i], pz, pw_fma(F.x[i], px, F.y[i] * py));
-    double d2 = ((-2.0 * g) + F.xx[i]) + pp;
+    double d2 = pw_m2add(g, F.xx[i]) + pp;
     double d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
     return d - F.vdw[i];
 }
@@ -262,13 +262,13 @@ PW_HD inline double point_gap_value(const Frame& F, int n, double px, double py,
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 double gg = pw_fma(az[j], pz, pw_fma(ax[j], px, ay[j] * py));
-                double d2 = ((-2.0 * gg) + aq[j]) + pp;
+                double d2 = pw_m2add(gg, aq[j]) + pp;
                 m2 = __builtin_fmin(m2, d2);
             }
         }
         for (; i < hi; ++i) {
             double gg = pw_fma(F.z[i], pz, pw_fma(F.x[i], px, F.y[i] * py));
-            double d2 = ((-2.0 * gg) + F.xx[i]) + pp;
+            double d2 = pw_m2add(gg, F.xx[i]) + pp;
             m2 = __builtin_fmin(m2, d2);
         }
         double d = pw_sqrt(m2 > 0.0 ? m2 : 0.0);
@@ -305,7 +305,7 @@ PW_HD inline void points_gap_values(const Frame& F, int n, const double* px, con
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 double gg = pw_fma(z, qz[p], pw_fma(x, qx[p], y * qy[p]));
-                double d2 = ((-2.0 * gg) + xx) + pp[p];
+                double d2 = pw_m2add(gg, xx) + pp[p];
                 m2[p] = __builtin_fmin(m2[p], d2);
             }
         }
@@ -777,29 +777,35 @@ PW_HD inline __attribute__((always_inline)) void ray_scan_multi_impl(const Frame
         any[r] = false;
     }
     const double c0 = cen[0], c1 = cen[1], c2 = cen[2];
-    for (int blk = 0; blk < n; blk += 64) {
-        unsigned long long mask[NR];
+    // The screen only has to be conservative, so it is as short as it can be: the squared distance
+    // from the line with one fused operation, one comparison.  It differs from the value the exact
+    // code below forms (|rel|^2 - along^2 rounded twice) by less than 2e-14 for these magnitudes; the
+    // limit carries 1e-12 (relative to the radius and to |rel|^2), and an atom whose value comes out
+    // negative is flagged too -- the exact code finds the NaN there, as the reference does.
+    for (int blk = 0; blk < n; blk += 32) {
+        unsigned mask[NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) mask[r] = 0;
-        int jend = n - blk < 64 ? n - blk : 64;
+        for (int r = 0; r < NR; ++r) mask[r] = 0u;
+        int jend = n - blk < 32 ? n - blk : 32;
 #pragma unroll 2
         for (int j = 0; j < jend; ++j) {
             int i = blk + j;
             double rx = F.x[i] - c0, ry = F.y[i] - c1, rz = F.z[i] - c2;
             double rr = sq3(rx, ry, rz);
-            double lim = (F.vdw[i] * F.vdw[i]) * (1.0 + 1e-14);
+            double lim = pw_fma(rr, 1e-12, (F.vdw[i] * F.vdw[i]) * (1.0 + 1e-12));
+            const unsigned bit = 1u << j;
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 double along = pw_fma(rz, uz[r], pw_fma(rx, ux[r], ry * uy[r]));
-                double q = rr - along * along;
-                if (q >= 0.0 && q <= lim) mask[r] |= 1ull << j;
+                double q = pw_fma(-along, along, rr);
+                mask[r] |= q <= lim ? bit : 0u;
             }
         }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            unsigned long long m = mask[r];
+            unsigned m = mask[r];
             while (m) {
-                int j = __builtin_ctzll(m);
+                int j = __builtin_ctz(m);
                 m &= m - 1;
                 int i = blk + j;
                 double rx = F.x[i] - c0, ry = F.y[i] - c1, rz = F.z[i] - c2;
@@ -1034,13 +1040,13 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         double gg = pw_fma(zi, az[u], pw_fma(yi, ay[u], xi * ax[u]));
-                        double d2 = (oi < ap[u]) ? ((-2.0 * gg) + xxi) + aq[u] : ((-2.0 * gg) + aq[u]) + xxi;
+                        double d2 = (oi < ap[u]) ? pw_m2add(gg, xxi) + aq[u] : pw_m2add(gg, aq[u]) + xxi;
                         m2 = __builtin_fmax(m2, d2);
                     }
                 }
                 for (; j < hi; ++j) {
                     double gg = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
-                    double d2 = (oi < F.perm[j]) ? ((-2.0 * gg) + xxi) + F.xx[j] : ((-2.0 * gg) + F.xx[j]) + xxi;
+                    double d2 = (oi < F.perm[j]) ? pw_m2add(gg, xxi) + F.xx[j] : pw_m2add(gg, F.xx[j]) + xxi;
                     m2 = __builtin_fmax(m2, d2);
                 }
                 double d = pw_sqrt(m2 > 0.0 ? m2 : 0.0);
@@ -1096,14 +1102,14 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         double gg = pw_fma(zi, az[u], pw_fma(yi, ay[u], xi * ax[u]));
-                        double d2 = (oi < ap[u]) ? ((-2.0 * gg) + xxi) + aq[u] : ((-2.0 * gg) + aq[u]) + xxi;
+                        double d2 = (oi < ap[u]) ? pw_m2add(gg, xxi) + aq[u] : pw_m2add(gg, aq[u]) + xxi;
                         if (d2 >= thr) candidate(d2, ap[u]);
                     }
                 }
                 for (; j < hi; ++j) {
                     double gg = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
                     int oj = F.perm[j];
-                    double d2 = (oi < oj) ? ((-2.0 * gg) + xxi) + F.xx[j] : ((-2.0 * gg) + F.xx[j]) + xxi;
+                    double d2 = (oi < oj) ? pw_m2add(gg, xxi) + F.xx[j] : pw_m2add(gg, F.xx[j]) + xxi;
                     if (d2 >= thr) candidate(d2, oj);
                 }
             }
@@ -1120,7 +1126,7 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
                 int oj = F.perm[j];
                 if (j != i) {
                     double gg = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
-                    double d2 = (oi < oj) ? ((-2.0 * gg) + xxi) + F.xx[j] : ((-2.0 * gg) + F.xx[j]) + xxi;
+                    double d2 = (oi < oj) ? pw_m2add(gg, xxi) + F.xx[j] : pw_m2add(gg, F.xx[j]) + xxi;
                     d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
                 }
                 double v = d + (vi + F.vdw[j]);
@@ -1938,8 +1944,8 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
 #pragma unroll
                     for (int p = 0; p < NK; ++p) {
                         double ax = px[p] - qx, ay = py[p] - qy, az = pz[p] - qz;
-                        double d = 0.0;
-                        d = d + ax * ax; d = d + ay * ay; d = d + az * az;
+                        double d = ax * ax;          // (0.0 + ax * ax of the reference is ax * ax exactly)
+                        d = d + ay * ay; d = d + az * az;
                         if (d < thr[p]) {
                             double v_ = d;
 #pragma unroll
@@ -2234,8 +2240,8 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
 #pragma unroll
                         for (int t = 0; t < 8; ++t) {
                             double ax = px - qx[t], ay = py - qy[t], az = pz - qz[t];
-                            double d = 0.0;
-                            d = d + ax * ax; d = d + ay * ay; d = d + az * az;
+                            double d = ax * ax;      // (0.0 + ax * ax is ax * ax exactly)
+                            d = d + ay * ay; d = d + az * az;
                             if (d <= e2) { bits |= 1ull << (j + t - wd * 64); ++cnt; }
                         }
                     }
@@ -2244,8 +2250,8 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                     const int pjk = surv_k[j];
                 const double pj[3] = {pts[PT(pjk, 0)], pts[PT(pjk, 1)], pts[PT(pjk, 2)]};
                     double ax = px - pj[0], ay = py - pj[1], az = pz - pj[2];
-                    double d = 0.0;
-                    d = d + ax * ax; d = d + ay * ay; d = d + az * az;
+                    double d = ax * ax;
+                    d = d + ay * ay; d = d + az * az;
                     if (d <= e2) { bits |= 1ull << (j - wd * 64); ++cnt; }
                 }
                 adj[(size_t)i * stride + wd] = bits;
