@@ -262,15 +262,16 @@ PW_HD inline double point_gap_value(const Frame& F, int n, double px, double py,
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 double gg = pw_fma(az[j], pz, pw_fma(ax[j], px, ay[j] * py));
-                double d2 = pw_m2add(gg, aq[j]) + pp;
-                m2 = __builtin_fmin(m2, d2);
+                m2 = __builtin_fmin(m2, pw_m2add(gg, aq[j]));
             }
         }
         for (; i < hi; ++i) {
             double gg = pw_fma(F.z[i], pz, pw_fma(F.x[i], px, F.y[i] * py));
-            double d2 = pw_m2add(gg, F.xx[i]) + pp;
-            m2 = __builtin_fmin(m2, d2);
+            m2 = __builtin_fmin(m2, pw_m2add(gg, F.xx[i]));
         }
+        // |p|^2 is added to the minimum instead of to every term: rounding is monotone, so
+        // min_i fl(a_i + pp) = fl(min_i a_i + pp) exactly
+        m2 = m2 + pp;
         double d = pw_sqrt(m2 > 0.0 ? m2 : 0.0);
         best = __builtin_fmin(best, d - C.vdw[g]);
     }
@@ -305,14 +306,15 @@ PW_HD inline void points_gap_values(const Frame& F, int n, const double* px, con
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 double gg = pw_fma(z, qz[p], pw_fma(x, qx[p], y * qy[p]));
-                double d2 = pw_m2add(gg, xx) + pp[p];
-                m2[p] = __builtin_fmin(m2[p], d2);
+                m2[p] = __builtin_fmin(m2[p], pw_m2add(gg, xx));
             }
         }
         const double r = C.vdw[g];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            double d = pw_sqrt(m2[p] > 0.0 ? m2[p] : 0.0);
+            // (|p|^2 added to the minimum, not to every term: rounding is monotone -- the same bits)
+            const double m2p = m2[p] + pp[p];
+            double d = pw_sqrt(m2p > 0.0 ? m2p : 0.0);
             best[p] = __builtin_fmin(best[p], d - r);
         }
     }
