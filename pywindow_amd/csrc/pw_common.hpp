@@ -9,6 +9,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -27,10 +28,18 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PW_LDS __attribute__((address_space(3)))
 #define PW_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
+#define PW_IS_LDS(p) __builtin_amdgcn_is_shared((const void*)(p))
 #else
 #define PW_LDS
 #define PW_ASSUME_LDS(p) do {} while (0)
+#define PW_IS_LDS(p) true
 #endif
+// Arrays carved from the idle part of the team's LDS fall back to the global workspace when they do not
+// fit, so their pointers are generic and every access a flat_* instruction (issued through the vector
+// memory path, waited for on both counters).  Hot loops over such arrays are written once as a generic
+// lambda over the pointer types and entered through PW_WITH_LDS*: when the arrays are in LDS -- the
+// usual case -- the loop runs on address-space-3 pointers (ds_* instructions).
+#define PW_AS_LDS(p) ((PW_LDS std::remove_pointer_t<decltype(p)>*)(p))
 
 namespace pw {
 

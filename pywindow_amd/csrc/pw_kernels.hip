@@ -77,8 +77,17 @@ constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STA
 // window launch (256 VGPRs) can share the SIMD with it, and sharing SIMDs between the launches is
 // what the pipeline lives on.  The spills that remain are outside the hot loops (0.2 % of the
 // chains' instructions, profiles/r02_*).
+#ifndef PW_OCC
+#define PW_OCC 2
+#endif
+#ifndef PW_OCC8
+#define PW_OCC8 1
+#endif
+#ifndef PW_OCC_A
+#define PW_OCC_A PW_OCC
+#endif
 template <int NW, unsigned MASK>
-__global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (MASK == PW_KERNEL_AVERAGE ? 3 : 2))
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? PW_OCC8 : (MASK == PW_KERNEL_AVERAGE ? 3 : (MASK == MASK_CHAINS ? PW_OCC_A : PW_OCC)))
 pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
                   const double* __restrict__ vdw, const double* __restrict__ mass, unsigned stages,
                   int nmax, int nrot, int nlb, int nframes, int lean, TeamWorkspace* __restrict__ workspaces,

@@ -209,6 +209,20 @@ PW_HD inline void team_atomic_max(PW_LDS int* p, int v) {
     if (v > *p) *p = v;
 #endif
 }
+PW_HD inline void team_atomic_min(int* p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(p, v);
+#else
+    if (v < *p) *p = v;
+#endif
+}
+PW_HD inline void team_atomic_add(int* p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(p, v);
+#else
+    *p += v;
+#endif
+}
 PW_HD inline void team_atomic_or(PW_LDS unsigned long long* p, unsigned long long v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicOr((unsigned long long*)p, v);
@@ -508,14 +522,14 @@ PW_HD inline void np_descend(int len, int e, int* off_out, int* len_out) {
 // whole leaves by construction: both bounds are leaf starts (or the chunk's end).  `src` holds the
 // elements from e_lo on: element e of the chunk is src[e - e_lo].  leafbuf[slot of the leaf's
 // start] receives the sum.  acc8 needs 8 doubles per 64-element slot of the range, plus one slot.
-template <class T>
-PW_HD inline void np_leaf_phase(const double* src, int len, int e_lo, int e_hi, int* tab, double* acc8,
-                                double* leafbuf) {
+template <class T, class SP, class IP, class DP>
+PW_HD inline __attribute__((always_inline)) void np_leaf_phase_t(SP src, int len, int e_lo, int e_hi, IP tab, DP acc8,
+                                                                 DP leafbuf) {
     const int sl_lo = e_lo >> 6;
     const int sl_hi = (e_hi + 63) >> 6;          // exclusive
     const int nslot = sl_hi - sl_lo;
-    int* t_off = tab;
-    int* t_len = tab + 128;
+    IP t_off = tab;
+    IP t_len = tab + 128;
     for (int s_ = T::tid(); s_ < nslot; s_ += T::SIZE) {
         const int sl = sl_lo + s_;
         int e = sl * 64, off, l, start = -1, ln = 0;
@@ -535,7 +549,7 @@ PW_HD inline void np_leaf_phase(const double* src, int len, int e_lo, int e_hi, 
         int sl = sl_lo + (task >> 3), c = task & 7;
         int start = t_off[sl];
         if (start < 0) continue;
-        const double* b = src + (start - e_lo);
+        SP b = src + (start - e_lo);
         int ln = t_len[sl];
         if (ln < 8) {
             if (c == 0) {
@@ -565,9 +579,9 @@ PW_HD inline void np_leaf_phase(const double* src, int len, int e_lo, int e_hi, 
         const int sl = sl_lo + s_;
         int start = t_off[sl];
         if (start < 0) continue;
-        const double* b = src + (start - e_lo);
+        SP b = src + (start - e_lo);
         int ln = t_len[sl];
-        const double* r = acc8 + 8 * s_;
+        DP r = acc8 + 8 * s_;
         double res;
         if (ln < 8) {
             res = r[0];
@@ -579,60 +593,49 @@ PW_HD inline void np_leaf_phase(const double* src, int len, int e_lo, int e_hi, 
     }
     T::sync();
 }
-// Combine the leaf sums of one chunk in recursion order (depth first; node stack (off, len, stage)
-// and value stack in team-shared memory).  For long arrays the four depth-2 subtrees are walked by
-// four waves at once (the walk is a chain of dependent LDS operations).  The result is valid on
-// thread 0.  acc8: at least 128 doubles; tab: 324 ints; leafbuf: 256 doubles.
 template <class T>
-PW_HD inline double np_walk_phase(int len, int* tab, double* acc8, double* leafbuf) {
-    auto walk = [&](int off0, int len0, int* st, double* vals) -> double {
-        int top = 0, vtop = 0;
-        st[0] = off0; st[1] = len0; st[2] = 0; top = 1;
-        while (top) {
-            int* c = st + 3 * (top - 1);
-            int coff = c[0], clen = c[1], cst = c[2];
-            if (clen <= 128) {
-                vals[vtop++] = leafbuf[coff >> 6];
-                --top;
-            } else {
-                int n2 = clen / 2;
+PW_HD inline void np_leaf_phase(const double* src, int len, int e_lo, int e_hi, int* tab, double* acc8,
+                                double* leafbuf) {
+    if (PW_IS_LDS(src) && PW_IS_LDS(tab) && PW_IS_LDS(acc8) && PW_IS_LDS(leafbuf))
+        np_leaf_phase_t<T>(PW_AS_LDS(src), len, e_lo, e_hi, PW_AS_LDS(tab), PW_AS_LDS(acc8), PW_AS_LDS(leafbuf));
+    else
+        np_leaf_phase_t<T>(src, len, e_lo, e_hi, tab, acc8, leafbuf);
+}
+// Combine the leaf sums of one chunk as numpy's recursion does: every inner node is (sum of its left
+// part) + (sum of its right part), whatever order the nodes are visited in -- so the tree is folded
+// level by level from the deepest one, one thread per node, instead of walking it depth first (that
+// walk was a chain of ~400 dependent LDS round trips for 64 leaves).  A node is named by its depth and
+// the left/right turns from the root; its (offset, length) follow from at most seven halvings.  The
+// right part is the larger one, and it is a leaf (<= 128 elements) at depth 7 at the latest for a
+// chunk of 8192.  The result is valid on thread 0.  acc8: at least 128 doubles; leafbuf: 256 doubles
+// (leaf sums by 64-element slot in the first 128).
+template <class T, class DP>
+PW_HD inline __attribute__((always_inline)) double np_walk_phase_t(int len, DP acc8, DP leafbuf) {
+    int depth = 0;
+    for (int l = len; l > 128; ++depth) { int n2 = l / 2; n2 -= n2 % 8; l -= n2; }
+    for (int d = depth; d >= 0; --d) {
+        DP mine = (d & 1) ? leafbuf + 128 : acc8;
+        DP below = (d & 1) ? acc8 : leafbuf + 128;
+        for (int t = T::tid(); t < (1 << d); t += T::SIZE) {
+            int off = 0, l = len;
+            bool exists = true;
+            for (int k = d - 1; k >= 0; --k) {
+                if (l <= 128) { exists = false; break; }
+                int n2 = l / 2;
                 n2 -= n2 % 8;
-                if (cst == 0) {
-                    c[2] = 1;
-                    int* d = st + 3 * top;
-                    d[0] = coff; d[1] = n2; d[2] = 0; ++top;
-                } else if (cst == 1) {
-                    c[2] = 2;
-                    int* d = st + 3 * top;
-                    d[0] = coff + n2; d[1] = clen - n2; d[2] = 0; ++top;
-                } else {
-                    double r = vals[--vtop];
-                    double l = vals[--vtop];
-                    vals[vtop++] = l + r;
-                    --top;
-                }
+                if ((t >> k) & 1) { off += n2; l -= n2; } else { l = n2; }
             }
-        }
-        return vals[0];
-    };
-    double part = 0.0;
-    if (len > 512 && T::NWAVES >= 4) {
-        int h = len / 2; h -= h % 8;                    // root: [0, h) + [h, len)
-        int hl = h / 2; hl -= hl % 8;                   // left child: [0, hl) + [hl, h)
-        int hr = (len - h) / 2; hr -= hr % 8;           // right child: [h, h + hr) + [h + hr, len)
-        int w = T::wave();
-        if (w < 4 && T::lane() == 0) {
-            int so = w == 0 ? 0 : (w == 1 ? hl : (w == 2 ? h : h + hr));
-            int sl = w == 0 ? hl : (w == 1 ? h - hl : (w == 2 ? hr : len - h - hr));
-            int* st = (int*)(acc8 + 64) + 32 * w;       // acc8 is free again after the leaf folds
-            acc8[w] = walk(so, sl, st, leafbuf + 128 + 8 * w);
+            if (exists) mine[t] = l <= 128 ? leafbuf[off >> 6] : below[2 * t] + below[2 * t + 1];
         }
         T::sync();
-        if (T::tid() == 0) part = (acc8[0] + acc8[1]) + (acc8[2] + acc8[3]);
-    } else if (T::tid() == 0) {
-        part = walk(0, len, tab + 256, leafbuf + 128);
     }
-    return part;
+    return acc8[0];
+}
+template <class T>
+PW_HD inline double np_walk_phase(int len, int* tab, double* acc8, double* leafbuf) {
+    (void)tab;
+    if (PW_IS_LDS(acc8) && PW_IS_LDS(leafbuf)) return np_walk_phase_t<T>(len, PW_AS_LDS(acc8), PW_AS_LDS(leafbuf));
+    return np_walk_phase_t<T>(len, acc8, leafbuf);
 }
 template <class T>
 PW_HD inline double np_sum_team(const double* a, int n, int* tab, double* acc8, double* leafbuf,
@@ -762,13 +765,15 @@ PW_NOINLINE PW_HD inline bool ray_scan(const Frame& F, int n, const double* cen,
     return ray_scan_impl(F, n, cen, dx, dy, dz, farthest);
 }
 
-// NR rays of one thread at once: the screen reads every atom once for all of them (register
+// NR (= 4) rays of one thread at once: the screen reads every atom once for all of them (register
 // blocking); the exact part per flagged (ray, atom) is the one of ray_scan_impl.  Results are
-// identical to NR calls of ray_scan.
-template <int NR>
+// identical to NR calls of ray_scan.  FAR = false: only `hit` is wanted (the sampling stage of
+// find_windows), so a ray that has hit something drops its remaining candidates.
+template <int NR, bool FAR>
 PW_HD inline __attribute__((always_inline)) void ray_scan_multi_impl(const Frame& F, int n, const double* cen,
                                                                      const double* dx, const double* dy,
                                                                      const double* dz, bool* hit, double* farthest) {
+    static_assert(NR == 4, "the merged exact loop below is written for four rays");
     double ux[NR], uy[NR], uz[NR], far[NR];
     bool any[NR];
 #pragma unroll
@@ -784,47 +789,72 @@ PW_HD inline __attribute__((always_inline)) void ray_scan_multi_impl(const Frame
     // code below forms (|rel|^2 - along^2 rounded twice) by less than 2e-14 for these magnitudes; the
     // limit carries 1e-12 (relative to the radius and to |rel|^2), and an atom whose value comes out
     // negative is flagged too -- the exact code finds the NaN there, as the reference does.
-    for (int blk = 0; blk < n; blk += 32) {
-        unsigned mask[NR];
+    // The flagged (ray, atom) pairs of 64 atoms are then worked off in ONE loop over all four rays: a
+    // wave runs a loop as long as its busiest lane, and the busiest lane of a loop per (ray, 32 atoms)
+    // has three pairs where the average lane has 0.6 -- merged, the ratio is two.
+    for (int blk = 0; blk < n; blk += 64) {
+        unsigned long long mask[NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) mask[r] = 0u;
-        int jend = n - blk < 32 ? n - blk : 32;
+        for (int r = 0; r < NR; ++r) mask[r] = 0ull;
+        for (int half = 0; half < 64 && blk + half < n; half += 32) {
+            unsigned mh[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) mh[r] = 0u;
+            const int base = blk + half;
+            const int jend = n - base < 32 ? n - base : 32;
 #pragma unroll 2
-        for (int j = 0; j < jend; ++j) {
-            int i = blk + j;
-            double rx = F.x[i] - c0, ry = F.y[i] - c1, rz = F.z[i] - c2;
-            double rr = sq3(rx, ry, rz);
-            double lim = pw_fma(rr, 1e-12, (F.vdw[i] * F.vdw[i]) * (1.0 + 1e-12));
-            const unsigned bit = 1u << j;
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                double along = pw_fma(rz, uz[r], pw_fma(rx, ux[r], ry * uy[r]));
-                double q = pw_fma(-along, along, rr);
-                mask[r] |= q <= lim ? bit : 0u;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            unsigned m = mask[r];
-            while (m) {
-                int j = __builtin_ctz(m);
-                m &= m - 1;
-                int i = blk + j;
+            for (int j = 0; j < jend; ++j) {
+                int i = base + j;
                 double rx = F.x[i] - c0, ry = F.y[i] - c1, rz = F.z[i] - c2;
-                double along = pw_fma(rz, uz[r], pw_fma(rx, ux[r], ry * uy[r]));
-                double sq = sq3(rx, ry, rz);
-                double perp = pw_sqrt(sq - along * along);
-                double radicand = F.vdw[i] * F.vdw[i] - perp * perp;
-                if (radicand > 0.0) {
-                    double half = pw_sqrt(radicand);
-                    double tin = along - half, tout = along + half;
-                    double ix = c0 + tin * ux[r], iy = c1 + tin * uy[r], iz = c2 + tin * uz[r];
-                    double ox = c0 + tout * ux[r], oy = c1 + tout * uy[r], oz = c2 + tout * uz[r];
-                    double nin = norm3(ix, iy, iz), nout = norm3(ox, oy, oz);
-                    if (nin < nout) {
-                        any[r] = true;
-                        if (nout > far[r]) far[r] = nout;
-                    }
+                double rr = sq3(rx, ry, rz);
+                double lim = pw_fma(rr, 1e-12, (F.vdw[i] * F.vdw[i]) * (1.0 + 1e-12));
+                const unsigned bit = 1u << j;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    double along = pw_fma(rz, uz[r], pw_fma(rx, ux[r], ry * uy[r]));
+                    double q = pw_fma(-along, along, rr);
+                    mh[r] |= q <= lim ? bit : 0u;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) mask[r] |= (unsigned long long)mh[r] << half;
+        }
+        if (!FAR) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) mask[r] = any[r] ? 0ull : mask[r];
+        }
+        while ((mask[0] | mask[1] | mask[2] | mask[3]) != 0ull) {
+            // the next pair of this thread: the lowest flagged atom of its first ray that has one
+            const int r = mask[0] ? 0 : (mask[1] ? 1 : (mask[2] ? 2 : 3));
+            const unsigned long long m = r == 0 ? mask[0] : (r == 1 ? mask[1] : (r == 2 ? mask[2] : mask[3]));
+            const unsigned long long rest = m & (m - 1);
+            const int i = blk + __builtin_ctzll(m);
+            const double vx = r == 0 ? ux[0] : (r == 1 ? ux[1] : (r == 2 ? ux[2] : ux[3]));
+            const double vy = r == 0 ? uy[0] : (r == 1 ? uy[1] : (r == 2 ? uy[2] : uy[3]));
+            const double vz = r == 0 ? uz[0] : (r == 1 ? uz[1] : (r == 2 ? uz[2] : uz[3]));
+            bool got = false;
+            double nout = -1.0;
+            double rx = F.x[i] - c0, ry = F.y[i] - c1, rz = F.z[i] - c2;
+            double along = pw_fma(rz, vz, pw_fma(rx, vx, ry * vy));
+            double sq = sq3(rx, ry, rz);
+            double perp = pw_sqrt(sq - along * along);
+            double radicand = F.vdw[i] * F.vdw[i] - perp * perp;
+            if (radicand > 0.0) {
+                double half = pw_sqrt(radicand);
+                double tin = along - half, tout = along + half;
+                double ix = c0 + tin * vx, iy = c1 + tin * vy, iz = c2 + tin * vz;
+                double ox = c0 + tout * vx, oy = c1 + tout * vy, oz = c2 + tout * vz;
+                double nin = norm3(ix, iy, iz);
+                nout = norm3(ox, oy, oz);
+                got = nin < nout;
+            }
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const bool mine = r == q;
+                if (mine) mask[q] = (!FAR && got) ? 0ull : rest;
+                if (mine && got) {
+                    any[q] = true;
+                    if (FAR && nout > far[q]) far[q] = nout;
                 }
             }
         }
@@ -832,10 +862,10 @@ PW_HD inline __attribute__((always_inline)) void ray_scan_multi_impl(const Frame
 #pragma unroll
     for (int r = 0; r < NR; ++r) { hit[r] = any[r]; farthest[r] = far[r]; }
 }
-template <int NR>
+template <int NR, bool FAR = true>
 PW_NOINLINE PW_HD inline void ray_scan_multi(const Frame& F, int n, const double* cen, const double* dx,
                                              const double* dy, const double* dz, bool* hit, double* farthest) {
-    ray_scan_multi_impl<NR>(F, n, cen, dx, dy, dz, hit, farthest);
+    ray_scan_multi_impl<NR, FAR>(F, n, cen, dx, dy, dz, hit, farthest);
 }
 
 // numpy floor division a // b for positive doubles (npy_divmod)
@@ -1000,59 +1030,75 @@ template <class T>
 PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& sh, const Frame& F, int n,
                                                                    double* item_best = nullptr) {
     // max over pairs (diagonal included) of d_ij + (vdw_i + vdw_j), first maximum in row-major
-    // order of the caller's numbering (utilities.py:355-372).  Two passes; a thread owns a
-    // (row, column half) and walks the columns, so the lanes of a wave hold consecutive rows and
-    // read the SAME column at the same time (LDS broadcast, no bank conflicts):
+    // order of the caller's numbering (utilities.py:355-372).  Two passes over the upper triangle:
     //   1. value only -- inside one radius group of the column the maximum of the sum is at the
     //      maximum squared distance (sqrt and the addition of a common constant are monotone), so
-    //      the tile loop carries squared distances and takes one sqrt per (row, group);
+    //      the column loop carries squared distances and takes one sqrt per (row, group);
     //   2. the winner's index: only pairs whose squared distance is within a few ulps of what
     //      the maximum requires are evaluated exactly and compared by index.
+    // Work items: row p is folded with row n-1-p (together they have n-1 columns above the diagonal,
+    // whatever p is), and the columns of a folded row are dealt to K threads by their residue mod K,
+    // K varying fastest over the threads: every item has (n-1)/K columns, the threads of a wave walk
+    // the radius groups in step (their counts per group differ by one at most) and read K adjacent
+    // columns at a time.  (Half rows per thread, the round-1 scheme, left the triangle's short rows
+    // idle: 164 column steps per thread for CC3 against 63 here.)
     const auto& C = *F.cls;
     const int ngrp = C.k;
-    const int half = (n + 1) / 2;
-    const int ntile = 2 * n;
+    const int R = (n + 1) / 2;
+    int K = 1;
+    {
+        long best_cost = 0x7fffffffffffffffl;
+        for (int k = 1; k <= 4; ++k) {
+            long passes = ((long)R * k + T::SIZE - 1) / T::SIZE;
+            long cost = passes * ((n - 1 + 64 / k + k - 1) / k);
+            if (cost < best_cost) { best_cost = cost; K = k; }
+        }
+    }
+    const int nitem = R * K;
+    if (nitem > PW_P_MAX) item_best = nullptr;
     double best = -PW_INF;
     if (ngrp > 0) {
-        for (int t = T::tid(); t < ntile; t += T::SIZE) {
-            const int part = t >= n ? 1 : 0;
-            const int i = t - part * n;
-            const int j0 = part * half, j1 = part ? n : half;
-            if (j1 <= i) continue;
-            const double xi = F.x[i], yi = F.y[i], zi = F.z[i], xxi = F.xx[i], vi = F.vdw[i];
-            const int oi = F.perm[i];
+        for (int t = T::tid(); t < nitem; t += T::SIZE) {
+            const int p = t / K, q = t - p * K;
             double ibest = -PW_INF;                                     // this item's maximum
-            if (j0 <= i) ibest = 0.0 + (vi + vi);                       // the diagonal entry
-            for (int g = 0; g < ngrp; ++g) {
-                int lo = C.off[g] > j0 ? C.off[g] : j0;
-                if (lo <= i) lo = i + 1;
-                const int hi = C.off[g + 1] < j1 ? C.off[g + 1] : j1;
-                if (lo >= hi) continue;
-                double m2 = -PW_INF;
-                int j = lo;
-                // entry (row, column) of the reference's matrix has row < column in the caller's
-                // numbering: the row norm is added first
-                for (; j + 8 <= hi; j += 8) {
-                    double ax[8], ay[8], az[8], aq[8];
-                    int ap[8];
+            for (int side = 0; side < 2; ++side) {
+                const int i = side == 0 ? p : n - 1 - p;
+                if (side == 1 && i == p) break;                         // (the middle row of an odd n)
+                const double xi = F.x[i], yi = F.y[i], zi = F.z[i], xxi = F.xx[i], vi = F.vdw[i];
+                const int oi = F.perm[i];
+                if (q == 0) ibest = pw_max(ibest, 0.0 + (vi + vi));     // the diagonal entry
+                for (int g = 0; g < ngrp; ++g) {
+                    int lo = C.off[g] > i + 1 ? C.off[g] : i + 1;
+                    const int hi = C.off[g + 1];
+                    lo += (q - lo % K + K) % K;                         // first column of residue q
+                    if (lo >= hi) continue;
+                    double m2 = -PW_INF;
+                    int j = lo;
+                    // entry (row, column) of the reference's matrix has row < column in the caller's
+                    // numbering: the row norm is added first
+                    for (; j + 7 * K < hi; j += 8 * K) {
+                        double ax[8], ay[8], az[8], aq[8];
+                        int ap[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        ax[u] = F.x[j + u]; ay[u] = F.y[j + u]; az[u] = F.z[j + u]; aq[u] = F.xx[j + u]; ap[u] = F.perm[j + u];
+                        for (int u = 0; u < 8; ++u) {
+                            const int c = j + u * K;
+                            ax[u] = F.x[c]; ay[u] = F.y[c]; az[u] = F.z[c]; aq[u] = F.xx[c]; ap[u] = F.perm[c];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            double gg = pw_fma(zi, az[u], pw_fma(yi, ay[u], xi * ax[u]));
+                            double d2 = (oi < ap[u]) ? pw_m2add(gg, xxi) + aq[u] : pw_m2add(gg, aq[u]) + xxi;
+                            m2 = __builtin_fmax(m2, d2);
+                        }
                     }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        double gg = pw_fma(zi, az[u], pw_fma(yi, ay[u], xi * ax[u]));
-                        double d2 = (oi < ap[u]) ? pw_m2add(gg, xxi) + aq[u] : pw_m2add(gg, aq[u]) + xxi;
+                    for (; j < hi; j += K) {
+                        double gg = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
+                        double d2 = (oi < F.perm[j]) ? pw_m2add(gg, xxi) + F.xx[j] : pw_m2add(gg, F.xx[j]) + xxi;
                         m2 = __builtin_fmax(m2, d2);
                     }
+                    double d = pw_sqrt(m2 > 0.0 ? m2 : 0.0);
+                    ibest = pw_max(ibest, d + (vi + C.vdw[g]));
                 }
-                for (; j < hi; ++j) {
-                    double gg = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
-                    double d2 = (oi < F.perm[j]) ? pw_m2add(gg, xxi) + F.xx[j] : pw_m2add(gg, F.xx[j]) + xxi;
-                    m2 = __builtin_fmax(m2, d2);
-                }
-                double d = pw_sqrt(m2 > 0.0 ? m2 : 0.0);
-                ibest = pw_max(ibest, d + (vi + C.vdw[g]));
             }
             best = pw_max(best, ibest);
             if (item_best) item_best[t] = ibest;
@@ -1068,51 +1114,53 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
     // pass 2: smallest row-major index among the pairs that reach vmax
     double bidx = PW_INF;
     if (ngrp > 0) {
-        for (int t = T::tid(); t < ntile; t += T::SIZE) {
-            const int part = t >= n ? 1 : 0;
-            const int i = t - part * n;
-            const int j0 = part * half, j1 = part ? n : half;
-            if (j1 <= i) continue;
+        for (int t = T::tid(); t < nitem; t += T::SIZE) {
             if (item_best && item_best[t] != vmax) continue;            // (written by this very thread)
-            const double xi = F.x[i], yi = F.y[i], zi = F.z[i], xxi = F.xx[i], vi = F.vdw[i];
-            const int oi = F.perm[i];
-            if (j0 <= i && 0.0 + (vi + vi) == vmax) bidx = pw_min(bidx, (double)(oi * n + oi));
-            for (int g = 0; g < ngrp; ++g) {
-                int lo = C.off[g] > j0 ? C.off[g] : j0;
-                if (lo <= i) lo = i + 1;
-                const int hi = C.off[g + 1] < j1 ? C.off[g + 1] : j1;
-                if (lo >= hi) continue;
-                const double c = vi + C.vdw[g];
-                // d + c == vmax needs d >= vmax - c - ulp(vmax); squared, with margin
-                const double need = (vmax - c) - 1e-15 * vmax;
-                const double thr = need > 0.0 ? need * need * (1.0 - 1e-15) : -PW_INF;
-                auto candidate = [&](double d2, int oj) {
-                    double d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
-                    if (d + c == vmax) {
-                        int idx = oi < oj ? oi * n + oj : oj * n + oi;
-                        bidx = pw_min(bidx, (double)idx);
-                    }
-                };
-                int j = lo;
-                for (; j + 8 <= hi; j += 8) {
-                    double ax[8], ay[8], az[8], aq[8];
-                    int ap[8];
+            const int p = t / K, q = t - p * K;
+            for (int side = 0; side < 2; ++side) {
+                const int i = side == 0 ? p : n - 1 - p;
+                if (side == 1 && i == p) break;
+                const double xi = F.x[i], yi = F.y[i], zi = F.z[i], xxi = F.xx[i], vi = F.vdw[i];
+                const int oi = F.perm[i];
+                if (q == 0 && 0.0 + (vi + vi) == vmax) bidx = pw_min(bidx, (double)(oi * n + oi));
+                for (int g = 0; g < ngrp; ++g) {
+                    int lo = C.off[g] > i + 1 ? C.off[g] : i + 1;
+                    const int hi = C.off[g + 1];
+                    lo += (q - lo % K + K) % K;
+                    if (lo >= hi) continue;
+                    const double c = vi + C.vdw[g];
+                    // d + c == vmax needs d >= vmax - c - ulp(vmax); squared, with margin
+                    const double need = (vmax - c) - 1e-15 * vmax;
+                    const double thr = need > 0.0 ? need * need * (1.0 - 1e-15) : -PW_INF;
+                    auto candidate = [&](double d2, int oj) {
+                        double d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
+                        if (d + c == vmax) {
+                            int idx = oi < oj ? oi * n + oj : oj * n + oi;
+                            bidx = pw_min(bidx, (double)idx);
+                        }
+                    };
+                    int j = lo;
+                    for (; j + 7 * K < hi; j += 8 * K) {
+                        double ax[8], ay[8], az[8], aq[8];
+                        int ap[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        ax[u] = F.x[j + u]; ay[u] = F.y[j + u]; az[u] = F.z[j + u]; aq[u] = F.xx[j + u]; ap[u] = F.perm[j + u];
-                    }
+                        for (int u = 0; u < 8; ++u) {
+                            const int cc = j + u * K;
+                            ax[u] = F.x[cc]; ay[u] = F.y[cc]; az[u] = F.z[cc]; aq[u] = F.xx[cc]; ap[u] = F.perm[cc];
+                        }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        double gg = pw_fma(zi, az[u], pw_fma(yi, ay[u], xi * ax[u]));
-                        double d2 = (oi < ap[u]) ? pw_m2add(gg, xxi) + aq[u] : pw_m2add(gg, aq[u]) + xxi;
-                        if (d2 >= thr) candidate(d2, ap[u]);
+                        for (int u = 0; u < 8; ++u) {
+                            double gg = pw_fma(zi, az[u], pw_fma(yi, ay[u], xi * ax[u]));
+                            double d2 = (oi < ap[u]) ? pw_m2add(gg, xxi) + aq[u] : pw_m2add(gg, aq[u]) + xxi;
+                            if (d2 >= thr) candidate(d2, ap[u]);
+                        }
                     }
-                }
-                for (; j < hi; ++j) {
-                    double gg = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
-                    int oj = F.perm[j];
-                    double d2 = (oi < oj) ? pw_m2add(gg, xxi) + F.xx[j] : pw_m2add(gg, F.xx[j]) + xxi;
-                    if (d2 >= thr) candidate(d2, oj);
+                    for (; j < hi; j += K) {
+                        double gg = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
+                        int oj = F.perm[j];
+                        double d2 = (oi < oj) ? pw_m2add(gg, xxi) + F.xx[j] : pw_m2add(gg, F.xx[j]) + xxi;
+                        if (d2 >= thr) candidate(d2, oj);
+                    }
                 }
             }
         }
@@ -1416,7 +1464,7 @@ PW_HD inline __attribute__((always_inline)) void stage_average_impl(UnitShared& 
                 int k = k0 + r * T::SIZE < P ? k0 + r * T::SIZE : k0;
                 sp.point(k, &dx[r], &dy[r], &dz[r]);
             }
-            if (INL) ray_scan_multi_impl<NR>(sh.S, n, cen, dx, dy, dz, hit, far);
+            if (INL) ray_scan_multi_impl<NR, true>(sh.S, n, cen, dx, dy, dz, hit, far);
             else ray_scan_multi<NR>(sh.S, n, cen, dx, dy, dz, hit, far);
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
@@ -1819,9 +1867,12 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     double keep_d = v.maxd;
     int keep_i = v.maxd_i, keep_j = v.maxd_j;
     T::sync();
+    if (T::wave() == 0) PW_T1(ws, 14, t_pre);
+    PW_T0(t_md);
     team_max_dim<T>(sh, sh.S, n, 2 * n <= PW_P_MAX ? ws->vals : nullptr);
     double radius = v.maxd / 2.0;
     T::sync();
+    if (T::wave() == 0) PW_T1(ws, 15, t_md);
     if (T::tid() == 0) { v.maxd = keep_d; v.maxd_i = keep_i; v.maxd_j = keep_j; }
     int P = sampling_count(radius, prm.adjust_windows);
     if (T::tid() == 0) {
@@ -1909,81 +1960,84 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         for (int p = 0; p < NK; ++p)
 #pragma unroll
             for (int q = 0; q < 10; ++q) dist[p][q] = 0.0;
-        for (int grp = T::tid(); grp < ngroups; grp += T::SIZE) {
-            const int k0 = grp * NK;
-            double px[NK], py[NK], pz[NK], t[NK][10];
+        auto knn_groups = [&](auto pts_) __attribute__((always_inline)) {
+            for (int grp = T::tid(); grp < ngroups; grp += T::SIZE) {
+                const int k0 = grp * NK;
+                double px[NK], py[NK], pz[NK], t[NK][10];
 #pragma unroll
-            for (int p = 0; p < NK; ++p) {
-                int k = k0 + p < P ? k0 + p : P - 1;
-                px[p] = pts[PT(k, 0)]; py[p] = pts[PT(k, 1)]; pz[p] = pts[PT(k, 2)];
-            }
-            const int klast = k0 + NK - 1 < P ? k0 + NK - 1 : P - 1;
-            int lo = k0 - W < 0 ? 0 : k0 - W, hi = klast + W > P - 1 ? P - 1 : klast + W;
-            for (int pass = 0; pass < 2; ++pass) {
+                for (int p = 0; p < NK; ++p) {
+                    int k = k0 + p < P ? k0 + p : P - 1;
+                    px[p] = pts_[PT(k, 0)]; py[p] = pts_[PT(k, 1)]; pz[p] = pts_[PT(k, 2)];
+                }
+                const int klast = k0 + NK - 1 < P ? k0 + NK - 1 : P - 1;
+                int lo = k0 - W < 0 ? 0 : k0 - W, hi = klast + W > P - 1 ? P - 1 : klast + W;
+                for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-                for (int p = 0; p < NK; ++p)
+                    for (int p = 0; p < NK; ++p)
 #pragma unroll
-                    for (int q = 0; q < 10; ++q) t[p][q] = PW_INF;
-                // pass 0: every thread walks the same offsets t relative to its first point (k0 = 4 * grp),
-                // so the lanes of a wave read consecutive doubles of one residue class; pass 1 (the whole
-                // sphere, only if the window did not prove itself) uses plain indices
-                const int t_lo = pass == 0 ? -W : -k0, t_hi = pass == 0 ? NK - 1 + W : P - 1 - k0;
-                // Candidates further than twice the expected tenth-neighbour distance are never entered
-                // (pass 0): the lanes walk the same offsets and a spiral lattice has its neighbours at the
-                // same offsets everywhere, so for most offsets no lane of the wave inserts anything and the
-                // whole insertion chain is skipped.  A list that is not full afterwards (t[9] still
-                // infinite) fails the proof below and the point is redone without a threshold.
-                const double tau = pass == 0 ? 80.0 * radius * radius / (double)P : PW_INF;
-                double thr[NK];
+                        for (int q = 0; q < 10; ++q) t[p][q] = PW_INF;
+                    // pass 0: every thread walks the same offsets t relative to its first point (k0 = 4 * grp),
+                    // so the lanes of a wave read consecutive doubles of one residue class; pass 1 (the whole
+                    // sphere, only if the window did not prove itself) uses plain indices
+                    const int t_lo = pass == 0 ? -W : -k0, t_hi = pass == 0 ? NK - 1 + W : P - 1 - k0;
+                    // Candidates further than twice the expected tenth-neighbour distance are never entered
+                    // (pass 0): the lanes walk the same offsets and a spiral lattice has its neighbours at the
+                    // same offsets everywhere, so for most offsets no lane of the wave inserts anything and the
+                    // whole insertion chain is skipped.  A list that is not full afterwards (t[9] still
+                    // infinite) fails the proof below and the point is redone without a threshold.
+                    const double tau = pass == 0 ? 80.0 * radius * radius / (double)P : PW_INF;
+                    double thr[NK];
 #pragma unroll
-                for (int p = 0; p < NK; ++p) thr[p] = tau;
+                    for (int p = 0; p < NK; ++p) thr[p] = tau;
 #pragma unroll 2
-                for (int tt = t_lo; tt <= t_hi; ++tt) {
-                    const int j = k0 + tt;
-                    if (j < lo || j > hi) continue;
-                    const int at = ((tt & 3) * Q4) + grp + (tt >> 2);      // == PT(j, 0): j = 4 * grp + tt
-                    const double qx = pts[at], qy = pts[4 * Q4 + at], qz = pts[8 * Q4 + at];
+                    for (int tt = t_lo; tt <= t_hi; ++tt) {
+                        const int j = k0 + tt;
+                        if (j < lo || j > hi) continue;
+                        const int at = ((tt & 3) * Q4) + grp + (tt >> 2);      // == PT(j, 0): j = 4 * grp + tt
+                        const double qx = pts_[at], qy = pts_[4 * Q4 + at], qz = pts_[8 * Q4 + at];
+#pragma unroll
+                        for (int p = 0; p < NK; ++p) {
+                            double ax = px[p] - qx, ay = py[p] - qy, az = pz[p] - qz;
+                            double d = ax * ax;          // (0.0 + ax * ax of the reference is ax * ax exactly)
+                            d = d + ay * ay; d = d + az * az;
+                            if (d < thr[p]) {
+                                double v_ = d;
+#pragma unroll
+                                for (int q = 0; q < 10; ++q) {
+                                    double lo_ = __builtin_fmin(t[p][q], v_);
+                                    v_ = __builtin_fmax(t[p][q], v_);
+                                    t[p][q] = lo_;
+                                }
+                                thr[p] = __builtin_fmin(tau, t[p][9]);
+                            }
+                        }
+                    }
+                    bool full = (lo == 0 && hi == P - 1);
+                    bool proven = true;
+#pragma unroll
+                    for (int p = 0; p < NK; ++p) proven = proven && (pw_sqrt(t[p][9]) < (double)(W - 1) * zstep);
+                    if (full || proven) break;
+                    lo = 0; hi = P - 1;
+                }
+                if (streamed) {
+                    // this thread's 40 distances stay in registers; they go to the tiles below
+#pragma unroll
+                    for (int p = 0; p < NK; ++p)
+#pragma unroll
+                        for (int q = 0; q < 10; ++q) dist[p][q] = pw_sqrt(t[p][q]);
+                } else {
 #pragma unroll
                     for (int p = 0; p < NK; ++p) {
-                        double ax = px[p] - qx, ay = py[p] - qy, az = pz[p] - qz;
-                        double d = ax * ax;          // (0.0 + ax * ax of the reference is ax * ax exactly)
-                        d = d + ay * ay; d = d + az * az;
-                        if (d < thr[p]) {
-                            double v_ = d;
+                        if (k0 + p < P) {
+                            double* row = &ws->knn[(k0 + p) * 10];
 #pragma unroll
-                            for (int q = 0; q < 10; ++q) {
-                                double lo_ = __builtin_fmin(t[p][q], v_);
-                                v_ = __builtin_fmax(t[p][q], v_);
-                                t[p][q] = lo_;
-                            }
-                            thr[p] = __builtin_fmin(tau, t[p][9]);
+                            for (int q = 0; q < 10; ++q) row[q] = pw_sqrt(t[p][q]);
                         }
                     }
                 }
-                bool full = (lo == 0 && hi == P - 1);
-                bool proven = true;
-#pragma unroll
-                for (int p = 0; p < NK; ++p) proven = proven && (pw_sqrt(t[p][9]) < (double)(W - 1) * zstep);
-                if (full || proven) break;
-                lo = 0; hi = P - 1;
             }
-            if (streamed) {
-                // this thread's 40 distances stay in registers; they go to the tiles below
-#pragma unroll
-                for (int p = 0; p < NK; ++p)
-#pragma unroll
-                    for (int q = 0; q < 10; ++q) dist[p][q] = pw_sqrt(t[p][q]);
-            } else {
-#pragma unroll
-                for (int p = 0; p < NK; ++p) {
-                    if (k0 + p < P) {
-                        double* row = &ws->knn[(k0 + p) * 10];
-#pragma unroll
-                        for (int q = 0; q < 10; ++q) row[q] = pw_sqrt(t[p][q]);
-                    }
-                }
-            }
-        }
+        };
+        if (PW_IS_LDS(pts)) knn_groups(PW_AS_LDS(pts)); else knn_groups(pts);
         T::sync();
         if (T::wave() == 0) PW_T1(ws, 24, t_knn);
         PW_T0(t_sum);
@@ -2009,13 +2063,16 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                         np_descend(len, lo + tile_cap, &off, &l);
                         hi = off;
                     }
+                    auto fill = [&](auto tile_) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int p = 0; p < NK; ++p)
+                        for (int p = 0; p < NK; ++p)
 #pragma unroll
-                        for (int q = 0; q < 10; ++q) {
-                            const int e = e_first + p * 10 + q - s0;      // position inside this chunk
-                            if (e >= lo && e < hi && e_first + p * 10 + q < n_el) tile[e - lo] = dist[p][q];
-                        }
+                            for (int q = 0; q < 10; ++q) {
+                                const int e = e_first + p * 10 + q - s0;      // position inside this chunk
+                                if (e >= lo && e < hi && e_first + p * 10 + q < n_el) tile_[e - lo] = dist[p][q];
+                            }
+                    };
+                    if (PW_IS_LDS(tile)) fill(PW_AS_LDS(tile)); else fill(tile);
                     T::sync();
                     np_leaf_phase<T>(tile, len, lo, hi, s_tab, s_acc, s_leaf);
                     lo = hi;
@@ -2069,7 +2126,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                     int k = k0 + r * T::SIZE < P ? k0 + r * T::SIZE : k0;
                     dx[r] = pts[PT(k, 0)]; dy[r] = pts[PT(k, 1)]; dz[r] = pts[PT(k, 2)];
                 }
-                ray_scan_multi<NR>(sh.S, n, cen, dx, dy, dz, hit, far);
+                ray_scan_multi<NR, false>(sh.S, n, cen, dx, dy, dz, hit, far);
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     int k = k0 + r * T::SIZE;
@@ -2189,16 +2246,12 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     // sklearn labels (sklearn/cluster/_dbscan_inner.pyx): core points = connected components
     // of the eps-graph numbered by their smallest member index; a border point takes the
     // label of the first (lowest-numbered) cluster with a core point next to it.  Both are
-    // independent of the traversal order inside a cluster, so each cluster is grown
-    // breadth-first with bitset frontiers, all lanes expanding frontier members at once.
+    // independent of the traversal order, so all clusters are found at once (below).
     {
         const int words = (ns + 63) / 64;
         double e2 = v.eps * v.eps;
         PW_LDS unsigned long long* core = v.bits[0];
-        PW_LDS unsigned long long* unl = v.bits[1];
         PW_LDS unsigned long long* frontier = v.bits[2];
-        PW_LDS unsigned long long* next = v.bits[3];
-        PW_LDS unsigned long long* next2 = v.bits[4];
         // adjacency rows live in LDS (the window frames are idle now) when they fit
         unsigned long long* adj = (unsigned long long*)arena.take((size_t)ns * (size_t)words * 8);
         int stride = words;
@@ -2208,111 +2261,148 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             T::sync();
             return;
         }
-        for (int wd = T::tid(); wd < words; wd += T::SIZE) {
-            core[wd] = 0;
-            int nb = ns - wd * 64;
-            unl[wd] = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+        PW_LDS unsigned long long* roots = frontier;
+        for (int wd = T::tid(); wd < words; wd += T::SIZE) { core[wd] = 0; roots[wd] = 0; }
+        PW_LDS int* chg = (PW_LDS int*)v.bits[1];      // "something changed" flags of the rounds below, used in turn
+        if (T::tid() == 0) { chg[0] = 0; chg[1] = 0; }
+        // the survivors' end points, compacted: the threads of a wave then read the same point at the
+        // same time (broadcast) and eight of them are fetched ahead of the arithmetic
+        double* cp = (double*)arena.take((size_t)ns * 24);
+        for (int i = T::tid(); i < ns; i += T::SIZE) {
+            labels[i] = 0;                  // (counts the neighbours first)
+            if (cp) {
+                const int pik = surv_k[i];
+                cp[3 * i] = pts[PT(pik, 0)]; cp[3 * i + 1] = pts[PT(pik, 1)]; cp[3 * i + 2] = pts[PT(pik, 2)];
+            }
         }
         T::sync();
-        // the survivors' end points, compacted: every thread then reads the same point at the same
-        // time (broadcast) and eight of them are fetched ahead of the arithmetic
-        double* cp = (double*)arena.take((size_t)ns * 24);
-        if (cp) {
-            for (int i = T::tid(); i < ns; i += T::SIZE) {
-                const int pik = surv_k[i];
-                const double pi[3] = {pts[PT(pik, 0)], pts[PT(pik, 1)], pts[PT(pik, 2)]};
-                cp[3 * i] = pi[0]; cp[3 * i + 1] = pi[1]; cp[3 * i + 2] = pi[2];
-            }
-            T::sync();
+        // Work items are (point, 64-bit word of its adjacency row), dealt point-major: the number of
+        // survivors is rarely a multiple of the team size (CC3: 250-270 against 256 threads), and a
+        // second round of whole rows for a handful of points would cost as much as the first.
+#define PW_ROW_ITEMS_BEGIN                                                                   \
+        {                                                                                    \
+            int i = T::tid(), wd = 0;                                                        \
+            while (i >= ns && wd < words) { i -= ns; ++wd; }                                 \
+            while (wd < words) {
+#define PW_ROW_ITEMS_END                                                                     \
+                i += T::SIZE;                                                                \
+                while (i >= ns && wd < words) { i -= ns; ++wd; }                             \
+            }                                                                                \
         }
-        for (int i = T::tid(); i < ns; i += T::SIZE) {
-            const int pik = surv_k[i];
-                const double pi[3] = {pts[PT(pik, 0)], pts[PT(pik, 1)], pts[PT(pik, 2)]};
-            double px = pi[0], py = pi[1], pz = pi[2];
-            int cnt = 0;
-            for (int wd = 0; wd < words; ++wd) {
+        const bool have_cp = cp != nullptr;
+        auto cluster = [&](auto cp_, auto adj_, auto labels_) __attribute__((always_inline)) {
+            PW_ROW_ITEMS_BEGIN
+                double px, py, pz;
+                if (have_cp) { px = cp_[3 * i]; py = cp_[3 * i + 1]; pz = cp_[3 * i + 2]; }
+                else { const int pik = surv_k[i]; px = pts[PT(pik, 0)]; py = pts[PT(pik, 1)]; pz = pts[PT(pik, 2)]; }
                 unsigned long long bits = 0;
-                int jend = (wd * 64 + 64 < ns) ? wd * 64 + 64 : ns;
+                const int jend = (wd * 64 + 64 < ns) ? wd * 64 + 64 : ns;
                 int j = wd * 64;
-                if (cp) {
+                if (have_cp) {
                     for (; j + 8 <= jend; j += 8) {
                         double qx[8], qy[8], qz[8];
 #pragma unroll
-                        for (int t = 0; t < 8; ++t) { qx[t] = cp[3 * (j + t)]; qy[t] = cp[3 * (j + t) + 1]; qz[t] = cp[3 * (j + t) + 2]; }
+                        for (int t = 0; t < 8; ++t) { qx[t] = cp_[3 * (j + t)]; qy[t] = cp_[3 * (j + t) + 1]; qz[t] = cp_[3 * (j + t) + 2]; }
 #pragma unroll
                         for (int t = 0; t < 8; ++t) {
                             double ax = px - qx[t], ay = py - qy[t], az = pz - qz[t];
                             double d = ax * ax;      // (0.0 + ax * ax is ax * ax exactly)
                             d = d + ay * ay; d = d + az * az;
-                            if (d <= e2) { bits |= 1ull << (j + t - wd * 64); ++cnt; }
+                            if (d <= e2) bits |= 1ull << (j + t - wd * 64);
                         }
                     }
                 }
                 for (; j < jend; ++j) {
                     const int pjk = surv_k[j];
-                const double pj[3] = {pts[PT(pjk, 0)], pts[PT(pjk, 1)], pts[PT(pjk, 2)]};
-                    double ax = px - pj[0], ay = py - pj[1], az = pz - pj[2];
+                    double ax = px - pts[PT(pjk, 0)], ay = py - pts[PT(pjk, 1)], az = pz - pts[PT(pjk, 2)];
                     double d = ax * ax;
                     d = d + ay * ay; d = d + az * az;
-                    if (d <= e2) { bits |= 1ull << (j - wd * 64); ++cnt; }
+                    if (d <= e2) bits |= 1ull << (j - wd * 64);
                 }
-                adj[(size_t)i * stride + wd] = bits;
-            }
-            if (cnt >= 5) team_atomic_or(&core[i >> 6], 1ull << (i & 63));
-            labels[i] = -1;
-        }
-        T::sync();
-        if (T::wave() == 0) PW_T1(ws, 11, t_db);      // adjacency rows + core points
-        PW_T0(t_bfs);
-        int label = 0;
-        for (;;) {
-            int seed = -1;
-            for (int wd = 0; wd < words; ++wd) {
-                unsigned long long m = unl[wd] & core[wd];
-                if (m) { seed = wd * 64 + __builtin_ctzll(m); break; }
-            }
-            if (seed < 0) break;
-            T::sync();                       // everybody has found the seed before anybody edits the sets
-            for (int wd = T::tid(); wd < words; wd += T::SIZE) {
-                unsigned long long b = (wd == (seed >> 6)) ? (1ull << (seed & 63)) : 0ull;
-                frontier[wd] = b;
-                unl[wd] &= ~b;
-                next[wd] = 0;
-                next2[wd] = 0;
-            }
-            if (T::tid() == 0) labels[seed] = label;
+                adj_[(size_t)i * stride + wd] = bits;
+                if (bits) team_atomic_add(&labels_[i], __builtin_popcountll(bits));
+            PW_ROW_ITEMS_END
             T::sync();
-            // breadth-first levels, two barriers each: the members of the frontier mark their
-            // unlabelled neighbours in one of two "next" sets (the other is cleared meanwhile)
-            for (int lv = 0;; ++lv) {
-                PW_LDS unsigned long long* nx = (lv & 1) ? next2 : next;
-                PW_LDS unsigned long long* nz = (lv & 1) ? next : next2;
-                for (int i = T::tid(); i < ns; i += T::SIZE) {
-                    if ((frontier[i >> 6] >> (i & 63)) & 1ull) {
-                        for (int wd = 0; wd < words; ++wd) {
-                            unsigned long long b = adj[(size_t)i * stride + wd] & unl[wd];
-                            if (b) team_atomic_or(&nx[wd], b);
+            // core points (at least min_samples = 5 neighbours, itself included) start as their own
+            // component; the others carry "none"
+            constexpr int NONE = 0x7fffffff;
+            for (int i = T::tid(); i < ns; i += T::SIZE) {
+                const bool is_core = labels_[i] >= 5;
+                if (is_core) team_atomic_or(&core[i >> 6], 1ull << (i & 63));
+                labels_[i] = is_core ? i : NONE;
+            }
+            T::sync();
+            if (T::wave() == 0) PW_T1(ws, 11, t_db);      // adjacency rows + core points
+            PW_T0(t_bfs);
+            // Components of the core graph by minimum-label propagation, all clusters at once: a core
+            // point takes the smallest label among its core neighbours (one row word per work item, the
+            // minimum entered atomically), then jumps to the label of the point its label names.  Labels
+            // only decrease and never below the smallest index of the component, so a round in which
+            // nothing changed was a round over a constant state: every component then carries its
+            // smallest member index.  The fixed point does not depend on the order of the updates.
+            for (int round = 0;; ++round) {
+                PW_LDS int* changed = &chg[round & 1];
+                PW_ROW_ITEMS_BEGIN
+                    unsigned long long b = adj_[(size_t)i * stride + wd] & core[wd];
+                    if (b != 0 && ((core[i >> 6] >> (i & 63)) & 1ull)) {
+                        int m = NONE;
+                        while (b) {
+                            const int j = wd * 64 + __builtin_ctzll(b);
+                            b &= b - 1;
+                            const int lj = labels_[j];
+                            m = lj < m ? lj : m;
                         }
+                        if (m < labels_[i]) { team_atomic_min(&labels_[i], m); *changed = 1; }
+                    }
+                PW_ROW_ITEMS_END
+                T::sync();
+                const bool again = *changed != 0;
+                if (!again) break;
+                if (T::tid() == 0) chg[(round + 1) & 1] = 0;
+                for (int i = T::tid(); i < ns; i += T::SIZE) {
+                    const int l = labels_[i];
+                    if (l != NONE) { const int r = labels_[l]; if (r < l) labels_[i] = r; }
+                }
+                T::sync();
+            }
+            // clusters are numbered by their smallest member (sklearn visits the points in index order)
+            for (int i = T::tid(); i < ns; i += T::SIZE)
+                if (labels_[i] == i) team_atomic_or(&roots[i >> 6], 1ull << (i & 63));
+            // a border point belongs to the lowest-numbered cluster with a core point next to it
+            // (only the labels of core points are read here, only those of the others written)
+            for (int i = T::tid(); i < ns; i += T::SIZE) {
+                if ((core[i >> 6] >> (i & 63)) & 1ull) continue;
+                int m = NONE;
+                for (int wd = 0; wd < words; ++wd) {
+                    unsigned long long b = adj_[(size_t)i * stride + wd] & core[wd];
+                    while (b) {
+                        const int j = wd * 64 + __builtin_ctzll(b);
+                        b &= b - 1;
+                        const int lj = labels_[j];
+                        m = lj < m ? lj : m;
                     }
                 }
-                T::sync();
-                bool any = false;
-                for (int wd = 0; wd < words; ++wd) any = any || (nx[wd] != 0);
-                if (!any) break;
-                for (int i = T::tid(); i < ns; i += T::SIZE)
-                    if ((nx[i >> 6] >> (i & 63)) & 1ull) labels[i] = label;
-                for (int wd = T::tid(); wd < words; wd += T::SIZE) {
-                    unsigned long long u = nx[wd];
-                    unl[wd] &= ~u;
-                    frontier[wd] = u & core[wd];
-                    nz[wd] = 0;
-                }
-                T::sync();
+                labels_[i] = m;
             }
-            label += 1;
-        }
-        T::sync();
-        if (T::wave() == 0) PW_T1(ws, 23, t_bfs);     // cluster growth
+            T::sync();
+            for (int i = T::tid(); i < ns; i += T::SIZE) {
+                const int r = labels_[i];
+                int lab = -1;
+                if (r != NONE) {
+                    lab = __builtin_popcountll(roots[r >> 6] & ((1ull << (r & 63)) - 1ull));
+                    for (int wd = 0; wd < (r >> 6); ++wd) lab += __builtin_popcountll(roots[wd]);
+                }
+                labels_[i] = lab;
+            }
+            T::sync();
+            if (T::wave() == 0) PW_T1(ws, 23, t_bfs);     // clusters
+        };
+        if (have_cp && PW_IS_LDS(cp) && PW_IS_LDS(adj) && PW_IS_LDS(labels)) cluster(PW_AS_LDS(cp), PW_AS_LDS(adj), PW_AS_LDS(labels));
+        else cluster(cp, adj, labels);
+#undef PW_ROW_ITEMS_BEGIN
+#undef PW_ROW_ITEMS_END
+        int label = 0;
+        for (int wd = 0; wd < words; ++wd) label += __builtin_popcountll(roots[wd]);
         if (T::tid() == 0) {
             v.n_clusters = label;
             out->n_clusters = label;

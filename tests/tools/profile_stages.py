@@ -28,7 +28,7 @@ L.pw_debug_stage_ticks.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 L.pw_debug_stage_ticks(ctx._h, buf)   # reset
 ms = res.time_launches(1)
 L.pw_debug_stage_ticks(ctx._h, buf)
-names2 = {16:"lb.cauchy",17:"lb.formk",18:"lb.cmprlb",19:"lb.subsm",20:"lb.lnsrlb",21:"lb.matupd",22:"lb.formt",24:"eps.knn",25:"eps.sum",26:"win.pre(shift,maxdim,points)",27:"avg.pre(shift,maxdim)",28:"avg.rays",29:"avg.compact+sum",11:"dbscan.adjacency",23:"dbscan.bfs",30:"smp.rays+compact",31:"smp.paths"}
+names2 = {14:"win.pre.shift",15:"win.pre.maxdim",16:"lb.cauchy",17:"lb.formk",18:"lb.cmprlb",19:"lb.subsm",20:"lb.lnsrlb",21:"lb.matupd",22:"lb.formt",24:"eps.knn",25:"eps.sum",26:"win.pre(shift,maxdim,points)",27:"avg.pre(shift,maxdim)",28:"avg.rays",29:"avg.compact+sum",11:"dbscan.adjacency",23:"dbscan.bfs",30:"smp.rays+compact",31:"smp.paths"}
 names = ["opt.step", "opt.eval", "win.path", "win.rotate", "win.z.step", "win.z.eval", "win.brute", "win.nm", "eps", "sampling", "dbscan", "-", "windows(total)", "average"]
 t = np.array(list(buf), float)[:14] / 100.0 / 2   # two launches (warm-up + timed) -> microseconds per launch
 t2 = np.array(list(buf), float) / 100.0 / 2
