@@ -77,6 +77,9 @@ constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STA
 // window launch (256 VGPRs) can share the SIMD with it, and sharing SIMDs between the launches is
 // what the pipeline lives on.  The spills that remain are outside the hot loops (0.2 % of the
 // chains' instructions, profiles/r02_*).
+#ifndef PW_A_PRIO
+#define PW_A_PRIO 3
+#endif
 #ifndef PW_OCC
 #define PW_OCC 2
 #endif
@@ -102,7 +105,7 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
     // the optimiser chains are latency-bound and on the critical path: when one shares a SIMD
     // with a bulk wave of another launch it must win the issue arbitration
     if (role == PW_ROLE_PRODUCER) {
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(PW_A_PRIO);
         if (threadIdx.x == 0) atomicAdd(&queue->started, 1);
     }
     TeamWorkspace* ws = workspaces + blockIdx.x;

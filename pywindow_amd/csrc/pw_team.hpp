@@ -2,9 +2,9 @@
 // against.  One *team* analyses one (frame, molecule) unit.
 //
 //   * DeviceTeam<NW>: a workgroup of NW wavefronts (64 lanes each) on gfx950.
-//     Wave-level reductions are DPP/ds_swizzle-free __shfl exchanges (exact:
-//     min/max/argmin only -- no floating-point sums are ever reduced across
-//     lanes, so results do not depend on the team shape).
+//     Wave-level reductions are exact: min/max/argmin through DPP moves; the
+//     only floating-point sums that cross lanes are folded in numpy's fixed
+//     order (np_leaf_sums_t), so results do not depend on the team shape.
 //   * HostTeam: one thread; used by tests/hostsim to run the identical
 //     pipeline on a CPU without a GPU.
 #pragma once
@@ -32,6 +32,7 @@ struct HostTeam {
     PW_HD static unsigned long long ballot(bool p) { return p ? 1ull : 0ull; }
     PW_HD static bool wave_all(bool p) { return p; }
     PW_HD static bool wave_any(bool p) { return p; }
+    PW_HD static double xor_d(double v, int /*lane_mask*/) { return v; }
     PW_HD static double bcast(double v, int /*src_lane*/) { return v; }
     PW_HD static double bcast_u(double v, int /*uniform_src_lane*/) { return v; }
     PW_HD static int bcast_i(int v, int /*src_lane*/) { return v; }
@@ -136,6 +137,7 @@ struct DeviceTeam {
     __device__ static unsigned long long ballot(bool p) { return __ballot(p); }
     __device__ static bool wave_all(bool p) { return __all(p); }
     __device__ static bool wave_any(bool p) { return __any(p); }
+    __device__ static double xor_d(double v, int lane_mask) { return __shfl_xor(v, lane_mask, 64); }
     __device__ static double bcast(double v, int src) { return __shfl(v, src, 64); }
     // source lane known to be the same in every lane: v_readlane, no LDS crossbar
     __device__ static double bcast_u(double v, int src) { return lane_d(v, __builtin_amdgcn_readfirstlane(src)); }

@@ -40,6 +40,19 @@
 #define PW_T1(ws, slot, var) do {} while (0)
 #endif
 
+// unroll factors of the three bulk loops (measured: tests/tools/variant_sweep.sh)
+#define PW_PRAGMA_(x) _Pragma(#x)
+#define PW_PRAGMA(x) PW_PRAGMA_(x)
+#ifndef PW_UNROLL_GAP
+#define PW_UNROLL_GAP 2
+#endif
+#ifndef PW_UNROLL_RAY
+#define PW_UNROLL_RAY 2
+#endif
+#ifndef PW_UNROLL_KNN
+#define PW_UNROLL_KNN 2
+#endif
+
 namespace pw {
 
 constexpr double GOLDEN_ANGLE = 2.399963229728653;   // np.pi * (3 - np.sqrt(5))
@@ -115,8 +128,8 @@ struct UnitVars {
     int red_i[16];
     // ---- window search only: everything from here on is NOT allocated for the optimiser-chain
     // launch (UnitShared::bytes with nframes == 1) ----
-    // DBSCAN bitsets: core / unlabelled / frontier / next (two, used in turn) (PW_P_MAX bits each)
-    unsigned long long bits[5][PW_P_MAX / 64];
+    // DBSCAN bitsets (PW_P_MAX bits each): core points / round flags / cluster roots
+    unsigned long long bits[3][PW_P_MAX / 64];
     // sampling vector chosen for each cluster (largest 2*gap, first occurrence)
     double win_vec[PW_W_MAX][3];
     // window results by cluster
@@ -314,7 +327,7 @@ PW_HD inline void points_gap_values(const Frame& F, int n, const double* px, con
 #pragma unroll
         for (int p = 0; p < NP; ++p) m2[p] = PW_INF;
         const int hi = C.off[g + 1];
-#pragma unroll 2
+PW_PRAGMA(unroll PW_UNROLL_GAP)
         for (int i = C.off[g]; i < hi; ++i) {
             const double x = F.x[i], y = F.y[i], z = F.z[i], xx = F.xx[i];
 #pragma unroll
@@ -518,20 +531,12 @@ PW_HD inline void np_descend(int len, int e, int* off_out, int* len_out) {
     *off_out = off;
     *len_out = l;
 }
-// Leaf sums of ONE 8192-element chunk (length len) for the leaves that start in [e_lo, e_hi) --
-// whole leaves by construction: both bounds are leaf starts (or the chunk's end).  `src` holds the
-// elements from e_lo on: element e of the chunk is src[e - e_lo].  leafbuf[slot of the leaf's
-// start] receives the sum.  acc8 needs 8 doubles per 64-element slot of the range, plus one slot.
-template <class T, class SP, class IP, class DP>
-PW_HD inline __attribute__((always_inline)) void np_leaf_phase_t(SP src, int len, int e_lo, int e_hi, IP tab, DP acc8,
-                                                                 DP leafbuf) {
-    const int sl_lo = e_lo >> 6;
-    const int sl_hi = (e_hi + 63) >> 6;          // exclusive
-    const int nslot = sl_hi - sl_lo;
-    IP t_off = tab;
-    IP t_len = tab + 128;
-    for (int s_ = T::tid(); s_ < nslot; s_ += T::SIZE) {
-        const int sl = sl_lo + s_;
+// Where the leaves of ONE 8192-element chunk (length len) start: tab[slot] = start of the leaf that
+// begins in the 64-element slot (-1: none), tab[128 + slot] = its length.  No barrier inside.
+template <class T, class IP>
+PW_HD inline __attribute__((always_inline)) void np_leaf_table_t(int len, IP tab) {
+    const int nslot = (len + 63) >> 6;
+    for (int sl = T::tid(); sl < nslot; sl += T::SIZE) {
         int e = sl * 64, off, l, start = -1, ln = 0;
         np_descend(len, e, &off, &l);
         if (off == e) { start = off; ln = l; }
@@ -540,66 +545,85 @@ PW_HD inline __attribute__((always_inline)) void np_leaf_phase_t(SP src, int len
             int lim = e + 64 < len ? e + 64 : len;
             if (nxt < lim) { np_descend(len, nxt, &off, &l); start = off; ln = l; }
         }
-        if (start < e_lo || start >= e_hi) { start = -1; ln = 0; }     // a leaf of another tile
-        t_off[sl] = start;
-        t_len[sl] = ln;
+        tab[sl] = start;
+        tab[128 + sl] = ln;
     }
-    T::sync();
+}
+template <class T>
+PW_HD inline void np_leaf_table(int len, int* tab) {
+    if (PW_IS_LDS(tab)) np_leaf_table_t<T>(len, PW_AS_LDS(tab)); else np_leaf_table_t<T>(len, tab);
+}
+// Leaf sums of the chunk for the leaves that start in [e_lo, e_hi) -- whole leaves by construction:
+// both bounds are leaf starts (or the chunk's end).  `src` holds the elements from e_lo on: element e of
+// the chunk is src[e - e_lo].  leafbuf[slot of the leaf's start] receives the sum.  The table above must
+// be visible (a barrier after np_leaf_table).  The eight strided accumulators of a leaf are eight
+// adjacent lanes: each adds its (at most 16) elements in order, then the eight are folded as numpy folds
+// them -- ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), by three lane exchanges (IEEE addition commutes, so
+// every lane of the eight ends up with the same value) -- and lane 0 adds the tail.  One barrier, at the
+// end.  (acc8 is only used by the one-thread host build, which has no lanes to exchange with.)
+template <class T, class SP, class IP, class DP>
+PW_HD inline __attribute__((always_inline)) void np_leaf_sums_t(SP src, int len, int e_lo, int e_hi, IP tab, DP acc8,
+                                                                DP leafbuf) {
+    (void)len;
+    const int sl_lo = e_lo >> 6;
+    const int sl_hi = (e_hi + 63) >> 6;          // exclusive
+    const int nslot = sl_hi - sl_lo;
     for (int task = T::tid(); task < nslot * 8; task += T::SIZE) {
-        int sl = sl_lo + (task >> 3), c = task & 7;
-        int start = t_off[sl];
-        if (start < 0) continue;
+        const int sl = sl_lo + (task >> 3), c = task & 7;
+        const int start = tab[sl];
+        if (start < e_lo || start >= e_hi) continue;                  // no leaf here, or a leaf of another tile
         SP b = src + (start - e_lo);
-        int ln = t_len[sl];
+        const int ln = tab[128 + sl];
         if (ln < 8) {
             if (c == 0) {
                 double r = 0.0;
                 for (int i = 0; i < ln; ++i) r = r + b[i];
-                acc8[task] = r;
+                leafbuf[sl] = r;
             }
-        } else {
-            // a leaf has at most 128 elements, i.e. at most 16 per accumulator: all loads first
-            // (they are independent), then the additions in order
-            int lim = ln - (ln % 8);
-            double vv[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                int i = c + 8 * u;
-                vv[u] = b[i < lim ? i : c];
-            }
-            double r = vv[0];
-#pragma unroll
-            for (int u = 1; u < 16; ++u)
-                if (c + 8 * u < lim) r = r + vv[u];
-            acc8[task] = r;
+            continue;
         }
-    }
-    T::sync();
-    for (int s_ = T::tid(); s_ < nslot; s_ += T::SIZE) {
-        const int sl = sl_lo + s_;
-        int start = t_off[sl];
-        if (start < 0) continue;
-        SP b = src + (start - e_lo);
-        int ln = t_len[sl];
-        DP r = acc8 + 8 * s_;
+        // a leaf has at most 128 elements, i.e. at most 16 per accumulator: all loads first
+        // (they are independent), then the additions in order
+        const int lim = ln - (ln % 8);
+        double vv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            int i = c + 8 * u;
+            vv[u] = b[i < lim ? i : c];
+        }
+        double r = vv[0];
+#pragma unroll
+        for (int u = 1; u < 16; ++u)
+            if (c + 8 * u < lim) r = r + vv[u];
         double res;
-        if (ln < 8) {
-            res = r[0];
+        if (T::SIZE >= 8) {
+            r = r + T::xor_d(r, 1);
+            r = r + T::xor_d(r, 2);
+            res = r + T::xor_d(r, 4);
         } else {
-            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-            for (int i = ln - (ln % 8); i < ln; ++i) res = res + b[i];
+            // one thread plays the eight accumulators in turn
+            acc8[c] = r;
+            if (c != 7) continue;
+            res = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
         }
-        leafbuf[sl] = res;
+        if (T::SIZE < 8 || c == 0) {
+            for (int i = lim; i < ln; ++i) res = res + b[i];
+            leafbuf[sl] = res;
+        }
     }
     T::sync();
 }
 template <class T>
 PW_HD inline void np_leaf_phase(const double* src, int len, int e_lo, int e_hi, int* tab, double* acc8,
-                                double* leafbuf) {
+                                double* leafbuf, bool table_ready = false) {
+    if (!table_ready) {
+        np_leaf_table<T>(len, tab);
+        T::sync();
+    }
     if (PW_IS_LDS(src) && PW_IS_LDS(tab) && PW_IS_LDS(acc8) && PW_IS_LDS(leafbuf))
-        np_leaf_phase_t<T>(PW_AS_LDS(src), len, e_lo, e_hi, PW_AS_LDS(tab), PW_AS_LDS(acc8), PW_AS_LDS(leafbuf));
+        np_leaf_sums_t<T>(PW_AS_LDS(src), len, e_lo, e_hi, PW_AS_LDS(tab), PW_AS_LDS(acc8), PW_AS_LDS(leafbuf));
     else
-        np_leaf_phase_t<T>(src, len, e_lo, e_hi, tab, acc8, leafbuf);
+        np_leaf_sums_t<T>(src, len, e_lo, e_hi, tab, acc8, leafbuf);
 }
 // Combine the leaf sums of one chunk as numpy's recursion does: every inner node is (sum of its left
 // part) + (sum of its right part), whatever order the nodes are visited in -- so the tree is folded
@@ -613,22 +637,26 @@ template <class T, class DP>
 PW_HD inline __attribute__((always_inline)) double np_walk_phase_t(int len, DP acc8, DP leafbuf) {
     int depth = 0;
     for (int l = len; l > 128; ++depth) { int n2 = l / 2; n2 -= n2 % 8; l -= n2; }
-    for (int d = depth; d >= 0; --d) {
-        DP mine = (d & 1) ? leafbuf + 128 : acc8;
-        DP below = (d & 1) ? acc8 : leafbuf + 128;
-        for (int t = T::tid(); t < (1 << d); t += T::SIZE) {
-            int off = 0, l = len;
-            bool exists = true;
-            for (int k = d - 1; k >= 0; --k) {
-                if (l <= 128) { exists = false; break; }
-                int n2 = l / 2;
-                n2 -= n2 % 8;
-                if ((t >> k) & 1) { off += n2; l -= n2; } else { l = n2; }
+    // (one wave: its lanes see each other's LDS writes without a team barrier)
+    if (T::wave() == 0) {
+        for (int d = depth; d >= 0; --d) {
+            DP mine = (d & 1) ? leafbuf + 128 : acc8;
+            DP below = (d & 1) ? acc8 : leafbuf + 128;
+            for (int t = T::lane(); t < (1 << d); t += T::WSIZE) {
+                int off = 0, l = len;
+                bool exists = true;
+                for (int k = d - 1; k >= 0; --k) {
+                    if (l <= 128) { exists = false; break; }
+                    int n2 = l / 2;
+                    n2 -= n2 % 8;
+                    if ((t >> k) & 1) { off += n2; l -= n2; } else { l = n2; }
+                }
+                if (exists) mine[t] = l <= 128 ? leafbuf[off >> 6] : below[2 * t] + below[2 * t + 1];
             }
-            if (exists) mine[t] = l <= 128 ? leafbuf[off >> 6] : below[2 * t] + below[2 * t + 1];
+            T::wave_sync();
         }
-        T::sync();
     }
+    T::sync();
     return acc8[0];
 }
 template <class T>
@@ -802,7 +830,7 @@ PW_HD inline __attribute__((always_inline)) void ray_scan_multi_impl(const Frame
             for (int r = 0; r < NR; ++r) mh[r] = 0u;
             const int base = blk + half;
             const int jend = n - base < 32 ? n - base : 32;
-#pragma unroll 2
+PW_PRAGMA(unroll PW_UNROLL_RAY)
             for (int j = 0; j < jend; ++j) {
                 int i = base + j;
                 double rx = F.x[i] - c0, ry = F.y[i] - c1, rz = F.z[i] - c2;
@@ -1025,8 +1053,10 @@ PW_HD inline void make_shifted(UnitShared& sh, int n, double cx, double cy, doub
     T::sync();
 }
 
-// max_dim over frame F (utilities.py:355-372); result in sh.v->maxd*, all threads.
-template <class T>
+// max_dim over frame F (utilities.py:355-372); result in sh.v->maxd*, all threads.  VALUE_ONLY: the
+// callers that only want the diameter of the shifted molecule (the radius of the sampling sphere)
+// skip the second pass; maxd_i / maxd_j are then not touched.
+template <class T, bool VALUE_ONLY = false>
 PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& sh, const Frame& F, int n,
                                                                    double* item_best = nullptr) {
     // max over pairs (diagonal included) of d_ij + (vdw_i + vdw_j), first maximum in row-major
@@ -1101,7 +1131,7 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
                 }
             }
             best = pw_max(best, ibest);
-            if (item_best) item_best[t] = ibest;
+            if (!VALUE_ONLY && item_best) item_best[t] = ibest;
         }
     }
     // team maximum of the values
@@ -1111,6 +1141,11 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
     double vmax = sh.v->red_v[0];
     for (int w = 1; w < T::NWAVES; ++w) vmax = pw_max(vmax, sh.v->red_v[w]);
     T::sync();
+    if (VALUE_ONLY && ngrp > 0) {
+        if (T::tid() == 0) sh.v->maxd = vmax;
+        T::sync();
+        return;
+    }
     // pass 2: smallest row-major index among the pairs that reach vmax
     double bidx = PW_INF;
     if (ngrp > 0) {
@@ -1218,9 +1253,9 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
     T::sync();
 }
 
-template <class T>
+template <class T, bool VALUE_ONLY = false>
 PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n, double* item_best = nullptr) {
-    team_max_dim_impl<T>(sh, F, n, item_best);
+    team_max_dim_impl<T, VALUE_ONLY>(sh, F, n, item_best);
 }
 
 // ---- stage: basic -------------------------------------------------------------------------
@@ -1422,7 +1457,7 @@ PW_HD inline __attribute__((always_inline)) void stage_average_impl(UnitShared& 
     T::sync();
     {
         double* ib = 2 * n <= PW_P_MAX ? ws->vals : nullptr;     // per-item maxima (free until the rays)
-        if (INL) team_max_dim_impl<T>(sh, sh.S, n, ib); else team_max_dim<T>(sh, sh.S, n, ib);
+        if (INL) team_max_dim_impl<T, true>(sh, sh.S, n, ib); else team_max_dim<T, true>(sh, sh.S, n, ib);
     }
     double radius = v.maxd;
     T::sync();
@@ -1869,7 +1904,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     T::sync();
     if (T::wave() == 0) PW_T1(ws, 14, t_pre);
     PW_T0(t_md);
-    team_max_dim<T>(sh, sh.S, n, 2 * n <= PW_P_MAX ? ws->vals : nullptr);
+    team_max_dim<T, true>(sh, sh.S, n, 2 * n <= PW_P_MAX ? ws->vals : nullptr);
     double radius = v.maxd / 2.0;
     T::sync();
     if (T::wave() == 0) PW_T1(ws, 15, t_md);
@@ -1989,7 +2024,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                     double thr[NK];
 #pragma unroll
                     for (int p = 0; p < NK; ++p) thr[p] = tau;
-#pragma unroll 2
+PW_PRAGMA(unroll PW_UNROLL_KNN)
                     for (int tt = t_lo; tt <= t_hi; ++tt) {
                         const int j = k0 + tt;
                         if (j < lo || j > hi) continue;
@@ -2053,6 +2088,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             bool first = true;
             for (int s0 = 0; s0 < n_el; s0 += 8192) {
                 const int len = n_el - s0 < 8192 ? n_el - s0 : 8192;
+                np_leaf_table<T>(len, s_tab);           // (visible after the barrier behind the first tile's fill)
                 int lo = 0;
                 while (lo < len) {
                     // the tile ends at the start of the leaf that holds element lo + tile_cap (leaf starts
@@ -2074,7 +2110,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                     };
                     if (PW_IS_LDS(tile)) fill(PW_AS_LDS(tile)); else fill(tile);
                     T::sync();
-                    np_leaf_phase<T>(tile, len, lo, hi, s_tab, s_acc, s_leaf);
+                    np_leaf_phase<T>(tile, len, lo, hi, s_tab, s_acc, s_leaf, true);
                     lo = hi;
                 }
                 double part = np_walk_phase<T>(len, s_tab, s_acc, s_leaf);
@@ -2251,7 +2287,6 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         const int words = (ns + 63) / 64;
         double e2 = v.eps * v.eps;
         PW_LDS unsigned long long* core = v.bits[0];
-        PW_LDS unsigned long long* frontier = v.bits[2];
         // adjacency rows live in LDS (the window frames are idle now) when they fit
         unsigned long long* adj = (unsigned long long*)arena.take((size_t)ns * (size_t)words * 8);
         int stride = words;
@@ -2261,7 +2296,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             T::sync();
             return;
         }
-        PW_LDS unsigned long long* roots = frontier;
+        PW_LDS unsigned long long* roots = v.bits[2];
         for (int wd = T::tid(); wd < words; wd += T::SIZE) { core[wd] = 0; roots[wd] = 0; }
         PW_LDS int* chg = (PW_LDS int*)v.bits[1];      // "something changed" flags of the rounds below, used in turn
         if (T::tid() == 0) { chg[0] = 0; chg[1] = 0; }
