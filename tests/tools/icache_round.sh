@@ -1,5 +1,6 @@
 #!/bin/bash
-# Instruction-cache and wait counters of the three launches (one analysis at a time), separate --pmc passes.
+# Instruction-cache and wait counters of the three launches (one analysis at a time), separate --pmc passes
+# (PW_PMC_SETS="A B;C D" replaces the default counter sets).
 #   tests/tools/icache_round.sh <tag>   -> gpurun_out/<tag>/pmc_icache*.csv
 tag=${1:-ic}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
@@ -8,7 +9,9 @@ mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 T=$R/tests/tools
 i=0
-for set in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS"; do
+SETS=("SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS")
+if [ -n "$PW_PMC_SETS" ]; then IFS=';' read -ra SETS <<< "$PW_PMC_SETS"; fi
+for set in "${SETS[@]}"; do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $set -d $O/p$i -o p$i --output-format csv -- python3 $T/run_stage.py 15 1000 4 > $O/p$i.log 2>&1
   cp $(find $O/p$i -name "*counter_collection.csv" | head -1) $O/pmc_icache_$i.csv
