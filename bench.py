@@ -403,6 +403,15 @@ def main():
     _, frames = synth.synthetic_units(args.frames, first=rank * args.frames)
     res = ctx.upload(_lib.Batch.uniform(frames, vdw, mass))
     gather = StepGather(res, args.frames) if dist is not None else None
+    if gather is not None:
+        # set-up, like creating the process group: RCCL finishes building its channels during the first
+        # collectives of a communicator (measured: the first ~20 all-gathers cost up to 6 % of a 25-step
+        # run, after that the gather is free) -- so the communicator is exercised before the W warm-up
+        # steps, on the buffers the steps use, without any analysis launch in between
+        res.launch()
+        for _ in range(20):
+            gather()
+        barrier(res)
     elapsed = timed(res, args.steps, args.warmup, gather)
     out = res.download()
     ok = bool((out["status"] == 0).all())
