@@ -443,7 +443,7 @@ def main():
         ms_step = 1e3 * elapsed / args.steps
         value = world * args.frames * args.steps / elapsed
         # kernel duration measured with HIP events on the launch stream
-        k_ms = res.time_launches(max(3, min(args.steps, 10)))
+        k_ms = res.time_launches(max(3, args.steps))
         # one launch on its own (no overlap with a neighbour): the latency of a single batch
         lat = []
         for _ in range(5):
