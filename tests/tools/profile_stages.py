@@ -7,7 +7,7 @@ csrc = ROOT / "pywindow_amd" / "csrc"
 so = ROOT / "tests" / "tools" / "libpw_prof.so"
 so.parent.mkdir(exist_ok=True)
 if "--build" in sys.argv:
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-DPW_PROFILE", "-c", str(csrc / "pw_kernels.hip"), "-o", "/tmp/pwk_prof.o"])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-DPW_PROFILE", *[a for a in sys.argv if a.startswith("-D")], "-c", str(csrc / "pw_kernels.hip"), "-o", "/tmp/pwk_prof.o"])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c", str(csrc / "pw_rebuild.hip"), "-o", "/tmp/pwr_prof.o"])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c", str(csrc / "pw_shape.hip"), "-o", "/tmp/pws_prof.o"])
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-c", str(csrc / "pw_history.cpp"), "-o", "/tmp/pwh_prof.o"])
