@@ -159,6 +159,12 @@ int pw_analysis_debug(pw_context *ctx, const pw_batch_in *in, uint32_t stages, p
 int pw_point_gaps(pw_context *ctx, const pw_batch_in *in, const int64_t *unit_of_point,
                   const double *points, int64_t n_points, double *gap, int32_t *argmin);
 
+/* Fine-grained: numpy's float64 add.reduce over a contiguous array (pairwise blocks of <= 128 with eight
+ * accumulators, 8192-element buffers) as one team computes it -- the order behind np.mean / np.sum in
+ * utilities.py:1434 (mean of the k-NN distances) and :1650 (mean of the ray exits).  mode bit 0: a
+ * one-wave team instead of four waves; bit 1: the team's scratch in global memory instead of LDS. */
+int pw_pairwise_sum(pw_context *ctx, const double *values, int64_t n, int mode, double *sum);
+
 /* Resident path (inputs stay in HBM between launches; used by bench.py and the
  * trajectory driver when several analyses run on the same frames). */
 int pw_resident_upload(pw_context *ctx, const pw_batch_in *in, pw_resident **res);

@@ -204,6 +204,7 @@ EXPORTED_SYMBOLS = [
     "pw_analysis_batch",
     "pw_analysis_debug",
     "pw_point_gaps",
+    "pw_pairwise_sum",
     "pw_resident_upload",
     "pw_resident_launch",
     "pw_resident_sync",
@@ -292,6 +293,7 @@ def load():
     L.pw_analysis_batch.argtypes = [vp, ctypes.POINTER(BatchIn), ctypes.c_uint32, vp]
     L.pw_analysis_debug.argtypes = [vp, ctypes.POINTER(BatchIn), ctypes.c_uint32, vp, vp]
     L.pw_point_gaps.argtypes = [vp, ctypes.POINTER(BatchIn), vp, vp, ctypes.c_int64, vp, vp]
+    L.pw_pairwise_sum.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int, vp]
     L.pw_resident_upload.argtypes = [vp, ctypes.POINTER(BatchIn), ctypes.POINTER(vp)]
     L.pw_resident_launch.argtypes = [vp, vp, ctypes.c_uint32]
     L.pw_resident_sync.argtypes = [vp]
@@ -445,6 +447,14 @@ class Context:
             "pw_point_gaps",
         )
         return gap, arg
+
+    def pairwise_sum(self, values, one_wave: bool = False, global_scratch: bool = False) -> float:
+        """``np.add.reduce`` of a float64 array in numpy's order, computed by one team on the GPU."""
+        a = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        out = ctypes.c_double(0.0)
+        _check(load().pw_pairwise_sum(self._h, a.ctypes.data, len(a), int(one_wave) | (int(global_scratch) << 1),
+                                      ctypes.byref(out)), "pw_pairwise_sum")
+        return out.value
 
     def shape(self, batch: Batch) -> np.ndarray:
         """``pw_shape_batch``: gyration / inertia tensors, sorted eigenvalues and the three shape

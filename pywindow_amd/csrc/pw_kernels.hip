@@ -202,6 +202,24 @@ __global__ void pw_head_gate_kernel(const UnitQueue* prev, unsigned long long ne
 // Fine-grained entry: min_i(|r_i - p| - vdw_i) and its first argmin for arbitrary
 // points p (reference pore_diameter(elements, coordinates, com=p)/2,
 // utilities.py:375-388).  One lane per point, atoms streamed from global memory.
+// numpy's float64 add.reduce of one array by one team (pw_pairwise_sum): the team-shared scratch of the
+// sum either in LDS or -- mode bit 1 -- in global memory (the fallback of molecules too large for LDS)
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) pw_pairwise_sum_kernel(const double* __restrict__ a, long n,
+                                                                   double* __restrict__ scratch, int use_global,
+                                                                   double* __restrict__ out) {
+    using T = DeviceTeam<NW>;
+    __shared__ int s_tab[324];
+    __shared__ double s_acc[8 * 160];
+    __shared__ double s_leaf[256];
+    __shared__ double s_slot;
+    int* tab = use_global ? (int*)(scratch + 8 * 160 + 256) : (int*)s_tab;
+    double* acc = use_global ? scratch : (double*)s_acc;
+    double* leaf = use_global ? scratch + 8 * 160 : (double*)s_leaf;
+    double r = np_sum_team<T>(a, (int)n, tab, acc, leaf, (double*)&s_slot);
+    if (threadIdx.x == 0) *out = r;
+}
+
 __global__ void pw_point_gap_kernel(long n_points, const long* __restrict__ unit_of_point,
                                     const double* __restrict__ points,
                                     const long* __restrict__ atom_offset,
@@ -1183,6 +1201,39 @@ int pw_point_gaps(pw_context* c, const pw_batch_in* in, const int64_t* unit_of_p
     PG_TRY(hipMemcpyAsync(argmin, d_a, sizeof(int) * n_points, hipMemcpyDeviceToHost, c->stream));
     PG_TRY(hipStreamSynchronize(c->stream));
 #undef PG_TRY
+    cleanup();
+    return PW_OK;
+}
+
+int pw_pairwise_sum(pw_context* c, const double* values, int64_t n, int mode, double* sum) {
+    if (!c || !sum || n < 0 || n > 0x7fffffff || (n > 0 && !values)) return PW_E_BAD_ARG;
+    PW_ON_DEVICE(c->device);
+    double *d_a = nullptr, *d_s = nullptr;
+    auto cleanup = [&]() {
+        if (d_a) (void)hipFree(d_a);
+        if (d_s) (void)hipFree(d_s);
+    };
+#define PS_TRY(call)                                   \
+    do {                                               \
+        hipError_t e_ = (call);                        \
+        if (e_ != hipSuccess) {                        \
+            set_err(#call, e_);                        \
+            cleanup();                                 \
+            return PW_E_HIP;                           \
+        }                                              \
+    } while (0)
+    const size_t scratch_doubles = 8 * 160 + 256 + 324 / 2 + 2;
+    PS_TRY(hipMalloc((void**)&d_a, sizeof(double) * (size_t)(n > 0 ? n : 1)));
+    PS_TRY(hipMalloc((void**)&d_s, sizeof(double) * scratch_doubles));
+    if (n > 0) PS_TRY(hipMemcpyAsync(d_a, values, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if (mode & 1)
+        hipLaunchKernelGGL(pw_pairwise_sum_kernel<1>, dim3(1), dim3(64), 0, c->stream, d_a, (long)n, d_s + 1, (mode >> 1) & 1, d_s);
+    else
+        hipLaunchKernelGGL(pw_pairwise_sum_kernel<4>, dim3(1), dim3(256), 0, c->stream, d_a, (long)n, d_s + 1, (mode >> 1) & 1, d_s);
+    PS_TRY(hipGetLastError());
+    PS_TRY(hipMemcpyAsync(sum, d_s, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PS_TRY(hipStreamSynchronize(c->stream));
+#undef PS_TRY
     cleanup();
     return PW_OK;
 }

@@ -64,6 +64,15 @@ static int run_batch(long n_units, const long* off, const double* xyz, const dou
     return 0;
 }
 extern "C" int hs_sizeof_unit_out() { return (int)sizeof(pw_unit_out); }
+// numpy's add.reduce order as the one-thread team computes it (the same source as pw_pairwise_sum)
+extern "C" double hs_pairwise_sum(const double* a, long n) {
+    static int tab[324];
+    static double acc[8 * 160], leaf[256];
+    double slot = 0.0;
+    return np_sum_team<HostTeam>(a, (int)n, tab, acc, leaf, &slot);
+}
+// ... and the serial restatement it replaced in round 1 (np_sum_serial), kept as a cross-check
+extern "C" double hs_pairwise_sum_serial(const double* a, long n) { return np_sum_serial(a, (int)n); }
 extern "C" long hs_lds_bytes(int nmax) { return (long)UnitShared::bytes(nmax, 1, 1); }
 extern "C" long hs_lds_offset(int nmax, int what) {
     // byte offsets of the parts of the team-shared block (for the poison tests)
