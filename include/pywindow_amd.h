@@ -159,6 +159,14 @@ int pw_analysis_debug(pw_context *ctx, const pw_batch_in *in, uint32_t stages, p
 int pw_point_gaps(pw_context *ctx, const pw_batch_in *in, const int64_t *unit_of_point,
                   const double *points, int64_t n_points, double *gap, int32_t *argmin);
 
+/* Fine-grained: sklearn.cluster.DBSCAN(eps, min_samples=5).fit(points).labels_ as find_windows calls it
+ * (utilities.py:1478-1487; sklearn/cluster/_dbscan_inner.pyx): clusters numbered in the order of their
+ * smallest member, border points with the lowest-numbered adjacent cluster, noise -1.  n <= PW_P_MAX points
+ * (n x 3, row-major).  mode bit 0: a one-wave team instead of four waves; bit 1: every array of the routine
+ * in global memory instead of LDS. */
+int pw_dbscan(pw_context *ctx, const double *points, int64_t n, double eps, int mode, int32_t *labels,
+              int32_t *n_clusters);
+
 /* Fine-grained: numpy's float64 add.reduce over a contiguous array (pairwise blocks of <= 128 with eight
  * accumulators, 8192-element buffers) as one team computes it -- the order behind np.mean / np.sum in
  * utilities.py:1434 (mean of the k-NN distances) and :1650 (mean of the ray exits).  mode bit 0: a

@@ -205,6 +205,7 @@ EXPORTED_SYMBOLS = [
     "pw_analysis_debug",
     "pw_point_gaps",
     "pw_pairwise_sum",
+    "pw_dbscan",
     "pw_resident_upload",
     "pw_resident_launch",
     "pw_resident_sync",
@@ -294,6 +295,7 @@ def load():
     L.pw_analysis_debug.argtypes = [vp, ctypes.POINTER(BatchIn), ctypes.c_uint32, vp, vp]
     L.pw_point_gaps.argtypes = [vp, ctypes.POINTER(BatchIn), vp, vp, ctypes.c_int64, vp, vp]
     L.pw_pairwise_sum.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int, vp]
+    L.pw_dbscan.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, vp, vp]
     L.pw_resident_upload.argtypes = [vp, ctypes.POINTER(BatchIn), ctypes.POINTER(vp)]
     L.pw_resident_launch.argtypes = [vp, vp, ctypes.c_uint32]
     L.pw_resident_sync.argtypes = [vp]
@@ -447,6 +449,15 @@ class Context:
             "pw_point_gaps",
         )
         return gap, arg
+
+    def dbscan(self, points, eps: float, one_wave: bool = False, global_memory: bool = False):
+        """``DBSCAN(eps, min_samples=5).fit(points).labels_`` by one team on the GPU -> (labels, n_clusters)."""
+        p = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        labels = np.zeros(len(p), dtype=np.int32)
+        k = ctypes.c_int32(0)
+        _check(load().pw_dbscan(self._h, p.ctypes.data, len(p), float(eps), int(one_wave) | (int(global_memory) << 1),
+                                labels.ctypes.data, ctypes.byref(k)), "pw_dbscan")
+        return labels, k.value
 
     def pairwise_sum(self, values, one_wave: bool = False, global_scratch: bool = False) -> float:
         """``np.add.reduce`` of a float64 array in numpy's order, computed by one team on the GPU."""

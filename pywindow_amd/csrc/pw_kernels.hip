@@ -21,6 +21,7 @@
 
 #include "../../include/pywindow_amd.h"
 #include "pw_host.hpp"
+#include <vector>
 #include "pw_unit.hpp"
 
 using namespace pw;
@@ -202,6 +203,32 @@ __global__ void pw_head_gate_kernel(const UnitQueue* prev, unsigned long long ne
 // Fine-grained entry: min_i(|r_i - p| - vdw_i) and its first argmin for arbitrary
 // points p (reference pore_diameter(elements, coordinates, com=p)/2,
 // utilities.py:375-388).  One lane per point, atoms streamed from global memory.
+// DBSCAN(eps, min_samples = 5) of one point set by one team (pw_dbscan): the routine of the window search on
+// its own.  pts: three arrays of n (x | y | z).  lds_bytes > 0: adjacency rows, compacted points and labels
+// in that much dynamic LDS when they fit (what the pipeline does for CC3); 0: everything in global memory.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) pw_dbscan_kernel(const double* __restrict__ pts, int n, double eps,
+                                                            int lds_bytes, TeamWorkspace* ws,
+                                                            unsigned long long* adj_base, const int* __restrict__ ident,
+                                                            int* __restrict__ labels, int* __restrict__ n_clusters) {
+    using T = DeviceTeam<NW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ unsigned long long bits[3][PW_P_MAX / 64];
+    if (threadIdx.x == 0) ws->adj = adj_base;
+    __syncthreads();
+    ScratchArena arena;
+    arena.cur = (unsigned char*)lds;
+    arena.left = (size_t)lds_bytes;
+    int* lab = (int*)arena.take((size_t)n * 4);
+    if (!lab) lab = labels;
+    auto PT = [n](int k, int c) { return c * n + k; };
+    int k = team_dbscan<T>((PW_LDS unsigned long long*)bits[0], (PW_LDS unsigned long long*)bits[1],
+                           (PW_LDS unsigned long long*)bits[2], arena, ws, pts, PT, ident, n, eps, lab);
+    if (lab != labels)
+        for (int i = threadIdx.x; i < n; i += NW * 64) labels[i] = lab[i];
+    if (threadIdx.x == 0) *n_clusters = k;
+}
+
 // numpy's float64 add.reduce of one array by one team (pw_pairwise_sum): the team-shared scratch of the
 // sum either in LDS or -- mode bit 1 -- in global memory (the fallback of molecules too large for LDS)
 template <int NW>
@@ -1201,6 +1228,64 @@ int pw_point_gaps(pw_context* c, const pw_batch_in* in, const int64_t* unit_of_p
     PG_TRY(hipMemcpyAsync(argmin, d_a, sizeof(int) * n_points, hipMemcpyDeviceToHost, c->stream));
     PG_TRY(hipStreamSynchronize(c->stream));
 #undef PG_TRY
+    cleanup();
+    return PW_OK;
+}
+
+int pw_dbscan(pw_context* c, const double* points, int64_t n, double eps, int mode, int32_t* labels,
+              int32_t* n_clusters) {
+    if (!c || !labels || !n_clusters || n < 0 || n > PW_P_MAX || (n > 0 && !points)) return PW_E_BAD_ARG;
+    *n_clusters = 0;
+    if (n == 0) return PW_OK;
+    PW_ON_DEVICE(c->device);
+    double* d_p = nullptr;
+    int *d_i = nullptr, *d_l = nullptr;
+    TeamWorkspace* d_ws = nullptr;
+    unsigned long long* d_adj = nullptr;
+    auto cleanup = [&]() {
+        if (d_p) (void)hipFree(d_p);
+        if (d_i) (void)hipFree(d_i);
+        if (d_l) (void)hipFree(d_l);
+        if (d_ws) (void)hipFree(d_ws);
+        if (d_adj) (void)hipFree(d_adj);
+    };
+#define DB_TRY(call)                                   \
+    do {                                               \
+        hipError_t e_ = (call);                        \
+        if (e_ != hipSuccess) {                        \
+            set_err(#call, e_);                        \
+            cleanup();                                 \
+            return PW_E_HIP;                           \
+        }                                              \
+    } while (0)
+    std::vector<double> soa((size_t)3 * n);
+    std::vector<int> ident((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) soa[(size_t)k * n + i] = points[3 * i + k];
+        ident[i] = (int)i;
+    }
+    DB_TRY(hipMalloc((void**)&d_p, sizeof(double) * 3 * n));
+    DB_TRY(hipMalloc((void**)&d_i, sizeof(int) * n));
+    DB_TRY(hipMalloc((void**)&d_l, sizeof(int) * (n + 1)));
+    DB_TRY(hipMalloc((void**)&d_ws, sizeof(TeamWorkspace)));
+    DB_TRY(hipMalloc((void**)&d_adj, sizeof(unsigned long long) * PW_ADJ_WORDS));
+    DB_TRY(hipMemcpyAsync(d_p, soa.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    DB_TRY(hipMemcpyAsync(d_i, ident.data(), sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    const int lds_bytes = (mode & 2) ? 0 : 96 * 1024;
+    if (mode & 1) {
+        DB_TRY(hipFuncSetAttribute((const void*)pw_dbscan_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        hipLaunchKernelGGL(pw_dbscan_kernel<1>, dim3(1), dim3(64), lds_bytes, c->stream, d_p, (int)n, eps, lds_bytes, d_ws,
+                           d_adj, d_i, d_l, d_l + n);
+    } else {
+        DB_TRY(hipFuncSetAttribute((const void*)pw_dbscan_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        hipLaunchKernelGGL(pw_dbscan_kernel<4>, dim3(1), dim3(256), lds_bytes, c->stream, d_p, (int)n, eps, lds_bytes, d_ws,
+                           d_adj, d_i, d_l, d_l + n);
+    }
+    DB_TRY(hipGetLastError());
+    DB_TRY(hipMemcpyAsync(labels, d_l, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+    DB_TRY(hipMemcpyAsync(n_clusters, d_l + n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    DB_TRY(hipStreamSynchronize(c->stream));
+#undef DB_TRY
     cleanup();
     return PW_OK;
 }

@@ -1881,6 +1881,170 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     }
 }
 
+// ---- DBSCAN(eps, min_samples = 5) (sklearn.cluster.DBSCAN as find_windows calls it, utilities.py:1478-1487)
+// on points pts[PT(surv_k[i], c)], i < ns: labels[i] = sklearn's label.  sklearn (_dbscan_inner.pyx): core
+// points = connected components of the eps-graph numbered by their smallest member index; a border point
+// takes the label of the first (lowest-numbered) cluster with a core point next to it.  Both are
+// independent of the traversal order, so all clusters are found at once.  core / flags / roots: three
+// team-shared bit sets of at least ns bits; adjacency rows in the arena (LDS) when they fit, else in the
+// team's global workspace.  Returns the number of clusters (every thread), -1 if the rows fit nowhere.
+template <class T, class PTF>
+PW_HD inline __attribute__((always_inline)) int team_dbscan(PW_LDS unsigned long long* core, PW_LDS unsigned long long* flags,
+                                                            PW_LDS unsigned long long* roots, ScratchArena arena,
+                                                            TeamWorkspace* ws, const double* pts, PTF PT, const int* surv_k,
+                                                            int ns, double eps, int* labels) {
+    PW_T0(t_adj);
+    const int words = (ns + 63) / 64;
+    const double e2 = eps * eps;
+    // adjacency rows live in LDS (the window frames are idle now) when they fit
+    unsigned long long* adj = (unsigned long long*)arena.take((size_t)ns * (size_t)words * 8);
+    int stride = words;
+    if (!adj) { adj = ws->adj; stride = PW_P_MAX / 64; }
+    if (adj == nullptr) return -1;   // launch without a global adjacency buffer and LDS too small
+    for (int wd = T::tid(); wd < words; wd += T::SIZE) { core[wd] = 0; roots[wd] = 0; }
+    PW_LDS int* chg = (PW_LDS int*)flags;          // "something changed" flags of the rounds below, used in turn
+    if (T::tid() == 0) { chg[0] = 0; chg[1] = 0; }
+    // the survivors' end points, compacted: the threads of a wave then read the same point at the
+    // same time (broadcast) and eight of them are fetched ahead of the arithmetic
+    double* cp = (double*)arena.take((size_t)ns * 24);
+    for (int i = T::tid(); i < ns; i += T::SIZE) {
+        labels[i] = 0;                  // (counts the neighbours first)
+        if (cp) {
+            const int pik = surv_k[i];
+            cp[3 * i] = pts[PT(pik, 0)]; cp[3 * i + 1] = pts[PT(pik, 1)]; cp[3 * i + 2] = pts[PT(pik, 2)];
+        }
+    }
+    T::sync();
+    // Work items are (point, 64-bit word of its adjacency row), dealt point-major: the number of
+    // survivors is rarely a multiple of the team size (CC3: 250-270 against 256 threads), and a
+    // second round of whole rows for a handful of points would cost as much as the first.
+#define PW_ROW_ITEMS_BEGIN                                                                   \
+    {                                                                                    \
+        int i = T::tid(), wd = 0;                                                        \
+        while (i >= ns && wd < words) { i -= ns; ++wd; }                                 \
+        while (wd < words) {
+#define PW_ROW_ITEMS_END                                                                     \
+            i += T::SIZE;                                                                \
+            while (i >= ns && wd < words) { i -= ns; ++wd; }                             \
+        }                                                                                \
+    }
+    const bool have_cp = cp != nullptr;
+    auto cluster = [&](auto cp_, auto adj_, auto labels_) __attribute__((always_inline)) {
+        PW_ROW_ITEMS_BEGIN
+            double px, py, pz;
+            if (have_cp) { px = cp_[3 * i]; py = cp_[3 * i + 1]; pz = cp_[3 * i + 2]; }
+            else { const int pik = surv_k[i]; px = pts[PT(pik, 0)]; py = pts[PT(pik, 1)]; pz = pts[PT(pik, 2)]; }
+            unsigned long long bits = 0;
+            const int jend = (wd * 64 + 64 < ns) ? wd * 64 + 64 : ns;
+            int j = wd * 64;
+            if (have_cp) {
+                for (; j + 8 <= jend; j += 8) {
+                    double qx[8], qy[8], qz[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) { qx[t] = cp_[3 * (j + t)]; qy[t] = cp_[3 * (j + t) + 1]; qz[t] = cp_[3 * (j + t) + 2]; }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        double ax = px - qx[t], ay = py - qy[t], az = pz - qz[t];
+                        double d = ax * ax;      // (0.0 + ax * ax is ax * ax exactly)
+                        d = d + ay * ay; d = d + az * az;
+                        if (d <= e2) bits |= 1ull << (j + t - wd * 64);
+                    }
+                }
+            }
+            for (; j < jend; ++j) {
+                const int pjk = surv_k[j];
+                double ax = px - pts[PT(pjk, 0)], ay = py - pts[PT(pjk, 1)], az = pz - pts[PT(pjk, 2)];
+                double d = ax * ax;
+                d = d + ay * ay; d = d + az * az;
+                if (d <= e2) bits |= 1ull << (j - wd * 64);
+            }
+            adj_[(size_t)i * stride + wd] = bits;
+            if (bits) team_atomic_add(&labels_[i], __builtin_popcountll(bits));
+        PW_ROW_ITEMS_END
+        T::sync();
+        // core points (at least min_samples = 5 neighbours, itself included) start as their own
+        // component; the others carry "none"
+        constexpr int NONE = 0x7fffffff;
+        for (int i = T::tid(); i < ns; i += T::SIZE) {
+            const bool is_core = labels_[i] >= 5;
+            if (is_core) team_atomic_or(&core[i >> 6], 1ull << (i & 63));
+            labels_[i] = is_core ? i : NONE;
+        }
+        T::sync();
+        if (T::wave() == 0) PW_T1(ws, 11, t_adj);     // adjacency rows + core points
+        PW_T0(t_bfs);
+        // Components of the core graph by minimum-label propagation, all clusters at once: a core
+        // point takes the smallest label among its core neighbours (one row word per work item, the
+        // minimum entered atomically), then jumps to the label of the point its label names.  Labels
+        // only decrease and never below the smallest index of the component, so a round in which
+        // nothing changed was a round over a constant state: every component then carries its
+        // smallest member index.  The fixed point does not depend on the order of the updates.
+        for (int round = 0;; ++round) {
+            PW_LDS int* changed = &chg[round & 1];
+            PW_ROW_ITEMS_BEGIN
+                unsigned long long b = adj_[(size_t)i * stride + wd] & core[wd];
+                if (b != 0 && ((core[i >> 6] >> (i & 63)) & 1ull)) {
+                    int m = NONE;
+                    while (b) {
+                        const int j = wd * 64 + __builtin_ctzll(b);
+                        b &= b - 1;
+                        const int lj = labels_[j];
+                        m = lj < m ? lj : m;
+                    }
+                    if (m < labels_[i]) { team_atomic_min(&labels_[i], m); *changed = 1; }
+                }
+            PW_ROW_ITEMS_END
+            T::sync();
+            const bool again = *changed != 0;
+            if (!again) break;
+            if (T::tid() == 0) chg[(round + 1) & 1] = 0;
+            for (int i = T::tid(); i < ns; i += T::SIZE) {
+                const int l = labels_[i];
+                if (l != NONE) { const int r = labels_[l]; if (r < l) labels_[i] = r; }
+            }
+            T::sync();
+        }
+        // clusters are numbered by their smallest member (sklearn visits the points in index order)
+        for (int i = T::tid(); i < ns; i += T::SIZE)
+            if (labels_[i] == i) team_atomic_or(&roots[i >> 6], 1ull << (i & 63));
+        // a border point belongs to the lowest-numbered cluster with a core point next to it
+        // (only the labels of core points are read here, only those of the others written)
+        for (int i = T::tid(); i < ns; i += T::SIZE) {
+            if ((core[i >> 6] >> (i & 63)) & 1ull) continue;
+            int m = NONE;
+            for (int wd = 0; wd < words; ++wd) {
+                unsigned long long b = adj_[(size_t)i * stride + wd] & core[wd];
+                while (b) {
+                    const int j = wd * 64 + __builtin_ctzll(b);
+                    b &= b - 1;
+                    const int lj = labels_[j];
+                    m = lj < m ? lj : m;
+                }
+            }
+            labels_[i] = m;
+        }
+        T::sync();
+        for (int i = T::tid(); i < ns; i += T::SIZE) {
+            const int r = labels_[i];
+            int lab = -1;
+            if (r != NONE) {
+                lab = __builtin_popcountll(roots[r >> 6] & ((1ull << (r & 63)) - 1ull));
+                for (int wd = 0; wd < (r >> 6); ++wd) lab += __builtin_popcountll(roots[wd]);
+            }
+            labels_[i] = lab;
+        }
+        T::sync();
+        if (T::wave() == 0) PW_T1(ws, 23, t_bfs);     // clusters
+    };
+    if (have_cp && PW_IS_LDS(cp) && PW_IS_LDS(adj) && PW_IS_LDS(labels)) cluster(PW_AS_LDS(cp), PW_AS_LDS(adj), PW_AS_LDS(labels));
+    else cluster(cp, adj, labels);
+#undef PW_ROW_ITEMS_BEGIN
+#undef PW_ROW_ITEMS_END
+    int label = 0;
+    for (int wd = 0; wd < words; ++wd) label += __builtin_popcountll(roots[wd]);
+    return label;
+}
+
 // ---- stage: windows ----------------------------------------------------------------------------
 template <class T>
 PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
@@ -2279,165 +2443,13 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
     PW_T0(t_db);
     arena = arena_mark;                   // tmpv is dead: its values were compacted into vals
     // ---- DBSCAN(eps, min_samples = 5) on the survivors' end points -----------------------
-    // sklearn labels (sklearn/cluster/_dbscan_inner.pyx): core points = connected components
-    // of the eps-graph numbered by their smallest member index; a border point takes the
-    // label of the first (lowest-numbered) cluster with a core point next to it.  Both are
-    // independent of the traversal order, so all clusters are found at once (below).
     {
-        const int words = (ns + 63) / 64;
-        double e2 = v.eps * v.eps;
-        PW_LDS unsigned long long* core = v.bits[0];
-        // adjacency rows live in LDS (the window frames are idle now) when they fit
-        unsigned long long* adj = (unsigned long long*)arena.take((size_t)ns * (size_t)words * 8);
-        int stride = words;
-        if (!adj) { adj = ws->adj; stride = PW_P_MAX / 64; }
-        if (adj == nullptr) {   // launch without a global adjacency buffer and LDS too small
+        const int label = team_dbscan<T>(v.bits[0], v.bits[1], v.bits[2], arena, ws, pts, PT, surv_k, ns, v.eps, labels);
+        if (label < 0) {
             if (T::tid() == 0) v.status |= PW_ST_POINTS_OVERFLOW;
             T::sync();
             return;
         }
-        PW_LDS unsigned long long* roots = v.bits[2];
-        for (int wd = T::tid(); wd < words; wd += T::SIZE) { core[wd] = 0; roots[wd] = 0; }
-        PW_LDS int* chg = (PW_LDS int*)v.bits[1];      // "something changed" flags of the rounds below, used in turn
-        if (T::tid() == 0) { chg[0] = 0; chg[1] = 0; }
-        // the survivors' end points, compacted: the threads of a wave then read the same point at the
-        // same time (broadcast) and eight of them are fetched ahead of the arithmetic
-        double* cp = (double*)arena.take((size_t)ns * 24);
-        for (int i = T::tid(); i < ns; i += T::SIZE) {
-            labels[i] = 0;                  // (counts the neighbours first)
-            if (cp) {
-                const int pik = surv_k[i];
-                cp[3 * i] = pts[PT(pik, 0)]; cp[3 * i + 1] = pts[PT(pik, 1)]; cp[3 * i + 2] = pts[PT(pik, 2)];
-            }
-        }
-        T::sync();
-        // Work items are (point, 64-bit word of its adjacency row), dealt point-major: the number of
-        // survivors is rarely a multiple of the team size (CC3: 250-270 against 256 threads), and a
-        // second round of whole rows for a handful of points would cost as much as the first.
-#define PW_ROW_ITEMS_BEGIN                                                                   \
-        {                                                                                    \
-            int i = T::tid(), wd = 0;                                                        \
-            while (i >= ns && wd < words) { i -= ns; ++wd; }                                 \
-            while (wd < words) {
-#define PW_ROW_ITEMS_END                                                                     \
-                i += T::SIZE;                                                                \
-                while (i >= ns && wd < words) { i -= ns; ++wd; }                             \
-            }                                                                                \
-        }
-        const bool have_cp = cp != nullptr;
-        auto cluster = [&](auto cp_, auto adj_, auto labels_) __attribute__((always_inline)) {
-            PW_ROW_ITEMS_BEGIN
-                double px, py, pz;
-                if (have_cp) { px = cp_[3 * i]; py = cp_[3 * i + 1]; pz = cp_[3 * i + 2]; }
-                else { const int pik = surv_k[i]; px = pts[PT(pik, 0)]; py = pts[PT(pik, 1)]; pz = pts[PT(pik, 2)]; }
-                unsigned long long bits = 0;
-                const int jend = (wd * 64 + 64 < ns) ? wd * 64 + 64 : ns;
-                int j = wd * 64;
-                if (have_cp) {
-                    for (; j + 8 <= jend; j += 8) {
-                        double qx[8], qy[8], qz[8];
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) { qx[t] = cp_[3 * (j + t)]; qy[t] = cp_[3 * (j + t) + 1]; qz[t] = cp_[3 * (j + t) + 2]; }
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) {
-                            double ax = px - qx[t], ay = py - qy[t], az = pz - qz[t];
-                            double d = ax * ax;      // (0.0 + ax * ax is ax * ax exactly)
-                            d = d + ay * ay; d = d + az * az;
-                            if (d <= e2) bits |= 1ull << (j + t - wd * 64);
-                        }
-                    }
-                }
-                for (; j < jend; ++j) {
-                    const int pjk = surv_k[j];
-                    double ax = px - pts[PT(pjk, 0)], ay = py - pts[PT(pjk, 1)], az = pz - pts[PT(pjk, 2)];
-                    double d = ax * ax;
-                    d = d + ay * ay; d = d + az * az;
-                    if (d <= e2) bits |= 1ull << (j - wd * 64);
-                }
-                adj_[(size_t)i * stride + wd] = bits;
-                if (bits) team_atomic_add(&labels_[i], __builtin_popcountll(bits));
-            PW_ROW_ITEMS_END
-            T::sync();
-            // core points (at least min_samples = 5 neighbours, itself included) start as their own
-            // component; the others carry "none"
-            constexpr int NONE = 0x7fffffff;
-            for (int i = T::tid(); i < ns; i += T::SIZE) {
-                const bool is_core = labels_[i] >= 5;
-                if (is_core) team_atomic_or(&core[i >> 6], 1ull << (i & 63));
-                labels_[i] = is_core ? i : NONE;
-            }
-            T::sync();
-            if (T::wave() == 0) PW_T1(ws, 11, t_db);      // adjacency rows + core points
-            PW_T0(t_bfs);
-            // Components of the core graph by minimum-label propagation, all clusters at once: a core
-            // point takes the smallest label among its core neighbours (one row word per work item, the
-            // minimum entered atomically), then jumps to the label of the point its label names.  Labels
-            // only decrease and never below the smallest index of the component, so a round in which
-            // nothing changed was a round over a constant state: every component then carries its
-            // smallest member index.  The fixed point does not depend on the order of the updates.
-            for (int round = 0;; ++round) {
-                PW_LDS int* changed = &chg[round & 1];
-                PW_ROW_ITEMS_BEGIN
-                    unsigned long long b = adj_[(size_t)i * stride + wd] & core[wd];
-                    if (b != 0 && ((core[i >> 6] >> (i & 63)) & 1ull)) {
-                        int m = NONE;
-                        while (b) {
-                            const int j = wd * 64 + __builtin_ctzll(b);
-                            b &= b - 1;
-                            const int lj = labels_[j];
-                            m = lj < m ? lj : m;
-                        }
-                        if (m < labels_[i]) { team_atomic_min(&labels_[i], m); *changed = 1; }
-                    }
-                PW_ROW_ITEMS_END
-                T::sync();
-                const bool again = *changed != 0;
-                if (!again) break;
-                if (T::tid() == 0) chg[(round + 1) & 1] = 0;
-                for (int i = T::tid(); i < ns; i += T::SIZE) {
-                    const int l = labels_[i];
-                    if (l != NONE) { const int r = labels_[l]; if (r < l) labels_[i] = r; }
-                }
-                T::sync();
-            }
-            // clusters are numbered by their smallest member (sklearn visits the points in index order)
-            for (int i = T::tid(); i < ns; i += T::SIZE)
-                if (labels_[i] == i) team_atomic_or(&roots[i >> 6], 1ull << (i & 63));
-            // a border point belongs to the lowest-numbered cluster with a core point next to it
-            // (only the labels of core points are read here, only those of the others written)
-            for (int i = T::tid(); i < ns; i += T::SIZE) {
-                if ((core[i >> 6] >> (i & 63)) & 1ull) continue;
-                int m = NONE;
-                for (int wd = 0; wd < words; ++wd) {
-                    unsigned long long b = adj_[(size_t)i * stride + wd] & core[wd];
-                    while (b) {
-                        const int j = wd * 64 + __builtin_ctzll(b);
-                        b &= b - 1;
-                        const int lj = labels_[j];
-                        m = lj < m ? lj : m;
-                    }
-                }
-                labels_[i] = m;
-            }
-            T::sync();
-            for (int i = T::tid(); i < ns; i += T::SIZE) {
-                const int r = labels_[i];
-                int lab = -1;
-                if (r != NONE) {
-                    lab = __builtin_popcountll(roots[r >> 6] & ((1ull << (r & 63)) - 1ull));
-                    for (int wd = 0; wd < (r >> 6); ++wd) lab += __builtin_popcountll(roots[wd]);
-                }
-                labels_[i] = lab;
-            }
-            T::sync();
-            if (T::wave() == 0) PW_T1(ws, 23, t_bfs);     // clusters
-        };
-        if (have_cp && PW_IS_LDS(cp) && PW_IS_LDS(adj) && PW_IS_LDS(labels)) cluster(PW_AS_LDS(cp), PW_AS_LDS(adj), PW_AS_LDS(labels));
-        else cluster(cp, adj, labels);
-#undef PW_ROW_ITEMS_BEGIN
-#undef PW_ROW_ITEMS_END
-        int label = 0;
-        for (int wd = 0; wd < words; ++wd) label += __builtin_popcountll(roots[wd]);
         if (T::tid() == 0) {
             v.n_clusters = label;
             out->n_clusters = label;

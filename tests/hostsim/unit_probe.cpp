@@ -3,6 +3,7 @@
 // control flow of the HIP kernels can be checked against the golden vectors in
 // a container without a GPU.  Test infrastructure only: the product library
 // (libpywindow_hip.so) never links or calls this.
+#include <vector>
 #include "../../pywindow_amd/csrc/pw_unit.hpp"
 #include <stdlib.h>
 #include <string.h>
@@ -64,6 +65,28 @@ static int run_batch(long n_units, const long* off, const double* xyz, const dou
     return 0;
 }
 extern "C" int hs_sizeof_unit_out() { return (int)sizeof(pw_unit_out); }
+// DBSCAN(eps, min_samples = 5) as the one-thread team computes it (the same source as pw_dbscan); points n x 3
+extern "C" int hs_dbscan(const double* points, long n, double eps, int* labels) {
+    static unsigned long long bits[3][PW_P_MAX / 64];
+    if (n > PW_P_MAX) return -2;
+    std::vector<double> soa((size_t)3 * n);
+    std::vector<int> ident((size_t)n);
+    for (long i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) soa[(size_t)k * n + i] = points[3 * i + k];
+        ident[i] = (int)i;
+    }
+    TeamWorkspace* ws = (TeamWorkspace*)calloc(1, sizeof(TeamWorkspace));
+    std::vector<unsigned long long> adj((size_t)PW_ADJ_WORDS);
+    ws->adj = adj.data();
+    ScratchArena arena;
+    arena.cur = nullptr;
+    arena.left = 0;
+    const int nn = (int)n;
+    auto PT = [nn](int k, int c) { return c * nn + k; };
+    int k = team_dbscan<HostTeam>(bits[0], bits[1], bits[2], arena, ws, soa.data(), PT, ident.data(), nn, eps, labels);
+    free(ws);
+    return k;
+}
 // numpy's add.reduce order as the one-thread team computes it (the same source as pw_pairwise_sum)
 extern "C" double hs_pairwise_sum(const double* a, long n) {
     static int tab[324];
