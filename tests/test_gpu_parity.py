@@ -424,3 +424,38 @@ def test_results_do_not_depend_on_what_the_cu_ran_before(hip_ctx):
             first = out.tobytes()
         assert out.tobytes() == first, "not reproducible run to run"
     res.free()
+
+
+def test_other_cages_with_fresh_noise_against_live_oracle(hip_ctx):
+    """Every molecule of the static golden group (60 to 468 atoms, 2 to 6 windows or none, different
+    element sets) with noise no fixture has seen, in ONE ragged batch: GPU against the oracle run live
+    (tests/tools/parity_variety.py is the larger version of this)."""
+    from oracle import pw_oracle as O
+    from pywindow_amd import _lib
+    from pywindow_amd import element_data as E
+
+    g = load_group("static")
+    rng = np.random.default_rng(20261003)
+    off, xyz, vdw, mass = group_batch(g)
+    xyz = xyz + rng.normal(0.0, 0.05, size=xyz.shape)
+    out = hip_ctx.analyse(_lib.Batch(off, xyz, vdw, mass))
+    checked_windows = 0
+    for u in range(len(off) - 1):
+        sl = slice(off[u], off[u + 1])
+        try:
+            ref = O.full_analysis(xyz[sl], vdw[sl], mass[sl])
+        except ValueError:                       # non-porous with this noise: the reference raises, the batch flags
+            assert int(out[u]["status"]) & _lib.ST_NEGATIVE_PORE, u
+            continue
+        r = out[u]
+        assert int(r["status"]) == 0, u
+        for key in ("mw", "maxd", "avg_d", "pore_d", "pore_opt_d"):
+            assert float(r[key]) == ref[key], (u, key)
+        assert (int(r["maxd_i"]), int(r["maxd_j"])) == (ref["maxd_i"], ref["maxd_j"]), u
+        assert np.array_equal(r["pore_opt_c"], ref["pore_opt_c"]), u
+        assert int(r["n_windows"]) == ref["n_windows"], u
+        n = ref["n_windows"]
+        if n > 0:
+            assert rel(r["win_d"][:n], ref["win_d"][:n]) <= LIVE_TOL_WINDOW, u      # (window order included)
+            checked_windows += n
+    assert checked_windows >= 30
