@@ -378,6 +378,9 @@ PW_HD inline double wave_gap_value(const Frame& F, int n, double px, double py, 
 // Four points at once (the f and the three forward-difference points of one gradient
 // request): each row of 16 lanes takes one point and the atoms are spread over the row.
 // Values only; identical to four wave_gap calls.
+// Keep it inlined into its callers: an out-of-line copy that read the caller's private arrays px/py/pz with
+// the lane-dependent index below returned wrong values on gfx950 / ROCm 7.0 (by-value arguments were fine,
+// and no faster than inlining) -- measured in round 2 when the evaluation was moved out of the optimiser step.
 template <class T>
 PW_HD inline void wave_gap4(const Frame& F, int n, const double* px, const double* py,
                             const double* pz, double* out) {
