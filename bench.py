@@ -380,6 +380,8 @@ def main():
                 return raw.view(_lib.UNIT_OUT_DTYPE)
             return self.last_host
 
+    per_rank = []           # seconds of the latest timed region, by rank
+
     def timed(res, steps, warmup, gather):
         for _ in range(warmup):
             res.launch()
@@ -395,8 +397,12 @@ def main():
         elapsed = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=tdev if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            per_rank[:] = [float(x.item()) for x in every]
+            elapsed = max(per_rank)                 # the job takes as long as its slowest rank
+        else:
+            per_rank[:] = [elapsed]
         return elapsed
 
     # ---- weak scaling (headline): every rank its own `frames` frames --------------------------------
@@ -413,6 +419,7 @@ def main():
             gather()
         barrier(res)
     elapsed = timed(res, args.steps, args.warmup, gather)
+    weak_per_rank = list(per_rank)
     out = res.download()
     ok = bool((out["status"] == 0).all())
     gather_ok = None
@@ -428,13 +435,16 @@ def main():
     if dist is not None and not args.no_strong:
         per = -(-args.frames // world)
         lo, hi = T.shard_range(args.frames, rank, world)
-        if hi - lo == per:
+        # the same decision on EVERY rank (a short last block would leave its rank out of the collectives
+        # the others enter): only trajectories that split evenly are timed
+        if args.frames % world == 0:
             _, mine = synth.synthetic_units(hi - lo, first=lo)
             res_s = ctx.upload(_lib.Batch.uniform(mine, vdw, mass))
             el_s = timed(res_s, args.steps, args.warmup, StepGather(res_s, per))
             strong = {"frames_total": args.frames, "frames_per_gpu": per, "ms_per_step": 1e3 * el_s / args.steps,
                       "value": args.frames * args.steps / el_s, "unit": "frames/s", "scaling": "strong",
-                      "includes_gather": True}
+                      "includes_gather": True,
+                      "ms_per_step_by_rank": {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps}}
             res_s.free()
         else:
             strong = {"skipped": f"{args.frames} frames do not split evenly over {world} ranks"}
@@ -503,6 +513,8 @@ def main():
                        "frames_per_gpu": args.frames, "stages": "all", "results_ok": ok,
                        "successive_steps_overlap": True, "single_step_latency_ms": single_ms,
                        "windows_eq_4": int((out["n_windows"] == 4).sum()),
+                       "ms_per_step_by_rank": {"min": 1e3 * min(weak_per_rank) / args.steps,
+                                               "max": 1e3 * max(weak_per_rank) / args.steps},
                        "gather_in_timed_region": dist is not None, "gather_ok": gather_ok,
                        "backend": backend if dist is not None else None},
             "roofline": {"bound": "fp64_valu", "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -524,6 +536,11 @@ def main():
                          "valu_issue_measured": valu_issue},
         }
         if strong is not None:
+            if "value" in strong:
+                # against `world` GPUs each as fast as this one analysing the whole trajectory on its own
+                strong["one_gpu_frames_per_s"] = units_per_s
+                strong["speedup"] = strong["value"] / units_per_s
+                strong["efficiency"] = strong["value"] / (world * units_per_s)
             line["strong"] = strong
         if world == 1:
             # what strong scaling of the 1000-frame trajectory can reach: a rank's share analysed on this

@@ -25,8 +25,13 @@
 extern "C" {
 #endif
 
-#define PW_W_MAX 16       /* windows reported per molecule (more => PW_ST_WINDOW_OVERFLOW) */
-#define PW_P_MAX 2048     /* sampling vectors per molecule the workspace is sized for */
+#define PW_W_MAX 16       /* windows held by the fixed-size record; a molecule with more keeps the first
+                             PW_W_MAX there, sets PW_ST_WINDOW_OVERFLOW and hands the rest over through
+                             pw_context_extra_windows -- the reference has no limit (utilities.py:1526-1536) */
+#define PW_DBSCAN_MAX 8192 /* points pw_dbscan accepts */
+#define PW_P_MAX 2048     /* sampling vectors the team workspaces are sized for AT LEAST; the capacity follows
+                             the `adjust` knobs of pw_params (the reference's count is unbounded,
+                             utilities.py:1409, 1616) and pw_analysis_batch grows it further when a unit asks */
 
 /* error codes */
 #define PW_OK 0
@@ -35,6 +40,7 @@ extern "C" {
 #define PW_E_HIP (-3)
 #define PW_E_TOO_LARGE (-4) /* a molecule has more atoms than fit in LDS */
 #define PW_E_NOMEM (-5)
+#define PW_E_RETRY (-6)     /* a capacity was grown for this batch: launch the analysis again, then download */
 
 /* stage selection bits for pw_analysis_* */
 #define PW_STAGE_BASIC 1u   /* molecular_weight, center_of_mass, max_dim, pore_diameter */
@@ -46,11 +52,15 @@ extern "C" {
 /* per-unit status bits (pw_unit_out.status) */
 #define PW_ST_OK 0
 #define PW_ST_NEGATIVE_PORE 1      /* pore radius <= 0: the reference's bounds would be inverted */
-#define PW_ST_WINDOW_OVERFLOW 2    /* more than PW_W_MAX clusters */
-#define PW_ST_POINTS_OVERFLOW 4    /* more than PW_P_MAX sampling vectors */
+#define PW_ST_WINDOW_OVERFLOW 2    /* more than PW_W_MAX windows: n_windows is the true count, the record holds the
+                                      first PW_W_MAX, the others are in the context's extra-window list */
+#define PW_ST_POINTS_OVERFLOW 4    /* more sampling vectors than the workspace of this launch holds (n_points /
+                                      n_points_avg say how many): avg_d is NaN / n_windows -1, NOT a result */
 #define PW_ST_WINDOW_DROPPED 8     /* a cluster's refined path scan failed (reference: None + warning) */
 #define PW_ST_WINDOW_NEGATIVE 16   /* a window diameter < 0 (reference: warning) */
 #define PW_ST_Z_BOUNDS 32          /* z_bounds upper < -new_z with lb_z (reference: scipy raises ValueError) */
+#define PW_ST_TOO_FEW_POINTS 64    /* fewer than 10 sampling vectors in find_windows (reference: KDTree.query(k=10)
+                                      raises ValueError, utilities.py:1428-1431) */
 
 /* Input batch: ragged molecules, atoms of unit u are [atom_offset[u], atom_offset[u+1]). */
 typedef struct pw_batch_in {
@@ -95,12 +105,22 @@ typedef struct pw_unit_out {
     double sphere_r;       /* sampling sphere radius in find_windows */
 } pw_unit_out;
 
+/* A window beyond the PW_W_MAX the record holds (PW_ST_WINDOW_OVERFLOW): position `index` >= PW_W_MAX in
+ * the reference's output order of unit `unit` (utilities.py:1526-1536). */
+typedef struct pw_extra_window {
+    int64_t unit;
+    int32_t index;
+    int32_t reserved;
+    double d;
+    double c[3];
+} pw_extra_window;
+
 /* Stage-level capture of find_windows for one unit (pw_analysis_debug; the parity tests compare it
  * with the reference's intermediate results). */
 typedef struct pw_unit_debug {
     int32_t n_survivors;            /* sampling vectors that pass vector_analysis (utilities.py:1457-1467) */
     int32_t n_clusters;
-    int32_t pass_idx[PW_P_MAX];     /* their indices on the sampling sphere, ascending */
+    int32_t pass_idx[PW_P_MAX];     /* their indices on the sampling sphere, ascending (the first PW_P_MAX) */
     int32_t labels[PW_P_MAX];       /* DBSCAN label of each (utilities.py:1478-1487) */
     double gap2[PW_P_MAX];          /* vector_analysis result [1]: 2 * narrowest gap along the path */
     double win[PW_W_MAX][12];       /* window_analysis per cluster (utilities.py:1191-1361): chosen vector (3),
@@ -147,6 +167,18 @@ int pw_context_set_params(pw_context *ctx, const pw_params *params);
  * for `stages == PW_STAGE_ALL`; partial `stages` give the fine-grained calls
  * (pore_diameter, max_dim, ... ) the parity tests exercise one by one. */
 int pw_analysis_batch(pw_context *ctx, const pw_batch_in *in, uint32_t stages, pw_unit_out *out);
+/* Windows beyond PW_W_MAX of the analysis whose records were fetched last on this context
+ * (pw_analysis_batch, pw_analysis_debug, pw_resident_download), ordered by (unit, index): copies at
+ * most `cap` entries to buf and returns how many exist.  find_windows has no upper limit on the
+ * number of windows (utilities.py:1526-1536); the record keeps the first PW_W_MAX. */
+int64_t pw_context_extra_windows(pw_context *ctx, pw_extra_window *buf, int64_t cap);
+/* 1 when analyses on this context run as the overlapped three-launch pipeline, 0 when as single launches:
+ * the pipeline needs its ten HIP streams to run concurrently, i.e. GPU_MAX_HW_QUEUES >= 10 in the
+ * environment BEFORE the process first initialises HIP; pw_context_create measures whether they do and
+ * falls back (with a line on stderr) instead of letting gate kernels wait for launches queued behind them */
+int pw_context_pipelined(pw_context *ctx);
+/* sampling vectors the team workspaces of this context currently hold per molecule (>= PW_P_MAX) */
+int pw_context_point_capacity(pw_context *ctx);
 
 /* The same analysis with the intermediate results of find_windows captured per unit (dbg: n_units
  * records, caller-allocated).  Test instrumentation: one launch at a time, no overlap. */
@@ -161,7 +193,7 @@ int pw_point_gaps(pw_context *ctx, const pw_batch_in *in, const int64_t *unit_of
 
 /* Fine-grained: sklearn.cluster.DBSCAN(eps, min_samples=5).fit(points).labels_ as find_windows calls it
  * (utilities.py:1478-1487; sklearn/cluster/_dbscan_inner.pyx): clusters numbered in the order of their
- * smallest member, border points with the lowest-numbered adjacent cluster, noise -1.  n <= PW_P_MAX points
+ * smallest member, border points with the lowest-numbered adjacent cluster, noise -1.  n <= PW_DBSCAN_MAX points
  * (n x 3, row-major).  mode bit 0: a one-wave team instead of four waves; bit 1: every array of the routine
  * in global memory instead of LDS. */
 int pw_dbscan(pw_context *ctx, const double *points, int64_t n, double eps, int mode, int32_t *labels,
@@ -188,6 +220,11 @@ int pw_resident_time(pw_context *ctx, pw_resident *res, uint32_t stages, int ite
 int pw_resident_stage_times(pw_context *ctx, pw_resident *res, float *ms3);
 /* raw device pointer of the result records (for RCCL gathers by the host side) */
 void *pw_resident_device_results(pw_resident *res);
+/* For callers that read the records on the device (pw_resident_results_ready): waits for the latest
+ * launch of the batch, fails with PW_E_HIP if its window launch timed out, and loads its windows beyond
+ * PW_W_MAX into the context's list (*count of them; pw_context_extra_windows reads them).  PW_E_RETRY: the
+ * device list for them has just been allocated -- launch again.  pw_resident_download does all of this. */
+int pw_resident_extra_windows(pw_context *ctx, pw_resident *res, int64_t *count);
 /* Stream-ordered hand-over of the latest launch's records to a stream of the caller (hipStream_t as
  * an opaque pointer; NULL = the legacy default stream): work queued on `stream` afterwards sees the
  * finished records at *results (device pointer), without a host synchronisation.  This is how the

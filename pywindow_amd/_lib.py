@@ -26,6 +26,10 @@ ST_POINTS_OVERFLOW = 4
 ST_WINDOW_DROPPED = 8
 ST_WINDOW_NEGATIVE = 16
 ST_Z_BOUNDS = 32
+ST_TOO_FEW_POINTS = 64
+
+E_RETRY = -6
+DBSCAN_MAX = 8192
 
 _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libpywindow_hip.so"
@@ -33,6 +37,10 @@ LIB_PATH = _PKG / "libpywindow_hip.so"
 
 class PwHipError(RuntimeError):
     """The HIP engine is missing, has no device, or a call failed."""
+
+
+class PwRetry(PwHipError):
+    """``PW_E_RETRY``: a capacity was grown for this batch; launch the analysis again."""
 
 
 class BatchIn(ctypes.Structure):
@@ -164,6 +172,12 @@ UNIT_OUT_DTYPE = np.dtype(
     align=True,
 )
 
+#: numpy mirror of ``pw_extra_window``: a window beyond the W_MAX a record holds
+EXTRA_WINDOW_DTYPE = np.dtype(
+    [("unit", np.int64), ("index", np.int32), ("reserved", np.int32), ("d", np.float64), ("c", np.float64, (3,))],
+    align=True,
+)
+
 #: numpy mirror of ``pw_unit_debug`` (stage capture of find_windows, ``Context.analyse_debug``)
 UNIT_DEBUG_DTYPE = np.dtype(
     [
@@ -202,6 +216,9 @@ EXPORTED_SYMBOLS = [
     "pw_params_default",
     "pw_context_set_params",
     "pw_analysis_batch",
+    "pw_context_extra_windows",
+    "pw_context_point_capacity",
+    "pw_context_pipelined",
     "pw_analysis_debug",
     "pw_point_gaps",
     "pw_pairwise_sum",
@@ -214,6 +231,7 @@ EXPORTED_SYMBOLS = [
     "pw_resident_time",
     "pw_resident_stage_times",
     "pw_resident_device_results",
+    "pw_resident_extra_windows",
     "pw_resident_results_ready",
     "pw_resident_results_release",
     "pw_resident_units",
@@ -293,6 +311,10 @@ def load():
     L.pw_context_set_params.argtypes = [vp, ctypes.POINTER(Params)]
     L.pw_analysis_batch.argtypes = [vp, ctypes.POINTER(BatchIn), ctypes.c_uint32, vp]
     L.pw_analysis_debug.argtypes = [vp, ctypes.POINTER(BatchIn), ctypes.c_uint32, vp, vp]
+    L.pw_context_extra_windows.argtypes = [vp, vp, ctypes.c_int64]
+    L.pw_context_extra_windows.restype = ctypes.c_int64
+    L.pw_context_point_capacity.argtypes = [vp]
+    L.pw_context_pipelined.argtypes = [vp]
     L.pw_point_gaps.argtypes = [vp, ctypes.POINTER(BatchIn), vp, vp, ctypes.c_int64, vp, vp]
     L.pw_pairwise_sum.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int, vp]
     L.pw_dbscan.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, vp, vp]
@@ -304,6 +326,7 @@ def load():
     L.pw_resident_free.restype = None
     L.pw_resident_time.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
     L.pw_resident_stage_times.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.pw_resident_extra_windows.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_int64)]
     L.pw_resident_device_results.argtypes = [vp]
     L.pw_resident_device_results.restype = vp
     L.pw_resident_results_ready.argtypes = [vp, vp, vp, ctypes.POINTER(vp)]
@@ -409,7 +432,29 @@ class Context:
         p = params if params is not None else Params()
         _check(load().pw_context_set_params(self._h, ctypes.byref(p)), "pw_context_set_params")
 
-    def analyse(self, batch: Batch, stages: int = STAGE_ALL, params: "Params | None" = None) -> np.ndarray:
+    def extra_windows(self) -> np.ndarray:
+        """Windows beyond ``W_MAX`` of the records fetched last on this context (``EXTRA_WINDOW_DTYPE``,
+        ordered by unit and position): the reference has no limit on the number of windows."""
+        n = load().pw_context_extra_windows(self._h, None, 0)
+        buf = np.zeros(n, dtype=EXTRA_WINDOW_DTYPE)
+        if n:
+            load().pw_context_extra_windows(self._h, buf.ctypes.data, n)
+        return buf
+
+    @property
+    def pipelined(self) -> bool:
+        """Whether analyses run as the overlapped pipeline (needs ``GPU_MAX_HW_QUEUES`` >= 10 exported before
+        the process first initialised HIP; measured at context creation) or as single launches."""
+        return bool(load().pw_context_pipelined(self._h))
+
+    @property
+    def point_capacity(self) -> int:
+        """Sampling vectors per molecule the workspaces hold at present (follows the ``adjust`` knobs)."""
+        return int(load().pw_context_point_capacity(self._h))
+
+    def analyse(self, batch: Batch, stages: int = STAGE_ALL, params: "Params | None" = None, extra=None) -> np.ndarray:
+        """``extra``: a list that receives the ``EXTRA_WINDOW_DTYPE`` array of this analysis (windows
+        beyond ``W_MAX``; read under the same lock as the analysis)."""
         out = np.zeros(batch.n_units, dtype=UNIT_OUT_DTYPE)
         if batch.n_units == 0:
             return out
@@ -421,6 +466,8 @@ class Context:
                     load().pw_analysis_batch(self._h, ctypes.byref(batch.c), stages, out.ctypes.data),
                     "pw_analysis_batch",
                 )
+                if extra is not None and (out["status"] & ST_WINDOW_OVERFLOW).any():
+                    extra.append(self.extra_windows())
             finally:
                 if params is not None:
                     self.set_params(None)
@@ -591,16 +638,38 @@ class Resident:
         return obj
 
     def launch(self, stages: int = STAGE_ALL):
+        self._stages = stages
         _check(load().pw_resident_launch(self.ctx._h, self._h, stages), "pw_resident_launch")
 
     def sync(self):
         _check(load().pw_resident_sync(self.ctx._h), "pw_resident_sync")
 
-    def download(self) -> np.ndarray:
+    def download(self, extra=None) -> np.ndarray:
+        """Records of the latest launch.  ``extra``: a list that receives the windows beyond ``W_MAX``
+        (``EXTRA_WINDOW_DTYPE``) when a unit has any.  The device list for those only exists once a launch
+        has asked for it (``PW_E_RETRY``): the analysis is then launched once more, here."""
         out = np.zeros(self.n_units, dtype=UNIT_OUT_DTYPE)
         if self.n_units:
-            _check(load().pw_resident_download(self.ctx._h, self._h, out.ctypes.data), "pw_resident_download")
+            rc = load().pw_resident_download(self.ctx._h, self._h, out.ctypes.data)
+            if rc == E_RETRY:
+                self.launch(getattr(self, "_stages", STAGE_ALL))
+                rc = load().pw_resident_download(self.ctx._h, self._h, out.ctypes.data)
+            _check(rc, "pw_resident_download")
+            if extra is not None and (out["status"] & ST_WINDOW_OVERFLOW).any():
+                extra.append(self.ctx.extra_windows())
         return out
+
+    def check(self) -> np.ndarray:
+        """For callers that read the records on the device: wait for the latest launch, raise if its
+        window launch timed out, and return its windows beyond ``W_MAX`` (``EXTRA_WINDOW_DTYPE``; empty
+        for all but unusual molecules).  ``PW_E_RETRY`` (the device list for such windows had to be
+        allocated first) is passed on as :class:`PwRetry`: launch again."""
+        n = ctypes.c_int64(0)
+        rc = load().pw_resident_extra_windows(self.ctx._h, self._h, ctypes.byref(n))
+        if rc == E_RETRY:
+            raise PwRetry(load().pw_last_error().decode(errors="replace"))
+        _check(rc, "pw_resident_extra_windows")
+        return self.ctx.extra_windows() if n.value else np.zeros(0, dtype=EXTRA_WINDOW_DTYPE)
 
     def time_launches(self, iters: int, stages: int = STAGE_ALL) -> float:
         ms = ctypes.c_float()

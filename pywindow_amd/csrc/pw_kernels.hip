@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 
 #include "../../include/pywindow_amd.h"
@@ -70,6 +71,25 @@ constexpr unsigned MASK_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE;
 constexpr unsigned MASK_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 
+// Where a launch's teams find their global workspaces: headers, the per-team slabs of the per-vector
+// arrays (sized by the launch's sampling-vector capacity p_cap), DBSCAN adjacency rows, and the launch-wide
+// list of windows beyond what a record holds.
+struct WsArgs {
+    TeamWorkspace* ws;
+    unsigned char* slab;            // team t: slab + t * team_slab_bytes(p_cap)
+    unsigned long long* adj;        // team t: adj + t * team_adj_words(p_cap); null: the launch runs no DBSCAN
+    pw_extra_window* xwin;
+    unsigned* xwin_count;
+    unsigned xwin_cap;
+    int p_cap;
+};
+__device__ inline void bind_workspace(TeamWorkspace* ws, const WsArgs& a, unsigned team, const unsigned* rsq_tab) {
+    bind_team_slab(ws, a.slab + (size_t)team * team_slab_bytes(a.p_cap), a.p_cap);
+    ws->adj = a.adj ? a.adj + (size_t)team * team_adj_words(a.p_cap) : nullptr;
+    ws->xwin = a.xwin; ws->xwin_count = a.xwin_count; ws->xwin_cap = a.xwin_cap;
+    ws->rsq = rsq_tab;
+}
+
 // MASK: the stage bits this instantiation can execute (the run-time mask is ANDed with it), so
 // the launches of the pipeline carry only the code -- and the registers -- of their own stages
 // Register budget: two waves per SIMD (three for the average-diameter launch).  A one-wave-per-SIMD
@@ -94,26 +114,22 @@ template <int NW, unsigned MASK>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? PW_OCC8 : (MASK == PW_KERNEL_AVERAGE ? 3 : (MASK == MASK_CHAINS ? PW_OCC_A : PW_OCC)))
 pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
                   const double* __restrict__ vdw, const double* __restrict__ mass, unsigned stages,
-                  int nmax, int nrot, int nlb, int nframes, int lean, TeamWorkspace* __restrict__ workspaces,
-                  unsigned long long* __restrict__ adj_base, unsigned long long* counter,
+                  int nmax, int nrot, int nlb, int nframes, int lean, WsArgs wsa, unsigned long long* counter,
                   pw_unit_out* __restrict__ out, int role, UnitQueue* queue, int* __restrict__ slots,
                   pw_params prm, const unsigned* __restrict__ rsq_tab, int vstride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ long s_unit;
     using T = DeviceTeam<NW>;
     UnitShared sh;
-    sh.carve(lds, nmax, nrot, nlb, nframes, lean != 0);     // as planned by the host (plan_launch)
+    sh.carve(lds, nmax, nrot, nlb, nframes, lean != 0, wsa.p_cap);     // as planned by the host (plan_launch)
     // the optimiser chains are latency-bound and on the critical path: when one shares a SIMD
     // with a bulk wave of another launch it must win the issue arbitration
     if (role == PW_ROLE_PRODUCER) {
         __builtin_amdgcn_s_setprio(PW_A_PRIO);
         if (threadIdx.x == 0) atomicAdd(&queue->started, 1);
     }
-    TeamWorkspace* ws = workspaces + blockIdx.x;
-    if (threadIdx.x == 0) {
-        ws->adj = adj_base ? adj_base + (size_t)blockIdx.x * PW_ADJ_WORDS : nullptr;
-        ws->rsq = rsq_tab;
-    }
+    TeamWorkspace* ws = wsa.ws + blockIdx.x;
+    if (threadIdx.x == 0) bind_workspace(ws, wsa, blockIdx.x, rsq_tab);
     __syncthreads();
     for (;;) {
         if (role == PW_ROLE_CONSUMER) {
@@ -200,6 +216,21 @@ __global__ void pw_head_gate_kernel(const UnitQueue* prev, unsigned long long ne
     }
 }
 
+// Probe of pw_context_create: K of these, one per stream of the pipeline, must be able to RUN AT THE SAME
+// TIME -- every one waits (bounded) until all K have started.  Streams that share a hardware queue
+// (GPU_MAX_HW_QUEUES too small, or exported after the process initialised HIP) run one after the other and
+// the probe says so; the pipeline's gate kernels would then sit in front of the launches they wait for.
+__global__ void pw_probe_kernel(int* started, int expected, int* together) {
+    if (threadIdx.x != 0) return;
+    atomicAdd(started, 1);
+    long long t0 = wall_clock64();
+    while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > 1000000ll) return;     // 10 ms
+    }
+    atomicAdd(together, 1);
+}
+
 // Fine-grained entry: min_i(|r_i - p| - vdw_i) and its first argmin for arbitrary
 // points p (reference pore_diameter(elements, coordinates, com=p)/2,
 // utilities.py:375-388).  One lane per point, atoms streamed from global memory.
@@ -208,13 +239,13 @@ __global__ void pw_head_gate_kernel(const UnitQueue* prev, unsigned long long ne
 // in that much dynamic LDS when they fit (what the pipeline does for CC3); 0: everything in global memory.
 template <int NW>
 __global__ void __launch_bounds__(NW * 64) pw_dbscan_kernel(const double* __restrict__ pts, int n, double eps,
-                                                            int lds_bytes, TeamWorkspace* ws,
+                                                            int lds_bytes, TeamWorkspace* ws, int p_cap,
                                                             unsigned long long* adj_base, const int* __restrict__ ident,
                                                             int* __restrict__ labels, int* __restrict__ n_clusters) {
     using T = DeviceTeam<NW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    __shared__ unsigned long long bits[3][PW_P_MAX / 64];
-    if (threadIdx.x == 0) ws->adj = adj_base;
+    __shared__ unsigned long long bits[3][PW_DBSCAN_MAX / 64];
+    if (threadIdx.x == 0) { ws->adj = adj_base; ws->p_cap = p_cap; }
     __syncthreads();
     ScratchArena arena;
     arena.cur = (unsigned char*)lds;
@@ -279,7 +310,7 @@ __global__ void pw_point_gap_kernel(long n_points, const long* __restrict__ unit
 // stream time each -- a tenth of the step of a small batch).
 __global__ void pw_reset_kernel(unsigned long long* __restrict__ out8, long n8, UnitQueue* queue, int* __restrict__ slots,
                                 long n_units, unsigned long long* ca, unsigned long long* cb,
-                                unsigned long long* cc) {
+                                unsigned long long* cc, unsigned* xw_count) {
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = i0; i < n8; i += stride) out8[i] = 0ull;
@@ -287,6 +318,7 @@ __global__ void pw_reset_kernel(unsigned long long* __restrict__ out8, long n8, 
     if (i0 == 0) {
         queue->tail = 0; queue->head = 0; queue->error = 0; queue->started = 0;
         *ca = 0; *cb = 0; *cc = 0;
+        *xw_count = 0u;
     }
 }
 
@@ -306,8 +338,12 @@ struct pw_context {
     size_t lds_per_cu;
     TeamWorkspace* ws;
     int ws_blocks;
+    unsigned char* slab;     // ws_blocks x team_slab_bytes(p_cap)
     unsigned long long* adj;
     int adj_blocks;
+    int p_cap;               // sampling vectors per molecule the slabs / adjacency rows are sized for (0: none yet)
+    int p_cap_min;           // ... and at least this many (raised when a unit asked for more than the knobs imply)
+    std::vector<pw_extra_window>* extra;   // windows beyond PW_W_MAX of the records fetched last (host copy)
     unsigned long long* counter;   // 4 work counters
     UnitQueue* queue;
     int* slots;
@@ -334,7 +370,9 @@ struct pw_context {
     UnitQueue* cur_queue;
     int* cur_slots;
     hipEvent_t ev0, ev1, ev_fork;
-    int fused;               // PW_FUSED=1: one launch per analysis instead of the pipeline
+    int fused;               // PW_FUSED=1: one launch per analysis instead of the pipeline (also chosen when the
+                             // streams of the pipeline do not run concurrently, see pw_context_create)
+    int concurrent_streams;  // how many of the pipeline's 2 + 2 x PW_SETS streams ran at the same time in the probe
     int c_waves;             // waves per team in the window launch (PW_C_WAVES, default 4)
     pw_params prm;           // knobs of find_windows / find_average_diameter
     unsigned* rsq_tab;       // VRSQRT14PD table on the device (numpy's arccos, pw_math.hpp)
@@ -362,6 +400,9 @@ struct pw_resident {
     double* d_mass;
     pw_unit_out* d_out;      // result records of the latest launch (= d_outs[cur])
     pw_unit_out* d_outs[PW_SETS];
+    pw_extra_window* d_xw[PW_SETS];   // windows beyond PW_W_MAX written by the launch into d_outs[k] ...
+    unsigned* d_xw_count;             // ... and how many (PW_SETS counters)
+    unsigned xw_cap;
     int nbuf;                // result buffers in rotation (= the context's sets in flight at upload)
     int cur;
     hipEvent_t ev_read[PW_SETS];   // a caller's stream has finished reading d_outs[k] (pw_resident_results_release)
@@ -369,14 +410,40 @@ struct pw_resident {
     int written_set[PW_SETS];      // pipeline set of the launch that last wrote d_outs[k], -1: none / not a pipeline launch
 };
 
+// sampling-vector capacity the next launch needs: what the adjust knobs imply (pw_unit.hpp: params_p_cap)
+// or what a unit of an earlier analysis asked for, whichever is larger
+static int wanted_p_cap(const pw_context* c) {
+    int p = params_p_cap(c->prm.adjust_windows, c->prm.adjust_average);
+    if (c->p_cap_min > p) p = round_p_cap(c->p_cap_min);
+    return p;
+}
 static int ensure_workspace(pw_context* c, int blocks, int adj_blocks) {
+    const int want = wanted_p_cap(c);
+    if (want > c->p_cap) {
+        // capacities only grow; everything sized by them is rebuilt (nothing is in flight afterwards)
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->slab) HIP_TRY(hipFree(c->slab));
+        c->slab = nullptr;
+        if (c->adj) HIP_TRY(hipFree(c->adj));
+        c->adj = nullptr;
+        if (blocks < c->ws_blocks) blocks = c->ws_blocks;
+        if (adj_blocks < c->adj_blocks) adj_blocks = c->adj_blocks;
+        c->adj_blocks = 0;
+        c->p_cap = want;
+        if (c->ws_blocks > 0) {
+            HIP_TRY(hipMalloc((void**)&c->slab, (size_t)c->ws_blocks * team_slab_bytes(c->p_cap)));
+        }
+    }
     if (c->ws_blocks < blocks) {
         HIP_TRY(hipDeviceSynchronize());
         if (c->ws) HIP_TRY(hipFree(c->ws));
         c->ws = nullptr;
+        if (c->slab) HIP_TRY(hipFree(c->slab));
+        c->slab = nullptr;
         c->ws_blocks = 0;
         HIP_TRY(hipMalloc((void**)&c->ws, (size_t)blocks * sizeof(TeamWorkspace)));
         HIP_TRY(hipMemset(c->ws, 0, (size_t)blocks * sizeof(TeamWorkspace)));
+        HIP_TRY(hipMalloc((void**)&c->slab, (size_t)blocks * team_slab_bytes(c->p_cap)));
         c->ws_blocks = blocks;
     }
     if (c->adj_blocks < adj_blocks) {
@@ -384,7 +451,7 @@ static int ensure_workspace(pw_context* c, int blocks, int adj_blocks) {
         if (c->adj) HIP_TRY(hipFree(c->adj));
         c->adj = nullptr;
         c->adj_blocks = 0;
-        HIP_TRY(hipMalloc((void**)&c->adj, (size_t)adj_blocks * PW_ADJ_WORDS * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void**)&c->adj, (size_t)adj_blocks * team_adj_words(c->p_cap) * sizeof(unsigned long long)));
         c->adj_blocks = adj_blocks;
     }
     return PW_OK;
@@ -405,7 +472,7 @@ static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool 
         int nslot = nw < 4 ? nw : 4;
         int nrot = rot ? nslot : 0;
         int nlb = lb_per_team < 0 ? nslot : lb_per_team;
-        size_t lds = UnitShared::bytes(nmax, nrot, nlb, nframes, lean) + 64;
+        size_t lds = UnitShared::bytes(nmax, nrot, nlb, nframes, lean, wanted_p_cap(c) > c->p_cap ? wanted_p_cap(c) : c->p_cap) + 64;
         if (lds <= max_lds || nw == 1) {
             if (lds > max_lds) {
                 snprintf(g_err, sizeof(g_err), "molecule with %d atoms does not fit in LDS", nmax);
@@ -446,10 +513,16 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
         }
     }
     if (reset_counter) HIP_TRY(hipMemsetAsync(c->counter + counter_slot, 0, sizeof(unsigned long long), st));
+    WsArgs wsa;
+    wsa.ws = c->ws + ws_first;
+    wsa.slab = c->slab + (size_t)ws_first * team_slab_bytes(c->p_cap);
+    wsa.adj = adj_first >= 0 ? c->adj + (size_t)adj_first * team_adj_words(c->p_cap) : (unsigned long long*)nullptr;
+    wsa.xwin = r->d_xw[r->cur];
+    wsa.xwin_count = r->d_xw_count + r->cur;
+    wsa.xwin_cap = r->xw_cap;
+    wsa.p_cap = c->p_cap;
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
-                       r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb, p.nframes, p.lean,
-                       c->ws + ws_first,
-                       adj_first >= 0 ? c->adj + (size_t)adj_first * PW_ADJ_WORDS : (unsigned long long*)nullptr,
+                       r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb, p.nframes, p.lean, wsa,
                        c->counter + counter_slot, r->d_out, role, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab,
                        r->vstride);
     HIP_TRY(hipGetLastError());
@@ -522,6 +595,8 @@ int pw_context_create(int device, pw_context** out) {
     CTX_TRY(hipMalloc((void**)&c->queue, PW_SETS * sizeof(UnitQueue)));
     CTX_TRY(hipMemset(c->queue, 0, PW_SETS * sizeof(UnitQueue)));
     c->flip = -1;
+    c->extra = new (std::nothrow) std::vector<pw_extra_window>();
+    if (!c->extra) { pw_context_destroy(c); return PW_E_NOMEM; }
     {
         const char* ns = getenv("PW_SETS_IN_FLIGHT");
         c->nsets = ns ? atoi(ns) : 0;
@@ -570,6 +645,33 @@ int pw_context_create(int device, pw_context** out) {
     const char* cw = getenv("PW_C_WAVES");
     c->c_waves = (cw && cw[0] == '8') ? 8 : 4;
     c->prm = default_params();
+    if (!c->fused) {
+        // Do the ten streams of the pipeline really run side by side?  (GPU_MAX_HW_QUEUES is read when the
+        // process initialises HIP: an application that did so before this library exported it -- PyTorch
+        // imported and used first, a direct binding of the C ABI -- has the default of four hardware queues.)
+        hipStream_t all[2 + 2 * PW_SETS];
+        int k = 0;
+        all[k++] = c->stream; all[k++] = c->aux;
+        for (int b = 0; b < PW_SETS; ++b) { all[k++] = c->prods[b]; all[k++] = c->cons[b]; }
+        int* flags = (int*)c->counter;                        // (the work counters are unused so far)
+        CTX_TRY(hipMemset(flags, 0, 2 * sizeof(int)));
+        for (int i = 0; i < k; ++i) hipLaunchKernelGGL(pw_probe_kernel, dim3(1), dim3(64), 0, all[i], flags, k, flags + 1);
+        CTX_TRY(hipDeviceSynchronize());
+        int got[2] = {0, 0};
+        CTX_TRY(hipMemcpy(got, flags, sizeof(got), hipMemcpyDeviceToHost));
+        CTX_TRY(hipMemset(flags, 0, 2 * sizeof(int)));
+        c->concurrent_streams = got[1];
+        if (got[1] < k) {
+            // not all of them: the overlapped pipeline cannot be trusted on this process -- every analysis
+            // becomes ONE launch (all stages in a team), which needs no concurrency at all
+            c->fused = 1;
+            const char* q = getenv("GPU_MAX_HW_QUEUES");
+            fprintf(stderr, "pywindow_amd: only %d of %d HIP streams run concurrently (GPU_MAX_HW_QUEUES=%s%s); analyses run as "
+                            "single launches.  Export GPU_MAX_HW_QUEUES=12 before the process first touches HIP for the "
+                            "overlapped pipeline (INTEGRATION.md).\n", got[1], k, q ? q : "unset",
+                    q ? ", possibly exported after HIP was initialised" : "");
+        }
+    }
     {
         unsigned* host = new (std::nothrow) unsigned[65536];
         if (!host) { pw_context_destroy(c); return PW_E_NOMEM; }
@@ -592,6 +694,8 @@ void pw_context_destroy(pw_context* c) {
     (void)scope.enter(c->device);
     (void)hipDeviceSynchronize();
     if (c->ws) (void)hipFree(c->ws);
+    if (c->slab) (void)hipFree(c->slab);
+    delete c->extra;
     if (c->ev_ext) (void)hipEventDestroy(c->ev_ext);
     for (int k = 0; k < 3; ++k)
         for (int e = 0; e < 2; ++e)
@@ -697,6 +801,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
             r->read_valid[r->cur] = 0;
         }
         r->written_set[r->cur] = -1;       // (the API stream joins every pipeline launch: nothing to remember)
+        HIP_TRY(hipMemsetAsync(r->d_xw_count + r->cur, 0, sizeof(unsigned), c->stream));
         return launch_plan(c, r, stages, p, c->stream, 0, win ? 0 : -1, 3 * PW_SETS + 1);
     }
     // Pipeline: the analysis is split by parallel shape and the pieces overlap.
@@ -753,7 +858,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         int k = atoi(cslots);
         if (k >= 1 && k < 4 && pc.nw == 4) {
             pc.nrot = pc.nlb = k;
-            pc.lds = UnitShared::bytes(r->nmax, k, k, 1, false) + 64;
+            pc.lds = UnitShared::bytes(r->nmax, k, k, 1, false, wanted_p_cap(c) > c->p_cap ? wanted_p_cap(c) : c->p_cap) + 64;
             int per_cu = (int)(c->lds_per_cu / pc.lds);
             if (per_cu > 4) per_cu = 4;
             long g = (long)c->n_cu * per_cu;
@@ -846,7 +951,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(pw_reset_kernel, dim3((unsigned)blocks), dim3(256), 0, c->prod, (unsigned long long*)r->d_out, n8,
                            c->cur_queue, c->cur_slots, r->n_units, c->counter + b, c->counter + PW_SETS + b,
-                           c->counter + 2 * PW_SETS + b);
+                           c->counter + 2 * PW_SETS + b, r->d_xw_count + r->cur);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev_reset[b], c->prod));
@@ -971,8 +1076,9 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
         UP_TRY(hipMalloc((void**)&r->d_vdw, sizeof(double) * nconst));
         UP_TRY(hipMalloc((void**)&r->d_mass, sizeof(double) * nconst));
         r->nbuf = c->nsets ? c->nsets : (r->n_units <= 1500 ? 4 : (r->n_units <= 6000 ? 3 : 2));
-        UP_TRY(hipMalloc((void**)&r->d_outs[0], r->nbuf * sizeof(pw_unit_out) * r->n_units));
+        UP_TRY(hipMalloc((void**)&r->d_outs[0], r->nbuf * sizeof(pw_unit_out) * r->n_units + 64));
         for (int k = 1; k < r->nbuf; ++k) r->d_outs[k] = r->d_outs[0] + (size_t)k * r->n_units;
+        r->d_xw_count = (unsigned*)(r->d_outs[0] + (size_t)r->nbuf * r->n_units);   // (extra-window counters)
         for (int k = 0; k < PW_SETS; ++k) r->written_set[k] = -1;
         r->d_out = r->d_outs[0];
         r->cur = 0;
@@ -984,7 +1090,7 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
                               c->stream));
         UP_TRY(hipMemcpyAsync(r->d_mass, in->mass, sizeof(double) * nconst, hipMemcpyHostToDevice,
                               c->stream));
-        UP_TRY(hipMemsetAsync(r->d_outs[0], 0, r->nbuf * sizeof(pw_unit_out) * r->n_units, c->stream));
+        UP_TRY(hipMemsetAsync(r->d_outs[0], 0, r->nbuf * sizeof(pw_unit_out) * r->n_units + 64, c->stream));
         UP_TRY(hipStreamSynchronize(c->stream));
     }
 #undef UP_TRY
@@ -1002,8 +1108,8 @@ int pw_internal_resident_adopt(pw_context* c, long n_units, long n_atoms, int nm
     if (!r) return PW_E_NOMEM;
     memset(r, 0, sizeof(*r));
     r->nbuf = c->nsets ? c->nsets : (n_units <= 1500 ? 4 : (n_units <= 6000 ? 3 : 2));
-    hipError_t e = hipMalloc((void**)&r->d_outs[0], r->nbuf * sizeof(pw_unit_out) * n_units);
-    if (e == hipSuccess) e = hipMemsetAsync(r->d_outs[0], 0, r->nbuf * sizeof(pw_unit_out) * n_units, c->stream);
+    hipError_t e = hipMalloc((void**)&r->d_outs[0], r->nbuf * sizeof(pw_unit_out) * n_units + 64);
+    if (e == hipSuccess) e = hipMemsetAsync(r->d_outs[0], 0, r->nbuf * sizeof(pw_unit_out) * n_units + 64, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         set_err("pw_internal_resident_adopt", e);
@@ -1014,11 +1120,39 @@ int pw_internal_resident_adopt(pw_context* c, long n_units, long n_atoms, int nm
     r->n_units = n_units; r->n_atoms = n_atoms; r->nmax = nmax; r->vstride = 1;
     r->d_offset = d_offset; r->d_xyz = d_xyz; r->d_vdw = d_vdw; r->d_mass = d_mass;
     for (int k = 1; k < r->nbuf; ++k) r->d_outs[k] = r->d_outs[0] + (size_t)k * n_units;
+    r->d_xw_count = (unsigned*)(r->d_outs[0] + (size_t)r->nbuf * n_units);
     for (int k = 0; k < PW_SETS; ++k) r->written_set[k] = -1;
     r->d_out = r->d_outs[0];
     r->cur = 0;
     c->need_fork = 1;
     *out = r;
+    return PW_OK;
+}
+
+// Windows beyond the PW_W_MAX a record holds (pw_unit.hpp: stage_windows appends them to the launch's list).
+// The list's device buffer only exists once a launch has asked for it: the first launch that meets such a
+// unit counts them, the download grows the buffer and reports PW_E_RETRY, the repeated launch fills it.
+static int fetch_extra_windows(pw_context* c, pw_resident* r, unsigned count) {
+    c->extra->clear();
+    if (count == 0) return PW_OK;
+    if (count > r->xw_cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (r->d_xw[0]) HIP_TRY(hipFree(r->d_xw[0]));
+        for (int k = 0; k < PW_SETS; ++k) r->d_xw[k] = nullptr;
+        r->xw_cap = 0;
+        const unsigned cap = ((count + count / 2 + 1023u) / 1024u) * 1024u;
+        HIP_TRY(hipMalloc((void**)&r->d_xw[0], (size_t)r->nbuf * cap * sizeof(pw_extra_window)));
+        for (int k = 1; k < r->nbuf; ++k) r->d_xw[k] = r->d_xw[0] + (size_t)k * cap;
+        r->xw_cap = cap;
+        snprintf(g_err, sizeof(g_err), "%u windows beyond the %d a record holds: launch the analysis again "
+                 "(the list for them has been allocated)", count, PW_W_MAX);
+        return PW_E_RETRY;
+    }
+    c->extra->resize(count);
+    HIP_TRY(hipMemcpy(c->extra->data(), r->d_xw[r->cur], (size_t)count * sizeof(pw_extra_window), hipMemcpyDeviceToHost));
+    std::sort(c->extra->begin(), c->extra->end(), [](const pw_extra_window& a, const pw_extra_window& b) {
+        return a.unit != b.unit ? a.unit < b.unit : a.index < b.index;
+    });
     return PW_OK;
 }
 
@@ -1035,11 +1169,53 @@ int pw_resident_download(pw_context* c, pw_resident* r, pw_unit_out* out) {
         int rcj = join_pipeline(c);
         if (rcj != PW_OK) return rcj;
     }
+    unsigned xw_count = 0;
     HIP_TRY(hipMemcpyAsync(out, r->d_out, sizeof(pw_unit_out) * r->n_units, hipMemcpyDeviceToHost,
                            c->stream));
+    HIP_TRY(hipMemcpyAsync(&xw_count, r->d_xw_count + r->cur, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return check_queue_error(c);
+    int rc = check_queue_error(c);
+    if (rc != PW_OK) return rc;
+    return fetch_extra_windows(c, r, xw_count);
 }
+
+// The same hand-over without the records: for callers that read the records on the device (the RCCL
+// gather).  Waits for the latest launch of the batch, reports a timed-out window launch (the only other
+// place that is checked is the download), and loads the launch's extra windows into the context's list.
+int pw_resident_extra_windows(pw_context* c, pw_resident* r, int64_t* count) {
+    if (!c || !r) return PW_E_BAD_ARG;
+    if (count) *count = 0;
+    if (r->n_units == 0) return PW_OK;
+    PW_ON_DEVICE(c->device);
+    const int ws = r->written_set[r->cur];
+    if (ws >= 0 && c->done_valid[ws]) {
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_done[ws], 0));
+    } else {
+        int rcj = join_pipeline(c);
+        if (rcj != PW_OK) return rcj;
+    }
+    unsigned xw_count = 0;
+    HIP_TRY(hipMemcpyAsync(&xw_count, r->d_xw_count + r->cur, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = check_queue_error(c);
+    if (rc != PW_OK) return rc;
+    rc = fetch_extra_windows(c, r, xw_count);
+    if (rc == PW_OK && count) *count = (int64_t)c->extra->size();
+    return rc;
+}
+
+int64_t pw_context_extra_windows(pw_context* c, pw_extra_window* buf, int64_t cap) {
+    if (!c || !c->extra) return 0;
+    const int64_t n = (int64_t)c->extra->size();
+    if (buf && cap > 0) memcpy(buf, c->extra->data(), (size_t)(n < cap ? n : cap) * sizeof(pw_extra_window));
+    return n;
+}
+
+/* 1: analyses on this context run as the overlapped three-launch pipeline; 0: as single launches (PW_FUSED=1,
+ * or the probe of pw_context_create found fewer concurrent streams than the pipeline needs) */
+int pw_context_pipelined(pw_context* c) { return c && !c->fused ? 1 : 0; }
+
+int pw_context_point_capacity(pw_context* c) { return c ? (c->p_cap > 0 ? c->p_cap : wanted_p_cap(c)) : 0; }
 
 void pw_resident_free(pw_context* c, pw_resident* r) {
     if (!r) return;
@@ -1051,6 +1227,7 @@ void pw_resident_free(pw_context* c, pw_resident* r) {
     if (r->d_mass) (void)hipFree(r->d_mass);
     if (c) (void)hipDeviceSynchronize();
     if (r->d_outs[0]) (void)hipFree(r->d_outs[0]);
+    if (r->d_xw[0]) (void)hipFree(r->d_xw[0]);
     for (int k = 0; k < PW_SETS; ++k)
         if (r->ev_read[k]) (void)hipEventDestroy(r->ev_read[k]);
     delete r;
@@ -1132,13 +1309,35 @@ int pw_resident_stage_times(pw_context* c, pw_resident* r, float* ms) {
     return PW_OK;
 }
 
+// launch + download with the two capacities that can only be known afterwards: a unit that wants more
+// sampling vectors than the adjust knobs imply (a sphere of several thousand angstroms) raises the
+// context's minimum, a unit with more windows than a record holds gets the launch's list allocated --
+// either way the launch is repeated, so no limit of the engine ever shows in a result
+static int launch_and_download(pw_context* c, pw_resident* r, uint32_t stages, pw_unit_out* out) {
+    int rc = PW_OK;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        rc = pw_resident_launch(c, r, stages);
+        if (rc == PW_OK) rc = pw_resident_download(c, r, out);
+        if (rc == PW_E_RETRY) continue;
+        if (rc != PW_OK) return rc;
+        long want = 0;
+        for (long u = 0; u < r->n_units; ++u)
+            if (out[u].status & PW_ST_POINTS_OVERFLOW) {
+                if (out[u].n_points > want) want = out[u].n_points;
+                if (out[u].n_points_avg > want) want = out[u].n_points_avg;
+            }
+        if (want <= c->p_cap) return PW_OK;      // (nothing flagged, or flagged for a reason a larger workspace does not cure)
+        c->p_cap_min = round_p_cap(want);
+    }
+    return rc;
+}
+
 int pw_analysis_batch(pw_context* c, const pw_batch_in* in, uint32_t stages, pw_unit_out* out) {
     if (!c || !in || !out) return PW_E_BAD_ARG;
     pw_resident* r = nullptr;
     int rc = pw_resident_upload(c, in, &r);
     if (rc != PW_OK) return rc;
-    rc = pw_resident_launch(c, r, stages);
-    if (rc == PW_OK) rc = pw_resident_download(c, r, out);
+    rc = launch_and_download(c, r, stages, out);
     pw_resident_free(c, r);
     return rc;
 }
@@ -1170,6 +1369,7 @@ int pw_analysis_debug(pw_context* c, const pw_batch_in* in, uint32_t stages, pw_
     // run follows with every workspace pointing at the buffer
     rc = pw_resident_launch(c, r, stages);
     if (rc == PW_OK) rc = pw_resident_sync(c);
+    if (rc == PW_OK) rc = launch_and_download(c, r, stages, out);      // (settles the capacities)
     if (rc == PW_OK) rc = set_debug(d_dbg);
     if (rc == PW_OK) rc = pw_resident_launch(c, r, stages);
     if (rc == PW_OK) rc = pw_resident_download(c, r, out);
@@ -1234,7 +1434,7 @@ int pw_point_gaps(pw_context* c, const pw_batch_in* in, const int64_t* unit_of_p
 
 int pw_dbscan(pw_context* c, const double* points, int64_t n, double eps, int mode, int32_t* labels,
               int32_t* n_clusters) {
-    if (!c || !labels || !n_clusters || n < 0 || n > PW_P_MAX || (n > 0 && !points)) return PW_E_BAD_ARG;
+    if (!c || !labels || !n_clusters || n < 0 || n > PW_DBSCAN_MAX || (n > 0 && !points)) return PW_E_BAD_ARG;
     *n_clusters = 0;
     if (n == 0) return PW_OK;
     PW_ON_DEVICE(c->device);
@@ -1268,17 +1468,18 @@ int pw_dbscan(pw_context* c, const double* points, int64_t n, double eps, int mo
     DB_TRY(hipMalloc((void**)&d_i, sizeof(int) * n));
     DB_TRY(hipMalloc((void**)&d_l, sizeof(int) * (n + 1)));
     DB_TRY(hipMalloc((void**)&d_ws, sizeof(TeamWorkspace)));
-    DB_TRY(hipMalloc((void**)&d_adj, sizeof(unsigned long long) * PW_ADJ_WORDS));
+    const int p_cap = round_p_cap((long)n);
+    DB_TRY(hipMalloc((void**)&d_adj, sizeof(unsigned long long) * team_adj_words(p_cap)));
     DB_TRY(hipMemcpyAsync(d_p, soa.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
     DB_TRY(hipMemcpyAsync(d_i, ident.data(), sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
     const int lds_bytes = (mode & 2) ? 0 : 96 * 1024;
     if (mode & 1) {
         DB_TRY(hipFuncSetAttribute((const void*)pw_dbscan_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        hipLaunchKernelGGL(pw_dbscan_kernel<1>, dim3(1), dim3(64), lds_bytes, c->stream, d_p, (int)n, eps, lds_bytes, d_ws,
+        hipLaunchKernelGGL(pw_dbscan_kernel<1>, dim3(1), dim3(64), lds_bytes, c->stream, d_p, (int)n, eps, lds_bytes, d_ws, p_cap,
                            d_adj, d_i, d_l, d_l + n);
     } else {
         DB_TRY(hipFuncSetAttribute((const void*)pw_dbscan_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        hipLaunchKernelGGL(pw_dbscan_kernel<4>, dim3(1), dim3(256), lds_bytes, c->stream, d_p, (int)n, eps, lds_bytes, d_ws,
+        hipLaunchKernelGGL(pw_dbscan_kernel<4>, dim3(1), dim3(256), lds_bytes, c->stream, d_p, (int)n, eps, lds_bytes, d_ws, p_cap,
                            d_adj, d_i, d_l, d_l + n);
     }
     DB_TRY(hipGetLastError());

@@ -80,26 +80,68 @@ struct Frame {
     const PW_LDS ClassInfo* cls;
 };
 
-// ---- global-memory workspace of one team (sized for PW_P_MAX vectors) ----------
+// ---- global-memory workspace of one team ---------------------------------------------------
+// The per-vector arrays are sized by the sampling-vector capacity of the launch (p_cap, a multiple of 64,
+// at least PW_P_MAX): the reference's count int(log10(4 pi R^2) * 250 * adjust) has no upper limit
+// (utilities.py:1409, 1616), so the host derives the capacity from the `adjust` knobs and every team gets a
+// slab of team_slab_bytes(p_cap) bytes that bind_team_slab() cuts up.  Only what does not fit the idle
+// part of the team's LDS ends up here (for CC3 at the default knobs: nothing but partial path rounds).
 struct TeamWorkspace {
-    double knn[PW_P_MAX * 10];
-    double pts[PW_P_MAX * 3];     // sampling vectors of find_windows
-    double vals[PW_P_MAX];        // per-ray exit distance / per-survivor 2*gap
+    double* knn;              // 10 p_cap: k-NN rows (non-streamed mean), later partial path rounds
+    double* pts;              // 3 p_cap: sampling vectors of find_windows
+    double* vals;             // p_cap: per-ray exit distance / per-survivor 2*gap / max_dim item maxima
+    int* surv_k;              // p_cap
+    int* labels;              // p_cap
+    unsigned char* flag;      // p_cap
+    unsigned long long* adj;  // p_cap x p_cap/64 words, only for launches that run DBSCAN
+    // window fits of a unit with more clusters than the record holds (PW_W_MAX): per cluster the chosen
+    // vector (3) | diameter (1) | centre (3), and the "fitted" flag -- a cluster count has no upper limit
+    // in the reference either (utilities.py:1481-1536)
+    double* xw;               // 7 p_cap
+    int* xw_ok;               // p_cap
+    int p_cap;
+    // launch-wide list of the windows beyond PW_W_MAX (appended with an atomic counter)
+    pw_extra_window* xwin;
+    unsigned* xwin_count;
+    unsigned xwin_cap;
     double leaf[256];
     double acc8[8 * 160];
     int leaf_tab[324];
-    int surv_k[PW_P_MAX];
-    int labels[PW_P_MAX];
-    unsigned char flag[PW_P_MAX];
-    unsigned char core[PW_P_MAX];
-    int stack[PW_P_MAX];
     unsigned long long prof[32];
-    unsigned long long* adj;   // PW_P_MAX x PW_P_MAX/64 words, only for launches that run DBSCAN
     const unsigned* rsq;       // VRSQRT14PD table (pw_math.hpp: rsqrt14_decode), for numpy's arccos
     pw_unit_debug* dbg_base;   // stage capture of pw_analysis_debug (one record per unit), else null
     long unit;                 // index of the unit this team is working on
 };
-constexpr size_t PW_ADJ_WORDS = (size_t)PW_P_MAX * (PW_P_MAX / 64);
+PW_HD inline size_t team_slab_bytes(int p_cap) { return (size_t)p_cap * 192; }   // 181 bytes per vector used
+PW_HD inline size_t team_adj_words(int p_cap) { return (size_t)p_cap * (size_t)(p_cap / 64); }
+PW_HD inline int round_p_cap(long p) {
+    if (p < PW_P_MAX) p = PW_P_MAX;
+    return (int)((p + 127) & ~127l);
+}
+// capacity implied by the adjust knobs: log10(4 pi R^2) * 250 stays below 2100 for sphere radii up to
+// 4400 A (a molecule that size is far beyond anything the path handles); a unit that asks for more is
+// flagged (PW_ST_POINTS_OVERFLOW) and pw_analysis_batch re-runs with what it asked for
+PW_HD inline int params_p_cap(double adjust_windows, double adjust_average) {
+    double a = adjust_windows > adjust_average ? adjust_windows : adjust_average;
+    if (!(a > 0.0)) a = 1.0;
+    double want = 2100.0 * a;
+    if (want > 4.0e6) want = 4.0e6;
+    return round_p_cap((long)want + 1);
+}
+PW_HD inline void bind_team_slab(TeamWorkspace* ws, unsigned char* slab, int p_cap) {
+    const size_t p = (size_t)p_cap;
+    double* d = (double*)slab;
+    ws->knn = d; d += 10 * p;
+    ws->pts = d; d += 3 * p;
+    ws->vals = d; d += p;
+    ws->xw = d; d += 7 * p;
+    int* i = (int*)d;
+    ws->surv_k = i; i += p;
+    ws->labels = i; i += p;
+    ws->xw_ok = i; i += p;
+    ws->flag = (unsigned char*)i;
+    ws->p_cap = p_cap;
+}
 
 // ---- per-unit scalars kept in LDS ----------------------------------------------
 struct UnitVars {
@@ -128,8 +170,7 @@ struct UnitVars {
     int red_i[16];
     // ---- window search only: everything from here on is NOT allocated for the optimiser-chain
     // launch (UnitShared::bytes with nframes == 1) ----
-    // DBSCAN bitsets (PW_P_MAX bits each): core points / round flags / cluster roots
-    unsigned long long bits[3][PW_P_MAX / 64];
+    int win_first;     // marks where the window-search variables start (offsetof)
     // sampling vector chosen for each cluster (largest 2*gap, first occurrence)
     double win_vec[PW_W_MAX][3];
     // window results by cluster
@@ -149,6 +190,8 @@ struct UnitShared {
     Frame S;        // shifted coordinates (COM frame, then pore-centre frame)
     Frame R[8];     // per-wave rotated coordinates (window frames)
     PW_LDS void* lb[8];    // per-wave optimiser state
+    // DBSCAN bit sets (p_cap bits each): core points / round flags / cluster roots (window search only)
+    PW_LDS unsigned long long* bits[3];
     size_t rot_words;  // 8-byte words in the rotated-frame region
     int nslots;        // waves that can fit a window at a time (rotated frames = optimiser states carved)
     // everything behind the shifted frame (window frames + optimiser states) is idle until the
@@ -158,21 +201,29 @@ struct UnitShared {
     // nrot = rotated window frames, nlb = optimiser states (both 0..nwaves)
     // nframes = 1: one frame - the optimiser-chain launch works on the input frame only, the other two
     // launches of the pipeline shift it in place; lean = without the window-search variables
-    PW_HD static size_t bytes(int nmax, int nrot, int nlb, int nframes = 2, bool lean = false) {
+    PW_HD static size_t bytes(int nmax, int nrot, int nlb, int nframes = 2, bool lean = false, int pcap = PW_P_MAX) {
         size_t n = (size_t)((nmax + 1) & ~1);
-        size_t b = lean ? offsetof(UnitVars, bits) : sizeof(UnitVars);
+        size_t b = lean ? offsetof(UnitVars, win_first) : sizeof(UnitVars);
         b = (b + 15) & ~(size_t)15;
+        if (!lean) b += 3 * (size_t)(pcap / 64) * 8;
         b += n * 8 * 2;                       // vdw, mass
         b += n * 4 * 2;                       // perm, inv
         b += n * 8 * 4 * ((size_t)nframes + (size_t)nrot);  // A, S, R[w]
         b += (size_t)nlb * ((sizeof(LbMem<3>) + 15) & ~(size_t)15);
         return b;
     }
-    PW_HD void carve(unsigned char* base, int nmax, int nrot, int nlb, int nframes = 2, bool lean = false) {
+    PW_HD void carve(unsigned char* base, int nmax, int nrot, int nlb, int nframes = 2, bool lean = false,
+                     int pcap = PW_P_MAX) {
         size_t n = (size_t)((nmax + 1) & ~1);
         PW_LDS unsigned char* p = (PW_LDS unsigned char*)base;
         v = (PW_LDS UnitVars*)p;
-        p += ((lean ? offsetof(UnitVars, bits) : sizeof(UnitVars)) + 15) & ~(size_t)15;
+        p += ((lean ? offsetof(UnitVars, win_first) : sizeof(UnitVars)) + 15) & ~(size_t)15;
+        bits[0] = bits[1] = bits[2] = nullptr;
+        if (!lean) {
+            const size_t bw = (size_t)(pcap / 64);
+            bits[0] = (PW_LDS unsigned long long*)p; bits[1] = bits[0] + bw; bits[2] = bits[1] + bw;
+            p += 3 * bw * 8;
+        }
         ldouble* d = (ldouble*)p;
         vdw = d; d += n;
         mass = d; d += n;
@@ -234,6 +285,14 @@ PW_HD inline void team_atomic_add(int* p, int v) {
     atomicAdd(p, v);
 #else
     *p += v;
+#endif
+}
+PW_HD inline unsigned team_atomic_inc(unsigned* p) {      // global counter shared by every team of a launch
+    if (!p) return 0xffffffffu;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(p, 1u);
+#else
+    return (*p)++;
 #endif
 }
 PW_HD inline void team_atomic_or(PW_LDS unsigned long long* p, unsigned long long v) {
@@ -1088,7 +1147,6 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
         }
     }
     const int nitem = R * K;
-    if (nitem > PW_P_MAX) item_best = nullptr;
     double best = -PW_INF;
     if (ngrp > 0) {
         for (int t = T::tid(); t < nitem; t += T::SIZE) {
@@ -1289,7 +1347,7 @@ PW_HD inline __attribute__((always_inline)) void stage_basic_impl(UnitShared& sh
     }
     T::sync();
     if (com_only) return;
-    team_max_dim<T>(sh, sh.A, n, 2 * n <= PW_P_MAX ? ws->vals : nullptr);
+    team_max_dim<T>(sh, sh.A, n, 2 * n + 2 <= ws->p_cap ? ws->vals : nullptr);
     if (T::wave() == 0) {
         int arg;
         double g = wave_gap<T>(sh.A, n, v.com[0], v.com[1], v.com[2], &arg);
@@ -1459,15 +1517,17 @@ PW_HD inline __attribute__((always_inline)) void stage_average_impl(UnitShared& 
     int keep_i = v.maxd_i, keep_j = v.maxd_j;
     T::sync();
     {
-        double* ib = 2 * n <= PW_P_MAX ? ws->vals : nullptr;     // per-item maxima (free until the rays)
+        double* ib = 2 * n + 2 <= ws->p_cap ? ws->vals : nullptr;     // per-item maxima (free until the rays)
         if (INL) team_max_dim_impl<T, true>(sh, sh.S, n, ib); else team_max_dim<T, true>(sh, sh.S, n, ib);
     }
     double radius = v.maxd;
     T::sync();
     if (T::tid() == 0) { v.maxd = keep_d; v.maxd_i = keep_i; v.maxd_j = keep_j; }
     int P = sampling_count(radius, prm.adjust_average);
-    if (P > PW_P_MAX) {
-        if (T::tid() == 0) { v.status |= PW_ST_POINTS_OVERFLOW; out->avg_d = 0.0; out->n_points_avg = P; }
+    if (P > ws->p_cap) {
+        // more rays than this launch's workspace holds: flagged, and the value is NOT a number (the host
+        // sizes the workspace from the adjust knob; pw_analysis_batch re-runs with the capacity asked for)
+        if (T::tid() == 0) { v.status |= PW_ST_POINTS_OVERFLOW; out->avg_d = __builtin_nan(""); out->n_points_avg = P; }
         T::sync();
         return;
     }
@@ -1644,15 +1704,23 @@ PW_NOINLINE PW_HD inline void wave_fmin_xy(const Frame& F, int n, double z, doub
 }
 
 // ---- one window (utilities.py:1191-1361), executed by ONE wave -------------------------------
+// per-cluster arrays of the window fits: in the team's LDS (UnitVars) for up to PW_W_MAX clusters, in the
+// team's global slab beyond -- the number of clusters has no upper limit (utilities.py:1481-1536)
+struct WinArrays {
+    double* vec;   // 3 per cluster: the sampling vector with the largest 2*gap
+    double* d;     // diameter
+    double* c;     // 3 per cluster: centre
+    int* ok;       // 1 fitted, 0 dropped by the refined path scan, -1 inverted z bounds
+};
 template <class T>
 PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int n, int cluster,
-                              const Sphere& sp, const pw_params& prm) {
+                              const Sphere& sp, const pw_params& prm, const WinArrays& wa) {
     auto& v = *sh.v;
     const int w = T::wave();
     Frame& R = sh.R[w];
     int evals = 0;
     // (i) the cluster's vector with the largest 2*gap was selected by stage_windows
-    double vx = v.win_vec[cluster][0], vy = v.win_vec[cluster][1], vz = v.win_vec[cluster][2];
+    double vx = wa.vec[3 * cluster], vy = wa.vec[3 * cluster + 1], vz = wa.vec[3 * cluster + 2];
     PW_T0(t_p);
     // (ii) refined path scan, increment2 (0.1), lanes over path points
     double nrm = norm3(vx, vy, vz);
@@ -1688,7 +1756,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     ok = T::wave_all(ok);
     if (!ok) {
         if (T::lane() == 0) {
-            v.win_ok[cluster] = 0;
+            wa.ok[cluster] = 0;
             v.red_i[8 + w] += evals;
         }
         return;
@@ -1757,7 +1825,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     }
     if (lo1[0] > up1[0]) {                       // scipy: ValueError -- reported through the status
         if (T::lane() == 0) {
-            v.win_ok[cluster] = -1;              // "bounds", not "path scan failed"
+            wa.ok[cluster] = -1;                 // "bounds", not "path scan failed"
             v.red_i[8 + w] += evals;
         }
         return;
@@ -1870,16 +1938,16 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     printf("DBG cluster %d vec %.17g %.17g %.17g a1 %.17g a2 %.17g new_z %.17g d0 %.17g zopt %.17g xy %.17g %.17g dfin %.17g\n", cluster, vx, vy, vz, a1, a2, new_z, d0, zopt, xo, yo, dfin);
 #endif
     if (T::lane() == 0) {
-        if (pw_unit_debug* dbg = ws->dbg_base ? ws->dbg_base + ws->unit : nullptr) {
+        if (pw_unit_debug* dbg = (ws->dbg_base && cluster < PW_W_MAX) ? ws->dbg_base + ws->unit : nullptr) {
             double* wd = dbg->win[cluster];
             wd[0] = vx; wd[1] = vy; wd[2] = vz; wd[3] = a1_raw; wd[4] = a2_raw; wd[5] = new_z; wd[6] = d0;
             wd[7] = zopt; wd[8] = xo; wd[9] = yo; wd[10] = dfin; wd[11] = (double)evals;
         }
-        v.win_ok[cluster] = 1;
-        v.win_d[cluster] = dfin;
-        v.win_c[cluster][0] = ux + v.shift[0];
-        v.win_c[cluster][1] = uy + v.shift[1];
-        v.win_c[cluster][2] = uz + v.shift[2];
+        wa.ok[cluster] = 1;
+        wa.d[cluster] = dfin;
+        wa.c[3 * cluster] = ux + v.shift[0];
+        wa.c[3 * cluster + 1] = uy + v.shift[1];
+        wa.c[3 * cluster + 2] = uz + v.shift[2];
         v.red_i[8 + w] += evals;
     }
 }
@@ -1902,7 +1970,7 @@ PW_HD inline __attribute__((always_inline)) int team_dbscan(PW_LDS unsigned long
     // adjacency rows live in LDS (the window frames are idle now) when they fit
     unsigned long long* adj = (unsigned long long*)arena.take((size_t)ns * (size_t)words * 8);
     int stride = words;
-    if (!adj) { adj = ws->adj; stride = PW_P_MAX / 64; }
+    if (!adj) { adj = ws->adj; stride = ws->p_cap / 64; }
     if (adj == nullptr) return -1;   // launch without a global adjacency buffer and LDS too small
     for (int wd = T::tid(); wd < words; wd += T::SIZE) { core[wd] = 0; roots[wd] = 0; }
     PW_LDS int* chg = (PW_LDS int*)flags;          // "something changed" flags of the rounds below, used in turn
@@ -2053,6 +2121,8 @@ template <class T>
 PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
                                              const pw_params& prm) {
     auto& v = *sh.v;
+    WinArrays wa;
+    wa.vec = (double*)&v.win_vec[0][0]; wa.d = (double*)v.win_d; wa.c = (double*)&v.win_c[0][0]; wa.ok = (int*)v.win_ok;
     // shift so that the optimised pore centre (pore_opt) or the centre of mass is the origin
     // (utilities.py:1380-1393)
     if (T::tid() == 0) {
@@ -2060,7 +2130,6 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
             double adjust = prm.pore_opt ? v.com[c] - v.opt_c[c] : 0.0;
             v.shift[c] = v.com[c] - adjust;
         }
-        for (int c = 0; c < PW_W_MAX; ++c) v.win_ok[c] = 0;
         for (int w = 0; w < 8; ++w) v.red_i[8 + w] = 0;
     }
     T::sync();
@@ -2071,7 +2140,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     T::sync();
     if (T::wave() == 0) PW_T1(ws, 14, t_pre);
     PW_T0(t_md);
-    team_max_dim<T, true>(sh, sh.S, n, 2 * n <= PW_P_MAX ? ws->vals : nullptr);
+    team_max_dim<T, true>(sh, sh.S, n, 2 * n + 2 <= ws->p_cap ? ws->vals : nullptr);
     double radius = v.maxd / 2.0;
     T::sync();
     if (T::wave() == 0) PW_T1(ws, 15, t_md);
@@ -2085,8 +2154,10 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         out->n_survivors = 0;
         out->eps = 0.0;
     }
-    if (P > PW_P_MAX || P < 16) {
-        if (T::tid() == 0) v.status |= PW_ST_POINTS_OVERFLOW;
+    if (P > ws->p_cap || P < 10) {
+        // too many for this launch's workspace (see stage_average), or fewer than the ten neighbours the
+        // DBSCAN radius is taken from (the reference: KDTree.query(k=10) raises, utilities.py:1428-1431)
+        if (T::tid() == 0) v.status |= P < 10 ? PW_ST_TOO_FEW_POINTS : PW_ST_POINTS_OVERFLOW;
         T::sync();
         return;
     }
@@ -2380,8 +2451,8 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
         const int left = ncand - whole;
         if (left > 0) {
             constexpr int PCAP = 64;                       // points per path handled this way
-            double* pm = ws->knn + PW_P_MAX;               // free since the DBSCAN radius is known (the first
-                                                           // PW_P_MAX entries may hold tmpv)
+            double* pm = ws->knn + ws->p_cap;              // free since the DBSCAN radius is known (the first
+                                                           // p_cap entries may hold tmpv); 9 p_cap >= 255 x 64
             bool fits = true;
             for (int item = T::tid(); item < left * PCAP; item += T::SIZE) {
                 int j = whole + item / PCAP, q = item % PCAP;
@@ -2447,7 +2518,7 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
     arena = arena_mark;                   // tmpv is dead: its values were compacted into vals
     // ---- DBSCAN(eps, min_samples = 5) on the survivors' end points -----------------------
     {
-        const int label = team_dbscan<T>(v.bits[0], v.bits[1], v.bits[2], arena, ws, pts, PT, surv_k, ns, v.eps, labels);
+        const int label = team_dbscan<T>(sh.bits[0], sh.bits[1], sh.bits[2], arena, ws, pts, PT, surv_k, ns, v.eps, labels);
         if (label < 0) {
             if (T::tid() == 0) v.status |= PW_ST_POINTS_OVERFLOW;
             T::sync();
@@ -2456,12 +2527,16 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
         if (T::tid() == 0) {
             v.n_clusters = label;
             out->n_clusters = label;
-            if (label > PW_W_MAX) v.status |= PW_ST_WINDOW_OVERFLOW;
         }
+        // the per-cluster arrays: team LDS for what a record holds, the team's global slab beyond
+        // (clusters <= core points <= survivors <= p_cap)
+        if (label > PW_W_MAX) {
+            wa.vec = ws->xw; wa.d = ws->xw + 3 * (size_t)ws->p_cap; wa.c = ws->xw + 4 * (size_t)ws->p_cap; wa.ok = ws->xw_ok;
+        }
+        for (int c = T::tid(); c < label; c += T::SIZE) wa.ok[c] = 0;
         T::sync();
         // utilities.py:1221 -- per cluster the vector with the largest 2*gap (first occurrence)
-        int ncl0 = label < PW_W_MAX ? label : PW_W_MAX;
-        for (int c = T::wave(); c < ncl0; c += T::NWAVES) {
+        for (int c = T::wave(); c < label; c += T::NWAVES) {
             double best = -PW_INF;
             int bidx = 0x7fffffff;
             for (int q = T::lane(); q < ns; q += T::WSIZE) {
@@ -2473,14 +2548,13 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
             T::wave_argmax(best, bidx);
             if (T::lane() == 0) {
                 const int pvk = surv_k[bidx];
-                const double pv[3] = {pts[PT(pvk, 0)], pts[PT(pvk, 1)], pts[PT(pvk, 2)]};
-                v.win_vec[c][0] = pv[0]; v.win_vec[c][1] = pv[1]; v.win_vec[c][2] = pv[2];
+                wa.vec[3 * c] = pts[PT(pvk, 0)]; wa.vec[3 * c + 1] = pts[PT(pvk, 1)]; wa.vec[3 * c + 2] = pts[PT(pvk, 2)];
             }
         }
         T::sync();
         // stage capture (pw_analysis_debug): survivors in pass order, their labels and path minima
         if (pw_unit_debug* dbg = ws->dbg_base ? ws->dbg_base + ws->unit : nullptr) {
-            for (int i = T::tid(); i < ns; i += T::SIZE) {
+            for (int i = T::tid(); i < ns && i < PW_P_MAX; i += T::SIZE) {
                 dbg->pass_idx[i] = surv_k[i];
                 dbg->labels[i] = labels[i];
                 dbg->gap2[i] = vals[i];
@@ -2491,26 +2565,39 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
     if (T::wave() == 0) PW_T1(ws, 10, t_db);
     PW_T0(t_w);
     // ---- one window per cluster, clusters dealt round-robin to the waves -------------------
-    int ncl = v.n_clusters < PW_W_MAX ? v.n_clusters : PW_W_MAX;
+    const int ncl = v.n_clusters;
     // at most four waves fit windows at a time (one rotated frame + optimiser state each);
     // in an 8-wave team the upper four only take part in the bulk stages
     int nslot = T::NWAVES < 4 ? T::NWAVES : 4;
     if (sh.nslots < nslot) nslot = sh.nslots;       // (a launch may carve fewer slots than waves to save LDS)
     if (T::wave() < nslot)
-        for (int c = T::wave(); c < ncl; c += nslot) wave_window<T>(sh, ws, n, c, sp, prm);
+        for (int c = T::wave(); c < ncl; c += nslot) wave_window<T>(sh, ws, n, c, sp, prm, wa);
     T::sync();
     if (T::wave() == 0) PW_T1(ws, 12, t_w);
     if (T::tid() == 0) {
+        // result assembly (utilities.py:1526-1536): the fitted windows in cluster order; the record holds
+        // PW_W_MAX of them, the others go to the launch's extra-window list
         int m = 0;
         for (int c = 0; c < ncl; ++c) {
-            if (v.win_ok[c] > 0) {
-                out->win_d[m] = v.win_d[c];
-                out->win_c[m][0] = v.win_c[c][0];
-                out->win_c[m][1] = v.win_c[c][1];
-                out->win_c[m][2] = v.win_c[c][2];
-                if (v.win_d[c] < 0.0) v.status |= PW_ST_WINDOW_NEGATIVE;
+            if (wa.ok[c] > 0) {
+                const double wd = wa.d[c];
+                if (m < PW_W_MAX) {
+                    out->win_d[m] = wd;
+                    out->win_c[m][0] = wa.c[3 * c];
+                    out->win_c[m][1] = wa.c[3 * c + 1];
+                    out->win_c[m][2] = wa.c[3 * c + 2];
+                } else {
+                    v.status |= PW_ST_WINDOW_OVERFLOW;
+                    unsigned slot = team_atomic_inc(ws->xwin_count);
+                    if (ws->xwin && slot < ws->xwin_cap) {
+                        pw_extra_window* e = ws->xwin + slot;
+                        e->unit = ws->unit; e->index = m; e->reserved = 0; e->d = wd;
+                        e->c[0] = wa.c[3 * c]; e->c[1] = wa.c[3 * c + 1]; e->c[2] = wa.c[3 * c + 2];
+                    }
+                }
+                if (wd < 0.0) v.status |= PW_ST_WINDOW_NEGATIVE;
                 ++m;
-            } else if (v.win_ok[c] < 0) {
+            } else if (wa.ok[c] < 0) {
                 v.status |= PW_ST_Z_BOUNDS;
             } else {
                 v.status |= PW_ST_WINDOW_DROPPED;

@@ -87,19 +87,53 @@ def make_batch(molecules) -> "_lib.Batch":
     return _lib.Batch(np.array(offs, np.int64), np.concatenate(xyz), np.concatenate(vdw), np.concatenate(mass))
 
 
-def analyse(molecules, stages: int = _lib.STAGE_ALL, device: int | None = None, params=None) -> np.ndarray:
+def analyse(molecules, stages: int = _lib.STAGE_ALL, device: int | None = None, params=None, extra=None) -> np.ndarray:
     """Run the selected stages for a list of molecules in ONE launch; returns the
     structured record array (``_lib.UNIT_OUT_DTYPE``).  ``params``: ``_lib.Params`` for
-    non-default find_windows / find_average_diameter knobs."""
-    return context(device).analyse(make_batch(molecules), stages, params)
+    non-default find_windows / find_average_diameter knobs.  ``extra``: a list that receives the
+    windows beyond ``_lib.W_MAX`` (see :func:`windows_of`)."""
+    return context(device).analyse(make_batch(molecules), stages, params, extra)
 
 
-def windows_of(rec):
-    """(diameters, centres) arrays or None, as ``find_windows`` returns them."""
+def extra_by_unit(extra) -> dict:
+    """``{unit: (diameters, centres)}`` from the ``EXTRA_WINDOW_DTYPE`` arrays an analysis appended to its
+    ``extra`` list (entries are ordered by unit, then by position)."""
+    out: dict = {}
+    for arr in extra or ():
+        for u in np.unique(arr["unit"]):
+            rows = arr[arr["unit"] == u]
+            out[int(u)] = (rows["d"].copy(), rows["c"].copy())
+    return out
+
+
+def windows_of(rec, more=None):
+    """(diameters, centres) arrays or None, as ``find_windows`` returns them (utilities.py:1526-1553).
+    ``more``: this unit's entry of :func:`extra_by_unit` -- a record holds ``_lib.W_MAX`` windows, the
+    reference any number.  No survivors -> ``None``; survivors but only noise -> two empty arrays, the
+    centres of shape ``(0,)`` like the reference's ``np.array([])``."""
     n = int(rec["n_windows"])
     if n < 0:
         return None
-    return np.array(rec["win_d"][:n]), np.array(rec["win_c"][:n]).reshape(n, 3)
+    if n == 0:
+        return np.array([]), np.array([])
+    k = min(n, _lib.W_MAX)
+    d, c = np.array(rec["win_d"][:k]), np.array(rec["win_c"][:k]).reshape(k, 3)
+    if n > k:
+        if more is None or len(more[0]) != n - k:
+            raise _lib.PwHipError(f"{n} windows but only {k} in the record: pass the analysis' extra-window list")
+        d, c = np.concatenate([d, more[0]]), np.concatenate([c, more[1]])
+    return d, c
+
+
+def raise_on_capacity(rec) -> None:
+    """A result that the engine could not compute is an error, never a value: more sampling vectors than
+    the workspace of the launch held (``pw_analysis_batch`` grows it and repeats, so this only shows on
+    the resident path) is raised here."""
+    st = int(rec["status"])
+    if st & _lib.ST_POINTS_OVERFLOW:
+        raise _lib.PwHipError(
+            f"sampling-vector workspace too small (find_windows wants {int(rec['n_points'])}, find_average_diameter "
+            f"{int(rec['n_points_avg'])}): analyse through pw_analysis_batch / Context.analyse, which grows it")
 
 
 #: what scipy.optimize.minimize raises inside the reference's opt_pore_diameter / find_windows when the
@@ -130,17 +164,30 @@ def warn_like_reference(rec) -> None:
         logger.warning(
             "Warning. One of the analysed windows has a vdW corrected diameter smaller than 0. See manual."
         )
-    if st & (_lib.ST_WINDOW_OVERFLOW | _lib.ST_POINTS_OVERFLOW):
-        logger.warning("pywindow_amd: workspace limit hit (status=%d); results truncated.", st)
+    if st & _lib.ST_POINTS_OVERFLOW:
+        logger.warning("pywindow_amd: sampling-vector workspace too small for this unit (status=%d): its average "
+                       "diameter is NaN and its windows None -- NOT results.", st)
+    if st & _lib.ST_TOO_FEW_POINTS:
+        logger.warning("pywindow_amd: fewer than ten sampling vectors; the reference raises ValueError here "
+                       "(KDTree.query(k=10)) -- the windows of this molecule are not computed.")
 
 
-def records_to_properties(recs: np.ndarray, stages: int = _lib.STAGE_ALL) -> list:
+def offset_extra(extra: np.ndarray, offset: int) -> np.ndarray:
+    """The extra-window entries of a piece of a batch, renumbered to the whole batch."""
+    out = extra.copy()
+    out["unit"] += offset
+    return out
+
+
+def records_to_properties(recs: np.ndarray, stages: int = _lib.STAGE_ALL, extra=None) -> list:
     """Many records -> the nested dicts of ``record_to_properties``, column-wise: every field is
     converted to Python objects once for the whole array (the per-record route spends its time in
-    numpy scalar look-ups), and the conditions the reference logs are reported on the way."""
+    numpy scalar look-ups), and the conditions the reference logs are reported on the way.
+    ``extra``: the ``EXTRA_WINDOW_DTYPE`` entries of these records (windows beyond ``_lib.W_MAX``)."""
     n = len(recs)
     if n == 0:
         return []
+    more = extra_by_unit([extra]) if extra is not None and len(extra) else {}
     for rec in recs[recs["status"] != 0]:
         warn_like_reference(rec)
     n_atoms = recs["n_atoms"].tolist()
@@ -170,14 +217,18 @@ def records_to_properties(recs: np.ndarray, stages: int = _lib.STAGE_ALL) -> lis
             k = n_win[i]
             if k < 0:
                 props["windows"] = {"diameters": None, "centre_of_mass": None}
-            else:
+            elif 0 < k <= _lib.W_MAX:
                 props["windows"] = {"diameters": win_d[i, :k].copy(), "centre_of_mass": win_c[i, :k].copy()}
+            else:           # none (two empty arrays, as the reference builds them) or more than a record holds
+                d, c = windows_of(recs[i], more.get(i))
+                props["windows"] = {"diameters": d, "centre_of_mass": c}
         out.append(props)
     return out
 
 
-def record_to_properties(rec, stages: int = _lib.STAGE_ALL) -> dict:
-    """One result record -> the nested dict ``Molecule.full_analysis()`` returns."""
+def record_to_properties(rec, stages: int = _lib.STAGE_ALL, more=None) -> dict:
+    """One result record -> the nested dict ``Molecule.full_analysis()`` returns.  ``more``: the unit's
+    windows beyond ``_lib.W_MAX`` as ``(diameters, centres)`` (:func:`extra_by_unit`)."""
     props: dict = {"no_of_atoms": int(rec["n_atoms"])}
     props["centre_of_mass"] = np.array(rec["com"])
     props["maximum_diameter"] = {
@@ -197,7 +248,7 @@ def record_to_properties(rec, stages: int = _lib.STAGE_ALL) -> dict:
         }
         props["pore_volume_opt"] = float(rec["pore_vol_opt"])
     if stages & _lib.STAGE_WINDOWS:
-        win = windows_of(rec)
+        win = windows_of(rec, more)
         if win is None:
             props["windows"] = {"diameters": None, "centre_of_mass": None}
         else:

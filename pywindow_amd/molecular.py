@@ -93,8 +93,11 @@ class Molecule:
         for have, rec in self._cache.items():
             if have & stages == stages:
                 return rec
-        rec = engine.analyse([(self.elements, self.coordinates)], stages)[0]
+        extra: list = []
+        rec = engine.analyse([(self.elements, self.coordinates)], stages, extra=extra)[0]
+        engine.raise_on_capacity(rec)
         self._cache = {stages: rec}
+        self._more = engine.extra_by_unit(extra).get(0)      # windows beyond what a record holds
         return rec
 
     def _invalidate(self):
@@ -113,11 +116,15 @@ class Molecule:
             self.calculate_pore_volume()
             engine.raise_like_reference(rec)
         self._fill_from(rec)
+        if int(rec["status"]) & _lib.ST_TOO_FEW_POINTS:
+            # molecular.py:200 -> utilities.py:1428-1431: KDTree.query(k=10) on fewer than ten sampling vectors
+            del self.properties["windows"]
+            raise ValueError("k must be less than or equal to the number of training points")
         return self.properties
 
     def _fill_from(self, rec):
         engine.warn_like_reference(rec)
-        props = engine.record_to_properties(rec)
+        props = engine.record_to_properties(rec, more=getattr(self, "_more", None))
         self.MW = float(rec["mw"])
         self.centre_of_mass = props["centre_of_mass"]
         md = props["maximum_diameter"]
@@ -188,7 +195,9 @@ class Molecule:
         r = self._record(_lib.STAGE_WINDOWS)
         engine.raise_like_reference(r)
         engine.warn_like_reference(r)
-        win = engine.windows_of(r)
+        if int(r["status"]) & _lib.ST_TOO_FEW_POINTS:
+            raise ValueError("k must be less than or equal to the number of training points")
+        win = engine.windows_of(r, getattr(self, "_more", None))
         if win is not None:
             self.properties["windows"] = {"diameters": win[0], "centre_of_mass": win[1]}
             return win[0]

@@ -170,14 +170,17 @@ class DLPOLY:
             raise _FunctionError("Didn't recognise the keyword. (see manual)")
         raise _FunctionError("frames must be an int, a list of ints, a (start, stop) tuple or 'all'")
 
-    def save_analysis(self, filepath=None, **kwargs) -> None:  # noqa: ARG002
-        """Dump ``analysis_output`` as JSON (reference trajectory.py:251-271: arrays become
-        lists, frame numbers become string keys)."""
+    def save_analysis(self, filepath=None, override: bool = False) -> None:
+        """Dump ``analysis_output`` as JSON (reference trajectory.py:251-271 -> io_tools.py:215-265: arrays
+        become lists, frame numbers string keys; ``.json`` is appended unless the file name contains it;
+        an existing file is only replaced with ``override=True`` -- ``FileExistsError`` otherwise)."""
         import json
 
         path = pathlib.Path(filepath) if filepath is not None else pathlib.Path.cwd() / f"{self.system_id}_pywindow_analysis"
-        if path.suffix != ".json":
+        if ".json" not in path.name:
             path = path.with_suffix(".json")
+        if override is False and path.is_file():
+            raise FileExistsError(f"The file {path} already exists. Use a different filepath, or set the 'override' to True.")
 
         def enc(obj):
             if isinstance(obj, np.ndarray):
@@ -185,7 +188,7 @@ class DLPOLY:
             raise TypeError("Not serializable")
 
         # (dumps, not dump: one pass of the C encoder instead of the chunk-by-chunk Python iterator)
-        path.write_text(json.dumps({str(k): v for k, v in self.analysis_output.items()}, default=enc))
+        path.write_text(json.dumps(self.analysis_output, default=enc))
 
     def analysis_records(self, frames="all", swap_atoms=None, forcefield=None, device=None) -> np.ndarray:
         """Columnar results: the structured record array (``_lib.UNIT_OUT_DTYPE``) for the
@@ -230,9 +233,12 @@ class DLPOLY:
             recs = self._run(mine, vdw, mass, device)
             if dist is not None and world > 1:
                 recs = gather_records(recs, len(sel), rank, world, dist)
+        extra = engine.offset_extra(getattr(self, "_extra", np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE)), lo)
+        if dist is not None and world > 1:
+            extra = gather_extra(extra, rank, world, dist, device)
         if rank != 0:
             return
-        for f, props in zip(sel, engine.records_to_properties(recs)):
+        for f, props in zip(sel, engine.records_to_properties(recs, extra=extra)):
             self.analysis_output[f] = {"0": props}
 
     def _run(self, frames: list[int], vdw, mass, device):
@@ -240,13 +246,18 @@ class DLPOLY:
         GPU analyses one piece (its launches are asynchronous) the host threads of the native reader
         tokenise the next, so the text parsing -- 1.3 ms per 1000 frames -- hides behind the kernels
         instead of preceding them (10 000 frames, file to records: 35 -> 26.5 ms)."""
+        self._extra = np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE)   # windows beyond what a record holds, by unit
         if not frames:
             return np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE)
         n = len(frames)
         pieces = 1 if n < 2 * RUN_PIECE_MIN else min(-(-n // RUN_PIECE_MIN), -(-n // RUN_PIECE) if n > 2 * RUN_PIECE else 2)
         if pieces <= 1:
             coords, _ = self._read_selected(frames, False)
-            return engine.context(device).analyse(_lib.Batch.uniform(coords, vdw, mass), _lib.STAGE_ALL)
+            extra: list = []
+            recs = engine.context(device).analyse(_lib.Batch.uniform(coords, vdw, mass), _lib.STAGE_ALL, extra=extra)
+            if extra:
+                self._extra = extra[0]
+            return recs
         ctx = engine.context(device)
         per = -(-n // pieces)
         inflight = []
@@ -256,7 +267,15 @@ class DLPOLY:
                 res = ctx.upload(_lib.Batch.uniform(coords, vdw, mass))
                 res.launch(_lib.STAGE_ALL)
                 inflight.append(res)
-            return np.concatenate([res.download() for res in inflight])
+            parts, extras, at = [], [], 0
+            for res in inflight:
+                extra = []
+                parts.append(res.download(extra))
+                extras += [engine.offset_extra(e, at) for e in extra]
+                at += res.n_units
+            if extras:
+                self._extra = np.concatenate(extras)
+            return np.concatenate(parts)
         finally:
             for res in inflight:
                 res.free()
@@ -270,8 +289,18 @@ class DLPOLY:
             coords, _ = self._read_selected(frames, False)
             res = engine.context(dev).upload(_lib.Batch.uniform(coords, vdw, mass))
             res.launch(_lib.STAGE_ALL)
+        self._extra = np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE)
         try:
-            return gather_records_device(res, n_total, rank, world, dist, torch.device("cuda", dev))
+            recs = gather_records_device(res, n_total, rank, world, dist, torch.device("cuda", dev))
+            if res is not None:
+                # the gather read the records on the device; what only the host can see comes now: a
+                # window launch that timed out (raises), and the windows beyond what a record holds
+                try:
+                    self._extra = res.check()
+                except _lib.PwRetry:
+                    res.launch(_lib.STAGE_ALL)
+                    self._extra = res.check()
+            return recs
         finally:
             if res is not None:
                 res.free()
@@ -306,9 +335,15 @@ class DLPOLY:
         piece = MODULAR_CHUNK if n < 2 * MODULAR_PIECE else min(MODULAR_CHUNK, MODULAR_PIECE)
         parts, waiting, spent = [], [], []
 
+        extras: list = []
+        done = [0]
+
         def collect(entry):
             res, n_mol = entry
-            recs = res.download() if res is not None else np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE)
+            extra: list = []
+            recs = res.download(extra) if res is not None else np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE)
+            extras.extend(engine.offset_extra(e, done[0]) for e in extra)
+            done[0] += len(recs)
             if res is not None:
                 spent.append(res)          # (released at the end: freeing device memory waits for the whole device)
             parts.append((recs, n_mol))
@@ -348,6 +383,7 @@ class DLPOLY:
                 if res is not None:
                     res.free()
         recs = np.concatenate([p[0] for p in parts])
+        self._extra = np.concatenate(extras) if extras else np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE)
         n_mol = np.concatenate([p[1] for p in parts])
         unit_frame = np.repeat(np.asarray(frames, np.int64), n_mol)
         unit_mol = (np.concatenate([np.arange(k) for k in n_mol]).astype(np.int64) if len(n_mol)
@@ -364,9 +400,13 @@ class DLPOLY:
         dist, rank, world = _dist_state(distributed)
         lo, hi = shard_range(len(sel), rank, world)
         recs, uframe, umol = self._run_modular(sel[lo:hi], rebuild, el, device)
+        extra = getattr(self, "_extra", np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE))
         if dist is not None and world > 1:
             tags = np.stack([uframe, umol], axis=1).astype(np.int64)
             dev = engine.resolve_device(device)
+            # (units are numbered rank after rank in the gathered arrays)
+            first = _exclusive_offset(np.array([len(recs)], np.int64), rank, world, dist, dev)
+            extra = gather_extra(engine.offset_extra(extra, first), rank, world, dist, dev)
             recs = gather_ragged(recs, rank, world, dist, dev)
             tags = gather_ragged(tags.reshape(-1), rank, world, dist, dev)
             if rank != 0:
@@ -375,7 +415,7 @@ class DLPOLY:
             uframe, umol = tags[:, 0], tags[:, 1]
         for f in sel:
             self.analysis_output[f] = {}
-        for props, f, m in zip(engine.records_to_properties(recs), uframe.tolist(), umol.tolist()):
+        for props, f, m in zip(engine.records_to_properties(recs, extra=extra), uframe.tolist(), umol.tolist()):
             self.analysis_output[f][m] = props
 
 
@@ -420,6 +460,32 @@ def gather_ragged(local: np.ndarray, rank: int, world: int, dist, device: int | 
         return np.zeros(0, dtype=local.dtype)
     parts = [recv[r].cpu().numpy()[: sizes[r]] for r in range(world)]
     return np.concatenate(parts).view(local.dtype)
+
+
+def _exclusive_offset(count: np.ndarray, rank: int, world: int, dist, device) -> int:
+    """Number of units on the ranks before this one (one all_gather of a counter)."""
+    import torch
+
+    dev = _collective_device(dist, device)
+    mine = torch.tensor([int(count[0])], dtype=torch.int64, device=dev)
+    alls = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(alls, mine)
+    return int(sum(int(a.item()) for a in alls[:rank]))
+
+
+def gather_extra(extra: np.ndarray, rank: int, world: int, dist, device=None) -> np.ndarray:
+    """Windows beyond what a record holds, from every rank to rank 0 (``unit`` already numbered for the
+    whole job).  Almost always there are none anywhere: one all-reduce of a flag says so and nothing
+    else is exchanged."""
+    import torch
+
+    dev = _collective_device(dist, device)
+    flag = torch.tensor([1 if len(extra) else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()) == 0:
+        return extra
+    out = gather_ragged(extra, rank, world, dist, device)
+    return out if rank == 0 else extra
 
 
 def gather_records(local: np.ndarray, n_total: int, rank: int, world: int, dist, device: int | None = None) -> np.ndarray:

@@ -81,7 +81,9 @@ def find_average_diameter(elements, coordinates, adjust=1, processes=None) -> fl
     ``processes`` is accepted and ignored (there is no CPU pool)."""
     del processes
     params = None if adjust == 1 else _lib.Params(adjust_average=adjust)
-    return float(_one(elements, coordinates, _lib.STAGE_AVG, params)["avg_d"])
+    r = _one(elements, coordinates, _lib.STAGE_AVG, params)
+    engine.raise_on_capacity(r)
+    return float(r["avg_d"])
 
 
 def find_windows(elements, coordinates, processes=None, adjust=1, pore_opt=True, increment=1.0,
@@ -101,7 +103,12 @@ def find_windows(elements, coordinates, processes=None, adjust=1, pore_opt=True,
     params = None if default else _lib.Params(
         adjust_windows=adjust, pore_opt=pore_opt is True, increment=increment, increment2=increment2,
         z_bounds=z_bounds, lb_z=bool(lb_z), z_second_mini=z_second_mini)
-    r = _one(elements, coordinates, _lib.STAGE_WINDOWS, params)
+    extra: list = []
+    r = engine.analyse([(elements, coordinates)], _lib.STAGE_WINDOWS, params=params, extra=extra)[0]
+    engine.raise_on_capacity(r)
+    if int(r["status"]) & _lib.ST_TOO_FEW_POINTS:
+        # sklearn's KDTree.query(k=10) raises this inside the reference (utilities.py:1428-1431)
+        raise ValueError("k must be less than or equal to the number of training points")
     if int(r["status"]) & _lib.ST_Z_BOUNDS:
         # scipy.optimize.minimize raises this from inside the reference's window_analysis
         raise ValueError("An upper bound is less than the corresponding lower bound.")
@@ -110,7 +117,7 @@ def find_windows(elements, coordinates, processes=None, adjust=1, pore_opt=True,
         engine.warn_like_reference(r)
     else:
         engine.warn_like_reference(np.array(int(r["status"]) & ~_lib.ST_NEGATIVE_PORE, dtype=[("status", np.int32)]))
-    return engine.windows_of(r)
+    return engine.windows_of(r, engine.extra_by_unit(extra).get(0))
 
 
 # ---- shape descriptors and circumcircles (reference utilities.py:434-650, 1653-1691) ---------------

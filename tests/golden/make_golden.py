@@ -651,6 +651,130 @@ def run_options(pool):
     print("options:", names, [r[0].tolist() for r in res])
 
 
+
+# ---- capacity cliffs the reference does not have: many sampling vectors, many windows,
+# ---- very few vectors, dropped / negative windows --------------------------------------------------------
+CLIFF_W = 64          # windows a cliff fixture row holds
+CLIFF_WINDOW_ADJUST = [0.05, 2.6, 3.0, 4.0]
+CLIFF_AVERAGE_ADJUST = [2.2, 3.0]
+
+
+def cliff_call(args):
+    """One call of the reference's find_windows / find_average_diameter with the log messages it emits and
+    the exception it raises, if any (utilities.py:1364-1553, 1586-1650)."""
+    kind, elements, coords, kwargs = args
+    load_reference()
+    from pywindow._internal import utilities as U
+
+    class Grab(logging.Handler):
+        def __init__(self):
+            super().__init__()
+            self.msgs = []
+
+        def emit(self, record):
+            self.msgs.append(record.getMessage())
+
+    grab = Grab()
+    U.logger.addHandler(grab)
+    out = {"n_win": -1, "win_d": np.zeros(CLIFF_W), "win_c": np.zeros((CLIFF_W, 3)), "avg": np.nan,
+           "centre_shape": (), "error": "", "dropped": 0, "negative": 0}
+    kwargs = dict(kwargs)
+    plain = U.window_analysis
+    if "increment2" in kwargs:
+        # a keyword of window_analysis (utilities.py:1191-1200) that find_windows never passes: bound here
+        import functools
+
+        U.window_analysis = functools.partial(plain, increment2=kwargs.pop("increment2"))
+    try:
+        if kind == "win":
+            res = U.find_windows(np.array(elements), np.array(coords, float), **kwargs)
+            if res is not None:
+                k = len(res[0])
+                assert k <= CLIFF_W
+                out["n_win"] = k
+                out["win_d"][:k] = res[0]
+                out["centre_shape"] = np.array(res[1]).shape
+                if k:
+                    out["win_c"][:k] = res[1]
+        else:
+            out["avg"] = float(U.find_average_diameter(np.array(elements), np.array(coords, float), **kwargs))
+    except Exception as exc:  # noqa: BLE001 - the fixture records what the reference raises
+        out["error"] = f"{type(exc).__name__}: {exc}"
+    finally:
+        U.logger.removeHandler(grab)
+        U.window_analysis = plain
+    out["dropped"] = sum("returned as None" in m for m in grab.msgs)
+    out["negative"] = sum("smaller than 0" in m for m in grab.msgs)
+    return out
+
+
+def hollow_shell(radius=11.0, spacing=1.45, holes=20, hole_radius=3.1):
+    """A constructed molecule with MANY windows: carbon atoms on a sphere (golden spiral), with the atoms
+    around `holes` evenly spread directions removed.  Hydrogen-free, pore at the centre."""
+    n = int(4 * np.pi * radius**2 / spacing**2)
+    k = np.arange(n)
+    z = 1 - (2 * k + 1) / n
+    th = k * np.pi * (3 - np.sqrt(5))
+    ring = np.sqrt(1 - z * z)
+    pts = radius * np.c_[ring * np.cos(th), ring * np.sin(th), z]
+    m = np.arange(holes)
+    hz = 1 - (2 * m + 1) / holes
+    hth = m * np.pi * (3 - np.sqrt(5)) + 0.3
+    hr = np.sqrt(1 - hz * hz)
+    dirs = radius * np.c_[hr * np.cos(hth), hr * np.sin(hth), hz]
+    keep = np.ones(n, bool)
+    for d in dirs:
+        keep &= np.linalg.norm(pts - d, axis=1) > hole_radius
+    pts = pts[keep] + np.array([12.0, 11.0, 13.0])
+    return np.array(["C"] * len(pts)), np.round(pts, 6)
+
+
+def cliff_cases():
+    n, e, x = static_cases()
+    mols = {k: (np.array(e[n.index(k)]), np.array(x[n.index(k)], float)) for k in ("cc3", "windows_case_5", "windows_case_2")}
+    calls = []          # (label, kind, molecule, kwargs)
+    for name in ("cc3", "windows_case_5", "windows_case_2"):
+        for a in CLIFF_WINDOW_ADJUST:
+            calls.append((f"{name}/win/adjust={a}", "win", name, {"adjust": a}))
+        for a in CLIFF_AVERAGE_ADJUST:
+            calls.append((f"{name}/avg/adjust={a}", "avg", name, {"adjust": a}))
+    # fewer than ten sampling vectors: KDTree.query(k=10) raises; ten to fifteen: fine
+    for a in (0.008, 0.0135, 0.018):
+        calls.append((f"cc3/win/adjust={a}", "win", "cc3", {"adjust": a}))
+    mols["shell20"] = hollow_shell()
+    mols["shell32"] = hollow_shell(radius=14.0, holes=32, hole_radius=3.0)
+    for name in ("shell20", "shell32"):
+        calls.append((f"{name}/win/default", "win", name, {}))
+        calls.append((f"{name}/avg/default", "avg", name, {}))
+    return mols, calls
+
+
+def run_cliffs(pool, extra=None):
+    mols, calls = cliff_cases()
+    if extra:
+        for name, (el, xyz) in extra["mols"].items():
+            mols[name] = (np.array(el), np.array(xyz, float))
+        calls += extra["calls"]
+    res = pool.map(cliff_call, [(kind, mols[m][0], mols[m][1], kw) for _, kind, m, kw in calls])
+    names = sorted(mols)
+    off = np.concatenate([[0], np.cumsum([len(mols[k][0]) for k in names])])
+    np.savez_compressed(
+        HERE / "cliffs.npz",
+        mol_names=np.array(names), atom_offset=off,
+        elements=np.concatenate([mols[k][0] for k in names]), coordinates=np.concatenate([mols[k][1] for k in names]),
+        labels=np.array([c[0] for c in calls]), kinds=np.array([c[1] for c in calls]),
+        mol_of_call=np.array([names.index(c[2]) for c in calls]),
+        kwargs=np.array([json.dumps(c[3]) for c in calls]),
+        n_windows=np.array([r["n_win"] for r in res]), win_d=np.array([r["win_d"] for r in res]),
+        win_c=np.array([r["win_c"] for r in res]), avg_d=np.array([r["avg"] for r in res]),
+        centre_ndim=np.array([len(r["centre_shape"]) for r in res]),
+        error=np.array([r["error"] for r in res]), dropped=np.array([r["dropped"] for r in res]),
+        negative=np.array([r["negative"] for r in res]),
+    )
+    for c, r in zip(calls, res):
+        print("cliffs:", c[0], "->", r["n_win"] if c[1] == "win" else r["avg"], r["error"], "dropped", r["dropped"], "negative", r["negative"])
+
+
 def rebuild_case(args):
     """discrete_molecules / create_supercell of the reference (utilities.py:768-1085) on one system."""
     name, system = args
@@ -861,6 +985,28 @@ def run_nonporous():
     print("nonporous:", msgs, list(p))
 
 
+def run_json():
+    """Trajectory.save_analysis of the reference (trajectory.py:251-271, io_tools.py:215-265) on three
+    frames of its own 20-frame trajectory: the JSON text it writes."""
+    import tempfile
+
+    pw = load_reference()
+    traj = pw.DLPOLY(REF / "examples/data/input/HISTORY_singlemol_short")
+    traj.analysis(frames=[0, 7, 19], swap_atoms={"he": "H"}, forcefield="opls")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = pathlib.Path(tmp) / "analysis"
+        traj.save_analysis(out)
+        text = (pathlib.Path(tmp) / "analysis.json").read_text()
+        try:
+            traj.save_analysis(out)
+            second = ""
+        except FileExistsError as exc:
+            second = str(exc).replace(str(pathlib.Path(tmp)), "<dir>")
+    (HERE / "history_analysis_3frames.json").write_text(text)
+    (HERE / "history_analysis_3frames.meta.json").write_text(json.dumps({"frames": [0, 7, 19], "second_save": second}))
+    print("json:", len(text), "bytes;", second)
+
+
 def run_tables():
     """The per-element constants of the path as the reference holds them (tables.py:22-286: mass,
     van der Waals and covalent radius, 85 upper-case keys each) and its OPLS atom-key table
@@ -916,11 +1062,13 @@ def run_history20():
 
 
 def main():
-    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj", "optopt", "winopt", "shape", "tables", "history20", "axes", "nonporous"}
+    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj", "optopt", "winopt", "shape", "tables", "history20", "axes", "nonporous", "cliffs", "json"}
     if "tables" in which:
         run_tables()
     if "history20" in which:
         run_history20()
+    if "json" in which:
+        run_json()
     if "nonporous" in which:
         run_nonporous()
     if "cc3base" in which:
@@ -962,6 +1110,15 @@ def main():
             run_shape(pool)
         if "axes" in which:
             run_axes(pool)
+        if "cliffs" in which:
+            extra = None
+            cases = HERE / "cliff_extra_cases.npz"      # found by tests/tools/find_edge_cases.py
+            if cases.exists():
+                z = np.load(cases)
+                extra = {"mols": {str(k): (z[f"{k}__el"], z[f"{k}__xyz"]) for k in z["names"]},
+                         "calls": [(str(lbl), "win", str(m), json.loads(str(kw)))
+                                   for lbl, m, kw in zip(z["labels"], z["mol"], z["kwargs"])]}
+            run_cliffs(pool, extra)
     meta = {
         "generator": "tests/golden/make_golden.py",
         "reference": "marcinmiklitz/pywindow @ /root/reference (imported with rdkit stub)",

@@ -9,7 +9,15 @@
 #include <string.h>
 using namespace pw;
 static int run_batch(long n_units, const long* off, const double* xyz, const double* vdw, const double* mass,
-                     unsigned stages, pw_unit_out* out, const pw_params* params, pw_unit_debug* dbg);
+                     unsigned stages, pw_unit_out* out, const pw_params* params, pw_unit_debug* dbg,
+                     int p_cap = 0, pw_extra_window* xw = nullptr, unsigned xw_cap = 0, unsigned* xw_count = nullptr);
+// the same with an explicit sampling-vector capacity (0: from the adjust knobs, as the library sizes it) and
+// the list of windows beyond PW_W_MAX
+extern "C" int hs_analysis_ext(long n_units, const long* off, const double* xyz, const double* vdw,
+                               const double* mass, unsigned stages, pw_unit_out* out, const pw_params* params,
+                               int p_cap, pw_extra_window* xw, unsigned xw_cap, unsigned* xw_count) {
+    return run_batch(n_units, off, xyz, vdw, mass, stages, out, params, nullptr, p_cap, xw, xw_cap, xw_count);
+}
 extern "C" int hs_analysis_batch(long n_units, const long* off, const double* xyz, const double* vdw,
                                  const double* mass, unsigned stages, pw_unit_out* out,
                                  const pw_params* params) {
@@ -23,16 +31,25 @@ extern "C" int hs_analysis_debug(long n_units, const long* off, const double* xy
 }
 extern "C" int hs_sizeof_unit_debug() { return (int)sizeof(pw_unit_debug); }
 static int run_batch(long n_units, const long* off, const double* xyz, const double* vdw, const double* mass,
-                     unsigned stages, pw_unit_out* out, const pw_params* params, pw_unit_debug* dbg) {
+                     unsigned stages, pw_unit_out* out, const pw_params* params, pw_unit_debug* dbg,
+                     int p_cap, pw_extra_window* xw, unsigned xw_cap, unsigned* xw_count) {
     pw_params prm = default_params();
     if (params) prm = *params;
+    if (p_cap <= 0) p_cap = params_p_cap(prm.adjust_windows, prm.adjust_average);
+    p_cap = round_p_cap(p_cap);
+    unsigned dummy_count = 0;
+    if (!xw_count) xw_count = &dummy_count;
+    *xw_count = 0;
     int nmax = 0;
     for (long u = 0; u < n_units; ++u) { int n = (int)(off[u + 1] - off[u]); if (n > nmax) nmax = n; }
-    size_t bytes = UnitShared::bytes(nmax, 1, 1);
+    size_t bytes = UnitShared::bytes(nmax, 1, 1, 2, false, p_cap);
     unsigned char* lds = (unsigned char*)aligned_alloc(16, (bytes + 15) & ~(size_t)15);
-    TeamWorkspace* ws = (TeamWorkspace*)malloc(sizeof(TeamWorkspace));
-    if (!lds || !ws) return -5;
-    ws->adj = (unsigned long long*)malloc(sizeof(unsigned long long) * PW_ADJ_WORDS);
+    TeamWorkspace* ws = (TeamWorkspace*)calloc(1, sizeof(TeamWorkspace));
+    unsigned char* slab = (unsigned char*)malloc(team_slab_bytes(p_cap));
+    if (!lds || !ws || !slab) return -5;
+    bind_team_slab(ws, slab, p_cap);
+    ws->adj = (unsigned long long*)malloc(sizeof(unsigned long long) * team_adj_words(p_cap));
+    ws->xwin = xw; ws->xwin_cap = xw_cap; ws->xwin_count = xw_count;
     static unsigned rsq_tab[65536];
     static bool rsq_ready = false;
     if (!rsq_ready) { rsqrt14_decode(rsq_tab); rsq_ready = true; }
@@ -56,19 +73,19 @@ static int run_batch(long n_units, const long* off, const double* xyz, const dou
             if ((fa || fb) && a < b) memset(lds + a, fill, b - a);
         }
         UnitShared sh;
-        sh.carve(lds, nmax, 1, 1);
+        sh.carve(lds, nmax, 1, 1, 2, false, p_cap);
         int n = (int)(off[u + 1] - off[u]);
         memset(&out[u], 0, sizeof(pw_unit_out));
         analyse_unit<HostTeam>(sh, ws, n, xyz + 3 * off[u], vdw + off[u], mass + off[u], stages, &out[u], prm);
     }
-    free(ws->adj); free(lds); free(ws);
+    free(ws->adj); free(slab); free(lds); free(ws);
     return 0;
 }
 extern "C" int hs_sizeof_unit_out() { return (int)sizeof(pw_unit_out); }
 // DBSCAN(eps, min_samples = 5) as the one-thread team computes it (the same source as pw_dbscan); points n x 3
 extern "C" int hs_dbscan(const double* points, long n, double eps, int* labels) {
-    static unsigned long long bits[3][PW_P_MAX / 64];
-    if (n > PW_P_MAX) return -2;
+    static unsigned long long bits[3][PW_DBSCAN_MAX / 64];
+    if (n > PW_DBSCAN_MAX) return -2;
     std::vector<double> soa((size_t)3 * n);
     std::vector<int> ident((size_t)n);
     for (long i = 0; i < n; ++i) {
@@ -76,8 +93,10 @@ extern "C" int hs_dbscan(const double* points, long n, double eps, int* labels) 
         ident[i] = (int)i;
     }
     TeamWorkspace* ws = (TeamWorkspace*)calloc(1, sizeof(TeamWorkspace));
-    std::vector<unsigned long long> adj((size_t)PW_ADJ_WORDS);
+    const int p_cap = round_p_cap(n);
+    std::vector<unsigned long long> adj(team_adj_words(p_cap));
     ws->adj = adj.data();
+    ws->p_cap = p_cap;
     ScratchArena arena;
     arena.cur = nullptr;
     arena.left = 0;

@@ -200,3 +200,53 @@ def test_element_tables_equal_the_reference():
     assert hashlib.sha256(text.encode()).hexdigest() == str(g["sha256"])
     assert (E.atomic_mass["C"], E.atomic_vdw_radius["C"]) == (12.011, 1.7)
     assert (E.atomic_mass["H"], E.atomic_vdw_radius["H"]) == (1.008, 1.09)
+
+
+def test_save_analysis_override_semantics(tmp_path):
+    """Trajectory.save_analysis (reference trajectory.py:251-271 -> io_tools.py:215-265): '.json' is
+    appended unless the name contains it, an existing file raises FileExistsError with the reference's
+    message unless override=True."""
+    import json
+
+    g = np.load(_util_golden() / "history20.npz")
+    path = tmp_path / "HISTORY_singlemol_short"
+    path.write_bytes(g["file_bytes"].tobytes())
+    traj = DLPOLY(path)
+    traj.analysis_output = {3: {"0": {"no_of_atoms": 168, "centre_of_mass": np.array([1.0, 2.0, 3.0]),
+                                      "windows": {"diameters": None, "centre_of_mass": None}}}}
+    out = tmp_path / "analysis"
+    traj.save_analysis(out)
+    written = tmp_path / "analysis.json"
+    assert json.loads(written.read_text()) == {"3": {"0": {"no_of_atoms": 168, "centre_of_mass": [1.0, 2.0, 3.0],
+                                                          "windows": {"diameters": None, "centre_of_mass": None}}}}
+    meta = json.loads((_util_golden() / "history_analysis_3frames.meta.json").read_text())
+    with pytest.raises(FileExistsError) as exc:
+        traj.save_analysis(out)
+    assert str(exc.value) == meta["second_save"].replace("<dir>", str(tmp_path))
+    with pytest.raises(FileExistsError):
+        traj.save_analysis(written)                     # the name already carries .json: not doubled
+    traj.analysis_output[3]["0"]["no_of_atoms"] = 1
+    traj.save_analysis(out, override=True)
+    assert json.loads(written.read_text())["3"]["0"]["no_of_atoms"] == 1
+    traj.save_analysis(tmp_path / "other.json.bak")     # '.json' in the name: kept as it is
+    assert (tmp_path / "other.json.bak").is_file()
+
+
+@pytest.mark.gpu
+def test_saved_analysis_equals_the_reference_file(tmp_path):
+    """DLPOLY.analysis + save_analysis on three frames of the reference's own trajectory: the JSON text
+    is the one the reference writes (tests/golden/history_analysis_3frames.json, make_golden.py json) --
+    same keys in the same order, every float with the same digits."""
+    import json
+
+    g = np.load(_util_golden() / "history20.npz")
+    path = tmp_path / "HISTORY_singlemol_short"
+    path.write_bytes(g["file_bytes"].tobytes())
+    meta = json.loads((_util_golden() / "history_analysis_3frames.meta.json").read_text())
+    traj = DLPOLY(path)
+    traj.analysis(frames=meta["frames"], swap_atoms={"he": "H"}, forcefield="opls")
+    traj.save_analysis(tmp_path / "mine")
+    mine = (tmp_path / "mine.json").read_text()
+    theirs = (_util_golden() / "history_analysis_3frames.json").read_text()
+    assert json.loads(mine) == json.loads(theirs)
+    assert mine == theirs
