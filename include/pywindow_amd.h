@@ -13,8 +13,9 @@
  * Conventions: plain pointers and sizes, caller-allocated buffers, no
  * exceptions across the ABI -- every function returns 0 on success or a
  * negative PW_E_* code.  All arithmetic is IEEE double.  There is no CPU
- * fallback: without a usable HIP device every compute call fails with
- * PW_E_NO_DEVICE.
+ * FALLBACK: without a usable HIP device every compute call on a device context
+ * fails with PW_E_NO_DEVICE.  (A host context, pw_context_create(-1, ..), is an
+ * explicit choice of the caller and runs the same source on host threads.)
  */
 #ifndef PYWINDOW_AMD_H
 #define PYWINDOW_AMD_H
@@ -156,7 +157,15 @@ int pw_device_count(void);
 const char *pw_version(void);
 const char *pw_last_error(void);
 
+/* device >= 0: a HIP device ordinal.  device == -1: the explicit HOST path -- the same unit pipeline
+ * (pywindow_amd/csrc/pw_unit.hpp, single source with the kernels) compiled for the host and run by threads
+ * over the units; it serves pw_analysis_batch / pw_analysis_debug / pw_point_gaps and the pw_resident_*
+ * calls (batches then live in host memory), nothing else, and it is never chosen implicitly: a context
+ * for a device that does not exist fails with PW_E_NO_DEVICE.  (BASELINE.json configs[0].) */
 int pw_context_create(int device, pw_context **ctx);
+/* threads of a device == -1 context (default: PW_CPU_THREADS or the hardware concurrency); threads <= 0
+ * only reports.  Returns 0 for device contexts. */
+int pw_context_host_threads(pw_context *ctx, int threads);
 void pw_context_destroy(pw_context *ctx);
 /* knobs used by every later launch on this context (validated: adjust > 0, increment > 0) */
 void pw_params_default(pw_params *params);

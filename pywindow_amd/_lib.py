@@ -213,6 +213,7 @@ EXPORTED_SYMBOLS = [
     "pw_last_error",
     "pw_context_create",
     "pw_context_destroy",
+    "pw_context_host_threads",
     "pw_params_default",
     "pw_context_set_params",
     "pw_analysis_batch",
@@ -304,6 +305,7 @@ def load():
     L.pw_version.restype = ctypes.c_char_p
     L.pw_last_error.restype = ctypes.c_char_p
     L.pw_context_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.pw_context_host_threads.argtypes = [vp, ctypes.c_int]
     L.pw_context_destroy.argtypes = [vp]
     L.pw_context_destroy.restype = None
     L.pw_params_default.argtypes = [ctypes.POINTER(Params)]
@@ -403,14 +405,17 @@ class Batch:
 
 
 class Context:
-    """One GPU: stream + workspace.  ``device`` is the HIP ordinal."""
+    """One GPU: stream + workspace.  ``device`` is the HIP ordinal; ``-1`` is the explicit host path
+    (the same kernel source run by host threads, ``host_threads`` of them) -- never chosen implicitly."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, host_threads: int = 0):
         L = load()
         h = ctypes.c_void_p()
         _check(L.pw_context_create(device, ctypes.byref(h)), "pw_context_create")
         self._h = h
         self.device = device
+        if device < 0 and host_threads > 0:
+            L.pw_context_host_threads(h, int(host_threads))
         # params live on the context between set and reset: one analysis with params at a time
         import threading
 

@@ -15,7 +15,11 @@
 #include <hip/hip_runtime.h>
 #define PW_HD __host__ __device__
 #define PW_D __device__
+#ifdef PW_STATIC_NOINLINE
+#define PW_NOINLINE __attribute__((noinline)) static
+#else
 #define PW_NOINLINE __attribute__((noinline))
+#endif
 #else
 #define PW_NOINLINE
 #define PW_HD

@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <new>
@@ -26,6 +27,11 @@
 #include "pw_unit.hpp"
 
 using namespace pw;
+
+// pw_hostpath.cpp (g++): the unit pipeline for a one-lane team, host threads over the units
+extern "C" int pw_hostpath_run(const pw_batch_in* in, unsigned stages, pw_unit_out* out, const pw_params* prm, int p_cap,
+                               int threads, pw_unit_debug* dbg, pw_extra_window* xw, unsigned xw_cap, unsigned* xw_count);
+extern "C" int pw_hostpath_default_threads(void);
 
 namespace {
 
@@ -82,12 +88,33 @@ struct WsArgs {
     unsigned* xwin_count;
     unsigned xwin_cap;
     int p_cap;
+    const unsigned* nb_off;         // neighbour tables of the sampling sphere (pw_unit.hpp), null: none
+    const unsigned short* nb_idx;
+    const double* nb_bound;
 };
 __device__ inline void bind_workspace(TeamWorkspace* ws, const WsArgs& a, unsigned team, const unsigned* rsq_tab) {
     bind_team_slab(ws, a.slab + (size_t)team * team_slab_bytes(a.p_cap), a.p_cap);
     ws->adj = a.adj ? a.adj + (size_t)team * team_adj_words(a.p_cap) : nullptr;
     ws->xwin = a.xwin; ws->xwin_count = a.xwin_count; ws->xwin_cap = a.xwin_cap;
+    ws->nb_off = a.nb_off; ws->nb_idx = a.nb_idx; ws->nb_bound = a.nb_bound;
     ws->rsq = rsq_tab;
+}
+
+// Neighbour tables of the sampling sphere, one block per vector count P (pw_unit.hpp: nb_build_point): the
+// P unit vectors go to LDS, every thread tabulates the rows of its points.
+__global__ void __launch_bounds__(256) pw_nb_build_kernel(unsigned* __restrict__ off, unsigned short* __restrict__ idx,
+                                                          double* __restrict__ bound) {
+    __shared__ double ux[PW_NB_PMAX], uy[PW_NB_PMAX], uz[PW_NB_PMAX];
+    // (large P first: their blocks run longest)
+    const int P = PW_NB_PMAX - (int)blockIdx.x;
+    Sphere sp;
+    sp.init(1.0, P);
+    for (int k = threadIdx.x; k < P; k += blockDim.x) sp.point(k, &ux[k], &uy[k], &uz[k]);
+    __syncthreads();
+    const unsigned first = nb_dense_offset(P);
+    if (threadIdx.x == 0) off[P] = first;
+    for (int k = threadIdx.x; k < P; k += blockDim.x)
+        nb_build_point(P, k, ux, uy, uz, idx + (size_t)(first + k) * PW_NB_K, bound + first + k);
 }
 
 // MASK: the stage bits this instantiation can execute (the run-time mask is ANDed with it), so
@@ -372,10 +399,14 @@ struct pw_context {
     hipEvent_t ev0, ev1, ev_fork;
     int fused;               // PW_FUSED=1: one launch per analysis instead of the pipeline (also chosen when the
                              // streams of the pipeline do not run concurrently, see pw_context_create)
+    int host_threads;        // device == -1 (the explicit host path, pw_hostpath.cpp): threads over the units
     int concurrent_streams;  // how many of the pipeline's 2 + 2 x PW_SETS streams ran at the same time in the probe
     int c_waves;             // waves per team in the window launch (PW_C_WAVES, default 4)
     pw_params prm;           // knobs of find_windows / find_average_diameter
     unsigned* rsq_tab;       // VRSQRT14PD table on the device (numpy's arccos, pw_math.hpp)
+    unsigned* nb_off;        // neighbour tables of the sampling sphere for P = PW_NB_PMIN .. PW_NB_PMAX (pw_unit.hpp)
+    unsigned short* nb_idx;
+    double* nb_bound;
     // team workspaces of the pipeline: C0 | A0 | B | A1 | C1, each region sized for the largest grid
     // any launch on this context has asked for so far.  The layout only changes when a maximum
     // grows, and growing synchronises the device first, so two launches in flight -- which may have
@@ -389,7 +420,16 @@ struct pw_context {
     size_t pool_bytes;
 };
 
+// a batch "resident" on the host (contexts created with device = -1)
+struct HostBatch {
+    std::vector<int64_t> offset;
+    std::vector<double> xyz, vdw, mass;
+    std::vector<pw_unit_out> out;
+    int64_t template_atoms;
+};
+
 struct pw_resident {
+    HostBatch* host;         // non-null: the batch of a host context, everything below unused
     long n_units;
     long n_atoms;
     int nmax;
@@ -521,6 +561,7 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
     wsa.xwin_count = r->d_xw_count + r->cur;
     wsa.xwin_cap = r->xw_cap;
     wsa.p_cap = c->p_cap;
+    wsa.nb_off = c->nb_off; wsa.nb_idx = c->nb_idx; wsa.nb_bound = c->nb_bound;
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
                        r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb, p.nframes, p.lean, wsa,
                        c->counter + counter_slot, r->d_out, role, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab,
@@ -552,6 +593,50 @@ static int join_pipeline(pw_context* c) {
     return PW_OK;
 }
 
+// ---- device = -1: the explicit host path ------------------------------------------------------------
+// the same two retries as launch_and_download: a unit that wants more sampling vectors than the knobs
+// imply, more windows than the list holds
+static int host_analyse(pw_context* c, const pw_batch_in* in, uint32_t stages, pw_unit_out* out, pw_unit_debug* dbg) {
+    if (in->n_units == 0) return PW_OK;
+    for (int64_t u = 0; u < in->n_units; ++u) {
+        const int64_t n = in->atom_offset[u + 1] - in->atom_offset[u];
+        if (n <= 0 || (in->template_atoms > 0 && n != in->template_atoms)) {
+            snprintf(g_err, sizeof(g_err), "unit %ld has %ld atoms", (long)u, (long)n);
+            return PW_E_BAD_ARG;
+        }
+    }
+    stages &= PW_STAGE_ALL;
+    int p_cap = wanted_p_cap(c);
+    std::vector<pw_extra_window> xw(1024);
+    c->extra->clear();
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        unsigned count = 0;
+        int rc = pw_hostpath_run(in, stages, out, &c->prm, p_cap, c->host_threads, dbg, xw.data(), (unsigned)xw.size(), &count);
+        if (rc != PW_OK) { snprintf(g_err, sizeof(g_err), "host path: out of memory"); return rc; }
+        long want = 0;
+        for (int64_t u = 0; u < in->n_units; ++u)
+            if (out[u].status & PW_ST_POINTS_OVERFLOW) {
+                if (out[u].n_points > want) want = out[u].n_points;
+                if (out[u].n_points_avg > want) want = out[u].n_points_avg;
+            }
+        if (want > p_cap) { p_cap = round_p_cap(want); c->p_cap_min = p_cap; continue; }
+        if (count > xw.size()) { xw.resize(count + count / 2); continue; }
+        xw.resize(count);
+        std::sort(xw.begin(), xw.end(), [](const pw_extra_window& a, const pw_extra_window& b) {
+            return a.unit != b.unit ? a.unit < b.unit : a.index < b.index;
+        });
+        *c->extra = xw;
+        return PW_OK;
+    }
+    snprintf(g_err, sizeof(g_err), "host path: capacities did not settle");
+    return PW_E_TOO_LARGE;
+}
+#define PW_HOST_UNSUPPORTED(c, what)                                                                       \
+    if ((c) && (c)->device < 0) {                                                                          \
+        snprintf(g_err, sizeof(g_err), what ": not part of the host path (device = -1 runs the analysis only)"); \
+        return PW_E_NO_DEVICE;                                                                             \
+    }
+
 extern "C" {
 
 const char* pw_version(void) { return "pywindow_amd 0.1 (gfx950)"; }
@@ -566,6 +651,20 @@ int pw_device_count(void) {
 int pw_context_create(int device, pw_context** out) {
     if (!out) return PW_E_BAD_ARG;
     *out = nullptr;
+    if (device == -1) {
+        // the explicit host path: no HIP call is made on behalf of this context, ever
+        pw_context* h = new (std::nothrow) pw_context();
+        if (!h) return PW_E_NOMEM;
+        memset(h, 0, sizeof(*h));
+        h->device = -1;
+        h->prm = default_params();
+        h->extra = new (std::nothrow) std::vector<pw_extra_window>();
+        if (!h->extra) { delete h; return PW_E_NOMEM; }
+        h->host_threads = pw_hostpath_default_threads();
+        h->fused = 1;
+        *out = h;
+        return PW_OK;
+    }
     int n = pw_device_count();
     if (n <= 0 || device < 0 || device >= n) {
         snprintf(g_err, sizeof(g_err), "no usable HIP device (count=%d, requested %d)", n, device);
@@ -683,6 +782,21 @@ int pw_context_create(int device, pw_context** out) {
         delete[] host;
         if (e2 != hipSuccess) { set_err("rsqrt14 table upload", e2); pw_context_destroy(c); return PW_E_HIP; }
     }
+    {
+        // the neighbour tables of the sampling sphere: 2.1 M rows of 40 bytes, built once (a few ms)
+        const char* nb = getenv("PW_NB_TABLES");
+        if (!(nb && nb[0] == '0')) {
+            const size_t rows = (size_t)nb_dense_offset(PW_NB_PMAX + 1);
+            CTX_TRY(hipMalloc((void**)&c->nb_off, (PW_NB_PMAX + 1) * sizeof(unsigned)));
+            CTX_TRY(hipMemset(c->nb_off, 0xff, (PW_NB_PMAX + 1) * sizeof(unsigned)));
+            CTX_TRY(hipMalloc((void**)&c->nb_idx, rows * PW_NB_K * sizeof(unsigned short)));
+            CTX_TRY(hipMalloc((void**)&c->nb_bound, rows * sizeof(double)));
+            hipLaunchKernelGGL(pw_nb_build_kernel, dim3(PW_NB_PMAX - PW_NB_PMIN + 1), dim3(256), 0, c->stream, c->nb_off,
+                               c->nb_idx, c->nb_bound);
+            CTX_TRY(hipGetLastError());
+            CTX_TRY(hipStreamSynchronize(c->stream));
+        }
+    }
 #undef CTX_TRY
     *out = c;
     return PW_OK;
@@ -690,6 +804,7 @@ int pw_context_create(int device, pw_context** out) {
 
 void pw_context_destroy(pw_context* c) {
     if (!c) return;
+    if (c->device < 0) { delete c->extra; delete c; return; }
     DeviceScope scope;
     (void)scope.enter(c->device);
     (void)hipDeviceSynchronize();
@@ -718,6 +833,9 @@ void pw_context_destroy(pw_context* c) {
     if (c->pool) (void)hipFree(c->pool);
     if (c->queue) (void)hipFree(c->queue);
     if (c->rsq_tab) (void)hipFree(c->rsq_tab);
+    if (c->nb_off) (void)hipFree(c->nb_off);
+    if (c->nb_idx) (void)hipFree(c->nb_idx);
+    if (c->nb_bound) (void)hipFree(c->nb_bound);
     if (c->slots) (void)hipFree(c->slots);
     for (int b = 0; b < PW_SETS; ++b)
         if (c->prods[b]) (void)hipStreamDestroy(c->prods[b]);
@@ -761,6 +879,7 @@ int pw_context_device(pw_context* c) { return c ? c->device : -1; }
 // the buffer is ordered on the API stream; growing it waits for the device.
 int pw_internal_pool(pw_context* c, size_t bytes, void** out) {
     if (!c || !out) return PW_E_BAD_ARG;
+    PW_HOST_UNSUPPORTED(c, "device scratch");
     if (c->pool_bytes < bytes) {
         HIP_TRY(hipDeviceSynchronize());
         if (c->pool) HIP_TRY(hipFree(c->pool));
@@ -776,9 +895,22 @@ char* pw_internal_error_buffer(void) { return g_err; }
 
 void* pw_context_stream(pw_context* c) { return c ? (void*)c->stream : nullptr; }
 
+// number of host threads of a device = -1 context (0: keep); returns the current number
+int pw_context_host_threads(pw_context* c, int threads) {
+    if (!c || c->device >= 0) return 0;
+    if (threads > 0) c->host_threads = threads;
+    return c->host_threads;
+}
+
 int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     if (!c || !r) return PW_E_BAD_ARG;
     if (r->n_units == 0) return PW_OK;
+    if (c->device < 0) {
+        if (!r->host) return PW_E_BAD_ARG;
+        pw_batch_in in = {r->n_units, r->host->offset.data(), r->host->xyz.data(), r->host->vdw.data(), r->host->mass.data(),
+                          r->host->template_atoms};
+        return host_analyse(c, &in, stages, r->host->out.data(), nullptr);
+    }
     PW_ON_DEVICE(c->device);
     stages &= PW_STAGE_ALL;
     const bool pipeline = !c->fused && (stages & PW_STAGE_WINDOWS) != 0;
@@ -1029,6 +1161,7 @@ static int check_queue_error(pw_context* c) {
 
 int pw_resident_sync(pw_context* c) {
     if (!c) return PW_E_BAD_ARG;
+    if (c->device < 0) return PW_OK;
     PW_ON_DEVICE(c->device);
     int rcj = join_pipeline(c);
     if (rcj != PW_OK) return rcj;
@@ -1039,6 +1172,25 @@ int pw_resident_sync(pw_context* c) {
 int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) {
     if (!c || !in || !out || in->n_units < 0 || in->template_atoms < 0) return PW_E_BAD_ARG;
     *out = nullptr;
+    if (c->device < 0) {
+        pw_resident* h = new (std::nothrow) pw_resident();
+        if (!h) return PW_E_NOMEM;
+        memset((void*)h, 0, sizeof(*h));
+        h->host = new (std::nothrow) HostBatch();
+        if (!h->host) { delete h; return PW_E_NOMEM; }
+        const int64_t na = in->n_units ? in->atom_offset[in->n_units] : 0;
+        const int64_t nc = in->template_atoms > 0 ? in->template_atoms : na;
+        h->n_units = (long)in->n_units;
+        h->n_atoms = (long)na;
+        h->host->offset.assign(in->atom_offset, in->atom_offset + in->n_units + 1);
+        h->host->xyz.assign(in->xyz, in->xyz + 3 * na);
+        h->host->vdw.assign(in->vdw, in->vdw + nc);
+        h->host->mass.assign(in->mass, in->mass + nc);
+        h->host->out.resize((size_t)in->n_units);
+        h->host->template_atoms = in->template_atoms;
+        *out = h;
+        return PW_OK;
+    }
     PW_ON_DEVICE(c->device);
     pw_resident* r = new (std::nothrow) pw_resident();
     if (!r) return PW_E_NOMEM;
@@ -1103,6 +1255,7 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
 int pw_internal_resident_adopt(pw_context* c, long n_units, long n_atoms, int nmax, long* d_offset, double* d_xyz,
                                double* d_vdw, double* d_mass, pw_resident** out) {
     if (!c || !out || n_units <= 0 || nmax <= 0) return PW_E_BAD_ARG;
+    PW_HOST_UNSUPPORTED(c, "device batches");
     PW_ON_DEVICE(c->device);
     pw_resident* r = new (std::nothrow) pw_resident();
     if (!r) return PW_E_NOMEM;
@@ -1159,6 +1312,11 @@ static int fetch_extra_windows(pw_context* c, pw_resident* r, unsigned count) {
 int pw_resident_download(pw_context* c, pw_resident* r, pw_unit_out* out) {
     if (!c || !r || !out) return PW_E_BAD_ARG;
     if (r->n_units == 0) return PW_OK;
+    if (c->device < 0) {
+        if (!r->host) return PW_E_BAD_ARG;
+        memcpy(out, r->host->out.data(), sizeof(pw_unit_out) * (size_t)r->n_units);
+        return PW_OK;
+    }
     PW_ON_DEVICE(c->device);
     // wait for the launch that wrote these records -- not for launches of other batches issued since
     // (a trajectory analysed in pieces downloads piece k while piece k + 1 is still running)
@@ -1186,6 +1344,7 @@ int pw_resident_extra_windows(pw_context* c, pw_resident* r, int64_t* count) {
     if (!c || !r) return PW_E_BAD_ARG;
     if (count) *count = 0;
     if (r->n_units == 0) return PW_OK;
+    if (c->device < 0) { if (count) *count = (int64_t)c->extra->size(); return PW_OK; }
     PW_ON_DEVICE(c->device);
     const int ws = r->written_set[r->cur];
     if (ws >= 0 && c->done_valid[ws]) {
@@ -1219,6 +1378,7 @@ int pw_context_point_capacity(pw_context* c) { return c ? (c->p_cap > 0 ? c->p_c
 
 void pw_resident_free(pw_context* c, pw_resident* r) {
     if (!r) return;
+    if (r->host) { delete r->host; delete r; return; }
     DeviceScope scope;
     if (c) (void)scope.enter(c->device);
     if (r->d_offset) (void)hipFree(r->d_offset);
@@ -1233,13 +1393,14 @@ void pw_resident_free(pw_context* c, pw_resident* r) {
     delete r;
 }
 
-void* pw_resident_device_results(pw_resident* r) { return r ? (void*)r->d_out : nullptr; }
+void* pw_resident_device_results(pw_resident* r) { return r ? (r->host ? (void*)r->host->out.data() : (void*)r->d_out) : nullptr; }
 int64_t pw_resident_units(pw_resident* r) { return r ? r->n_units : 0; }
 
 // Stream-ordered hand-over of the latest results to a caller's stream (the RCCL gather of a
 // one-process-per-GPU job runs on PyTorch's stream): no host synchronisation on either side.
 int pw_resident_results_ready(pw_context* c, pw_resident* r, void* stream, void** results) {
     if (!c || !r) return PW_E_BAD_ARG;
+    PW_HOST_UNSUPPORTED(c, "stream-ordered hand-over");
     PW_ON_DEVICE(c->device);
     hipStream_t ext = (hipStream_t)stream;
     for (int b = 0; b < PW_SETS; ++b)
@@ -1253,6 +1414,7 @@ int pw_resident_results_ready(pw_context* c, pw_resident* r, void* stream, void*
 
 int pw_resident_results_release(pw_context* c, pw_resident* r, void* stream) {
     if (!c || !r) return PW_E_BAD_ARG;
+    PW_HOST_UNSUPPORTED(c, "stream-ordered hand-over");
     PW_ON_DEVICE(c->device);
     // the launch that next writes this result buffer (two launches of this batch from now) waits for
     // what the caller's stream has been given so far; launches in between are not held back
@@ -1265,6 +1427,17 @@ int pw_resident_results_release(pw_context* c, pw_resident* r, void* stream) {
 
 int pw_resident_time(pw_context* c, pw_resident* r, uint32_t stages, int iters, float* ms) {
     if (!c || !r || !ms || iters < 1) return PW_E_BAD_ARG;
+    if (c->device < 0) {
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int i = 0; i < iters; ++i) {
+            int rch = pw_resident_launch(c, r, stages);
+            if (rch != PW_OK) return rch;
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        *ms = (float)(((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6) / iters);
+        return PW_OK;
+    }
     PW_ON_DEVICE(c->device);
     int rc = pw_resident_launch(c, r, stages);  // warm-up, also sizes the workspace
     if (rc != PW_OK) return rc;
@@ -1291,6 +1464,7 @@ int pw_resident_time(pw_context* c, pw_resident* r, uint32_t stages, int iters, 
 // from the moment the chains are resident until the last published unit is fitted).
 int pw_resident_stage_times(pw_context* c, pw_resident* r, float* ms) {
     if (!c || !r || !ms) return PW_E_BAD_ARG;
+    PW_HOST_UNSUPPORTED(c, "per-launch timing");
     if (c->fused) { snprintf(g_err, sizeof(g_err), "PW_FUSED=1: the analysis is one launch"); return PW_E_BAD_ARG; }
     PW_ON_DEVICE(c->device);
     for (int k = 0; k < 3; ++k)
@@ -1334,6 +1508,7 @@ static int launch_and_download(pw_context* c, pw_resident* r, uint32_t stages, p
 
 int pw_analysis_batch(pw_context* c, const pw_batch_in* in, uint32_t stages, pw_unit_out* out) {
     if (!c || !in || !out) return PW_E_BAD_ARG;
+    if (c->device < 0) return host_analyse(c, in, stages, out, nullptr);
     pw_resident* r = nullptr;
     int rc = pw_resident_upload(c, in, &r);
     if (rc != PW_OK) return rc;
@@ -1345,6 +1520,14 @@ int pw_analysis_batch(pw_context* c, const pw_batch_in* in, uint32_t stages, pw_
 int pw_analysis_debug(pw_context* c, const pw_batch_in* in, uint32_t stages, pw_unit_out* out, pw_unit_debug* dbg) {
     if (!c || !in || !out || !dbg) return PW_E_BAD_ARG;
     if (in->n_units == 0) return PW_OK;
+    if (c->device < 0) {
+        memset(dbg, 0, sizeof(pw_unit_debug) * (size_t)in->n_units);
+        const int keep = c->host_threads;
+        c->host_threads = 1;                     // (test instrumentation: one unit at a time)
+        int rch = host_analyse(c, in, stages, out, dbg);
+        c->host_threads = keep;
+        return rch;
+    }
     PW_ON_DEVICE(c->device);
     pw_resident* r = nullptr;
     int rc = pw_resident_upload(c, in, &r);
@@ -1390,6 +1573,26 @@ int pw_point_gaps(pw_context* c, const pw_batch_in* in, const int64_t* unit_of_p
     if (n_points == 0) return PW_OK;
     for (int64_t q = 0; q < n_points; ++q)
         if (unit_of_point[q] < 0 || unit_of_point[q] >= in->n_units) return PW_E_BAD_ARG;
+    if (c->device < 0) {
+        const int vs = in->template_atoms > 0 ? 0 : 1;
+        for (int64_t q = 0; q < n_points; ++q) {
+            const int64_t a0 = in->atom_offset[unit_of_point[q]];
+            const int n = (int)(in->atom_offset[unit_of_point[q] + 1] - a0);
+            const double px = points[3 * q], py = points[3 * q + 1], pz = points[3 * q + 2], pp = sq3(px, py, pz);
+            double best = PW_INF;
+            int bi = 0;
+            for (int i = 0; i < n; ++i) {
+                const double x = in->xyz[3 * (a0 + i)], y = in->xyz[3 * (a0 + i) + 1], z = in->xyz[3 * (a0 + i) + 2];
+                const double g = pw_fma(z, pz, pw_fma(x, px, y * py));
+                const double d2 = pw_m2add(g, sq3(x, y, z)) + pp;
+                const double v = pw_sqrt(d2 > 0.0 ? d2 : 0.0) - in->vdw[a0 * vs + i];
+                if (v < best) { best = v; bi = i; }
+            }
+            gap[q] = best;
+            argmin[q] = bi;
+        }
+        return PW_OK;
+    }
     PW_ON_DEVICE(c->device);
     pw_resident* r = nullptr;
     int rc = pw_resident_upload(c, in, &r);
@@ -1437,6 +1640,7 @@ int pw_dbscan(pw_context* c, const double* points, int64_t n, double eps, int mo
     if (!c || !labels || !n_clusters || n < 0 || n > PW_DBSCAN_MAX || (n > 0 && !points)) return PW_E_BAD_ARG;
     *n_clusters = 0;
     if (n == 0) return PW_OK;
+    PW_HOST_UNSUPPORTED(c, "pw_dbscan");
     PW_ON_DEVICE(c->device);
     double* d_p = nullptr;
     int *d_i = nullptr, *d_l = nullptr;
@@ -1493,6 +1697,7 @@ int pw_dbscan(pw_context* c, const double* points, int64_t n, double eps, int mo
 
 int pw_pairwise_sum(pw_context* c, const double* values, int64_t n, int mode, double* sum) {
     if (!c || !sum || n < 0 || n > 0x7fffffff || (n > 0 && !values)) return PW_E_BAD_ARG;
+    PW_HOST_UNSUPPORTED(c, "pw_pairwise_sum");
     PW_ON_DEVICE(c->device);
     double *d_a = nullptr, *d_s = nullptr;
     auto cleanup = [&]() {

@@ -248,6 +248,10 @@ extern "C" int pw_discrete_molecules(pw_context* ctx, const pw_cell_in* in, cons
         return PW_E_BAD_ARG;
     if (in->n_frames == 0) return PW_OK;
     DeviceScope dev_scope_;
+    if (pw_context_device(ctx) < 0) {
+        snprintf(pw_internal_error_buffer(), 512, "not part of the host path (device = -1 runs the analysis only)");
+        return PW_E_NO_DEVICE;
+    }
     RB_TRY(dev_scope_.enter(pw_context_device(ctx)));
     Buffers buf;
     DeviceCells dev;
@@ -271,6 +275,10 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
         return PW_E_BAD_ARG;
     *res = nullptr;
     DeviceScope dev_scope_;
+    if (pw_context_device(ctx) < 0) {
+        snprintf(pw_internal_error_buffer(), 512, "not part of the host path (device = -1 runs the analysis only)");
+        return PW_E_NO_DEVICE;
+    }
     RB_TRY(dev_scope_.enter(pw_context_device(ctx)));
     Buffers buf;
     DeviceCells dev;

@@ -78,6 +78,10 @@ extern "C" int pw_shape_batch(pw_context* ctx, const pw_batch_in* in, pw_shape_o
         }
     }
     DeviceScope dev_scope_;
+    if (pw_context_device(ctx) < 0) {
+        snprintf(pw_internal_error_buffer(), 512, "not part of the host path (device = -1 runs the analysis only)");
+        return PW_E_NO_DEVICE;
+    }
     SH_TRY(dev_scope_.enter(pw_context_device(ctx)));
     hipStream_t st = (hipStream_t)pw_context_stream(ctx);
     Buffers buf;
@@ -111,6 +115,10 @@ extern "C" int pw_circumcircle(pw_context* ctx, const double* xyz, int64_t n_ato
             return PW_E_BAD_ARG;       // the reference: IndexError
         }
     DeviceScope dev_scope_;
+    if (pw_context_device(ctx) < 0) {
+        snprintf(pw_internal_error_buffer(), 512, "not part of the host path (device = -1 runs the analysis only)");
+        return PW_E_NO_DEVICE;
+    }
     SH_TRY(dev_scope_.enter(pw_context_device(ctx)));
     hipStream_t st = (hipStream_t)pw_context_stream(ctx);
     Buffers buf;

@@ -100,6 +100,10 @@ struct TeamWorkspace {
     double* xw;               // 7 p_cap
     int* xw_ok;               // p_cap
     int p_cap;
+    // neighbour tables of the sampling sphere (see NbTables below); null: none (the windowed search runs)
+    const unsigned* nb_off;
+    const unsigned short* nb_idx;
+    const double* nb_bound;
     // launch-wide list of the windows beyond PW_W_MAX (appended with an atomic counter)
     pw_extra_window* xwin;
     unsigned* xwin_count;
@@ -292,7 +296,7 @@ PW_HD inline unsigned team_atomic_inc(unsigned* p) {      // global counter shar
 #if defined(__HIP_DEVICE_COMPILE__)
     return atomicAdd(p, 1u);
 #else
-    return (*p)++;
+    return __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED);       // (host teams of several threads share it too)
 #endif
 }
 PW_HD inline void team_atomic_or(PW_LDS unsigned long long* p, unsigned long long v) {
@@ -770,6 +774,52 @@ struct Sphere {
         *pz = z * R;
     }
 };
+// ---- neighbour tables of the sampling sphere ----------------------------------------------------
+// The DBSCAN radius is the mean of the ten nearest-neighbour distances of ALL P sampling vectors
+// (utilities.py:1427-1434).  The vectors are a golden spiral scaled by the sphere radius R, so WHICH
+// points are a point's nearest neighbours is a property of (P, point) alone; only the distances depend on
+// R.  For every P of interest the sixteen nearest points of each point ON THE UNIT SPHERE are tabulated
+// once per context (itself included, ascending), together with the squared unit distance of the
+// seventeenth -- a lower bound for every point not in the list.  At run time the sixteen exact distances
+// (the reference's arithmetic, on the scaled vectors) are formed; if they come out ascending and the tenth
+// is provably below everything outside the list, the first ten ARE the reference's ten -- otherwise (exact
+// ties, never seen) the point goes through the windowed search.  16 distances per point instead of ~200.
+constexpr int PW_NB_K = 16;
+constexpr int PW_NB_PMIN = 32;
+constexpr int PW_NB_PMAX = PW_P_MAX;
+constexpr unsigned PW_NB_NONE = 0xffffffffu;
+// first point of the table of P when the tables of PW_NB_PMIN .. P - 1 precede it
+PW_HD inline unsigned nb_dense_offset(int P) {
+    return (unsigned)(((long)(P - 1) * P - (long)(PW_NB_PMIN - 1) * PW_NB_PMIN) / 2);
+}
+// one row of a table: the PW_NB_K nearest of point k among the P unit vectors u*, and the bound
+PW_HD inline void nb_build_point(int P, int k, const double* ux, const double* uy, const double* uz,
+                                 unsigned short* idx, double* bound) {
+    double t[PW_NB_K + 1];
+    int id[PW_NB_K + 1];
+#pragma unroll
+    for (int q = 0; q <= PW_NB_K; ++q) { t[q] = PW_INF; id[q] = 0; }
+    const double x = ux[k], y = uy[k], z = uz[k];
+    for (int j = 0; j < P; ++j) {
+        double ax = x - ux[j], ay = y - uy[j], az = z - uz[j];
+        double d = ax * ax + ay * ay + az * az;
+        if (d < t[PW_NB_K]) {
+            int jj = j;
+#pragma unroll
+            for (int q = 0; q <= PW_NB_K; ++q) {
+                const bool lower = d < t[q];
+                const double td = t[q];
+                const int ti = id[q];
+                t[q] = lower ? d : td; id[q] = lower ? jj : ti;
+                d = lower ? td : d; jj = lower ? ti : jj;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PW_NB_K; ++q) idx[q] = (unsigned short)id[q];
+    *bound = t[PW_NB_K];
+}
+
 PW_HD inline pw_params default_params() {
     pw_params p;
     p.adjust_windows = 1.0; p.adjust_average = 1.0; p.increment = 1.0; p.pore_opt = 1; p.opt_flags = 0;
@@ -1390,8 +1440,8 @@ PW_HD inline double fd_step(double x, double lb, double ub) {
 
 // ---- stage: optimised pore (wave 0) --------------------------------------------------------
 template <class T>
-PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
-                                        const pw_params& prm) {
+PW_HD inline __attribute__((always_inline)) void stage_opt_impl(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
+                                                                const pw_params& prm) {
     (void)ws;
     auto& v = *sh.v;
     if (T::wave() == 0) {
@@ -1501,6 +1551,12 @@ PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n
         }
     }
     T::sync();
+}
+
+template <class T>
+PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
+                                        const pw_params& prm) {
+    stage_opt_impl<T>(sh, ws, n, out, prm);
 }
 
 // ---- stage: average diameter ---------------------------------------------------------------
@@ -2233,6 +2289,13 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         for (int p = 0; p < NK; ++p)
 #pragma unroll
             for (int q = 0; q < 10; ++q) dist[p][q] = 0.0;
+        // this P's neighbour table, if the context has one
+        const unsigned short* nb_idx = nullptr;
+        const double* nb_bound = nullptr;
+        if (ws->nb_off && P >= PW_NB_PMIN && P <= PW_NB_PMAX && ws->nb_off[P] != PW_NB_NONE) {
+            nb_idx = ws->nb_idx + (size_t)ws->nb_off[P] * PW_NB_K;
+            nb_bound = ws->nb_bound + ws->nb_off[P];
+        }
         auto knn_groups = [&](auto pts_) __attribute__((always_inline)) {
             for (int grp = T::tid(); grp < ngroups; grp += T::SIZE) {
                 const int k0 = grp * NK;
@@ -2244,7 +2307,57 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
                 }
                 const int klast = k0 + NK - 1 < P ? k0 + NK - 1 : P - 1;
                 int lo = k0 - W < 0 ? 0 : k0 - W, hi = klast + W > P - 1 ? P - 1 : klast + W;
-                for (int pass = 0; pass < 2; ++pass) {
+                bool tabled = false;
+                if (nb_idx) {
+                    // the sixteen tabulated candidates of each point: exact distances, which must come out
+                    // ascending with the tenth provably below everything outside the list (see NbTables)
+                    tabled = true;
+                    const double slack = (radius * radius) * (1.0 - 1e-9);
+#pragma unroll
+                    for (int p = 0; p < NK; ++p) {
+                        const int k = k0 + p < P ? k0 + p : P - 1;
+                        const unsigned* row = (const unsigned*)(nb_idx + (size_t)k * PW_NB_K);   // (32-byte rows)
+                        unsigned w[8];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) w[c] = row[c];
+                        double prev = -1.0, cd[PW_NB_K];
+                        bool sorted = true;
+#pragma unroll
+                        for (int c = 0; c < PW_NB_K; ++c) {
+                            const int j = (int)((w[c >> 1] >> (16 * (c & 1))) & 0xffffu);
+                            const double qx = pts_[PT(j, 0)], qy = pts_[PT(j, 1)], qz = pts_[PT(j, 2)];
+                            double ax = px[p] - qx, ay = py[p] - qy, az = pz[p] - qz;
+                            double d = ax * ax;
+                            d = d + ay * ay; d = d + az * az;
+                            sorted = sorted && d >= prev;
+                            prev = d;
+                            cd[c] = d;
+                            if (c < 10) t[p][c] = d;
+                        }
+                        if (!sorted) {
+                            // mirror-image neighbours near the equator are ties on the unit sphere that the
+                            // scaled arithmetic breaks either way: sort what the list holds (rare)
+#pragma unroll
+                            for (int q = 0; q < 10; ++q) t[p][q] = PW_INF;
+#pragma unroll
+                            for (int c = 0; c < PW_NB_K; ++c) {
+                                double v_ = cd[c];
+#pragma unroll
+                                for (int q = 0; q < 10; ++q) {
+                                    double lo_ = __builtin_fmin(t[p][q], v_);
+                                    v_ = __builtin_fmax(t[p][q], v_);
+                                    t[p][q] = lo_;
+                                }
+                            }
+                        }
+                        tabled = tabled && t[p][9] < nb_bound[k] * slack;
+                    }
+#if defined(PW_NB_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+                    { static long hit = 0, miss = 0; (tabled ? hit : miss)++; if (((hit + miss) & 1023) == 0) fprintf(stderr, "nb tables: %ld groups from the table, %ld through the search\n", hit, miss);
+                      if (!tabled) for (int p = 0; p < NK; ++p) { int k = k0 + p < P ? k0 + p : P - 1; fprintf(stderr, "  miss P %d k %d t9 %.17g bound*R2 %.17g ratio %.3e\n", P, k, t[p][9], nb_bound[k] * radius * radius, t[p][9] / (nb_bound[k] * radius * radius) - 1.0); } }
+#endif
+                }
+                for (int pass = tabled ? 2 : 0; pass < 2; ++pass) {
 #pragma unroll
                     for (int p = 0; p < NK; ++p)
 #pragma unroll
@@ -2626,6 +2739,7 @@ PW_HD inline void record_or_status(pw_unit_out* out, int st, int evals) {
 }
 
 constexpr unsigned PW_KERNEL_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
+constexpr unsigned PW_KERNEL_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE;
 
 template <class T, unsigned KMASK = 0xffffffffu>
 PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const double* xyz,
@@ -2659,7 +2773,14 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
     } else {
         stage_basic<T>(sh, ws, n, out, (stages & PW_STAGE_COM_ONLY) != 0);
     }
+#ifdef PW_INLINE_OPT
+    // the optimiser-chain kernel: the chain IS the kernel body (no call, no callee-saved register save area)
+    if (stages & PW_STAGE_OPT) {
+        if (KMASK == PW_KERNEL_CHAINS) stage_opt_impl<T>(sh, ws, n, out, prm); else stage_opt<T>(sh, ws, n, out, prm);
+    }
+#else
     if (stages & PW_STAGE_OPT) stage_opt<T>(sh, ws, n, out, prm);
+#endif
     if (reuse_opt) {
         if (T::tid() == 0) {
             sh.v->opt_c[0] = out->pore_opt_c[0];

@@ -50,6 +50,33 @@ static int run_batch(long n_units, const long* off, const double* xyz, const dou
     bind_team_slab(ws, slab, p_cap);
     ws->adj = (unsigned long long*)malloc(sizeof(unsigned long long) * team_adj_words(p_cap));
     ws->xwin = xw; ws->xwin_cap = xw_cap; ws->xwin_count = xw_count;
+    // neighbour tables of the sampling sphere (HS_NB_TABLES=0: without, the windowed search only): built for
+    // the vector counts this batch needs -- found by a first pass without tables
+    static std::vector<unsigned> nb_off(PW_NB_PMAX + 1, PW_NB_NONE);
+    static std::vector<unsigned short> nb_idx;
+    static std::vector<double> nb_bound;
+    const char* nbt = getenv("HS_NB_TABLES");
+    const bool want_tables = !(nbt && nbt[0] == '0') && (stages & PW_STAGE_WINDOWS);
+    ws->nb_off = nullptr; ws->nb_idx = nullptr; ws->nb_bound = nullptr;
+    for (int pass = want_tables ? 0 : 1; pass < 2; ++pass) {
+    if (pass == 1 && want_tables) {
+        for (long u = 0; u < n_units; ++u) {
+            const int P = out[u].n_points;
+            if (P < PW_NB_PMIN || P > PW_NB_PMAX || nb_off[P] != PW_NB_NONE) continue;
+            const unsigned first = (unsigned)nb_bound.size();
+            std::vector<double> ux(P), uy(P), uz(P);
+            Sphere sp;
+            sp.init(1.0, P);
+            for (int k = 0; k < P; ++k) sp.point(k, &ux[k], &uy[k], &uz[k]);
+            nb_idx.resize((size_t)(first + P) * PW_NB_K);
+            nb_bound.resize(first + P);
+            for (int k = 0; k < P; ++k)
+                nb_build_point(P, k, ux.data(), uy.data(), uz.data(), nb_idx.data() + (size_t)(first + k) * PW_NB_K, nb_bound.data() + first + k);
+            nb_off[P] = first;
+        }
+        ws->nb_off = nb_off.data(); ws->nb_idx = nb_idx.data(); ws->nb_bound = nb_bound.data();
+        *xw_count = 0;
+    }
     static unsigned rsq_tab[65536];
     static bool rsq_ready = false;
     if (!rsq_ready) { rsqrt14_decode(rsq_tab); rsq_ready = true; }
@@ -77,6 +104,7 @@ static int run_batch(long n_units, const long* off, const double* xyz, const dou
         int n = (int)(off[u + 1] - off[u]);
         memset(&out[u], 0, sizeof(pw_unit_out));
         analyse_unit<HostTeam>(sh, ws, n, xyz + 3 * off[u], vdw + off[u], mass + off[u], stages, &out[u], prm);
+    }
     }
     free(ws->adj); free(slab); free(lds); free(ws);
     return 0;

@@ -1,0 +1,110 @@
+"""``device = -1``: the explicit host path of the C ABI (BASELINE.json configs[0] "CC3 single-frame
+full_analysis() on CPU").  ``pw_context_create(-1)`` runs the kernel SOURCE (pywindow_amd/csrc/pw_unit.hpp)
+compiled by g++ for a one-lane team on host threads -- through the product's own boundary, so these tests
+read like the GPU ones: every golden unit produced by the reference, bit for bit.  Nothing ever selects
+this path implicitly (tests/test_abi.py::test_no_silent_cpu_fallback)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from _util import GROUPS, check_records, group_batch, load_group, molecules
+from pywindow_amd import _lib, engine
+from pywindow_amd import element_data as E
+
+
+@pytest.fixture(scope="module")
+def host_ctx():
+    return _lib.Context(-1, host_threads=4)
+
+
+@pytest.mark.parametrize("tag", GROUPS)
+def test_host_context_matches_reference(host_ctx, tag):
+    g = load_group(tag)
+    off, xyz, vdw, mass = group_batch(g)
+    out = host_ctx.analyse(_lib.Batch(off, xyz, vdw, mass))
+    stats = check_records(out, g, where=f"host {tag}")
+    assert stats["win_d"] == 0.0 and stats["win_c_abs"] == 0.0
+    assert (out["status"] == 0).all()
+
+
+def test_host_context_threads_do_not_change_results():
+    g = load_group("synth64")
+    off, xyz, vdw, mass = group_batch(g)
+    one = _lib.Context(-1, host_threads=1).analyse(_lib.Batch(off, xyz, vdw, mass))
+    many = _lib.Context(-1, host_threads=7).analyse(_lib.Batch(off, xyz, vdw, mass))
+    assert one.tobytes() == many.tobytes()
+
+
+def test_config0_cc3_full_analysis_on_cpu():
+    """BASELINE.json configs[0]: the reference's known-answer CC3 input (tests/test_validate_cc3.py:353-439)
+    through Molecule.full_analysis() with the host context selected explicitly."""
+    import pywindow_amd as pw
+
+    g = load_group("static")
+    el, xyz = molecules(g)[list(g["names"]).index("cc3")]
+    engine.set_default_device(-1)
+    try:
+        props = pw.Molecule({"elements": el, "coordinates": xyz}, "cc3", 0).full_analysis()
+    finally:
+        engine.set_default_device(None)
+    np.testing.assert_almost_equal(props["centre_of_mass"], [12.4, 12.4, 12.4])
+    assert props["maximum_diameter"] == {"diameter": 22.179369990077188, "atom_1": 12, "atom_2": 54}
+    assert props["pore_diameter"]["diameter"] == 5.397020177310022
+    assert props["pore_volume"] == 82.31154385154417
+    assert props["pore_diameter_opt"]["diameter"] == 5.397020177310022
+    np.testing.assert_almost_equal(props["average_diameter"], 13.832017514255472, decimal=7)
+    np.testing.assert_almost_equal(np.sort(props["windows"]["diameters"]),
+                                   np.sort([3.63778746, 3.63562103, 3.62896512, 3.63707237]), decimal=7)
+
+
+def test_host_context_has_no_cliffs(host_ctx):
+    """The capacity fixtures (tests/test_cliffs.py) through the ABI: the host context sizes its workspace
+    from the adjust knob, grows it when a unit asks, and delivers windows beyond PW_W_MAX."""
+    from test_cliffs import check_window_call, load_cliffs, params_of
+
+    mols, calls = load_cliffs()
+    for call in calls:
+        el, xyz = mols[call["mol"]]
+        ids = E.element_ids(el)
+        prm, stages = params_of(call)
+        extra = []
+        rec = host_ctx.analyse(_lib.Batch(np.array([0, len(xyz)], np.int64), xyz, E.VDW[ids], E.MASS[ids]), stages, prm, extra)[0]
+        if call["kind"] == "avg":
+            assert float(rec["avg_d"]) == call["avg_d"], call["label"]
+        else:
+            check_window_call(call, rec, extra[0] if extra else np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE))
+
+
+def test_host_context_resident_and_trajectory(tmp_path, host_ctx):
+    """The trajectory driver on the host context: the reference's own 20-frame DL_POLY file, frames 3..6,
+    against the md20 golden group."""
+    from pywindow_amd.trajectory import DLPOLY
+
+    g = np.load(load_group.__globals__["GOLDEN"] / "history20.npz")
+    path = tmp_path / "HISTORY_singlemol_short"
+    path.write_bytes(g["file_bytes"].tobytes())
+    traj = DLPOLY(path)
+    recs = traj.analysis_records(frames=[3, 4, 5, 6], swap_atoms={"he": "H"}, forcefield="opls", device=-1)
+    md = load_group("md20")
+    for k, f in enumerate((3, 4, 5, 6)):
+        assert float(recs[k]["pore_opt_d"]) == float(md["pore_opt_d"][f])
+        n = int(md["n_windows"][f])
+        assert int(recs[k]["n_windows"]) == n and np.array_equal(recs[k]["win_d"][:n], md["win_d"][f][:n])
+    # a batch kept "resident" (host memory here)
+    off, xyz, vdw, mass = group_batch(md)
+    res = host_ctx.upload(_lib.Batch(off[:4], xyz[: off[3]], vdw[: off[3]], mass[: off[3]]))
+    res.launch()
+    assert np.array_equal(res.download()["pore_opt_d"], md["pore_opt_d"][:3])
+    res.free()
+
+
+def test_host_context_serves_the_analysis_only(host_ctx):
+    with pytest.raises(_lib.PwHipError, match="host path"):
+        host_ctx.dbscan(np.zeros((8, 3)), 1.0)
+    with pytest.raises(_lib.PwHipError, match="host path"):
+        host_ctx.pairwise_sum(np.ones(8))
+    assert not host_ctx.pipelined
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    assert L.pw_context_create(-2, ctypes.byref(h)) == -1        # PW_E_NO_DEVICE: only -1 names the host
