@@ -20,6 +20,7 @@
 #ifndef PYWINDOW_AMD_H
 #define PYWINDOW_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -163,6 +164,10 @@ const char *pw_last_error(void);
  * calls (batches then live in host memory), nothing else, and it is never chosen implicitly: a context
  * for a device that does not exist fails with PW_E_NO_DEVICE.  (BASELINE.json configs[0].) */
 int pw_context_create(int device, pw_context **ctx);
+/* Page-locked host staging buffer owned by the context (at least `bytes`, valid until a later call asks
+ * for more): a reader that decodes frames straight into it (pw_history_read) makes the copies of
+ * pw_resident_upload asynchronous DMA.  Device contexts only. */
+int pw_context_pinned(pw_context *ctx, size_t bytes, void **ptr);
 /* threads of a device == -1 context (default: PW_CPU_THREADS or the hardware concurrency); threads <= 0
  * only reports.  Returns 0 for device contexts. */
 int pw_context_host_threads(pw_context *ctx, int threads);

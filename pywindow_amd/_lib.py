@@ -214,6 +214,7 @@ EXPORTED_SYMBOLS = [
     "pw_context_create",
     "pw_context_destroy",
     "pw_context_host_threads",
+    "pw_context_pinned",
     "pw_params_default",
     "pw_context_set_params",
     "pw_analysis_batch",
@@ -306,6 +307,7 @@ def load():
     L.pw_last_error.restype = ctypes.c_char_p
     L.pw_context_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
     L.pw_context_host_threads.argtypes = [vp, ctypes.c_int]
+    L.pw_context_pinned.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     L.pw_context_destroy.argtypes = [vp]
     L.pw_context_destroy.restype = None
     L.pw_params_default.argtypes = [ctypes.POINTER(Params)]
@@ -445,6 +447,19 @@ class Context:
         if n:
             load().pw_context_extra_windows(self._h, buf.ctypes.data, n)
         return buf
+
+    def pinned_array(self, shape) -> np.ndarray:
+        """float64 array of ``shape`` in the context's page-locked staging buffer (``pw_context_pinned``):
+        decode frames into it and the upload copies by DMA.  ONE buffer per context: the array is valid
+        until the next call; an upload has finished with it when it returns.  Host contexts: a plain array."""
+        n = int(np.prod(shape))
+        if self.device < 0 or n == 0:
+            return np.empty(shape, dtype=np.float64)
+        ptr = ctypes.c_void_p()
+        _check(load().pw_context_pinned(self._h, n * 8, ctypes.byref(ptr)), "pw_context_pinned")
+        buf = (ctypes.c_double * n).from_address(ptr.value)
+        arr = np.frombuffer(buf, dtype=np.float64, count=n).reshape(shape)
+        return arr
 
     @property
     def pipelined(self) -> bool:

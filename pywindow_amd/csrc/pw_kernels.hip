@@ -390,6 +390,7 @@ struct pw_context {
     hipEvent_t ev_tail[PW_SETS];   // tail gate of the launch using set b has run
     int tail_valid[PW_SETS];
     long last_units[PW_SETS];
+    const void* last_res[PW_SETS];   // batch of the latest launch on each set (identity only, never dereferenced)
     int tail_pct;            // PW_TAIL_GATE: start the next optimiser launch at this % published
                              // (default 80; 0 = strictly one optimiser launch at a time)
     int flip;                // buffer set of the latest pipeline launch (-1: none yet)
@@ -418,6 +419,13 @@ struct pw_context {
     pw_unit_debug* dbg;      // per-unit stage capture of the current debug analysis, else null
     void* pool;              // device scratch kept between calls (the team slabs of the periodic re-assembly)
     size_t pool_bytes;
+    // device blocks of freed batches, kept for the next upload (hipMalloc / hipFree cost tens of microseconds
+    // each and hipFree waits for the device: a trajectory that goes through in pieces would pay both per piece)
+    struct Block { void* p; size_t bytes; };
+    std::vector<Block>* blocks;
+    size_t blocks_bytes;
+    void* pinned;            // page-locked host staging buffer handed to the reader (pw_context_pinned)
+    size_t pinned_bytes;
 };
 
 // a batch "resident" on the host (contexts created with device = -1)
@@ -438,6 +446,8 @@ struct pw_resident {
     double* d_xyz;
     double* d_vdw;
     double* d_mass;
+    void* block;             // one device block holds every array of an uploaded batch (from the context's cache)
+    size_t block_bytes;
     pw_unit_out* d_out;      // result records of the latest launch (= d_outs[cur])
     pw_unit_out* d_outs[PW_SETS];
     pw_extra_window* d_xw[PW_SETS];   // windows beyond PW_W_MAX written by the launch into d_outs[k] ...
@@ -449,6 +459,34 @@ struct pw_resident {
     int read_valid[PW_SETS];
     int written_set[PW_SETS];      // pipeline set of the launch that last wrote d_outs[k], -1: none / not a pipeline launch
 };
+
+static int block_take(pw_context* c, size_t bytes, void** out, size_t* got) {
+    bytes = (bytes + 65535) & ~(size_t)65535;
+    int best = -1;
+    for (int i = 0; i < (int)c->blocks->size(); ++i) {
+        const size_t b = (*c->blocks)[i].bytes;
+        if (b >= bytes && b <= 2 * bytes + (1u << 20) && (best < 0 || b < (*c->blocks)[best].bytes)) best = i;
+    }
+    if (best >= 0) {
+        *out = (*c->blocks)[best].p;
+        *got = (*c->blocks)[best].bytes;
+        c->blocks_bytes -= *got;
+        c->blocks->erase(c->blocks->begin() + best);
+        return PW_OK;
+    }
+    HIP_TRY(hipMalloc(out, bytes));
+    *got = bytes;
+    return PW_OK;
+}
+static void block_give(pw_context* c, void* p, size_t bytes) {
+    if (!p) return;
+    if (c && c->blocks && c->blocks->size() < 32 && c->blocks_bytes + bytes <= ((size_t)8 << 30)) {
+        c->blocks->push_back({p, bytes});
+        c->blocks_bytes += bytes;
+    } else {
+        (void)hipFree(p);
+    }
+}
 
 // sampling-vector capacity the next launch needs: what the adjust knobs imply (pw_unit.hpp: params_p_cap)
 // or what a unit of an earlier analysis asked for, whichever is larger
@@ -695,7 +733,8 @@ int pw_context_create(int device, pw_context** out) {
     CTX_TRY(hipMemset(c->queue, 0, PW_SETS * sizeof(UnitQueue)));
     c->flip = -1;
     c->extra = new (std::nothrow) std::vector<pw_extra_window>();
-    if (!c->extra) { pw_context_destroy(c); return PW_E_NOMEM; }
+    c->blocks = new (std::nothrow) std::vector<pw_context::Block>();
+    if (!c->extra || !c->blocks) { pw_context_destroy(c); return PW_E_NOMEM; }
     {
         const char* ns = getenv("PW_SETS_IN_FLIGHT");
         c->nsets = ns ? atoi(ns) : 0;
@@ -810,6 +849,9 @@ void pw_context_destroy(pw_context* c) {
     (void)hipDeviceSynchronize();
     if (c->ws) (void)hipFree(c->ws);
     if (c->slab) (void)hipFree(c->slab);
+    if (c->blocks) for (auto& b : *c->blocks) (void)hipFree(b.p);
+    delete c->blocks;
+    if (c->pinned) (void)hipHostFree(c->pinned);
     delete c->extra;
     if (c->ev_ext) (void)hipEventDestroy(c->ev_ext);
     for (int k = 0; k < 3; ++k)
@@ -894,6 +936,26 @@ int pw_internal_pool(pw_context* c, size_t bytes, void** out) {
 char* pw_internal_error_buffer(void) { return g_err; }
 
 void* pw_context_stream(pw_context* c) { return c ? (void*)c->stream : nullptr; }
+
+// Page-locked host staging buffer of the context (grown on demand, one per context): the reader decodes
+// frames straight into it and pw_resident_upload's copies from it are real asynchronous DMA instead of
+// going through the runtime's bounce buffer.  Valid until the next call that asks for more.
+int pw_context_pinned(pw_context* c, size_t bytes, void** out) {
+    if (!c || !out) return PW_E_BAD_ARG;
+    PW_HOST_UNSUPPORTED(c, "pinned staging");
+    PW_ON_DEVICE(c->device);
+    if (c->pinned_bytes < bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->pinned) HIP_TRY(hipHostFree(c->pinned));
+        c->pinned = nullptr;
+        c->pinned_bytes = 0;
+        const size_t want = (bytes + (bytes >> 2) + 4095) & ~(size_t)4095;
+        HIP_TRY(hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
+        c->pinned_bytes = want;
+    }
+    *out = c->pinned;
+    return PW_OK;
+}
 
 // number of host threads of a device = -1 context (0: keep); returns the current number
 int pw_context_host_threads(pw_context* c, int threads) {
@@ -1088,7 +1150,12 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     }
     HIP_TRY(hipEventRecord(c->ev_reset[b], c->prod));
     c->tail_valid[b] = 0;
-    const bool have_prev = p >= 0 && p != b && c->done_valid[p] && c->last_units[p] > 0;
+    // The gates pace RE-launches of one batch (the steps of a streamed analysis: start where the older launch
+    // leaves the chip idle).  Launches of DIFFERENT batches -- the pieces of one trajectory on their way
+    // through -- are independent work that should all be in flight as soon as it arrives: no gates, no
+    // ordering against the previous launch.
+    const bool same_batch = p >= 0 && c->last_res[p] == (const void*)r;
+    const bool have_prev = p >= 0 && p != b && c->done_valid[p] && c->last_units[p] > 0 && same_batch;
     if (c->tail_pct > 0 && have_prev) {
         unsigned long long need = (unsigned long long)((c->last_units[p] * c->tail_pct) / 100);
         hipLaunchKernelGGL(pw_tail_gate_kernel, dim3(1), dim3(64), 0, c->prod, c->queue + p, need);
@@ -1097,6 +1164,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         c->tail_valid[b] = 1;
     }
     c->last_units[b] = r->n_units;
+    c->last_res[b] = (const void*)r;
     // several optimiser launches can be in flight: separate work counters and workspaces
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][0], c->prod));
     rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod, ws_a, -1, b, PW_ROLE_PRODUCER, false);
@@ -1223,12 +1291,22 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
         }                                     \
     } while (0)
     if (r->n_units) {
-        UP_TRY(hipMalloc((void**)&r->d_offset, sizeof(long) * (r->n_units + 1)));
-        UP_TRY(hipMalloc((void**)&r->d_xyz, sizeof(double) * 3 * natoms));
-        UP_TRY(hipMalloc((void**)&r->d_vdw, sizeof(double) * nconst));
-        UP_TRY(hipMalloc((void**)&r->d_mass, sizeof(double) * nconst));
         r->nbuf = c->nsets ? c->nsets : (r->n_units <= 1500 ? 4 : (r->n_units <= 6000 ? 3 : 2));
-        UP_TRY(hipMalloc((void**)&r->d_outs[0], r->nbuf * sizeof(pw_unit_out) * r->n_units + 64));
+        // ONE device block for the whole batch, taken from the context's cache of freed blocks
+        auto up256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t b_off = up256(sizeof(long) * (size_t)(r->n_units + 1)), b_xyz = up256(sizeof(double) * 3 * (size_t)natoms);
+        const size_t b_con = up256(sizeof(double) * (size_t)nconst);
+        const size_t b_out = up256((size_t)r->nbuf * sizeof(pw_unit_out) * (size_t)r->n_units + 64);
+        {
+            int rcb = block_take(c, b_off + b_xyz + 2 * b_con + b_out, &r->block, &r->block_bytes);
+            if (rcb != PW_OK) { pw_resident_free(c, r); return rcb; }
+        }
+        unsigned char* base = (unsigned char*)r->block;
+        r->d_offset = (long*)base; base += b_off;
+        r->d_xyz = (double*)base; base += b_xyz;
+        r->d_vdw = (double*)base; base += b_con;
+        r->d_mass = (double*)base; base += b_con;
+        r->d_outs[0] = (pw_unit_out*)base;
         for (int k = 1; k < r->nbuf; ++k) r->d_outs[k] = r->d_outs[0] + (size_t)k * r->n_units;
         r->d_xw_count = (unsigned*)(r->d_outs[0] + (size_t)r->nbuf * r->n_units);   // (extra-window counters)
         for (int k = 0; k < PW_SETS; ++k) r->written_set[k] = -1;
@@ -1381,12 +1459,26 @@ void pw_resident_free(pw_context* c, pw_resident* r) {
     if (r->host) { delete r->host; delete r; return; }
     DeviceScope scope;
     if (c) (void)scope.enter(c->device);
-    if (r->d_offset) (void)hipFree(r->d_offset);
-    if (r->d_xyz) (void)hipFree(r->d_xyz);
-    if (r->d_vdw) (void)hipFree(r->d_vdw);
-    if (r->d_mass) (void)hipFree(r->d_mass);
-    if (c) (void)hipDeviceSynchronize();
-    if (r->d_outs[0]) (void)hipFree(r->d_outs[0]);
+    if (r->block) {
+        // an uploaded batch: wait for the launches that touched it -- not for the whole device -- and keep
+        // its block for the next upload
+        if (c) {
+            for (int k = 0; k < PW_SETS; ++k) {
+                const int ws = r->written_set[k];
+                if (ws >= 0 && c->done_valid[ws]) (void)hipEventSynchronize(c->ev_done[ws]);
+                if (r->read_valid[k]) (void)hipEventSynchronize(r->ev_read[k]);
+            }
+            (void)hipStreamSynchronize(c->stream);
+        }
+        block_give(c, r->block, r->block_bytes);
+    } else {
+        if (r->d_offset) (void)hipFree(r->d_offset);
+        if (r->d_xyz) (void)hipFree(r->d_xyz);
+        if (r->d_vdw) (void)hipFree(r->d_vdw);
+        if (r->d_mass) (void)hipFree(r->d_mass);
+        if (c) (void)hipDeviceSynchronize();
+        if (r->d_outs[0]) (void)hipFree(r->d_outs[0]);
+    }
     if (r->d_xw[0]) (void)hipFree(r->d_xw[0]);
     for (int k = 0; k < PW_SETS; ++k)
         if (r->ev_read[k]) (void)hipEventDestroy(r->ev_read[k]);

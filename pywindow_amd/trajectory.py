@@ -30,10 +30,11 @@ MODULAR_CHUNK = 8192
 #: being read and re-assembled
 MODULAR_PIECE = 1024
 MODULAR_IN_FLIGHT = 2
-#: a plain analysis of many frames is cut into pieces of about RUN_PIECE frames (never smaller than
-#: RUN_PIECE_MIN) so that parsing overlaps the kernels (see DLPOLY._run)
+#: a plain analysis goes through in about RUN_PIECES pieces, each between RUN_PIECE_MIN and RUN_PIECE frames, so
+#: that parsing, copies and kernels of successive pieces overlap (see DLPOLY._run)
+RUN_PIECES = 8
 RUN_PIECE = 4096
-RUN_PIECE_MIN = 1000
+RUN_PIECE_MIN = 250
 
 
 class _FunctionError(Exception):
@@ -94,11 +95,16 @@ class DLPOLY:
             pass
 
     # ---- frame access ---------------------------------------------------------------
-    def read_coordinates(self, first: int, count: int, lattice: np.ndarray | None = None) -> np.ndarray:
+    def read_coordinates(self, first: int, count: int, lattice: np.ndarray | None = None, out: np.ndarray | None = None) -> np.ndarray:
         """(count, natoms, 3) float64, parsed natively; ``lattice`` (count, 3, 3) receives the
         lattice matrices in the reference's orientation (cell vectors as columns,
-        trajectory.py:724-726)."""
-        xyz = np.empty((count, self.no_of_atoms, 3), dtype=np.float64)
+        trajectory.py:724-726).  ``out``: a C-contiguous float64 array of that shape to decode into."""
+        if out is not None:
+            if out.shape != (count, self.no_of_atoms, 3) or out.dtype != np.float64 or not out.flags.c_contiguous:
+                raise ValueError("out must be a C-contiguous float64 array of shape (count, natoms, 3)")
+            xyz = out
+        else:
+            xyz = np.empty((count, self.no_of_atoms, 3), dtype=np.float64)
         if count:
             rc = _lib.load().pw_history_read(self._h, first, count, xyz.ctypes.data,
                                              None if lattice is None else lattice.ctypes.data)
@@ -110,16 +116,17 @@ class DLPOLY:
     def periodic(self) -> bool:
         return self.periodic_boundary in ("cubic", "orthorhombic", "parallelepiped")
 
-    def _read_selected(self, frames: list[int], want_lattice: bool):
-        """Coordinates (and lattices) of arbitrary frames; contiguous runs are one native call."""
-        coords = np.empty((len(frames), self.no_of_atoms, 3))
+    def _read_selected(self, frames: list[int], want_lattice: bool, out: np.ndarray | None = None):
+        """Coordinates (and lattices) of arbitrary frames; contiguous runs are one native call, decoded in
+        place.  ``out``: where the coordinates go (e.g. a context's page-locked staging buffer)."""
+        coords = out if out is not None else np.empty((len(frames), self.no_of_atoms, 3))
         lattice = np.zeros((len(frames), 3, 3)) if want_lattice else None
         i = 0
         while i < len(frames):
             j = i
             while j + 1 < len(frames) and frames[j + 1] == frames[j] + 1:
                 j += 1
-            coords[i : j + 1] = self.read_coordinates(frames[i], j - i + 1, None if lattice is None else lattice[i : j + 1])
+            self.read_coordinates(frames[i], j - i + 1, None if lattice is None else lattice[i : j + 1], out=coords[i : j + 1])
             i = j + 1
         return coords, lattice
 
@@ -250,20 +257,19 @@ class DLPOLY:
         if not frames:
             return np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE)
         n = len(frames)
-        pieces = 1 if n < 2 * RUN_PIECE_MIN else min(-(-n // RUN_PIECE_MIN), -(-n // RUN_PIECE) if n > 2 * RUN_PIECE else 2)
-        if pieces <= 1:
-            coords, _ = self._read_selected(frames, False)
-            extra: list = []
-            recs = engine.context(device).analyse(_lib.Batch.uniform(coords, vdw, mass), _lib.STAGE_ALL, extra=extra)
-            if extra:
-                self._extra = extra[0]
-            return recs
         ctx = engine.context(device)
-        per = -(-n // pieces)
+        per = min(max(-(-n // RUN_PIECES), RUN_PIECE_MIN), RUN_PIECE)
+        if n < 2 * RUN_PIECE_MIN:
+            per = n
+        # The pieces go through one after the other on the host -- decode into the context's page-locked
+        # buffer, one pooled device block, copies by DMA, three asynchronous launches -- and all at once on
+        # the device: piece k is being analysed while piece k + 1 is tokenised (1000 frames: four pieces of
+        # 250; the launches of different pieces are not paced against each other, pw_resident_launch).
         inflight = []
         try:
             for lo in range(0, n, per):
-                coords, _ = self._read_selected(frames[lo:lo + per], False)
+                sel = frames[lo:lo + per]
+                coords, _ = self._read_selected(sel, False, out=ctx.pinned_array((len(sel), self.no_of_atoms, 3)))
                 res = ctx.upload(_lib.Batch.uniform(coords, vdw, mass))
                 res.launch(_lib.STAGE_ALL)
                 inflight.append(res)
@@ -275,7 +281,7 @@ class DLPOLY:
                 at += res.n_units
             if extras:
                 self._extra = np.concatenate(extras)
-            return np.concatenate(parts)
+            return parts[0] if len(parts) == 1 else np.concatenate(parts)
         finally:
             for res in inflight:
                 res.free()

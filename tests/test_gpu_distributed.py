@@ -7,6 +7,8 @@ import socket
 import numpy as np
 import pytest
 
+from _util import ROOT
+
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
@@ -189,3 +191,71 @@ def test_two_ranks_on_two_gpus_over_rccl(hip_ctx, tmp_path):
     one.analysis(forcefield="opls", swap_atoms={"he": "H"}, distributed=False)
     assert got[0][2] == {f: v["0"]["pore_diameter_opt"]["diameter"] for f, v in one.analysis_output.items()}
     assert got[1][2] == {}
+
+
+def _run_bench_child(extra_env, gpus=2, frames=240):
+    """``python bench.py --gpus N`` as a FRESH child process (it starts its own ranks through
+    torch.distributed.run before touching a GPU); returns the parsed JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    env.update(extra_env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1",
+           "--frames", str(frames), "--no-cpu-baseline", "--no-secondary"]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _check_multi_rank_line(line, world, frames):
+    assert line["n_gpus"] == world and line["scaling"] == "weak"
+    cfg = line["config"]
+    assert cfg["gather_in_timed_region"] is True and cfg["gather_ok"] is True and cfg["results_ok"] is True
+    assert cfg["frames_per_gpu"] == frames
+    by_rank = cfg["ms_per_step_by_rank"]
+    assert 0 < by_rank["min"] <= by_rank["max"] and abs(by_rank["max"] - line["ms_per_step"]) < 1e-6
+    assert line["value"] > 0 and abs(line["value"] - world * frames / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    strong = line["strong"]
+    assert strong["scaling"] == "strong" and strong["frames_total"] == frames and strong["frames_per_gpu"] == frames // world
+    assert strong["includes_gather"] is True and 0 < strong["efficiency"] and strong["speedup"] == pytest.approx(
+        strong["efficiency"] * world)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_executes_on_hardware_gloo():
+    """The multi-rank command itself, executed: two ranks started by ``bench.py --gpus 2`` on this box's
+    one GPU with the gloo backend (the rehearsal of the RCCL run the driver makes on eight): the process
+    group forms, every step ends with the gather inside the timed region, rank 0 checks the gathered
+    records against its own and prints the line, a strong-scaling block included.  (Trajectory fan-out of
+    the reference: trajectory.py:553-586.)"""
+    line = _run_bench_child({"PW_BENCH_BACKEND": "gloo", "PW_BENCH_DEVICE": "0"})
+    _check_multi_rank_line(line, 2, 240)
+    assert line["config"]["backend"] == "gloo"
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_executes_on_hardware_rccl():
+    """... and over RCCL, one rank per GPU, where the box has two."""
+    from pywindow_amd import _lib
+
+    if _lib.load().pw_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    line = _run_bench_child({})
+    _check_multi_rank_line(line, 2, 240)
+    assert line["config"]["backend"] == "nccl"
+
+
+@pytest.mark.gpu
+def test_bench_uneven_split_does_not_hang():
+    """A trajectory that does not split evenly over the ranks: every rank takes the same decision (the
+    strong-scaling block is skipped) instead of some entering collectives the others never reach."""
+    line = _run_bench_child({"PW_BENCH_BACKEND": "gloo", "PW_BENCH_DEVICE": "0"}, gpus=2, frames=125)
+    assert line["n_gpus"] == 2 and "skipped" in line["strong"]
