@@ -29,7 +29,9 @@
 // LDS (address space 3) qualification: pointers that always point into the team's
 // shared memory carry it on the device so that loads/stores become ds_* instead of
 // flat_* instructions; PW_ASSUME_LDS tells the optimiser the same about `this`.
-#if defined(__HIP_DEVICE_COMPILE__)
+// PW_GENERIC_TEAM_MEM (pw_kernels_big.hip): the team's shared block lives in GLOBAL memory -- molecules whose
+// coordinates do not fit the 160 KB of a CU's LDS -- so nothing is qualified and nothing is assumed.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_GENERIC_TEAM_MEM)
 #define PW_LDS __attribute__((address_space(3)))
 #define PW_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
 #define PW_IS_LDS(p) __builtin_amdgcn_is_shared((const void*)(p))

@@ -25,6 +25,7 @@
 #include "pw_host.hpp"
 #include <vector>
 #include "pw_unit.hpp"
+#include "pw_launch.hpp"
 
 using namespace pw;
 
@@ -32,6 +33,12 @@ using namespace pw;
 extern "C" int pw_hostpath_run(const pw_batch_in* in, unsigned stages, pw_unit_out* out, const pw_params* prm, int p_cap,
                                int threads, pw_unit_debug* dbg, pw_extra_window* xw, unsigned xw_cap, unsigned* xw_count);
 extern "C" int pw_hostpath_default_threads(void);
+// pw_kernels_big.hip: the same source with the team's shared block in global memory (molecules beyond LDS)
+extern "C" size_t pw_internal_big_block_bytes(int nmax, int p_cap);
+extern "C" int pw_internal_big_launch(void* stream, int grid, long n_units, const long* atom_offset, const double* xyz,
+                                      const double* vdw, const double* mass, unsigned stages, int nmax, const PwWsArgs* wsa,
+                                      unsigned char* blocks, size_t block_bytes, unsigned long long* counter, pw_unit_out* out,
+                                      const pw_params* prm, const unsigned* rsq_tab, int vstride);
 
 namespace {
 
@@ -77,29 +84,6 @@ constexpr unsigned MASK_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE;
 constexpr unsigned MASK_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 
-// Where a launch's teams find their global workspaces: headers, the per-team slabs of the per-vector
-// arrays (sized by the launch's sampling-vector capacity p_cap), DBSCAN adjacency rows, and the launch-wide
-// list of windows beyond what a record holds.
-struct WsArgs {
-    TeamWorkspace* ws;
-    unsigned char* slab;            // team t: slab + t * team_slab_bytes(p_cap)
-    unsigned long long* adj;        // team t: adj + t * team_adj_words(p_cap); null: the launch runs no DBSCAN
-    pw_extra_window* xwin;
-    unsigned* xwin_count;
-    unsigned xwin_cap;
-    int p_cap;
-    const unsigned* nb_off;         // neighbour tables of the sampling sphere (pw_unit.hpp), null: none
-    const unsigned short* nb_idx;
-    const double* nb_bound;
-};
-__device__ inline void bind_workspace(TeamWorkspace* ws, const WsArgs& a, unsigned team, const unsigned* rsq_tab) {
-    bind_team_slab(ws, a.slab + (size_t)team * team_slab_bytes(a.p_cap), a.p_cap);
-    ws->adj = a.adj ? a.adj + (size_t)team * team_adj_words(a.p_cap) : nullptr;
-    ws->xwin = a.xwin; ws->xwin_count = a.xwin_count; ws->xwin_cap = a.xwin_cap;
-    ws->nb_off = a.nb_off; ws->nb_idx = a.nb_idx; ws->nb_bound = a.nb_bound;
-    ws->rsq = rsq_tab;
-}
-
 // Neighbour tables of the sampling sphere, one block per vector count P (pw_unit.hpp: nb_build_point): the
 // P unit vectors go to LDS, every thread tabulates the rows of its points.
 __global__ void __launch_bounds__(256) pw_nb_build_kernel(unsigned* __restrict__ off, unsigned short* __restrict__ idx,
@@ -141,7 +125,7 @@ template <int NW, unsigned MASK>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? PW_OCC8 : (MASK == PW_KERNEL_AVERAGE ? 3 : (MASK == MASK_CHAINS ? PW_OCC_A : PW_OCC)))
 pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
                   const double* __restrict__ vdw, const double* __restrict__ mass, unsigned stages,
-                  int nmax, int nrot, int nlb, int nframes, int lean, WsArgs wsa, unsigned long long* counter,
+                  int nmax, int nrot, int nlb, int nframes, int lean, PwWsArgs wsa, unsigned long long* counter,
                   pw_unit_out* __restrict__ out, int role, UnitQueue* queue, int* __restrict__ slots,
                   pw_params prm, const unsigned* __restrict__ rsq_tab, int vstride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -155,8 +139,8 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
         __builtin_amdgcn_s_setprio(PW_A_PRIO);
         if (threadIdx.x == 0) atomicAdd(&queue->started, 1);
     }
-    TeamWorkspace* ws = wsa.ws + blockIdx.x;
-    if (threadIdx.x == 0) bind_workspace(ws, wsa, blockIdx.x, rsq_tab);
+    TeamWorkspace* ws = (TeamWorkspace*)wsa.ws + blockIdx.x;
+    if (threadIdx.x == 0) bind_workspace(ws, wsa, blockIdx.x, rsq_tab, team_slab_bytes(wsa.p_cap), team_adj_words(wsa.p_cap));
     __syncthreads();
     for (;;) {
         if (role == PW_ROLE_CONSUMER) {
@@ -424,6 +408,8 @@ struct pw_context {
     struct Block { void* p; size_t bytes; };
     std::vector<Block>* blocks;
     size_t blocks_bytes;
+    unsigned char* bigmem;   // team blocks of the global-memory analysis (pw_kernels_big.hip), grown on demand
+    size_t bigmem_bytes;
     void* pinned;            // page-locked host staging buffer handed to the reader (pw_context_pinned)
     size_t pinned_bytes;
 };
@@ -591,7 +577,7 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
         }
     }
     if (reset_counter) HIP_TRY(hipMemsetAsync(c->counter + counter_slot, 0, sizeof(unsigned long long), st));
-    WsArgs wsa;
+    PwWsArgs wsa;
     wsa.ws = c->ws + ws_first;
     wsa.slab = c->slab + (size_t)ws_first * team_slab_bytes(c->p_cap);
     wsa.adj = adj_first >= 0 ? c->adj + (size_t)adj_first * team_adj_words(c->p_cap) : (unsigned long long*)nullptr;
@@ -852,6 +838,7 @@ void pw_context_destroy(pw_context* c) {
     if (c->blocks) for (auto& b : *c->blocks) (void)hipFree(b.p);
     delete c->blocks;
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->bigmem) (void)hipFree(c->bigmem);
     delete c->extra;
     if (c->ev_ext) (void)hipEventDestroy(c->ev_ext);
     for (int k = 0; k < 3; ++k)
@@ -975,8 +962,54 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     }
     PW_ON_DEVICE(c->device);
     stages &= PW_STAGE_ALL;
-    const bool pipeline = !c->fused && (stages & PW_STAGE_WINDOWS) != 0;
     int rc;
+    {
+        // a molecule whose coordinates do not fit a CU's LDS (about 1700 atoms): the same source with the
+        // team's shared block in global memory (pw_kernels_big.hip), one launch, every stage in a team
+        const int pcap = wanted_p_cap(c) > c->p_cap ? wanted_p_cap(c) : c->p_cap;
+        const bool win_ = (stages & PW_STAGE_WINDOWS) != 0, opt_ = win_ || (stages & PW_STAGE_OPT);
+        // (the smallest team either launch shape can fall back to: one wave, one window-fit slot)
+        const size_t need = (!c->fused && win_) ? UnitShared::bytes(r->nmax, 1, 1, 1, false, pcap)
+                                                : UnitShared::bytes(r->nmax, win_ ? 1 : 0, win_ ? 1 : (opt_ ? 1 : 0), 2, false, pcap);
+        if (need + 64 > 160 * 1024 - 256) {
+            if (r->nmax > 40000) {
+                snprintf(g_err, sizeof(g_err), "molecule with %d atoms: more than the 40000 the pair indices are sized for", r->nmax);
+                return PW_E_TOO_LARGE;
+            }
+            long grid = 2L * c->n_cu;
+            if (grid > r->n_units) grid = r->n_units;
+            rc = ensure_workspace(c, (int)grid, (int)grid);
+            if (rc != PW_OK) return rc;
+            const size_t bb = pw_internal_big_block_bytes(r->nmax, c->p_cap);
+            if (c->bigmem_bytes < bb * (size_t)grid) {
+                HIP_TRY(hipDeviceSynchronize());
+                if (c->bigmem) HIP_TRY(hipFree(c->bigmem));
+                c->bigmem = nullptr;
+                c->bigmem_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&c->bigmem, bb * (size_t)grid));
+                c->bigmem_bytes = bb * (size_t)grid;
+            }
+            c->need_fork = 1;
+            rc = join_pipeline(c);
+            if (rc != PW_OK) return rc;
+            if (r->read_valid[r->cur]) {
+                HIP_TRY(hipStreamWaitEvent(c->stream, r->ev_read[r->cur], 0));
+                r->read_valid[r->cur] = 0;
+            }
+            r->written_set[r->cur] = -1;
+            HIP_TRY(hipMemsetAsync(r->d_xw_count + r->cur, 0, sizeof(unsigned), c->stream));
+            HIP_TRY(hipMemsetAsync(c->counter + 3 * PW_SETS + 1, 0, sizeof(unsigned long long), c->stream));
+            PwWsArgs wsa;
+            wsa.ws = c->ws; wsa.slab = c->slab; wsa.adj = c->adj;
+            wsa.xwin = r->d_xw[r->cur]; wsa.xwin_count = r->d_xw_count + r->cur; wsa.xwin_cap = r->xw_cap;
+            wsa.p_cap = c->p_cap;
+            wsa.nb_off = c->nb_off; wsa.nb_idx = c->nb_idx; wsa.nb_bound = c->nb_bound;
+            return pw_internal_big_launch((void*)c->stream, (int)grid, r->n_units, r->d_offset, r->d_xyz, r->d_vdw, r->d_mass,
+                                          stages, r->nmax, &wsa, c->bigmem, bb, c->counter + 3 * PW_SETS + 1, r->d_out, &c->prm,
+                                          c->rsq_tab, r->vstride);
+        }
+    }
+    const bool pipeline = !c->fused && (stages & PW_STAGE_WINDOWS) != 0;
     if (!pipeline) {
         // one launch: every requested stage inside the same team
         LaunchPlan p;

@@ -1,0 +1,33 @@
+// pw_launch.hpp -- what a launch hands its teams, shared by the translation units that hold analysis
+// kernels (pw_kernels.hip: team memory in LDS; pw_kernels_big.hip: team memory in global memory).
+#pragma once
+#include "../../include/pywindow_amd.h"
+
+// Where a launch's teams find their global workspaces: headers, the per-team slabs of the per-vector
+// arrays (sized by the launch's sampling-vector capacity p_cap), DBSCAN adjacency rows, the launch-wide
+// list of windows beyond what a record holds, and the neighbour tables of the sampling sphere.
+struct PwWsArgs {
+    void* ws;                       // TeamWorkspace array of the launch
+    unsigned char* slab;            // team t: slab + t * team_slab_bytes(p_cap)
+    unsigned long long* adj;        // team t: adj + t * team_adj_words(p_cap); null: the launch runs no DBSCAN
+    pw_extra_window* xwin;
+    unsigned* xwin_count;
+    unsigned xwin_cap;
+    int p_cap;
+    const unsigned* nb_off;         // neighbour tables of the sampling sphere (pw_unit.hpp), null: none
+    const unsigned short* nb_idx;
+    const double* nb_bound;
+};
+
+#if defined(__HIPCC__)
+// (slab_bytes / adj_words: team_slab_bytes(p_cap) / team_adj_words(p_cap) of the caller's pw_unit.hpp)
+template <class WS>
+__device__ inline void bind_workspace(WS* ws, const PwWsArgs& a, unsigned team, const unsigned* rsq_tab, size_t slab_bytes,
+                                      size_t adj_words) {
+    bind_team_slab(ws, a.slab + (size_t)team * slab_bytes, a.p_cap);
+    ws->adj = a.adj ? a.adj + (size_t)team * adj_words : nullptr;
+    ws->xwin = a.xwin; ws->xwin_count = a.xwin_count; ws->xwin_cap = a.xwin_cap;
+    ws->nb_off = a.nb_off; ws->nb_idx = a.nb_idx; ws->nb_bound = a.nb_bound;
+    ws->rsq = rsq_tab;
+}
+#endif

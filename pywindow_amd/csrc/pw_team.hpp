@@ -52,6 +52,11 @@ struct DeviceTeam {
     // compiler not to reorder across this point and the LDS queue drained
     __device__ static void wave_sync() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#if defined(PW_GENERIC_TEAM_MEM)
+        // team memory is global here: lanes exchange data through the vector memory path, so its queue
+        // is drained as well
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }

@@ -743,7 +743,9 @@ def cliff_cases():
         calls.append((f"cc3/win/adjust={a}", "win", "cc3", {"adjust": a}))
     mols["shell20"] = hollow_shell()
     mols["shell32"] = hollow_shell(radius=14.0, holes=32, hole_radius=3.0)
-    for name in ("shell20", "shell32"):
+    # more atoms than a team's LDS holds (the engine's coordinates then live in global memory)
+    mols["shell_big"] = hollow_shell(radius=26.0, holes=14, hole_radius=7.5)
+    for name in ("shell20", "shell32", "shell_big"):
         calls.append((f"{name}/win/default", "win", name, {}))
         calls.append((f"{name}/avg/default", "avg", name, {}))
     return mols, calls

@@ -25,4 +25,4 @@ with tempfile.TemporaryDirectory() as tmp:
                 ts.append(1e3 * (time.perf_counter() - t0))
             print(f"frames {n} {label}: median {np.median(ts[2:]):.2f} ms ({n / np.median(ts[2:]) * 1e3:.0f} frames/s) "
                   f"reps {[round(t, 1) for t in ts]} status0 {(recs['status'] == 0).all()}", flush=True)
-        trajectory.RUN_PIECE_MIN = 1000
+        trajectory.RUN_PIECE_MIN = 250
