@@ -79,7 +79,7 @@ extern "C" int pw_hostpath_run(const pw_batch_in* in, unsigned stages, pw_unit_o
     unsigned xcount = 0;            // (bumped with atomic increments: pw_unit.hpp team_atomic_inc)
     const int vstride = in->template_atoms > 0 ? 0 : 1;
     auto worker = [&]() {
-        const size_t bytes = UnitShared::bytes(nmax, 1, 1, 2, false, p_cap);
+        const size_t bytes = UnitShared::bytes(nmax, 1, 8, 2, false, p_cap);
         unsigned char* lds = (unsigned char*)aligned_alloc(16, (bytes + 15) & ~(size_t)15);
         TeamWorkspace* ws = (TeamWorkspace*)calloc(1, sizeof(TeamWorkspace));
         unsigned char* slab = (unsigned char*)malloc(team_slab_bytes(p_cap));
@@ -101,7 +101,7 @@ extern "C" int pw_hostpath_run(const pw_batch_in* in, unsigned stages, pw_unit_o
             ws->nb_off = g_tables.off.data(); ws->nb_idx = g_tables.idx.data(); ws->nb_bound = g_tables.bound.data();
             memset(lds, 0, bytes);
             UnitShared sh;
-            sh.carve(lds, nmax, 1, 1, 2, false, p_cap);
+            sh.carve(lds, nmax, 1, 8, 2, false, p_cap);
             const long a0 = (long)in->atom_offset[u];
             const int n = (int)(in->atom_offset[u + 1] - a0);
             memset(&out[u], 0, sizeof(pw_unit_out));

@@ -769,8 +769,10 @@ int pw_context_create(int device, pw_context** out) {
     const char* cw = getenv("PW_C_WAVES");
     c->c_waves = (cw && cw[0] == '8') ? 8 : 4;
     c->prm = default_params();
-    if (!c->fused) {
-        // Do the ten streams of the pipeline really run side by side?  (GPU_MAX_HW_QUEUES is read when the
+    if (!c->fused && !(getenv("PW_STREAM_PROBE") && getenv("PW_STREAM_PROBE")[0] == '0')) {
+        // Do the ten streams of the pipeline really run side by side?  (PW_STREAM_PROBE=0 skips the question:
+        // a profiler that serialises kernels -- rocprofv3 --pmc -- would otherwise turn the pipeline off and
+        // count a different kernel.)  (GPU_MAX_HW_QUEUES is read when the
         // process initialises HIP: an application that did so before this library exported it -- PyTorch
         // imported and used first, a direct binding of the C ABI -- has the default of four hardware queues.)
         hipStream_t all[2 + 2 * PW_SETS];
@@ -1056,7 +1058,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     bool do_avg = (stages & PW_STAGE_AVG) != 0;
     pb.grid = 0;
     if (do_avg) {
-        rc = plan_launch(c, r->n_units, r->nmax, 4, false, 2, &pb, 1, true);   // one frame; 2 state slots = 14 KB of scratch
+        rc = plan_launch(c, r->n_units, r->nmax, 4, false, 7, &pb, 1, true);   // one frame; 7 state slots = 51 KB of scratch (ray vectors + cone pairs)
         if (rc != PW_OK) return rc;
     }
     rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pc, 1);      // one frame, shifted in place

@@ -1008,6 +1008,121 @@ PW_NOINLINE PW_HD inline void ray_scan_multi(const Frame& F, int n, const double
     ray_scan_multi_impl<NR, FAR>(F, n, cen, dx, dy, dz, hit, farthest);
 }
 
+
+// ---- ray tests of a whole sampling sphere, atom by atom --------------------------------------------
+// vector_preanalysis / vector_analysis_reversed (utilities.py:1132-1161, 1556-1583) ask, for each of P
+// rays from the centroid, which atoms the line meets.  An atom of radius r at distance |rel| can only be
+// met by rays inside a cone of half-angle asin(r / |rel|) about its direction -- some 1 % of the sphere --
+// and the rays of a golden spiral with a given polar angle are a contiguous index range.  So instead of
+// testing every (ray, atom) pair (P x N screens), one wave per atom walks the atom's index range, keeps
+// the rays inside the cone (one dot product each, conservative) as (ray, atom) pairs, and the exact
+// arithmetic of the reference then runs on the pairs only, one pair per lane.  A ray is stopped if any of
+// its pairs says so and its farthest exit is the maximum over its pairs: both independent of the order in
+// which the pairs are visited, so the results are those of the dense scan, bit for bit.
+// Returns false (nothing written) when the pair list is too small or an index does not fit 16 bits.
+PW_HD inline void team_store_max_pos(double* p, double v) {     // *p = max(*p, v) for v > 0, *p >= -1
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMax((long long*)p, __double_as_longlong(v));           // (positive doubles order like their bits)
+#else
+    if (v > *p) *p = v;
+#endif
+}
+template <class T, bool FAR, class GETP>
+PW_HD inline __attribute__((always_inline)) bool team_ray_tests(const Frame& F, int n, const double* cen, const Sphere& sp,
+                                                               GETP getp, unsigned* pairs, int cap, PW_LDS int* counter,
+                                                               unsigned char* flag, unsigned char hit_value, double* far) {
+    const int P = sp.P;
+    if (P >= 65536 || n >= 65536 || cap < 64) return false;
+    if (T::tid() == 0) *counter = 0;
+    T::sync();
+    const double c0 = cen[0], c1 = cen[1], c2 = cen[2];
+    const double cn = norm3(c0, c1, c2);
+    for (int i = T::wave(); i < n; i += T::NWAVES) {
+        const double rx = F.x[i] - c0, ry = F.y[i] - c1, rz = F.z[i] - c2, vr = F.vdw[i];
+        const double rr = sq3(rx, ry, rz);
+        // the line meets the sphere only if |rel|^2 - along^2 <= r^2 (with the margin of the dense screen)
+        const double a2 = rr - pw_fma(rr, 1e-12, (vr * vr) * (1.0 + 1e-12));
+        int klo = 0, khi = P - 1;
+        double thr = -PW_INF;                       // on dot(ray vector, rel); -inf: every ray is a candidate
+        bool two_sided = true;
+        if (a2 > 0.0) {
+            const double amin = pw_sqrt(a2) * (1.0 - 1e-9);      // smallest |along| of a meeting line
+            thr = amin * sp.R * (1.0 - 1e-9);
+            // an atom behind the centroid (along < 0) only counts if along > -(cen . u) >= -|cen|
+            // (utilities.py:1152-1155 compares distances from the ORIGIN): out of the question when the
+            // cone's smallest |along| exceeds |cen|
+            if (amin > cn + 1e-6) {
+                two_sided = false;
+                const double len = pw_sqrt(rr);
+                const double zd = rz / len, c = amin / len;
+                const double s_ = pw_sqrt(pw_max(1.0 - c * c, 0.0)) * (1.0 + 1e-9) + 1e-9;
+                const double rho = pw_sqrt(pw_max(1.0 - zd * zd, 0.0));
+                const double zhi = zd >= c ? 1.0 : pw_min(1.0, zd * c + rho * s_ + 1e-9);
+                const double zlo = zd <= -c ? -1.0 : pw_max(-1.0, zd * c - rho * s_ - 1e-9);
+                // z_k = start + k * step, step < 0
+                const double kh = (zlo - sp.start) / sp.step, kl = (zhi - sp.start) / sp.step;
+                klo = (int)pw_max(kl - 2.0, 0.0);
+                khi = (int)pw_min(kh + 3.0, (double)(P - 1));
+            }
+        }
+        for (int kb = klo; kb <= khi; kb += T::WSIZE) {
+            const int k = kb + T::lane();
+            bool f = false;
+            if (k <= khi) {
+                double px, py, pz;
+                getp(k, &px, &py, &pz);
+                const double dot = pw_fma(pz, rz, pw_fma(px, rx, py * ry));
+                f = two_sided ? pw_abs(dot) >= thr : dot >= thr;
+            }
+            const unsigned long long bal = T::ballot(f);
+            if (bal) {
+                int base = 0;
+                if (T::lane() == 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    base = atomicAdd((int*)counter, __builtin_popcountll(bal));
+#else
+                    base = *counter; *counter += __builtin_popcountll(bal);
+#endif
+                }
+                base = T::bcast_i(base, 0);
+                const int pos = base + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
+                if (f && pos < cap) pairs[pos] = ((unsigned)k << 16) | (unsigned)i;
+            }
+        }
+    }
+    T::sync();
+    const int np = *counter;
+    T::sync();
+    if (np > cap) return false;
+    for (int p = T::tid(); p < np; p += T::SIZE) {
+        const unsigned pr = pairs[p];
+        const int k = (int)(pr >> 16), i = (int)(pr & 0xffffu);
+        double dx, dy, dz;
+        getp(k, &dx, &dy, &dz);
+        // the exact arithmetic of ray_scan_impl for this (ray, atom)
+        const double nrm = norm3(dx, dy, dz);
+        const double ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
+        const double rx = F.x[i] - c0, ry = F.y[i] - c1, rz = F.z[i] - c2;
+        const double along = pw_fma(rz, uz, pw_fma(rx, ux, ry * uy));
+        const double sq = sq3(rx, ry, rz);
+        const double perp = pw_sqrt(sq - along * along);
+        const double radicand = F.vdw[i] * F.vdw[i] - perp * perp;
+        if (radicand > 0.0) {
+            const double half = pw_sqrt(radicand);
+            const double tin = along - half, tout = along + half;
+            const double ix = c0 + tin * ux, iy = c1 + tin * uy, iz = c2 + tin * uz;
+            const double ox = c0 + tout * ux, oy = c1 + tout * uy, oz = c2 + tout * uz;
+            const double nin = norm3(ix, iy, iz), nout = norm3(ox, oy, oz);
+            if (nin < nout) {
+                flag[k] = hit_value;
+                if (FAR) team_store_max_pos(&far[k], nout);
+            }
+        }
+    }
+    T::sync();
+    return true;
+}
+
 // numpy floor division a // b for positive doubles (npy_divmod)
 PW_HD inline double np_floordiv(double a, double b) {
     double mod = __builtin_fmod(a, b);
@@ -1607,7 +1722,27 @@ PW_HD inline __attribute__((always_inline)) void stage_average_impl(UnitShared& 
     double cen[3] = {v.centroid[0], v.centroid[1], v.centroid[2]};
     if (T::wave() == 0) PW_T1(ws, 27, t_a0);
     PW_T0(t_a1);
-    if (T::SIZE > 1) {
+    // atom by atom over the rays inside each atom's cone (team_ray_tests) when the ray vectors fit the
+    // launch's LDS scratch; the dense scan (every ray against every atom) otherwise
+    bool done = false;
+    {
+        ScratchArena a2 = arena;
+        double* apts = (double*)a2.take((size_t)P * 24);
+        if (apts) {
+            for (int k = T::tid(); k < P; k += T::SIZE) {
+                sp.point(k, &apts[k], &apts[P + k], &apts[2 * P + k]);
+                vals[k] = -1.0;
+                flag[k] = 0;
+            }
+            int cap = (int)(a2.left / 4);
+            unsigned* pairs = (unsigned*)a2.take((size_t)cap * 4);
+            if (cap < 4 * P) { pairs = (unsigned*)ws->knn; cap = 20 * ws->p_cap; }
+            auto getp = [&](int k, double* x, double* y, double* z) { *x = apts[k]; *y = apts[P + k]; *z = apts[2 * P + k]; };
+            done = team_ray_tests<T, true>(sh.S, n, cen, sp, getp, pairs, cap, (PW_LDS int*)&v.red_i[0], flag, 1, vals);
+        }
+    }
+    if (done) {
+    } else if (T::SIZE > 1) {
         // four rays per thread and pass over the atoms
         constexpr int NR = 4;
         for (int k0 = T::tid(); k0 < P; k0 += NR * T::SIZE) {
@@ -2503,7 +2638,20 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
     //      neighbours walk a path.
     {
         double cen[3] = {v.centroid[0], v.centroid[1], v.centroid[2]};
-        if (T::SIZE > 1) {
+        // atom by atom over the rays inside each atom's cone (team_ray_tests); the pair list borrows what is
+        // left of the arena (the path-scan values are not alive yet), else the k-NN rows of the workspace
+        bool done = false;
+        {
+            for (int k = T::tid(); k < P; k += T::SIZE) flag[k] = 1;
+            ScratchArena a2 = arena_mark;
+            int cap = (int)(a2.left / 4);
+            unsigned* pairs = (unsigned*)a2.take((size_t)cap * 4);
+            if (cap < 4 * P) { pairs = (unsigned*)ws->knn; cap = 20 * ws->p_cap; }
+            auto getp = [&](int k, double* x, double* y, double* z) { *x = pts[PT(k, 0)]; *y = pts[PT(k, 1)]; *z = pts[PT(k, 2)]; };
+            done = team_ray_tests<T, false>(sh.S, n, cen, sp, getp, pairs, cap, (PW_LDS int*)&v.red_i[0], flag, 0, nullptr);
+        }
+        if (done) {
+        } else if (T::SIZE > 1) {
             constexpr int NR = 4;
             for (int k0 = T::tid(); k0 < P; k0 += NR * T::SIZE) {
                 double dx[NR], dy[NR], dz[NR], far[NR];
@@ -2739,7 +2887,6 @@ PW_HD inline void record_or_status(pw_unit_out* out, int st, int evals) {
 }
 
 constexpr unsigned PW_KERNEL_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
-constexpr unsigned PW_KERNEL_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE;
 
 template <class T, unsigned KMASK = 0xffffffffu>
 PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const double* xyz,
@@ -2773,14 +2920,7 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
     } else {
         stage_basic<T>(sh, ws, n, out, (stages & PW_STAGE_COM_ONLY) != 0);
     }
-#ifdef PW_INLINE_OPT
-    // the optimiser-chain kernel: the chain IS the kernel body (no call, no callee-saved register save area)
-    if (stages & PW_STAGE_OPT) {
-        if (KMASK == PW_KERNEL_CHAINS) stage_opt_impl<T>(sh, ws, n, out, prm); else stage_opt<T>(sh, ws, n, out, prm);
-    }
-#else
     if (stages & PW_STAGE_OPT) stage_opt<T>(sh, ws, n, out, prm);
-#endif
     if (reuse_opt) {
         if (T::tid() == 0) {
             sh.v->opt_c[0] = out->pore_opt_c[0];

@@ -30,11 +30,9 @@ MODULAR_CHUNK = 8192
 #: being read and re-assembled
 MODULAR_PIECE = 1024
 MODULAR_IN_FLIGHT = 2
-#: a plain analysis goes through in about RUN_PIECES pieces, each between RUN_PIECE_MIN and RUN_PIECE frames, so
-#: that parsing, copies and kernels of successive pieces overlap (see DLPOLY._run)
-RUN_PIECES = 8
-RUN_PIECE = 4096
-RUN_PIECE_MIN = 250
+#: a plain analysis goes through in ONE piece up to 2 x RUN_PIECE frames and in pieces of RUN_PIECE beyond (what
+#: bounds the device memory of a very long trajectory; see DLPOLY._run for why not smaller)
+RUN_PIECE = 16384
 
 
 class _FunctionError(Exception):
@@ -249,22 +247,19 @@ class DLPOLY:
             self.analysis_output[f] = {"0": props}
 
     def _run(self, frames: list[int], vdw, mass, device):
-        """Records of the given frames.  A long selection goes through in pieces of equal size: while the
-        GPU analyses one piece (its launches are asynchronous) the host threads of the native reader
-        tokenise the next, so the text parsing -- 1.3 ms per 1000 frames -- hides behind the kernels
-        instead of preceding them (10 000 frames, file to records: 35 -> 26.5 ms)."""
+        """Records of the given frames (tokenised by the native reader's threads, 1.3 ms per 1000 frames)."""
         self._extra = np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE)   # windows beyond what a record holds, by unit
         if not frames:
             return np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE)
         n = len(frames)
         ctx = engine.context(device)
-        per = min(max(-(-n // RUN_PIECES), RUN_PIECE_MIN), RUN_PIECE)
-        if n < 2 * RUN_PIECE_MIN:
-            per = n
-        # The pieces go through one after the other on the host -- decode into the context's page-locked
-        # buffer, one pooled device block, copies by DMA, three asynchronous launches -- and all at once on
-        # the device: piece k is being analysed while piece k + 1 is tokenised (1000 frames: four pieces of
-        # 250; the launches of different pieces are not paced against each other, pw_resident_launch).
+        per = n if n <= 2 * RUN_PIECE else RUN_PIECE
+        # Decode into the context's page-locked buffer, one pooled device block, copies by DMA, three
+        # asynchronous launches.  Cutting a trajectory into small pieces that overlap on the device was
+        # measured and is SLOWER (MI355X, file to records: 1000 frames 5.05 ms in one piece, 7.0 ms in four;
+        # 10 000 frames 21.8 against 22.7 ms): the persistent window teams of a piece keep their LDS until the
+        # piece's slowest optimiser chain is done, so the teams of later pieces wait for a place instead of
+        # working -- one launch hands finished units to whichever team is free.  Pieces only bound memory.
         inflight = []
         try:
             for lo in range(0, n, per):

@@ -42,7 +42,11 @@ static int run_batch(long n_units, const long* off, const double* xyz, const dou
     *xw_count = 0;
     int nmax = 0;
     for (long u = 0; u < n_units; ++u) { int n = (int)(off[u + 1] - off[u]); if (n > nmax) nmax = n; }
-    size_t bytes = UnitShared::bytes(nmax, 1, 1, 2, false, p_cap);
+    // (HS_NLB: optimiser-state slots carved = size of the team's scratch arena; 8 lets every LDS-resident
+    // variant of the stages run on the host as it does in the kernels, 1 forces their fallbacks)
+    const char* nlb_env = getenv("HS_NLB");
+    const int nlb = nlb_env ? atoi(nlb_env) : 8;
+    size_t bytes = UnitShared::bytes(nmax, 1, nlb, 2, false, p_cap);
     unsigned char* lds = (unsigned char*)aligned_alloc(16, (bytes + 15) & ~(size_t)15);
     TeamWorkspace* ws = (TeamWorkspace*)calloc(1, sizeof(TeamWorkspace));
     unsigned char* slab = (unsigned char*)malloc(team_slab_bytes(p_cap));
@@ -100,7 +104,7 @@ static int run_batch(long n_units, const long* off, const double* xyz, const dou
             if ((fa || fb) && a < b) memset(lds + a, fill, b - a);
         }
         UnitShared sh;
-        sh.carve(lds, nmax, 1, 1, 2, false, p_cap);
+        sh.carve(lds, nmax, 1, nlb, 2, false, p_cap);
         int n = (int)(off[u + 1] - off[u]);
         memset(&out[u], 0, sizeof(pw_unit_out));
         analyse_unit<HostTeam>(sh, ws, n, xyz + 3 * off[u], vdw + off[u], mass + off[u], stages, &out[u], prm);
@@ -143,12 +147,12 @@ extern "C" double hs_pairwise_sum(const double* a, long n) {
 }
 // ... and the serial restatement it replaced in round 1 (np_sum_serial), kept as a cross-check
 extern "C" double hs_pairwise_sum_serial(const double* a, long n) { return np_sum_serial(a, (int)n); }
-extern "C" long hs_lds_bytes(int nmax) { return (long)UnitShared::bytes(nmax, 1, 1); }
+extern "C" long hs_lds_bytes(int nmax) { return (long)UnitShared::bytes(nmax, 1, 8); }
 extern "C" long hs_lds_offset(int nmax, int what) {
     // byte offsets of the parts of the team-shared block (for the poison tests)
     static unsigned char dummy[1];
     UnitShared sh;
-    sh.carve(dummy, nmax, 1, 1);
+    sh.carve(dummy, nmax, 1, 8);
     const unsigned char* base = dummy;
     switch (what) {
         case 0: return (long)((const unsigned char*)sh.v - base);
@@ -160,6 +164,6 @@ extern "C" long hs_lds_offset(int nmax, int what) {
         case 6: return (long)((const unsigned char*)sh.S.x - base);
         case 7: return (long)((const unsigned char*)sh.R[0].x - base);
         case 8: return (long)((const unsigned char*)sh.lb[0] - base);
-        default: return (long)UnitShared::bytes(nmax, 1, 1);
+        default: return (long)UnitShared::bytes(nmax, 1, 8);
     }
 }

@@ -86,13 +86,13 @@ def test_dlpoly_batched_analysis(tmp_path):
     from pywindow_amd import trajectory
 
     whole = traj.analysis_records()
-    old = trajectory.RUN_PIECE_MIN, trajectory.RUN_PIECE
-    trajectory.RUN_PIECE_MIN, trajectory.RUN_PIECE = 2, 4
+    old = trajectory.RUN_PIECE
+    trajectory.RUN_PIECE = 4
     try:
         assert traj.analysis_records().tobytes() == whole.tobytes()       # 12 frames -> 3 pieces of 4
         assert traj.analysis_records(frames=list(range(11))).tobytes() == whole[:11].tobytes()
     finally:
-        trajectory.RUN_PIECE_MIN, trajectory.RUN_PIECE = old
+        trajectory.RUN_PIECE = old
 
 
 def test_record_gather_over_rccl_single_rank():

@@ -16,8 +16,8 @@ with tempfile.TemporaryDirectory() as tmp:
     for n in sizes:
         path = synth.write_synthetic_history(pathlib.Path(tmp) / f"H{n}", n)
         traj = pw.DLPOLY(path)
-        for label, piece_min in (("one piece", 10 ** 9), ("pieces", trajectory.RUN_PIECE_MIN)):
-            trajectory.RUN_PIECE_MIN = piece_min
+        for label, piece in (("one piece", 10 ** 9), ("four pieces", max(1, n // 4))):
+            trajectory.RUN_PIECE = piece if piece < 10 ** 9 else 10 ** 9
             ts = []
             for rep in range(7):
                 t0 = time.perf_counter()
@@ -25,4 +25,4 @@ with tempfile.TemporaryDirectory() as tmp:
                 ts.append(1e3 * (time.perf_counter() - t0))
             print(f"frames {n} {label}: median {np.median(ts[2:]):.2f} ms ({n / np.median(ts[2:]) * 1e3:.0f} frames/s) "
                   f"reps {[round(t, 1) for t in ts]} status0 {(recs['status'] == 0).all()}", flush=True)
-        trajectory.RUN_PIECE_MIN = 250
+        trajectory.RUN_PIECE = 16384

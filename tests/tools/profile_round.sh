@@ -14,6 +14,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
+export PW_STREAM_PROBE=0     # (counter passes serialise kernels: keep the pipeline's launch shape anyway)
 T=$R/tests/tools
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/ov -o ov --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/ov.log 2>&1
