@@ -1027,32 +1027,34 @@ PW_HD inline void team_store_max_pos(double* p, double v) {     // *p = max(*p, 
     if (v > *p) *p = v;
 #endif
 }
+// per-atom cone data computed by one lane each (band of ray indices, threshold on dot(ray vector, rel))
+struct ConeBand { double thr; int klo, khi; };     // khi < 0: two-sided test (|dot|), khi = -khi - 1
 template <class T, bool FAR, class GETP>
 PW_HD inline __attribute__((always_inline)) bool team_ray_tests(const Frame& F, int n, const double* cen, const Sphere& sp,
-                                                               GETP getp, unsigned* pairs, int cap, PW_LDS int* counter,
-                                                               unsigned char* flag, unsigned char hit_value, double* far) {
+                                                               GETP getp, ConeBand* bands, unsigned* pairs, int cap,
+                                                               PW_LDS int* counts, unsigned char* flag,
+                                                               unsigned char hit_value, double* far) {
     const int P = sp.P;
-    if (P >= 65536 || n >= 65536 || cap < 64) return false;
-    if (T::tid() == 0) *counter = 0;
-    T::sync();
+    const int seg = cap / T::NWAVES;                 // every wave appends to a segment of its own: no atomics
+    if (P >= 65536 || n >= 65536 || seg < 64) return false;
     const double c0 = cen[0], c1 = cen[1], c2 = cen[2];
     const double cn = norm3(c0, c1, c2);
-    for (int i = T::wave(); i < n; i += T::NWAVES) {
+    // ---- the cones, one atom per lane ----
+    for (int i = T::tid(); i < n; i += T::SIZE) {
         const double rx = F.x[i] - c0, ry = F.y[i] - c1, rz = F.z[i] - c2, vr = F.vdw[i];
         const double rr = sq3(rx, ry, rz);
         // the line meets the sphere only if |rel|^2 - along^2 <= r^2 (with the margin of the dense screen)
         const double a2 = rr - pw_fma(rr, 1e-12, (vr * vr) * (1.0 + 1e-12));
-        int klo = 0, khi = P - 1;
-        double thr = -PW_INF;                       // on dot(ray vector, rel); -inf: every ray is a candidate
-        bool two_sided = true;
+        ConeBand b;
+        b.klo = 0; b.khi = -P;                     // every ray, two-sided
+        b.thr = -PW_INF;
         if (a2 > 0.0) {
             const double amin = pw_sqrt(a2) * (1.0 - 1e-9);      // smallest |along| of a meeting line
-            thr = amin * sp.R * (1.0 - 1e-9);
+            b.thr = amin * sp.R * (1.0 - 1e-9);
             // an atom behind the centroid (along < 0) only counts if along > -(cen . u) >= -|cen|
             // (utilities.py:1152-1155 compares distances from the ORIGIN): out of the question when the
             // cone's smallest |along| exceeds |cen|
             if (amin > cn + 1e-6) {
-                two_sided = false;
                 const double len = pw_sqrt(rr);
                 const double zd = rz / len, c = amin / len;
                 const double s_ = pw_sqrt(pw_max(1.0 - c * c, 0.0)) * (1.0 + 1e-9) + 1e-9;
@@ -1061,45 +1063,54 @@ PW_HD inline __attribute__((always_inline)) bool team_ray_tests(const Frame& F, 
                 const double zlo = zd <= -c ? -1.0 : pw_max(-1.0, zd * c - rho * s_ - 1e-9);
                 // z_k = start + k * step, step < 0
                 const double kh = (zlo - sp.start) / sp.step, kl = (zhi - sp.start) / sp.step;
-                klo = (int)pw_max(kl - 2.0, 0.0);
-                khi = (int)pw_min(kh + 3.0, (double)(P - 1));
+                b.klo = (int)pw_max(kl - 2.0, 0.0);
+                b.khi = (int)pw_min(kh + 3.0, (double)(P - 1));
             }
         }
-        for (int kb = klo; kb <= khi; kb += T::WSIZE) {
+        bands[i] = b;
+    }
+    T::sync();
+    // ---- the rays inside each cone: one wave per atom walks the atom's index band ----
+    int mine = 0;                                   // pairs appended by this wave so far (wave-uniform)
+    unsigned* my = pairs + (size_t)T::wave() * seg;
+    for (int i = T::wave(); i < n; i += T::NWAVES) {
+        const ConeBand b = bands[i];
+        const bool two_sided = b.khi < 0;
+        const int khi = two_sided ? -b.khi - 1 : b.khi;
+        const double rx = F.x[i] - c0, ry = F.y[i] - c1, rz = F.z[i] - c2;
+        for (int kb = b.klo; kb <= khi; kb += T::WSIZE) {
             const int k = kb + T::lane();
             bool f = false;
             if (k <= khi) {
                 double px, py, pz;
                 getp(k, &px, &py, &pz);
                 const double dot = pw_fma(pz, rz, pw_fma(px, rx, py * ry));
-                f = two_sided ? pw_abs(dot) >= thr : dot >= thr;
+                f = two_sided ? pw_abs(dot) >= b.thr : dot >= b.thr;
             }
             const unsigned long long bal = T::ballot(f);
-            if (bal) {
-                int base = 0;
-                if (T::lane() == 0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                    base = atomicAdd((int*)counter, __builtin_popcountll(bal));
-#else
-                    base = *counter; *counter += __builtin_popcountll(bal);
-#endif
-                }
-                base = T::bcast_i(base, 0);
-                const int pos = base + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
-                if (f && pos < cap) pairs[pos] = ((unsigned)k << 16) | (unsigned)i;
-            }
+            const int pos = mine + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
+            if (f && pos < seg) my[pos] = ((unsigned)k << 16) | (unsigned)i;
+            mine += __builtin_popcountll(bal);
         }
     }
+    if (T::lane() == 0) counts[T::wave()] = mine;
     T::sync();
-    const int np = *counter;
+    int cum[T::NWAVES + 1];
+    cum[0] = 0;
+    bool fits = true;
+#pragma unroll
+    for (int w = 0; w < T::NWAVES; ++w) { const int cw = counts[w]; fits = fits && cw <= seg; cum[w + 1] = cum[w] + cw; }
     T::sync();
-    if (np > cap) return false;
-    for (int p = T::tid(); p < np; p += T::SIZE) {
-        const unsigned pr = pairs[p];
+    if (!fits) return false;
+    // ---- the reference's arithmetic on the pairs, one pair per lane ----
+    for (int g = T::tid(); g < cum[T::NWAVES]; g += T::SIZE) {
+        int w = 0;
+#pragma unroll
+        for (int q = 1; q < T::NWAVES; ++q) w += g >= cum[q] ? 1 : 0;
+        const unsigned pr = pairs[(size_t)w * seg + (g - cum[w])];
         const int k = (int)(pr >> 16), i = (int)(pr & 0xffffu);
         double dx, dy, dz;
         getp(k, &dx, &dy, &dz);
-        // the exact arithmetic of ray_scan_impl for this (ray, atom)
         const double nrm = norm3(dx, dy, dz);
         const double ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
         const double rx = F.x[i] - c0, ry = F.y[i] - c1, rz = F.z[i] - c2;
@@ -1734,11 +1745,14 @@ PW_HD inline __attribute__((always_inline)) void stage_average_impl(UnitShared& 
                 vals[k] = -1.0;
                 flag[k] = 0;
             }
+            ConeBand* bands = (ConeBand*)a2.take((size_t)n * sizeof(ConeBand));
             int cap = (int)(a2.left / 4);
             unsigned* pairs = (unsigned*)a2.take((size_t)cap * 4);
-            if (cap < 4 * P) { pairs = (unsigned*)ws->knn; cap = 20 * ws->p_cap; }
+            if (cap < 4 * P) { pairs = (unsigned*)ws->knn; cap = 16 * ws->p_cap; }
+            if (!bands && (size_t)n * sizeof(ConeBand) <= (size_t)ws->p_cap * 16) bands = (ConeBand*)(ws->knn + 8 * (size_t)ws->p_cap);
             auto getp = [&](int k, double* x, double* y, double* z) { *x = apts[k]; *y = apts[P + k]; *z = apts[2 * P + k]; };
-            done = team_ray_tests<T, true>(sh.S, n, cen, sp, getp, pairs, cap, (PW_LDS int*)&v.red_i[0], flag, 1, vals);
+            if (bands)
+                done = team_ray_tests<T, true>(sh.S, n, cen, sp, getp, bands, pairs, cap, (PW_LDS int*)&v.red_i[0], flag, 1, vals);
         }
     }
     if (done) {
@@ -2644,11 +2658,14 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
         {
             for (int k = T::tid(); k < P; k += T::SIZE) flag[k] = 1;
             ScratchArena a2 = arena_mark;
+            ConeBand* bands = (ConeBand*)a2.take((size_t)n * sizeof(ConeBand));
             int cap = (int)(a2.left / 4);
             unsigned* pairs = (unsigned*)a2.take((size_t)cap * 4);
-            if (cap < 4 * P) { pairs = (unsigned*)ws->knn; cap = 20 * ws->p_cap; }
+            if (cap < 4 * P) { pairs = (unsigned*)ws->knn; cap = 16 * ws->p_cap; }
+            if (!bands && (size_t)n * sizeof(ConeBand) <= (size_t)ws->p_cap * 16) bands = (ConeBand*)(ws->knn + 8 * (size_t)ws->p_cap);
             auto getp = [&](int k, double* x, double* y, double* z) { *x = pts[PT(k, 0)]; *y = pts[PT(k, 1)]; *z = pts[PT(k, 2)]; };
-            done = team_ray_tests<T, false>(sh.S, n, cen, sp, getp, pairs, cap, (PW_LDS int*)&v.red_i[0], flag, 0, nullptr);
+            if (bands)
+                done = team_ray_tests<T, false>(sh.S, n, cen, sp, getp, bands, pairs, cap, (PW_LDS int*)&v.red_i[0], flag, 0, nullptr);
         }
         if (done) {
         } else if (T::SIZE > 1) {
