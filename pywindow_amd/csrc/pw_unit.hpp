@@ -52,6 +52,14 @@
 #ifndef PW_UNROLL_KNN
 #define PW_UNROLL_KNN 2
 #endif
+// register tiles of the two bulk evaluations of the window search: path points / grid points per thread
+// that share one pass over the atoms (6 and 7 fill a 256-register budget; smaller tiles for smaller budgets)
+#ifndef PW_TILE_PATH
+#define PW_TILE_PATH 6
+#endif
+#ifndef PW_TILE_GRID
+#define PW_TILE_GRID 7
+#endif
 
 namespace pw {
 
@@ -1164,7 +1172,7 @@ PW_NOINLINE PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx,
     bool ok = true;
     // six path points per pass over the atoms (the reference stops at the first point inside a
     // sphere; evaluating the rest changes nothing: the vector is rejected either way)
-    constexpr int NP = 6;
+    constexpr int NP = PW_TILE_PATH;
     for (int k0 = 0; k0 <= chunks && ok; k0 += NP) {
         double qx[NP], qy[NP], qz[NP], m[NP];
 #pragma unroll
@@ -2091,23 +2099,25 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
         double gbest = PW_INF;
         int gidx = 0x7fffffff;
         if (T::WSIZE == 64) {
-            // a lane's (up to) seven grid points share one pass over the atoms
-            constexpr int NP = 7;
-            double qx[NP], qy[NP], qz[NP], m[NP];
+            // a lane's (up to) seven grid points share one pass over the atoms (PW_TILE_GRID of them at a time)
+            constexpr int NP = PW_TILE_GRID;
+            for (int p0 = 0; p0 < 7; p0 += NP) {
+                double qx[NP], qy[NP], qz[NP], m[NP];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                int q = T::lane() + 64 * p;
-                if (q >= 400) q = T::lane();
-                qx[p] = (double)(q / 20) * gstep + gstart;
-                qy[p] = (double)(q % 20) * gstep + gstart;
-                qz[p] = zopt;
-            }
-            points_gap_values<NP>(R, n, qx, qy, qz, m);
+                for (int p = 0; p < NP; ++p) {
+                    int q = T::lane() + 64 * (p0 + p);
+                    if (q >= 400) q = T::lane();
+                    qx[p] = (double)(q / 20) * gstep + gstart;
+                    qy[p] = (double)(q % 20) * gstep + gstart;
+                    qz[p] = zopt;
+                }
+                points_gap_values<NP>(R, n, qx, qy, qz, m);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                int q = T::lane() + 64 * p;
-                double f = -(m[p] * 2.0);
-                if (q < 400 && f < gbest) { gbest = f; gidx = q; }
+                for (int p = 0; p < NP; ++p) {
+                    int q = T::lane() + 64 * (p0 + p);
+                    double f = -(m[p] * 2.0);
+                    if (p0 + p < 7 && q < 400 && f < gbest) { gbest = f; gidx = q; }
+                }
             }
         } else {
             for (int q = T::lane(); q < 400; q += T::WSIZE) {
