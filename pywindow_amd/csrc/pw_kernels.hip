@@ -434,6 +434,8 @@ struct pw_resident {
     double* d_mass;
     void* block;             // one device block holds every array of an uploaded batch (from the context's cache)
     size_t block_bytes;
+    void* parts[5];          // ... or, for a batch assembled on the device (pw_resident_from_cells), one block per array
+    size_t part_bytes[5];
     pw_unit_out* d_out;      // result records of the latest launch (= d_outs[cur])
     pw_unit_out* d_outs[PW_SETS];
     pw_extra_window* d_xw[PW_SETS];   // windows beyond PW_W_MAX written by the launch into d_outs[k] ...
@@ -466,13 +468,20 @@ static int block_take(pw_context* c, size_t bytes, void** out, size_t* got) {
 }
 static void block_give(pw_context* c, void* p, size_t bytes) {
     if (!p) return;
-    if (c && c->blocks && c->blocks->size() < 32 && c->blocks_bytes + bytes <= ((size_t)8 << 30)) {
+    if (c && c->blocks && c->blocks->size() < 96 && c->blocks_bytes + bytes <= ((size_t)8 << 30)) {
         c->blocks->push_back({p, bytes});
         c->blocks_bytes += bytes;
     } else {
         (void)hipFree(p);
     }
 }
+
+// the same cache for the other translation units (periodic re-assembly: its seventeen temporaries per call)
+extern "C" int pw_internal_block_take(pw_context* c, size_t bytes, void** out, size_t* got) {
+    if (!c || !out || !got || c->device < 0) return PW_E_BAD_ARG;
+    return block_take(c, bytes ? bytes : 8, out, got);
+}
+extern "C" void pw_internal_block_give(pw_context* c, void* p, size_t bytes) { block_give(c, p, bytes); }
 
 // sampling-vector capacity the next launch needs: what the adjust knobs imply (pw_unit.hpp: params_p_cap)
 // or what a unit of an earlier analysis asked for, whichever is larger
@@ -1364,27 +1373,35 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
     return PW_OK;
 }
 
-// a batch whose arrays are already on the device (pw_resident_from_cells); takes ownership
+// a batch whose arrays are already on the device (pw_resident_from_cells); takes ownership of the four
+// blocks (taken from the context's cache: part_bytes says how large each is)
 int pw_internal_resident_adopt(pw_context* c, long n_units, long n_atoms, int nmax, long* d_offset, double* d_xyz,
-                               double* d_vdw, double* d_mass, pw_resident** out) {
-    if (!c || !out || n_units <= 0 || nmax <= 0) return PW_E_BAD_ARG;
+                               double* d_vdw, double* d_mass, const size_t* part_bytes, pw_resident** out) {
+    if (!c || !out || n_units <= 0 || nmax <= 0 || !part_bytes) return PW_E_BAD_ARG;
     PW_HOST_UNSUPPORTED(c, "device batches");
     PW_ON_DEVICE(c->device);
     pw_resident* r = new (std::nothrow) pw_resident();
     if (!r) return PW_E_NOMEM;
-    memset(r, 0, sizeof(*r));
+    memset((void*)r, 0, sizeof(*r));
     r->nbuf = c->nsets ? c->nsets : (n_units <= 1500 ? 4 : (n_units <= 6000 ? 3 : 2));
-    hipError_t e = hipMalloc((void**)&r->d_outs[0], r->nbuf * sizeof(pw_unit_out) * n_units + 64);
-    if (e == hipSuccess) e = hipMemsetAsync(r->d_outs[0], 0, r->nbuf * sizeof(pw_unit_out) * n_units + 64, c->stream);
+    void* outs = nullptr;
+    size_t outs_bytes = 0;
+    int rcb = block_take(c, r->nbuf * sizeof(pw_unit_out) * (size_t)n_units + 64, &outs, &outs_bytes);
+    if (rcb != PW_OK) { delete r; return rcb; }
+    r->d_outs[0] = (pw_unit_out*)outs;
+    hipError_t e = hipMemsetAsync(r->d_outs[0], 0, r->nbuf * sizeof(pw_unit_out) * n_units + 64, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
         set_err("pw_internal_resident_adopt", e);
-        if (r->d_outs[0]) (void)hipFree(r->d_outs[0]);
+        block_give(c, outs, outs_bytes);
         delete r;
         return PW_E_HIP;
     }
     r->n_units = n_units; r->n_atoms = n_atoms; r->nmax = nmax; r->vstride = 1;
     r->d_offset = d_offset; r->d_xyz = d_xyz; r->d_vdw = d_vdw; r->d_mass = d_mass;
+    r->parts[0] = d_offset; r->parts[1] = d_xyz; r->parts[2] = d_vdw; r->parts[3] = d_mass; r->parts[4] = outs;
+    for (int k = 0; k < 4; ++k) r->part_bytes[k] = part_bytes[k];
+    r->part_bytes[4] = outs_bytes;
     for (int k = 1; k < r->nbuf; ++k) r->d_outs[k] = r->d_outs[0] + (size_t)k * n_units;
     r->d_xw_count = (unsigned*)(r->d_outs[0] + (size_t)r->nbuf * n_units);
     for (int k = 0; k < PW_SETS; ++k) r->written_set[k] = -1;
@@ -1494,26 +1511,19 @@ void pw_resident_free(pw_context* c, pw_resident* r) {
     if (r->host) { delete r->host; delete r; return; }
     DeviceScope scope;
     if (c) (void)scope.enter(c->device);
-    if (r->block) {
-        // an uploaded batch: wait for the launches that touched it -- not for the whole device -- and keep
-        // its block for the next upload
-        if (c) {
-            for (int k = 0; k < PW_SETS; ++k) {
-                const int ws = r->written_set[k];
-                if (ws >= 0 && c->done_valid[ws]) (void)hipEventSynchronize(c->ev_done[ws]);
-                if (r->read_valid[k]) (void)hipEventSynchronize(r->ev_read[k]);
-            }
-            (void)hipStreamSynchronize(c->stream);
+    // wait for the launches that touched this batch -- not for the whole device -- and keep its blocks for
+    // the next one
+    if (c) {
+        for (int k = 0; k < PW_SETS; ++k) {
+            const int ws = r->written_set[k];
+            if (ws >= 0 && c->done_valid[ws]) (void)hipEventSynchronize(c->ev_done[ws]);
+            if (r->read_valid[k]) (void)hipEventSynchronize(r->ev_read[k]);
         }
-        block_give(c, r->block, r->block_bytes);
-    } else {
-        if (r->d_offset) (void)hipFree(r->d_offset);
-        if (r->d_xyz) (void)hipFree(r->d_xyz);
-        if (r->d_vdw) (void)hipFree(r->d_vdw);
-        if (r->d_mass) (void)hipFree(r->d_mass);
-        if (c) (void)hipDeviceSynchronize();
-        if (r->d_outs[0]) (void)hipFree(r->d_outs[0]);
+        (void)hipStreamSynchronize(c->stream);
     }
+    if (r->block) block_give(c, r->block, r->block_bytes);
+    for (int k = 0; k < 5; ++k)
+        if (r->parts[k]) block_give(c, r->parts[k], r->part_bytes[k]);
     if (r->d_xw[0]) (void)hipFree(r->d_xw[0]);
     for (int k = 0; k < PW_SETS; ++k)
         if (r->ev_read[k]) (void)hipEventDestroy(r->ev_read[k]);

@@ -22,6 +22,8 @@ using namespace pw;
 extern "C" char* pw_internal_error_buffer(void);   // pw_kernels.hip (512 bytes, thread local)
 extern "C" int pw_context_device(pw_context* ctx);
 extern "C" int pw_internal_pool(pw_context* ctx, size_t bytes, void** out);   // pw_kernels.hip
+extern "C" int pw_internal_block_take(pw_context* ctx, size_t bytes, void** out, size_t* got);
+extern "C" void pw_internal_block_give(pw_context* ctx, void* p, size_t bytes);
 
 namespace {
 
@@ -73,16 +75,24 @@ pw_rebuild_kernel(pw_cell_in in, pw_cell_out out, unsigned char* __restrict__ sl
     }
 }
 
+// temporaries of one call, taken from the context's cache of device blocks and given back at the end
+// (every caller synchronises its stream before returning): no hipMalloc / hipFree -- and no device-wide
+// wait -- per call once the cache is warm
 struct Buffers {
     static constexpr int CAP = 32;
+    pw_context* ctx = nullptr;
     void* p[CAP];
+    size_t bytes_[CAP];
     int n = 0;
-    ~Buffers() { for (int i = 0; i < n; ++i) if (p[i]) (void)hipFree(p[i]); }
+    ~Buffers() { for (int i = 0; i < n; ++i) if (p[i]) pw_internal_block_give(ctx, p[i], bytes_[i]); }
     template <class X> hipError_t alloc(X** out, size_t bytes) {
-        if (n >= CAP) return hipErrorOutOfMemory;
-        hipError_t e = hipMalloc((void**)out, bytes ? bytes : 8);
-        if (e == hipSuccess) p[n++] = *out;
-        return e;
+        if (n >= CAP || !ctx) return hipErrorOutOfMemory;
+        void* q = nullptr;
+        size_t got = 0;
+        if (pw_internal_block_take(ctx, bytes ? bytes : 8, &q, &got) != PW_OK) return hipErrorOutOfMemory;
+        *out = (X*)q;
+        p[n] = q; bytes_[n] = got; ++n;
+        return hipSuccess;
     }
 };
 
@@ -98,7 +108,8 @@ struct Buffers {
     } while (0)
 
 extern "C" int pw_internal_resident_adopt(pw_context* ctx, long n_units, long n_atoms, int nmax, long* d_offset,
-                                          double* d_xyz, double* d_vdw, double* d_mass, pw_resident** out);
+                                          double* d_xyz, double* d_vdw, double* d_mass, const size_t* part_bytes,
+                                          pw_resident** out);
 
 namespace {
 
@@ -254,6 +265,7 @@ extern "C" int pw_discrete_molecules(pw_context* ctx, const pw_cell_in* in, cons
     }
     RB_TRY(dev_scope_.enter(pw_context_device(ctx)));
     Buffers buf;
+    buf.ctx = ctx;
     DeviceCells dev;
     int rc = rebuild_on_device(ctx, in, out->atoms_cap, out->mols_cap, buf, &dev);
     if (rc != PW_OK) return rc;
@@ -281,6 +293,7 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
     }
     RB_TRY(dev_scope_.enter(pw_context_device(ctx)));
     Buffers buf;
+    buf.ctx = ctx;
     DeviceCells dev;
     int rc = rebuild_on_device(ctx, in, atoms_cap, mols_cap, buf, &dev);
     if (rc != PW_OK) return rc;
@@ -314,12 +327,14 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
     if (U == 0) return PW_OK;      // nothing to analyse: *res stays NULL
     long* d_offset = nullptr;
     double *d_xyz = nullptr, *d_uv = nullptr, *d_um = nullptr;
+    size_t part_bytes[4] = {0, 0, 0, 0};
     auto drop = [&]() {
-        if (d_offset) (void)hipFree(d_offset);
-        if (d_xyz) (void)hipFree(d_xyz);
-        if (d_uv) (void)hipFree(d_uv);
-        if (d_um) (void)hipFree(d_um);
+        pw_internal_block_give(ctx, d_offset, part_bytes[0]);
+        pw_internal_block_give(ctx, d_xyz, part_bytes[1]);
+        pw_internal_block_give(ctx, d_uv, part_bytes[2]);
+        pw_internal_block_give(ctx, d_um, part_bytes[3]);
     };
+    auto take = [&](void** q, size_t bytes, int k) { return pw_internal_block_take(ctx, bytes, q, &part_bytes[k]) == PW_OK ? hipSuccess : hipErrorOutOfMemory; };
 #define RBF_TRY(call)                                                                      \
     do {                                                                                   \
         hipError_t e_ = (call);                                                            \
@@ -329,10 +344,10 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
             return PW_E_HIP;                                                               \
         }                                                                                  \
     } while (0)
-    RBF_TRY(hipMalloc((void**)&d_offset, sizeof(long) * (U + 1)));
-    RBF_TRY(hipMalloc((void**)&d_xyz, sizeof(double) * 3 * A));
-    RBF_TRY(hipMalloc((void**)&d_uv, sizeof(double) * A));
-    RBF_TRY(hipMalloc((void**)&d_um, sizeof(double) * A));
+    RBF_TRY(take((void**)&d_offset, sizeof(long) * (U + 1), 0));
+    RBF_TRY(take((void**)&d_xyz, sizeof(double) * 3 * A, 1));
+    RBF_TRY(take((void**)&d_uv, sizeof(double) * A, 2));
+    RBF_TRY(take((void**)&d_um, sizeof(double) * A, 3));
     hipLaunchKernelGGL(rb_gather_kernel, dim3((unsigned)F), dim3(256), 0, st, F, (int)atoms_cap, (int)mols_cap,
                        dev.n_mol, dev.off, dev.src, dev.oxyz, d_vdw_atom, dev.mass, d_ubase, d_abase, d_offset, d_xyz,
                        d_uv, d_um, d_nmax);
@@ -341,7 +356,7 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
     RBF_TRY(hipMemcpyAsync(&nmax, d_nmax, sizeof(int), hipMemcpyDeviceToHost, st));
     RBF_TRY(hipStreamSynchronize(st));
 #undef RBF_TRY
-    rc = pw_internal_resident_adopt(ctx, U, A, nmax, d_offset, d_xyz, d_uv, d_um, res);
+    rc = pw_internal_resident_adopt(ctx, U, A, nmax, d_offset, d_xyz, d_uv, d_um, part_bytes, res);
     if (rc != PW_OK) drop();
     return rc;
 }

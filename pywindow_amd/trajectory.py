@@ -346,7 +346,8 @@ class DLPOLY:
             extras.extend(engine.offset_extra(e, done[0]) for e in extra)
             done[0] += len(recs)
             if res is not None:
-                spent.append(res)          # (released at the end: freeing device memory waits for the whole device)
+                res.free()                 # (its blocks go back to the context's cache: no device-wide wait, and the
+                                           # memory of a long trajectory stays at the pieces in flight)
             parts.append((recs, n_mol))
 
         def read_piece(i):
