@@ -192,6 +192,153 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
     }
 }
 
+// ---- experiment (PW_ROW_CHAINS=1): four optimiser chains per wavefront ----------------------------------
+// One chain per ROW of 16 lanes (RowTeam), rows refilled one by one as their chains end, the same Lbfgsb<3>
+// source.  The basic stage of the units (centre of mass, pore radius at it: the start and the box of the
+// optimisation) comes from a launch of its own, queued ahead on the same stream.  Publishes finished units
+// like the one-wave chains.  Default bounds / start only (pw_params::opt_flags == 0).
+__global__ void __launch_bounds__(64, 2)
+pw_row_chains_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
+                     const double* __restrict__ vdw, int vstride, int nmax, pw_unit_out* __restrict__ out,
+                     unsigned long long* counter, UnitQueue* queue, int* __restrict__ slots) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    using T = RowTeam;
+    const int row = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const size_t nn = (size_t)((nmax + 1) & ~1);
+    const size_t row_bytes = nn * 8 * 5 + ((sizeof(LbMem<3>) + 15) & ~(size_t)15);
+    PW_LDS unsigned char* base = (PW_LDS unsigned char*)lds + row * row_bytes;
+    Frame F;
+    F.x = (ldouble*)base; F.y = F.x + nn; F.z = F.y + nn; F.xx = F.z + nn;
+    ldouble* rv = F.xx + nn;
+    F.vdw = rv; F.perm = nullptr; F.cls = nullptr;
+    LbMem<3>* Smem = (LbMem<3>*)(rv + nn);
+    __builtin_amdgcn_s_setprio(PW_A_PRIO);
+    if (threadIdx.x == 0) atomicAdd(&queue->started, 1);
+    Lbfgsb<3> S;
+    int state = 0;      // 0 wants a unit, 1 optimising, 2 no more units
+    long unit = -1;
+    int n = 0;
+    double lo[3] = {0, 0, 0}, up[3] = {0, 0, 0}, x0[3] = {0, 0, 0};
+    int nit = 0, nfev = 0;
+    bool have_last = false, bad = false, limit = false;
+    double lx = 0, ly = 0, lz = 0, lf = 0, lg0 = 0, lg1 = 0, lg2 = 0;
+    S.task = LB_STOP;
+    S.msg = 0;
+    for (;;) {
+        if (state == 0) {
+            long u = -1;
+            if (l == 0) u = (long)atomicAdd(counter, 1ull);
+            u = __shfl(u, 0, 16);
+            if (u >= n_units) state = 2;
+            else {
+                unit = u;
+                const long a0 = atom_offset[u];
+                n = (int)(atom_offset[u + 1] - a0);
+                const double* c = xyz + 3 * a0;
+                const double* vd = vdw + a0 * vstride;
+                for (int i = l; i < n; i += 16) {
+                    double x = c[3 * i], y = c[3 * i + 1], z = c[3 * i + 2];
+                    F.x[i] = x; F.y[i] = y; F.z[i] = z; F.xx[i] = sq3(x, y, z); rv[i] = vd[i];
+                }
+                // the basic stage's results (an earlier launch on this stream wrote them)
+                const double r0 = out[u].pore_d / 2.0;          // pore_d = gap * 2: the division is exact
+                int nbd[3] = {2, 2, 2};
+                for (int k = 0; k < 3; ++k) { x0[k] = out[u].com[k]; lo[k] = x0[k] - r0; up[k] = x0[k] + r0; }
+                bad = !(r0 > 0.0);
+                T::wave_sync();
+                nit = 0; nfev = 0; have_last = false; limit = false;
+                S.task = LB_STOP;
+                if (!bad) S.template setup<T>(Smem, x0, lo, up, nbd, 1e7, 1e-5, 20);
+                state = 1;
+            }
+        }
+        if (__all(state == 2)) break;
+        if (state == 1) {
+            if (!bad) {
+                if (S.task == LB_FG) {
+                    const double px = S.x[0], py = S.x[1], pz = S.x[2];
+                    if (!(have_last && px == lx && py == ly && pz == lz)) {
+                        // f and the three forward-difference points (stage_opt), all four by this row: every
+                        // atom read serves the four of them
+                        double qx[4] = {px, px, px, px}, qy[4] = {py, py, py, py}, qz[4] = {pz, pz, pz, pz}, dxs[3];
+                        for (int c = 0; c < 3; ++c) {
+                            const double xc = c == 0 ? px : (c == 1 ? py : pz);
+                            const double h = fd_step(xc, lo[c], up[c]);
+                            const double x1 = xc + h;
+                            dxs[c] = x1 - xc;
+                            if (c == 0) qx[1] = x1; else if (c == 1) qy[2] = x1; else qz[3] = x1;
+                        }
+                        double pp[4], best[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { pp[q] = sq3(qx[q], qy[q], qz[q]); best[q] = PW_INF; }
+                        for (int i = l; i < n; i += 16) {
+                            const double ax = F.x[i], ay = F.y[i], az = F.z[i], aq = F.xx[i], ar = rv[i];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const double g = pw_fma(az, qz[q], pw_fma(ax, qx[q], ay * qy[q]));
+                                const double d2 = pw_m2add(g, aq) + pp[q];
+                                const double d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
+                                best[q] = __builtin_fmin(best[q], d - ar);
+                            }
+                        }
+                        double gv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) gv[q] = T::row_min(best[q]);
+                        const double f0 = -(gv[0] * 2.0);
+                        lg0 = (-(gv[1] * 2.0) - f0) / dxs[0];
+                        lg1 = (-(gv[2] * 2.0) - f0) / dxs[1];
+                        lg2 = (-(gv[3] * 2.0) - f0) / dxs[2];
+                        lf = f0; lx = px; ly = py; lz = pz;
+                        have_last = true;
+                        nfev += 4;
+                    }
+                    S.f = lf;
+                    S.g[0] = lg0; S.g[1] = lg1; S.g[2] = lg2;
+                    T::wave_sync();
+                } else if (S.task == LB_NEW_X) {
+                    nit += 1;
+                    if (nit >= 15000 || nfev > 15000) limit = true;      // scipy's driver: tested at a new iterate only
+                }
+                if (!limit) {
+                    S.template step<T>();
+                    T::wave_sync();
+                }
+            }
+            if (bad || limit || (S.task != LB_FG && S.task != LB_NEW_X)) {
+                // the chain has ended: diameter and closest atom at its last point, the record, the hand-over
+                const double cx = bad ? x0[0] : S.x[0], cy = bad ? x0[1] : S.x[1], cz = bad ? x0[2] : S.x[2];
+                const double pp = sq3(cx, cy, cz);
+                double gbest = PW_INF;
+                int gi = 0x7fffffff;
+                for (int i = l; i < n; i += 16) {
+                    const double v = gap_atom(F, i, cx, cy, cz, pp);
+                    if (v < gbest || (v == gbest && i < gi)) { gbest = v; gi = i; }
+                }
+                T::row_argmin(gbest, gi);
+                if (l == 0) {
+                    pw_unit_out* o = out + unit;
+                    o->pore_opt_d = gbest * 2.0;
+                    o->pore_opt_atom = gi;
+                    o->pore_opt_c[0] = cx; o->pore_opt_c[1] = cy; o->pore_opt_c[2] = cz;
+                    const double rr = o->pore_opt_d / 2.0;
+                    o->pore_vol_opt = FOUR_THIRDS_PI * pw_cube_np(rr);
+                    o->opt_nit = nit;
+                    o->opt_nfev = nfev;
+                    o->opt_task = bad ? -1 : S.task;
+                    o->opt_msg = bad ? 0 : S.msg;
+                    record_or_status(o, bad ? PW_ST_NEGATIVE_PORE : 0, nfev + 1);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const long pos = (long)atomicAdd(&queue->tail, 1ull);
+                    __hip_atomic_store(&slots[pos], (int)unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                state = 0;
+            }
+        }
+    }
+}
+
 // Gate: one wave, no LDS.  Holds the stream it is launched on until every team of the
 // optimiser launch is resident, so that launches queued behind it cannot take the LDS those
 // teams need.  It can never block them itself, and its wait is bounded.
@@ -321,14 +468,14 @@ __global__ void pw_point_gap_kernel(long n_points, const long* __restrict__ unit
 // stream time each -- a tenth of the step of a small batch).
 __global__ void pw_reset_kernel(unsigned long long* __restrict__ out8, long n8, UnitQueue* queue, int* __restrict__ slots,
                                 long n_units, unsigned long long* ca, unsigned long long* cb,
-                                unsigned long long* cc, unsigned* xw_count) {
+                                unsigned long long* cc, unsigned long long* cd, unsigned* xw_count) {
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = i0; i < n8; i += stride) out8[i] = 0ull;
     for (long i = i0; i < n_units; i += stride) slots[i] = -1;
     if (i0 == 0) {
         queue->tail = 0; queue->head = 0; queue->error = 0; queue->started = 0;
-        *ca = 0; *cb = 0; *cc = 0;
+        *ca = 0; *cb = 0; *cc = 0; *cd = 0;
         *xw_count = 0u;
     }
 }
@@ -382,6 +529,7 @@ struct pw_context {
     UnitQueue* cur_queue;
     int* cur_slots;
     hipEvent_t ev0, ev1, ev_fork;
+    int row_chains;          // PW_ROW_CHAINS=1: the optimiser launch packs four chains per wavefront (experiment)
     int fused;               // PW_FUSED=1: one launch per analysis instead of the pipeline (also chosen when the
                              // streams of the pipeline do not run concurrently, see pw_context_create)
     int host_threads;        // device == -1 (the explicit host path, pw_hostpath.cpp): threads over the units
@@ -723,7 +871,7 @@ int pw_context_create(int device, pw_context** out) {
     c->n_cu = prop.multiProcessorCount;
     c->lds_per_cu = 160 * 1024;
     CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CTX_TRY(hipMalloc((void**)&c->counter, (3 * PW_SETS + 2) * sizeof(unsigned long long)));
+    CTX_TRY(hipMalloc((void**)&c->counter, (4 * PW_SETS + 2) * sizeof(unsigned long long)));
     CTX_TRY(hipMalloc((void**)&c->queue, PW_SETS * sizeof(UnitQueue)));
     CTX_TRY(hipMemset(c->queue, 0, PW_SETS * sizeof(UnitQueue)));
     c->flip = -1;
@@ -775,6 +923,10 @@ int pw_context_create(int device, pw_context** out) {
     CTX_TRY(hipEventCreateWithFlags(&c->ev_ext, hipEventDisableTiming));
     const char* fz = getenv("PW_FUSED");
     c->fused = (fz && fz[0] == '1') ? 1 : 0;
+    {
+        const char* rc_ = getenv("PW_ROW_CHAINS");
+        c->row_chains = (rc_ && rc_[0] == '1') ? 1 : 0;
+    }
     const char* cw = getenv("PW_C_WAVES");
     c->c_waves = (cw && cw[0] == '8') ? 8 : 4;
     c->prm = default_params();
@@ -1009,14 +1161,14 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
             }
             r->written_set[r->cur] = -1;
             HIP_TRY(hipMemsetAsync(r->d_xw_count + r->cur, 0, sizeof(unsigned), c->stream));
-            HIP_TRY(hipMemsetAsync(c->counter + 3 * PW_SETS + 1, 0, sizeof(unsigned long long), c->stream));
+            HIP_TRY(hipMemsetAsync(c->counter + 4 * PW_SETS + 1, 0, sizeof(unsigned long long), c->stream));
             PwWsArgs wsa;
             wsa.ws = c->ws; wsa.slab = c->slab; wsa.adj = c->adj;
             wsa.xwin = r->d_xw[r->cur]; wsa.xwin_count = r->d_xw_count + r->cur; wsa.xwin_cap = r->xw_cap;
             wsa.p_cap = c->p_cap;
             wsa.nb_off = c->nb_off; wsa.nb_idx = c->nb_idx; wsa.nb_bound = c->nb_bound;
             return pw_internal_big_launch((void*)c->stream, (int)grid, r->n_units, r->d_offset, r->d_xyz, r->d_vdw, r->d_mass,
-                                          stages, r->nmax, &wsa, c->bigmem, bb, c->counter + 3 * PW_SETS + 1, r->d_out, &c->prm,
+                                          stages, r->nmax, &wsa, c->bigmem, bb, c->counter + 4 * PW_SETS + 1, r->d_out, &c->prm,
                                           c->rsq_tab, r->vstride);
         }
     }
@@ -1064,10 +1216,22 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         }
         if (getenv("PW_PLAN_DEBUG")) fprintf(stderr, "plan A: grid %d lds %zu\n", pa.grid, pa.lds);
     }
+    // the row-packed variant of the optimiser launch (PW_ROW_CHAINS=1): four units per wavefront
+    int row_grid = 0;
+    size_t row_lds = 0;
+    if (c->row_chains) {
+        const size_t nn = (size_t)((r->nmax + 1) & ~1);
+        row_lds = 4 * (nn * 8 * 5 + ((sizeof(LbMem<3>) + 15) & ~(size_t)15));
+        if (row_lds <= 160 * 1024 - 256) row_grid = (int)((r->n_units + 3) / 4);
+    }
     bool do_avg = (stages & PW_STAGE_AVG) != 0;
     pb.grid = 0;
     if (do_avg) {
-        rc = plan_launch(c, r->n_units, r->nmax, 4, false, 7, &pb, 1, true);   // one frame; 7 state slots = 51 KB of scratch (ray vectors + cone pairs)
+        // one frame; the optimiser-state slots are this launch's scratch arena: 7 (51 KB) hold the ray vectors and
+        // the cone pairs of team_ray_tests, 2 (14 KB) make the stage fall back to the dense ray scan (PW_B_LB)
+        int b_lb = 7;
+        if (const char* e = getenv("PW_B_LB")) b_lb = atoi(e) > 0 ? atoi(e) : b_lb;
+        rc = plan_launch(c, r->n_units, r->nmax, 4, false, b_lb, &pb, 1, true);
         if (rc != PW_OK) return rc;
     }
     rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pc, 1);      // one frame, shifted in place
@@ -1189,7 +1353,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(pw_reset_kernel, dim3((unsigned)blocks), dim3(256), 0, c->prod, (unsigned long long*)r->d_out, n8,
                            c->cur_queue, c->cur_slots, r->n_units, c->counter + b, c->counter + PW_SETS + b,
-                           c->counter + 2 * PW_SETS + b, r->d_xw_count + r->cur);
+                           c->counter + 2 * PW_SETS + b, c->counter + 3 * PW_SETS + b, r->d_xw_count + r->cur);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev_reset[b], c->prod));
@@ -1211,13 +1375,33 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     c->last_res[b] = (const void*)r;
     // several optimiser launches can be in flight: separate work counters and workspaces
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][0], c->prod));
-    rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod, ws_a, -1, b, PW_ROLE_PRODUCER, false);
-    if (rc != PW_OK) return rc;
+    const bool rows = c->row_chains && c->prm.opt_flags == 0 && row_grid > 0;
+    if (rows) {
+        // basic stage of every unit (4-wave teams), then four chains per wavefront
+        LaunchPlan pbas;
+        rc = plan_launch(c, r->n_units, r->nmax, 4, false, 0, &pbas, 1, true);
+        if (rc != PW_OK) return rc;
+        if (pbas.grid > c->max_a) pbas.grid = c->max_a;
+        rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_MERGE, pbas, c->prod, ws_a, -1, 3 * PW_SETS + b, PW_ROLE_PLAIN, false);
+        if (rc != PW_OK) return rc;
+        static std::atomic<unsigned long long> attr_done{0};
+        const unsigned long long bit = 1ull << (c->device & 63);
+        if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+            HIP_TRY(hipFuncSetAttribute((const void*)pw_row_chains_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            attr_done.fetch_or(bit, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(pw_row_chains_kernel, dim3(row_grid), dim3(64), row_lds, c->prod, r->n_units, r->d_offset, r->d_xyz,
+                           r->d_vdw, r->vstride, r->nmax, r->d_out, c->counter + b, c->cur_queue, c->cur_slots);
+        HIP_TRY(hipGetLastError());
+    } else {
+        rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod, ws_a, -1, b, PW_ROLE_PRODUCER, false);
+        if (rc != PW_OK) return rc;
+    }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][1], c->prod));
     HIP_TRY(hipEventRecord(c->ev_prod[b], c->prod));
     hipStream_t cs = c->cons[b];
     HIP_TRY(hipStreamWaitEvent(cs, c->ev_reset[b], 0));
-    hipLaunchKernelGGL(pw_gate_kernel, dim3(1), dim3(64), 0, cs, c->cur_queue, pa.grid);
+    hipLaunchKernelGGL(pw_gate_kernel, dim3(1), dim3(64), 0, cs, c->cur_queue, rows ? row_grid : pa.grid);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_gate[b], cs));
     c->head_valid[b] = 0;

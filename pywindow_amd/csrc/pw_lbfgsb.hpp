@@ -682,10 +682,11 @@ struct Lbfgsb {
                 // block (2,1): element (M+r, jy) <- (M+r+1, jy+1), r = 0..M-2
                 constexpr int CELLS = (M - 1) * (M - 1);
                 constexpr int PER = (CELLS + T::WSIZE - 1) / T::WSIZE;
-                if (PER <= 2) {
-                    double s11[2] = {0.0, 0.0}, s22[2] = {0.0, 0.0}, s21[2] = {0.0, 0.0};
+                if (T::WSIZE > 1) {
+                    double s11[PER], s22[PER], s21[PER];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
+                    for (int q = 0; q < PER; ++q) {
+                        s11[q] = s22[q] = s21[q] = 0.0;
                         int e = T::lane() + q * T::WSIZE;
                         if (e < CELLS) {
                             int jy = e / (M - 1), r = e % (M - 1);
@@ -695,7 +696,7 @@ struct Lbfgsb {
                     }
                     T::wave_sync();
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
+                    for (int q = 0; q < PER; ++q) {
                         int e = T::lane() + q * T::WSIZE;
                         if (e < CELLS) {
                             int jy = e / (M - 1), r = e % (M - 1);
@@ -1216,9 +1217,12 @@ struct Lbfgsb {
         T::wave_sync();
         if (iupdat > M) {
             // move the old information up-left by one (read everything, then write)
-            double keep_ss[2], keep_sy[2];
+            constexpr int PERM = ((M - 1) * (M - 1) + T::WSIZE - 1) / T::WSIZE;     // cells per lane
+            double keep_ss[PERM], keep_sy[PERM];
             int cnt = (col - 1) * (col - 1);
-            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int q = 0; q < PERM; ++q) {
+                keep_ss[q] = keep_sy[q] = 0.0;
                 int e = T::lane() + q * T::WSIZE;
                 if (e < cnt && T::WSIZE > 1) {
                     int j = e / (col - 1), i = e % (col - 1);
@@ -1228,7 +1232,8 @@ struct Lbfgsb {
             }
             if (T::WSIZE > 1) {
                 T::wave_sync();
-                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int q = 0; q < PERM; ++q) {
                     int e = T::lane() + q * T::WSIZE;
                     if (e < cnt) {
                         int j = e / (col - 1), i = e % (col - 1);

@@ -459,3 +459,27 @@ def test_other_cages_with_fresh_noise_against_live_oracle(hip_ctx):
             assert rel(r["win_d"][:n], ref["win_d"][:n]) <= LIVE_TOL_WINDOW, u      # (window order included)
             checked_windows += n
     assert checked_windows >= 30
+
+
+def test_row_packed_chains_variant_is_bit_identical(monkeypatch):
+    """PW_ROW_CHAINS=1 -- four optimiser chains per wavefront, one per row of 16 lanes (measured 2x slower in
+    the pipeline, profiles/r03_row_packed_chains.txt; kept selectable) -- must give the records of the default
+    one-wave chains byte for byte: the same Lbfgsb<3> source on a 16-lane team."""
+    g = load_group("md20")
+    off, xyz, vdw, mass = group_batch(g)
+    batch = _lib.Batch(off, xyz, vdw, mass)
+    plain = _lib.Context(0)
+    a = plain.upload(batch)
+    a.launch()
+    ra = a.download()
+    a.free()
+    plain.close()
+    monkeypatch.setenv("PW_ROW_CHAINS", "1")
+    rows = _lib.Context(0)
+    b = rows.upload(batch)
+    b.launch()
+    rb = b.download()
+    b.free()
+    rows.close()
+    assert ra.tobytes() == rb.tobytes()
+    check_records(rb, g, where="row-packed chains")
