@@ -465,6 +465,8 @@ def test_row_packed_chains_variant_is_bit_identical(monkeypatch):
     """PW_ROW_CHAINS=1 -- four optimiser chains per wavefront, one per row of 16 lanes (measured 2x slower in
     the pipeline, profiles/r03_row_packed_chains.txt; kept selectable) -- must give the records of the default
     one-wave chains byte for byte: the same Lbfgsb<3> source on a 16-lane team."""
+    from pywindow_amd import _lib
+
     g = load_group("md20")
     off, xyz, vdw, mass = group_batch(g)
     batch = _lib.Batch(off, xyz, vdw, mass)
