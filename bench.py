@@ -46,8 +46,8 @@ ALGO_FLOP_BY_KERNEL = {
 HBM_PEAK_GBS = 8000.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 # static inputs measured with rocprofv3 --pmc (separate passes; committed summaries), NOT by this run
-TRAFFIC_FILES = ("r02_hbm_traffic.json", "r01j_hbm_traffic.json")
-COUNTER_FILES = ("r02_instruction_counters.json", "r01j_instruction_counters.json")
+TRAFFIC_FILES = ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01j_hbm_traffic.json")
+COUNTER_FILES = ("r03_instruction_counters.json", "r02_instruction_counters.json", "r01j_instruction_counters.json")
 # the only figure for this metric the reference's repository holds: 715-frame CC3 trajectory,
 # traj.analysis(ncpus=8) in 286.5 s (examples/Example7_AnalysingTrajectorySingleMol.ipynb:569-575)
 REFERENCE_NOTEBOOK_FPS = 715 / 286.5
