@@ -208,3 +208,97 @@ def test_hip_resident_path_delivers_extra_windows(hip_ctx):
             check_window_call(call, recs[1], xw)
     finally:
         res.free()
+
+
+def _two_atoms(distance):
+    """Two atoms `distance` apart (they set the size of the sampling sphere) and a third one near the middle
+    for the rays to meet."""
+    xyz = np.zeros((3, 3))
+    xyz[1, 0] = distance
+    xyz[2] = (distance / 2.0, 5.0, 0.0)
+    return _lib.Batch(np.array([0, 3], np.int64), xyz, np.full(3, 1.70), np.full(3, 12.011))
+
+
+def test_host_context_grows_the_workspace_when_a_unit_asks():
+    """Two atoms 12 000 A apart: the average-diameter sphere wants 2300 rays, more than the 2176
+    the default knobs imply.  pw_analysis_batch raises the capacity and repeats; the value equals a run that
+    had the capacity from the start."""
+    ctx = _lib.Context(-1, host_threads=2)
+    before = ctx.point_capacity
+    rec = ctx.analyse(_two_atoms(12000.0), _lib.STAGE_AVG)[0]
+    assert int(rec["n_points_avg"]) > before and not int(rec["status"]) & _lib.ST_POINTS_OVERFLOW
+    assert np.isfinite(rec["avg_d"]) and rec["avg_d"] > 0
+    roomy = _lib.Context(-1, host_threads=1).analyse(_two_atoms(12000.0), _lib.STAGE_AVG, _lib.Params(adjust_average=1.0))[0]
+    assert float(roomy["avg_d"]) == float(rec["avg_d"])
+
+
+def test_host_context_extra_windows_with_threads():
+    """Several molecules with more than 16 windows in one batch, analysed by four threads: every unit gets
+    its own extra windows, in order, whatever the threads did."""
+    from pywindow_amd import engine
+
+    mols, calls = load_cliffs()
+    call = next(c for c in calls if c["n_windows"] > _lib.W_MAX)
+    el, xyz = mols[call["mol"]]
+    cc3 = mols["cc3"]
+    batch = engine.make_batch([(el, xyz), cc3, (el, xyz), (el, xyz), cc3, (el, xyz)])
+    extra = []
+    recs = _lib.Context(-1, host_threads=4).analyse(batch, _lib.STAGE_WINDOWS, None, extra)
+    more = engine.extra_by_unit(extra)
+    assert sorted(more) == [0, 2, 3, 5]
+    for u in (0, 2, 3, 5):
+        d, c = engine.windows_of(recs[u], more[u])
+        assert np.array_equal(d, call["win_d"][: call["n_windows"]]) and np.array_equal(c, call["win_c"][: call["n_windows"]])
+    assert int(recs[1]["n_windows"]) == 4 and int(recs[4]["n_windows"]) == 4
+
+
+@pytest.mark.gpu
+def test_hip_grows_the_workspace_when_a_unit_asks(hip_ctx):
+    """The same on the GPU, against the host context; and the resident path, which cannot repeat by itself,
+    flags the unit (NaN, never a value) and the wrappers raise."""
+    from pywindow_amd import engine
+
+    want = _lib.Context(-1, host_threads=1).analyse(_two_atoms(12000.0), _lib.STAGE_AVG)[0]
+    fresh = _lib.Context(0)
+    try:
+        assert fresh.point_capacity < int(want["n_points_avg"])
+        res = fresh.upload(_two_atoms(12000.0))
+        res.launch(_lib.STAGE_AVG)
+        rec = res.download()[0]
+        res.free()
+        assert int(rec["status"]) & _lib.ST_POINTS_OVERFLOW and np.isnan(rec["avg_d"])
+        with pytest.raises(_lib.PwHipError):
+            engine.raise_on_capacity(rec)
+        got = fresh.analyse(_two_atoms(12000.0), _lib.STAGE_AVG)[0]
+        assert float(got["avg_d"]) == float(want["avg_d"]) and int(got["n_points_avg"]) == int(want["n_points_avg"])
+        assert fresh.point_capacity >= int(want["n_points_avg"])
+    finally:
+        fresh.close()
+
+
+@pytest.mark.gpu
+def test_hip_large_and_small_molecules_in_one_batch(hip_ctx):
+    """A batch whose largest molecule does not fit LDS runs from global memory as a whole: the small
+    molecules beside it still come out as the reference has them."""
+    from pywindow_amd import engine
+
+    mols, calls = load_cliffs()
+    big = mols["shell_big"]
+    call = next(c for c in calls if c["mol"] == "shell_big" and c["kind"] == "win")
+    avg = next(c for c in calls if c["mol"] == "shell_big" and c["kind"] == "avg")
+    cc3_win = next(c for c in calls if c["mol"] == "windows_case_5" and c["kwargs"].get("adjust") == 3.0)
+    del cc3_win
+    from _util import load_group, molecules
+
+    g = load_group("static")
+    static = molecules(g)
+    batch = engine.make_batch([static[0], big, static[5]])
+    recs = hip_ctx.analyse(batch)
+    assert int(recs[1]["n_atoms"]) == len(big[0]) > 1700
+    assert int(recs[1]["n_windows"]) == call["n_windows"]
+    assert np.array_equal(recs[1]["win_d"][: call["n_windows"]], call["win_d"][: call["n_windows"]])
+    assert float(recs[1]["avg_d"]) == avg["avg_d"]
+    for u, k in ((0, 0), (2, 5)):
+        assert float(recs[u]["pore_opt_d"]) == float(g["pore_opt_d"][k]) and float(recs[u]["avg_d"]) == float(g["avg_d"][k])
+        n = int(g["n_windows"][k])
+        assert int(recs[u]["n_windows"]) == n and np.array_equal(recs[u]["win_d"][: max(n, 0)], g["win_d"][k][: max(n, 0)])
