@@ -109,6 +109,7 @@ struct RebuildShared {
     double red_v[8];
     double com[3], origin[3], bound[2];
     double box[27 * 6];
+    float shift[27 * 3];           // image i = central image + shift[i] (lattice translation, single precision)
     int red_i[8];
     int n_work, n_next, n_final, start;
     double cf[3];                  // unrounded fractional centre of mass of the molecule being closed
@@ -144,6 +145,8 @@ struct RebuildWs {
     // what the first walk through a molecule learned (rebuild only; see "walks that can be predicted")
     float* scan;          // 3 x (27n | n): x, y, z of every (image, atom) in single precision, for the
                           // conservative candidate scan only (coalesced 4-byte reads)
+    float* blk;           // 6 x ceil(n / 64): bounding boxes of the blocks of 64 consecutive atoms of the central
+                          // image (lo x, y, z, hi x, y, z), for the candidate scan
     int* cage_of;         // n: serial of the first walk that visited the atom, 0 = none yet
     unsigned char* cage_off;    // n: image (0..26) in which that walk met the atom
     unsigned char* cage_ok;     // n + 1, by walk serial: the walk was clean (no truncation / marginal bond / repeat)
@@ -158,7 +161,7 @@ struct RebuildWs {
         size_t d = (size_t)3 * n + n + (rebuild ? (size_t)81 * n : 0) + id + 3 * ((size_t)n + 1);
         size_t i = (size_t)n + (size_t)n * RB_NB_CAP + 5 * id + 2 * ((size_t)n + 1);
         return sizeof(RebuildWs) + 64 + d * 8 + i * 4 + 4 * (size_t)n + 64 + 64 +
-               3 * (rebuild ? (size_t)27 * n : (size_t)n) * 4 + 64;
+               3 * (rebuild ? (size_t)27 * n : (size_t)n) * 4 + 64 + 6 * (((size_t)n + 63) / 64) * 4 + 64;
     }
     // fast memory: the hit segments always, the two bit sets when `with_bits`
     PW_HD static size_t fast_bytes(int n, int rebuild, bool with_bits) {
@@ -208,6 +211,8 @@ struct RebuildWs {
         w->cage_ok = p; p += (size_t)n + 1;
         p = (unsigned char*)(((size_t)p + 63) & ~(size_t)63);
         w->scan = (float*)p; p += 3 * (rebuild ? (size_t)27 * n : (size_t)n) * 4;
+        p = (unsigned char*)(((size_t)p + 63) & ~(size_t)63);
+        w->blk = (float*)p; p += 6 * (((size_t)n + 63) / 64) * 4;
         return w;
     }
 };
@@ -455,6 +460,35 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
             bx0 = b[0] - reach; by0 = b[1] - reach; bz0 = b[2] - reach;
             bx1 = b[3] + reach; by1 = b[4] + reach; bz1 = b[5] + reach;
         }
+        // Atoms that follow each other in the input belong to the same molecule and lie together, so the
+        // atoms of an image are taken in blocks of 64 with a bounding box each (the boxes of the central
+        // image; an image's are those shifted by its lattice translation): a heavy atom is compared with
+        // the boxes first -- one box per lane -- and only the blocks it can have a neighbour in are scanned.
+        // A handful of blocks per atom instead of every atom of every image in reach; the hits keep their
+        // (image, atom) order because images, blocks and lanes are all taken in ascending order.
+        const int nblk = (n + 63) >> 6;
+        const size_t comp = fr.rebuild ? (size_t)27 * n : (size_t)n;
+        const float* X0 = WS.scan + (fr.rebuild ? (size_t)RB_CENTRAL * n : 0);
+        for (int b = T::wave(); b < nblk; b += T::NWAVES) {
+            float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+            const int qend = (b + 1) * 64 < n ? (b + 1) * 64 : n;
+            for (int q = b * 64 + T::lane(); q < qend; q += T::WSIZE)
+                for (int c = 0; c < 3; ++c) {
+                    const float v = X0[c * comp + q];
+                    lo[c] = v < lo[c] ? v : lo[c]; hi[c] = v > hi[c] ? v : hi[c];
+                }
+            for (int c = 0; c < 3; ++c) {
+                const double l = T::wave_min((double)lo[c]), h = -T::wave_min(-(double)hi[c]);
+                if (T::lane() == 0) { WS.blk[6 * b + c] = (float)l; WS.blk[6 * b + 3 + c] = (float)h; }
+            }
+        }
+        if (fr.rebuild) {
+            for (int i = tid; i < 27 * 3; i += T::SIZE) {
+                const int img = i / 3, c = i % 3;
+                sh.shift[i] = (float)(WS.S[3 * ((size_t)img * n) + c] - WS.S[3 * ((size_t)RB_CENTRAL * n) + c]);
+            }
+        }
+        T::sync();
         for (int p = T::wave(); p < n; p += T::NWAVES) {
             if (fr.terminal[p]) continue;
             const double* C = fr.rebuild ? &WS.S[3 * ((size_t)RB_CENTRAL * n + p)] : &WS.V[3 * p];
@@ -463,6 +497,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
             // single precision moves a coordinate by at most 6e-8 of its size: the slack grows with it
             const double reach_f = fr.max_dist + 2e-3 + 5e-7 * (pw_abs(cx) + pw_abs(cy) + pw_abs(cz));
             const float reach2f = (float)(reach_f * reach_f);
+            const float reachb = (float)(reach_f + 1e-3 + 1e-6 * (pw_abs(cx) + pw_abs(cy) + pw_abs(cz)));   // (box test: shifts in single precision)
             int cnt = 0;
             unsigned long long images = 1ull << RB_CENTRAL;
             if (fr.rebuild) {
@@ -483,40 +518,80 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                 const int img = __builtin_ctzll(images);
                 // single-precision copies, one array per component: the test only has to be conservative
                 // (reach carries 2e-3 of slack, single precision moves a distance here by < 1e-4)
-                const size_t comp = fr.rebuild ? (size_t)27 * n : (size_t)n;
                 const float* X = WS.scan + (fr.rebuild ? (size_t)img * n : 0);
-                constexpr int UN = 11;       // blocks of candidates whose loads are in flight together
+                // the atom as the central image sees it from this image
+                const float sx = fr.rebuild ? sh.shift[3 * img] : 0.0f, sy = fr.rebuild ? sh.shift[3 * img + 1] : 0.0f,
+                            sz = fr.rebuild ? sh.shift[3 * img + 2] : 0.0f;
+                const float rx = fcx - sx, ry = fcy - sy, rz = fcz - sz;
 #if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
                 ++rb_imgs;
 #endif
-                for (int q0 = 0; q0 < n; q0 += UN * T::WSIZE) {
+                for (int g0 = 0; g0 < nblk; g0 += T::WSIZE) {
+                    const int bb = g0 + T::lane();
+                    bool pass = false;
+                    if (bb < nblk) {
+                        const float* B = WS.blk + 6 * bb;
+                        pass = !(rx < B[0] - reachb || rx > B[3] + reachb || ry < B[1] - reachb || ry > B[4] + reachb ||
+                                 rz < B[2] - reachb || rz > B[5] + reachb);
+                    }
+                    unsigned long long bm = T::ballot(pass);
+                    if (T::WSIZE < 64) {
+                        // a narrow team (the host build's one lane): block after block, position after position
+                        for (; bm; bm &= bm - 1) {
+                            const int blk = g0 + __builtin_ctzll(bm);
+                            for (int l1 = 0; l1 < 64; l1 += T::WSIZE) {
+                                const int q = blk * 64 + l1 + T::lane();
+                                bool h = false;
+                                if (q < n) {
+                                    float dx = X[q] - fcx, dy = X[comp + q] - fcy, dz = X[2 * comp + q] - fcz;
+                                    h = dx * dx + dy * dy + dz * dz < reach2f && !(img == RB_CENTRAL && q == p);
+                                }
+                                const unsigned long long bal = T::ballot(h);
+                                if (bal) {
+                                    int pos = cnt + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
+                                    if (h && pos < RB_NB_CAP) WS.nb[(size_t)p * RB_NB_CAP + pos] = img * n + q;
+                                    cnt += __builtin_popcountll(bal);
+                                }
+                            }
+                        }
+                        continue;
+                    }
+                    while (bm) {
 #if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-                    ++rb_rounds;
+                        ++rb_rounds;
 #endif
-                    bool hit[UN];
-                    float vx[UN], vy[UN], vz[UN];
-                    // unconditional (clamped) loads, so that all of them are issued before the first use
+                        // up to four blocks with their loads in flight together, one atom per lane
+                        constexpr int UN = 4;
+                        int blk[UN];
 #pragma unroll
-                    for (int u = 0; u < UN; ++u) {
-                        int q = q0 + u * T::WSIZE + T::lane();
-                        int qq = q < n ? q : n - 1;
-                        vx[u] = X[qq]; vy[u] = X[comp + qq]; vz[u] = X[2 * comp + qq];
-                    }
+                        for (int u = 0; u < UN; ++u) {
+                            blk[u] = bm ? g0 + __builtin_ctzll(bm) : -1;
+                            bm &= bm - 1;
+                        }
+                        bool hit[UN];
+                        float vx[UN], vy[UN], vz[UN];
 #pragma unroll
-                    for (int u = 0; u < UN; ++u) {
-                        int q = q0 + u * T::WSIZE + T::lane();
-                        float dx = vx[u] - fcx, dy = vy[u] - fcy, dz = vz[u] - fcz;
-                        float d2 = dx * dx + dy * dy + dz * dz;
-                        hit[u] = q < n && d2 < reach2f && !(img == RB_CENTRAL && q == p);
-                    }
+                        for (int u = 0; u < UN; ++u) {
+                            int q = (blk[u] < 0 ? 0 : blk[u] * 64) + T::lane();
+                            int qq = q < n ? q : n - 1;
+                            vx[u] = X[qq]; vy[u] = X[comp + qq]; vz[u] = X[2 * comp + qq];
+                        }
 #pragma unroll
-                    for (int u = 0; u < UN; ++u) {
-                        unsigned long long bal = T::ballot(hit[u]);
-                        if (bal) {
-                            int q = q0 + u * T::WSIZE + T::lane();
-                            int pos = cnt + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
-                            if (hit[u] && pos < RB_NB_CAP) WS.nb[(size_t)p * RB_NB_CAP + pos] = img * n + q;
-                            cnt += __builtin_popcountll(bal);
+                        for (int u = 0; u < UN; ++u) {
+                            int q = blk[u] * 64 + T::lane();
+                            float dx = vx[u] - fcx, dy = vy[u] - fcy, dz = vz[u] - fcz;
+                            float d2 = dx * dx + dy * dy + dz * dz;
+                            hit[u] = blk[u] >= 0 && q < n && d2 < reach2f && !(img == RB_CENTRAL && q == p);
+                        }
+#pragma unroll
+                        for (int u = 0; u < UN; ++u) {
+                            unsigned long long bal = T::ballot(hit[u]);
+                            if (bal) {
+                                int q = blk[u] * 64 + T::lane();
+                                int pos = cnt + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
+                                if (hit[u] && pos < RB_NB_CAP) WS.nb[(size_t)p * RB_NB_CAP + pos] = img * n + q;
+                                cnt += __builtin_popcountll(bal);
+                            }
                         }
                     }
                 }

@@ -13,14 +13,10 @@ csrc = ROOT / "pywindow_amd" / "csrc"
 so = ROOT / "tests" / "tools" / "libpw_rbprof.so"
 if "--build" in sys.argv:
     hip = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c"]
-    objs = []
-    for src in ("pw_kernels.hip", "pw_rebuild.hip", "pw_shape.hip"):
-        obj = f"/tmp/rbprof_{src}.o"
-        flags = ["-DPW_RB_PROFILE"] if src == "pw_rebuild.hip" else []
-        subprocess.check_call(hip + flags + [str(csrc / src), "-o", obj])
-        objs.append(obj)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-c", str(csrc / "pw_history.cpp"), "-o", "/tmp/rbprof_h.o"])
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "/tmp/rbprof_h.o", "-o", str(so)])
+    subprocess.check_call(hip + ["-DPW_RB_PROFILE", str(csrc / "pw_rebuild.hip"), "-o", "/tmp/rbprof_rebuild.o"])
+    # (the other translation units as the product build left them)
+    rest = [str(csrc / o) for o in ("pw_kernels.o", "pw_kernels_big.o", "pw_shape.o", "pw_history.o", "pw_hostpath.o")]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread", "/tmp/rbprof_rebuild.o", *rest, "-o", str(so)])
     sys.exit(0)
 import numpy as np  # noqa: E402
 from test_rebuild import CASES  # noqa: E402
