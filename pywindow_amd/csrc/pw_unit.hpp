@@ -1112,10 +1112,11 @@ PW_HD inline __attribute__((always_inline)) bool team_ray_tests(const Frame& F, 
     if (!fits) return false;
     // ---- the reference's arithmetic on the pairs, one pair per lane ----
     for (int g = T::tid(); g < cum[T::NWAVES]; g += T::SIZE) {
-        int w = 0;
+        int w = 0, first = 0;                   // (selects, not an indexed read of cum[]: that would live in scratch)
 #pragma unroll
-        for (int q = 1; q < T::NWAVES; ++q) w += g >= cum[q] ? 1 : 0;
-        const unsigned pr = pairs[(size_t)w * seg + (g - cum[w])];
+        for (int q = 1; q < T::NWAVES; ++q)
+            if (g >= cum[q]) { w = q; first = cum[q]; }
+        const unsigned pr = pairs[(size_t)w * seg + (g - first)];
         const int k = (int)(pr >> 16), i = (int)(pr & 0xffffu);
         double dx, dy, dz;
         getp(k, &dx, &dy, &dz);
