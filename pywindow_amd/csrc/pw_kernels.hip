@@ -871,7 +871,7 @@ int pw_context_create(int device, pw_context** out) {
     c->n_cu = prop.multiProcessorCount;
     c->lds_per_cu = 160 * 1024;
     CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CTX_TRY(hipMalloc((void**)&c->counter, (4 * PW_SETS + 2) * sizeof(unsigned long long)));
+    CTX_TRY(hipMalloc((void**)&c->counter, (4 * PW_SETS + 2) * sizeof(unsigned long long)));      // per set: chains | windows | average | basic; + 2 for single launches
     CTX_TRY(hipMalloc((void**)&c->queue, PW_SETS * sizeof(UnitQueue)));
     CTX_TRY(hipMemset(c->queue, 0, PW_SETS * sizeof(UnitQueue)));
     c->flip = -1;
@@ -941,17 +941,21 @@ int pw_context_create(int device, pw_context** out) {
         all[k++] = c->stream; all[k++] = c->aux;
         for (int b = 0; b < PW_SETS; ++b) { all[k++] = c->prods[b]; all[k++] = c->cons[b]; }
         int* flags = (int*)c->counter;                        // (the work counters are unused so far)
-        // (a first round that waits for nobody: the code object is loaded and every stream has dispatched
-        // once before the round that is timed against a 10 ms limit)
-        CTX_TRY(hipMemset(flags, 0, 2 * sizeof(int)));
+        // (a first round that waits for nobody: the code object is loaded and every stream has dispatched once
+        // before the round that is timed against a 10 ms limit.  The flags are cleared on one of the streams
+        // and the device is idle before any probe starts: these streams do not wait for the default stream.)
+        CTX_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(int), c->stream));
+        CTX_TRY(hipDeviceSynchronize());
         for (int i = 0; i < k; ++i) hipLaunchKernelGGL(pw_probe_kernel, dim3(1), dim3(64), 0, all[i], flags, 0, flags + 1);
         CTX_TRY(hipDeviceSynchronize());
-        CTX_TRY(hipMemset(flags, 0, 2 * sizeof(int)));
+        CTX_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(int), c->stream));
+        CTX_TRY(hipDeviceSynchronize());
         for (int i = 0; i < k; ++i) hipLaunchKernelGGL(pw_probe_kernel, dim3(1), dim3(64), 0, all[i], flags, k, flags + 1);
         CTX_TRY(hipDeviceSynchronize());
         int got[2] = {0, 0};
         CTX_TRY(hipMemcpy(got, flags, sizeof(got), hipMemcpyDeviceToHost));
-        CTX_TRY(hipMemset(flags, 0, 2 * sizeof(int)));
+        CTX_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(int), c->stream));
+        CTX_TRY(hipDeviceSynchronize());
         c->concurrent_streams = got[1];
         if (got[1] < k) {
             // not all of them: the overlapped pipeline cannot be trusted on this process -- every analysis
@@ -1197,7 +1201,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         }
         r->written_set[r->cur] = -1;       // (the API stream joins every pipeline launch: nothing to remember)
         HIP_TRY(hipMemsetAsync(r->d_xw_count + r->cur, 0, sizeof(unsigned), c->stream));
-        return launch_plan(c, r, stages, p, c->stream, 0, win ? 0 : -1, 3 * PW_SETS + 1);
+        return launch_plan(c, r, stages, p, c->stream, 0, win ? 0 : -1, 4 * PW_SETS);
     }
     // Pipeline: the analysis is split by parallel shape and the pieces overlap.
     //   A (producer stream): stage_basic + pore-centre optimiser, ONE wave per unit -- the serial

@@ -145,3 +145,18 @@ def test_torch_can_start_after_the_library():
     out = subprocess.run([sys.executable, str(tool), "both"], capture_output=True, text=True, timeout=1200,   # (a fresh box pages torch in for minutes)
                          cwd=str(tool.parents[2]))
     assert out.returncode == 0 and "torch ok" in out.stdout, out.stdout[-500:] + out.stderr[-1500:]
+
+
+def test_stream_probe_is_stable():
+    """pw_context_create measures whether the pipeline's ten streams run concurrently and falls back to single
+    launches when they do not.  With GPU_MAX_HW_QUEUES exported before HIP started (importing the package
+    first does that) the answer must be "they do", every time: a probe that misfires would silently cost
+    2.6x of the throughput."""
+    from pywindow_amd import _lib
+
+    for k in range(25):
+        ctx = _lib.Context(0)
+        try:
+            assert ctx.pipelined, f"context {k}: the stream probe failed"
+        finally:
+            ctx.close()
