@@ -26,6 +26,9 @@ def hostsim():
 
 @pytest.fixture(scope="session")
 def hip_ctx():
-    from pywindow_amd import _lib
+    """THE context of device 0 in this process -- the one `engine.context()` hands to the façade as well: one
+    context per device keeps the hardware queues for its ten streams (a second live context would run single
+    launches, see pw_context_create's stream probe), so the parity tests exercise the overlapped pipeline."""
+    from pywindow_amd import engine
 
-    return _lib.Context(0)
+    return engine.context(0)
