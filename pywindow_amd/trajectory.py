@@ -260,7 +260,16 @@ class DLPOLY:
         # 10 000 frames 21.8 against 22.7 ms): the persistent window teams of a piece keep their LDS until the
         # piece's slowest optimiser chain is done, so the teams of later pieces wait for a place instead of
         # working -- one launch hands finished units to whichever team is free.  Pieces only bound memory.
-        inflight = []
+        inflight, parts, extras = [], [], []
+        done = [0]
+
+        def collect(res):
+            extra = []
+            parts.append(res.download(extra))
+            extras.extend(engine.offset_extra(e, done[0]) for e in extra)
+            done[0] += res.n_units
+            res.free()                  # (its device block goes back to the context's cache)
+
         try:
             for lo in range(0, n, per):
                 sel = frames[lo:lo + per]
@@ -268,12 +277,10 @@ class DLPOLY:
                 res = ctx.upload(_lib.Batch.uniform(coords, vdw, mass))
                 res.launch(_lib.STAGE_ALL)
                 inflight.append(res)
-            parts, extras, at = [], [], 0
-            for res in inflight:
-                extra = []
-                parts.append(res.download(extra))
-                extras += [engine.offset_extra(e, at) for e in extra]
-                at += res.n_units
+                if len(inflight) > 2:   # at most three pieces on the device, however long the trajectory
+                    collect(inflight.pop(0))
+            while inflight:
+                collect(inflight.pop(0))
             if extras:
                 self._extra = np.concatenate(extras)
             return parts[0] if len(parts) == 1 else np.concatenate(parts)
