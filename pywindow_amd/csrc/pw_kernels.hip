@@ -638,22 +638,28 @@ static int wanted_p_cap(const pw_context* c) {
     if (c->p_cap_min > p) p = round_p_cap(c->p_cap_min);
     return p;
 }
+// capacities beyond this are "large": such launches run as single launches on a limited number of teams
+// (the slabs and adjacency rows of thousands of pipeline teams would not fit), and the workspace is rebuilt
+// small again when the knobs go back
+constexpr int PW_P_CAP_PIPELINE = 8448;          // round_p_cap(2100 x 4): up to adjust = 4 the pipeline runs
+static size_t team_ws_bytes(int p_cap, bool with_adj) {
+    return sizeof(TeamWorkspace) + team_slab_bytes(p_cap) + (with_adj ? team_adj_words(p_cap) * 8 : 0);
+}
 static int ensure_workspace(pw_context* c, int blocks, int adj_blocks) {
     const int want = wanted_p_cap(c);
-    if (want > c->p_cap) {
-        // capacities only grow; everything sized by them is rebuilt (nothing is in flight afterwards)
+    if (want > c->p_cap || (want < c->p_cap && c->p_cap > PW_P_CAP_PIPELINE)) {
+        // the capacity follows the knobs upwards always, downwards only from a large one; everything sized by
+        // it is rebuilt for THIS launch's teams (nothing is in flight afterwards)
         HIP_TRY(hipDeviceSynchronize());
+        if (c->ws) HIP_TRY(hipFree(c->ws));
+        c->ws = nullptr;
         if (c->slab) HIP_TRY(hipFree(c->slab));
         c->slab = nullptr;
         if (c->adj) HIP_TRY(hipFree(c->adj));
         c->adj = nullptr;
-        if (blocks < c->ws_blocks) blocks = c->ws_blocks;
-        if (adj_blocks < c->adj_blocks) adj_blocks = c->adj_blocks;
+        c->ws_blocks = 0;
         c->adj_blocks = 0;
         c->p_cap = want;
-        if (c->ws_blocks > 0) {
-            HIP_TRY(hipMalloc((void**)&c->slab, (size_t)c->ws_blocks * team_slab_bytes(c->p_cap)));
-        }
     }
     if (c->ws_blocks < blocks) {
         HIP_TRY(hipDeviceSynchronize());
@@ -1066,6 +1072,7 @@ int pw_context_set_params(pw_context* c, const pw_params* p) {
         return PW_E_BAD_ARG;
     }
     c->prm = *p;
+    c->p_cap_min = 0;        // (what an earlier batch asked for beyond its knobs does not outlive them)
     c->prm.pore_opt = p->pore_opt ? 1 : 0;
     c->prm.lb_z = p->lb_z ? 1 : 0;
     c->prm.z_second_mini = p->z_second_mini ? 1 : 0;
@@ -1181,7 +1188,8 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
                                           c->rsq_tab, r->vstride);
         }
     }
-    const bool pipeline = !c->fused && (stages & PW_STAGE_WINDOWS) != 0;
+    const bool large = wanted_p_cap(c) > PW_P_CAP_PIPELINE;
+    const bool pipeline = !c->fused && (stages & PW_STAGE_WINDOWS) != 0 && !large;
     if (!pipeline) {
         // one launch: every requested stage inside the same team
         LaunchPlan p;
@@ -1190,6 +1198,20 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         rc = plan_launch(c, r->n_units, r->nmax, (win || (stages & PW_STAGE_AVG)) ? 4 : 1, win,
                          win ? -1 : (opt ? 1 : 0), &p);
         if (rc != PW_OK) return rc;
+        if (large) {
+            // tens of thousands of sampling vectors per molecule (adjust beyond 4): as many teams as 48 GB of
+            // workspace allow -- the adjacency rows of DBSCAN are p_cap^2 / 8 bytes per team
+            const size_t per = team_ws_bytes(wanted_p_cap(c), win);
+            const size_t budget = (size_t)48 << 30;
+            if (per > ((size_t)192 << 30)) {
+                snprintf(g_err, sizeof(g_err), "%d sampling vectors per molecule need %zu GB of workspace per team",
+                         wanted_p_cap(c), per >> 30);
+                return PW_E_TOO_LARGE;
+            }
+            long g = (long)(budget / per);
+            if (g < 1) g = 1;
+            if (g < p.grid) p.grid = (int)g;
+        }
         rc = ensure_workspace(c, p.grid, win ? p.grid : 0);
         if (rc != PW_OK) return rc;
         c->need_fork = 1;

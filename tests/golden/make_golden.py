@@ -738,6 +738,9 @@ def cliff_cases():
             calls.append((f"{name}/win/adjust={a}", "win", name, {"adjust": a}))
         for a in CLIFF_AVERAGE_ADJUST:
             calls.append((f"{name}/avg/adjust={a}", "avg", name, {"adjust": a}))
+    # tens of thousands of vectors (the engine then runs single launches on few teams)
+    calls.append(("cc3/win/adjust=12", "win", "cc3", {"adjust": 12}))
+    calls.append(("cc3/avg/adjust=12", "avg", "cc3", {"adjust": 12}))
     # fewer than ten sampling vectors: KDTree.query(k=10) raises; ten to fifteen: fine
     for a in (0.008, 0.0135, 0.018):
         calls.append((f"cc3/win/adjust={a}", "win", "cc3", {"adjust": a}))
