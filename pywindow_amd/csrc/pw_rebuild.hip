@@ -31,13 +31,13 @@ constexpr int RB_WAVES = 4;
 
 __global__ void __launch_bounds__(RB_WAVES * 64)
 pw_rebuild_kernel(pw_cell_in in, pw_cell_out out, unsigned char* __restrict__ slabs, size_t slab_bytes,
-                  unsigned long long* counter, int with_bits) {
+                  unsigned long long* counter, int with_bits, int with_scan) {
     using T = DeviceTeam<RB_WAVES>;
     extern __shared__ __attribute__((aligned(16))) unsigned char fast[];   // RebuildWs::fast_bytes
     __shared__ long s_frame;
     const int n = in.n_atoms;
     RebuildWs* w = RebuildWs::carve(slabs + (size_t)blockIdx.x * slab_bytes, n, in.rebuild, T::SIZE);
-    w->attach_fast(fast, n, in.rebuild, with_bits != 0);
+    w->attach_fast(fast, n, in.rebuild, with_bits != 0, with_scan != 0);
     __syncthreads();
     for (;;) {
         if (threadIdx.x == 0) {
@@ -189,7 +189,9 @@ int rebuild_on_device(pw_context* ctx, const pw_cell_in* in, int atoms_cap, int 
     d_out.src_atom = dev->src; d_out.src_image = (int8_t*)dev->img; d_out.xyz = dev->oxyz;
     // team-shared memory: the hit segments, and the two visit bit sets when they fit beside them
     int with_bits = RebuildWs::fast_bytes(n, in->rebuild, true) <= 96 * 1024 ? 1 : 0;
-    size_t lds = RebuildWs::fast_bytes(n, in->rebuild, with_bits != 0);
+    // ... and the single-precision coordinates of the candidate scan while two teams still fit a CU
+    int with_scan = RebuildWs::fast_bytes(n, in->rebuild, with_bits != 0, true) <= 79 * 1024 ? 1 : 0;
+    size_t lds = RebuildWs::fast_bytes(n, in->rebuild, with_bits != 0, with_scan != 0);
     {
         // the limit, not a request: set once per device (host threads may launch concurrently)
         static std::atomic<unsigned long long> done{0};
@@ -201,25 +203,45 @@ int rebuild_on_device(pw_context* ctx, const pw_cell_in* in, int atoms_cap, int 
         }
     }
     hipLaunchKernelGGL(pw_rebuild_kernel, dim3((unsigned)grid), dim3(RB_WAVES * 64), lds, st, d_in, d_out,
-                       d_slabs, slab, d_counter, with_bits);
+                       d_slabs, slab, d_counter, with_bits, with_scan);
     RB_TRY(hipGetLastError());
     return PW_OK;
 }
 
 // exclusive scans over the frames: first unit and first atom of every frame (F + 1 entries each)
-__global__ void rb_scan_kernel(long F, int mols_cap, const int* __restrict__ n_mol, const int* __restrict__ off,
-                               long* __restrict__ unit_base, long* __restrict__ atom_base) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void __launch_bounds__(256)
+rb_scan_kernel(long F, int mols_cap, const int* __restrict__ n_mol, const int* __restrict__ off,
+               long* __restrict__ unit_base, long* __restrict__ atom_base) {
+    // one block: a thread sums a run of consecutive frames, the runs are scanned through team-shared memory
+    // (a single thread walking the frames paid two dependent memory round trips per frame)
+    __shared__ long su[256], sa[256];
+    const int t = threadIdx.x;
+    const long per = (F + 255) / 256;
+    const long f0 = t * per, f1 = f0 + per < F ? f0 + per : F;
     long u = 0, a = 0;
-    for (long f = 0; f < F; ++f) {
-        unit_base[f] = u;
-        atom_base[f] = a;
-        int m = n_mol[f];
+    for (long f = f0; f < f1; ++f) {
+        const int m = n_mol[f];
         u += m;
         a += off[f * (mols_cap + 1) + m];
     }
-    unit_base[F] = u;
-    atom_base[F] = a;
+    su[t] = u; sa[t] = a;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        long xu = 0, xa = 0;
+        if (t >= d) { xu = su[t - d]; xa = sa[t - d]; }
+        __syncthreads();
+        su[t] += xu; sa[t] += xa;
+        __syncthreads();
+    }
+    u = su[t] - u; a = sa[t] - a;              // exclusive
+    for (long f = f0; f < f1; ++f) {
+        unit_base[f] = u;
+        atom_base[f] = a;
+        const int m = n_mol[f];
+        u += m;
+        a += off[f * (mols_cap + 1) + m];
+    }
+    if (t == 255) { unit_base[F] = su[255]; atom_base[F] = sa[255]; }
 }
 
 // the molecules of all frames as one ragged batch: offsets, coordinates, radii and masses by source atom
@@ -309,7 +331,7 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
     RB_TRY(buf.alloc(&d_nmax, sizeof(int)));
     RB_TRY(hipMemcpyAsync(d_vdw_atom, vdw, sizeof(double) * n, hipMemcpyHostToDevice, st));
     RB_TRY(hipMemsetAsync(d_nmax, 0, sizeof(int), st));
-    hipLaunchKernelGGL(rb_scan_kernel, dim3(1), dim3(64), 0, st, F, (int)mols_cap, dev.n_mol, dev.off, d_ubase, d_abase);
+    hipLaunchKernelGGL(rb_scan_kernel, dim3(1), dim3(256), 0, st, F, (int)mols_cap, dev.n_mol, dev.off, d_ubase, d_abase);
     RB_TRY(hipGetLastError());
     long totals[2] = {0, 0};
     RB_TRY(hipMemcpyAsync(n_mol, dev.n_mol, sizeof(int) * F, hipMemcpyDeviceToHost, st));

@@ -31,7 +31,8 @@
 
 namespace pw {
 
-constexpr int RB_NB_CAP = 32;      // conservative neighbour candidates kept per heavy atom
+constexpr int RB_NB_CAP = 16;      // neighbour candidates kept per heavy atom (bonded, or too close to a threshold to say)
+constexpr int RB_NCELL = 2048;     // cells of the candidate grid
 constexpr int RB_SEG_CAP = 32;     // bonded neighbours one atom can contribute per layer
 constexpr int RB_CHUNK = 64;       // atoms of a layer expanded between two merges
 constexpr int RB_LFINAL = 1024;    // atoms of the molecule being walked kept in team-shared memory
@@ -40,6 +41,11 @@ constexpr int RB_WF_TRUNCATED = 1;  // a neighbour candidate lay outside the 3x3
 constexpr int RB_WF_MARGINAL = 2;   // a distance within 1e-6 of a threshold of the bond test
 constexpr int RB_WF_REPEAT = 4;     // the same atom met in two images (or twice by value): not a finite molecule
 constexpr int RB_CENTRAL = 13;     // image (0,0,0) in the a,b,c-nested 3x3x3 enumeration
+// a candidate entry: image * n + atom, plus the outcome of the bond test when it cannot depend on the image
+// the pair is met in (see "bond tests made once")
+constexpr int RB_NB_CLEAR = 1 << 30;
+constexpr int RB_NB_BONDED = 1 << 29;
+constexpr int RB_NB_MASK = RB_NB_BONDED - 1;
 
 // status bits of one frame (pw_cell_out.status)
 constexpr int RB_ST_NB_OVERFLOW = 1;      // > RB_NB_CAP candidates around one atom
@@ -104,6 +110,29 @@ PW_HD inline double rb_dist_sk(const double* x, double xx, double px, double py,
     return pw_sqrt(d2 > 0.0 ? d2 : 0.0);
 }
 
+// The reference's bond test between a visited atom at p and a candidate at x: scikit-learn's distance inside
+// (0.1, max_dist), then distance() (utilities.py:80-93) inside (lo, hi).  *clearance = how far the comparisons
+// that decided were from their thresholds.
+PW_HD inline bool rb_bond(double x0, double x1, double x2, double px, double py, double pz, double pp, double lo,
+                          double hi, double max_dist, double* clearance) {
+    const double xx = sq3(x0, x1, x2);          // == Vxx[q] for a cell atom
+    const double xv[3] = {x0, x1, x2};
+    const double d = rb_dist_sk(xv, xx, px, py, pz, pp);
+    const double c1 = pw_min(pw_abs(d - 0.1), pw_abs(d - max_dist));
+    *clearance = c1;
+    if (!(d > 0.1 && d < max_dist)) return false;
+    double dx = px - x0, dy = py - x1, dz = pz - x2;
+    double r2 = (dx * dx + dy * dy) + dz * dz;
+    // distance(): (...) ** 0.5 on a float is libm pow, which is within one ulp of the correctly
+    // rounded square root: only a comparison that close to a limit needs the libm value
+    double r = pw_sqrt(r2);
+    const double margin = r * 1.0e-15;
+    if ((pw_abs(r - lo) <= margin || pw_abs(r - hi) <= margin) && r2 >= 2.2250738585072014e-308)
+        r = pw_pow_np(r2, 0.5);
+    *clearance = pw_min(c1, pw_min(pw_abs(r - lo), pw_abs(r - hi)));
+    return lo < r && r < hi;
+}
+
 // scalars and small arrays every phase of the walk passes through: team-shared memory
 struct RebuildShared {
     double red_v[8];
@@ -143,33 +172,38 @@ struct RebuildWs {
     unsigned char* remaining;   // n
     unsigned char* alias;       // n
     // what the first walk through a molecule learned (rebuild only; see "walks that can be predicted")
-    float* scan;          // 3 x (27n | n): x, y, z of every (image, atom) in single precision, for the
-                          // conservative candidate scan only (coalesced 4-byte reads)
-    float* blk;           // 6 x ceil(n / 64): bounding boxes of the blocks of 64 consecutive atoms of the central
-                          // image (lo x, y, z, hi x, y, z), for the candidate scan
+    // ---- the candidate scan: a uniform grid over the central image (the cell when nothing is rebuilt) ----
+    float* scan;          // n x 4: x, y, z in single precision and the covalent radius of every atom - the scan only
+                          // has to be conservative; an image is the central one seen from a shifted atom
+    int* grid_ids;        // n: the atoms sorted by grid cell
+    int* grid_start;      // RB_NCELL + 1: first position of every cell in grid_ids
+    int scan_fast;        // ... the three of them are in team-shared memory (attach_fast)
     int* cage_of;         // n: serial of the first walk that visited the atom, 0 = none yet
     unsigned char* cage_off;    // n: image (0..26) in which that walk met the atom
     unsigned char* cage_ok;     // n + 1, by walk serial: the walk was clean (no truncation / marginal bond / repeat)
     int* cage_rng;        // n + 1: lowest and highest image offset per axis (2 bits each)
     double* cage_f;       // (n + 1) x 3: fractional centre of mass of that walk's molecule
+    double* dorig;        // n: distance of every cell atom to the pseudo origin (the start atoms are its arg-minima)
     int status, n_mol, n_out;
 
     PW_HD static size_t ids(int n, int rebuild) { return rebuild ? (size_t)28 * n : (size_t)n; }
     PW_HD static size_t bytes(int n, int rebuild, int team) {
         size_t id = ids(n, rebuild);
         (void)team;
-        size_t d = (size_t)3 * n + n + (rebuild ? (size_t)81 * n : 0) + id + 3 * ((size_t)n + 1);
+        size_t d = (size_t)3 * n + n + (rebuild ? (size_t)81 * n : 0) + id + 3 * ((size_t)n + 1) + n;
         size_t i = (size_t)n + (size_t)n * RB_NB_CAP + 5 * id + 2 * ((size_t)n + 1);
         return sizeof(RebuildWs) + 64 + d * 8 + i * 4 + 4 * (size_t)n + 64 + 64 +
-               3 * (rebuild ? (size_t)27 * n : (size_t)n) * 4 + 64 + 6 * (((size_t)n + 63) / 64) * 4 + 64;
+               scan_bytes(n) + 64;
     }
-    // fast memory: the hit segments always, the two bit sets when `with_bits`
-    PW_HD static size_t fast_bytes(int n, int rebuild, bool with_bits) {
+    PW_HD static size_t scan_bytes(int n) { return (size_t)n * 16 + (((size_t)n * 4 + 15) & ~(size_t)15) + ((size_t)RB_NCELL + 4) * 4; }
+    // fast memory: the hit segments always, the two bit sets when `with_bits`, the scan coordinates when `with_scan`
+    PW_HD static size_t fast_bytes(int n, int rebuild, bool with_bits, bool with_scan = false) {
         size_t words = (ids(n, rebuild) + 63) / 64;
         return (size_t)RB_CHUNK * RB_SEG_CAP * 8 + (size_t)RB_CHUNK * 4 + (with_bits ? 2 * words * 8 : 0) +
-               ((sizeof(RebuildShared) + 15) & ~(size_t)15) + (with_bits ? (((size_t)n + 15) & ~(size_t)15) : 0);
+               ((sizeof(RebuildShared) + 15) & ~(size_t)15) + (with_bits ? 2 * (((size_t)n + 15) & ~(size_t)15) : 0) +
+               (with_scan ? scan_bytes(n) : 0);
     }
-    PW_HD void attach_fast(unsigned char* base, int n, int rebuild, bool with_bits) {
+    PW_HD void attach_fast(unsigned char* base, int n, int rebuild, bool with_bits, bool with_scan = false) {
         sh = (RebuildShared*)base;
         base += (sizeof(RebuildShared) + 15) & ~(size_t)15;
         seg = (long long*)base;
@@ -184,7 +218,15 @@ struct RebuildWs {
         base += (size_t)RB_CHUNK * 4;
         // the atom list ("remaining") is read and written at every step of the walk: with the bit sets
         // it moves into team-shared memory (carve() pointed it into the slab)
-        if (with_bits) remaining = base;
+        // (and "the central image's copy of this atom is the same list item", looked up beside it)
+        if (with_bits) { remaining = base; base += ((size_t)n + 15) & ~(size_t)15; alias = base; base += ((size_t)n + 15) & ~(size_t)15; }
+        scan_fast = with_scan ? 1 : 0;
+        if (with_scan) attach_scan(base, n);
+    }
+    PW_HD void attach_scan(unsigned char* base, int n) {
+        scan = (float*)base; base += (size_t)n * 16;
+        grid_ids = (int*)base; base += ((size_t)n * 4 + 15) & ~(size_t)15;
+        grid_start = (int*)base;
     }
     // `base` -> [RebuildWs header][arrays]; returns the header
     PW_HD static RebuildWs* carve(unsigned char* base, int n, int rebuild, int team) {
@@ -196,6 +238,7 @@ struct RebuildWs {
         w->S = (double*)p; p += rebuild ? (size_t)81 * n * 8 : 0;
         w->msum = (double*)p; p += id * 8;
         w->cage_f = (double*)p; p += 3 * ((size_t)n + 1) * 8;
+        w->dorig = (double*)p; p += (size_t)n * 8;
         w->nb_cnt = (int*)p; p += (size_t)n * 4;
         w->nb = (int*)p; p += (size_t)n * RB_NB_CAP * 4;
         w->stamp_final = (int*)p; p += id * 4;
@@ -210,9 +253,8 @@ struct RebuildWs {
         w->cage_off = p; p += n;
         w->cage_ok = p; p += (size_t)n + 1;
         p = (unsigned char*)(((size_t)p + 63) & ~(size_t)63);
-        w->scan = (float*)p; p += 3 * (rebuild ? (size_t)27 * n : (size_t)n) * 4;
-        p = (unsigned char*)(((size_t)p + 63) & ~(size_t)63);
-        w->blk = (float*)p; p += 6 * (((size_t)n + 63) / 64) * 4;
+        w->attach_scan(p, n);
+        w->scan_fast = 0;
         return w;
     }
 };
@@ -282,12 +324,17 @@ PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, int* sta
     const int cnt = cnt0 < RB_NB_CAP ? cnt0 : RB_NB_CAP;
     for (int e = T::lane(); e < cnt; e += T::WSIZE) {
         int packed = e == T::lane() ? first : w.nb[(size_t)q0 * RB_NB_CAP + e];
+        // bond tests made once: the candidate scan has already tested this pair in the central image; when
+        // no comparison came near a threshold the outcome is the same in whichever image the walk meets it
+        const bool clear = (packed & RB_NB_CLEAR) != 0, bonded = (packed & RB_NB_BONDED) != 0;
+        packed &= RB_NB_MASK;
         int dimg = packed / n;
         int q = packed - dimg * n;
         int bx = ax + dimg / 9 - 1, by = ay + (dimg / 3) % 3 - 1, bz = az + dimg % 3 - 1;
         bool central = bx == 0 && by == 0 && bz == 0;
-        double rc = ri + fr.cov[q];
-        double lo = rc - fr.tol, hi = rc + fr.tol;
+        const bool outside = bx < -1 || bx > 1 || by < -1 || by > 1 || bz < -1 || bz > 1;
+        if (fr.rebuild && outside) rb_atomic_or(wflags, RB_WF_TRUNCATED);
+        if (clear && !bonded) continue;
         // a candidate is tested as a remaining cell atom (utilities.py:996-1013) and / or as a
         // supercell atom that is not, by value, in the remaining atom list (:1014-1036); nearly
         // always exactly one of the two applies, so the lanes pick theirs first and share one
@@ -295,8 +342,6 @@ PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, int* sta
         const unsigned char rem = central ? w.remaining[q] : (unsigned char)0;
         const bool same_item = central && w.alias[q];
         const bool do0 = central && rem;
-        const bool outside = bx < -1 || bx > 1 || by < -1 || by > 1 || bz < -1 || bz > 1;
-        if (fr.rebuild && outside) rb_atomic_or(wflags, RB_WF_TRUNCATED);
         const bool do1 = fr.rebuild && !outside && !(same_item && rem);
         const int s1 = ((bx + 1) * 9 + (by + 1) * 3 + (bz + 1)) * n + q;
         RB_XT(1);
@@ -305,26 +350,18 @@ PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, int* sta
             const bool as_image = pass == 0 ? (!do0 && do1) : (do0 && do1);
             if (pass == 1 && !T::wave_any(as_image)) break;
             if (!as_cell && !as_image) continue;
-            const double* X = as_cell ? &w.V[3 * q] : &w.S[3 * (size_t)s1];
-            const double x0 = X[0], x1 = X[1], x2 = X[2];
-            RB_XT(2);
-            const double xx = sq3(x0, x1, x2);          // == Vxx[q] for a cell atom
             const long long key = as_cell ? (((long long)q << 32) | (unsigned)q)
                                           : (((long long)(n + s1) << 32) | (unsigned)(same_item ? q : n + s1));
-            const double xv[3] = {x0, x1, x2};
-            double d = rb_dist_sk(xv, xx, px, py, pz, pp);
-            if (pw_abs(d - 0.1) < 1e-6 || pw_abs(d - fr.max_dist) < 1e-6) rb_atomic_or(wflags, RB_WF_MARGINAL);
-            if (!(d > 0.1 && d < fr.max_dist)) continue;
-            double dx = px - x0, dy = py - x1, dz = pz - x2;
-            double r2 = (dx * dx + dy * dy) + dz * dz;
-            // distance(): (...) ** 0.5 on a float is libm pow, which is within one ulp of the correctly
-            // rounded square root: only a comparison that close to a limit needs the libm value
-            double r = pw_sqrt(r2);
-            const double margin = r * 1.0e-15;
-            if ((pw_abs(r - lo) <= margin || pw_abs(r - hi) <= margin) && r2 >= 2.2250738585072014e-308)
-                r = pw_pow_np(r2, 0.5);
-            if (pw_abs(r - lo) < 1e-6 || pw_abs(r - hi) < 1e-6) rb_atomic_or(wflags, RB_WF_MARGINAL);
-            if (!(lo < r && r < hi)) continue;
+            if (!clear) {
+                const double* X = as_cell ? &w.V[3 * q] : &w.S[3 * (size_t)s1];
+                const double x0 = X[0], x1 = X[1], x2 = X[2];
+                RB_XT(2);
+                const double rc = ri + fr.cov[q];
+                double clearance;
+                const bool hit = rb_bond(x0, x1, x2, px, py, pz, pp, rc - fr.tol, rc + fr.tol, fr.max_dist, &clearance);
+                if (clearance < 1e-6) rb_atomic_or(wflags, RB_WF_MARGINAL);
+                if (!hit) continue;
+            }
             int k = rb_atomic_add(&w.seg_cnt[slot], 1);
             if (k < RB_SEG_CAP) w.seg[(size_t)slot * RB_SEG_CAP + k] = key;
             else rb_atomic_or(status, RB_ST_SEG_OVERFLOW);
@@ -363,20 +400,27 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
     const int n = fr.n;
     const int n_ids = (int)RebuildWs::ids(n, fr.rebuild);
     const int tid = T::tid();
+    static_assert(T::NWAVES <= 4, "red_v[4 + wave] carries the coordinate maxima");
     if (tid == 0) {
         w.status = 0; w.n_mol = 0; w.n_out = 0;
         out.mol_offset[0] = 0;
     }
     // ---- value coordinates ------------------------------------------------------------
+    double vmax = 0.0;                                 // largest coordinate of the cell (for clear_min, below)
     for (int i = tid; i < n; i += T::SIZE) {
         double x = rb_round8(fr.xyz[3 * i]), y = rb_round8(fr.xyz[3 * i + 1]), z = rb_round8(fr.xyz[3 * i + 2]);
+        vmax = pw_max(vmax, pw_max(pw_abs(x), pw_max(pw_abs(y), pw_abs(z))));
         WS.V[3 * i] = x; WS.V[3 * i + 1] = y; WS.V[3 * i + 2] = z;
         WS.Vxx[i] = sq3(x, y, z);
-        if (!fr.rebuild) { WS.scan[i] = (float)x; WS.scan[(size_t)n + i] = (float)y; WS.scan[2 * (size_t)n + i] = (float)z; }
+        if (!fr.rebuild) { WS.scan[4 * i] = (float)x; WS.scan[4 * i + 1] = (float)y; WS.scan[4 * i + 2] = (float)z; WS.scan[4 * i + 3] = (float)fr.cov[i]; }
         WS.remaining[i] = 1;
         WS.alias[i] = 0;
         WS.nb_cnt[i] = 0;
         WS.cage_of[i] = 0;
+    }
+    {
+        const double wm = -T::wave_min(-vmax);
+        if (T::lane() == 0) sh.red_v[4 + T::wave()] = wm;
     }
     const bool use_bits = WS.bits_final != nullptr;
     if (use_bits) {
@@ -395,7 +439,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                 rb_mat3(fr.lattice, fq[0] + sa, fq[1] + sb, fq[2] + sc, c);
                 size_t s = (size_t)img * n + i;
                 WS.S[3 * s] = rb_round8(c[0]); WS.S[3 * s + 1] = rb_round8(c[1]); WS.S[3 * s + 2] = rb_round8(c[2]);
-                WS.scan[s] = (float)c[0]; WS.scan[(size_t)27 * n + s] = (float)c[1]; WS.scan[(size_t)54 * n + s] = (float)c[2];
+                if (img == RB_CENTRAL) { WS.scan[4 * i] = (float)c[0]; WS.scan[4 * i + 1] = (float)c[1]; WS.scan[4 * i + 2] = (float)c[2]; WS.scan[4 * i + 3] = (float)fr.cov[i]; }
             }
             size_t s0 = (size_t)RB_CENTRAL * n + i;
             WS.alias[i] = (WS.S[3 * s0] == WS.V[3 * i] && WS.S[3 * s0 + 1] == WS.V[3 * i + 1] &&
@@ -409,22 +453,6 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
     for (int col = tid; col < 3; col += T::SIZE)
         sh.com[col] = seq_sum_blocked(n, [&](int r) { return fr.xyz[3 * r + col] * fr.mass[r]; });
     if (tid == SUM_THREAD) sh.red_v[0] = np_sum_serial(fr.mass, n);
-    if (fr.rebuild) {
-        // bounding box of every image (candidate culling only; min / max are exact in any order):
-        // one wave per image, lanes over the atoms
-        for (int img = T::wave(); img < 27; img += T::NWAVES) {
-            double lo[3] = {PW_INF, PW_INF, PW_INF}, hi[3] = {-PW_INF, -PW_INF, -PW_INF};
-            for (int i = T::lane(); i < n; i += T::WSIZE)
-                for (int c = 0; c < 3; ++c) {
-                    double v = WS.S[3 * ((size_t)img * n + i) + c];
-                    lo[c] = pw_min(lo[c], v); hi[c] = pw_max(hi[c], v);
-                }
-            for (int c = 0; c < 3; ++c) {
-                double l = T::wave_min(lo[c]), h = -T::wave_min(-hi[c]);
-                if (T::lane() == 0) { sh.box[6 * img + c] = l; sh.box[6 * img + 3 + c] = h; }
-            }
-        }
-    }
     T::sync();
     if (tid == 0) {
         double total = sh.red_v[0];
@@ -447,160 +475,189 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
         }
     }
     RB_TICK(1);
-    // ---- conservative candidate lists around every heavy atom ----------------------------
+    // ---- candidate lists around every heavy atom ------------------------------------------------
+    // Which pairs of atoms the walk has to test is a property of the frame, not of the walk: the value
+    // coordinates of an image are the central image's plus a lattice translation (and 1e-8 of rounding), so the
+    // pair "atom p in image a, atom q in image a + d" is the pair "p in the central image, q in image d".  The
+    // lists are therefore built once, around the atoms of the central image:
+    //   * a uniform grid over the central image (cells no smaller than the reach of a bond, atoms sorted by
+    //     cell) in single precision: an image is the central one seen from the atom shifted back by the
+    //     image's translation, and only the 27 cells around that point are looked at - one atom per lane;
+    //   * a single-precision screen with the pair's own limits (covalent radii + tolerance, max_dist), 2e-3 and
+    //     the rounding of the coordinates to spare: what fails it fails the bond test in every image;
+    //   * bond tests made once: the survivors are tested with the reference's arithmetic on the value
+    //     coordinates.  When no comparison of the test comes within `clear_min` of its threshold the outcome -
+    //     and the absence of a marginal comparison - is the same in whichever image the walk meets the pair:
+    //     the bonded ones are marked and the walk appends them without touching a coordinate, the others are
+    //     dropped (an unbonded candidate outside the supercell cuts nothing off a walk); a pair near a
+    //     threshold stays unmarked and is tested where it is met.
+    // A list is kept in (image, atom) order by insertion (a handful of entries).
     {
-        const double reach = fr.max_dist + 1e-3;
-        // one wave per heavy atom, lanes over the atoms of an image (coalesced reads); the hits of a
-        // pass keep their (image, atom) order through a ballot prefix
-        // lane i < 27 keeps the (widened) box of image i: one comparison pass per atom gives the
-        // set of images worth scanning
-        double bx0 = 0.0, bx1 = 0.0, by0 = 0.0, by1 = 0.0, bz0 = 0.0, bz1 = 0.0;
-        if (fr.rebuild && T::WSIZE >= 32 && T::lane() < 27) {
-            const PW_LDS double* b = &sh.box[6 * T::lane()];
-            bx0 = b[0] - reach; by0 = b[1] - reach; bz0 = b[2] - reach;
-            bx1 = b[3] + reach; by1 = b[4] + reach; bz1 = b[5] + reach;
-        }
-        // Atoms that follow each other in the input belong to the same molecule and lie together, so the
-        // atoms of an image are taken in blocks of 64 with a bounding box each (the boxes of the central
-        // image; an image's are those shifted by its lattice translation): a heavy atom is compared with
-        // the boxes first -- one box per lane -- and only the blocks it can have a neighbour in are scanned.
-        // A handful of blocks per atom instead of every atom of every image in reach; the hits keep their
-        // (image, atom) order because images, blocks and lanes are all taken in ascending order.
-        const int nblk = (n + 63) >> 6;
-        const size_t comp = fr.rebuild ? (size_t)27 * n : (size_t)n;
-        const float* X0 = WS.scan + (fr.rebuild ? (size_t)RB_CENTRAL * n : 0);
-        for (int b = T::wave(); b < nblk; b += T::NWAVES) {
-            float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-            const int qend = (b + 1) * 64 < n ? (b + 1) * 64 : n;
-            for (int q = b * 64 + T::lane(); q < qend; q += T::WSIZE)
-                for (int c = 0; c < 3; ++c) {
-                    const float v = X0[c * comp + q];
-                    lo[c] = v < lo[c] ? v : lo[c]; hi[c] = v > hi[c] ? v : hi[c];
-                }
-            for (int c = 0; c < 3; ++c) {
-                const double l = T::wave_min((double)lo[c]), h = -T::wave_min(-(double)hi[c]);
-                if (T::lane() == 0) { WS.blk[6 * b + c] = (float)l; WS.blk[6 * b + 3 + c] = (float)h; }
-            }
-        }
+        static_assert((size_t)RB_NB_CAP * T::SIZE * 4 <= (size_t)RB_CHUNK * RB_SEG_CAP * 8, "the lists are staged in the hit segments");
         if (fr.rebuild) {
             for (int i = tid; i < 27 * 3; i += T::SIZE) {
                 const int img = i / 3, c = i % 3;
                 sh.shift[i] = (float)(WS.S[3 * ((size_t)img * n) + c] - WS.S[3 * ((size_t)RB_CENTRAL * n) + c]);
             }
         }
-        T::sync();
-        for (int p = T::wave(); p < n; p += T::NWAVES) {
-            if (fr.terminal[p]) continue;
-            const double* C = fr.rebuild ? &WS.S[3 * ((size_t)RB_CENTRAL * n + p)] : &WS.V[3 * p];
-            double cx = C[0], cy = C[1], cz = C[2];
-            const float fcx = (float)cx, fcy = (float)cy, fcz = (float)cz;
-            // single precision moves a coordinate by at most 6e-8 of its size: the slack grows with it
-            const double reach_f = fr.max_dist + 2e-3 + 5e-7 * (pw_abs(cx) + pw_abs(cy) + pw_abs(cz));
-            const float reach2f = (float)(reach_f * reach_f);
-            const float reachb = (float)(reach_f + 1e-3 + 1e-6 * (pw_abs(cx) + pw_abs(cy) + pw_abs(cz)));   // (box test: shifts in single precision)
-            int cnt = 0;
-            unsigned long long images = 1ull << RB_CENTRAL;
-            if (fr.rebuild) {
-                if (T::WSIZE >= 32) {
-                    images = T::ballot(T::lane() < 27 && !(cx < bx0 || cx > bx1 || cy < by0 || cy > by1 ||
-                                                            cz < bz0 || cz > bz1));
-                } else {
-                    images = 0;
-                    for (int img = 0; img < 27; ++img) {
-                        const PW_LDS double* b = &sh.box[6 * img];
-                        if (!(cx < b[0] - reach || cx > b[3] + reach || cy < b[1] - reach || cy > b[4] + reach ||
-                              cz < b[2] - reach || cz > b[5] + reach))
-                            images |= 1ull << img;
-                    }
+        double amax = 0.0, lsum = 0.0;
+        for (int t = 0; t < T::NWAVES; ++t) amax = pw_max(amax, sh.red_v[4 + t]);
+        if (fr.rebuild) for (int i = 0; i < 9; ++i) lsum += pw_abs(fr.lattice[i]);
+        const double ext = amax + lsum + 1.0;       // no coordinate of the supercell is larger
+        // comparisons this far from their thresholds come out the same in every image: 1e-6 is where a
+        // comparison counts as marginal, 1e-7 covers the rounding of the value coordinates, the last term the
+        // rounding of scikit-learn's formula at the largest coordinates of the supercell
+        const double clear_min = 1.1e-6 + 6e-14 * ext * ext;
+        // single precision moves a coordinate by at most 6e-8 of its size (the atom's, the translation's, the
+        // shifted atom's): the slack of the screen grows with the supercell
+        const float slack = (float)(2e-3 + 1e-6 * ext);
+        const float reach = (float)fr.max_dist + slack;
+        // the grid: bounding box of the central image, cells of side >= reach, at most RB_NCELL of them
+        auto build = [&](auto X, auto ids, auto cs) __attribute__((always_inline)) {
+            float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+            for (int q = tid; q < n; q += T::SIZE)
+                for (int c = 0; c < 3; ++c) {
+                    const float v = X[4 * q + c];
+                    lo[c] = v < lo[c] ? v : lo[c]; hi[c] = v > hi[c] ? v : hi[c];
+                }
+            for (int c = 0; c < 3; ++c) {
+                const double l = T::wave_min((double)lo[c]), h = -T::wave_min(-(double)hi[c]);
+                if (T::lane() == 0) { sh.box[6 * T::wave() + c] = l; sh.box[6 * T::wave() + 3 + c] = h; }
+            }
+            for (int c = tid; c <= RB_NCELL + 1; c += T::SIZE) cs[c] = 0;
+            T::sync();
+            // every start atom is the remaining heavy atom closest to the pseudo origin (utilities.py:955-972):
+            // the distances do not change during the frame
+            {
+                const double ox = sh.origin[0], oy = sh.origin[1], oz = sh.origin[2];
+                const double oo = sq3(ox, oy, oz);
+                for (int q = tid; q < n; q += T::SIZE) WS.dorig[q] = rb_dist_sk(&WS.V[3 * q], WS.Vxx[q], ox, oy, oz, oo);
+            }
+            float g0[3], ginv, gh = reach + slack;
+            int gn[3];
+            for (int c = 0; c < 3; ++c) {
+                double l = sh.box[c], h = sh.box[3 + c];
+                for (int t = 1; t < T::NWAVES; ++t) { l = pw_min(l, sh.box[6 * t + c]); h = pw_max(h, sh.box[6 * t + 3 + c]); }
+                g0[c] = (float)l; hi[c] = (float)h;
+            }
+            long cells;
+            for (;;) {
+                ginv = 1.0f / gh;
+                cells = 1;
+                for (int c = 0; c < 3; ++c) {
+                    const float w_ = (hi[c] - g0[c]) * ginv;
+                    gn[c] = w_ < 1.0e6f ? (int)w_ + 1 : 1000000;
+                    cells *= gn[c];
+                }
+                if (cells <= RB_NCELL) break;
+                gh *= 1.26f;
+            }
+            auto cell_of = [&](float v, int c) { int i = (int)((v - g0[c]) * ginv); return i < 0 ? 0 : (i >= gn[c] ? gn[c] - 1 : i); };
+            // atoms per cell, first positions (cs[c + 1] holds the start of cell c until the atoms are dealt,
+            // its end - the start of cell c + 1 - afterwards), atoms by cell
+            for (int q = tid; q < n; q += T::SIZE) {
+                const int c = (cell_of(X[4 * q + 2], 2) * gn[1] + cell_of(X[4 * q + 1], 1)) * gn[0] + cell_of(X[4 * q], 0);
+                rb_atomic_add((int*)&cs[c + 2], 1);
+            }
+            T::sync();
+            if (T::wave() == 0) {
+                // inclusive scan of cs[2..]: cs[c + 2] = atoms in cells 0..c = start of cell c + 1
+                int run = 0;
+                for (int b0 = 0; b0 < (int)cells; b0 += T::WSIZE) {
+                    const int c = b0 + T::lane() + 2;
+                    int v = c <= (int)cells + 1 ? cs[c] : 0, incl = v;
+                    for (int d = 1; d < T::WSIZE; d <<= 1) { int t = T::shfl_up_i(incl, d); if (T::lane() >= d) incl += t; }
+                    if (c <= (int)cells + 1) cs[c] = run + incl;
+                    run += T::bcast_i(incl, T::WSIZE - 1);
                 }
             }
-            for (; images; images &= images - 1) {        // ascending image order
-                const int img = __builtin_ctzll(images);
-                // single-precision copies, one array per component: the test only has to be conservative
-                // (reach carries 2e-3 of slack, single precision moves a distance here by < 1e-4)
-                const float* X = WS.scan + (fr.rebuild ? (size_t)img * n : 0);
-                // the atom as the central image sees it from this image
-                const float sx = fr.rebuild ? sh.shift[3 * img] : 0.0f, sy = fr.rebuild ? sh.shift[3 * img + 1] : 0.0f,
-                            sz = fr.rebuild ? sh.shift[3 * img + 2] : 0.0f;
-                const float rx = fcx - sx, ry = fcy - sy, rz = fcz - sz;
-#if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-                ++rb_imgs;
-#endif
-                for (int g0 = 0; g0 < nblk; g0 += T::WSIZE) {
-                    const int bb = g0 + T::lane();
-                    bool pass = false;
-                    if (bb < nblk) {
-                        const float* B = WS.blk + 6 * bb;
-                        pass = !(rx < B[0] - reachb || rx > B[3] + reachb || ry < B[1] - reachb || ry > B[4] + reachb ||
-                                 rz < B[2] - reachb || rz > B[5] + reachb);
+            T::sync();
+            for (int q = tid; q < n; q += T::SIZE) {
+                const int c = (cell_of(X[4 * q + 2], 2) * gn[1] + cell_of(X[4 * q + 1], 1)) * gn[0] + cell_of(X[4 * q], 0);
+                const int pos = rb_atomic_add((int*)&cs[c + 1], 1);
+                ids[pos] = q;
+            }
+            T::sync();
+            // ---- one atom per lane ----
+            auto stage = [&](int e) -> decltype(auto) { return ((PW_LDS int*)seg)[e * T::SIZE + tid]; };
+            for (int p0 = 0; p0 < n; p0 += T::SIZE) {
+                const int p = p0 + tid;
+                const bool heavy = p < n && !fr.terminal[p];
+                int cnt = 0;
+                double cx = 0.0, cy = 0.0, cz = 0.0, rp = 0.0;
+                if (heavy) {
+                    const double* C = fr.rebuild ? &WS.S[3 * ((size_t)RB_CENTRAL * n + p)] : &WS.V[3 * p];
+                    cx = C[0]; cy = C[1]; cz = C[2]; rp = fr.cov[p];
+                }
+                const float fcx = (float)cx, fcy = (float)cy, fcz = (float)cz, frp = (float)rp;
+                const double pp = sq3(cx, cy, cz);
+                for (int img = 0; img < (fr.rebuild ? 27 : 1); ++img) {
+                    const int im = fr.rebuild ? img : RB_CENTRAL;
+                    // the atom as the central image sees it from this image
+                    const float r[3] = {fcx - (fr.rebuild ? sh.shift[3 * img] : 0.0f), fcy - (fr.rebuild ? sh.shift[3 * img + 1] : 0.0f),
+                                        fcz - (fr.rebuild ? sh.shift[3 * img + 2] : 0.0f)};
+                    int c0[3], c1[3];
+                    bool act = heavy;
+                    for (int c = 0; c < 3; ++c) {
+                        const float f = (r[c] - g0[c]) * ginv;
+                        // (a point a whole cell or more outside the grid has no neighbour in it)
+                        if (!(f > -1.0f && f < (float)gn[c] + 1.0f)) { act = false; c0[c] = 0; c1[c] = -1; continue; }
+                        const int i = (int)(f + 1.0f) - 1;              // floor for f > -1
+                        c0[c] = i - 1 < 0 ? 0 : i - 1;
+                        c1[c] = i + 1 >= gn[c] ? gn[c] - 1 : i + 1;
                     }
-                    unsigned long long bm = T::ballot(pass);
-                    if (T::WSIZE < 64) {
-                        // a narrow team (the host build's one lane): block after block, position after position
-                        for (; bm; bm &= bm - 1) {
-                            const int blk = g0 + __builtin_ctzll(bm);
-                            for (int l1 = 0; l1 < 64; l1 += T::WSIZE) {
-                                const int q = blk * 64 + l1 + T::lane();
-                                bool h = false;
-                                if (q < n) {
-                                    float dx = X[q] - fcx, dy = X[comp + q] - fcy, dz = X[2 * comp + q] - fcz;
-                                    h = dx * dx + dy * dy + dz * dz < reach2f && !(img == RB_CENTRAL && q == p);
-                                }
-                                const unsigned long long bal = T::ballot(h);
-                                if (bal) {
-                                    int pos = cnt + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
-                                    if (h && pos < RB_NB_CAP) WS.nb[(size_t)p * RB_NB_CAP + pos] = img * n + q;
-                                    cnt += __builtin_popcountll(bal);
-                                }
+                    if (!T::wave_any(act)) continue;
+                    if (!act) continue;
+                    for (int iz = c0[2]; iz <= c1[2]; ++iz)
+                        for (int iy = c0[1]; iy <= c1[1]; ++iy) {
+                            const int row = (iz * gn[1] + iy) * gn[0];
+                            const int k0 = cs[row + c0[0]], k1 = cs[row + c1[0] + 1];
+                            for (int k = k0; k < k1; ++k) {
+                                const int q = ids[k];
+                                const float qx = X[4 * q], qy = X[4 * q + 1], qz = X[4 * q + 2], qr = X[4 * q + 3];
+                                const float dx = qx - r[0], dy = qy - r[1], dz = qz - r[2];
+                                const float d2 = dx * dx + dy * dy + dz * dz;
+                                // the screen: inside (0.1, max_dist) and inside (Rcov sum -+ tol), generously
+                                const float hi_f = frp + qr + (float)fr.tol + slack;
+                                float lo_f = frp + qr - (float)fr.tol - slack;
+                                lo_f = lo_f > 0.1f - slack ? lo_f : 0.1f - slack;
+                                lo_f = lo_f > 0.0f ? lo_f : 0.0f;
+                                const float up = hi_f < reach ? hi_f : reach;
+                                if (!(d2 < up * up && d2 > lo_f * lo_f) || (im == RB_CENTRAL && q == p)) continue;
+                                if (cnt < RB_NB_CAP) stage(cnt) = im * n + q;
+                                ++cnt;
                             }
                         }
-                        continue;
-                    }
-                    while (bm) {
-#if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-                        ++rb_rounds;
-#endif
-                        // up to four blocks with their loads in flight together, one atom per lane
-                        constexpr int UN = 4;
-                        int blk[UN];
-#pragma unroll
-                        for (int u = 0; u < UN; ++u) {
-                            blk[u] = bm ? g0 + __builtin_ctzll(bm) : -1;
-                            bm &= bm - 1;
-                        }
-                        bool hit[UN];
-                        float vx[UN], vy[UN], vz[UN];
-#pragma unroll
-                        for (int u = 0; u < UN; ++u) {
-                            int q = (blk[u] < 0 ? 0 : blk[u] * 64) + T::lane();
-                            int qq = q < n ? q : n - 1;
-                            vx[u] = X[qq]; vy[u] = X[comp + qq]; vz[u] = X[2 * comp + qq];
-                        }
-#pragma unroll
-                        for (int u = 0; u < UN; ++u) {
-                            int q = blk[u] * 64 + T::lane();
-                            float dx = vx[u] - fcx, dy = vy[u] - fcy, dz = vz[u] - fcz;
-                            float d2 = dx * dx + dy * dy + dz * dz;
-                            hit[u] = blk[u] >= 0 && q < n && d2 < reach2f && !(img == RB_CENTRAL && q == p);
-                        }
-#pragma unroll
-                        for (int u = 0; u < UN; ++u) {
-                            unsigned long long bal = T::ballot(hit[u]);
-                            if (bal) {
-                                int q = blk[u] * 64 + T::lane();
-                                int pos = cnt + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
-                                if (hit[u] && pos < RB_NB_CAP) WS.nb[(size_t)p * RB_NB_CAP + pos] = img * n + q;
-                                cnt += __builtin_popcountll(bal);
-                            }
-                        }
-                    }
+                }
+                // the reference's test on the value coordinates of the survivors (entry e of every lane at the
+                // same time: the loads of a round are in flight together), kept in (image, atom) order
+                const int m = cnt < RB_NB_CAP ? cnt : RB_NB_CAP;
+                int kept = 0;
+                for (int e = 0; e < m; ++e) {
+                    const int key = stage(e);
+                    const int img = key / n, q = key - img * n;
+                    const double* Xc = fr.rebuild ? &WS.S[3 * ((size_t)img * n + q)] : &WS.V[3 * q];
+                    const double rc = rp + fr.cov[q];
+                    double clearance;
+                    const bool hit = rb_bond(Xc[0], Xc[1], Xc[2], cx, cy, cz, pp, rc - fr.tol, rc + fr.tol, fr.max_dist,
+                                             &clearance);
+                    const bool clear = clearance >= clear_min;
+                    if (!hit && clear) continue;
+                    const int val = key | (clear ? RB_NB_CLEAR : 0) | (hit ? RB_NB_BONDED : 0);
+                    int k = kept;
+                    while (k > 0 && (stage(k - 1) & RB_NB_MASK) > key) { stage(k) = stage(k - 1); --k; }
+                    stage(k) = val;
+                    ++kept;
+                }
+                if (heavy) {
+                    for (int e = 0; e < kept; ++e) WS.nb[(size_t)p * RB_NB_CAP + e] = stage(e);
+                    WS.nb_cnt[p] = kept;
+                    if (cnt > RB_NB_CAP) rb_atomic_or(&w.status, RB_ST_NB_OVERFLOW);
                 }
             }
-            if (T::lane() == 0) {
-                WS.nb_cnt[p] = cnt;
-                if (cnt > RB_NB_CAP) rb_atomic_or(&w.status, RB_ST_NB_OVERFLOW);
-            }
-        }
+        };
+        if (WS.scan_fast) build((const PW_LDS float*)WS.scan, (PW_LDS int*)WS.grid_ids, (PW_LDS int*)WS.grid_start);
+        else build((const float*)WS.scan, WS.grid_ids, WS.grid_start);
     }
     T::sync();
     RB_TICK(2);
@@ -609,13 +666,11 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
     for (;;) {
         // start: the remaining heavy atom closest to the pseudo origin (utilities.py:955-972)
         {
-            double ox = sh.origin[0], oy = sh.origin[1], oz = sh.origin[2];
-            double oo = sq3(ox, oy, oz);
             double best = PW_INF;
             int bi = -1;
             for (int q = tid; q < n; q += T::SIZE) {
                 if (!WS.remaining[q] || fr.terminal[q]) continue;
-                double d = rb_dist_sk(&WS.V[3 * q], WS.Vxx[q], ox, oy, oz, oo);
+                double d = WS.dorig[q];
                 if (d < best || bi < 0) { best = d; bi = q; }
             }
             if (bi < 0) { best = PW_INF; bi = 0x7fffffff; }

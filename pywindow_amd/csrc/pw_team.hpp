@@ -36,6 +36,7 @@ struct HostTeam {
     PW_HD static double bcast(double v, int /*src_lane*/) { return v; }
     PW_HD static double bcast_u(double v, int /*uniform_src_lane*/) { return v; }
     PW_HD static int bcast_i(int v, int /*src_lane*/) { return v; }
+    PW_HD static int shfl_up_i(int v, int /*delta*/) { return v; }
 };
 
 #if defined(__HIPCC__)
@@ -147,6 +148,7 @@ struct DeviceTeam {
     // source lane known to be the same in every lane: v_readlane, no LDS crossbar
     __device__ static double bcast_u(double v, int src) { return lane_d(v, __builtin_amdgcn_readfirstlane(src)); }
     __device__ static int bcast_i(int v, int src) { return __shfl(v, src, 64); }
+    __device__ static int shfl_up_i(int v, int delta) { return __shfl_up(v, delta, 64); }
 };
 // A ROW of 16 lanes as a team: four of them share a wavefront, each running its own optimiser chain
 // (pw_row_chains_kernel).  Only what pw_lbfgsb.hpp asks of a team: lane numbering, a lane-to-lane move with a

@@ -14,11 +14,12 @@ extern "C" int hs_discrete_molecules(int n, const double* xyz, const double* lat
     if (!base) return -5;
     memset(base, 0, bytes);
     RebuildWs* w = RebuildWs::carve(base, n, rebuild, 1);
-    size_t fb = RebuildWs::fast_bytes(n, rebuild, with_bits != 0);
+    // with_bits: bit 0 = the visit bit sets, bit 1 = the scan coordinates in "team-shared" memory
+    size_t fb = RebuildWs::fast_bytes(n, rebuild, (with_bits & 1) != 0, (with_bits & 2) != 0);
     unsigned char* fast = (unsigned char*)aligned_alloc(64, (fb + 63) & ~(size_t)63);
     if (!fast) { free(base); return -5; }
     memset(fast, 0xff, fb);                     // the kernel must not rely on zeroed team-shared memory
-    w->attach_fast(fast, n, rebuild, with_bits != 0);
+    w->attach_fast(fast, n, rebuild, (with_bits & 1) != 0, (with_bits & 2) != 0);
     RebuildFrame fr;
     fr.n = n; fr.periodic = lattice != nullptr; fr.rebuild = rebuild;
     fr.xyz = xyz; fr.lattice = lattice; fr.lattice_inv = lattice_inv;

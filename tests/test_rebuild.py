@@ -88,7 +88,7 @@ def run_hostsim(hostsim, system, rebuild, with_bits=True):
         topo.terminal.ctypes.data_as(vp), ctypes.c_double(topo.max_dist), ctypes.c_double(topo.tol),
         ctypes.c_int(1 if rebuild else 0), ctypes.c_int(cap), ctypes.c_int(cap), ctypes.byref(n_mol),
         ctypes.byref(status), off.ctypes.data_as(vp), src.ctypes.data_as(vp), img.ctypes.data_as(vp),
-        oxyz.ctypes.data_as(vp), ctypes.c_int(1 if with_bits else 0))
+        oxyz.ctypes.data_as(vp), ctypes.c_int(int(with_bits)))
     assert rc == 0
     return RB.molecules_from_output(system, n_mol.value, off, src, oxyz), status.value
 
@@ -104,6 +104,9 @@ def test_host_team_matches_reference(hostsim, name):
         assert status == 0
         check_molecules(mols, expect, "rebuild", f"hostsim/{name}/rebuild")
         # cells too large for the visit bit sets in team-shared memory use the stamp arrays
+        mols, status = run_hostsim(hostsim, system, True, with_bits=3)      # + scan coordinates in fast memory
+        assert status == 0
+        check_molecules(mols, expect, "rebuild", f"hostsim/{name}/rebuild/fast-scan")
         mols, status = run_hostsim(hostsim, system, True, with_bits=False)
         assert status == 0
         check_molecules(mols, expect, "rebuild", f"hostsim/{name}/rebuild/stamps")
