@@ -528,7 +528,7 @@ def main():
             "config": {"workload": "CC3 1000-frame synthetic DL_POLY trajectory (BASELINE configs[1]), "
                                    "per-frame pore+windows, 168 atoms/frame",
                        "frames_per_gpu": args.frames, "stages": "all", "results_ok": ok,
-                       "successive_steps_overlap": bool(ctx.pipelined), "pipelined": bool(ctx.pipelined),
+                       "successive_steps_overlap": bool(ctx.pipelined), "pipelined": bool(ctx.pipelined), "gate_timeouts": ctx.gate_timeouts,
                        "single_step_latency_ms": single_ms,
                        "windows_eq_4": int((out["n_windows"] == 4).sum()),
                        "ms_per_step_by_rank": {"min": 1e3 * min(weak_per_rank) / args.steps,

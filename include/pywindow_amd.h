@@ -191,6 +191,10 @@ int64_t pw_context_extra_windows(pw_context *ctx, pw_extra_window *buf, int64_t 
  * environment BEFORE the process first initialises HIP; pw_context_create measures whether they do and
  * falls back (with a line on stderr) instead of letting gate kernels wait for launches queued behind them */
 int pw_context_pipelined(pw_context *ctx);
+/* diagnostic: how many pacing gates of the pipeline gave up waiting since the context was created (tail gates |
+ * head gates << 16 | residency gates << 32).  A gate is never a dependency - a time-out costs 20 ms (2 s for a
+ * residency gate) and changes no result; zero on a healthy device. */
+int pw_context_gate_timeouts(pw_context *ctx, uint64_t *count);
 /* sampling vectors the team workspaces of this context currently hold per molecule (>= PW_P_MAX) */
 int pw_context_point_capacity(pw_context *ctx);
 

@@ -221,6 +221,7 @@ EXPORTED_SYMBOLS = [
     "pw_context_extra_windows",
     "pw_context_point_capacity",
     "pw_context_pipelined",
+    "pw_context_gate_timeouts",
     "pw_analysis_debug",
     "pw_point_gaps",
     "pw_pairwise_sum",
@@ -319,6 +320,7 @@ def load():
     L.pw_context_extra_windows.restype = ctypes.c_int64
     L.pw_context_point_capacity.argtypes = [vp]
     L.pw_context_pipelined.argtypes = [vp]
+    L.pw_context_gate_timeouts.argtypes = [vp, vp]
     L.pw_point_gaps.argtypes = [vp, ctypes.POINTER(BatchIn), vp, vp, ctypes.c_int64, vp, vp]
     L.pw_pairwise_sum.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int, vp]
     L.pw_dbscan.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, vp, vp]
@@ -466,6 +468,14 @@ class Context:
         """Whether analyses run as the overlapped pipeline (needs ``GPU_MAX_HW_QUEUES`` >= 10 exported before
         the process first initialised HIP; measured at context creation) or as single launches."""
         return bool(load().pw_context_pipelined(self._h))
+
+    @property
+    def gate_timeouts(self) -> dict:
+        """Diagnostic: pacing gates of the pipeline that gave up waiting since the context was created (a gate is
+        never a dependency: 20 ms lost, no result changed).  All zero on a healthy device."""
+        v = ctypes.c_uint64(0)
+        _check(load().pw_context_gate_timeouts(self._h, ctypes.byref(v)), "pw_context_gate_timeouts")
+        return {"tail": int(v.value & 0xffff), "head": int((v.value >> 16) & 0xffff), "residency": int(v.value >> 32)}
 
     @property
     def point_capacity(self) -> int:

@@ -342,35 +342,36 @@ pw_row_chains_kernel(long n_units, const long* __restrict__ atom_offset, const d
 // Gate: one wave, no LDS.  Holds the stream it is launched on until every team of the
 // optimiser launch is resident, so that launches queued behind it cannot take the LDS those
 // teams need.  It can never block them itself, and its wait is bounded.
-__global__ void pw_gate_kernel(UnitQueue* queue, int expected) {
+__global__ void pw_gate_kernel(UnitQueue* queue, int expected, unsigned long long* timeouts) {
     if (threadIdx.x != 0) return;
     long long t0 = wall_clock64();
     while (__hip_atomic_load(&queue->started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
         __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t0 > 200000000ll) break;   // 2 s
+        if (wall_clock64() - t0 > 200000000ll) { atomicAdd(timeouts, 1ull << 32); break; }   // 2 s
     }
 }
 
 // Tail gate: holds the optimiser launch of analysis k+1 until all but the slowest few chains
 // of analysis k have been published, so that the two launches overlap only where the older one
 // leaves most SIMDs idle.  One wave, bounded wait.
-__global__ void pw_tail_gate_kernel(const UnitQueue* prev, unsigned long long need) {
+__global__ void pw_tail_gate_kernel(const UnitQueue* prev, unsigned long long need, unsigned long long* timeouts) {
     if (threadIdx.x != 0) return;
     long long t0 = wall_clock64();
     while (__hip_atomic_load(&prev->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
         __builtin_amdgcn_s_sleep(32);
-        if (wall_clock64() - t0 > 2000000ll) break;     // 20 ms: only an optimisation, never a dependency
+        // 20 ms: only an optimisation, never a dependency (counted: pw_context_gate_timeouts)
+        if (wall_clock64() - t0 > 2000000ll) { atomicAdd(timeouts, 1ull); break; }
     }
 }
 
 // The same for the window launch: analysis k+1's consumers start when all but the last few
 // units of analysis k have been TAKEN by a team (its queue head has advanced that far).
-__global__ void pw_head_gate_kernel(const UnitQueue* prev, unsigned long long need) {
+__global__ void pw_head_gate_kernel(const UnitQueue* prev, unsigned long long need, unsigned long long* timeouts) {
     if (threadIdx.x != 0) return;
     long long t0 = wall_clock64();
     while (__hip_atomic_load(&prev->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
         __builtin_amdgcn_s_sleep(32);
-        if (wall_clock64() - t0 > 2000000ll) break;     // 20 ms: only an optimisation, never a dependency
+        if (wall_clock64() - t0 > 2000000ll) { atomicAdd(timeouts, 1ull << 16); break; }     // 20 ms, as above
     }
 }
 
@@ -877,7 +878,8 @@ int pw_context_create(int device, pw_context** out) {
     c->n_cu = prop.multiProcessorCount;
     c->lds_per_cu = 160 * 1024;
     CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CTX_TRY(hipMalloc((void**)&c->counter, (4 * PW_SETS + 2) * sizeof(unsigned long long)));      // per set: chains | windows | average | basic; + 2 for single launches
+    CTX_TRY(hipMalloc((void**)&c->counter, (4 * PW_SETS + 3) * sizeof(unsigned long long)));      // per set: chains | windows | average | basic; + 2 for single launches; + the gates' time-outs
+    CTX_TRY(hipMemset(c->counter, 0, (4 * PW_SETS + 3) * sizeof(unsigned long long)));
     CTX_TRY(hipMalloc((void**)&c->queue, PW_SETS * sizeof(UnitQueue)));
     CTX_TRY(hipMemset(c->queue, 0, PW_SETS * sizeof(UnitQueue)));
     c->flip = -1;
@@ -1397,7 +1399,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     const bool have_prev = p >= 0 && p != b && c->done_valid[p] && c->last_units[p] > 0 && same_batch;
     if (c->tail_pct > 0 && have_prev) {
         unsigned long long need = (unsigned long long)((c->last_units[p] * c->tail_pct) / 100);
-        hipLaunchKernelGGL(pw_tail_gate_kernel, dim3(1), dim3(64), 0, c->prod, c->queue + p, need);
+        hipLaunchKernelGGL(pw_tail_gate_kernel, dim3(1), dim3(64), 0, c->prod, c->queue + p, need, c->counter + 4 * PW_SETS + 2);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_tail[b], c->prod));
         c->tail_valid[b] = 1;
@@ -1432,7 +1434,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     HIP_TRY(hipEventRecord(c->ev_prod[b], c->prod));
     hipStream_t cs = c->cons[b];
     HIP_TRY(hipStreamWaitEvent(cs, c->ev_reset[b], 0));
-    hipLaunchKernelGGL(pw_gate_kernel, dim3(1), dim3(64), 0, cs, c->cur_queue, rows ? row_grid : pa.grid);
+    hipLaunchKernelGGL(pw_gate_kernel, dim3(1), dim3(64), 0, cs, c->cur_queue, rows ? row_grid : pa.grid, c->counter + 4 * PW_SETS + 2);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_gate[b], cs));
     c->head_valid[b] = 0;
@@ -1440,7 +1442,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         if (c->head_pct > 0) {
             // start beside the tail of the previous window launch, not behind it
             unsigned long long need_h = (unsigned long long)((c->last_units[p] * c->head_pct) / 100);
-            hipLaunchKernelGGL(pw_head_gate_kernel, dim3(1), dim3(64), 0, cs, c->queue + p, need_h);
+            hipLaunchKernelGGL(pw_head_gate_kernel, dim3(1), dim3(64), 0, cs, c->queue + p, need_h, c->counter + 4 * PW_SETS + 2);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev_head[b], cs));
             c->head_valid[b] = 1;
@@ -1743,6 +1745,20 @@ void pw_resident_free(pw_context* c, pw_resident* r) {
     for (int k = 0; k < PW_SETS; ++k)
         if (r->ev_read[k]) (void)hipEventDestroy(r->ev_read[k]);
     delete r;
+}
+
+// How many of the pipeline's pacing gates gave up waiting since the context was created (tail | head << 16 |
+// residency << 32).  A gate only paces launches, it is never a dependency: a time-out costs 20 ms and nothing else.
+// Diagnostic: zero on a healthy device.
+int pw_context_gate_timeouts(pw_context* c, uint64_t* count) {
+    if (!c || !count) return PW_E_BAD_ARG;
+    *count = 0;
+    if (c->device < 0 || !c->counter) return PW_OK;
+    PW_ON_DEVICE(c->device);
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpy(&v, c->counter + 4 * PW_SETS + 2, sizeof(v), hipMemcpyDeviceToHost));
+    *count = (uint64_t)v;
+    return PW_OK;
 }
 
 void* pw_resident_device_results(pw_resident* r) { return r ? (r->host ? (void*)r->host->out.data() : (void*)r->d_out) : nullptr; }

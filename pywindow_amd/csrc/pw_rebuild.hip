@@ -121,7 +121,7 @@ struct DeviceCells {
 };
 
 bool args_ok(pw_context* ctx, const pw_cell_in* in) {
-    return ctx && in && in->n_frames >= 0 && in->n_atoms > 0 && in->xyz && in->cov && in->mass && in->terminal;
+    return ctx && in && in->n_frames >= 0 && in->n_atoms > 0 && in->n_atoms < (1 << RB_NB_IMG_SHIFT) && in->xyz && in->cov && in->mass && in->terminal;
 }
 
 // upload the frames, run the rebuild kernel; outputs stay on the device

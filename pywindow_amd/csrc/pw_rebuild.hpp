@@ -41,11 +41,13 @@ constexpr int RB_WF_TRUNCATED = 1;  // a neighbour candidate lay outside the 3x3
 constexpr int RB_WF_MARGINAL = 2;   // a distance within 1e-6 of a threshold of the bond test
 constexpr int RB_WF_REPEAT = 4;     // the same atom met in two images (or twice by value): not a finite molecule
 constexpr int RB_CENTRAL = 13;     // image (0,0,0) in the a,b,c-nested 3x3x3 enumeration
-// a candidate entry: image * n + atom, plus the outcome of the bond test when it cannot depend on the image
+// a candidate entry: (image, atom), plus the outcome of the bond test when it cannot depend on the image
 // the pair is met in (see "bond tests made once")
 constexpr int RB_NB_CLEAR = 1 << 30;
 constexpr int RB_NB_BONDED = 1 << 29;
 constexpr int RB_NB_MASK = RB_NB_BONDED - 1;
+constexpr int RB_NB_IMG_SHIFT = 24;            // entry = flags | image << 24 | atom  (n < 2^24)
+constexpr int RB_NB_Q_MASK = (1 << RB_NB_IMG_SHIFT) - 1;
 
 // status bits of one frame (pw_cell_out.status)
 constexpr int RB_ST_NB_OVERFLOW = 1;      // > RB_NB_CAP candidates around one atom
@@ -184,14 +186,17 @@ struct RebuildWs {
     int* cage_rng;        // n + 1: lowest and highest image offset per axis (2 bits each)
     double* cage_f;       // (n + 1) x 3: fractional centre of mass of that walk's molecule
     double* dorig;        // n: distance of every cell atom to the pseudo origin (the start atoms are its arg-minima)
+    int* csr;             // n + 1 offsets, then the candidate lists one after the other (when team-shared memory
+                          // cannot hold them)
     int status, n_mol, n_out;
+    double inv_n;         // 1 / n
 
     PW_HD static size_t ids(int n, int rebuild) { return rebuild ? (size_t)28 * n : (size_t)n; }
     PW_HD static size_t bytes(int n, int rebuild, int team) {
         size_t id = ids(n, rebuild);
         (void)team;
         size_t d = (size_t)3 * n + n + (rebuild ? (size_t)81 * n : 0) + id + 3 * ((size_t)n + 1) + n;
-        size_t i = (size_t)n + (size_t)n * RB_NB_CAP + 5 * id + 2 * ((size_t)n + 1);
+        size_t i = (size_t)n + 2 * (size_t)n * RB_NB_CAP + 5 * id + 3 * ((size_t)n + 1);
         return sizeof(RebuildWs) + 64 + d * 8 + i * 4 + 4 * (size_t)n + 64 + 64 +
                scan_bytes(n) + 64;
     }
@@ -241,6 +246,7 @@ struct RebuildWs {
         w->dorig = (double*)p; p += (size_t)n * 8;
         w->nb_cnt = (int*)p; p += (size_t)n * 4;
         w->nb = (int*)p; p += (size_t)n * RB_NB_CAP * 4;
+        w->csr = (int*)p; p += ((size_t)n * RB_NB_CAP + n + 1) * 4;
         w->stamp_final = (int*)p; p += id * 4;
         w->stamp_temp = (int*)p; p += id * 4;
         w->work = (int*)p; p += id * 4;
@@ -255,6 +261,7 @@ struct RebuildWs {
         p = (unsigned char*)(((size_t)p + 63) & ~(size_t)63);
         w->attach_scan(p, n);
         w->scan_fast = 0;
+        w->inv_n = 1.0 / (double)n;
         return w;
     }
 };
@@ -289,7 +296,11 @@ PW_HD inline void rb_decode(const RebuildWs& w, int n, int id, int* q, int* ax, 
         *q = id; *ax = *ay = *az = 0; *pos = &w.V[3 * id];
     } else {
         int s = id - n;
-        int img = s / n;
+        // s / n without an integer division (a long instruction sequence here): the quotient of the doubles is
+        // at most one off
+        int img = (int)((double)s * w.inv_n);
+        if ((img + 1) * n <= s) ++img;
+        else if (img * n > s) --img;
         *q = s - img * n;
         *ax = img / 9 - 1; *ay = (img / 3) % 3 - 1; *az = img % 3 - 1;
         *pos = &w.S[3 * (size_t)s];
@@ -298,8 +309,8 @@ PW_HD inline void rb_decode(const RebuildWs& w, int n, int id, int* q, int* ax, 
 
 // one wave expands one atom of the current layer: lanes over its candidate list
 template <class T>
-PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, int* status, int* wflags, int id, int slot,
-                            long long* xprof = nullptr) {
+PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, const int* nb_off, const int* nb_ent,
+                            int* status, int* wflags, int id, int slot, long long* xprof = nullptr) {
 #if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     long long xt = wall_clock64();
 #define RB_XT(k) do { if (xprof && T::lane() == 0) { long long t_ = wall_clock64(); xprof[k] += t_ - xt; xt = t_; } } while (0)
@@ -312,24 +323,18 @@ PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, int* sta
     int q0, ax, ay, az;
     const double* P;
     rb_decode(w, n, id, &q0, &ax, &ay, &az, &P);
-    // everything that depends on q0 only is requested at once (one memory round trip, not four)
-    const unsigned char term0 = fr.terminal[q0];
-    const double ri = fr.cov[q0];
-    const int cnt0 = w.nb_cnt[q0];
-    const int first = w.nb[(size_t)q0 * RB_NB_CAP + (T::lane() < RB_NB_CAP ? T::lane() : 0)];
-    const double px = P[0], py = P[1], pz = P[2];
+    // the atom's list (empty for the elements the walk does not expand: their lists were never built)
+    const int beg = nb_off[q0], cnt = nb_off[q0 + 1] - beg;
+    const int first = T::lane() < cnt ? nb_ent[beg + T::lane()] : 0;
     RB_XT(0);
-    if (term0) return;
-    const double pp = sq3(px, py, pz);
-    const int cnt = cnt0 < RB_NB_CAP ? cnt0 : RB_NB_CAP;
+    if (cnt == 0) return;
     for (int e = T::lane(); e < cnt; e += T::WSIZE) {
-        int packed = e == T::lane() ? first : w.nb[(size_t)q0 * RB_NB_CAP + e];
+        int packed = e == T::lane() ? first : nb_ent[beg + e];
         // bond tests made once: the candidate scan has already tested this pair in the central image; when
         // no comparison came near a threshold the outcome is the same in whichever image the walk meets it
         const bool clear = (packed & RB_NB_CLEAR) != 0, bonded = (packed & RB_NB_BONDED) != 0;
-        packed &= RB_NB_MASK;
-        int dimg = packed / n;
-        int q = packed - dimg * n;
+        const int dimg = (packed >> RB_NB_IMG_SHIFT) & 31;
+        const int q = packed & RB_NB_Q_MASK;
         int bx = ax + dimg / 9 - 1, by = ay + (dimg / 3) % 3 - 1, bz = az + dimg % 3 - 1;
         bool central = bx == 0 && by == 0 && bz == 0;
         const bool outside = bx < -1 || bx > 1 || by < -1 || by > 1 || bz < -1 || bz > 1;
@@ -353,10 +358,13 @@ PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, int* sta
             const long long key = as_cell ? (((long long)q << 32) | (unsigned)q)
                                           : (((long long)(n + s1) << 32) | (unsigned)(same_item ? q : n + s1));
             if (!clear) {
+                // (rare: a comparison of this pair's bond test is too close to its threshold to be made once)
                 const double* X = as_cell ? &w.V[3 * q] : &w.S[3 * (size_t)s1];
                 const double x0 = X[0], x1 = X[1], x2 = X[2];
+                const double px = P[0], py = P[1], pz = P[2];
+                const double pp = sq3(px, py, pz);
                 RB_XT(2);
-                const double rc = ri + fr.cov[q];
+                const double rc = fr.cov[q0] + fr.cov[q];
                 double clearance;
                 const bool hit = rb_bond(x0, x1, x2, px, py, pz, pp, rc - fr.tol, rc + fr.tol, fr.max_dist, &clearance);
                 if (clearance < 1e-6) rb_atomic_or(wflags, RB_WF_MARGINAL);
@@ -370,6 +378,173 @@ PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, int* sta
     }
     RB_XT(4);
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// One wavefront walks one molecule.  The layers of a molecule are a few atoms wide, and a layer handled by the
+// whole team costs two team barriers whatever its width; here the four phases of a layer - the layer's atoms
+// join the molecule, their lists are expanded, the hits are merged in list order into the next layer, the
+// layer's atoms leave the atom list (utilities.py:982-1055) - run in one wave, ordered by nothing more than
+// the wave's own LDS queue:
+//   * expansion: the list entries of up to 64 atoms of the layer are dealt one per lane (prefix sum of the list
+//     lengths; at most 64 entries per pass).  An entry's hits need no sorting: a list is in (image, atom) order,
+//     which is the order of the reference's supercell scan whatever image the atom sits in, and the remaining
+//     cell atoms - scanned first by the reference - are one run of it (the central image), so the hits of an
+//     atom are its cell hits followed by its image hits, each in list order: positions by ballots;
+//   * merge: one hit per lane - first occurrence by lane-to-lane comparison, "seen in this layer" and "in the
+//     molecule" from the bit sets, positions in the next layer from a ballot.
+// Returns the number of layers.  Needs the visit bit sets (and the atom list) in team-shared memory.
+template <class T, class LISTP>
+__device__ inline int rb_wave_walk(const RebuildFrame& fr, const RebuildWs& WS, LISTP nb_off, LISTP nb_ent, int start) {
+    PW_LDS RebuildShared& sh = *(PW_LDS RebuildShared*)WS.sh;
+    PW_LDS unsigned long long* const bits_final = (PW_LDS unsigned long long*)WS.bits_final;
+    PW_LDS unsigned long long* const bits_temp = (PW_LDS unsigned long long*)WS.bits_temp;
+    PW_LDS int* const hits = (PW_LDS int*)WS.seg;
+    PW_LDS unsigned char* const remaining = (PW_LDS unsigned char*)WS.remaining;
+    const PW_LDS unsigned char* const alias = (const PW_LDS unsigned char*)WS.alias;
+    int* work = WS.work;
+    int* work_next = WS.work_next;
+    const int n = fr.n, lane = T::lane();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int cur = 0, nw = 1, nf = 0, layers = 0;
+    if (lane == 0) sh.lwork[0][0] = start;
+    T::wave_sync();
+    while (nw > 0) {
+        const PW_LDS int* wl = sh.lwork[cur];
+        PW_LDS int* wn = sh.lwork[cur ^ 1];
+        auto LW = [&](int k) { return k < RB_LWORK ? wl[k] : work[k]; };
+        for (int k = lane; k < nw; k += 64) {
+            const int id = LW(k);
+            if (nf + k < RB_LFINAL) sh.lfinal[nf + k] = id;
+            else WS.final_[nf + k] = id;
+            atomicOr((unsigned long long*)&bits_final[id >> 6], 1ull << (id & 63));
+        }
+        for (int i = lane; i < WS.bit_words; i += 64) bits_temp[i] = 0;
+        T::wave_sync();
+        int nn = 0;
+        for (int a0 = 0; a0 < nw;) {
+            // lane k: atom a0 + k of the layer
+            const int ka = a0 + lane;
+            const bool va = ka < nw;
+            int id0 = 0, q0 = 0, ax = 0, ay = 0, az = 0, beg = 0, cnt = 0;
+            if (va) {
+                const double* P;
+                id0 = LW(ka);
+                rb_decode(WS, n, id0, &q0, &ax, &ay, &az, &P);
+                beg = nb_off[q0];
+                cnt = nb_off[q0 + 1] - beg;
+            }
+            const int incl = T::incl_scan_i(cnt);
+            // the atoms whose entries fit this pass (a list has at most RB_NB_CAP entries: never none)
+            const int na = __popcll(__ballot(va && incl <= 64));
+            const int E = __shfl(incl, na - 1);
+            // lane l: entry l of the pass; its atom
+            int j = 0;
+            for (int k = 0; k < na; ++k) j += (__builtin_amdgcn_readlane(incl, k) <= lane) ? 1 : 0;
+            const bool ve = lane < E;
+            const int jj = ve ? j : 0;
+            const int j_incl = __shfl(incl, jj), j_cnt = __shfl(cnt, jj), j_beg = __shfl(beg, jj);
+            const int j_q0 = __shfl(q0, jj), j_id = __shfl(id0, jj);
+            const int j_a = __shfl((ax + 1) | ((ay + 1) << 2) | ((az + 1) << 4), jj);
+            const int j_excl = j_incl - j_cnt;
+            bool cell_hit = false, img_hit = false;
+            int cell_id = 0, img_id = 0;
+            if (ve) {
+                const int packed = nb_ent[j_beg + (lane - j_excl)];
+                const bool clear = (packed & RB_NB_CLEAR) != 0, bonded = (packed & RB_NB_BONDED) != 0;
+                const int dimg = (packed >> RB_NB_IMG_SHIFT) & 31;
+                const int q = packed & RB_NB_Q_MASK;
+                const int bx = (j_a & 3) - 1 + dimg / 9 - 1, by = ((j_a >> 2) & 3) - 1 + (dimg / 3) % 3 - 1,
+                          bz = ((j_a >> 4) & 3) - 1 + dimg % 3 - 1;
+                const bool central = bx == 0 && by == 0 && bz == 0;
+                const bool outside = bx < -1 || bx > 1 || by < -1 || by > 1 || bz < -1 || bz > 1;
+                if (fr.rebuild && outside) atomicOr((int*)&sh.wflags, RB_WF_TRUNCATED);
+                // as a remaining cell atom (utilities.py:996-1013) and / or as a supercell atom that is not, by
+                // value, in the remaining atom list (:1014-1036)
+                const unsigned char rem = central ? remaining[q] : (unsigned char)0;
+                const bool same_item = central && alias[q];
+                const bool do0 = central && rem;
+                const bool do1 = fr.rebuild && !outside && !(same_item && rem);
+                const int s1 = ((bx + 1) * 9 + (by + 1) * 3 + (bz + 1)) * n + q;
+                bool t0 = bonded, t1 = bonded;
+                if (!clear && (do0 || do1)) {
+                    // (rare: a comparison of this pair's bond test is too close to its threshold to be made once)
+                    int qq, a1, a2, a3;
+                    const double* P;
+                    rb_decode(WS, n, j_id, &qq, &a1, &a2, &a3, &P);
+                    const double px = P[0], py = P[1], pz = P[2];
+                    const double pp = sq3(px, py, pz);
+                    const double rc = fr.cov[j_q0] + fr.cov[q];
+                    double clearance;
+                    if (do0) {
+                        const double* X = &WS.V[3 * q];
+                        t0 = rb_bond(X[0], X[1], X[2], px, py, pz, pp, rc - fr.tol, rc + fr.tol, fr.max_dist, &clearance);
+                        if (clearance < 1e-6) atomicOr((int*)&sh.wflags, RB_WF_MARGINAL);
+                    }
+                    if (do1) {
+                        const double* X = &WS.S[3 * (size_t)s1];
+                        t1 = rb_bond(X[0], X[1], X[2], px, py, pz, pp, rc - fr.tol, rc + fr.tol, fr.max_dist, &clearance);
+                        if (clearance < 1e-6) atomicOr((int*)&sh.wflags, RB_WF_MARGINAL);
+                    }
+                }
+                cell_hit = do0 && t0;
+                img_hit = do1 && t1;
+                cell_id = q;
+                img_id = same_item ? q : n + s1;
+            }
+            const unsigned long long C = __ballot(cell_hit), I = __ballot(img_hit);
+            const int H = __popcll(C) + __popcll(I);
+            if (H) {
+                const unsigned long long below = j_excl == 0 ? 0ull : (~0ull >> (64 - j_excl));
+                const unsigned long long upto = j_incl >= 64 ? ~0ull : ((1ull << j_incl) - 1ull);
+                const unsigned long long segm = upto & ~below;
+                const int base = __popcll(C & below) + __popcll(I & below);
+                const int ncell = __popcll(C & segm);
+                if (cell_hit) hits[base + __popcll(C & segm & lt)] = cell_id;
+                if (img_hit) hits[base + ncell + __popcll(I & segm & lt)] = img_id;
+                T::wave_sync();
+                // unique(working_list_temp), then "not in final_molecule" (utilities.py:1044-1055)
+                for (int h0 = 0; h0 < H; h0 += 64) {
+                    const int hn = H - h0 < 64 ? H - h0 : 64;
+                    const bool act = lane < hn;
+                    const int id = act ? hits[h0 + lane] : -1 - lane;       // (distinct dummies for idle lanes)
+                    bool dup = false;
+                    for (int t = 0; t < hn; ++t) { const int idt = __builtin_amdgcn_readlane(id, t); dup = dup || (t < lane && idt == id); }
+                    bool keep = false;
+                    if (act && !dup) {
+                        const unsigned long long bit = 1ull << (id & 63);
+                        const bool fresh = !(bits_temp[id >> 6] & bit);
+                        keep = fresh && !(bits_final[id >> 6] & bit);
+                        if (fresh) atomicOr((unsigned long long*)&bits_temp[id >> 6], bit);
+                    }
+                    const unsigned long long bal = __ballot(keep);
+                    const int pos = nn + __popcll(bal & lt);
+                    if (keep) {
+                        if (pos < RB_LWORK) wn[pos] = id;
+                        else work_next[pos] = id;
+                    }
+                    nn += __popcll(bal);
+                    T::wave_sync();
+                }
+            }
+            a0 += na;
+        }
+        // atom_list.remove(i) for the atoms of this layer, after the last of them has been expanded
+        for (int k = lane; k < nw; k += 64) {
+            const int id = LW(k);
+            if (id < n) remaining[id] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // (layers wider than RB_LWORK: tails in global lists)
+        T::wave_sync();
+        nf += nw;
+        nw = nn;
+        cur ^= 1;
+        { int* t = work; work = work_next; work_next = t; }
+        ++layers;
+    }
+    if (lane == 0) { sh.n_final = nf; sh.n_work = 0; sh.n_next = 0; }
+    return layers;
+}
+#endif
 
 // -DPW_RB_PROFILE: team 0 prints the wall time of its phases per frame (tests/tools/rebuild_profile.py)
 #if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -404,6 +579,26 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
     if (tid == 0) {
         w.status = 0; w.n_mol = 0; w.n_out = 0;
         out.mol_offset[0] = 0;
+    }
+    // ---- system centre of mass (utilities.py:127-148 on the unrounded input) -----------
+    // numpy adds the rows one after the other: three threads, one chain of additions each.  The products are
+    // staged in team-shared memory by everybody first (the scan arrays are not written yet) so that the chains
+    // do not wait for global memory.
+    constexpr int SUM_THREAD = T::SIZE > 3 ? 3 : 0;
+    const bool com_staged = WS.scan_fast && n <= RB_CHUNK * RB_SEG_CAP && (size_t)24 * n <= RebuildWs::scan_bytes(n);
+    if (com_staged) {
+        PW_LDS double* t3 = (PW_LDS double*)WS.scan;
+        PW_LDS double* tm = (PW_LDS double*)WS.seg;
+        for (int i = tid; i < n; i += T::SIZE) {
+            const double m = fr.mass[i];
+            t3[i] = fr.xyz[3 * i] * m; t3[(size_t)n + i] = fr.xyz[3 * i + 1] * m; t3[2 * (size_t)n + i] = fr.xyz[3 * i + 2] * m;
+            tm[i] = m;
+        }
+        T::sync();
+        for (int col = tid; col < 3; col += T::SIZE)
+            sh.com[col] = seq_sum_blocked(n, [&](int r) { return t3[(size_t)col * n + r]; });
+        if (tid == SUM_THREAD) sh.red_v[0] = np_sum_serial((const double*)WS.seg, n);
+        T::sync();
     }
     // ---- value coordinates ------------------------------------------------------------
     double vmax = 0.0;                                 // largest coordinate of the cell (for clear_min, below)
@@ -448,11 +643,11 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
     }
     T::sync();
     RB_TICK(0);
-    // ---- system centre of mass (utilities.py:127-148 on the unrounded input) -----------
-    constexpr int SUM_THREAD = T::SIZE > 3 ? 3 : 0;
-    for (int col = tid; col < 3; col += T::SIZE)
-        sh.com[col] = seq_sum_blocked(n, [&](int r) { return fr.xyz[3 * r + col] * fr.mass[r]; });
-    if (tid == SUM_THREAD) sh.red_v[0] = np_sum_serial(fr.mass, n);
+    if (!com_staged) {
+        for (int col = tid; col < 3; col += T::SIZE)
+            sh.com[col] = seq_sum_blocked(n, [&](int r) { return fr.xyz[3 * r + col] * fr.mass[r]; });
+        if (tid == SUM_THREAD) sh.red_v[0] = np_sum_serial(fr.mass, n);
+    }
     T::sync();
     if (tid == 0) {
         double total = sh.red_v[0];
@@ -526,13 +721,6 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
             }
             for (int c = tid; c <= RB_NCELL + 1; c += T::SIZE) cs[c] = 0;
             T::sync();
-            // every start atom is the remaining heavy atom closest to the pseudo origin (utilities.py:955-972):
-            // the distances do not change during the frame
-            {
-                const double ox = sh.origin[0], oy = sh.origin[1], oz = sh.origin[2];
-                const double oo = sq3(ox, oy, oz);
-                for (int q = tid; q < n; q += T::SIZE) WS.dorig[q] = rb_dist_sk(&WS.V[3 * q], WS.Vxx[q], ox, oy, oz, oo);
-            }
             float g0[3], ginv, gh = reach + slack;
             int gn[3];
             for (int c = 0; c < 3; ++c) {
@@ -624,7 +812,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                                 lo_f = lo_f > 0.0f ? lo_f : 0.0f;
                                 const float up = hi_f < reach ? hi_f : reach;
                                 if (!(d2 < up * up && d2 > lo_f * lo_f) || (im == RB_CENTRAL && q == p)) continue;
-                                if (cnt < RB_NB_CAP) stage(cnt) = im * n + q;
+                                if (cnt < RB_NB_CAP) stage(cnt) = (im << RB_NB_IMG_SHIFT) | q;
                                 ++cnt;
                             }
                         }
@@ -635,7 +823,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                 int kept = 0;
                 for (int e = 0; e < m; ++e) {
                     const int key = stage(e);
-                    const int img = key / n, q = key - img * n;
+                    const int img = key >> RB_NB_IMG_SHIFT, q = key & RB_NB_Q_MASK;
                     const double* Xc = fr.rebuild ? &WS.S[3 * ((size_t)img * n + q)] : &WS.V[3 * q];
                     const double rc = rp + fr.cov[q];
                     double clearance;
@@ -660,6 +848,45 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
         else build((const float*)WS.scan, WS.grid_ids, WS.grid_start);
     }
     T::sync();
+    // ---- what the walk reads at every step, side by side in the memory the scan no longer needs ------------
+    // the lists one after the other behind an offset per atom, and the distance of every heavy atom to the
+    // pseudo origin (every start atom is the remaining heavy atom closest to it, utilities.py:955-972; the
+    // distances do not change during the frame).  Team-shared memory when the scan arrays were there and the
+    // lists fit, the team's slab otherwise.
+    const int* nb_off;
+    const int* nb_ent;
+    const double* dorig;
+    bool lists_fast;
+    {
+        const int per = (n + T::SIZE - 1) / T::SIZE;
+        const int qa = tid * per < n ? tid * per : n, qb = qa + per < n ? qa + per : n;
+        int sum = 0;
+        for (int q = qa; q < qb; ++q) sum += WS.nb_cnt[q];
+        int incl = sum;
+        for (int d = 1; d < T::WSIZE; d <<= 1) { int t = T::shfl_up_i(incl, d); if (T::lane() >= d) incl += t; }
+        if (T::lane() == T::WSIZE - 1) sh.red_i[T::wave()] = incl;
+        T::sync();
+        int run = incl - sum, total = 0;
+        for (int t = 0; t < T::NWAVES; ++t) { if (t < T::wave()) run += sh.red_i[t]; total += sh.red_i[t]; }
+        const size_t fast_ints = RebuildWs::scan_bytes(n) / 4;
+        const bool fast = WS.scan_fast && 2 * (size_t)n + (size_t)n + 1 + (size_t)total <= fast_ints;
+        double* dd = fast ? (double*)WS.scan : WS.dorig;
+        int* off = fast ? (int*)WS.scan + 2 * (size_t)n : WS.csr;
+        int* ent = off + n + 1;
+        for (int q = qa; q < qb; ++q) {
+            const int c = WS.nb_cnt[q];
+            off[q] = run;
+            for (int e = 0; e < c; ++e) ent[run + e] = WS.nb[(size_t)q * RB_NB_CAP + e];
+            run += c;
+        }
+        if (tid == 0) off[n] = total;
+        const double ox = sh.origin[0], oy = sh.origin[1], oz = sh.origin[2];
+        const double oo = sq3(ox, oy, oz);
+        for (int q = tid; q < n; q += T::SIZE)
+            dd[q] = fr.terminal[q] ? PW_INF : rb_dist_sk(&WS.V[3 * q], WS.Vxx[q], ox, oy, oz, oo);
+        nb_off = off; nb_ent = ent; dorig = dd; lists_fast = fast;
+    }
+    T::sync();
     RB_TICK(2);
     // ---- molecules, one at a time ------------------------------------------------------------
     int mol_serial = 0, layer_serial = 0;
@@ -669,8 +896,9 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
             double best = PW_INF;
             int bi = -1;
             for (int q = tid; q < n; q += T::SIZE) {
-                if (!WS.remaining[q] || fr.terminal[q]) continue;
-                double d = WS.dorig[q];
+                if (!WS.remaining[q]) continue;
+                double d = dorig[q];
+                if (!(d < PW_INF)) continue;           // (an element the walk does not start from)
                 if (d < best || bi < 0) { best = d; bi = q; }
             }
             if (bi < 0) { best = PW_INF; bi = 0x7fffffff; }
@@ -747,7 +975,25 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
         //   C  thread 0 merges the hits in list order (unique, then "not in the molecule") into the
         //      next layer while the other threads retire the layer's atoms from the atom list.
         int cur = 0;                       // which team-shared copy holds the current layer
-        for (;;) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // on the device, with the visit bit sets in team-shared memory: the whole walk by one wave, no barriers
+        const bool wave_walk = T::WSIZE == 64 && use_bits;
+        if (wave_walk) {
+            if (T::wave() == 0) {
+                const int nl = lists_fast ? rb_wave_walk<T>(fr, WS, (const PW_LDS int*)nb_off, (const PW_LDS int*)nb_ent, sh.start)
+                                          : rb_wave_walk<T>(fr, WS, nb_off, nb_ent, sh.start);
+                (void)nl;
+#if defined(PW_RB_PROFILE)
+                rb_layers += nl;
+#endif
+            }
+            T::sync();
+            RB_TICK(5);
+        }
+#else
+        const bool wave_walk = false;
+#endif
+        for (; !wave_walk;) {
             const int nw = sh.n_work;
             if (nw == 0) break;
             ++layer_serial;
@@ -770,9 +1016,9 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                     if (T::lane() == 0) seg_cnt[k] = 0;
                     T::wave_sync();
 #if defined(PW_RB_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-                    rb_expand<T>(fr, WS, &w.status, (int*)&sh.wflags, c0 + k < RB_LWORK ? wl[c0 + k] : work[c0 + k], k, T::wave() == 0 ? rb_xp : nullptr);
+                    rb_expand<T>(fr, WS, nb_off, nb_ent, &w.status, (int*)&sh.wflags, c0 + k < RB_LWORK ? wl[c0 + k] : work[c0 + k], k, T::wave() == 0 ? rb_xp : nullptr);
 #else
-                    rb_expand<T>(fr, WS, &w.status, (int*)&sh.wflags, c0 + k < RB_LWORK ? wl[c0 + k] : work[c0 + k], k);
+                    rb_expand<T>(fr, WS, nb_off, nb_ent, &w.status, (int*)&sh.wflags, c0 + k < RB_LWORK ? wl[c0 + k] : work[c0 + k], k);
 #endif
                     T::wave_sync();
                     if (T::lane() == 0) {

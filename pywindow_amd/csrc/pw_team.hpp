@@ -149,6 +149,18 @@ struct DeviceTeam {
     __device__ static double bcast_u(double v, int src) { return lane_d(v, __builtin_amdgcn_readfirstlane(src)); }
     __device__ static int bcast_i(int v, int src) { return __shfl(v, src, 64); }
     __device__ static int shfl_up_i(int v, int delta) { return __shfl_up(v, delta, 64); }
+    // inclusive prefix sum over the lanes of the wave: four row_shr steps inside every row of 16 lanes (a lane
+    // without a source adds 0), then the totals of the rows below by v_readlane
+    __device__ static int incl_scan_i(int v) {
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+        const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31),
+                  r2 = __builtin_amdgcn_readlane(v, 47);
+        const int row = (threadIdx.x & 63) >> 4;
+        return v + (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
+    }
 };
 // A ROW of 16 lanes as a team: four of them share a wavefront, each running its own optimiser chain
 // (pw_row_chains_kernel).  Only what pw_lbfgsb.hpp asks of a team: lane numbering, a lane-to-lane move with a

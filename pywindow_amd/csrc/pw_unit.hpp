@@ -1262,20 +1262,23 @@ PW_HD inline void load_unit(UnitShared& sh, int n, const double* xyz, const doub
 // sum_{i<n} term(i), strictly left to right (numpy's axis-0 reduction over rows), with the terms
 // of eight rows fetched before they are added: the additions stay one dependent chain, the LDS
 // reads (two levels through the permutation) no longer sit on it
-template <class F>
-PW_HD inline double seq_sum_blocked(int n, F term) {
+// (B terms requested together, then added one after the other)
+template <int B, class F>
+PW_HD inline double seq_sum_blocks(int n, F term) {
     double s = term(0);
     int i = 1;
-    for (; i + 8 <= n; i += 8) {
-        double v[8];
+    for (; i + B <= n; i += B) {
+        double v[B];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = term(i + j);
+        for (int j = 0; j < B; ++j) v[j] = term(i + j);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s = s + v[j];
+        for (int j = 0; j < B; ++j) s = s + v[j];
     }
     for (; i < n; ++i) s = s + term(i);
     return s;
 }
+template <class F>
+PW_HD inline double seq_sum_blocked(int n, F term) { return seq_sum_blocks<8>(n, term); }
 
 // shifted copy S = A - c (elementwise), with |r|^2 and the row-sequential centroid
 template <class T>

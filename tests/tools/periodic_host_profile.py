@@ -24,6 +24,7 @@ with tempfile.TemporaryDirectory() as tmp:
     ids = element_ids(traj.elements())
     topo = rb.CellTopology(traj.elements())
     ctx = engine.context()
+    print("context: pipelined =", ctx.pipelined, flush=True)
     for rep in range(3):
         t = [time.perf_counter()]
         coords, lattice = traj._read_selected(list(range(n)), True); t.append(time.perf_counter())
@@ -33,4 +34,5 @@ with tempfile.TemporaryDirectory() as tmp:
         recs = res.download(); t.append(time.perf_counter())
         res.free(); t.append(time.perf_counter())
         names = ["parse", "pack_frames", "resident_from_cells", "launch", "download(wait)", "free"]
+        print("gate timeouts", ctx.gate_timeouts, end=" | ")
         print(f"frames {n}: " + " | ".join(f"{k} {1e3 * (b - a):.1f}" for k, a, b in zip(names, t[:-1], t[1:])) + f" | total {1e3 * (t[-1] - t[0]):.1f} ms", flush=True)
