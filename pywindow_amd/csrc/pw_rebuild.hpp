@@ -597,7 +597,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
         T::sync();
         for (int col = tid; col < 3; col += T::SIZE)
             sh.com[col] = seq_sum_blocked(n, [&](int r) { return t3[(size_t)col * n + r]; });
-        if (tid == SUM_THREAD) sh.red_v[0] = np_sum_serial((const double*)WS.seg, n);
+        if (tid == SUM_THREAD) sh.red_v[0] = np_sum_lean((const double*)WS.seg, n);
         T::sync();
     }
     // ---- value coordinates ------------------------------------------------------------
@@ -646,7 +646,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
     if (!com_staged) {
         for (int col = tid; col < 3; col += T::SIZE)
             sh.com[col] = seq_sum_blocked(n, [&](int r) { return fr.xyz[3 * r + col] * fr.mass[r]; });
-        if (tid == SUM_THREAD) sh.red_v[0] = np_sum_serial(fr.mass, n);
+        if (tid == SUM_THREAD) sh.red_v[0] = np_sum_lean(fr.mass, n);
     }
     T::sync();
     if (tid == 0) {
@@ -1146,7 +1146,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                 T::sync();
                 for (int col = tid; col < 3; col += T::SIZE)
                     sh.com[col] = seq_sum_blocked(m, [&](int k) { return tx[col * tc + k]; });
-                if (tid == SUM_THREAD) sh.red_v[0] = np_sum_serial((const double*)(tx + 3 * tc), m);
+                if (tid == SUM_THREAD) sh.red_v[0] = np_sum_lean((const double*)(tx + 3 * tc), m);
             } else {
                 for (int k = tid; k < m; k += T::SIZE) {
                     int q, ax, ay, az;
@@ -1162,7 +1162,7 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                         rb_decode(WS, n, (k < RB_LFINAL ? sh.lfinal[k] : WS.final_[k]), &q, &ax, &ay, &az, &P);
                         return P[col] * fr.mass[q];
                     });
-                if (tid == SUM_THREAD) sh.red_v[0] = np_sum_serial(WS.msum, m);
+                if (tid == SUM_THREAD) sh.red_v[0] = np_sum_lean(WS.msum, m);
             }
             T::sync();
             if (tid == 0) {

@@ -588,6 +588,46 @@ PW_HD inline double np_sum_serial(const double* a, int n) {
     }
     return total;
 }
+// ... and one whose state is scalars only (nothing a GPU compiler has to put into scratch memory): the leaves
+// are visited left to right - each found by walking down the recursion from the root - and a finished node
+// that is a right child is added to its parent's pending left sum on the spot.  Depth <= 8 for 8192 elements.
+PW_HD inline double np_sum_lean(const double* a, int n) {
+    double total = 0.0;
+    bool first = true;
+    for (int s = 0; s < n; s += 8192) {
+        const int len = n - s < 8192 ? n - s : 8192;
+        double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0, l4 = 0.0, l5 = 0.0, l6 = 0.0, l7 = 0.0, part = 0.0;
+        for (int e = 0; e < len;) {
+            int off = 0, l = len, depth = 0;
+            unsigned path = 0;                       // bit d: the walk went right at depth d
+            while (l > 128) {
+                int n2 = l / 2;
+                n2 -= n2 % 8;
+                if (e < off + n2) { l = n2; } else { off += n2; l -= n2; path |= 1u << depth; }
+                ++depth;
+            }
+            double v = np_leaf_sum(a + s + off, l);
+            int d = depth;
+            while (d > 0 && ((path >> (d - 1)) & 1u)) {
+                const int k = d - 1;
+                const double lv = k == 0 ? l0 : k == 1 ? l1 : k == 2 ? l2 : k == 3 ? l3 : k == 4 ? l4 : k == 5 ? l5 : k == 6 ? l6 : l7;
+                v = lv + v;
+                --d;
+            }
+            if (d > 0) {
+                const int k = d - 1;
+                l0 = k == 0 ? v : l0; l1 = k == 1 ? v : l1; l2 = k == 2 ? v : l2; l3 = k == 3 ? v : l3;
+                l4 = k == 4 ? v : l4; l5 = k == 5 ? v : l5; l6 = k == 6 ? v : l6; l7 = k == 7 ? v : l7;
+            } else {
+                part = v;
+            }
+            e = off + l;
+        }
+        total = first ? part : total + part;
+        first = false;
+    }
+    return total;
+}
 // team version.  Leaves are at least 64 elements long (for n > 128), so every 64-element
 // slot holds at most one leaf start; a thread finds it by walking down the recursion
 // (no tables, no private stacks -- those would live in scratch memory on the GPU).  The

@@ -147,6 +147,8 @@ extern "C" double hs_pairwise_sum(const double* a, long n) {
 }
 // ... and the serial restatement it replaced in round 1 (np_sum_serial), kept as a cross-check
 extern "C" double hs_pairwise_sum_serial(const double* a, long n) { return np_sum_serial(a, (int)n); }
+// ... and the scalar-state variant the periodic re-assembly uses (np_sum_lean)
+extern "C" double hs_pairwise_sum_lean(const double* a, long n) { return np_sum_lean(a, (int)n); }
 extern "C" long hs_lds_bytes(int nmax) { return (long)UnitShared::bytes(nmax, 1, 8); }
 extern "C" long hs_lds_offset(int nmax, int what) {
     // byte offsets of the parts of the team-shared block (for the poison tests)

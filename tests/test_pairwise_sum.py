@@ -23,7 +23,7 @@ def _values(n, seed):
 @pytest.fixture(scope="module")
 def probe(hostsim):
     L = ctypes.CDLL(str(hostsim / "libunitprobe.so"))
-    for f in (L.hs_pairwise_sum, L.hs_pairwise_sum_serial):
+    for f in (L.hs_pairwise_sum, L.hs_pairwise_sum_serial, L.hs_pairwise_sum_lean):
         f.restype = ctypes.c_double
         f.argtypes = [ctypes.c_void_p, ctypes.c_long]
     return L
@@ -35,6 +35,8 @@ def test_host_team_sum_is_numpy_sum(probe):
         want = float(np.add.reduce(a)) if n else 0.0
         assert probe.hs_pairwise_sum(a.ctypes.data, n) == want, n
         assert probe.hs_pairwise_sum_serial(a.ctypes.data, n) == want, n
+        if n:
+            assert probe.hs_pairwise_sum_lean(a.ctypes.data, n) == want, n      # (the scalar-state walk of the re-assembly)
 
 
 @pytest.mark.gpu
