@@ -169,3 +169,18 @@ def test_stream_probe_is_stable():
     proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stderr[-1500:]
     assert "BAD []" in proc.stdout, (proc.stdout[-500:], proc.stderr[-1500:])
+
+
+def test_pacing_gates_do_not_time_out(hip_ctx):
+    """The pipeline's gates only pace launches; one that gives up waiting costs 20 ms and is counted."""
+    from pywindow_amd import _lib, synth
+    from pywindow_amd import element_data as E
+
+    elements, frames = synth.synthetic_units(96)
+    ids = E.element_ids(elements)
+    res = hip_ctx.upload(_lib.Batch.uniform(frames, E.VDW[ids], E.MASS[ids]))
+    for _ in range(6):
+        res.launch()
+    res.download()
+    res.free()
+    assert hip_ctx.gate_timeouts == {"tail": 0, "head": 0, "residency": 0}

@@ -247,6 +247,32 @@ def test_long_modular_analysis_in_pieces(hip_ctx, tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("copies", [(2, 1, 1), (2, 2, 1), (2, 2, 2)], ids=["2688 atoms", "5376 atoms", "10752 atoms"])
+def test_hip_larger_cells_take_the_other_memory_layouts(hip_ctx, hostsim, copies):
+    """Copies of the CC3 test cell side by side: 2 688 atoms (visit bit sets in team-shared memory, candidate grid and
+    lists in the team's slab, one-wave walk over global lists), 5 376 (the same, near the limit of the bit sets)
+    and 10 752 (no bit sets: stamp arrays and the four-wave layer loop) - each against the host-compiled kernel
+    source, whose agreement with the reference the smaller cases pin."""
+    from pywindow_amd import rebuild as RB
+
+    base = CASES["cc3_cell"][0]
+    lat = np.asarray(base["lattice"], float)
+    xyz0 = np.asarray(base["coordinates"], float)
+    shifts = [(a, b, c) for a in range(copies[0]) for b in range(copies[1]) for c in range(copies[2])]
+    xyz = np.concatenate([xyz0 + lat @ np.array(s, float) for s in shifts])
+    big = lat * np.array(copies, float)[None, :]            # (columns are the cell vectors)
+    system = {"elements": np.concatenate([np.asarray(base["elements"])] * len(shifts)), "coordinates": xyz, "lattice": big}
+    topo = RB.CellTopology(system["elements"])
+    n_mol, off, src, img, out = RB.discrete_molecules_frames(topo, xyz[None], big[None], True)
+    got = RB.molecules_from_output(system, int(n_mol[0]), off[0], src[0], out[0])
+    want, status = run_hostsim(hostsim, system, True, with_bits=False)
+    assert status == 0 and len(got) == len(want) == 8 * len(shifts)
+    for g, w in zip(got, want):
+        assert list(g["elements"]) == list(w["elements"])
+        assert np.array_equal(g["coordinates"], w["coordinates"])
+
+
+@pytest.mark.gpu
 def test_resident_hand_over_matches_host_path(hip_ctx):
     """pw_resident_from_cells: the ragged unit batch built on the device gives the same analysis
     records as the host-marshalled path; capacity retries (a framework 27x the cell) work."""
