@@ -28,7 +28,7 @@ from .molecular import MolecularSystem, decipher_atom_key
 MODULAR_CHUNK = 8192
 #: ... a long one in pieces of MODULAR_PIECE frames, up to MODULAR_IN_FLIGHT of them analysed while the next is
 #: being read and re-assembled
-MODULAR_PIECE = 1024
+MODULAR_PIECE = 512
 MODULAR_IN_FLIGHT = 2
 #: a plain analysis goes through in ONE piece up to 2 x RUN_PIECE frames and in pieces of RUN_PIECE beyond (what
 #: bounds the device memory of a very long trajectory; see DLPOLY._run for why not smaller)

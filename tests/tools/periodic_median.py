@@ -22,7 +22,8 @@ with tempfile.TemporaryDirectory() as tmp:
     traj = pw.DLPOLY(path)
     ref = None
     for label, piece, fl in (("one piece", 10 ** 9, 2), ("pieces of 512, 2 in flight", 512, 2), ("pieces of 512, 3 in flight", 512, 3),
-                             ("pieces of 1024, 2 in flight", 1024, 2), ("pieces of 256, 3 in flight", 256, 3)):
+                             ("pieces of 1024, 2 in flight", 1024, 2), ("pieces of 256, 2 in flight", 256, 2), ("pieces of 256, 3 in flight", 256, 3),
+                             ("pieces of 128, 3 in flight", 128, 3)):
         trajectory.MODULAR_PIECE = piece
         trajectory.MODULAR_IN_FLIGHT = fl
         ts = []
