@@ -956,12 +956,17 @@ int pw_context_create(int device, pw_context** out) {
         CTX_TRY(hipDeviceSynchronize());
         for (int i = 0; i < k; ++i) hipLaunchKernelGGL(pw_probe_kernel, dim3(1), dim3(64), 0, all[i], flags, 0, flags + 1);
         CTX_TRY(hipDeviceSynchronize());
-        CTX_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(int), c->stream));
-        CTX_TRY(hipDeviceSynchronize());
-        for (int i = 0; i < k; ++i) hipLaunchKernelGGL(pw_probe_kernel, dim3(1), dim3(64), 0, all[i], flags, k, flags + 1);
-        CTX_TRY(hipDeviceSynchronize());
+        // (up to three timed rounds: streams that share a hardware queue fail every round, but a host thread
+        // that is not scheduled for 10 ms in the middle of the k launches - seen on loaded hosts,
+        // tests/tools/launch_jitter.py - fails one, and the verdict lasts for the life of the context)
         int got[2] = {0, 0};
-        CTX_TRY(hipMemcpy(got, flags, sizeof(got), hipMemcpyDeviceToHost));
+        for (int round = 0; round < 3 && got[1] < k; ++round) {
+            CTX_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(int), c->stream));
+            CTX_TRY(hipDeviceSynchronize());
+            for (int i = 0; i < k; ++i) hipLaunchKernelGGL(pw_probe_kernel, dim3(1), dim3(64), 0, all[i], flags, k, flags + 1);
+            CTX_TRY(hipDeviceSynchronize());
+            CTX_TRY(hipMemcpy(got, flags, sizeof(got), hipMemcpyDeviceToHost));
+        }
         CTX_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(int), c->stream));
         CTX_TRY(hipDeviceSynchronize());
         c->concurrent_streams = got[1];
