@@ -394,7 +394,14 @@ PW_HD inline void rb_expand(const RebuildFrame& fr, const RebuildWs& w, const in
 //     molecule" from the bit sets, positions in the next layer from a ballot.
 // Returns the number of layers.  Needs the visit bit sets (and the atom list) in team-shared memory.
 template <class T, class LISTP>
-__device__ inline int rb_wave_walk(const RebuildFrame& fr, const RebuildWs& WS, LISTP nb_off, LISTP nb_ent, int start) {
+__device__ inline int rb_wave_walk(const RebuildFrame& fr, const RebuildWs& WS, LISTP nb_off, LISTP nb_ent, int start,
+                                   long long* wprof = nullptr) {
+#if defined(PW_RB_PROFILE)
+    long long wt = wall_clock64();
+#define RB_WT(k) do { if (wprof && T::lane() == 0) { long long t_ = wall_clock64(); wprof[k] += t_ - wt; wt = t_; } } while (0)
+#else
+#define RB_WT(k) do { } while (0)
+#endif
     PW_LDS RebuildShared& sh = *(PW_LDS RebuildShared*)WS.sh;
     PW_LDS unsigned long long* const bits_final = (PW_LDS unsigned long long*)WS.bits_final;
     PW_LDS unsigned long long* const bits_temp = (PW_LDS unsigned long long*)WS.bits_temp;
@@ -418,9 +425,12 @@ __device__ inline int rb_wave_walk(const RebuildFrame& fr, const RebuildWs& WS, 
             else WS.final_[nf + k] = id;
             atomicOr((unsigned long long*)&bits_final[id >> 6], 1ull << (id & 63));
         }
-        for (int i = lane; i < WS.bit_words; i += 64) bits_temp[i] = 0;
         T::wave_sync();
+        RB_WT(0);
         int nn = 0;
+        // "seen in this layer": first occurrences inside a merge round are found lane to lane; the bit set is only
+        // needed - and only then cleared - when a layer takes more than one round
+        bool temp_live = false;
         for (int a0 = 0; a0 < nw;) {
             // lane k: atom a0 + k of the layer
             const int ka = a0 + lane;
@@ -433,6 +443,7 @@ __device__ inline int rb_wave_walk(const RebuildFrame& fr, const RebuildWs& WS, 
                 beg = nb_off[q0];
                 cnt = nb_off[q0 + 1] - beg;
             }
+            RB_WT(1);
             const int incl = T::incl_scan_i(cnt);
             // the atoms whose entries fit this pass (a list has at most RB_NB_CAP entries: never none)
             const int na = __popcll(__ballot(va && incl <= 64));
@@ -446,6 +457,7 @@ __device__ inline int rb_wave_walk(const RebuildFrame& fr, const RebuildWs& WS, 
             const int j_q0 = __shfl(q0, jj), j_id = __shfl(id0, jj);
             const int j_a = __shfl((ax + 1) | ((ay + 1) << 2) | ((az + 1) << 4), jj);
             const int j_excl = j_incl - j_cnt;
+            RB_WT(2);
             bool cell_hit = false, img_hit = false;
             int cell_id = 0, img_id = 0;
             if (ve) {
@@ -493,7 +505,13 @@ __device__ inline int rb_wave_walk(const RebuildFrame& fr, const RebuildWs& WS, 
             }
             const unsigned long long C = __ballot(cell_hit), I = __ballot(img_hit);
             const int H = __popcll(C) + __popcll(I);
+            RB_WT(3);
             if (H) {
+                const bool use_temp = !(a0 == 0 && na >= nw && H <= 64);
+                if (use_temp && !temp_live) {
+                    for (int i = lane; i < WS.bit_words; i += 64) bits_temp[i] = 0;
+                    temp_live = true;
+                }
                 const unsigned long long below = j_excl == 0 ? 0ull : (~0ull >> (64 - j_excl));
                 const unsigned long long upto = j_incl >= 64 ? ~0ull : ((1ull << j_incl) - 1ull);
                 const unsigned long long segm = upto & ~below;
@@ -512,9 +530,9 @@ __device__ inline int rb_wave_walk(const RebuildFrame& fr, const RebuildWs& WS, 
                     bool keep = false;
                     if (act && !dup) {
                         const unsigned long long bit = 1ull << (id & 63);
-                        const bool fresh = !(bits_temp[id >> 6] & bit);
+                        const bool fresh = use_temp ? !(bits_temp[id >> 6] & bit) : true;
                         keep = fresh && !(bits_final[id >> 6] & bit);
-                        if (fresh) atomicOr((unsigned long long*)&bits_temp[id >> 6], bit);
+                        if (use_temp && fresh) atomicOr((unsigned long long*)&bits_temp[id >> 6], bit);
                     }
                     const unsigned long long bal = __ballot(keep);
                     const int pos = nn + __popcll(bal & lt);
@@ -526,6 +544,7 @@ __device__ inline int rb_wave_walk(const RebuildFrame& fr, const RebuildWs& WS, 
                     T::wave_sync();
                 }
             }
+            RB_WT(4);
             a0 += na;
         }
         // atom_list.remove(i) for the atoms of this layer, after the last of them has been expanded
@@ -540,6 +559,7 @@ __device__ inline int rb_wave_walk(const RebuildFrame& fr, const RebuildWs& WS, 
         cur ^= 1;
         { int* t = work; work = work_next; work_next = t; }
         ++layers;
+        RB_WT(5);
     }
     if (lane == 0) { sh.n_final = nf; sh.n_work = 0; sh.n_next = 0; }
     return layers;
@@ -980,8 +1000,13 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
         const bool wave_walk = T::WSIZE == 64 && use_bits;
         if (wave_walk) {
             if (T::wave() == 0) {
-                const int nl = lists_fast ? rb_wave_walk<T>(fr, WS, (const PW_LDS int*)nb_off, (const PW_LDS int*)nb_ent, sh.start)
-                                          : rb_wave_walk<T>(fr, WS, nb_off, nb_ent, sh.start);
+#if defined(PW_RB_PROFILE)
+                long long* const wp = rb_xp;
+#else
+                long long* const wp = nullptr;
+#endif
+                const int nl = lists_fast ? rb_wave_walk<T>(fr, WS, (const PW_LDS int*)nb_off, (const PW_LDS int*)nb_ent, sh.start, wp)
+                                          : rb_wave_walk<T>(fr, WS, nb_off, nb_ent, sh.start, wp);
                 (void)nl;
 #if defined(PW_RB_PROFILE)
                 rb_layers += nl;
@@ -1267,8 +1292,8 @@ PW_HD inline void rebuild_frame(const RebuildFrame& fr, RebuildWs& w, const Rebu
                w.n_mol);
     if (tid == 0 && blockIdx.x == 0) printf("RBPROF wave 0 candidate scan: %d images, %d rounds; walks predicted and skipped: %d\n", rb_imgs, rb_rounds, rb_skipped);
     if (tid == 0 && blockIdx.x == 0)
-        printf("RBPROF expand (wave 0) us: q0 loads %lld, candidate flags %lld, coordinates %lld, test+append %lld, tail %lld\n",
-               rb_xp[0] / 100, rb_xp[1] / 100, rb_xp[2] / 100, rb_xp[3] / 100, rb_xp[4] / 100);
+        printf("RBPROF walk (one wave) us: join+clear %lld, layer atoms+lists %lld, scan+entry atoms %lld, entries %lld, hits+merge %lld, retire %lld\n",
+               rb_xp[0] / 100, rb_xp[1] / 100, rb_xp[2] / 100, rb_xp[3] / 100, rb_xp[4] / 100, rb_xp[5] / 100);
 #endif
 }
 
