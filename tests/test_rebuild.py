@@ -112,6 +112,66 @@ def test_host_team_matches_reference(hostsim, name):
         check_molecules(mols, expect, "rebuild", f"hostsim/{name}/rebuild/stamps")
 
 
+def threshold_system():
+    """Carbon pairs whose separations sit 3e-7 either side of the limits of the bond test (Rcov sum -+ tol = 0.96 /
+    1.76, the latter also max_dist), along an axis, along a diagonal and through a cell face, beside pairs that are
+    clearly bonded / clearly apart: the pairs whose test cannot be made once per frame."""
+    L = 20.0
+    lo, hi = 0.96, 1.76
+    sites = []
+    d111 = np.array([1.0, 1.0, 1.0]) / np.sqrt(3.0)
+    d120 = np.array([1.0, 2.0, 0.0]) / np.sqrt(5.0)
+    k = 0
+    for r in (hi - 3e-7, hi + 3e-7, lo + 3e-7, lo - 3e-7, hi - 5e-6, hi + 5e-6, 1.4, 0.5 * (lo + hi) + 1e-9,
+              hi - 1e-8, hi + 1e-8, lo + 1e-8, lo - 1e-8):
+        for u in (np.array([1.0, 0.0, 0.0]), d111, d120):
+            base = np.array([2.5 + 5.0 * (k % 3), 2.5 + 5.0 * ((k // 3) % 3), 2.5 + 4.0 * (k // 9)])
+            sites.append(base)
+            sites.append(base + r * u)
+            k += 1
+    # through the faces: the partner is an image
+    for m, r in enumerate((hi - 3e-7, hi + 3e-7, 1.5)):
+        sites.append(np.array([0.3, 17.5, 18.5 - 4.0 * m]))
+        sites.append(np.array([L - (r - 0.3), 17.5, 18.5 - 4.0 * m]))
+    xyz = np.round(np.array(sites), 8)
+    n = len(xyz)
+    return {"elements": np.array(["C"] * n), "atom_ids": np.array(["C"] * n), "coordinates": xyz,
+            "unit_cell": np.array([L, L, L, 90.0, 90.0, 90.0]), "lattice": np.eye(3) * L}
+
+
+def same_molecules(got, want, where):
+    assert len(got) == len(want), f"{where}: {len(got)} molecules, oracle {len(want)}"
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert list(g["elements"]) == list(w["elements"]), f"{where}: molecule {k}"
+        assert np.array_equal(np.asarray(g["coordinates"]), np.asarray(w["coordinates"])), f"{where}: molecule {k}"
+
+
+def test_pairs_at_the_limits_of_the_bond_test_host(hostsim):
+    from oracle import pw_rebuild as R
+
+    system = threshold_system()
+    want_plain = R.discrete_molecules(system)
+    want = R.discrete_molecules(system, rebuild=R.create_supercell(system))
+    assert 2 < len(want) < len(system["elements"])           # some pairs bond, some do not
+    for bits in (1, 3, 0):
+        mols, status = run_hostsim(hostsim, system, False, with_bits=bits)
+        assert status == 0
+        same_molecules(mols, want_plain, f"hostsim/{bits}/plain")
+        mols, status = run_hostsim(hostsim, system, True, with_bits=bits)
+        assert status == 0
+        same_molecules(mols, want, f"hostsim/{bits}/rebuild")
+
+
+@pytest.mark.gpu
+def test_pairs_at_the_limits_of_the_bond_test_hip(hip_ctx):
+    from oracle import pw_rebuild as R
+
+    system = threshold_system()
+    same_molecules(RB.discrete_molecules(dict(system)), R.discrete_molecules(system), "hip/plain")
+    same_molecules(RB.discrete_molecules(dict(system), rebuild=True),
+                   R.discrete_molecules(system, rebuild=R.create_supercell(system)), "hip/rebuild")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", SMALL + ["cc3_cell_md1", "MIBQAR"])
 def test_hip_matches_reference(hip_ctx, name):
