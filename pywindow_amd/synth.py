@@ -136,3 +136,30 @@ def synthetic_units(
     for k in range(n_frames):
         out[k] = quantise_like_history(noisy_frame(base, seed_base + first + k, sigma))
     return elements, out
+
+
+def threshold_cell():
+    """Carbon pairs whose separations sit 3e-7 either side of the limits of the bond test (Rcov sum -+ tol = 0.96 /
+    1.76, the latter also max_dist), along an axis, along a diagonal and through a cell face, beside pairs that are
+    clearly bonded / clearly apart: the pairs whose test cannot be made once per frame."""
+    L = 20.0
+    lo, hi = 0.96, 1.76
+    sites = []
+    d111 = np.array([1.0, 1.0, 1.0]) / np.sqrt(3.0)
+    d120 = np.array([1.0, 2.0, 0.0]) / np.sqrt(5.0)
+    k = 0
+    for r in (hi - 3e-7, hi + 3e-7, lo + 3e-7, lo - 3e-7, hi - 5e-6, hi + 5e-6, 1.4, 0.5 * (lo + hi) + 1e-9,
+              hi - 1e-8, hi + 1e-8, lo + 1e-8, lo - 1e-8):
+        for u in (np.array([1.0, 0.0, 0.0]), d111, d120):
+            base = np.array([2.5 + 5.0 * (k % 3), 2.5 + 5.0 * ((k // 3) % 3), 2.5 + 4.0 * (k // 9)])
+            sites.append(base)
+            sites.append(base + r * u)
+            k += 1
+    # through the faces: the partner is an image
+    for m, r in enumerate((hi - 3e-7, hi + 3e-7, 1.5)):
+        sites.append(np.array([0.3, 17.5, 18.5 - 4.0 * m]))
+        sites.append(np.array([L - (r - 0.3), 17.5, 18.5 - 4.0 * m]))
+    xyz = np.round(np.array(sites), 8)
+    n = len(xyz)
+    return {"elements": np.array(["C"] * n), "atom_ids": np.array(["C"] * n), "coordinates": xyz,
+            "unit_cell": np.array([L, L, L, 90.0, 90.0, 90.0]), "lattice": np.eye(3) * L}

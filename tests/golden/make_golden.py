@@ -803,6 +803,23 @@ def rebuild_case(args):
     return name, out
 
 
+def run_rebuild_limits(pool):
+    """The reference's discrete_molecules (plain and rebuilt) on synth.threshold_cell(): atom pairs 3e-7 / 1e-8
+    either side of the limits of its bond test -> rebuild_limits.npz."""
+    from pywindow_amd import synth
+
+    system = synth.threshold_cell()
+    name, res = pool.map(rebuild_case, [("limits", system)])[0]
+    arrays = {"names": np.array([name])}
+    for k, v in system.items():
+        arrays[f"{name}__in_{k}"] = np.asarray(v)
+    for k, v in res.items():
+        arrays[f"{name}__{k}"] = v
+    print("rebuild limits", len(system["elements"]), "atoms ->", len(res["plain_offset"]) - 1, "molecules,",
+          len(res["rebuild_offset"]) - 1, "rebuilt")
+    np.savez_compressed(HERE / "rebuild_limits.npz", **arrays)
+
+
 def run_rebuild(pool):
     pw = load_reference()
     cases = []
@@ -1067,7 +1084,7 @@ def run_history20():
 
 
 def main():
-    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj", "optopt", "winopt", "shape", "tables", "history20", "axes", "nonporous", "cliffs", "json"}
+    which = set(sys.argv[1:]) or {"static", "md20", "synth64", "periodic", "cc3base", "options", "rebuild", "ptraj", "optopt", "winopt", "shape", "tables", "history20", "axes", "nonporous", "cliffs", "json", "rebuild_limits"}
     if "tables" in which:
         run_tables()
     if "history20" in which:
@@ -1105,6 +1122,8 @@ def main():
             run_options(pool)
         if "rebuild" in which:
             run_rebuild(pool)
+        if "rebuild_limits" in which:
+            run_rebuild_limits(pool)
         if "ptraj" in which:
             run_ptraj(pool)
         if "optopt" in which:

@@ -112,64 +112,44 @@ def test_host_team_matches_reference(hostsim, name):
         check_molecules(mols, expect, "rebuild", f"hostsim/{name}/rebuild/stamps")
 
 
-def threshold_system():
-    """Carbon pairs whose separations sit 3e-7 either side of the limits of the bond test (Rcov sum -+ tol = 0.96 /
-    1.76, the latter also max_dist), along an axis, along a diagonal and through a cell face, beside pairs that are
-    clearly bonded / clearly apart: the pairs whose test cannot be made once per frame."""
-    L = 20.0
-    lo, hi = 0.96, 1.76
-    sites = []
-    d111 = np.array([1.0, 1.0, 1.0]) / np.sqrt(3.0)
-    d120 = np.array([1.0, 2.0, 0.0]) / np.sqrt(5.0)
-    k = 0
-    for r in (hi - 3e-7, hi + 3e-7, lo + 3e-7, lo - 3e-7, hi - 5e-6, hi + 5e-6, 1.4, 0.5 * (lo + hi) + 1e-9,
-              hi - 1e-8, hi + 1e-8, lo + 1e-8, lo - 1e-8):
-        for u in (np.array([1.0, 0.0, 0.0]), d111, d120):
-            base = np.array([2.5 + 5.0 * (k % 3), 2.5 + 5.0 * ((k // 3) % 3), 2.5 + 4.0 * (k // 9)])
-            sites.append(base)
-            sites.append(base + r * u)
-            k += 1
-    # through the faces: the partner is an image
-    for m, r in enumerate((hi - 3e-7, hi + 3e-7, 1.5)):
-        sites.append(np.array([0.3, 17.5, 18.5 - 4.0 * m]))
-        sites.append(np.array([L - (r - 0.3), 17.5, 18.5 - 4.0 * m]))
-    xyz = np.round(np.array(sites), 8)
-    n = len(xyz)
-    return {"elements": np.array(["C"] * n), "atom_ids": np.array(["C"] * n), "coordinates": xyz,
-            "unit_cell": np.array([L, L, L, 90.0, 90.0, 90.0]), "lattice": np.eye(3) * L}
+def load_limits():
+    """tests/golden/rebuild_limits.npz: the reference's own output on synth.threshold_cell() - carbon pairs 3e-7 and
+    1e-8 either side of the limits of its bond test (Rcov sum -+ tol, max_dist), along an axis, along diagonals and
+    through a cell face (make_golden.py rebuild_limits)."""
+    from pywindow_amd import synth
 
-
-def same_molecules(got, want, where):
-    assert len(got) == len(want), f"{where}: {len(got)} molecules, oracle {len(want)}"
-    for k, (g, w) in enumerate(zip(got, want)):
-        assert list(g["elements"]) == list(w["elements"]), f"{where}: molecule {k}"
-        assert np.array_equal(np.asarray(g["coordinates"]), np.asarray(w["coordinates"])), f"{where}: molecule {k}"
+    g = np.load(GOLDEN / "rebuild_limits.npz")
+    system = {k.split("__in_")[1]: g[k] for k in g.files if k.startswith("limits__in_")}
+    expect = {k.split("__")[1]: g[k] for k in g.files if k.startswith("limits__") and "__in_" not in k}
+    fresh = synth.threshold_cell()                      # the fixture is what the generator makes today
+    assert np.array_equal(fresh["coordinates"], system["coordinates"]) and list(fresh["elements"]) == list(system["elements"])
+    return system, expect
 
 
 def test_pairs_at_the_limits_of_the_bond_test_host(hostsim):
+    """The pairs whose bond test cannot be made once per frame are tested where the walk meets them:
+    oracle and host-compiled kernel source (every memory layout) against the reference's output."""
     from oracle import pw_rebuild as R
 
-    system = threshold_system()
-    want_plain = R.discrete_molecules(system)
-    want = R.discrete_molecules(system, rebuild=R.create_supercell(system))
-    assert 2 < len(want) < len(system["elements"])           # some pairs bond, some do not
+    system, expect = load_limits()
+    n_plain, n_reb = len(expect["plain_offset"]) - 1, len(expect["rebuild_offset"]) - 1
+    assert 2 < n_reb < n_plain < len(system["elements"])           # some pairs bond, some do not, some only by image
+    check_molecules(R.discrete_molecules(system), expect, "plain", "oracle/limits")
+    check_molecules(R.discrete_molecules(system, rebuild=R.create_supercell(system)), expect, "rebuild", "oracle/limits/rebuild")
     for bits in (1, 3, 0):
         mols, status = run_hostsim(hostsim, system, False, with_bits=bits)
         assert status == 0
-        same_molecules(mols, want_plain, f"hostsim/{bits}/plain")
+        check_molecules(mols, expect, "plain", f"hostsim/{bits}/limits")
         mols, status = run_hostsim(hostsim, system, True, with_bits=bits)
         assert status == 0
-        same_molecules(mols, want, f"hostsim/{bits}/rebuild")
+        check_molecules(mols, expect, "rebuild", f"hostsim/{bits}/limits/rebuild")
 
 
 @pytest.mark.gpu
 def test_pairs_at_the_limits_of_the_bond_test_hip(hip_ctx):
-    from oracle import pw_rebuild as R
-
-    system = threshold_system()
-    same_molecules(RB.discrete_molecules(dict(system)), R.discrete_molecules(system), "hip/plain")
-    same_molecules(RB.discrete_molecules(dict(system), rebuild=True),
-                   R.discrete_molecules(system, rebuild=R.create_supercell(system)), "hip/rebuild")
+    system, expect = load_limits()
+    check_molecules(RB.discrete_molecules(dict(system)), expect, "plain", "hip/limits")
+    check_molecules(RB.discrete_molecules(dict(system), rebuild=True), expect, "rebuild", "hip/limits/rebuild")
 
 
 @pytest.mark.gpu
