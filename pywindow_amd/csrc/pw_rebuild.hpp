@@ -18,9 +18,11 @@
 //   * an atom of the central image whose value equals the cell atom's is the SAME list item
 //     (canonical id = the cell atom); all other image atoms are items of their own;
 //   * per visited heavy atom the reference scans the remaining cell atoms in index order,
-//     then the supercell in (image, atom) order; here only a conservative candidate list is
-//     scanned (translation-invariant, built once per frame) and the hits are ordered by
-//     that same position key before they are merged;
+//     then the supercell in (image, atom) order; here the pairs that can bond are found once
+//     per frame around the atoms of the central image (uniform grid, single-precision screen,
+//     then the reference's own test - see "candidate lists" in rebuild_frame) and the walk
+//     looks an atom's list up; the hits enter the merge in that same order (cell atoms first,
+//     then images) by construction of the lists;
 //   * bond test = the reference's two formulas: scikit-learn's euclidean_distances for the
 //     0.1 < d < max_dist pre-filter, distance() (utilities.py:80-93) against Rcov_i + Rcov_j
 //     +- tol.
