@@ -17,7 +17,7 @@ cd /tmp; export TMPDIR=/tmp
 export PW_STREAM_PROBE=0     # (counter passes serialise kernels: keep the pipeline's launch shape anyway)
 T=$R/tests/tools
 python3 $R/bench.py --steps 100 --warmup 5 > $O/bench.json 2> $O/bench.err
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/ov -o ov --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/ov.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/ov -o ov --output-format csv -- python3 $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-secondary > $O/ov.log 2>&1
 cp $(find $O/ov -name "*kernel_stats.csv" | head -1) $O/overlapped_kernel_stats.csv
 ( export PW_TAIL_GATE=0 PW_HEAD_GATE=0 PW_SETS_IN_FLIGHT=2
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/se -o se --output-format csv -- python3 $T/timeline.py 1000 20 > $O/se.log 2>&1 )
