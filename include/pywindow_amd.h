@@ -16,6 +16,25 @@
  * FALLBACK: without a usable HIP device every compute call on a device context
  * fails with PW_E_NO_DEVICE.  (A host context, pw_context_create(-1, ..), is an
  * explicit choice of the caller and runs the same source on host threads.)
+ *
+ * Threads (the reference's workers are stateless processes,
+ * trajectory.py:564-582).  Every entry point that takes a pw_context holds that
+ * context's mutex for the duration of the call: any number of threads may call
+ * into ONE context, their calls run one after the other, and different contexts
+ * share no mutable state -- two threads with a context each (even on the same
+ * device) never wait for one another in the library.  pw_last_error() is per
+ * thread.  What the library cannot see is which calls belong together.  Three
+ * pieces of per-context state outlive a call, and a caller that shares a context
+ * between threads keeps each sequence together itself (the Python binding holds
+ * Context.lock across them):
+ *   - the page-locked staging buffer: pw_context_pinned .. pw_resident_upload
+ *     (the buffer is free again when the upload returns);
+ *   - "the records fetched last": pw_resident_download / pw_resident_extra_windows
+ *     .. pw_context_extra_windows;
+ *   - the knobs: pw_context_set_params .. the launches that should see them.
+ * pw_history handles are read-only after pw_history_open and may be read from
+ * any number of threads.  A second live device context on a device runs its
+ * analyses as single launches (pw_context_pipelined), not as the pipeline.
  */
 #ifndef PYWINDOW_AMD_H
 #define PYWINDOW_AMD_H
@@ -197,6 +216,11 @@ int pw_context_pipelined(pw_context *ctx);
 int pw_context_gate_timeouts(pw_context *ctx, uint64_t *count);
 /* sampling vectors the team workspaces of this context currently hold per molecule (>= PW_P_MAX) */
 int pw_context_point_capacity(pw_context *ctx);
+/* at least n_points sampling vectors per molecule in the workspaces of every later launch.  pw_analysis_batch
+ * does this by itself when a unit carries PW_ST_POINTS_OVERFLOW (the reference's count
+ * int(log10(4 pi R^2) * 250 * adjust), utilities.py:1409, 1616, has no upper limit); callers of the
+ * pw_resident_* entry points read n_points / n_points_avg of the flagged records, reserve, launch again. */
+int pw_context_reserve_points(pw_context *ctx, int64_t n_points);
 
 /* The same analysis with the intermediate results of find_windows captured per unit (dbg: n_units
  * records, caller-allocated).  Test instrumentation: one launch at a time, no overlap. */
@@ -338,6 +362,12 @@ int pw_history_imcon(const pw_history *h);
 int64_t pw_history_atom_keys(const pw_history *h, char *buf, int64_t buflen);
 /* coordinates of frames [first, first+count) -> xyz[count][natoms][3]; lattice[count][9] may be NULL */
 int pw_history_read(const pw_history *h, int64_t first, int64_t count, double *xyz, double *lattice);
+/* nstep and tstep of the "timestep" record of one frame (reference: frame_info, trajectory.py:712-721; natms,
+ * keytrj and imcon of the record are the file's: pw_history_atoms / _keytrj / _imcon) */
+int pw_history_frame_info(const pw_history *h, int64_t frame, int64_t *nstep, double *tstep);
+/* host threads the reader decodes with (PW_READER_THREADS or the hardware concurrency, at most 16; they are
+ * started once per process and parked between calls) */
+int pw_history_reader_threads(void);
 void pw_history_close(pw_history *h);
 
 #ifdef __cplusplus

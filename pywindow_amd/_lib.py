@@ -220,6 +220,7 @@ EXPORTED_SYMBOLS = [
     "pw_analysis_batch",
     "pw_context_extra_windows",
     "pw_context_point_capacity",
+    "pw_context_reserve_points",
     "pw_context_pipelined",
     "pw_context_gate_timeouts",
     "pw_analysis_debug",
@@ -251,6 +252,8 @@ EXPORTED_SYMBOLS = [
     "pw_history_imcon",
     "pw_history_atom_keys",
     "pw_history_read",
+    "pw_history_frame_info",
+    "pw_history_reader_threads",
     "pw_history_close",
 ]
 
@@ -319,6 +322,7 @@ def load():
     L.pw_context_extra_windows.argtypes = [vp, vp, ctypes.c_int64]
     L.pw_context_extra_windows.restype = ctypes.c_int64
     L.pw_context_point_capacity.argtypes = [vp]
+    L.pw_context_reserve_points.argtypes = [vp, ctypes.c_int64]
     L.pw_context_pipelined.argtypes = [vp]
     L.pw_context_gate_timeouts.argtypes = [vp, vp]
     L.pw_point_gaps.argtypes = [vp, ctypes.POINTER(BatchIn), vp, vp, ctypes.c_int64, vp, vp]
@@ -357,6 +361,8 @@ def load():
     L.pw_history_atom_keys.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
     L.pw_history_atom_keys.restype = ctypes.c_int64
     L.pw_history_read.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, vp]
+    L.pw_history_frame_info.argtypes = [vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
+    L.pw_history_reader_threads.argtypes = []
     L.pw_history_close.argtypes = [vp]
     L.pw_history_close.restype = None
     _lib = L
@@ -424,6 +430,11 @@ class Context:
         import threading
 
         self._params_lock = threading.Lock()
+        #: held across the multi-call protocols that go through per-context state -- the page-locked staging
+        #: buffer (pinned_array -> upload), "the records fetched last" (download -> extra_windows), the capacities
+        #: a repeated launch relies on.  The C library serialises single calls on a context by itself
+        #: (include/pywindow_amd.h, "Threads"); what belongs together is the caller's to keep together.
+        self.lock = threading.RLock()
 
     def close(self):
         if self._h:
@@ -476,6 +487,12 @@ class Context:
         v = ctypes.c_uint64(0)
         _check(load().pw_context_gate_timeouts(self._h, ctypes.byref(v)), "pw_context_gate_timeouts")
         return {"tail": int(v.value & 0xffff), "head": int((v.value >> 16) & 0xffff), "residency": int(v.value >> 32)}
+
+    def reserve_points(self, n_points: int) -> None:
+        """At least ``n_points`` sampling vectors per molecule in the workspaces of every later launch
+        (``pw_context_reserve_points``): what ``pw_analysis_batch`` does by itself when a unit asks for more
+        than the ``adjust`` knobs imply, for callers of the resident entry points."""
+        _check(load().pw_context_reserve_points(self._h, int(n_points)), "pw_context_reserve_points")
 
     @property
     def point_capacity(self) -> int:
@@ -688,6 +705,25 @@ class Resident:
             if extra is not None and (out["status"] & ST_WINDOW_OVERFLOW).any():
                 extra.append(self.ctx.extra_windows())
         return out
+
+    def download_settled(self, extra=None) -> np.ndarray:
+        """``download`` for the resident path with what ``pw_analysis_batch`` does for the one-call path: a
+        unit that wanted more sampling vectors than the launch's workspace held (``PW_ST_POINTS_OVERFLOW``:
+        a sphere of thousands of angstroms) raises the context's capacity and the analysis is launched again,
+        so no capacity of the engine shows in a result.  Download and extra windows under the context's lock."""
+        with self.ctx.lock:
+            for _attempt in range(3):
+                mine = []
+                out = self.download(mine)
+                flagged = out[(out["status"] & ST_POINTS_OVERFLOW) != 0]
+                want = int(max(flagged["n_points"].max(), flagged["n_points_avg"].max())) if len(flagged) else 0
+                if want <= self.ctx.point_capacity:
+                    break
+                self.ctx.reserve_points(want)
+                self.launch(getattr(self, "_stages", STAGE_ALL))
+            if extra is not None:
+                extra.extend(mine)
+            return out
 
     def check(self) -> np.ndarray:
         """For callers that read the records on the device: wait for the latest launch, raise if its

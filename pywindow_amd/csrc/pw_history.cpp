@@ -19,6 +19,11 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <pthread.h>
+
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -37,6 +42,94 @@ struct pw_history {
 };
 
 namespace {
+
+// ---- reader threads -------------------------------------------------------------------------------------
+// Indexing a file and decoding a block of frames are cut into independent ranges for up to 16 host threads.
+// The threads are started ONCE per process and parked on a condition variable between calls (spawning and
+// joining sixteen std::threads cost 0.2-0.4 ms of every call -- a tenth of a 1000-frame analysis end to end);
+// the calling thread takes range 0 itself.  One parallel region at a time: a second caller that finds the
+// team busy runs its ranges on threads of its own, as every call used to.  A forked child starts a fresh team.
+class ReaderTeam {
+  public:
+    static int max_threads() {
+        unsigned hw = std::thread::hardware_concurrency();
+        int n = hw ? (int)hw : 1;
+        if (const char* e = getenv("PW_READER_THREADS")) if (atoi(e) > 0) n = atoi(e);
+        return n > 16 ? 16 : n;
+    }
+    // fn(t) for t in [0, n): returns when all have run
+    static void run(int n, const std::function<void(int)>& fn) {
+        if (n <= 1) { if (n == 1) fn(0); return; }
+        ReaderTeam* team = instance();
+        std::unique_lock<std::mutex> region(team->region_, std::try_to_lock);
+        if (!region.owns_lock() || !team->start(n - 1)) {
+            std::vector<std::thread> own;
+            for (int t = 1; t < n; ++t) own.emplace_back(fn, t);
+            fn(0);
+            for (auto& th : own) th.join();
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(team->m_);
+            team->fn_ = &fn;
+            team->n_ = n;
+            team->next_ = 1;
+            team->left_ = n - 1;
+            team->epoch_ += 1;
+        }
+        team->wake_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> g(team->m_);
+        team->done_.wait(g, [&] { return team->left_ == 0; });
+        team->fn_ = nullptr;
+    }
+
+  private:
+    static ReaderTeam*& slot() { static ReaderTeam* t = nullptr; return t; }
+    static ReaderTeam* instance() {
+        static std::once_flag once;
+        std::call_once(once, [] {
+            slot() = new ReaderTeam();
+            // the threads do not exist in a forked child: it gets a team of its own on first use
+            pthread_atfork(nullptr, nullptr, [] { slot() = new ReaderTeam(); });
+        });
+        return slot();
+    }
+    bool start(int want) {          // (caller holds region_)
+        try {
+            while ((int)threads_.size() < want && (int)threads_.size() < 15) {
+                threads_.emplace_back([this] { loop(); });
+                threads_.back().detach();
+            }
+        } catch (...) {
+        }
+        return (int)threads_.size() >= want;
+    }
+    void loop() {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(int)>* fn = nullptr;
+            int t = -1;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                wake_.wait(g, [&] { return epoch_ != seen && next_ < n_; });
+                // (several ranges may be left: take one, stay awake for the next)
+                t = next_++;
+                fn = fn_;
+                if (next_ >= n_) seen = epoch_;
+            }
+            (*fn)(t);
+            std::lock_guard<std::mutex> g(m_);
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    std::mutex region_, m_;
+    std::condition_variable wake_, done_;
+    std::vector<std::thread> threads_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int n_ = 0, next_ = 0, left_ = 0;
+    unsigned long epoch_ = 0;
+};
 
 inline const char* line_end(const char* p, const char* end) {
     const char* q = (const char*)memchr(p, '\n', (size_t)(end - p));
@@ -203,9 +296,7 @@ int pw_history_open(const char* path, pw_history** out) {
     }
     // frame starts: lines whose first token is "timestep".  The file is cut into byte ranges, one
     // host thread each; a range begins at the first line start at or after its first byte.
-    unsigned hw = std::thread::hardware_concurrency();
-    int nthreads = hw ? (int)hw : 1;
-    if (nthreads > 16) nthreads = 16;
+    int nthreads = ReaderTeam::max_threads();
     if ((size_t)nthreads > h->size / (1u << 20)) nthreads = (int)(h->size / (1u << 20));
     if (nthreads < 1) nthreads = 1;
     std::vector<std::vector<size_t>> found((size_t)nthreads);
@@ -223,13 +314,7 @@ int pw_history_open(const char* path, pw_history** out) {
             p = le < end ? le + 1 : end;
         }
     };
-    if (nthreads == 1) {
-        scan(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthreads; ++t) pool.emplace_back(scan, t);
-        for (auto& th : pool) th.join();
-    }
+    ReaderTeam::run(nthreads, scan);
     for (auto& part : found)
         for (size_t off : part) {
             if (!h->frame_start.empty()) h->frame_end.push_back(off);
@@ -293,19 +378,33 @@ int pw_history_read(const pw_history* h, int64_t first, int64_t count, double* x
     if (!h || !xyz || first < 0 || count < 0 || first + count > (int64_t)h->frame_start.size())
         return PW_E_BAD_ARG;
     // frames are independent: decode them on several host threads
-    unsigned hw = std::thread::hardware_concurrency();
-    int64_t nthreads = hw ? (int64_t)hw : 1;
-    if (nthreads > 16) nthreads = 16;
+    int64_t nthreads = ReaderTeam::max_threads();
     if (nthreads > count / 16) nthreads = count / 16;
     if (nthreads <= 1) return read_range(h, first, 0, count, xyz, lattice);
-    std::vector<std::thread> pool;
     std::vector<int> rcs((size_t)nthreads, PW_OK);
-    for (int64_t t = 0; t < nthreads; ++t) {
-        int64_t f0 = count * t / nthreads, f1 = count * (t + 1) / nthreads;
-        pool.emplace_back([&, t, f0, f1]() { rcs[(size_t)t] = read_range(h, first, f0, f1, xyz, lattice); });
-    }
-    for (auto& th : pool) th.join();
+    ReaderTeam::run((int)nthreads, [&](int t) {
+        const int64_t f0 = count * t / nthreads, f1 = count * (t + 1) / nthreads;
+        rcs[(size_t)t] = read_range(h, first, f0, f1, xyz, lattice);
+    });
     for (int rc : rcs) if (rc != PW_OK) return rc;
+    return PW_OK;
+}
+
+int pw_history_reader_threads(void) { return ReaderTeam::max_threads(); }
+
+// nstep and tstep of the "timestep" record of frame f (the reference keeps them as frame_info,
+// trajectory.py:712-721)
+int pw_history_frame_info(const pw_history* h, int64_t frame, int64_t* nstep, double* tstep) {
+    if (!h || frame < 0 || frame >= (int64_t)h->frame_start.size()) return PW_E_BAD_ARG;
+    const char* p = h->data + h->frame_start[(size_t)frame];
+    const char* end = h->data + h->frame_end[(size_t)frame];
+    const char* le = line_end(p, end);
+    const char* q = skip_ws(p, le);
+    while (q < le && *q != ' ' && *q != '\t') ++q;
+    double v[5];
+    if (parse_doubles(q, le, v, 5) != 5) return PW_E_BAD_ARG;
+    if (nstep) *nstep = (int64_t)v[0];
+    if (tstep) *tstep = v[4];
     return PW_OK;
 }
 

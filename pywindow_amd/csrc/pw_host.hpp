@@ -23,3 +23,19 @@ struct DeviceScope {
 };
 
 }  // namespace pw
+
+// Threads (include/pywindow_amd.h, "Threads"): every entry point that takes a context holds the context's
+// mutex for the duration of the call, so calls from several threads on ONE context are serialised and
+// contexts never share mutable state.  Recursive: entry points are built from each other
+// (pw_analysis_batch = upload + launch + download).
+struct pw_context;
+extern "C" void pw_internal_lock(pw_context* ctx);
+extern "C" void pw_internal_unlock(pw_context* ctx);
+struct PwContextLock {
+    pw_context* c;
+    explicit PwContextLock(pw_context* c_) : c(c_) { if (c) pw_internal_lock(c); }
+    ~PwContextLock() { if (c) pw_internal_unlock(c); }
+    PwContextLock(const PwContextLock&) = delete;
+    PwContextLock& operator=(const PwContextLock&) = delete;
+};
+#define PW_LOCK_CONTEXT(c) PwContextLock ctx_lock_(c)

@@ -28,6 +28,10 @@ namespace {
 // neighbour tables of the sampling sphere (pw_unit.hpp), built per vector count on first use
 struct HostTables {
     std::mutex lock;
+    // bumped (release) after a table has been appended: a worker copies `off` under the lock when the version
+    // it last saw is stale, and reads rows only through its copy -- every row it can reach was complete before
+    // the version it acquired (no plain read of memory another thread may be writing)
+    std::atomic<unsigned> version{0};
     std::vector<unsigned> off = std::vector<unsigned>(PW_NB_PMAX + 1, PW_NB_NONE);
     // one allocation per P (pointers handed to running threads must stay valid): offsets index `rows`
     std::vector<unsigned short> idx;
@@ -52,8 +56,16 @@ struct HostTables {
         bound.resize(first + P);
         for (int k = 0; k < P; ++k)
             nb_build_point(P, k, ux.data(), uy.data(), uz.data(), idx.data() + (first + k) * PW_NB_K, bound.data() + first + k);
-        std::atomic_thread_fence(std::memory_order_release);
         off[P] = (unsigned)first;
+        version.fetch_add(1, std::memory_order_release);
+    }
+    // the worker's private view of `off` (see `version`)
+    void snapshot(std::vector<unsigned>& mine, unsigned& seen) {
+        const unsigned v = version.load(std::memory_order_acquire);
+        if (v == seen && !mine.empty()) return;
+        std::lock_guard<std::mutex> g(lock);
+        mine = off;
+        seen = version.load(std::memory_order_relaxed);
     }
 };
 HostTables g_tables;
@@ -78,15 +90,19 @@ extern "C" int pw_hostpath_run(const pw_batch_in* in, unsigned stages, pw_unit_o
     std::atomic<int> failed{0};
     unsigned xcount = 0;            // (bumped with atomic increments: pw_unit.hpp team_atomic_inc)
     const int vstride = in->template_atoms > 0 ? 0 : 1;
+    // PW_HOST_SPLIT=1: the window search in the pipeline's two parts (default: one team does it all)
+    const char* split_env = getenv("PW_HOST_SPLIT");
+    const bool split = split_env && split_env[0] == '1';
     auto worker = [&]() {
         const size_t bytes = UnitShared::bytes(nmax, 1, 8, 2, false, p_cap);
         unsigned char* lds = (unsigned char*)aligned_alloc(16, (bytes + 15) & ~(size_t)15);
         TeamWorkspace* ws = (TeamWorkspace*)calloc(1, sizeof(TeamWorkspace));
         unsigned char* slab = (unsigned char*)malloc(team_slab_bytes(p_cap));
         unsigned long long* adj = (unsigned long long*)malloc(sizeof(unsigned long long) * team_adj_words(p_cap));
-        if (!lds || !ws || !slab || !adj) {
+        unsigned char* fit_lds = (unsigned char*)aligned_alloc(16, (FitShared::bytes(nmax) + 15) & ~(size_t)15);
+        if (!lds || !ws || !slab || !adj || !fit_lds) {
             failed = 1;
-            free(lds); free(ws); free(slab); free(adj);
+            free(lds); free(ws); free(slab); free(adj); free(fit_lds);
             return;
         }
         bind_team_slab(ws, slab, p_cap);
@@ -94,22 +110,53 @@ extern "C" int pw_hostpath_run(const pw_batch_in* in, unsigned stages, pw_unit_o
         ws->rsq = g_rsq;
         ws->dbg_base = dbg;
         ws->xwin = xw; ws->xwin_cap = xw_cap; ws->xwin_count = &xcount;
+        std::vector<unsigned> nb_off;
+        unsigned nb_seen = 0;
         for (;;) {
             const long u = next.fetch_add(1);
             if (u >= n_units) break;
             ws->unit = u;
-            ws->nb_off = g_tables.off.data(); ws->nb_idx = g_tables.idx.data(); ws->nb_bound = g_tables.bound.data();
+            g_tables.snapshot(nb_off, nb_seen);
+            ws->nb_off = nb_off.data(); ws->nb_idx = g_tables.idx.data(); ws->nb_bound = g_tables.bound.data();
             memset(lds, 0, bytes);
             UnitShared sh;
             sh.carve(lds, nmax, 1, 8, 2, false, p_cap);
             const long a0 = (long)in->atom_offset[u];
             const int n = (int)(in->atom_offset[u + 1] - a0);
             memset(&out[u], 0, sizeof(pw_unit_out));
-            analyse_unit<HostTeam>(sh, ws, n, in->xyz + 3 * a0, in->vdw + a0 * vstride, in->mass + a0 * vstride, stages,
-                                   &out[u], prm);
+            if (split && (stages & PW_STAGE_WINDOWS)) {
+                // the pipeline's launch shape, one step after the other: sampling up to the clustering, the
+                // clusters handed over in a ticket, every fit on a frame of its own, the record assembled last
+                // (pw_kernels.hip: the sampling launch and the fit workers); a unit with more clusters than a
+                // ticket holds goes through the fused window search instead
+                const double* xyz = in->xyz + 3 * a0;
+                const double* vdw = in->vdw + a0 * vstride;
+                FitTicket ticket;
+                memset(&ticket, 0, sizeof(ticket));
+                int ncl = -1;
+                analyse_unit<HostTeam>(sh, ws, n, xyz, vdw, in->mass + a0 * vstride,
+                                       (stages & ~PW_STAGE_WINDOWS) | PW_STAGE_WIN_BULK, &out[u], prm, &ticket, &ncl);
+                if (ncl > PW_W_MAX) {
+                    analyse_unit<HostTeam>(sh, ws, n, xyz, vdw, in->mass + a0 * vstride,
+                                           PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, &out[u], prm);
+                } else if (ncl >= 1) {
+                    FitShared fs;
+                    fs.carve(fit_lds, nmax);
+                    int evals = 0;
+                    for (int c = 0; c < ncl; ++c) {
+                        memset(fit_lds, 0xff, FitShared::bytes(nmax));       // (nothing may depend on what the block held)
+                        evals += fit_item<HostTeam>(fs, ws, n, xyz, vdw, &out[u], &ticket, c, prm);
+                    }
+                    out[u].status |= windows_finish(ticket_arrays(&ticket), ncl, &out[u], ws, u);
+                    out[u].n_eval += evals;
+                }
+            } else {
+                analyse_unit<HostTeam>(sh, ws, n, in->xyz + 3 * a0, in->vdw + a0 * vstride, in->mass + a0 * vstride, stages,
+                                       &out[u], prm);
+            }
             if ((stages & PW_STAGE_WINDOWS) && out[u].n_points >= PW_NB_PMIN) g_tables.ensure(out[u].n_points);
         }
-        free(adj); free(slab); free(ws); free(lds);
+        free(adj); free(slab); free(ws); free(lds); free(fit_lds);
     };
     if (threads == 1) {
         worker();

@@ -19,6 +19,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 
 #include "../../include/pywindow_amd.h"
@@ -33,6 +34,12 @@ using namespace pw;
 extern "C" int pw_hostpath_run(const pw_batch_in* in, unsigned stages, pw_unit_out* out, const pw_params* prm, int p_cap,
                                int threads, pw_unit_debug* dbg, pw_extra_window* xw, unsigned xw_cap, unsigned* xw_count);
 extern "C" int pw_hostpath_default_threads(void);
+// pw_kernels_sampling.hip: the sampling launch of the split window search, a translation unit built for its own
+// register budget
+extern "C" int pw_internal_sampling_launch(void* stream, int grid, size_t lds_bytes, long n_units, const long* atom_offset,
+                                           const double* xyz, const double* vdw, const double* mass, int nmax, int nrot, int nlb,
+                                           const PwWsArgs* wsa, pw_unit_out* out, UnitQueue* queue, int* slots,
+                                           const pw_params* prm, const unsigned* rsq_tab, int vstride, const FitArgs* fa);
 // pw_kernels_big.hip: the same source with the team's shared block in global memory (molecules beyond LDS)
 extern "C" size_t pw_internal_big_block_bytes(int nmax, int p_cap);
 extern "C" int pw_internal_big_launch(void* stream, int grid, long n_units, const long* atom_offset, const double* xyz,
@@ -61,25 +68,12 @@ void set_err(const char* what, hipError_t e) {
     DeviceScope dev_scope_;                   \
     HIP_TRY(dev_scope_.enter(dev))
 
-// Hand-off between the optimiser launch (producer, one wave per unit) and the window
-// launch (consumer, persistent teams): a producer publishes the index of a unit whose pore
-// centre is in its result record, consumers take published units in completion order.
-//   producer: record stores -> s_waitcnt -> agent release fence -> s_waitcnt -> relaxed store
-//   consumer: ONE relaxed poll loop -> agent acquire fence -> s_waitcnt -> team barrier -> loads
-// (MI355X guide, "Inter-workgroup communication").  Every spin is bounded.
-struct UnitQueue {
-    unsigned long long tail;   // next free slot (producers)
-    unsigned long long head;   // next slot to consume
-    int error;                 // set when a consumer gives up waiting
-    int started;               // producer teams that have begun (gate for the other launches)
-};
-enum : int { PW_ROLE_PLAIN = 0, PW_ROLE_PRODUCER = 1, PW_ROLE_CONSUMER = 2 };
 // Successive analyses rotate through up to PW_SETS sets of (result buffer, queue, slots, streams,
 // events, team workspaces): that many analyses can be in flight, the optimiser chains of the later
 // ones filling the SIMDs that the long tails of the earlier ones leave idle.
 constexpr int PW_SETS = 4;      // (2 + 2 x PW_SETS streams, each needs a hardware queue of its own: GPU_MAX_HW_QUEUES = 12)
 
-constexpr unsigned MASK_ANY = 0xffffffffu;
+constexpr unsigned MASK_ANY = 0xffffffffu & ~PW_STAGE_WIN_BULK;      // (only the sampling launch carries that half-stage)
 constexpr unsigned MASK_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE;
 constexpr unsigned MASK_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
@@ -127,12 +121,12 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
                   const double* __restrict__ vdw, const double* __restrict__ mass, unsigned stages,
                   int nmax, int nrot, int nlb, int nframes, int lean, PwWsArgs wsa, unsigned long long* counter,
                   pw_unit_out* __restrict__ out, int role, UnitQueue* queue, int* __restrict__ slots,
-                  pw_params prm, const unsigned* __restrict__ rsq_tab, int vstride) {
+                  pw_params prm, const unsigned* __restrict__ rsq_tab, int vstride, FitArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ long s_unit;
     using T = DeviceTeam<NW>;
     UnitShared sh;
-    sh.carve(lds, nmax, nrot, nlb, nframes, lean != 0, wsa.p_cap);     // as planned by the host (plan_launch)
+    sh.carve(lds, nmax, nrot, nlb, nframes, lean, wsa.p_cap);     // as planned by the host (plan_launch)
     // the optimiser chains are latency-bound and on the critical path: when one shares a SIMD
     // with a bulk wave of another launch it must win the issue arbitration
     if (role == PW_ROLE_PRODUCER) {
@@ -163,6 +157,13 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
                 }
                 s_unit = u;
             }
+        } else if (role == PW_ROLE_LIST) {
+            // the units the sampling launch could not hand over (more clusters than a ticket holds): that launch
+            // has ended, so the list and its length are final
+            if (threadIdx.x == 0) {
+                long i = (long)atomicAdd(counter, 1ull);
+                s_unit = i < (long)fa.q->n_deferred ? (long)fa.deferred[i] : -1;
+            }
         } else {
             if (threadIdx.x == 0) {
                 long u = (long)atomicAdd(counter, 1ull);
@@ -192,150 +193,128 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
     }
 }
 
-// ---- experiment (PW_ROW_CHAINS=1): four optimiser chains per wavefront ----------------------------------
-// One chain per ROW of 16 lanes (RowTeam), rows refilled one by one as their chains end, the same Lbfgsb<3>
-// source.  The basic stage of the units (centre of mass, pore radius at it: the start and the box of the
-// optimisation) comes from a launch of its own, queued ahead on the same stream.  Publishes finished units
-// like the one-wave chains.  Default bounds / start only (pw_params::opt_flags == 0).
-__global__ void __launch_bounds__(64, 2)
-pw_row_chains_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
-                     const double* __restrict__ vdw, int vstride, int nmax, pw_unit_out* __restrict__ out,
-                     unsigned long long* counter, UnitQueue* queue, int* __restrict__ slots) {
+// ---- one-wave workers: optimiser chains AND window fits ----------------------------------------------------
+// The two serial, latency-bound parts of an analysis have the same shape -- one wave, a frame of the molecule
+// and one optimiser block in LDS, a 256-register budget -- so one launch of one-wave teams does both: a worker
+// takes a published fit item if there is one, else the next unit whose pore-centre chain has not started, and
+// when there is neither it leaves (its SIMD slot and LDS go to the next analysis), except the first n_pool
+// workers, which wait until the sampling launch has closed the fit queue.  The chains are what stage_basic +
+// stage_opt were in the optimiser launch (published to `queue` for the sampling teams); a fit is fit_item
+// (pw_unit.hpp): the frame shifted on the way in, one cluster of the unit's ticket, and the worker that
+// finishes a unit's last cluster assembles the record.
+__device__ inline long wave_uniform_long(long v) {
+    union { long l; int i[2]; } a;
+    a.l = v;
+    a.i[0] = __builtin_amdgcn_readfirstlane(a.i[0]);
+    a.i[1] = __builtin_amdgcn_readfirstlane(a.i[1]);
+    return a.l;
+}
+__global__ void __launch_bounds__(64, PW_OCC_A)
+pw_worker_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
+                 const double* __restrict__ vdw, const double* __restrict__ mass, int nmax, PwWsArgs wsa,
+                 unsigned long long* counter, pw_unit_out* __restrict__ out, UnitQueue* queue, int* __restrict__ slots,
+                 pw_params prm, const unsigned* __restrict__ rsq_tab, int vstride, FitArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    using T = RowTeam;
-    const int row = threadIdx.x >> 4, l = threadIdx.x & 15;
-    const size_t nn = (size_t)((nmax + 1) & ~1);
-    const size_t row_bytes = nn * 8 * 5 + ((sizeof(LbMem<3>) + 15) & ~(size_t)15);
-    PW_LDS unsigned char* base = (PW_LDS unsigned char*)lds + row * row_bytes;
-    Frame F;
-    F.x = (ldouble*)base; F.y = F.x + nn; F.z = F.y + nn; F.xx = F.z + nn;
-    ldouble* rv = F.xx + nn;
-    F.vdw = rv; F.perm = nullptr; F.cls = nullptr;
-    LbMem<3>* Smem = (LbMem<3>*)(rv + nn);
+    using T = DeviceTeam<1>;
+    UnitShared sh;
+    sh.carve(lds, nmax, 0, 1, 1, 1, wsa.p_cap);      // a chain: the input frame, no window variables, one optimiser block
+    FitShared fs;
+    fs.carve(lds, nmax);                             // a fit: the same bytes laid out for it
     __builtin_amdgcn_s_setprio(PW_A_PRIO);
     if (threadIdx.x == 0) atomicAdd(&queue->started, 1);
-    Lbfgsb<3> S;
-    int state = 0;      // 0 wants a unit, 1 optimising, 2 no more units
-    long unit = -1;
-    int n = 0;
-    double lo[3] = {0, 0, 0}, up[3] = {0, 0, 0}, x0[3] = {0, 0, 0};
-    int nit = 0, nfev = 0;
-    bool have_last = false, bad = false, limit = false;
-    double lx = 0, ly = 0, lz = 0, lf = 0, lg0 = 0, lg1 = 0, lg2 = 0;
-    S.task = LB_STOP;
-    S.msg = 0;
+    TeamWorkspace* ws = (TeamWorkspace*)wsa.ws + blockIdx.x;
+    if (threadIdx.x == 0) bind_workspace(ws, wsa, blockIdx.x, rsq_tab, team_slab_bytes(wsa.p_cap), team_adj_words(wsa.p_cap));
+    T::wave_sync();
+    bool chains_left = true;
     for (;;) {
-        if (state == 0) {
-            long u = -1;
-            if (l == 0) u = (long)atomicAdd(counter, 1ull);
-            u = __shfl(u, 0, 16);
-            if (u >= n_units) state = 2;
-            else {
-                unit = u;
-                const long a0 = atom_offset[u];
-                n = (int)(atom_offset[u + 1] - a0);
-                const double* c = xyz + 3 * a0;
-                const double* vd = vdw + a0 * vstride;
-                for (int i = l; i < n; i += 16) {
-                    double x = c[3 * i], y = c[3 * i + 1], z = c[3 * i + 2];
-                    F.x[i] = x; F.y[i] = y; F.z[i] = z; F.xx[i] = sq3(x, y, z); rv[i] = vd[i];
-                }
-                // the basic stage's results (an earlier launch on this stream wrote them)
-                const double r0 = out[u].pore_d / 2.0;          // pore_d = gap * 2: the division is exact
-                int nbd[3] = {2, 2, 2};
-                for (int k = 0; k < 3; ++k) { x0[k] = out[u].com[k]; lo[k] = x0[k] - r0; up[k] = x0[k] + r0; }
-                bad = !(r0 > 0.0);
-                T::wave_sync();
-                nit = 0; nfev = 0; have_last = false; limit = false;
-                S.task = LB_STOP;
-                if (!bad) S.template setup<T>(Smem, x0, lo, up, nbd, 1e7, 1e-5, 20);
-                state = 1;
-            }
-        }
-        if (__all(state == 2)) break;
-        if (state == 1) {
-            if (!bad) {
-                if (S.task == LB_FG) {
-                    const double px = S.x[0], py = S.x[1], pz = S.x[2];
-                    if (!(have_last && px == lx && py == ly && pz == lz)) {
-                        // f and the three forward-difference points (stage_opt), all four by this row: every
-                        // atom read serves the four of them
-                        double qx[4] = {px, px, px, px}, qy[4] = {py, py, py, py}, qz[4] = {pz, pz, pz, pz}, dxs[3];
-                        for (int c = 0; c < 3; ++c) {
-                            const double xc = c == 0 ? px : (c == 1 ? py : pz);
-                            const double h = fd_step(xc, lo[c], up[c]);
-                            const double x1 = xc + h;
-                            dxs[c] = x1 - xc;
-                            if (c == 0) qx[1] = x1; else if (c == 1) qy[2] = x1; else qz[3] = x1;
-                        }
-                        double pp[4], best[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { pp[q] = sq3(qx[q], qy[q], qz[q]); best[q] = PW_INF; }
-                        for (int i = l; i < n; i += 16) {
-                            const double ax = F.x[i], ay = F.y[i], az = F.z[i], aq = F.xx[i], ar = rv[i];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const double g = pw_fma(az, qz[q], pw_fma(ax, qx[q], ay * qy[q]));
-                                const double d2 = pw_m2add(g, aq) + pp[q];
-                                const double d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
-                                best[q] = __builtin_fmin(best[q], d - ar);
-                            }
-                        }
-                        double gv[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) gv[q] = T::row_min(best[q]);
-                        const double f0 = -(gv[0] * 2.0);
-                        lg0 = (-(gv[1] * 2.0) - f0) / dxs[0];
-                        lg1 = (-(gv[2] * 2.0) - f0) / dxs[1];
-                        lg2 = (-(gv[3] * 2.0) - f0) / dxs[2];
-                        lf = f0; lx = px; ly = py; lz = pz;
-                        have_last = true;
-                        nfev += 4;
+        // 1. a fit that is ready?  (head never passes tail: items are taken with a compare-and-swap)
+        long item = -1;
+        if (threadIdx.x == 0) {
+            for (;;) {
+                unsigned long long h = __hip_atomic_load(&fa.q->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long t = __hip_atomic_load(&fa.q->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (h >= t) break;
+                if (__hip_atomic_compare_exchange_strong(&fa.q->head, &h, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT)) {
+                    // the publisher stores the slot right after moving the tail: a short wait at most
+                    long long t0 = wall_clock64();
+                    for (;;) {
+                        const int v = __hip_atomic_load(&fa.slots2[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (v >= 0) { item = v; break; }
+                        __builtin_amdgcn_s_sleep(4);
+                        if (wall_clock64() - t0 > 500000000ll) { atomicExch(&fa.q->error, 1); break; }
                     }
-                    S.f = lf;
-                    S.g[0] = lg0; S.g[1] = lg1; S.g[2] = lg2;
-                    T::wave_sync();
-                } else if (S.task == LB_NEW_X) {
-                    nit += 1;
-                    if (nit >= 15000 || nfev > 15000) limit = true;      // scipy's driver: tested at a new iterate only
-                }
-                if (!limit) {
-                    S.template step<T>();
-                    T::wave_sync();
-                }
-            }
-            if (bad || limit || (S.task != LB_FG && S.task != LB_NEW_X)) {
-                // the chain has ended: diameter and closest atom at its last point, the record, the hand-over
-                const double cx = bad ? x0[0] : S.x[0], cy = bad ? x0[1] : S.x[1], cz = bad ? x0[2] : S.x[2];
-                const double pp = sq3(cx, cy, cz);
-                double gbest = PW_INF;
-                int gi = 0x7fffffff;
-                for (int i = l; i < n; i += 16) {
-                    const double v = gap_atom(F, i, cx, cy, cz, pp);
-                    if (v < gbest || (v == gbest && i < gi)) { gbest = v; gi = i; }
-                }
-                T::row_argmin(gbest, gi);
-                if (l == 0) {
-                    pw_unit_out* o = out + unit;
-                    o->pore_opt_d = gbest * 2.0;
-                    o->pore_opt_atom = gi;
-                    o->pore_opt_c[0] = cx; o->pore_opt_c[1] = cy; o->pore_opt_c[2] = cz;
-                    const double rr = o->pore_opt_d / 2.0;
-                    o->pore_vol_opt = FOUR_THIRDS_PI * pw_cube_np(rr);
-                    o->opt_nit = nit;
-                    o->opt_nfev = nfev;
-                    o->opt_task = bad ? -1 : S.task;
-                    o->opt_msg = bad ? 0 : S.msg;
-                    record_or_status(o, bad ? PW_ST_NEGATIVE_PORE : 0, nfev + 1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const long pos = (long)atomicAdd(&queue->tail, 1ull);
-                    __hip_atomic_store(&slots[pos], (int)unit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
                 }
-                state = 0;
             }
         }
+        item = wave_uniform_long(item);
+        if (item >= 0) {
+            const long u = item >> 4;
+            const int cluster = (int)(item & 15);
+            const long a0 = atom_offset[u];
+            const int n = (int)(atom_offset[u + 1] - a0);
+            if (threadIdx.x == 0) ws->unit = u;
+            T::wave_sync();
+            FitTicket* ticket = (FitTicket*)fa.tickets + u;
+            const int evals = fit_item<T>(fs, ws, n, xyz + 3 * a0, vdw + a0 * vstride, out + u, ticket, cluster, prm);
+            if (threadIdx.x == 0) {
+                atomicAdd(&out[u].n_eval, evals);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                const int left = atomicSub(&ticket->remaining, 1);
+                if (left == 1) {
+                    // the unit's last fit: every other worker's results are visible after the acquire
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const int st = windows_finish(ticket_arrays(ticket), ticket->ncl, out + u, ws, u);
+                    if (st) atomicOr(&out[u].status, st);
+                }
+            }
+            T::wave_sync();
+            continue;
+        }
+        // 2. a chain that has not started?
+        long u = -1;
+        if (chains_left) {
+            if (threadIdx.x == 0) u = (long)atomicAdd(counter, 1ull);
+            u = wave_uniform_long(u);
+            if (u >= n_units) { u = -1; chains_left = false; }
+        }
+        if (u >= 0) {
+            const long a0 = atom_offset[u];
+            const int n = (int)(atom_offset[u + 1] - a0);
+            const long v0 = a0 * vstride;
+            if (threadIdx.x == 0) ws->unit = u;
+            analyse_unit<T, MASK_CHAINS>(sh, ws, n, xyz + 3 * a0, vdw + v0, mass + v0, MASK_CHAINS, out + u, prm);
+            if (threadIdx.x == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                long pos = (long)atomicAdd(&queue->tail, 1ull);
+                __hip_atomic_store(&slots[pos], (int)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            continue;
+        }
+        // 3. nothing to do right now: only the pool stays, until there is a fit or there will never be another
+        if ((int)blockIdx.x >= fa.n_pool) break;
+        int leave = 0;
+        if (threadIdx.x == 0) {
+            long long t0 = wall_clock64();
+            for (;;) {
+                const unsigned long long h = __hip_atomic_load(&fa.q->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long t = __hip_atomic_load(&fa.q->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (h < t) break;
+                const unsigned long long fin = __hip_atomic_load(&fa.q->final, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (h >= fin) { leave = 1; break; }
+                __builtin_amdgcn_s_sleep(32);
+                if (wall_clock64() - t0 > 500000000ll) { atomicExch(&fa.q->error, 1); leave = 1; break; }
+            }
+        }
+        leave = __builtin_amdgcn_readfirstlane(leave);
+        if (leave) break;
     }
 }
 
@@ -469,15 +448,22 @@ __global__ void pw_point_gap_kernel(long n_points, const long* __restrict__ unit
 // stream time each -- a tenth of the step of a small batch).
 __global__ void pw_reset_kernel(unsigned long long* __restrict__ out8, long n8, UnitQueue* queue, int* __restrict__ slots,
                                 long n_units, unsigned long long* ca, unsigned long long* cb,
-                                unsigned long long* cc, unsigned long long* cd, unsigned* xw_count) {
+                                unsigned long long* cc, unsigned long long* cd, unsigned* xw_count,
+                                FitQueue* fitq, int* __restrict__ slots2) {
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = i0; i < n8; i += stride) out8[i] = 0ull;
     for (long i = i0; i < n_units; i += stride) slots[i] = -1;
+    if (slots2)
+        for (long i = i0; i < 16 * n_units; i += stride) slots2[i] = -1;
     if (i0 == 0) {
         queue->tail = 0; queue->head = 0; queue->error = 0; queue->started = 0;
         *ca = 0; *cb = 0; *cc = 0; *cd = 0;
         *xw_count = 0u;
+        if (fitq) {
+            fitq->tail = 0; fitq->head = 0; fitq->final = ~0ull;
+            fitq->units_done = 0; fitq->n_deferred = 0;     // (error is sticky until the host has seen it)
+        }
     }
 }
 
@@ -529,8 +515,16 @@ struct pw_context {
     int need_fork;           // main stream carries work the next pipeline launch must wait for
     UnitQueue* cur_queue;
     int* cur_slots;
+    FitArgs cur_fit;         // the split window search's hand-offs of the current launch (zeros otherwise)
+    // the split window search (sampling launch + fit workers): per set a queue, 16 item slots, a ticket and a
+    // deferred-list entry per unit (sized like `slots`)
+    int split;               // PW_SPLIT (default 1): 0 = the window search as ONE launch of 4-wave teams (round 3's shape)
+    int fit_pool;            // PW_FIT_POOL: workers that stay until the fit queue is closed
+    FitQueue* fitq;
+    int* slots2;
+    FitTicket* tickets;
+    int* deferred;
     hipEvent_t ev0, ev1, ev_fork;
-    int row_chains;          // PW_ROW_CHAINS=1: the optimiser launch packs four chains per wavefront (experiment)
     int fused;               // PW_FUSED=1: one launch per analysis instead of the pipeline (also chosen when the
                              // streams of the pipeline do not run concurrently, see pw_context_create)
     int host_threads;        // device == -1 (the explicit host path, pw_hostpath.cpp): threads over the units
@@ -561,7 +555,11 @@ struct pw_context {
     size_t bigmem_bytes;
     void* pinned;            // page-locked host staging buffer handed to the reader (pw_context_pinned)
     size_t pinned_bytes;
+    std::recursive_mutex* mu;      // held by every entry point for the duration of the call (pw_host.hpp)
 };
+
+extern "C" void pw_internal_lock(pw_context* c) { if (c && c->mu) c->mu->lock(); }
+extern "C" void pw_internal_unlock(pw_context* c) { if (c && c->mu) c->mu->unlock(); }
 
 // a batch "resident" on the host (contexts created with device = -1)
 struct HostBatch {
@@ -693,7 +691,7 @@ struct LaunchPlan {
 // team width, LDS carve and grid for one launch.  want_nw: preferred waves per team;
 // rot/lb: whether window frames / optimiser states are needed (per wave).
 static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool rot, int lb_per_team,
-                       LaunchPlan* p, int nframes = 2, bool lean = false) {
+                       LaunchPlan* p, int nframes = 2, int lean = 0) {
     const size_t max_lds = 160 * 1024 - 256;
     int nw = want_nw;
     for (;;) {
@@ -706,7 +704,7 @@ static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool 
                 snprintf(g_err, sizeof(g_err), "molecule with %d atoms does not fit in LDS", nmax);
                 return PW_E_TOO_LARGE;
             }
-            p->nw = nw; p->nrot = nrot; p->nlb = nlb; p->lds = lds; p->nframes = nframes; p->lean = lean ? 1 : 0;
+            p->nw = nw; p->nrot = nrot; p->nlb = nlb; p->lds = lds; p->nframes = nframes; p->lean = lean;
             break;
         }
         nw >>= 1;
@@ -753,7 +751,7 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
                        r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb, p.nframes, p.lean, wsa,
                        c->counter + counter_slot, r->d_out, role, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab,
-                       r->vstride);
+                       r->vstride, c->cur_fit);
     HIP_TRY(hipGetLastError());
     return PW_OK;
 }
@@ -847,7 +845,8 @@ int pw_context_create(int device, pw_context** out) {
         h->device = -1;
         h->prm = default_params();
         h->extra = new (std::nothrow) std::vector<pw_extra_window>();
-        if (!h->extra) { delete h; return PW_E_NOMEM; }
+        h->mu = new (std::nothrow) std::recursive_mutex();
+        if (!h->extra || !h->mu) { delete h->extra; delete h->mu; delete h; return PW_E_NOMEM; }
         h->host_threads = pw_hostpath_default_threads();
         h->fused = 1;
         *out = h;
@@ -882,10 +881,13 @@ int pw_context_create(int device, pw_context** out) {
     CTX_TRY(hipMemset(c->counter, 0, (4 * PW_SETS + 3) * sizeof(unsigned long long)));
     CTX_TRY(hipMalloc((void**)&c->queue, PW_SETS * sizeof(UnitQueue)));
     CTX_TRY(hipMemset(c->queue, 0, PW_SETS * sizeof(UnitQueue)));
+    CTX_TRY(hipMalloc((void**)&c->fitq, PW_SETS * sizeof(FitQueue)));
+    CTX_TRY(hipMemset(c->fitq, 0, PW_SETS * sizeof(FitQueue)));
     c->flip = -1;
     c->extra = new (std::nothrow) std::vector<pw_extra_window>();
     c->blocks = new (std::nothrow) std::vector<pw_context::Block>();
-    if (!c->extra || !c->blocks) { pw_context_destroy(c); return PW_E_NOMEM; }
+    c->mu = new (std::nothrow) std::recursive_mutex();
+    if (!c->extra || !c->blocks || !c->mu) { pw_context_destroy(c); return PW_E_NOMEM; }
     {
         const char* ns = getenv("PW_SETS_IN_FLIGHT");
         c->nsets = ns ? atoi(ns) : 0;
@@ -932,8 +934,10 @@ int pw_context_create(int device, pw_context** out) {
     const char* fz = getenv("PW_FUSED");
     c->fused = (fz && fz[0] == '1') ? 1 : 0;
     {
-        const char* rc_ = getenv("PW_ROW_CHAINS");
-        c->row_chains = (rc_ && rc_[0] == '1') ? 1 : 0;
+        const char* sp_ = getenv("PW_SPLIT");
+        c->split = (sp_ && sp_[0] == '0') ? 0 : 1;
+        const char* fp_ = getenv("PW_FIT_POOL");
+        c->fit_pool = fp_ && atoi(fp_) > 0 ? atoi(fp_) : 0;      // 0: by the size of the chip (pw_resident_launch)
     }
     const char* cw = getenv("PW_C_WAVES");
     c->c_waves = (cw && cw[0] == '8') ? 8 : 4;
@@ -1014,7 +1018,7 @@ int pw_context_create(int device, pw_context** out) {
 
 void pw_context_destroy(pw_context* c) {
     if (!c) return;
-    if (c->device < 0) { delete c->extra; delete c; return; }
+    if (c->device < 0) { delete c->extra; delete c->mu; delete c; return; }
     DeviceScope scope;
     (void)scope.enter(c->device);
     (void)hipDeviceSynchronize();
@@ -1046,6 +1050,10 @@ void pw_context_destroy(pw_context* c) {
     if (c->adj) (void)hipFree(c->adj);
     if (c->pool) (void)hipFree(c->pool);
     if (c->queue) (void)hipFree(c->queue);
+    if (c->fitq) (void)hipFree(c->fitq);
+    if (c->slots2) (void)hipFree(c->slots2);
+    if (c->tickets) (void)hipFree(c->tickets);
+    if (c->deferred) (void)hipFree(c->deferred);
     if (c->rsq_tab) (void)hipFree(c->rsq_tab);
     if (c->nb_off) (void)hipFree(c->nb_off);
     if (c->nb_idx) (void)hipFree(c->nb_idx);
@@ -1055,6 +1063,7 @@ void pw_context_destroy(pw_context* c) {
         if (c->prods[b]) (void)hipStreamDestroy(c->prods[b]);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c->mu;
     delete c;
 }
 
@@ -1064,6 +1073,7 @@ void pw_params_default(pw_params* p) {
 
 int pw_context_set_params(pw_context* c, const pw_params* p) {
     if (!c || !p) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     if (!(p->adjust_windows > 0.0) || !(p->adjust_average > 0.0) || !(p->increment > 0.0) || !(p->increment2 > 0.0)) {
         snprintf(g_err, sizeof(g_err), "pw_params: adjust and increment must be positive");
         return PW_E_BAD_ARG;
@@ -1094,6 +1104,7 @@ int pw_context_device(pw_context* c) { return c ? c->device : -1; }
 // the buffer is ordered on the API stream; growing it waits for the device.
 int pw_internal_pool(pw_context* c, size_t bytes, void** out) {
     if (!c || !out) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     PW_HOST_UNSUPPORTED(c, "device scratch");
     if (c->pool_bytes < bytes) {
         HIP_TRY(hipDeviceSynchronize());
@@ -1115,6 +1126,7 @@ void* pw_context_stream(pw_context* c) { return c ? (void*)c->stream : nullptr; 
 // going through the runtime's bounce buffer.  Valid until the next call that asks for more.
 int pw_context_pinned(pw_context* c, size_t bytes, void** out) {
     if (!c || !out) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     PW_HOST_UNSUPPORTED(c, "pinned staging");
     PW_ON_DEVICE(c->device);
     if (c->pinned_bytes < bytes) {
@@ -1133,12 +1145,14 @@ int pw_context_pinned(pw_context* c, size_t bytes, void** out) {
 // number of host threads of a device = -1 context (0: keep); returns the current number
 int pw_context_host_threads(pw_context* c, int threads) {
     if (!c || c->device >= 0) return 0;
+    PW_LOCK_CONTEXT(c);
     if (threads > 0) c->host_threads = threads;
     return c->host_threads;
 }
 
 int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     if (!c || !r) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     if (r->n_units == 0) return PW_OK;
     if (c->device < 0) {
         if (!r->host) return PW_E_BAD_ARG;
@@ -1254,14 +1268,6 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         }
         if (getenv("PW_PLAN_DEBUG")) fprintf(stderr, "plan A: grid %d lds %zu\n", pa.grid, pa.lds);
     }
-    // the row-packed variant of the optimiser launch (PW_ROW_CHAINS=1): four units per wavefront
-    int row_grid = 0;
-    size_t row_lds = 0;
-    if (c->row_chains) {
-        const size_t nn = (size_t)((r->nmax + 1) & ~1);
-        row_lds = 4 * (nn * 8 * 5 + ((sizeof(LbMem<3>) + 15) & ~(size_t)15));
-        if (row_lds <= 160 * 1024 - 256) row_grid = (int)((r->n_units + 3) / 4);
-    }
     bool do_avg = (stages & PW_STAGE_AVG) != 0;
     pb.grid = 0;
     if (do_avg) {
@@ -1272,8 +1278,45 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         rc = plan_launch(c, r->n_units, r->nmax, 4, false, b_lb, &pb, 1, true);
         if (rc != PW_OK) return rc;
     }
-    rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pc, 1);      // one frame, shifted in place
+    // The window search: split (default) = a sampling launch of 4-wave teams up to the clustering + the fits by
+    // the one-wave workers of launch A; PW_SPLIT=0 (and team shapes the sampling kernel is not built for) = ONE
+    // launch of 4-wave teams that do both (round 3's shape; also what follows up on units with more clusters
+    // than a ticket holds)
+    bool split = c->split != 0 && c->c_waves == 4;
+    LaunchPlan pcf;                              // the fused window search
+    rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pcf, 1);      // one frame, shifted in place
     if (rc != PW_OK) return rc;
+    if (pcf.nw != 4) split = false;
+    pc = pcf;
+    if (split) {
+        // the same arena (the window frames and optimiser blocks the fused search would carve are this launch's
+        // scratch), no per-cluster arrays
+        int s_rot = 4, s_lb = 4;
+        if (const char* e = getenv("PW_S_ARENA")) {       // tuning: "rot,lb" slots that make up the arena
+            int a = 0, b2 = 0;
+            if (sscanf(e, "%d,%d", &a, &b2) == 2 && a >= 0 && a <= 4 && b2 >= 0 && b2 <= 8 && a + b2 > 0) { s_rot = a; s_lb = b2; }
+        }
+        pc.nrot = s_rot; pc.nlb = s_lb; pc.lean = 2;
+        pc.lds = UnitShared::bytes(r->nmax, s_rot, s_lb, 1, 2, wanted_p_cap(c) > c->p_cap ? wanted_p_cap(c) : c->p_cap) + 64;
+        if (pc.lds > 160 * 1024 - 256) split = false, pc = pcf;
+        else {
+            int per_cu = (int)(c->lds_per_cu / pc.lds);
+            if (per_cu > 4) per_cu = 4;
+            long g = (long)c->n_cu * (per_cu < 1 ? 1 : per_cu);
+            pc.grid = (int)(g < r->n_units ? g : r->n_units);
+        }
+    }
+    int pool = 0;
+    if (split) {
+        // workers: one per unit plus the pool, at most what the chip holds at a time
+        pool = c->fit_pool > 0 ? c->fit_pool : (c->n_cu + 1) / 2;
+        int per_cu = (int)(c->lds_per_cu / pa.lds);
+        if (per_cu > 16) per_cu = 16;
+        long cap = (long)c->n_cu * (per_cu < 1 ? 1 : per_cu);
+        long want = r->n_units + pool;
+        pa.grid = (int)(want < cap ? want : cap);
+        if (pool > pa.grid) pool = pa.grid;
+    }
     // A batch of up to a few units per SIMD is latency-bound by its optimiser chains: one window team
     // per CU keeps LDS free for the chains of the next launch (measured on 1000 units: 2.56 -> 2.45 ms);
     // larger batches want every team the LDS admits (4000 units: 9.2 ms against 10.0).
@@ -1285,14 +1328,17 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         // PW_C_TEAMS / PW_B_TEAMS: cap the persistent teams of the window / average launches (tuning)
         const char* ct = getenv("PW_C_TEAMS");
         if (ct && atoi(ct) > 0) {
-            rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pc, 1);      // one frame, shifted in place
-            if (rc != PW_OK) return rc;
-            if (atoi(ct) < pc.grid) pc.grid = atoi(ct);
+            long g = (long)c->n_cu * 4;
+            if (g > r->n_units) g = r->n_units;
+            int per_cu = (int)(c->lds_per_cu / pc.lds);
+            if (per_cu < 1) per_cu = 1;
+            if (g > (long)c->n_cu * per_cu) g = (long)c->n_cu * per_cu;
+            pc.grid = atoi(ct) < g ? atoi(ct) : (int)g;
         }
         const char* bt = getenv("PW_B_TEAMS");
         if (bt && do_avg && atoi(bt) > 0 && atoi(bt) < pb.grid) pb.grid = atoi(bt);
     }
-    if (const char* cslots = getenv("PW_C_SLOTS")) {
+    if (const char* cslots = split ? nullptr : getenv("PW_C_SLOTS")) {
         // experiment: fewer window-fit slots than waves (less LDS per team, windows fitted in rounds);
         // PW_C_TEAMS then sets the number of teams (up to what the smaller request admits per CU)
         int k = atoi(cslots);
@@ -1341,6 +1387,17 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         if (c->slots) HIP_TRY(hipFree(c->slots));
         c->slots = nullptr;
         HIP_TRY(hipMalloc((void**)&c->slots, PW_SETS * sizeof(int) * (size_t)r->n_units));
+        if (c->slots2) HIP_TRY(hipFree(c->slots2));
+        c->slots2 = nullptr;
+        if (c->tickets) HIP_TRY(hipFree(c->tickets));
+        c->tickets = nullptr;
+        if (c->deferred) HIP_TRY(hipFree(c->deferred));
+        c->deferred = nullptr;
+        if (c->split) {
+            HIP_TRY(hipMalloc((void**)&c->slots2, PW_SETS * sizeof(int) * 16 * (size_t)r->n_units));
+            HIP_TRY(hipMalloc((void**)&c->tickets, PW_SETS * sizeof(FitTicket) * (size_t)r->n_units));
+            HIP_TRY(hipMalloc((void**)&c->deferred, PW_SETS * sizeof(int) * (size_t)r->n_units));
+        }
         c->slots_cap = r->n_units;
         for (int k = 0; k < PW_SETS; ++k) c->done_valid[k] = c->tail_valid[k] = c->head_valid[k] = 0;
     }
@@ -1360,6 +1417,14 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     r->d_out = r->d_outs[r->cur];
     c->cur_queue = c->queue + b;
     c->cur_slots = c->slots + (size_t)b * c->slots_cap;
+    memset(&c->cur_fit, 0, sizeof(c->cur_fit));
+    if (split) {
+        c->cur_fit.q = c->fitq + b;
+        c->cur_fit.slots2 = c->slots2 + (size_t)b * 16 * c->slots_cap;
+        c->cur_fit.tickets = (void*)(c->tickets + (size_t)b * c->slots_cap);
+        c->cur_fit.deferred = c->deferred + (size_t)b * c->slots_cap;
+        c->cur_fit.n_pool = pool;
+    }
     if (c->need_fork) {
         // uploads, single-launch analyses and timing marks on the main stream come first
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
@@ -1391,7 +1456,8 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(pw_reset_kernel, dim3((unsigned)blocks), dim3(256), 0, c->prod, (unsigned long long*)r->d_out, n8,
                            c->cur_queue, c->cur_slots, r->n_units, c->counter + b, c->counter + PW_SETS + b,
-                           c->counter + 2 * PW_SETS + b, c->counter + 3 * PW_SETS + b, r->d_xw_count + r->cur);
+                           c->counter + 2 * PW_SETS + b, c->counter + 3 * PW_SETS + b, r->d_xw_count + r->cur,
+                           c->cur_fit.q, c->cur_fit.slots2);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev_reset[b], c->prod));
@@ -1413,23 +1479,26 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     c->last_res[b] = (const void*)r;
     // several optimiser launches can be in flight: separate work counters and workspaces
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][0], c->prod));
-    const bool rows = c->row_chains && c->prm.opt_flags == 0 && row_grid > 0;
-    if (rows) {
-        // basic stage of every unit (4-wave teams), then four chains per wavefront
-        LaunchPlan pbas;
-        rc = plan_launch(c, r->n_units, r->nmax, 4, false, 0, &pbas, 1, true);
-        if (rc != PW_OK) return rc;
-        if (pbas.grid > c->max_a) pbas.grid = c->max_a;
-        rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_MERGE, pbas, c->prod, ws_a, -1, 3 * PW_SETS + b, PW_ROLE_PLAIN, false);
-        if (rc != PW_OK) return rc;
+    if (split) {
+        // the one-wave workers: the chains of every unit, and the window fits the sampling launch hands over
         static std::atomic<unsigned long long> attr_done{0};
         const unsigned long long bit = 1ull << (c->device & 63);
         if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-            HIP_TRY(hipFuncSetAttribute((const void*)pw_row_chains_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            HIP_TRY(hipFuncSetAttribute((const void*)pw_worker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
             attr_done.fetch_or(bit, std::memory_order_release);
         }
-        hipLaunchKernelGGL(pw_row_chains_kernel, dim3(row_grid), dim3(64), row_lds, c->prod, r->n_units, r->d_offset, r->d_xyz,
-                           r->d_vdw, r->vstride, r->nmax, r->d_out, c->counter + b, c->cur_queue, c->cur_slots);
+        if (getenv("PW_PLAN_DEBUG"))
+            fprintf(stderr, "launch workers grid %d (pool %d) lds %zu | sampling grid %d lds %zu\n", pa.grid, pool, pa.lds, pc.grid, pc.lds);
+        PwWsArgs wsa;
+        wsa.ws = c->ws + ws_a;
+        wsa.slab = c->slab + (size_t)ws_a * team_slab_bytes(c->p_cap);
+        wsa.adj = nullptr;
+        wsa.xwin = r->d_xw[r->cur]; wsa.xwin_count = r->d_xw_count + r->cur; wsa.xwin_cap = r->xw_cap;
+        wsa.p_cap = c->p_cap;
+        wsa.nb_off = c->nb_off; wsa.nb_idx = c->nb_idx; wsa.nb_bound = c->nb_bound;
+        hipLaunchKernelGGL(pw_worker_kernel, dim3(pa.grid), dim3(64), pa.lds, c->prod, r->n_units, r->d_offset, r->d_xyz, r->d_vdw,
+                           r->d_mass, r->nmax, wsa, c->counter + b, r->d_out, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab,
+                           r->vstride, c->cur_fit);
         HIP_TRY(hipGetLastError());
     } else {
         rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod, ws_a, -1, b, PW_ROLE_PRODUCER, false);
@@ -1439,7 +1508,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     HIP_TRY(hipEventRecord(c->ev_prod[b], c->prod));
     hipStream_t cs = c->cons[b];
     HIP_TRY(hipStreamWaitEvent(cs, c->ev_reset[b], 0));
-    hipLaunchKernelGGL(pw_gate_kernel, dim3(1), dim3(64), 0, cs, c->cur_queue, rows ? row_grid : pa.grid, c->counter + 4 * PW_SETS + 2);
+    hipLaunchKernelGGL(pw_gate_kernel, dim3(1), dim3(64), 0, cs, c->cur_queue, pa.grid, c->counter + 4 * PW_SETS + 2);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_gate[b], cs));
     c->head_valid[b] = 0;
@@ -1456,9 +1525,31 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         }
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][0], cs));
-    rc = launch_plan(c, r, PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, pc, cs,
-                     ws_c, b * c->max_c, PW_SETS + b, PW_ROLE_CONSUMER, false);
-    if (rc != PW_OK) return rc;
+    if (split) {
+        {
+            PwWsArgs wsa;
+            wsa.ws = c->ws + ws_c;
+            wsa.slab = c->slab + (size_t)ws_c * team_slab_bytes(c->p_cap);
+            wsa.adj = c->adj + (size_t)(b * c->max_c) * team_adj_words(c->p_cap);
+            wsa.xwin = r->d_xw[r->cur]; wsa.xwin_count = r->d_xw_count + r->cur; wsa.xwin_cap = r->xw_cap;
+            wsa.p_cap = c->p_cap;
+            wsa.nb_off = c->nb_off; wsa.nb_idx = c->nb_idx; wsa.nb_bound = c->nb_bound;
+            rc = pw_internal_sampling_launch((void*)cs, pc.grid, pc.lds, r->n_units, r->d_offset, r->d_xyz, r->d_vdw, r->d_mass,
+                                             r->nmax, pc.nrot, pc.nlb, &wsa, r->d_out, c->cur_queue, c->cur_slots, &c->prm,
+                                             c->rsq_tab, r->vstride, &c->cur_fit);
+            if (rc != PW_OK) return rc;
+        }
+        // follow-up: units with more clusters than a ticket holds, through the fused window search (a handful of
+        // teams that find an empty list and leave, nearly always)
+        LaunchPlan pl = pcf;
+        pl.grid = pcf.grid < 16 ? pcf.grid : 16;
+        if (pl.grid > pc.grid) pl.grid = pc.grid;
+        rc = launch_plan(c, r, MASK_WINDOWS, pl, cs, ws_c, b * c->max_c, PW_SETS + b, PW_ROLE_LIST, false);
+        if (rc != PW_OK) return rc;
+    } else {
+        rc = launch_plan(c, r, MASK_WINDOWS, pc, cs, ws_c, b * c->max_c, PW_SETS + b, PW_ROLE_CONSUMER, false);
+        if (rc != PW_OK) return rc;
+    }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][1], cs));
     if (do_avg) {
         HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_gate[b], 0));
@@ -1482,12 +1573,16 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
 // for a finished one -- neither downloaded nor timed
 static int check_queue_error(pw_context* c) {
     UnitQueue q[PW_SETS];
+    FitQueue f[PW_SETS];
     HIP_TRY(hipMemcpy(q, c->queue, sizeof(q), hipMemcpyDeviceToHost));
-    bool any = false;
-    for (int b = 0; b < PW_SETS; ++b) any = any || q[b].error != 0;
-    if (any) {
+    HIP_TRY(hipMemcpy(f, c->fitq, sizeof(f), hipMemcpyDeviceToHost));
+    bool any = false, anyf = false;
+    for (int b = 0; b < PW_SETS; ++b) { any = any || q[b].error != 0; anyf = anyf || f[b].error != 0; }
+    if (any || anyf) {
         (void)hipMemset(c->queue, 0, sizeof(q));
-        snprintf(g_err, sizeof(g_err), "window launch timed out waiting for the optimiser launch");
+        (void)hipMemset(c->fitq, 0, sizeof(f));
+        snprintf(g_err, sizeof(g_err), any ? "window launch timed out waiting for the optimiser launch"
+                                           : "fit workers timed out waiting for the sampling launch");
         return PW_E_HIP;
     }
     return PW_OK;
@@ -1495,6 +1590,7 @@ static int check_queue_error(pw_context* c) {
 
 int pw_resident_sync(pw_context* c) {
     if (!c) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     if (c->device < 0) return PW_OK;
     PW_ON_DEVICE(c->device);
     int rcj = join_pipeline(c);
@@ -1505,6 +1601,7 @@ int pw_resident_sync(pw_context* c) {
 
 int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) {
     if (!c || !in || !out || in->n_units < 0 || in->template_atoms < 0) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     *out = nullptr;
     if (c->device < 0) {
         pw_resident* h = new (std::nothrow) pw_resident();
@@ -1600,6 +1697,7 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
 int pw_internal_resident_adopt(pw_context* c, long n_units, long n_atoms, int nmax, long* d_offset, double* d_xyz,
                                double* d_vdw, double* d_mass, const size_t* part_bytes, pw_resident** out) {
     if (!c || !out || n_units <= 0 || nmax <= 0 || !part_bytes) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     PW_HOST_UNSUPPORTED(c, "device batches");
     PW_ON_DEVICE(c->device);
     pw_resident* r = new (std::nothrow) pw_resident();
@@ -1663,6 +1761,7 @@ static int fetch_extra_windows(pw_context* c, pw_resident* r, unsigned count) {
 
 int pw_resident_download(pw_context* c, pw_resident* r, pw_unit_out* out) {
     if (!c || !r || !out) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     if (r->n_units == 0) return PW_OK;
     if (c->device < 0) {
         if (!r->host) return PW_E_BAD_ARG;
@@ -1694,6 +1793,7 @@ int pw_resident_download(pw_context* c, pw_resident* r, pw_unit_out* out) {
 // place that is checked is the download), and loads the launch's extra windows into the context's list.
 int pw_resident_extra_windows(pw_context* c, pw_resident* r, int64_t* count) {
     if (!c || !r) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     if (count) *count = 0;
     if (r->n_units == 0) return PW_OK;
     if (c->device < 0) { if (count) *count = (int64_t)c->extra->size(); return PW_OK; }
@@ -1717,6 +1817,7 @@ int pw_resident_extra_windows(pw_context* c, pw_resident* r, int64_t* count) {
 
 int64_t pw_context_extra_windows(pw_context* c, pw_extra_window* buf, int64_t cap) {
     if (!c || !c->extra) return 0;
+    PW_LOCK_CONTEXT(c);
     const int64_t n = (int64_t)c->extra->size();
     if (buf && cap > 0) memcpy(buf, c->extra->data(), (size_t)(n < cap ? n : cap) * sizeof(pw_extra_window));
     return n;
@@ -1728,8 +1829,17 @@ int pw_context_pipelined(pw_context* c) { return c && !c->fused ? 1 : 0; }
 
 int pw_context_point_capacity(pw_context* c) { return c ? (c->p_cap > 0 ? c->p_cap : wanted_p_cap(c)) : 0; }
 
+int pw_context_reserve_points(pw_context* c, int64_t n_points) {
+    if (!c || n_points < 0 || n_points > 4000000) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
+    const int want = round_p_cap((long)n_points);
+    if (want > c->p_cap_min) c->p_cap_min = want;
+    return PW_OK;
+}
+
 void pw_resident_free(pw_context* c, pw_resident* r) {
     if (!r) return;
+    PW_LOCK_CONTEXT(c);
     if (r->host) { delete r->host; delete r; return; }
     DeviceScope scope;
     if (c) (void)scope.enter(c->device);
@@ -1757,6 +1867,7 @@ void pw_resident_free(pw_context* c, pw_resident* r) {
 // Diagnostic: zero on a healthy device.
 int pw_context_gate_timeouts(pw_context* c, uint64_t* count) {
     if (!c || !count) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     *count = 0;
     if (c->device < 0 || !c->counter) return PW_OK;
     PW_ON_DEVICE(c->device);
@@ -1773,6 +1884,7 @@ int64_t pw_resident_units(pw_resident* r) { return r ? r->n_units : 0; }
 // one-process-per-GPU job runs on PyTorch's stream): no host synchronisation on either side.
 int pw_resident_results_ready(pw_context* c, pw_resident* r, void* stream, void** results) {
     if (!c || !r) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     PW_HOST_UNSUPPORTED(c, "stream-ordered hand-over");
     PW_ON_DEVICE(c->device);
     hipStream_t ext = (hipStream_t)stream;
@@ -1787,6 +1899,7 @@ int pw_resident_results_ready(pw_context* c, pw_resident* r, void* stream, void*
 
 int pw_resident_results_release(pw_context* c, pw_resident* r, void* stream) {
     if (!c || !r) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     PW_HOST_UNSUPPORTED(c, "stream-ordered hand-over");
     PW_ON_DEVICE(c->device);
     // the launch that next writes this result buffer (two launches of this batch from now) waits for
@@ -1800,6 +1913,7 @@ int pw_resident_results_release(pw_context* c, pw_resident* r, void* stream) {
 
 int pw_resident_time(pw_context* c, pw_resident* r, uint32_t stages, int iters, float* ms) {
     if (!c || !r || !ms || iters < 1) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     if (c->device < 0) {
         timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -1837,6 +1951,7 @@ int pw_resident_time(pw_context* c, pw_resident* r, uint32_t stages, int iters, 
 // from the moment the chains are resident until the last published unit is fitted).
 int pw_resident_stage_times(pw_context* c, pw_resident* r, float* ms) {
     if (!c || !r || !ms) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     PW_HOST_UNSUPPORTED(c, "per-launch timing");
     if (c->fused) { snprintf(g_err, sizeof(g_err), "PW_FUSED=1: the analysis is one launch"); return PW_E_BAD_ARG; }
     PW_ON_DEVICE(c->device);
@@ -1881,6 +1996,7 @@ static int launch_and_download(pw_context* c, pw_resident* r, uint32_t stages, p
 
 int pw_analysis_batch(pw_context* c, const pw_batch_in* in, uint32_t stages, pw_unit_out* out) {
     if (!c || !in || !out) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     if (c->device < 0) return host_analyse(c, in, stages, out, nullptr);
     pw_resident* r = nullptr;
     int rc = pw_resident_upload(c, in, &r);
@@ -1892,6 +2008,7 @@ int pw_analysis_batch(pw_context* c, const pw_batch_in* in, uint32_t stages, pw_
 
 int pw_analysis_debug(pw_context* c, const pw_batch_in* in, uint32_t stages, pw_unit_out* out, pw_unit_debug* dbg) {
     if (!c || !in || !out || !dbg) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     if (in->n_units == 0) return PW_OK;
     if (c->device < 0) {
         memset(dbg, 0, sizeof(pw_unit_debug) * (size_t)in->n_units);
@@ -1943,6 +2060,7 @@ int pw_analysis_debug(pw_context* c, const pw_batch_in* in, uint32_t stages, pw_
 int pw_point_gaps(pw_context* c, const pw_batch_in* in, const int64_t* unit_of_point,
                   const double* points, int64_t n_points, double* gap, int32_t* argmin) {
     if (!c || !in || !unit_of_point || !points || !gap || !argmin || n_points < 0) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     if (n_points == 0) return PW_OK;
     for (int64_t q = 0; q < n_points; ++q)
         if (unit_of_point[q] < 0 || unit_of_point[q] >= in->n_units) return PW_E_BAD_ARG;
@@ -2011,6 +2129,7 @@ int pw_point_gaps(pw_context* c, const pw_batch_in* in, const int64_t* unit_of_p
 int pw_dbscan(pw_context* c, const double* points, int64_t n, double eps, int mode, int32_t* labels,
               int32_t* n_clusters) {
     if (!c || !labels || !n_clusters || n < 0 || n > PW_DBSCAN_MAX || (n > 0 && !points)) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     *n_clusters = 0;
     if (n == 0) return PW_OK;
     PW_HOST_UNSUPPORTED(c, "pw_dbscan");
@@ -2070,6 +2189,7 @@ int pw_dbscan(pw_context* c, const double* points, int64_t n, double eps, int mo
 
 int pw_pairwise_sum(pw_context* c, const double* values, int64_t n, int mode, double* sum) {
     if (!c || !sum || n < 0 || n > 0x7fffffff || (n > 0 && !values)) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
     PW_HOST_UNSUPPORTED(c, "pw_pairwise_sum");
     PW_ON_DEVICE(c->device);
     double *d_a = nullptr, *d_s = nullptr;

@@ -75,16 +75,22 @@ pw_rebuild_kernel(pw_cell_in in, pw_cell_out out, unsigned char* __restrict__ sl
     }
 }
 
-// temporaries of one call, taken from the context's cache of device blocks and given back at the end
-// (every caller synchronises its stream before returning): no hipMalloc / hipFree -- and no device-wide
-// wait -- per call once the cache is warm
+// temporaries of one call, taken from the context's cache of device blocks and given back at the end: no
+// hipMalloc / hipFree -- and no device-wide wait -- per call once the cache is warm.  A block may only go
+// back once nothing queued on the stream can still touch it: the success paths end with a stream
+// synchronisation and say so (`synced`); every other way out (an error return half-way) waits here first.
 struct Buffers {
     static constexpr int CAP = 32;
     pw_context* ctx = nullptr;
+    hipStream_t st = nullptr;
+    bool synced = false;
     void* p[CAP];
     size_t bytes_[CAP];
     int n = 0;
-    ~Buffers() { for (int i = 0; i < n; ++i) if (p[i]) pw_internal_block_give(ctx, p[i], bytes_[i]); }
+    ~Buffers() {
+        if (n > 0 && !synced) (void)hipStreamSynchronize(st);
+        for (int i = 0; i < n; ++i) if (p[i]) pw_internal_block_give(ctx, p[i], bytes_[i]);
+    }
     template <class X> hipError_t alloc(X** out, size_t bytes) {
         if (n >= CAP || !ctx) return hipErrorOutOfMemory;
         void* q = nullptr;
@@ -280,6 +286,7 @@ extern "C" int pw_discrete_molecules(pw_context* ctx, const pw_cell_in* in, cons
         !out->src_image || !out->xyz || out->atoms_cap <= 0 || out->mols_cap <= 0)
         return PW_E_BAD_ARG;
     if (in->n_frames == 0) return PW_OK;
+    PW_LOCK_CONTEXT(ctx);
     DeviceScope dev_scope_;
     if (pw_context_device(ctx) < 0) {
         snprintf(pw_internal_error_buffer(), 512, "not part of the host path (device = -1 runs the analysis only)");
@@ -288,6 +295,7 @@ extern "C" int pw_discrete_molecules(pw_context* ctx, const pw_cell_in* in, cons
     RB_TRY(dev_scope_.enter(pw_context_device(ctx)));
     Buffers buf;
     buf.ctx = ctx;
+    buf.st = (hipStream_t)pw_context_stream(ctx);
     DeviceCells dev;
     int rc = rebuild_on_device(ctx, in, out->atoms_cap, out->mols_cap, buf, &dev);
     if (rc != PW_OK) return rc;
@@ -300,6 +308,7 @@ extern "C" int pw_discrete_molecules(pw_context* ctx, const pw_cell_in* in, cons
     RB_TRY(hipMemcpyAsync(out->src_image, dev.img, (size_t)F * out->atoms_cap, hipMemcpyDeviceToHost, st));
     RB_TRY(hipMemcpyAsync(out->xyz, dev.oxyz, sizeof(double) * 3 * F * out->atoms_cap, hipMemcpyDeviceToHost, st));
     RB_TRY(hipStreamSynchronize(st));
+    buf.synced = true;
     return PW_OK;
 }
 
@@ -308,6 +317,7 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
     if (!args_ok(ctx, in) || !vdw || !res || !n_mol || !status || atoms_cap <= 0 || mols_cap <= 0 || in->n_frames <= 0)
         return PW_E_BAD_ARG;
     *res = nullptr;
+    PW_LOCK_CONTEXT(ctx);
     DeviceScope dev_scope_;
     if (pw_context_device(ctx) < 0) {
         snprintf(pw_internal_error_buffer(), 512, "not part of the host path (device = -1 runs the analysis only)");
@@ -316,6 +326,7 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
     RB_TRY(dev_scope_.enter(pw_context_device(ctx)));
     Buffers buf;
     buf.ctx = ctx;
+    buf.st = (hipStream_t)pw_context_stream(ctx);
     DeviceCells dev;
     int rc = rebuild_on_device(ctx, in, atoms_cap, mols_cap, buf, &dev);
     if (rc != PW_OK) return rc;
@@ -339,6 +350,7 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
     RB_TRY(hipMemcpyAsync(&totals[0], d_ubase + F, sizeof(long), hipMemcpyDeviceToHost, st));
     RB_TRY(hipMemcpyAsync(&totals[1], d_abase + F, sizeof(long), hipMemcpyDeviceToHost, st));
     RB_TRY(hipStreamSynchronize(st));
+    buf.synced = true;             // (until the gather below is queued)
     for (long f = 0; f < F; ++f)
         if (status[f] & (PW_RB_ATOMS_OVERFLOW | PW_RB_MOLS_OVERFLOW)) {
             snprintf(pw_internal_error_buffer(), 512, "frame %ld needs more than %d atoms / %d molecules", f,
@@ -351,6 +363,7 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
     double *d_xyz = nullptr, *d_uv = nullptr, *d_um = nullptr;
     size_t part_bytes[4] = {0, 0, 0, 0};
     auto drop = [&]() {
+        (void)hipStreamSynchronize(st);          // (the gather may be running on these blocks)
         pw_internal_block_give(ctx, d_offset, part_bytes[0]);
         pw_internal_block_give(ctx, d_xyz, part_bytes[1]);
         pw_internal_block_give(ctx, d_uv, part_bytes[2]);
@@ -370,6 +383,7 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
     RBF_TRY(take((void**)&d_xyz, sizeof(double) * 3 * A, 1));
     RBF_TRY(take((void**)&d_uv, sizeof(double) * A, 2));
     RBF_TRY(take((void**)&d_um, sizeof(double) * A, 3));
+    buf.synced = false;
     hipLaunchKernelGGL(rb_gather_kernel, dim3((unsigned)F), dim3(256), 0, st, F, (int)atoms_cap, (int)mols_cap,
                        dev.n_mol, dev.off, dev.src, dev.oxyz, d_vdw_atom, dev.mass, d_ubase, d_abase, d_offset, d_xyz,
                        d_uv, d_um, d_nmax);
@@ -377,6 +391,7 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
     int nmax = 0;
     RBF_TRY(hipMemcpyAsync(&nmax, d_nmax, sizeof(int), hipMemcpyDeviceToHost, st));
     RBF_TRY(hipStreamSynchronize(st));
+    buf.synced = true;
 #undef RBF_TRY
     rc = pw_internal_resident_adopt(ctx, U, A, nmax, d_offset, d_xyz, d_uv, d_um, part_bytes, res);
     if (rc != PW_OK) drop();

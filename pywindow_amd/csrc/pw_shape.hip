@@ -67,6 +67,7 @@ extern "C" int pw_shape_batch(pw_context* ctx, const pw_batch_in* in, pw_shape_o
         return PW_E_BAD_ARG;
     const long U = (long)in->n_units;
     if (U == 0) return PW_OK;
+    PW_LOCK_CONTEXT(ctx);
     const long A = (long)in->atom_offset[U];
     const long TA = (long)in->template_atoms;       // > 0: one mass template for every unit
     if (TA < 0) return PW_E_BAD_ARG;
@@ -109,6 +110,7 @@ extern "C" int pw_circumcircle(pw_context* ctx, const double* xyz, int64_t n_ato
     if (!ctx || n_sets < 0 || n_atoms <= 0 || !xyz || (n_sets && (!atom_sets || !diameter || !centre)))
         return PW_E_BAD_ARG;
     if (n_sets == 0) return PW_OK;
+    PW_LOCK_CONTEXT(ctx);
     for (long k = 0; k < 3 * (long)n_sets; ++k)
         if (atom_sets[k] < 0 || atom_sets[k] >= n_atoms) {
             snprintf(pw_internal_error_buffer(), 512, "pw_circumcircle: atom index %d out of range", atom_sets[k]);

@@ -211,27 +211,29 @@ struct UnitShared {
     PW_LDS unsigned char* scratch;
     size_t scratch_bytes;
     // nrot = rotated window frames, nlb = optimiser states (both 0..nwaves)
-    // nframes = 1: one frame - the optimiser-chain launch works on the input frame only, the other two
-    // launches of the pipeline shift it in place; lean = without the window-search variables
-    PW_HD static size_t bytes(int nmax, int nrot, int nlb, int nframes = 2, bool lean = false, int pcap = PW_P_MAX) {
+    // nframes = 1: one frame - the optimiser-chain launch works on the input frame only, the other
+    // launches of the pipeline shift it in place; lean = 1: without the window-search variables and the DBSCAN
+    // bit sets (chains, average diameter), 2: with the bit sets but without the per-cluster arrays of the window
+    // fits (the sampling launch: its clusters go to a FitTicket)
+    PW_HD static size_t bytes(int nmax, int nrot, int nlb, int nframes = 2, int lean = 0, int pcap = PW_P_MAX) {
         size_t n = (size_t)((nmax + 1) & ~1);
         size_t b = lean ? offsetof(UnitVars, win_first) : sizeof(UnitVars);
         b = (b + 15) & ~(size_t)15;
-        if (!lean) b += 3 * (size_t)(pcap / 64) * 8;
+        if (lean != 1) b += 3 * (size_t)(pcap / 64) * 8;
         b += n * 8 * 2;                       // vdw, mass
         b += n * 4 * 2;                       // perm, inv
         b += n * 8 * 4 * ((size_t)nframes + (size_t)nrot);  // A, S, R[w]
         b += (size_t)nlb * ((sizeof(LbMem<3>) + 15) & ~(size_t)15);
         return b;
     }
-    PW_HD void carve(unsigned char* base, int nmax, int nrot, int nlb, int nframes = 2, bool lean = false,
+    PW_HD void carve(unsigned char* base, int nmax, int nrot, int nlb, int nframes = 2, int lean = 0,
                      int pcap = PW_P_MAX) {
         size_t n = (size_t)((nmax + 1) & ~1);
         PW_LDS unsigned char* p = (PW_LDS unsigned char*)base;
         v = (PW_LDS UnitVars*)p;
         p += ((lean ? offsetof(UnitVars, win_first) : sizeof(UnitVars)) + 15) & ~(size_t)15;
         bits[0] = bits[1] = bits[2] = nullptr;
-        if (!lean) {
+        if (lean != 1) {
             const size_t bw = (size_t)(pcap / 64);
             bits[0] = (PW_LDS unsigned long long*)p; bits[1] = bits[0] + bw; bits[2] = bits[1] + bw;
             p += 3 * bw * 8;
@@ -1969,12 +1971,14 @@ struct WinArrays {
     double* c;     // 3 per cluster: centre
     int* ok;       // 1 fitted, 0 dropped by the refined path scan, -1 inverted z bounds
 };
+// FS: the molecule with the pore centre at the origin; R: where the rotated copy goes -- R may be FS itself (a
+// fit worker that owns its frame rotates in place: every lane reads its atoms before it writes them, and FS is
+// not read again).  shift: what make_shifted subtracted (added back to the window centre).  evals_sink: lane 0
+// adds the number of objective evaluations there.
 template <class T>
-PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int n, int cluster,
-                              const Sphere& sp, const pw_params& prm, const WinArrays& wa) {
-    auto& v = *sh.v;
-    const int w = T::wave();
-    Frame& R = sh.R[w];
+PW_NOINLINE PW_HD inline void wave_window(const Frame& FS, const Frame& R, PW_LDS void* lbmem, TeamWorkspace* ws, int n,
+                                          int cluster, const double* shift, const pw_params& prm, const WinArrays& wa,
+                                          int* evals_sink) {
     int evals = 0;
     // (i) the cluster's vector with the largest 2*gap was selected by stage_windows
     double vx = wa.vec[3 * cluster], vy = wa.vec[3 * cluster + 1], vz = wa.vec[3 * cluster + 2];
@@ -1994,7 +1998,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
             double qy[2] = {cy * (double)k0, cy * (double)k1};
             double qz[2] = {cz * (double)k0, cz * (double)k1};
             double m[2];
-            points_gap_values<2>(sh.S, n, qx, qy, qz, m);
+            points_gap_values<2>(FS, n, qx, qy, qz, m);
             if (!(m[0] > 0.0)) ok = false;
             if (m[0] < pbest) { pbest = m[0]; ppos = k0; }
             if (k1 != k0) {
@@ -2004,7 +2008,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
         }
     } else {
         for (int k = T::lane(); k <= chunks; k += T::WSIZE) {
-            double m = point_gap_value(sh.S, n, cx * (double)k, cy * (double)k, cz * (double)k);
+            double m = point_gap_value(FS, n, cx * (double)k, cy * (double)k, cz * (double)k);
             if (!(m > 0.0)) ok = false;
             if (m < pbest) { pbest = m; ppos = k; }
         }
@@ -2014,7 +2018,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     if (!ok) {
         if (T::lane() == 0) {
             wa.ok[cluster] = 0;
-            v.red_i[8 + w] += evals;
+            *evals_sink += evals;
         }
         return;
     }
@@ -2051,7 +2055,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
         return pw_fma(m2, z, pw_fma(m0, x, m1 * y));
     };
     for (int i = T::lane(); i < n; i += T::WSIZE) {
-        double x = sh.S.x[i], y = sh.S.y[i], z = sh.S.z[i];
+        double x = FS.x[i], y = FS.y[i], z = FS.z[i];
         double x1 = row(co1, -s1, 0.0, x, y, z);
         double y1 = row(s1, co1, 0.0, x, y, z);
         double z1 = row(0.0, 0.0, 1.0, x, y, z);
@@ -2072,7 +2076,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     // search once more from the in-plane optimum (z_second_mini, :1326-1334)
     Lbfgsb<1> zopt_state;
     Lbfgsb<1>* S = &zopt_state;
-    LbMem<1>* Smem = (LbMem<1>*)sh.lb[w];
+    LbMem<1>* Smem = (LbMem<1>*)lbmem;
     PW_ASSUME_LDS(Smem);
     double lo1[1] = {prm.lb_z ? -new_z : prm.z_lo}, up1[1] = {prm.z_hi};
     int nbd1[1];
@@ -2083,7 +2087,7 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
     if (lo1[0] > up1[0]) {                       // scipy: ValueError -- reported through the status
         if (T::lane() == 0) {
             wa.ok[cluster] = -1;                 // "bounds", not "path scan failed"
-            v.red_i[8 + w] += evals;
+            *evals_sink += evals;
         }
         return;
     }
@@ -2204,10 +2208,10 @@ PW_NOINLINE PW_HD inline void wave_window(UnitShared& sh, TeamWorkspace* ws, int
         }
         wa.ok[cluster] = 1;
         wa.d[cluster] = dfin;
-        wa.c[3 * cluster] = ux + v.shift[0];
-        wa.c[3 * cluster + 1] = uy + v.shift[1];
-        wa.c[3 * cluster + 2] = uz + v.shift[2];
-        v.red_i[8 + w] += evals;
+        wa.c[3 * cluster] = ux + shift[0];
+        wa.c[3 * cluster + 1] = uy + shift[1];
+        wa.c[3 * cluster + 2] = uz + shift[2];
+        *evals_sink += evals;
     }
 }
 
@@ -2376,12 +2380,21 @@ PW_HD inline __attribute__((always_inline)) int team_dbscan(PW_LDS unsigned long
 }
 
 // ---- stage: windows ----------------------------------------------------------------------------
+// ---- find_windows in two parts (utilities.py:1364-1553) -------------------------------------------------
+// windows_bulk: everything up to and including the clustering -- shift, sampling sphere, DBSCAN radius, ray
+// pre-analysis, path scans, DBSCAN, the vector chosen for every cluster (:1374-1487, :1221) -- the part that
+// is bulk loops over sampling vectors and atoms and needs no optimiser state.  Returns the number of clusters
+// (their chosen vectors in wa.vec, wa.ok cleared), or -1 when the search has ended (no vector reaches the
+// outside, or a capacity flag: the record is final).  wave_window fits one cluster; windows_finish assembles
+// the record.  One team can do all three in a row (stage_windows: single launches, the host path, molecules
+// beyond LDS), or the pipeline hands the clusters over in a FitTicket: the sampling launch (4-wave teams, a
+// register budget without the optimisers' state) writes it, one-wave fit workers consume it.
+// defer_large: more clusters than a ticket holds (PW_W_MAX) are not set up here -- the count is returned and
+// the caller sends the unit through stage_windows instead.
 template <class T>
-PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
-                                             const pw_params& prm) {
+PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
+                                                                  const pw_params& prm, WinArrays& wa, bool defer_large) {
     auto& v = *sh.v;
-    WinArrays wa;
-    wa.vec = (double*)&v.win_vec[0][0]; wa.d = (double*)v.win_d; wa.c = (double*)&v.win_c[0][0]; wa.ok = (int*)v.win_ok;
     // shift so that the optimised pore centre (pore_opt) or the centre of mass is the origin
     // (utilities.py:1380-1393)
     if (T::tid() == 0) {
@@ -2418,7 +2431,7 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
         // DBSCAN radius is taken from (the reference: KDTree.query(k=10) raises, utilities.py:1428-1431)
         if (T::tid() == 0) v.status |= P < 10 ? PW_ST_TOO_FEW_POINTS : PW_ST_POINTS_OVERFLOW;
         T::sync();
-        return;
+        return -1;
     }
     Sphere sp;
     sp.init(radius, P);
@@ -2844,7 +2857,7 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
         // no vector reaches the outside: find_windows returns None
         if (T::tid() == 0) out->n_windows = -1;
         T::sync();
-        return;
+        return -1;
     }
     PW_T0(t_db);
     arena = arena_mark;                   // tmpv is dead: its values were compacted into vals
@@ -2854,7 +2867,7 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
         if (label < 0) {
             if (T::tid() == 0) v.status |= PW_ST_POINTS_OVERFLOW;
             T::sync();
-            return;
+            return -1;
         }
         if (T::tid() == 0) {
             v.n_clusters = label;
@@ -2863,6 +2876,7 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
         // the per-cluster arrays: team LDS for what a record holds, the team's global slab beyond
         // (clusters <= core points <= survivors <= p_cap)
         if (label > PW_W_MAX) {
+            if (defer_large) return label;
             wa.vec = ws->xw; wa.d = ws->xw + 3 * (size_t)ws->p_cap; wa.c = ws->xw + 4 * (size_t)ws->p_cap; wa.ok = ws->xw_ok;
         }
         for (int c = T::tid(); c < label; c += T::SIZE) wa.ok[c] = 0;
@@ -2895,6 +2909,55 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
         }
     }
     if (T::wave() == 0) PW_T1(ws, 10, t_db);
+    return v.n_clusters;
+}
+
+// result assembly (utilities.py:1526-1536) by ONE thread: the fitted windows in cluster order; the record holds
+// PW_W_MAX of them, the others go to the launch's extra-window list.  Returns the status bits to merge.
+PW_HD inline int windows_finish(const WinArrays& wa, int ncl, pw_unit_out* out, TeamWorkspace* ws, long unit) {
+    int st = 0, m = 0;
+    for (int c = 0; c < ncl; ++c) {
+        if (wa.ok[c] > 0) {
+            const double wd = wa.d[c];
+            if (m < PW_W_MAX) {
+                out->win_d[m] = wd;
+                out->win_c[m][0] = wa.c[3 * c];
+                out->win_c[m][1] = wa.c[3 * c + 1];
+                out->win_c[m][2] = wa.c[3 * c + 2];
+            } else {
+                st |= PW_ST_WINDOW_OVERFLOW;
+                unsigned slot = team_atomic_inc(ws->xwin_count);
+                if (ws->xwin && slot < ws->xwin_cap) {
+                    pw_extra_window* e = ws->xwin + slot;
+                    e->unit = unit; e->index = m; e->reserved = 0; e->d = wd;
+                    e->c[0] = wa.c[3 * c]; e->c[1] = wa.c[3 * c + 1]; e->c[2] = wa.c[3 * c + 2];
+                }
+            }
+            if (wd < 0.0) st |= PW_ST_WINDOW_NEGATIVE;
+            ++m;
+        } else if (wa.ok[c] < 0) {
+            st |= PW_ST_Z_BOUNDS;
+        } else {
+            st |= PW_ST_WINDOW_DROPPED;
+        }
+    }
+    out->n_windows = m;
+    return st;
+}
+
+template <class T>
+PW_NOINLINE PW_HD inline int stage_windows_bulk(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
+                                                const pw_params& prm, WinArrays& wa) {
+    return windows_bulk_impl<T>(sh, ws, n, out, prm, wa, true);
+}
+
+template <class T>
+PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
+                                             const pw_params& prm) {
+    auto& v = *sh.v;
+    WinArrays wa;
+    wa.vec = (double*)&v.win_vec[0][0]; wa.d = (double*)v.win_d; wa.c = (double*)&v.win_c[0][0]; wa.ok = (int*)v.win_ok;
+    if (windows_bulk_impl<T>(sh, ws, n, out, prm, wa, false) < 0) return;
     PW_T0(t_w);
     // ---- one window per cluster, clusters dealt round-robin to the waves -------------------
     const int ncl = v.n_clusters;
@@ -2902,43 +2965,160 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
     // in an 8-wave team the upper four only take part in the bulk stages
     int nslot = T::NWAVES < 4 ? T::NWAVES : 4;
     if (sh.nslots < nslot) nslot = sh.nslots;       // (a launch may carve fewer slots than waves to save LDS)
-    if (T::wave() < nslot)
-        for (int c = T::wave(); c < ncl; c += nslot) wave_window<T>(sh, ws, n, c, sp, prm, wa);
+    if (T::wave() < nslot) {
+        const double shift[3] = {v.shift[0], v.shift[1], v.shift[2]};
+        for (int c = T::wave(); c < ncl; c += nslot)
+            wave_window<T>(sh.S, sh.R[T::wave()], sh.lb[T::wave()], ws, n, c, shift, prm, wa, (int*)&v.red_i[8 + T::wave()]);
+    }
     T::sync();
     if (T::wave() == 0) PW_T1(ws, 12, t_w);
     if (T::tid() == 0) {
-        // result assembly (utilities.py:1526-1536): the fitted windows in cluster order; the record holds
-        // PW_W_MAX of them, the others go to the launch's extra-window list
-        int m = 0;
-        for (int c = 0; c < ncl; ++c) {
-            if (wa.ok[c] > 0) {
-                const double wd = wa.d[c];
-                if (m < PW_W_MAX) {
-                    out->win_d[m] = wd;
-                    out->win_c[m][0] = wa.c[3 * c];
-                    out->win_c[m][1] = wa.c[3 * c + 1];
-                    out->win_c[m][2] = wa.c[3 * c + 2];
-                } else {
-                    v.status |= PW_ST_WINDOW_OVERFLOW;
-                    unsigned slot = team_atomic_inc(ws->xwin_count);
-                    if (ws->xwin && slot < ws->xwin_cap) {
-                        pw_extra_window* e = ws->xwin + slot;
-                        e->unit = ws->unit; e->index = m; e->reserved = 0; e->d = wd;
-                        e->c[0] = wa.c[3 * c]; e->c[1] = wa.c[3 * c + 1]; e->c[2] = wa.c[3 * c + 2];
-                    }
-                }
-                if (wd < 0.0) v.status |= PW_ST_WINDOW_NEGATIVE;
-                ++m;
-            } else if (wa.ok[c] < 0) {
-                v.status |= PW_ST_Z_BOUNDS;
-            } else {
-                v.status |= PW_ST_WINDOW_DROPPED;
-            }
-        }
-        out->n_windows = m;
+        v.status |= windows_finish(wa, ncl, out, ws, ws->unit);
         for (int w = 0; w < T::NWAVES && w < 8; ++w) v.n_eval += v.red_i[8 + w];
     }
     T::sync();
+}
+
+// ---- hand-over between the sampling launch and the fit workers ---------------------------------------------
+// One ticket per unit in global memory.  The sampling team fills ncl / remaining / vec and publishes one queue
+// item per cluster; the worker that fits cluster c writes ok[c], d[c], c[c]; the worker that takes `remaining`
+// to zero assembles the record (windows_finish).  Units with more clusters than a ticket holds never get one
+// (they go through stage_windows in a follow-up launch).
+struct FitTicket {
+    int ncl;
+    int remaining;
+    double vec[PW_W_MAX][3];
+    double d[PW_W_MAX];
+    double c[PW_W_MAX][3];
+    int ok[PW_W_MAX];
+};
+PW_HD inline WinArrays ticket_arrays(FitTicket* t) {
+    WinArrays wa;
+    wa.vec = &t->vec[0][0]; wa.d = t->d; wa.c = &t->c[0][0]; wa.ok = t->ok;
+    return wa;
+}
+
+// Team memory of one fit worker (ONE wave): the molecule's frame -- shifted on the way in, rotated in place by
+// the fit -- radii, an index array, the radius groups, one optimiser block.  Smaller than what an optimiser
+// chain asks for (UnitShared::bytes(nmax, 0, 1, 1, 1)), so the workers of one launch can do either.
+struct FitVars {
+    ClassInfo cls;
+    int evals;
+};
+struct FitShared {
+    PW_LDS FitVars* v;
+    ldouble* vdw;
+    lint* perm;
+    Frame F;
+    PW_LDS void* lb;
+    PW_HD static size_t bytes(int nmax) {
+        const size_t n = (size_t)((nmax + 1) & ~1);
+        return ((sizeof(FitVars) + 15) & ~(size_t)15) + n * 8 + n * 4 + n * 8 * 4 + ((sizeof(LbMem<1>) + 15) & ~(size_t)15);
+    }
+    PW_HD void carve(unsigned char* base, int nmax) {
+        const size_t n = (size_t)((nmax + 1) & ~1);
+        PW_LDS unsigned char* p = (PW_LDS unsigned char*)base;
+        v = (PW_LDS FitVars*)p;
+        p += (sizeof(FitVars) + 15) & ~(size_t)15;
+        ldouble* d = (ldouble*)p;
+        vdw = d; d += n;
+        F.x = d; d += n; F.y = d; d += n; F.z = d; d += n; F.xx = d; d += n;
+        perm = (lint*)d; d += n / 2;
+        lb = (PW_LDS void*)d;
+        F.vdw = vdw; F.perm = perm; F.cls = &v->cls;
+    }
+};
+
+// The frame of a fit, by one wave: atoms grouped by radius like load_unit does (groups in order of first
+// appearance, ascending atom index inside a group; more than PW_KCLS radii: no grouping), coordinates minus
+// `shift` with |r|^2 -- the same numbers make_shifted produces, and every evaluation of the fit is a minimum
+// over atoms (or over groups of per-group minima), so the order inside the arrays cannot show in a result.
+// Groups are found with wave ballots: n x groups / 64 steps instead of load_unit's n^2 / 64.
+template <class T>
+PW_HD inline void load_fit_frame(FitShared& fs, int n, const double* xyz, const double* vdw, const double* shift) {
+    PW_LDS ClassInfo& C = fs.v->cls;
+    const unsigned long long below = T::lane() >= 63 ? ~0ull >> 1 : ((1ull << T::lane()) - 1ull);
+    for (int i = T::lane(); i < n; i += T::WSIZE) fs.vdw[i] = vdw[i];       // caller's order for the moment
+    T::wave_sync();
+    int k = 0;
+    bool many = false;
+    for (int base = 0; base < n && !many; base += T::WSIZE) {
+        const int i = base + T::lane();
+        const double r = i < n ? fs.vdw[i] : 0.0;
+        bool fresh = i < n;
+        for (int g = 0; g < k; ++g) fresh = fresh && !(r == C.vdw[g]);
+        for (;;) {
+            const unsigned long long m = T::ballot(fresh);
+            if (!m) break;
+            if (k == PW_KCLS) { many = true; break; }
+            const double rf = T::bcast_u(r, __builtin_ctzll(m));
+            C.vdw[k] = rf;                      // (every lane stores the same value)
+            k += 1;
+            fresh = fresh && !(r == rf);
+        }
+        T::wave_sync();
+    }
+    if (many) {
+        if (T::lane() == 0) { C.k = 0; C.off[0] = 0; }
+        for (int i = T::lane(); i < n; i += T::WSIZE) fs.perm[i] = i;
+    } else {
+        // positions: group by group, chunk by chunk (stable)
+        int off = 0;
+        for (int g = 0; g < k; ++g) {
+            const double rg = C.vdw[g];
+            if (T::lane() == 0) C.off[g] = off;
+            for (int base = 0; base < n; base += T::WSIZE) {
+                const int i = base + T::lane();
+                const bool mine = i < n && fs.vdw[i] == rg;
+                const unsigned long long m = T::ballot(mine);
+                if (mine) fs.perm[i] = off + __builtin_popcountll(m & below);
+                off += __builtin_popcountll(m);
+            }
+        }
+        if (T::lane() == 0) { C.k = k; C.off[k] = n; }
+    }
+    T::wave_sync();
+    for (int i = T::lane(); i < n; i += T::WSIZE) {
+        const int pos = fs.perm[i];
+        const double x = xyz[3 * i] - shift[0], y = xyz[3 * i + 1] - shift[1], z = xyz[3 * i + 2] - shift[2];
+        fs.F.x[pos] = x; fs.F.y[pos] = y; fs.F.z[pos] = z;
+        fs.F.xx[pos] = sq3(x, y, z);
+    }
+    T::wave_sync();
+    if (!many)      // radii in stored order (every read of the caller-order copy is done)
+        for (int g = 0; g < k; ++g) {
+            const double rg = C.vdw[g];
+            for (int p = C.off[g] + T::lane(); p < C.off[g + 1]; p += T::WSIZE) fs.vdw[p] = rg;
+        }
+    T::wave_sync();
+}
+
+// the shift of find_windows as windows_bulk forms it, from the record (centre of mass and optimised pore
+// centre are there once the optimiser launch has published the unit)
+PW_HD inline void window_shift(const pw_unit_out* out, const pw_params& prm, double* shift) {
+    for (int c = 0; c < 3; ++c) {
+        const double adjust = prm.pore_opt ? out->com[c] - out->pore_opt_c[c] : 0.0;
+        shift[c] = out->com[c] - adjust;
+    }
+}
+
+// One fit by one wave: cluster `cluster` of the unit whose ticket this is.  Returns (lane 0) the number of
+// objective evaluations.
+template <class T>
+PW_HD inline int fit_item(FitShared& fs, TeamWorkspace* ws, int n, const double* xyz, const double* vdw,
+                          const pw_unit_out* out, FitTicket* ticket, int cluster, const pw_params& prm) {
+    double shift[3];
+    window_shift(out, prm, shift);
+#ifdef PW_SABOTAGE
+    shift[0] += 1e-9;
+#endif
+    load_fit_frame<T>(fs, n, xyz, vdw, shift);
+    if (T::lane() == 0) fs.v->evals = 0;
+    T::wave_sync();
+    const WinArrays wa = ticket_arrays(ticket);
+    wave_window<T>(fs.F, fs.F, fs.lb, ws, n, cluster, shift, prm, wa, (int*)&fs.v->evals);
+    T::wave_sync();
+    return fs.v->evals;
 }
 
 // ---- the unit ------------------------------------------------------------------------------------
@@ -2946,6 +3126,7 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
 constexpr unsigned PW_STAGE_REUSE_OPT = 16u;   // pore centre already in the record (earlier launch)
 constexpr unsigned PW_STAGE_MERGE = 32u;       // record is shared with other launches: no resets
 constexpr unsigned PW_STAGE_COM_ONLY = 64u;    // only what later stages need from stage_basic
+constexpr unsigned PW_STAGE_WIN_BULK = 128u;   // find_windows up to the clustering; the clusters go to a FitTicket
 
 PW_HD inline void record_or_status(pw_unit_out* out, int st, int evals) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -2959,13 +3140,17 @@ PW_HD inline void record_or_status(pw_unit_out* out, int st, int evals) {
 
 constexpr unsigned PW_KERNEL_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 
+// ticket / bulk_ncl (PW_STAGE_WIN_BULK only): where the clusters of the window search go, and how many there
+// are: -1 the search has ended, 0 none (two empty arrays), 1 .. PW_W_MAX to be fitted from the ticket, more:
+// nothing was set up and nothing merged into the record -- the caller runs PW_STAGE_WINDOWS on the unit instead
 template <class T, unsigned KMASK = 0xffffffffu>
 PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const double* xyz,
                                const double* vdw, const double* mass, unsigned stages,
-                               pw_unit_out* out, const pw_params& prm) {
+                               pw_unit_out* out, const pw_params& prm, FitTicket* ticket = nullptr,
+                               int* bulk_ncl = nullptr) {
     const bool merge = (stages & PW_STAGE_MERGE) != 0;
     const bool reuse_opt = (stages & PW_STAGE_REUSE_OPT) != 0;
-    if ((stages & PW_STAGE_WINDOWS) && !reuse_opt && prm.pore_opt) stages |= PW_STAGE_OPT;
+    if ((stages & (PW_STAGE_WINDOWS | PW_STAGE_WIN_BULK)) && !reuse_opt && prm.pore_opt) stages |= PW_STAGE_OPT;
     if (T::tid() == 0 && !merge) {
         out->status = 0;
         out->n_eval = 0;
@@ -3011,7 +3196,23 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
         if (!(prm.pore_opt && (sh.v->status & PW_ST_NEGATIVE_PORE))) stage_windows<T>(sh, ws, n, out, prm);
         else if (T::tid() == 0) out->n_windows = -1;     // no window search: None, whichever launch shape
     }
-    if (T::tid() == 0) {
+    bool deferred = false;
+    if ((KMASK & PW_STAGE_WIN_BULK) && (stages & PW_STAGE_WIN_BULK)) {
+        int ncl = -1;
+        if (!(prm.pore_opt && (sh.v->status & PW_ST_NEGATIVE_PORE))) {
+            WinArrays wa = ticket_arrays(ticket);
+            ncl = stage_windows_bulk<T>(sh, ws, n, out, prm, wa);
+            if (T::tid() == 0) {
+                if (ncl == 0) out->n_windows = 0;        // every survivor is noise: two empty arrays
+                if (ncl >= 1 && ncl <= PW_W_MAX) { ticket->ncl = ncl; ticket->remaining = ncl; }
+            }
+            deferred = ncl > PW_W_MAX;
+        } else if (T::tid() == 0) {
+            out->n_windows = -1;
+        }
+        *bulk_ncl = ncl;
+    }
+    if (T::tid() == 0 && !deferred) {
         if (merge) {
             record_or_status(out, sh.v->status, sh.v->n_eval);
         } else {

@@ -136,6 +136,20 @@ def raise_on_capacity(rec) -> None:
             f"{int(rec['n_points_avg'])}): analyse through pw_analysis_batch / Context.analyse, which grows it")
 
 
+def raise_on_uncomputable(recs) -> None:
+    """The resident paths (trajectory drivers) after their capacities have settled (``Resident.download_settled``
+    grows the sampling-vector workspace and repeats the launch): a unit that STILL carries
+    ``PW_ST_POINTS_OVERFLOW`` has no average diameter and no windows -- an error, never a value -- and a unit
+    with fewer than ten sampling vectors makes the reference's trajectory analysis raise ``ValueError`` from
+    ``KDTree.query(k=10)`` (utilities.py:1428-1431), so it does here."""
+    st = recs["status"]
+    bad = np.flatnonzero(st & _lib.ST_POINTS_OVERFLOW)
+    if len(bad):
+        raise_on_capacity(recs[bad[0]])
+    if (st & _lib.ST_TOO_FEW_POINTS).any():
+        raise ValueError("k must be less than or equal to the number of training points")
+
+
 #: what scipy.optimize.minimize raises inside the reference's opt_pore_diameter / find_windows when the
 #: pore radius at the start is negative: the box ``start -/+ r`` is inverted (utilities.py:412-424)
 NEGATIVE_PORE_MESSAGE = "An upper bound is less than the corresponding lower bound."

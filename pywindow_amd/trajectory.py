@@ -23,6 +23,7 @@ import numpy as np
 from . import _lib, engine
 from .element_data import MASS, VDW, element_ids
 from .molecular import MolecularSystem, decipher_atom_key
+from .records import LazyAnalysis, RecordStore
 
 #: most frames a modular analysis pushes through the device in one piece (see Trajectory._run_modular)
 MODULAR_CHUNK = 8192
@@ -67,6 +68,7 @@ class DLPOLY:
         self.system_id = self.filepath.name.split(".")[0]
         self.frames: dict = {}
         self.analysis_output: dict = {}
+        self._record_view = LazyAnalysis()      # the records behind analysis_output (save_records / lazy views)
         L = _lib.load()
         h = ctypes.c_void_p()
         rc = L.pw_history_open(str(self.filepath).encode(), ctypes.byref(h))
@@ -143,15 +145,26 @@ class DLPOLY:
         sel = self._select(frames)
         el = self.elements(swap_atoms, forcefield)
         out = {}
+        L = _lib.load()
+        imcon = int(L.pw_history_imcon(self._h))
+        keytrj = int(L.pw_history_keytrj(self._h))
         for f in sel:
             lat = np.zeros((1, 3, 3)) if self.periodic else None
             xyz = self.read_coordinates(f, 1, lat)[0]
-            sysd = {"atom_ids": self.atom_ids.copy(), "coordinates": xyz, "elements": el.copy()}
+            nstep, tstep = ctypes.c_int64(0), ctypes.c_double(0.0)
+            if L.pw_history_frame_info(self._h, f, ctypes.byref(nstep), ctypes.byref(tstep)) != 0:
+                raise _TrajectoryError(f"cannot decode the timestep record of frame {f}")
+            # the keys of the reference's decoded frame, in its order (trajectory.py:712-766)
+            sysd = {"frame_info": {"nstep": int(nstep.value), "natms": self.no_of_atoms, "keytrj": keytrj,
+                                   "imcon": imcon, "tstep": float(tstep.value)}}
             if lat is not None:
                 from .rebuild import lattice_array_to_unit_cell
 
                 sysd["lattice"] = lat[0]
                 sysd["unit_cell"] = lattice_array_to_unit_cell(lat[0])
+            sysd["atom_ids"] = self.atom_ids.copy()
+            sysd["coordinates"] = xyz
+            sysd["elements"] = el.copy()
             out[f] = MolecularSystem.load_system(sysd, f"{self.system_id}_{f}")
             self.frames[f] = out[f]
         if isinstance(frames, int):
@@ -193,7 +206,54 @@ class DLPOLY:
             raise TypeError("Not serializable")
 
         # (dumps, not dump: one pass of the C encoder instead of the chunk-by-chunk Python iterator)
-        path.write_text(json.dumps(self.analysis_output, default=enc))
+        out = self.analysis_output.materialise() if isinstance(self.analysis_output, LazyAnalysis) else self.analysis_output
+        path.write_text(json.dumps(out, default=enc))
+
+    # ---- columnar persistence and lazy views --------------------------------------
+    def _keep(self, store: RecordStore, lazy: bool) -> None:
+        """Results of an analysis enter ``analysis_output``: as the reference's nested dicts (default), or --
+        ``lazy`` -- as a view that builds a frame's dict from the records when it is first asked for."""
+        self._record_view.attach(store)
+        if lazy or isinstance(self.analysis_output, LazyAnalysis):
+            if not isinstance(self.analysis_output, LazyAnalysis):
+                self.analysis_output = LazyAnalysis(self.analysis_output)
+            self.analysis_output.attach(store)
+            return
+        if store.modular:
+            for f in store.spans():
+                self.analysis_output[f] = {}
+            props = engine.records_to_properties(store.records, store.stages, extra=store.extra)
+            for p, f, m in zip(props, store.unit_frame.tolist(), store.unit_molecule.tolist()):
+                self.analysis_output[f][m] = p
+        else:
+            props = engine.records_to_properties(store.records, store.stages, extra=store.extra)
+            for f, p in zip(store.unit_frame.tolist(), props):
+                self.analysis_output[f] = {"0": p}
+
+    def save_records(self, filepath=None, override: bool = False):
+        """The analysis so far as ONE flat file: the structured record array, the (frame, molecule) of every
+        unit, the windows beyond what a record holds (pywindow_amd/records.py: JSON header + raw arrays,
+        reopened as a memory map).  The columnar counterpart of ``save_analysis`` (reference
+        trajectory.py:251-271 writes JSON): 500 000 units are 350 MB, a fraction of a second to write and
+        milliseconds to reopen.  Same ``override`` rule as ``save_analysis``."""
+        path = pathlib.Path(filepath) if filepath is not None else pathlib.Path.cwd() / f"{self.system_id}_pywindow_records"
+        if path.suffix == "":
+            path = path.with_suffix(".pwrec")
+        if override is False and path.is_file():
+            raise FileExistsError(f"The file {path} already exists. Use a different filepath, or set the 'override' to True.")
+        return self._record_view.record_store().save(path)
+
+    def load_records(self, filepath) -> RecordStore:
+        """Reopen what ``save_records`` wrote: ``analysis_output`` becomes a lazy view of the records
+        (``analysis_output[frame][molecule]`` is built on first access), ``analysis_store`` returns them."""
+        store = RecordStore.load(filepath)
+        self._keep(store, lazy=True)
+        return store
+
+    @property
+    def analysis_store(self) -> RecordStore:
+        """The records behind ``analysis_output`` (every frame analysed or loaded so far, in order)."""
+        return self._record_view.record_store()
 
     def analysis_records(self, frames="all", swap_atoms=None, forcefield=None, device=None) -> np.ndarray:
         """Columnar results: the structured record array (``_lib.UNIT_OUT_DTYPE``) for the
@@ -205,8 +265,13 @@ class DLPOLY:
     # ---- the hot path -----------------------------------------------------------------------
     def analysis(self, frames="all", ncpus: int = 1, ncpus_analysis: int = 1, override: bool = False,
                  modular: bool = False, rebuild: bool = False, swap_atoms: dict | None = None,
-                 forcefield: str | None = None, device: int | None = None, distributed: bool | None = None):
+                 forcefield: str | None = None, device: int | None = None, distributed: bool | None = None,
+                 lazy: bool = False):
         """``full_analysis`` of every selected frame in one launch per GPU.
+
+        ``lazy=True``: ``analysis_output`` becomes a view of the result records that builds a frame's dict when
+        it is first asked for (pywindow_amd/records.py) instead of a dict per unit up front -- at 500 000 units the
+        dicts cost as much as the analysis.  ``save_records`` / ``load_records`` persist the records either way.
 
         ``ncpus`` / ``ncpus_analysis`` are accepted for API compatibility and
         ignored (there is no CPU path).  Results land in ``analysis_output[frame]["0"]``
@@ -218,7 +283,7 @@ class DLPOLY:
         """
         del ncpus, ncpus_analysis
         if modular is True:
-            return self._analysis_modular(frames, override, rebuild is True, swap_atoms, forcefield, device, distributed)
+            return self._analysis_modular(frames, override, rebuild is True, swap_atoms, forcefield, device, distributed, lazy)
         sel = self._select(frames)
         if not override:
             sel = [f for f in sel if f not in self.analysis_output]
@@ -243,8 +308,7 @@ class DLPOLY:
             extra = gather_extra(extra, rank, world, dist, device)
         if rank != 0:
             return
-        for f, props in zip(sel, engine.records_to_properties(recs, extra=extra)):
-            self.analysis_output[f] = {"0": props}
+        self._keep(RecordStore(recs, np.asarray(sel, np.int64), None, extra), lazy)
 
     def _run(self, frames: list[int], vdw, mass, device):
         """Records of the given frames (tokenised by the native reader's threads, 1.3 ms per 1000 frames)."""
@@ -263,55 +327,67 @@ class DLPOLY:
         inflight, parts, extras = [], [], []
         done = [0]
 
-        def collect(res):
-            extra = []
-            parts.append(res.download(extra))
-            extras.extend(engine.offset_extra(e, done[0]) for e in extra)
-            done[0] += res.n_units
-            res.free()                  # (its device block goes back to the context's cache)
+        def collect():
+            res = inflight[0]           # (stays listed until it has been freed: a download that raises leaks nothing)
+            try:
+                extra = []
+                parts.append(res.download_settled(extra))
+                extras.extend(engine.offset_extra(e, done[0]) for e in extra)
+                done[0] += res.n_units
+            finally:
+                inflight.pop(0)
+                res.free()              # (its device block goes back to the context's cache)
 
-        try:
-            for lo in range(0, n, per):
-                sel = frames[lo:lo + per]
-                coords, _ = self._read_selected(sel, False, out=ctx.pinned_array((len(sel), self.no_of_atoms, 3)))
-                res = ctx.upload(_lib.Batch.uniform(coords, vdw, mass))
-                res.launch(_lib.STAGE_ALL)
-                inflight.append(res)
-                if len(inflight) > 2:   # at most three pieces on the device, however long the trajectory
-                    collect(inflight.pop(0))
-            while inflight:
-                collect(inflight.pop(0))
-            if extras:
-                self._extra = np.concatenate(extras)
-            return parts[0] if len(parts) == 1 else np.concatenate(parts)
-        finally:
-            for res in inflight:
-                res.free()
+        # the context's staging buffer, its "records fetched last" list and its capacities are one per context:
+        # one trajectory at a time goes through (threads analysing on the same device take turns here)
+        with ctx.lock:
+            try:
+                for lo in range(0, n, per):
+                    sel = frames[lo:lo + per]
+                    coords, _ = self._read_selected(sel, False, out=ctx.pinned_array((len(sel), self.no_of_atoms, 3)))
+                    res = ctx.upload(_lib.Batch.uniform(coords, vdw, mass))
+                    inflight.append(res)
+                    res.launch(_lib.STAGE_ALL)
+                    if len(inflight) > 2:   # at most three pieces on the device, however long the trajectory
+                        collect()
+                while inflight:
+                    collect()
+            finally:
+                for res in inflight:
+                    res.free()
+        if extras:
+            self._extra = np.concatenate(extras)
+        recs = parts[0] if len(parts) == 1 else np.concatenate(parts)
+        engine.raise_on_uncomputable(recs)
+        return recs
 
     def _run_and_gather_on_device(self, frames, vdw, mass, device, n_total, rank, world, dist):
         import torch
 
         dev = engine.resolve_device(device)
         res = None
-        if frames:
-            coords, _ = self._read_selected(frames, False)
-            res = engine.context(dev).upload(_lib.Batch.uniform(coords, vdw, mass))
-            res.launch(_lib.STAGE_ALL)
-        self._extra = np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE)
-        try:
-            recs = gather_records_device(res, n_total, rank, world, dist, torch.device("cuda", dev))
-            if res is not None:
-                # the gather read the records on the device; what only the host can see comes now: a
-                # window launch that timed out (raises), and the windows beyond what a record holds
-                try:
-                    self._extra = res.check()
-                except _lib.PwRetry:
-                    res.launch(_lib.STAGE_ALL)
-                    self._extra = res.check()
-            return recs
-        finally:
-            if res is not None:
-                res.free()
+        ctx = engine.context(dev)
+        with ctx.lock:
+            if frames:
+                coords, _ = self._read_selected(frames, False)
+                res = ctx.upload(_lib.Batch.uniform(coords, vdw, mass))
+                res.launch(_lib.STAGE_ALL)
+            self._extra = np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE)
+            try:
+                recs = gather_records_device(res, n_total, rank, world, dist, torch.device("cuda", dev))
+                if res is not None:
+                    # the gather read the records on the device; what only the host can see comes now: a
+                    # window launch that timed out (raises), and the windows beyond what a record holds
+                    try:
+                        self._extra = res.check()
+                    except _lib.PwRetry:
+                        res.launch(_lib.STAGE_ALL)
+                        self._extra = res.check()
+                engine.raise_on_uncomputable(recs)
+                return recs
+            finally:
+                if res is not None:
+                    res.free()
 
     # ---- modular analysis: frames -> discrete molecules -> units --------------------------------
     def modular_records(self, frames="all", rebuild: bool = False, swap_atoms=None, forcefield=None, device=None):
@@ -346,16 +422,19 @@ class DLPOLY:
         extras: list = []
         done = [0]
 
-        def collect(entry):
-            res, n_mol = entry
-            extra: list = []
-            recs = res.download(extra) if res is not None else np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE)
-            extras.extend(engine.offset_extra(e, done[0]) for e in extra)
-            done[0] += len(recs)
-            if res is not None:
-                res.free()                 # (its blocks go back to the context's cache: no device-wide wait, and the
+        def collect():
+            res, n_mol = waiting[0]        # (stays listed until it has been freed: a download that raises leaks nothing)
+            try:
+                extra: list = []
+                recs = res.download_settled(extra) if res is not None else np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE)
+                extras.extend(engine.offset_extra(e, done[0]) for e in extra)
+                done[0] += len(recs)
+                parts.append((recs, n_mol))
+            finally:
+                waiting.pop(0)
+                if res is not None:
+                    res.free()             # (its blocks go back to the context's cache: no device-wide wait, and the
                                            # memory of a long trajectory stays at the pieces in flight)
-            parts.append((recs, n_mol))
 
         def read_piece(i):
             coords, lattice = self._read_selected(frames[i:i + piece], self.periodic)
@@ -369,6 +448,7 @@ class DLPOLY:
             from concurrent.futures import ThreadPoolExecutor
 
             pool = ThreadPoolExecutor(max_workers=1)
+        ctx.lock.acquire()                 # (one trajectory at a time per context, see _run)
         try:
             ahead = pool.submit(read_piece, starts[0]) if pool else None
             for k, i in enumerate(starts):
@@ -378,20 +458,22 @@ class DLPOLY:
                 else:
                     coords, lat, inv = read_piece(i)
                 res, n_mol = ctx.resident_from_cells(topo, vdw, coords, lat, inv, rebuild)
+                waiting.append((res, n_mol))
                 if res is not None:
                     res.launch(_lib.STAGE_ALL)
-                waiting.append((res, n_mol))
                 if len(waiting) > MODULAR_IN_FLIGHT:
-                    collect(waiting.pop(0))
+                    collect()
             while waiting:
-                collect(waiting.pop(0))
+                collect()
         finally:
             if pool is not None:
                 pool.shutdown(wait=True)
             for res in spent + [w[0] for w in waiting]:
                 if res is not None:
                     res.free()
+            ctx.lock.release()
         recs = np.concatenate([p[0] for p in parts])
+        engine.raise_on_uncomputable(recs)
         self._extra = np.concatenate(extras) if extras else np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE)
         n_mol = np.concatenate([p[1] for p in parts])
         unit_frame = np.repeat(np.asarray(frames, np.int64), n_mol)
@@ -399,7 +481,7 @@ class DLPOLY:
                     else np.zeros(0, np.int64))
         return recs, unit_frame, unit_mol
 
-    def _analysis_modular(self, frames, override, rebuild, swap_atoms, forcefield, device, distributed):
+    def _analysis_modular(self, frames, override, rebuild, swap_atoms, forcefield, device, distributed, lazy=False):
         sel = self._select(frames)
         if not override:
             sel = [f for f in sel if f not in self.analysis_output]
@@ -422,10 +504,17 @@ class DLPOLY:
                 return
             tags = tags.reshape(-1, 2)
             uframe, umol = tags[:, 0], tags[:, 1]
-        for f in sel:
-            self.analysis_output[f] = {}
-        for props, f, m in zip(engine.records_to_properties(recs, extra=extra), uframe.tolist(), umol.tolist()):
-            self.analysis_output[f][m] = props
+        store = RecordStore(recs, uframe, umol, extra)
+        view = lazy or isinstance(self.analysis_output, LazyAnalysis)
+        if not view:
+            for f in sel:                      # (key order = selection order, as the reference's loop leaves it)
+                self.analysis_output[f] = {}
+        self._keep(store, lazy)
+        if view:
+            # a frame in which no molecule was found has no unit: the reference leaves an empty dict for it
+            for f in sel:
+                if f not in store.spans():
+                    self.analysis_output[f] = {}
 
 
 def _dist_state(distributed):

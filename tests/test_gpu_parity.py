@@ -461,27 +461,33 @@ def test_other_cages_with_fresh_noise_against_live_oracle(hip_ctx):
     assert checked_windows >= 30
 
 
-def test_row_packed_chains_variant_is_bit_identical(monkeypatch):
-    """PW_ROW_CHAINS=1 -- four optimiser chains per wavefront, one per row of 16 lanes (measured 2x slower in
-    the pipeline, profiles/r03_row_packed_chains.txt; kept selectable) -- must give the records of the default
-    one-wave chains byte for byte: the same Lbfgsb<3> source on a 16-lane team."""
+def test_every_launch_shape_gives_the_same_records(monkeypatch):
+    """One analysis, three launch shapes, the same bytes: the default pipeline (optimiser chains and window fits
+    by one-wave workers, the sampling half of the window search by 4-wave teams, hand-over through FitTickets),
+    PW_SPLIT=0 (the window search as one launch of 4-wave teams, round 3's shape) and PW_FUSED=1 (every stage in
+    one team).  On the real MD frames and on the static molecules (60 to 468 atoms, none to six windows)."""
     from pywindow_amd import _lib
 
-    g = load_group("md20")
-    off, xyz, vdw, mass = group_batch(g)
-    batch = _lib.Batch(off, xyz, vdw, mass)
-    plain = _lib.Context(0)
-    a = plain.upload(batch)
-    a.launch()
-    ra = a.download()
-    a.free()
-    plain.close()
-    monkeypatch.setenv("PW_ROW_CHAINS", "1")
-    rows = _lib.Context(0)
-    b = rows.upload(batch)
-    b.launch()
-    rb = b.download()
-    b.free()
-    rows.close()
-    assert ra.tobytes() == rb.tobytes()
-    check_records(rb, g, where="row-packed chains")
+    for tag in ("md20", "static"):
+        g = load_group(tag)
+        off, xyz, vdw, mass = group_batch(g)
+        batch = _lib.Batch(off, xyz, vdw, mass)
+        got = {}
+        for name, env in (("split", {}), ("one window launch", {"PW_SPLIT": "0"}), ("one launch", {"PW_FUSED": "1"})):
+            for k in ("PW_SPLIT", "PW_FUSED"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ctx = _lib.Context(0)
+            assert ctx.pipelined == (name != "one launch")
+            res = ctx.upload(batch)
+            res.launch()
+            got[name] = res.download()
+            # ... and again on the same context (the second launch runs on another buffer set)
+            res.launch()
+            assert res.download().tobytes() == got[name].tobytes(), (tag, name)
+            res.free()
+            ctx.close()
+        check_records(got["split"], g, where=f"{tag} split pipeline")
+        assert got["split"].tobytes() == got["one window launch"].tobytes(), tag
+        assert got["split"].tobytes() == got["one launch"].tobytes(), tag

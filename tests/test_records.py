@@ -1,0 +1,174 @@
+"""Columnar persistence and lazy views of a trajectory analysis (pywindow_amd/records.py).
+
+The reference keeps ``analysis_output[frame][molecule]`` dicts and dumps them as JSON (trajectory.py:251-271,
+io_tools.py:215-265).  Here the records ARE the result: ``save_records`` / ``load_records`` persist the structured
+array with its (frame, molecule) index and the extra windows, ``analysis(lazy=True)`` / a loaded file give a view
+that builds a frame's dict on first access -- deep-equal to what the eager path builds.  Runs on the explicit host
+context (device = -1), i.e. without a GPU; the records are the same bytes on the device (test_gpu_parity.py)."""
+import json
+import time
+
+import numpy as np
+import pytest
+
+from pywindow_amd import _lib, engine, records, synth
+from pywindow_amd.trajectory import DLPOLY
+
+
+def deep_equal(a, b, where="root"):
+    assert type(a) is type(b), (where, type(a), type(b))
+    if isinstance(a, dict):
+        assert list(a.keys()) == list(b.keys()), where
+        for k in a:
+            deep_equal(a[k], b[k], f"{where}[{k!r}]")
+    elif isinstance(a, np.ndarray):
+        assert a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes(), where
+    else:
+        assert a == b or (a != a and b != b), where
+
+
+@pytest.fixture(scope="module")
+def history(tmp_path_factory):
+    return synth.write_synthetic_history(tmp_path_factory.mktemp("rec") / "HISTORY", 12)
+
+
+def test_lazy_view_equals_the_eager_dicts(history):
+    eager = DLPOLY(history)
+    eager.analysis(device=-1)
+    lazy = DLPOLY(history)
+    lazy.analysis(device=-1, lazy=True)
+    assert type(eager.analysis_output) is dict
+    assert isinstance(lazy.analysis_output, records.LazyAnalysis)
+    assert list(lazy.analysis_output) == list(eager.analysis_output) == list(range(12))
+    assert len(lazy.analysis_output) == 12 and 3 in lazy.analysis_output and 99 not in lazy.analysis_output
+    assert "0 built" in repr(lazy.analysis_output)
+    deep_equal(lazy.analysis_output[5], eager.analysis_output[5])
+    assert "1 built" in repr(lazy.analysis_output)
+    assert lazy.analysis_output[5] is lazy.analysis_output[5]            # built once, cached
+    deep_equal(lazy.analysis_output.materialise(), eager.analysis_output)
+    with pytest.raises(KeyError):
+        lazy.analysis_output[99]
+    # later analyses keep feeding the view; frames already there are skipped unless override
+    lazy.analysis(frames=[2, 3], device=-1)
+    assert isinstance(lazy.analysis_output, records.LazyAnalysis) and len(lazy.analysis_output) == 12
+    # hand-made entries are kept as given
+    lazy.analysis_output[40] = {"0": {"note": 1}}
+    assert lazy.analysis_output[40] == {"0": {"note": 1}} and list(lazy.analysis_output)[-1] == 40
+
+
+def test_records_survive_a_file(history, tmp_path):
+    traj = DLPOLY(history)
+    traj.analysis(frames=[7, 2, 3], device=-1)
+    path = traj.save_records(tmp_path / "cc3")
+    assert path.name == "cc3.pwrec"
+    with pytest.raises(FileExistsError):
+        traj.save_records(tmp_path / "cc3")
+    traj.save_records(tmp_path / "cc3", override=True)
+    raw = path.read_bytes()                                     # a JSON header, then the arrays as they lie in memory
+    assert raw.startswith(records.MAGIC) and len(raw) % records.HEADER_BYTES == 0
+    meta = json.loads(raw[len(records.MAGIC):records.HEADER_BYTES].rstrip(b"\0"))
+    assert meta["format"] == records.FORMAT and meta["arrays"]["records"]["count"] == 3
+    at = meta["arrays"]["records"]["offset"]
+    assert raw[at:at + 3 * _lib.UNIT_OUT_DTYPE.itemsize] == traj.analysis_store.records.tobytes()
+    plain = records.RecordStore.load(path, mmap=False)
+    assert plain.unit_frame.tolist() == [7, 2, 3] and plain.unit_molecule.tolist() == [-1, -1, -1]
+    again = DLPOLY(history)
+    store = again.load_records(path)
+    assert store.records.tobytes() == traj.analysis_store.records.tobytes()
+    assert list(again.analysis_output) == [7, 2, 3]
+    deep_equal(again.analysis_output.materialise(), traj.analysis_output)
+    # the JSON route is what it was: the text of a loaded analysis equals the text of the original
+    traj.save_analysis(tmp_path / "a")
+    again.save_analysis(tmp_path / "b")
+    assert (tmp_path / "a.json").read_text() == (tmp_path / "b.json").read_text()
+    assert list(json.loads((tmp_path / "a.json").read_text())) == ["7", "2", "3"]
+    # a second analysis on the loaded trajectory appends to the same store
+    again.analysis(frames=[0, 2], device=-1)
+    assert list(again.analysis_output) == [7, 2, 3, 0]
+    assert again.analysis_store.unit_frame.tolist() == [7, 2, 3, 0]
+
+
+def test_modular_store_round_trip(tmp_path):
+    """Units keyed (frame, molecule): int molecule keys, several units per frame, a frame without units, and
+    windows beyond what a record holds travel through the file."""
+    rng = np.random.default_rng(5)
+    recs = np.zeros(6, dtype=_lib.UNIT_OUT_DTYPE)
+    recs["n_atoms"] = 168
+    recs["n_windows"] = [4, 0, -1, 18, 2, 1]
+    recs["win_d"] = rng.random((6, _lib.W_MAX))
+    recs["win_c"] = rng.random((6, _lib.W_MAX, 3))
+    recs["status"][3] = _lib.ST_WINDOW_OVERFLOW
+    extra = np.zeros(2, dtype=_lib.EXTRA_WINDOW_DTYPE)
+    extra["unit"] = 3
+    extra["index"] = [16, 17]
+    extra["d"] = [1.5, 2.5]
+    store = records.RecordStore(recs, [4, 4, 4, 9, 9, 11], [0, 1, 2, 0, 1, 0], extra)
+    assert store.modular and store.spans() == {4: (0, 3), 9: (3, 5), 11: (5, 6)}
+    back = records.RecordStore.load(store.save(tmp_path / "m.pwrec"))
+    assert back.records.tobytes() == recs.tobytes() and back.extra.tobytes() == extra.tobytes()
+    f9 = back.frame_properties(9)
+    assert list(f9) == [0, 1] and len(f9[0]["windows"]["diameters"]) == 18
+    assert f9[0]["windows"]["diameters"][16:].tolist() == [1.5, 2.5]
+    assert back.frame_properties(4)[2]["windows"] == {"diameters": None, "centre_of_mass": None}
+    eager = engine.records_to_properties(recs, extra=extra)
+    deep_equal(back.frame_properties(9)[0], eager[3])
+    # a subset keeps its extra windows attached to the right unit
+    sub = back.select([11, 9])
+    assert sub.unit_frame.tolist() == [11, 9, 9] and sub.extra["unit"].tolist() == [1, 1]
+    deep_equal(sub.frame_properties(9)[0], eager[3])
+    with pytest.raises(ValueError):
+        records.RecordStore(recs, [4, 9, 4, 9, 9, 11]).spans()
+
+
+def test_config5_sized_result_saves_and_reopens_within_a_second(tmp_path):
+    """BASELINE config 5: 5000 cages x 100 frames = 500 000 units.  The columnar file is 350 MB: reopened
+    (index included, nothing materialised) in milliseconds, a frame's dicts appear on first access, and writing it
+    costs what writing 350 MB costs on the file system -- under a second where the disk allows (checked against a
+    plain write of as many bytes to the same directory, and in absolute terms on /dev/shm).  The dict fan-out of
+    the same result is 0.75 s and its JSON several seconds."""
+    import os
+    import pathlib
+    import shutil
+
+    n_frames, n_cages = 100, 5000
+    recs = np.zeros(n_frames * n_cages, dtype=_lib.UNIT_OUT_DTYPE)
+    recs["n_atoms"] = 168
+    recs["n_windows"] = 4
+    recs["pore_d"] = np.arange(len(recs)) * 1e-6
+    recs["win_d"] = np.random.default_rng(1).random((len(recs), _lib.W_MAX))
+    uf = np.repeat(np.arange(n_frames), n_cages)
+    um = np.tile(np.arange(n_cages), n_frames)
+    store = records.RecordStore(recs, uf, um)
+
+    def round_trip(folder):
+        t0 = time.perf_counter()
+        path = store.save(folder / "config5")
+        t1 = time.perf_counter()
+        back = records.RecordStore.load(path)
+        view = records.LazyAnalysis()
+        view.attach(back)
+        t2 = time.perf_counter()
+        assert path.stat().st_size > 340e6 and len(view) == n_frames
+        frame = view[42]
+        t3 = time.perf_counter()
+        assert len(frame) == n_cages and frame[7]["pore_diameter"]["diameter"] == (42 * n_cages + 7) * 1e-6
+        assert back.records[123456].tobytes() == recs[123456].tobytes()
+        return t1 - t0, t2 - t1, t3 - t2
+
+    t0 = time.perf_counter()
+    with open(tmp_path / "plain.bin", "wb") as fh:
+        fh.write(recs.view(np.uint8).data)
+    plain = time.perf_counter() - t0
+    save, reopen, first = round_trip(tmp_path)
+    print(f"{tmp_path}: plain write {plain:.3f} s | save {save:.3f} s, reopen {reopen:.3f} s, one frame of {n_cages} dicts {first:.3f} s")
+    assert reopen < 0.2 and save < 1.5 * plain + 0.5
+    shm = pathlib.Path("/dev/shm")
+    if shm.is_dir() and os.access(shm, os.W_OK):
+        folder = shm / f"pw_records_test_{os.getpid()}"
+        folder.mkdir()
+        try:
+            save, reopen, first = round_trip(folder)
+            print(f"{folder}: save {save:.3f} s, reopen {reopen:.3f} s")
+            assert save < 1.0 and reopen < 0.2
+        finally:
+            shutil.rmtree(folder, ignore_errors=True)
