@@ -359,6 +359,25 @@ def main():
     tdev = torch.device("cuda", device_index)
     rec_bytes = _lib.UNIT_OUT_DTYPE.itemsize
 
+    # where every rank runs, as the process group and the runtime report it -- so that "did the N ranks get N
+    # different GPUs" can be answered from the line alone
+    def placement():
+        try:
+            props = torch.cuda.get_device_properties(device_index)
+            bus = getattr(props, "pci_bus_id", None)
+            pci = None if bus is None else "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), bus, getattr(props, "pci_device_id", 0))
+            name = props.name
+        except Exception as exc:  # noqa: BLE001
+            pci, name = f"unknown ({exc!r})", None
+        return {"rank": rank, "local_rank": local_rank, "device": device_index, "pci_bus_id": pci, "gpu": name,
+                "visible_devices": torch.cuda.device_count(), "host": socket.gethostname(), "pid": os.getpid()}
+
+    ranks_info = [placement()]
+    if dist is not None:
+        every = [None] * world
+        dist.all_gather_object(every, ranks_info[0])
+        ranks_info = every
+
     def barrier(res):
         res.sync()                     # the engine's own HIP streams
         torch.cuda.synchronize()
@@ -534,7 +553,11 @@ def main():
                        "ms_per_step_by_rank": {"min": 1e3 * min(weak_per_rank) / args.steps,
                                                "max": 1e3 * max(weak_per_rank) / args.steps},
                        "gather_in_timed_region": dist is not None, "gather_ok": gather_ok,
-                       "backend": backend if dist is not None else None},
+                       "backend": backend if dist is not None else None,
+                       "world_size_reported_by_backend": world if dist is not None else None,
+                       "world_size_env": world_env,
+                       "ranks": ranks_info,
+                       "distinct_gpus": len({(r["host"], r["pci_bus_id"]) for r in ranks_info})},
             "roofline": {"bound": "fp64_valu", "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS,
                          "algorithmic_flop_per_launch": ALGO_FLOP_PER_UNIT * args.frames,

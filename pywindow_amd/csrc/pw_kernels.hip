@@ -40,6 +40,7 @@ extern "C" int pw_internal_sampling_launch(void* stream, int grid, size_t lds_by
                                            const double* xyz, const double* vdw, const double* mass, int nmax, int nrot, int nlb,
                                            const PwWsArgs* wsa, pw_unit_out* out, UnitQueue* queue, int* slots,
                                            const pw_params* prm, const unsigned* rsq_tab, int vstride, const FitArgs* fa);
+extern "C" size_t pw_internal_sampling_static_lds(void);
 // pw_kernels_big.hip: the same source with the team's shared block in global memory (molecules beyond LDS)
 extern "C" size_t pw_internal_big_block_bytes(int nmax, int p_cap);
 extern "C" int pw_internal_big_launch(void* stream, int grid, long n_units, const long* atom_offset, const double* xyz,
@@ -77,6 +78,7 @@ constexpr unsigned MASK_ANY = 0xffffffffu & ~PW_STAGE_WIN_BULK;      // (only th
 constexpr unsigned MASK_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE;
 constexpr unsigned MASK_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
+constexpr unsigned MASK_SAMPLING = PW_STAGE_WIN_BULK | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 
 // Neighbour tables of the sampling sphere, one block per vector count P (pw_unit.hpp: nb_build_point): the
 // P unit vectors go to LDS, every thread tabulates the rows of its points.
@@ -137,7 +139,7 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
     if (threadIdx.x == 0) bind_workspace(ws, wsa, blockIdx.x, rsq_tab, team_slab_bytes(wsa.p_cap), team_adj_words(wsa.p_cap));
     __syncthreads();
     for (;;) {
-        if (role == PW_ROLE_CONSUMER) {
+        if (role == PW_ROLE_CONSUMER || role == PW_ROLE_SAMPLER) {
             if (threadIdx.x == 0) {
                 long pos = (long)atomicAdd(&queue->head, 1ull);
                 long u = -1;
@@ -179,7 +181,35 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
         // vstride 0: one molecule type, vdw / mass hold a single template (per-trajectory constants)
         const long v0 = a0 * vstride;
         if (threadIdx.x == 0) ws->unit = u;     // (read by the debug capture only; ordered by load_unit's barrier)
-        analyse_unit<T, MASK>(sh, ws, n, xyz + 3 * a0, vdw + v0, mass + v0, stages & MASK, out + u, prm);
+        int ncl = -1;
+        analyse_unit<T, MASK>(sh, ws, n, xyz + 3 * a0, vdw + v0, mass + v0, stages & MASK, out + u, prm,
+                              role == PW_ROLE_SAMPLER ? (FitTicket*)fa.tickets + u : (FitTicket*)nullptr, &ncl);
+        if (role == PW_ROLE_SAMPLER) {
+            // (the sampling half of the window search inside this translation unit -- PW_SPLIT=2: the same hand-over
+            // as pw_kernels_sampling.hip, at this kernel's register budget)
+            ncl = __builtin_amdgcn_readfirstlane(ncl);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                if (ncl > PW_W_MAX) {
+                    const int at = atomicAdd(&fa.q->n_deferred, 1);
+                    fa.deferred[at] = (int)u;
+                } else if (ncl >= 1) {
+                    const long pos = (long)atomicAdd(&fa.q->tail, (unsigned long long)ncl);
+                    for (int i = 0; i < ncl; ++i)
+                        __hip_atomic_store(&fa.slots2[pos + i], (int)u * 16 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                const int done = atomicAdd(&fa.q->units_done, 1) + 1;
+                if (done == (int)n_units) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    const unsigned long long t = __hip_atomic_load(&fa.q->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&fa.q->final, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();       // (keeps this thread-0 region and the one at the top of the loop apart)
+        }
         if (role == PW_ROLE_PRODUCER) {
             // analyse_unit ended with a team barrier; thread 0 wrote the record
             if (threadIdx.x == 0) {
@@ -259,7 +289,7 @@ pw_worker_kernel(long n_units, const long* __restrict__ atom_offset, const doubl
             if (threadIdx.x == 0) ws->unit = u;
             T::wave_sync();
             FitTicket* ticket = (FitTicket*)fa.tickets + u;
-            const int evals = fit_item<T>(fs, ws, n, xyz + 3 * a0, vdw + a0 * vstride, out + u, ticket, cluster, prm);
+            const int evals = (fa.debug & 2) ? 0 : fit_item<T>(fs, ws, n, xyz + 3 * a0, vdw + a0 * vstride, out + u, ticket, cluster, prm);
             if (threadIdx.x == 0) {
                 atomicAdd(&out[u].n_eval, evals);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -296,22 +326,33 @@ pw_worker_kernel(long n_units, const long* __restrict__ atom_offset, const doubl
                 long pos = (long)atomicAdd(&queue->tail, 1ull);
                 __hip_atomic_store(&slots[pos], (int)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            // (a wave-level barrier between this lane-0 region and the one at the top of the loop: without a
+            // convergent operation between them the compiler may thread lane 0 from one straight into the other)
+            T::wave_sync();
             continue;
         }
-        // 3. nothing to do right now: only the pool stays, until there is a fit or there will never be another
-        if ((int)blockIdx.x >= fa.n_pool) break;
+        // 3. nothing to do right now.  Up to n_pool idle workers wait (at low priority) until there is a fit or
+        // there will never be another; beyond that an idle worker leaves -- its SIMD slot and LDS go to the next
+        // analysis.  (A waiter that leaves its place first gives it up, so the count never leaks.)
         int leave = 0;
         if (threadIdx.x == 0) {
-            long long t0 = wall_clock64();
-            for (;;) {
-                const unsigned long long h = __hip_atomic_load(&fa.q->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long t = __hip_atomic_load(&fa.q->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (h < t) break;
-                const unsigned long long fin = __hip_atomic_load(&fa.q->final, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (h >= fin) { leave = 1; break; }
-                __builtin_amdgcn_s_sleep(32);
-                if (wall_clock64() - t0 > 500000000ll) { atomicExch(&fa.q->error, 1); leave = 1; break; }
+            if (atomicAdd(&fa.q->waiting, 1) >= fa.n_pool) {
+                leave = 1;
+            } else {
+                __builtin_amdgcn_s_setprio(0);
+                long long t0 = wall_clock64();
+                for (;;) {
+                    const unsigned long long h = __hip_atomic_load(&fa.q->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long t = __hip_atomic_load(&fa.q->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (h < t) break;
+                    const unsigned long long fin = __hip_atomic_load(&fa.q->final, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (h >= fin) { leave = 1; break; }
+                    __builtin_amdgcn_s_sleep(64);
+                    if (wall_clock64() - t0 > 500000000ll) { atomicExch(&fa.q->error, 1); leave = 1; break; }
+                }
+                __builtin_amdgcn_s_setprio(PW_A_PRIO);
             }
+            atomicSub(&fa.q->waiting, 1);
         }
         leave = __builtin_amdgcn_readfirstlane(leave);
         if (leave) break;
@@ -462,7 +503,7 @@ __global__ void pw_reset_kernel(unsigned long long* __restrict__ out8, long n8, 
         *xw_count = 0u;
         if (fitq) {
             fitq->tail = 0; fitq->head = 0; fitq->final = ~0ull;
-            fitq->units_done = 0; fitq->n_deferred = 0;     // (error is sticky until the host has seen it)
+            fitq->units_done = 0; fitq->n_deferred = 0; fitq->waiting = 0;     // (error is sticky until the host has seen it)
         }
     }
 }
@@ -518,7 +559,9 @@ struct pw_context {
     FitArgs cur_fit;         // the split window search's hand-offs of the current launch (zeros otherwise)
     // the split window search (sampling launch + fit workers): per set a queue, 16 item slots, a ticket and a
     // deferred-list entry per unit (sized like `slots`)
-    int split;               // PW_SPLIT (default 1): 0 = the window search as ONE launch of 4-wave teams (round 3's shape)
+    int split;               // PW_SPLIT: 0 (default) the window search as ONE launch of 4-wave teams; 1 sampling launch
+                             // (pw_kernels_sampling.hip, three waves per SIMD) + fits by the one-wave workers; 2 the same with
+                             // the sampling launch as an instance of this file's kernel.  Measured slower: DESIGN.md section 3
     int fit_pool;            // PW_FIT_POOL: workers that stay until the fit queue is closed
     FitQueue* fitq;
     int* slots2;
@@ -765,6 +808,8 @@ static int launch_plan(pw_context* c, pw_resident* r, unsigned stages, const Lau
         return launch_nw<4, MASK_AVERAGE>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
     if (stages == MASK_WINDOWS && p.nw == 4)
         return launch_nw<4, MASK_WINDOWS>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
+    if (stages == MASK_SAMPLING && p.nw == 4)
+        return launch_nw<4, MASK_SAMPLING>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
     if (p.nw == 8) return launch_nw<8, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
     if (p.nw == 4) return launch_nw<4, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
     if (p.nw == 2) return launch_nw<2, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
@@ -935,7 +980,7 @@ int pw_context_create(int device, pw_context** out) {
     c->fused = (fz && fz[0] == '1') ? 1 : 0;
     {
         const char* sp_ = getenv("PW_SPLIT");
-        c->split = (sp_ && sp_[0] == '0') ? 0 : 1;
+        c->split = (sp_ && sp_[0] == '1') ? 1 : ((sp_ && sp_[0] == '2') ? 2 : 0);
         const char* fp_ = getenv("PW_FIT_POOL");
         c->fit_pool = fp_ && atoi(fp_) > 0 ? atoi(fp_) : 0;      // 0: by the size of the chip (pw_resident_launch)
     }
@@ -1298,9 +1343,10 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         }
         pc.nrot = s_rot; pc.nlb = s_lb; pc.lean = 2;
         pc.lds = UnitShared::bytes(r->nmax, s_rot, s_lb, 1, 2, wanted_p_cap(c) > c->p_cap ? wanted_p_cap(c) : c->p_cap) + 64;
-        if (pc.lds > 160 * 1024 - 256) split = false, pc = pcf;
+        const size_t s_static = pw_internal_sampling_static_lds();
+        if (pc.lds + s_static > 160 * 1024 - 256) split = false, pc = pcf;
         else {
-            int per_cu = (int)(c->lds_per_cu / pc.lds);
+            int per_cu = (int)(c->lds_per_cu / (pc.lds + s_static));
             if (per_cu > 4) per_cu = 4;
             long g = (long)c->n_cu * (per_cu < 1 ? 1 : per_cu);
             pc.grid = (int)(g < r->n_units ? g : r->n_units);
@@ -1309,13 +1355,16 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     int pool = 0;
     if (split) {
         // workers: one per unit plus the pool, at most what the chip holds at a time
-        pool = c->fit_pool > 0 ? c->fit_pool : (c->n_cu + 1) / 2;
+        pool = c->fit_pool > 0 ? c->fit_pool : c->n_cu;
         int per_cu = (int)(c->lds_per_cu / pa.lds);
         if (per_cu > 16) per_cu = 16;
         long cap = (long)c->n_cu * (per_cu < 1 ? 1 : per_cu);
-        long want = r->n_units + pool;
+        // (a small batch gets spare workers -- a lone unit's four windows are fitted side by side, not one after the
+        // other; a large one is its own pool: the workers whose chains end first wait for the first fits)
+        long want = r->n_units;
+        const long spare = 4 * r->n_units < pool ? 4 * r->n_units : pool;
+        if (want < spare) want = spare;
         pa.grid = (int)(want < cap ? want : cap);
-        if (pool > pa.grid) pool = pa.grid;
     }
     // A batch of up to a few units per SIMD is latency-bound by its optimiser chains: one window team
     // per CU keeps LDS free for the chains of the next launch (measured on 1000 units: 2.56 -> 2.45 ms);
@@ -1424,6 +1473,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         c->cur_fit.tickets = (void*)(c->tickets + (size_t)b * c->slots_cap);
         c->cur_fit.deferred = c->deferred + (size_t)b * c->slots_cap;
         c->cur_fit.n_pool = pool;
+        if (const char* e = getenv("PW_SPLIT_DEBUG")) c->cur_fit.debug = atoi(e);
     }
     if (c->need_fork) {
         // uploads, single-launch analyses and timing marks on the main stream come first
@@ -1508,7 +1558,9 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     HIP_TRY(hipEventRecord(c->ev_prod[b], c->prod));
     hipStream_t cs = c->cons[b];
     HIP_TRY(hipStreamWaitEvent(cs, c->ev_reset[b], 0));
-    hipLaunchKernelGGL(pw_gate_kernel, dim3(1), dim3(64), 0, cs, c->cur_queue, pa.grid, c->counter + 4 * PW_SETS + 2);
+    // (the residency gate counts the workers that carry a chain: the spare ones of the split pipeline only ever fit)
+    hipLaunchKernelGGL(pw_gate_kernel, dim3(1), dim3(64), 0, cs, c->cur_queue,
+                       (long)pa.grid < r->n_units ? pa.grid : (int)r->n_units, c->counter + 4 * PW_SETS + 2);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_gate[b], cs));
     c->head_valid[b] = 0;
@@ -1526,7 +1578,11 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][0], cs));
     if (split) {
-        {
+        if (c->split == 2) {
+            // the sampling launch as an instance of this translation unit's kernel (its register budget: two waves per SIMD)
+            rc = launch_plan(c, r, MASK_SAMPLING, pc, cs, ws_c, b * c->max_c, PW_SETS + b, PW_ROLE_SAMPLER, false);
+            if (rc != PW_OK) return rc;
+        } else {
             PwWsArgs wsa;
             wsa.ws = c->ws + ws_c;
             wsa.slab = c->slab + (size_t)ws_c * team_slab_bytes(c->p_cap);

@@ -43,7 +43,7 @@ struct FitQueue {
     int units_done;              // units the sampling launch has finished
     int n_deferred;
     int error;
-    int pad;
+    int waiting;                 // workers parked until there is a fit or the queue closes (at most FitArgs::n_pool)
 };
 enum : int { PW_ROLE_PLAIN = 0, PW_ROLE_PRODUCER = 1, PW_ROLE_CONSUMER = 2, PW_ROLE_SAMPLER = 3, PW_ROLE_LIST = 4 };
 
@@ -53,7 +53,8 @@ struct FitArgs {
     int* slots2;            // 16 per unit
     void* tickets;          // FitTicket (pw_unit.hpp), one per unit
     int* deferred;          // one per unit
-    int n_pool;             // workers that stay until the queue is closed (pw_worker_kernel)
+    int n_pool;             // idle workers that may wait for fits at a time (pw_worker_kernel); the others leave
+    int debug;              // PW_SPLIT_DEBUG (diagnosis): 1 every unit goes to the follow-up launch, 2 fits are not computed
 };
 
 

@@ -61,6 +61,24 @@
 #define PW_TILE_GRID 7
 #endif
 
+// PW_TEAM_STATE_IN_LDS (a translation unit's choice, before this header): the kernel keeps its UnitShared -- the
+// table of where everything of the team lives -- and its copy of the parameters in LDS instead of on its stack,
+// and the stage functions may assume so: their look-ups become ds_read instead of scratch loads, and the kernel
+// has no stack object whose address escapes into a call.
+#if defined(PW_TEAM_STATE_IN_LDS) && defined(__HIP_DEVICE_COMPILE__)
+#define PW_ASSUME_TEAM_STATE(sh, prm) do { PW_ASSUME_LDS(&(sh)); PW_ASSUME_LDS(&(prm)); } while (0)
+#else
+#define PW_ASSUME_TEAM_STATE(sh, prm) do {} while (0)
+#endif
+
+// diagnostic builds (-DPW_DCHECKS, tests/tools/build_debug_variant.sh): an impossible value stops the wave where
+// rocgdb shows the line
+#if defined(PW_DCHECKS) && defined(__HIP_DEVICE_COMPILE__)
+#define PW_DCHECK(cond, code) do { if (!(cond)) asm volatile("s_mov_b32 m0, %0\n\ts_trap 2" :: "n"(code) : "memory"); } while (0)
+#else
+#define PW_DCHECK(cond, code) do {} while (0)
+#endif
+
 namespace pw {
 
 constexpr double GOLDEN_ANGLE = 2.399963229728653;   // np.pi * (3 - np.sqrt(5))
@@ -1127,6 +1145,8 @@ PW_HD inline __attribute__((always_inline)) bool team_ray_tests(const Frame& F, 
         const ConeBand b = bands[i];
         const bool two_sided = b.khi < 0;
         const int khi = two_sided ? -b.khi - 1 : b.khi;
+        PW_DCHECK(P >= 10 && P <= 4096, 102);
+        PW_DCHECK(b.klo >= 0 && khi < P, 103);
         const double rx = F.x[i] - c0, ry = F.y[i] - c1, rz = F.z[i] - c2;
         for (int kb = b.klo; kb <= khi; kb += T::WSIZE) {
             const int k = kb + T::lane();
@@ -2380,6 +2400,84 @@ PW_HD inline __attribute__((always_inline)) int team_dbscan(PW_LDS unsigned long
 }
 
 // ---- stage: windows ----------------------------------------------------------------------------
+// ---- k-NN of the sampling sphere: the search that needs no table --------------------------------------------
+// The ten smallest squared distances (ascending) of the four consecutive sampling vectors 4 grp .. 4 grp + 3 to
+// all P vectors: candidates within an index window either side (a spiral lattice has its near neighbours at the
+// same index offsets everywhere), four points sharing every candidate read, sorted insertion by a
+// compare-exchange chain; a window that cannot prove itself (tenth distance within (W - 1) z-levels) is redone
+// over the whole sphere.  Writes the DISTANCES (square roots) to rows[10 k + q].  Out of line: its forty-plus
+// forty live doubles are the register peak of the sampling stages, and with the neighbour tables
+// (nb_build_point) it runs for no point at all -- only when a table is missing or cannot be proven.
+// pts_: the sampling vectors, point k at [(c * 4 + (k & 3)) * Q4 + (k >> 2)], c = 0, 1, 2.
+template <class PTS>
+PW_NOINLINE PW_HD inline void knn_window_group(PTS pts_, int Q4, int P, int grp, int W, double radius, double zstep,
+                                               double* rows) {
+    constexpr int NK = 4;
+    const int k0 = grp * NK;
+    double px[NK], py[NK], pz[NK], t[NK][10];
+#pragma unroll
+    for (int p = 0; p < NK; ++p) {
+        const int k = k0 + p < P ? k0 + p : P - 1;
+        const int at = (k & 3) * Q4 + (k >> 2);
+        px[p] = pts_[at]; py[p] = pts_[4 * Q4 + at]; pz[p] = pts_[8 * Q4 + at];
+    }
+    const int klast = k0 + NK - 1 < P ? k0 + NK - 1 : P - 1;
+    int lo = k0 - W < 0 ? 0 : k0 - W, hi = klast + W > P - 1 ? P - 1 : klast + W;
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int p = 0; p < NK; ++p)
+#pragma unroll
+            for (int q = 0; q < 10; ++q) t[p][q] = PW_INF;
+        // pass 0: every thread walks the same offsets tt relative to its first point (k0 = 4 * grp), so the lanes
+        // of a wave read consecutive doubles of one residue class; pass 1 (the whole sphere, only if the window
+        // did not prove itself) covers every index
+        const int t_lo = pass == 0 ? -W : -k0, t_hi = pass == 0 ? NK - 1 + W : P - 1 - k0;
+        // Candidates further than twice the expected tenth-neighbour distance are never entered (pass 0): for
+        // most offsets no lane of the wave inserts anything and the whole insertion chain is skipped.  A list
+        // that is not full afterwards (t[9] still infinite) fails the proof below and the point is redone
+        // without a threshold.
+        const double tau = pass == 0 ? 80.0 * radius * radius / (double)P : PW_INF;
+        double thr[NK];
+#pragma unroll
+        for (int p = 0; p < NK; ++p) thr[p] = tau;
+PW_PRAGMA(unroll PW_UNROLL_KNN)
+        for (int tt = t_lo; tt <= t_hi; ++tt) {
+            const int j = k0 + tt;
+            if (j < lo || j > hi) continue;
+            const int at = ((tt & 3) * Q4) + grp + (tt >> 2);      // j = 4 * grp + tt
+            const double qx = pts_[at], qy = pts_[4 * Q4 + at], qz = pts_[8 * Q4 + at];
+#pragma unroll
+            for (int p = 0; p < NK; ++p) {
+                double ax = px[p] - qx, ay = py[p] - qy, az = pz[p] - qz;
+                double d = ax * ax;          // (0.0 + ax * ax of the reference is ax * ax exactly)
+                d = d + ay * ay; d = d + az * az;
+                if (d < thr[p]) {
+                    double v_ = d;
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) {
+                        double lo_ = __builtin_fmin(t[p][q], v_);
+                        v_ = __builtin_fmax(t[p][q], v_);
+                        t[p][q] = lo_;
+                    }
+                    thr[p] = __builtin_fmin(tau, t[p][9]);
+                }
+            }
+        }
+        bool full = (lo == 0 && hi == P - 1);
+        bool proven = true;
+#pragma unroll
+        for (int p = 0; p < NK; ++p) proven = proven && (pw_sqrt(t[p][9]) < (double)(W - 1) * zstep);
+        if (full || proven) break;
+        lo = 0; hi = P - 1;
+    }
+#pragma unroll
+    for (int p = 0; p < NK; ++p)
+        if (k0 + p < P) {
+#pragma unroll
+            for (int q = 0; q < 10; ++q) rows[(size_t)(k0 + p) * 10 + q] = pw_sqrt(t[p][q]);
+        }
+}
+
 // ---- find_windows in two parts (utilities.py:1364-1553) -------------------------------------------------
 // windows_bulk: everything up to and including the clustering -- shift, sampling sphere, DBSCAN radius, ray
 // pre-analysis, path scans, DBSCAN, the vector chosen for every cluster (:1374-1487, :1221) -- the part that
@@ -2394,6 +2492,8 @@ PW_HD inline __attribute__((always_inline)) int team_dbscan(PW_LDS unsigned long
 template <class T>
 PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
                                                                   const pw_params& prm, WinArrays& wa, bool defer_large) {
+    PW_ASSUME_TEAM_STATE(sh, prm);
+    PW_DCHECK(__builtin_amdgcn_read_exec() == ~0ull, 111);
     auto& v = *sh.v;
     // shift so that the optimised pore centre (pore_opt) or the centre of mass is the origin
     // (utilities.py:1380-1393)
@@ -2413,6 +2513,7 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
     if (T::wave() == 0) PW_T1(ws, 14, t_pre);
     PW_T0(t_md);
     team_max_dim<T, true>(sh, sh.S, n, 2 * n + 2 <= ws->p_cap ? ws->vals : nullptr);
+    PW_DCHECK(__builtin_amdgcn_read_exec() == ~0ull, 112);
     double radius = v.maxd / 2.0;
     T::sync();
     if (T::wave() == 0) PW_T1(ws, 15, t_md);
@@ -2433,6 +2534,7 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
         T::sync();
         return -1;
     }
+    PW_DCHECK(radius > 1.0 && radius < 1.0e3, 101);
     Sphere sp;
     sp.init(radius, P);
     // per-unit arrays of the sampling stages: LDS scratch first, global workspace otherwise
@@ -2456,23 +2558,17 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
     // ---- eps: mean of all 10-NN distances (self included), utilities.py:1427-1434 ----
     PW_T0(t_eps);
     {
-        // candidates within an index window; exactness is verified per point and a
-        // full scan is done when the window cannot be proven sufficient
-        double zstep = pw_abs(sp.step) * radius;
-        // the 10th neighbour of a point on the equator is about R*sqrt(40/P) away, i.e. 0.112*P z-levels:
-        // a window of 0.118*P + 6 indices either side proves itself for every point (checked below)
-        int W = (int)(0.118 * (double)P) + 6;
         PW_T0(t_knn);
-        // A thread takes FOUR consecutive points: their index windows overlap almost completely, so
-        // every candidate is read once and measured against all four (register blocking); the
-        // ten smallest squared distances of each point live in registers (sorted insertion by a
-        // compare-exchange chain).
+        // A thread takes FOUR consecutive points (a "group").  With this P's neighbour table (the sixteen nearest
+        // points of every point on the unit sphere, NbTables) a point is sixteen exact distances that must come
+        // out ascending, the tenth provably below everything outside the list; a point the table cannot prove --
+        // or a context without tables -- sends its group through the windowed search (knn_window_group), which
+        // leaves the group's distances in the team's global rows.
         constexpr int NK = 4;
         const int ngroups = (P + NK - 1) / NK;
-        // scratch of the mean: leaf tables, accumulators, and -- when every thread has at most one
-        // group of points, i.e. its distances fit its registers -- a tile for the streamed sum, so that
-        // the P x 10 distances never leave the CU (they were 64 KB per unit written to and read back
-        // from the global workspace)
+        // scratch of the mean: leaf tables, accumulators, and -- when every thread has at most one group of
+        // points -- a tile for the streamed sum, so that the P x 10 distances never leave the CU (they were
+        // 64 KB per unit written to and read back from the global workspace)
         int* s_tab = (int*)arena.take(324 * 4);
         double* s_leaf = (double*)arena.take(256 * 8);
         double* s_acc = nullptr;
@@ -2500,11 +2596,6 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
             s_leaf = (double*)arena.take(256 * 8);
             if (!s_tab || !s_acc || !s_leaf) { s_tab = ws->leaf_tab; s_acc = ws->acc8; s_leaf = ws->leaf; }
         }
-        double dist[NK][10];
-#pragma unroll
-        for (int p = 0; p < NK; ++p)
-#pragma unroll
-            for (int q = 0; q < 10; ++q) dist[p][q] = 0.0;
         // this P's neighbour table, if the context has one
         const unsigned short* nb_idx = nullptr;
         const double* nb_bound = nullptr;
@@ -2512,134 +2603,84 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
             nb_idx = ws->nb_idx + (size_t)ws->nb_off[P] * PW_NB_K;
             nb_bound = ws->nb_bound + ws->nb_off[P];
         }
-        auto knn_groups = [&](auto pts_) __attribute__((always_inline)) {
-            for (int grp = T::tid(); grp < ngroups; grp += T::SIZE) {
-                const int k0 = grp * NK;
-                double px[NK], py[NK], pz[NK], t[NK][10];
+        // (the windowed search: the 10th neighbour of a point on the equator is about R*sqrt(40/P) away, i.e.
+        // 0.112*P z-levels: a window of 0.118*P + 6 indices either side proves itself for every point)
+        const int W = (int)(0.118 * (double)P) + 6;
+        const double zstep = pw_abs(sp.step) * radius;
+        // the ten distances of point k (ascending) from the table; false: the table cannot vouch for them
+        auto point_tabled = [&](auto pts_, int k, double* d10) __attribute__((always_inline)) {
+            if (!nb_idx) return false;
+            const double slack = (radius * radius) * (1.0 - 1e-9);
+            const double px = pts_[PT(k, 0)], py = pts_[PT(k, 1)], pz = pts_[PT(k, 2)];
+            const unsigned* row = (const unsigned*)(nb_idx + (size_t)k * PW_NB_K);   // (32-byte rows)
+            unsigned w[8];
 #pragma unroll
-                for (int p = 0; p < NK; ++p) {
-                    int k = k0 + p < P ? k0 + p : P - 1;
-                    px[p] = pts_[PT(k, 0)]; py[p] = pts_[PT(k, 1)]; pz[p] = pts_[PT(k, 2)];
-                }
-                const int klast = k0 + NK - 1 < P ? k0 + NK - 1 : P - 1;
-                int lo = k0 - W < 0 ? 0 : k0 - W, hi = klast + W > P - 1 ? P - 1 : klast + W;
-                bool tabled = false;
-                if (nb_idx) {
-                    // the sixteen tabulated candidates of each point: exact distances, which must come out
-                    // ascending with the tenth provably below everything outside the list (see NbTables)
-                    tabled = true;
-                    const double slack = (radius * radius) * (1.0 - 1e-9);
+            for (int c = 0; c < 8; ++c) w[c] = row[c];
+            double prev = -1.0, cd[PW_NB_K];
+            bool sorted = true;
 #pragma unroll
-                    for (int p = 0; p < NK; ++p) {
-                        const int k = k0 + p < P ? k0 + p : P - 1;
-                        const unsigned* row = (const unsigned*)(nb_idx + (size_t)k * PW_NB_K);   // (32-byte rows)
-                        unsigned w[8];
+            for (int c = 0; c < PW_NB_K; ++c) {
+                const int j = (int)((w[c >> 1] >> (16 * (c & 1))) & 0xffffu);
+                const double qx = pts_[PT(j, 0)], qy = pts_[PT(j, 1)], qz = pts_[PT(j, 2)];
+                double ax = px - qx, ay = py - qy, az = pz - qz;
+                double d = ax * ax;
+                d = d + ay * ay; d = d + az * az;
+                sorted = sorted && d >= prev;
+                prev = d;
+                cd[c] = d;
+                if (c < 10) d10[c] = d;
+            }
+            if (!sorted) {
+                // mirror-image neighbours near the equator are ties on the unit sphere that the scaled
+                // arithmetic breaks either way: sort what the list holds (rare)
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) w[c] = row[c];
-                        double prev = -1.0, cd[PW_NB_K];
-                        bool sorted = true;
+                for (int q = 0; q < 10; ++q) d10[q] = PW_INF;
 #pragma unroll
-                        for (int c = 0; c < PW_NB_K; ++c) {
-                            const int j = (int)((w[c >> 1] >> (16 * (c & 1))) & 0xffffu);
-                            const double qx = pts_[PT(j, 0)], qy = pts_[PT(j, 1)], qz = pts_[PT(j, 2)];
-                            double ax = px[p] - qx, ay = py[p] - qy, az = pz[p] - qz;
-                            double d = ax * ax;
-                            d = d + ay * ay; d = d + az * az;
-                            sorted = sorted && d >= prev;
-                            prev = d;
-                            cd[c] = d;
-                            if (c < 10) t[p][c] = d;
-                        }
-                        if (!sorted) {
-                            // mirror-image neighbours near the equator are ties on the unit sphere that the
-                            // scaled arithmetic breaks either way: sort what the list holds (rare)
+                for (int c = 0; c < PW_NB_K; ++c) {
+                    double v_ = cd[c];
 #pragma unroll
-                            for (int q = 0; q < 10; ++q) t[p][q] = PW_INF;
-#pragma unroll
-                            for (int c = 0; c < PW_NB_K; ++c) {
-                                double v_ = cd[c];
-#pragma unroll
-                                for (int q = 0; q < 10; ++q) {
-                                    double lo_ = __builtin_fmin(t[p][q], v_);
-                                    v_ = __builtin_fmax(t[p][q], v_);
-                                    t[p][q] = lo_;
-                                }
-                            }
-                        }
-                        tabled = tabled && t[p][9] < nb_bound[k] * slack;
-                    }
-#if defined(PW_NB_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
-                    { static long hit = 0, miss = 0; (tabled ? hit : miss)++; if (((hit + miss) & 1023) == 0) fprintf(stderr, "nb tables: %ld groups from the table, %ld through the search\n", hit, miss);
-                      if (!tabled) for (int p = 0; p < NK; ++p) { int k = k0 + p < P ? k0 + p : P - 1; fprintf(stderr, "  miss P %d k %d t9 %.17g bound*R2 %.17g ratio %.3e\n", P, k, t[p][9], nb_bound[k] * radius * radius, t[p][9] / (nb_bound[k] * radius * radius) - 1.0); } }
-#endif
-                }
-                for (int pass = tabled ? 2 : 0; pass < 2; ++pass) {
-#pragma unroll
-                    for (int p = 0; p < NK; ++p)
-#pragma unroll
-                        for (int q = 0; q < 10; ++q) t[p][q] = PW_INF;
-                    // pass 0: every thread walks the same offsets t relative to its first point (k0 = 4 * grp),
-                    // so the lanes of a wave read consecutive doubles of one residue class; pass 1 (the whole
-                    // sphere, only if the window did not prove itself) uses plain indices
-                    const int t_lo = pass == 0 ? -W : -k0, t_hi = pass == 0 ? NK - 1 + W : P - 1 - k0;
-                    // Candidates further than twice the expected tenth-neighbour distance are never entered
-                    // (pass 0): the lanes walk the same offsets and a spiral lattice has its neighbours at the
-                    // same offsets everywhere, so for most offsets no lane of the wave inserts anything and the
-                    // whole insertion chain is skipped.  A list that is not full afterwards (t[9] still
-                    // infinite) fails the proof below and the point is redone without a threshold.
-                    const double tau = pass == 0 ? 80.0 * radius * radius / (double)P : PW_INF;
-                    double thr[NK];
-#pragma unroll
-                    for (int p = 0; p < NK; ++p) thr[p] = tau;
-PW_PRAGMA(unroll PW_UNROLL_KNN)
-                    for (int tt = t_lo; tt <= t_hi; ++tt) {
-                        const int j = k0 + tt;
-                        if (j < lo || j > hi) continue;
-                        const int at = ((tt & 3) * Q4) + grp + (tt >> 2);      // == PT(j, 0): j = 4 * grp + tt
-                        const double qx = pts_[at], qy = pts_[4 * Q4 + at], qz = pts_[8 * Q4 + at];
-#pragma unroll
-                        for (int p = 0; p < NK; ++p) {
-                            double ax = px[p] - qx, ay = py[p] - qy, az = pz[p] - qz;
-                            double d = ax * ax;          // (0.0 + ax * ax of the reference is ax * ax exactly)
-                            d = d + ay * ay; d = d + az * az;
-                            if (d < thr[p]) {
-                                double v_ = d;
-#pragma unroll
-                                for (int q = 0; q < 10; ++q) {
-                                    double lo_ = __builtin_fmin(t[p][q], v_);
-                                    v_ = __builtin_fmax(t[p][q], v_);
-                                    t[p][q] = lo_;
-                                }
-                                thr[p] = __builtin_fmin(tau, t[p][9]);
-                            }
-                        }
-                    }
-                    bool full = (lo == 0 && hi == P - 1);
-                    bool proven = true;
-#pragma unroll
-                    for (int p = 0; p < NK; ++p) proven = proven && (pw_sqrt(t[p][9]) < (double)(W - 1) * zstep);
-                    if (full || proven) break;
-                    lo = 0; hi = P - 1;
-                }
-                if (streamed) {
-                    // this thread's 40 distances stay in registers; they go to the tiles below
-#pragma unroll
-                    for (int p = 0; p < NK; ++p)
-#pragma unroll
-                        for (int q = 0; q < 10; ++q) dist[p][q] = pw_sqrt(t[p][q]);
-                } else {
-#pragma unroll
-                    for (int p = 0; p < NK; ++p) {
-                        if (k0 + p < P) {
-                            double* row = &ws->knn[(k0 + p) * 10];
-#pragma unroll
-                            for (int q = 0; q < 10; ++q) row[q] = pw_sqrt(t[p][q]);
-                        }
+                    for (int q = 0; q < 10; ++q) {
+                        double lo_ = __builtin_fmin(d10[q], v_);
+                        v_ = __builtin_fmax(d10[q], v_);
+                        d10[q] = lo_;
                     }
                 }
             }
+            const bool ok = d10[9] < nb_bound[k] * slack;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) d10[q] = pw_sqrt(d10[q]);
+            return ok;
         };
-        if (PW_IS_LDS(pts)) knn_groups(PW_AS_LDS(pts)); else knn_groups(pts);
+        // the ten distances of point k of group grp into d10; `searched` (per group): the windowed search has
+        // run for this group and its rows in ws->knn hold the distances
+        auto point_dists = [&](auto pts_, int grp, int k, bool& searched, double* d10) __attribute__((always_inline)) {
+            if (!searched && point_tabled(pts_, k, d10)) return;
+            if (!searched) {
+                knn_window_group(pts_, Q4, P, grp, W, radius, zstep, ws->knn);
+                searched = true;
+            }
+#pragma unroll
+            for (int q = 0; q < 10; ++q) d10[q] = ws->knn[(size_t)k * 10 + q];
+        };
+        if (!streamed) {
+            // the distances go to the team's global rows, the mean is taken from there
+            auto rows_of_groups = [&](auto pts_) __attribute__((always_inline)) {
+                for (int grp = T::tid(); grp < ngroups; grp += T::SIZE) {
+                    bool searched = false;
+                    for (int p = 0; p < NK; ++p) {
+                        const int k = grp * NK + p;
+                        if (k >= P) break;
+                        double d10[10];
+                        point_dists(pts_, grp, k, searched, d10);
+                        if (!searched) {
+#pragma unroll
+                            for (int q = 0; q < 10; ++q) ws->knn[(size_t)k * 10 + q] = d10[q];
+                        }
+                    }
+                }
+            };
+            if (PW_IS_LDS(pts)) rows_of_groups(PW_AS_LDS(pts)); else rows_of_groups(pts);
+        }
         T::sync();
         if (T::wave() == 0) PW_T1(ws, 24, t_knn);
         PW_T0(t_sum);
@@ -2649,8 +2690,13 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
             // through a tile of team-shared memory, a run of whole leaves of the recursion at a time (a
             // leaf -- at most 128 consecutive elements -- is all a leaf sum needs); the leaf sums are
             // kept and combined in recursion order at the end, chunk by chunk of 8192 elements.
+            // A thread's forty distances are formed when the tile that holds them is filled (a group that
+            // straddles two tiles is formed twice: sixty-four distance evaluations) -- nothing of the k-NN stage
+            // stays in registers across the barriers of the sum.
             const int n_el = P * 10;
-            const int e_first = T::tid() * NK * 10;         // flattened position of this thread's first distance
+            const int grp = T::tid();                       // (streamed: at most one group per thread)
+            const int e_first = grp * NK * 10;              // flattened position of this thread's first distance
+            bool searched = false;
             double total = 0.0;
             bool first = true;
             for (int s0 = 0; s0 < n_el; s0 += 8192) {
@@ -2666,16 +2712,20 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
                         np_descend(len, lo + tile_cap, &off, &l);
                         hi = off;
                     }
-                    auto fill = [&](auto tile_) __attribute__((always_inline)) {
+                    auto fill = [&](auto tile_, auto pts_) __attribute__((always_inline)) {
+                        if (grp >= ngroups) return;
+                        for (int p = 0; p < NK; ++p) {
+                            const int k = grp * NK + p;
+                            const int e0 = e_first + p * 10 - s0;             // position inside this chunk
+                            if (k >= P || e0 + 10 <= lo || e0 >= hi) continue;
+                            double d10[10];
+                            point_dists(pts_, grp, k, searched, d10);
 #pragma unroll
-                        for (int p = 0; p < NK; ++p)
-#pragma unroll
-                            for (int q = 0; q < 10; ++q) {
-                                const int e = e_first + p * 10 + q - s0;      // position inside this chunk
-                                if (e >= lo && e < hi && e_first + p * 10 + q < n_el) tile_[e - lo] = dist[p][q];
-                            }
+                            for (int q = 0; q < 10; ++q)
+                                if (e0 + q >= lo && e0 + q < hi) tile_[e0 + q - lo] = d10[q];
+                        }
                     };
-                    if (PW_IS_LDS(tile)) fill(PW_AS_LDS(tile)); else fill(tile);
+                    if (PW_IS_LDS(tile) && PW_IS_LDS(pts)) fill(PW_AS_LDS(tile), PW_AS_LDS(pts)); else fill(tile, pts);
                     T::sync();
                     np_leaf_phase<T>(tile, len, lo, hi, s_tab, s_acc, s_leaf, true);
                     lo = hi;
@@ -2775,6 +2825,7 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
         T::sync();
         int ncand = v.n_surv;
         int evals = 0;
+        PW_DCHECK(ncand >= 0 && ncand <= P, 104);
         if (T::wave() == 0) PW_T1(ws, 30, t_smp);     // rays + compaction
         PW_T0(t_path);
         // whole rounds: one path per thread.  The last, partial round would keep a handful of
@@ -2786,6 +2837,7 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
         if ((ncand - whole) * 4 >= T::SIZE) whole = ncand;
         for (int j = T::tid(); j < whole; j += T::SIZE) {
             int k = labels[j];
+            PW_DCHECK(k >= 0 && k < P, 105);
             double g2, chunk[3];
             int pos;
             bool ok = path_scan_thread(sh.S, n, pts[PT(k, 0)], pts[PT(k, 1)], pts[PT(k, 2)], prm.increment,

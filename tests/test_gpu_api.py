@@ -184,3 +184,97 @@ def test_pacing_gates_do_not_time_out(hip_ctx):
     res.download()
     res.free()
     assert hip_ctx.gate_timeouts == {"tail": 0, "head": 0, "residency": 0}
+
+
+@pytest.mark.gpu
+def test_threads_on_one_context_and_on_two_contexts():
+    """The ABI's threading contract (include/pywindow_amd.h, "Threads"; the reference's workers are
+    stateless processes, trajectory.py:564-582): calls from several threads on ONE context serialise inside the
+    library, two contexts share no state -- the second live context of a device runs its analyses as single
+    launches -- and every thread gets the records a lone thread gets, byte for byte.  Trajectories analysed from
+    two threads through the shared per-device context keep their own frames (the staging buffer and the "records
+    fetched last" list are held under Context.lock)."""
+    import threading
+
+    from pywindow_amd import _lib, synth
+    from pywindow_amd import element_data as E
+
+    elements, frames = synth.synthetic_units(96)
+    ids = E.element_ids(elements)
+    vdw, mass = E.VDW[ids], E.MASS[ids]
+    parts = [frames[:48], frames[48:]]
+    first = _lib.Context(0)
+    expect = [first.analyse(_lib.Batch.uniform(p, vdw, mass)) for p in parts]
+    assert first.pipelined
+
+    def run_threads(ctxs, rounds=3):
+        got, errors = [None, None], []
+
+        def work(k):
+            try:
+                ctx = ctxs[k]
+                for _ in range(rounds):
+                    # the one-call path ...
+                    a = ctx.analyse(_lib.Batch.uniform(parts[k], vdw, mass))
+                    # ... and the resident path, whose calls interleave with the other thread's
+                    res = ctx.upload(_lib.Batch.uniform(parts[k], vdw, mass))
+                    res.launch()
+                    b = res.download_settled()
+                    res.free()
+                    assert a.tobytes() == b.tobytes()
+                    got[k] = b
+            except Exception as exc:  # noqa: BLE001
+                errors.append(repr(exc))
+
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=600)
+        assert not errors, errors
+        return got
+
+    # two threads, ONE context
+    got = run_threads([first, first])
+    assert got[0].tobytes() == expect[0].tobytes() and got[1].tobytes() == expect[1].tobytes()
+    # two threads, a context each on the same device (the second one finds the hardware queues taken and runs
+    # every analysis as a single launch: correct, slower)
+    second = _lib.Context(0)
+    got = run_threads([first, second])
+    assert got[0].tobytes() == expect[0].tobytes() and got[1].tobytes() == expect[1].tobytes()
+    second.close()
+    first.close()
+
+
+@pytest.mark.gpu
+def test_two_threads_analyse_trajectories_on_the_shared_context(tmp_path):
+    """DLPOLY._run decodes into the context's ONE page-locked buffer and reads windows beyond
+    W_MAX from the context's "fetched last" list; two threads analysing different trajectories on the same
+    device must not see each other's frames."""
+    import threading
+
+    import pywindow_amd as pw
+    from pywindow_amd import synth
+
+    paths = [synth.write_synthetic_history(tmp_path / f"HISTORY_{k}", 200, seed_base=synth.SEED_BASE + 1000 * k) for k in range(2)]
+    alone = []
+    for p in paths:
+        t = pw.DLPOLY(p)
+        alone.append(t.analysis_records(forcefield="opls", swap_atoms={"he": "H"}))
+    assert alone[0].tobytes() != alone[1].tobytes()
+    got, errors = [None, None], []
+
+    def work(k):
+        try:
+            for _ in range(4):
+                got[k] = pw.DLPOLY(paths[k]).analysis_records(forcefield="opls", swap_atoms={"he": "H"})
+                assert got[k].tobytes() == alone[k].tobytes()
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    assert not errors, errors

@@ -242,6 +242,23 @@ def test_bench_two_ranks_executes_on_hardware_gloo():
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_dry_run_gloo():
+    """The driver's SCALE run is ``bench.py --gpus 8`` on an eight-GPU node; nothing here can measure it, so it is
+    rehearsed: EIGHT ranks (gloo, all on this box's one GPU), three steps.  The line must say what the real run
+    has to say -- the world size the process group reports, a gather that rank 0 verified, per-rank step times,
+    the strong-scaling block, and where every rank ran (device ordinal, PCI bus id), so that "did RCCL see eight
+    ranks on eight GPUs" is answerable from the JSON alone."""
+    line = _run_bench_child({"PW_BENCH_BACKEND": "gloo", "PW_BENCH_DEVICE": "0"}, gpus=8, frames=64)
+    _check_multi_rank_line(line, 8, 64)
+    cfg = line["config"]
+    assert cfg["world_size_reported_by_backend"] == 8 and cfg["world_size_env"] == 8
+    assert [r["rank"] for r in cfg["ranks"]] == list(range(8)) and [r["local_rank"] for r in cfg["ranks"]] == list(range(8))
+    assert all(r["device"] == 0 and r["pci_bus_id"] for r in cfg["ranks"])
+    assert cfg["distinct_gpus"] == 1            # (the rehearsal's one GPU; eight on the driver's node)
+    assert len({r["pid"] for r in cfg["ranks"]}) == 8
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_executes_on_hardware_rccl():
     """... and over RCCL, one rank per GPU, where the box has two."""
     from pywindow_amd import _lib

@@ -462,9 +462,10 @@ def test_other_cages_with_fresh_noise_against_live_oracle(hip_ctx):
 
 
 def test_every_launch_shape_gives_the_same_records(monkeypatch):
-    """One analysis, three launch shapes, the same bytes: the default pipeline (optimiser chains and window fits
-    by one-wave workers, the sampling half of the window search by 4-wave teams, hand-over through FitTickets),
-    PW_SPLIT=0 (the window search as one launch of 4-wave teams, round 3's shape) and PW_FUSED=1 (every stage in
+    """One analysis, four launch shapes, the same bytes: the default pipeline (optimiser chains | average diameter
+    | window search, three launches), PW_SPLIT=1 (the window search split: a sampling launch of 4-wave teams built
+    for three waves per SIMD, the fits by one-wave workers that also run the chains, hand-over through FitTickets),
+    PW_SPLIT=2 (the same with the sampling launch inside the main translation unit) and PW_FUSED=1 (every stage in
     one team).  On the real MD frames and on the static molecules (60 to 468 atoms, none to six windows)."""
     from pywindow_amd import _lib
 
@@ -473,7 +474,8 @@ def test_every_launch_shape_gives_the_same_records(monkeypatch):
         off, xyz, vdw, mass = group_batch(g)
         batch = _lib.Batch(off, xyz, vdw, mass)
         got = {}
-        for name, env in (("split", {}), ("one window launch", {"PW_SPLIT": "0"}), ("one launch", {"PW_FUSED": "1"})):
+        for name, env in (("pipeline", {}), ("split", {"PW_SPLIT": "1"}), ("split in one translation unit", {"PW_SPLIT": "2"}),
+                          ("one launch", {"PW_FUSED": "1"})):
             for k in ("PW_SPLIT", "PW_FUSED"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
@@ -488,6 +490,6 @@ def test_every_launch_shape_gives_the_same_records(monkeypatch):
             assert res.download().tobytes() == got[name].tobytes(), (tag, name)
             res.free()
             ctx.close()
-        check_records(got["split"], g, where=f"{tag} split pipeline")
-        assert got["split"].tobytes() == got["one window launch"].tobytes(), tag
-        assert got["split"].tobytes() == got["one launch"].tobytes(), tag
+        check_records(got["pipeline"], g, where=f"{tag} pipeline")
+        for name in ("split", "split in one translation unit", "one launch"):
+            assert got[name].tobytes() == got["pipeline"].tobytes(), (tag, name)
