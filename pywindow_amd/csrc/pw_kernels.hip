@@ -25,6 +25,8 @@
 #include "../../include/pywindow_amd.h"
 #include "pw_host.hpp"
 #include <vector>
+// the analysis kernels of this file keep their UnitShared / FitShared and parameters in (static) LDS, not on the stack
+#define PW_TEAM_STATE_IN_LDS 1
 #include "pw_unit.hpp"
 #include "pw_launch.hpp"
 
@@ -73,6 +75,10 @@ void set_err(const char* what, hipError_t e) {
 // events, team workspaces): that many analyses can be in flight, the optimiser chains of the later
 // ones filling the SIMDs that the long tails of the earlier ones leave idle.
 constexpr int PW_SETS = 4;      // (2 + 2 x PW_SETS streams, each needs a hardware queue of its own: GPU_MAX_HW_QUEUES = 12)
+
+// static LDS of an analysis kernel (team state: UnitShared, FitShared, parameters, the unit slot): what every
+// launch plan leaves free beside its dynamic request
+constexpr size_t PW_KERNEL_STATIC_LDS = 1024;
 
 constexpr unsigned MASK_ANY = 0xffffffffu & ~PW_STAGE_WIN_BULK;      // (only the sampling launch carries that half-stage)
 constexpr unsigned MASK_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE;
@@ -123,12 +129,16 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
                   const double* __restrict__ vdw, const double* __restrict__ mass, unsigned stages,
                   int nmax, int nrot, int nlb, int nframes, int lean, PwWsArgs wsa, unsigned long long* counter,
                   pw_unit_out* __restrict__ out, int role, UnitQueue* queue, int* __restrict__ slots,
-                  pw_params prm, const unsigned* __restrict__ rsq_tab, int vstride, FitArgs fa) {
+                  pw_params prm_in, const unsigned* __restrict__ rsq_tab, int vstride, FitArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ long s_unit;
+    // the team's table of pointers and its parameters live in LDS (PW_TEAM_STATE_IN_LDS, pw_unit.hpp): the stage
+    // functions are out of line and take them by reference -- on the stack they were 600 bytes of scratch per
+    // lane that every look-up went through
+    __shared__ UnitShared s_sh;
+    __shared__ pw_params s_prm;
+    static_assert(sizeof(UnitShared) + sizeof(pw_params) + 16 <= PW_KERNEL_STATIC_LDS, "static LDS of the analysis kernels");
     using T = DeviceTeam<NW>;
-    UnitShared sh;
-    sh.carve(lds, nmax, nrot, nlb, nframes, lean, wsa.p_cap);     // as planned by the host (plan_launch)
     // the optimiser chains are latency-bound and on the critical path: when one shares a SIMD
     // with a bulk wave of another launch it must win the issue arbitration
     if (role == PW_ROLE_PRODUCER) {
@@ -136,8 +146,14 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
         if (threadIdx.x == 0) atomicAdd(&queue->started, 1);
     }
     TeamWorkspace* ws = (TeamWorkspace*)wsa.ws + blockIdx.x;
-    if (threadIdx.x == 0) bind_workspace(ws, wsa, blockIdx.x, rsq_tab, team_slab_bytes(wsa.p_cap), team_adj_words(wsa.p_cap));
+    if (threadIdx.x == 0) {
+        s_sh.carve(lds, nmax, nrot, nlb, nframes, lean, wsa.p_cap);     // as planned by the host (plan_launch)
+        s_prm = prm_in;
+        bind_workspace(ws, wsa, blockIdx.x, rsq_tab, team_slab_bytes(wsa.p_cap), team_adj_words(wsa.p_cap));
+    }
     __syncthreads();
+    UnitShared& sh = s_sh;
+    const pw_params& prm = s_prm;
     for (;;) {
         if (role == PW_ROLE_CONSUMER || role == PW_ROLE_SAMPLER) {
             if (threadIdx.x == 0) {
@@ -243,18 +259,26 @@ __global__ void __launch_bounds__(64, PW_OCC_A)
 pw_worker_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
                  const double* __restrict__ vdw, const double* __restrict__ mass, int nmax, PwWsArgs wsa,
                  unsigned long long* counter, pw_unit_out* __restrict__ out, UnitQueue* queue, int* __restrict__ slots,
-                 pw_params prm, const unsigned* __restrict__ rsq_tab, int vstride, FitArgs fa) {
+                 pw_params prm_in, const unsigned* __restrict__ rsq_tab, int vstride, FitArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ UnitShared s_sh;
+    __shared__ FitShared s_fs;
+    __shared__ pw_params s_prm;
+    static_assert(sizeof(UnitShared) + sizeof(FitShared) + sizeof(pw_params) + 16 <= PW_KERNEL_STATIC_LDS, "static LDS of the workers");
     using T = DeviceTeam<1>;
-    UnitShared sh;
-    sh.carve(lds, nmax, 0, 1, 1, 1, wsa.p_cap);      // a chain: the input frame, no window variables, one optimiser block
-    FitShared fs;
-    fs.carve(lds, nmax);                             // a fit: the same bytes laid out for it
     __builtin_amdgcn_s_setprio(PW_A_PRIO);
     if (threadIdx.x == 0) atomicAdd(&queue->started, 1);
     TeamWorkspace* ws = (TeamWorkspace*)wsa.ws + blockIdx.x;
-    if (threadIdx.x == 0) bind_workspace(ws, wsa, blockIdx.x, rsq_tab, team_slab_bytes(wsa.p_cap), team_adj_words(wsa.p_cap));
-    T::wave_sync();
+    if (threadIdx.x == 0) {
+        s_sh.carve(lds, nmax, 0, 1, 1, 1, wsa.p_cap);      // a chain: the input frame, no window variables, one optimiser block
+        s_fs.carve(lds, nmax);                             // a fit: the same bytes laid out for it
+        s_prm = prm_in;
+        bind_workspace(ws, wsa, blockIdx.x, rsq_tab, team_slab_bytes(wsa.p_cap), team_adj_words(wsa.p_cap));
+    }
+    __syncthreads();
+    UnitShared& sh = s_sh;
+    FitShared& fs = s_fs;
+    const pw_params& prm = s_prm;
     bool chains_left = true;
     for (;;) {
         // 1. a fit that is ready?  (head never passes tail: items are taken with a compare-and-swap)
@@ -735,7 +759,7 @@ struct LaunchPlan {
 // rot/lb: whether window frames / optimiser states are needed (per wave).
 static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool rot, int lb_per_team,
                        LaunchPlan* p, int nframes = 2, int lean = 0) {
-    const size_t max_lds = 160 * 1024 - 256;
+    const size_t max_lds = 160 * 1024 - 256 - PW_KERNEL_STATIC_LDS;
     int nw = want_nw;
     for (;;) {
         int nslot = nw < 4 ? nw : 4;
@@ -752,7 +776,7 @@ static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool 
         }
         nw >>= 1;
     }
-    int per_cu = (int)(c->lds_per_cu / p->lds);
+    int per_cu = (int)(c->lds_per_cu / (p->lds + PW_KERNEL_STATIC_LDS));
     int wave_cap = p->nw == 8 ? 1 : 16 / p->nw;  // kernels are built for 2 waves per SIMD (8-wave teams: one team per CU)
     if (per_cu > wave_cap) per_cu = wave_cap;
     if (per_cu < 1) per_cu = 1;
@@ -777,7 +801,7 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
         unsigned long long bit = 1ull << (c->device & 63);
         if (!(done.load(std::memory_order_acquire) & bit)) {
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        160 * 1024 - 256));
+                                        160 * 1024 - 256 - (int)PW_KERNEL_STATIC_LDS));
             done.fetch_or(bit, std::memory_order_release);
         }
     }
@@ -1216,7 +1240,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         // (the smallest team either launch shape can fall back to: one wave, one window-fit slot)
         const size_t need = (!c->fused && win_) ? UnitShared::bytes(r->nmax, 1, 1, 1, false, pcap)
                                                 : UnitShared::bytes(r->nmax, win_ ? 1 : 0, win_ ? 1 : (opt_ ? 1 : 0), 2, false, pcap);
-        if (need + 64 > 160 * 1024 - 256) {
+        if (need + 64 > 160 * 1024 - 256 - PW_KERNEL_STATIC_LDS) {
             if (r->nmax > 40000) {
                 snprintf(g_err, sizeof(g_err), "molecule with %d atoms: more than the 40000 the pair indices are sized for", r->nmax);
                 return PW_E_TOO_LARGE;
@@ -1309,7 +1333,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         const char* al = getenv("PW_A_LDS_KB");
         if (al && atoi(al) > 0) {
             size_t want = (size_t)atoi(al) * 1024;
-            if (want > pa.lds && want <= 160 * 1024 - 256) pa.lds = want;
+            if (want > pa.lds && want <= 160 * 1024 - 256 - PW_KERNEL_STATIC_LDS) pa.lds = want;
         }
         if (getenv("PW_PLAN_DEBUG")) fprintf(stderr, "plan A: grid %d lds %zu\n", pa.grid, pa.lds);
     }
@@ -1534,7 +1558,8 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         static std::atomic<unsigned long long> attr_done{0};
         const unsigned long long bit = 1ull << (c->device & 63);
         if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-            HIP_TRY(hipFuncSetAttribute((const void*)pw_worker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            HIP_TRY(hipFuncSetAttribute((const void*)pw_worker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024 - 256 - (int)PW_KERNEL_STATIC_LDS));
             attr_done.fetch_or(bit, std::memory_order_release);
         }
         if (getenv("PW_PLAN_DEBUG"))

@@ -67,8 +67,10 @@
 // has no stack object whose address escapes into a call.
 #if defined(PW_TEAM_STATE_IN_LDS) && defined(__HIP_DEVICE_COMPILE__)
 #define PW_ASSUME_TEAM_STATE(sh, prm) do { PW_ASSUME_LDS(&(sh)); PW_ASSUME_LDS(&(prm)); } while (0)
+#define PW_ASSUME_TEAM_SH(sh) PW_ASSUME_LDS(&(sh))
 #else
 #define PW_ASSUME_TEAM_STATE(sh, prm) do {} while (0)
+#define PW_ASSUME_TEAM_SH(sh) do {} while (0)
 #endif
 
 // diagnostic builds (-DPW_DCHECKS, tests/tools/build_debug_variant.sh): an impossible value stops the wave where
@@ -1566,6 +1568,7 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
 
 template <class T, bool VALUE_ONLY = false>
 PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n, double* item_best = nullptr) {
+    PW_ASSUME_TEAM_SH(sh);
     team_max_dim_impl<T, VALUE_ONLY>(sh, F, n, item_best);
 }
 
@@ -1578,7 +1581,9 @@ PW_HD inline __attribute__((always_inline)) void stage_basic_impl(UnitShared& sh
     if (T::tid() == 0) {
         double tot = 0.0;
         for (int s0 = 0; s0 < n; s0 += 8192) {
-            double part = np_sum_small((const double*)(sh.mass + s0), n - s0 < 8192 ? n - s0 : 8192);
+            // (np_sum_lean: the recursion walked with scalars only -- np_sum_small's leaf tables were 500 bytes of
+            // scratch per lane in every kernel that contains this stage)
+            double part = np_sum_lean((const double*)(sh.mass + s0), n - s0 < 8192 ? n - s0 : 8192);
             tot = s0 == 0 ? part : tot + part;
         }
         v.mw = tot;
@@ -1620,6 +1625,7 @@ PW_HD inline __attribute__((always_inline)) void stage_basic_impl(UnitShared& sh
 template <class T>
 PW_NOINLINE PW_HD inline void stage_basic(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
                                            bool com_only) {
+    PW_ASSUME_TEAM_SH(sh);
     stage_basic_impl<T>(sh, ws, n, out, com_only);
 }
 
@@ -1756,6 +1762,7 @@ PW_HD inline __attribute__((always_inline)) void stage_opt_impl(UnitShared& sh, 
 template <class T>
 PW_NOINLINE PW_HD inline void stage_opt(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
                                         const pw_params& prm) {
+    PW_ASSUME_TEAM_STATE(sh, prm);
     stage_opt_impl<T>(sh, ws, n, out, prm);
 }
 
@@ -1889,6 +1896,7 @@ PW_HD inline __attribute__((always_inline)) void stage_average_impl(UnitShared& 
 template <class T>
 PW_NOINLINE PW_HD inline void stage_average(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
                                              const pw_params& prm) {
+    PW_ASSUME_TEAM_STATE(sh, prm);
     stage_average_impl<T, false>(sh, ws, n, out, prm);
 }
 
