@@ -46,8 +46,8 @@ ALGO_FLOP_BY_KERNEL = {
 HBM_PEAK_GBS = 8000.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 # static inputs measured with rocprofv3 --pmc (separate passes; committed summaries), NOT by this run
-TRAFFIC_FILES = ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01j_hbm_traffic.json")
-COUNTER_FILES = ("r03_instruction_counters.json", "r02_instruction_counters.json", "r01j_instruction_counters.json")
+TRAFFIC_FILES = ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01j_hbm_traffic.json")
+COUNTER_FILES = ("r04_instruction_counters.json", "r03_instruction_counters.json", "r02_instruction_counters.json", "r01j_instruction_counters.json")
 # the only figure for this metric the reference's repository holds: 715-frame CC3 trajectory,
 # traj.analysis(ncpus=8) in 286.5 s (examples/Example7_AnalysingTrajectorySingleMol.ipynb:569-575)
 REFERENCE_NOTEBOOK_FPS = 715 / 286.5
@@ -190,6 +190,21 @@ def _median_ms(fn, reps=5, warm=1):
     return float(np.median(ts)), [round(t, 3) for t in ts]
 
 
+def _median_legs(legs):
+    """Median of every numeric entry of a list of DLPOLY.last_timings dicts (flags / counts: the last one)."""
+    if not legs:
+        return None
+    out = {}
+    for k, v in legs[-1].items():
+        if isinstance(v, bool) or not isinstance(v, (int, float)):
+            out[k] = v
+        elif k.endswith("_ms"):
+            out[k] = round(float(np.median([l[k] for l in legs])), 4)
+        else:
+            out[k] = v
+    return out
+
+
 def secondary(ctx, vdw, mass):
     """BASELINE.json's other shapes, reported beside the headline (not part of `value`), each the
     median of five repetitions after a warm-up."""
@@ -210,13 +225,20 @@ def secondary(ctx, vdw, mass):
         path = synth.write_synthetic_history(os.path.join(tmp, "HISTORY"), FRAMES)
         traj = pw.DLPOLY(path)
 
+        legs = []
+
         def e2e():
-            return traj.analysis_records(forcefield="opls", swap_atoms={"he": "H"})
+            recs = traj.analysis_records(forcefield="opls", swap_atoms={"he": "H"})
+            legs.append(dict(traj.last_timings))
+            return recs
 
         med, reps = _median_ms(e2e)
         out["e2e_history_to_records"] = {"frames": FRAMES, "ms": med, "frames_per_s": FRAMES / (med * 1e-3), "reps_ms": reps,
-                                         "includes": "tokenising the HISTORY text, H2D, all launches, D2H of the records; "
-                                                     "the file goes through in pieces that overlap on the device"}
+                                         "includes": "tokenising the HISTORY text, H2D, all launches, D2H of the records; the "
+                                                     "analysis is launched first and the reader feeds it (streamed batch)",
+                                         "breakdown_ms": _median_legs(legs[1:]),
+                                         "breakdown_note": "host-side legs, medians: the analysis runs asynchronously -- what the "
+                                                           "host sees of it is wait_download (which contains the D2H copy)"}
 
         def e2e_dicts():
             traj.analysis_output = {}
@@ -261,8 +283,11 @@ def secondary(ctx, vdw, mass):
             ptraj = pw.DLPOLY(hpath)
             pstate = {}
 
+            plegs = []
+
             def prun():
                 pstate["r"] = ptraj.modular_records("all", rebuild=True)
+                plegs.append(dict(ptraj.last_timings))
 
             pmed, preps = _median_ms(prun, reps=5)
             precs = pstate["r"][0]
@@ -271,6 +296,10 @@ def secondary(ctx, vdw, mass):
                 "frames": pframes, "cages": int(len(precs)), "ms": pmed, "reps_ms": preps,
                 "frames_per_s": pframes / (pmed * 1e-3), "cages_per_s": len(precs) / (pmed * 1e-3),
                 "includes": "tokenising the text, H2D, periodic re-assembly, analysis of every cage, D2H",
+                "breakdown_ms": _median_legs(plegs[1:]),
+                "breakdown_note": "host-side legs, medians, summed over the pieces: tokenise_wait = waiting for the reader "
+                                  "thread (it decodes the next piece beside the device work), rebuild = H2D + re-assembly "
+                                  "launch + hand-over, wait_download = analysis not yet finished + D2H",
                 "all_status_zero": bool((precs["status"] == 0).all())}
         out["periodic_cell"] = {
             "workload": "cubic cell, 8 CC3 cages / 1344 atoms per frame (tests/data/system_periodic.pdb + 0.02 A noise)",
@@ -288,6 +317,36 @@ def _load_profile(names):
                 return json.load(fh), name
         except (OSError, ValueError):
             continue
+    return None, None
+
+
+SERIAL_STATS_FILES = ("r04_serial_kernel_stats.csv", "r03_serial_kernel_stats.csv")
+# which launch a kernel name of the stats file belongs to (template arguments: waves per team, stage mask)
+_KERNEL_OF = (("pw_analyse_kernel<1, 37u>", "chains"), ("pw_analyse_kernel<4, 98u>", "average"),
+              ("pw_analyse_kernel<4, 120u>", "windows"))
+
+
+def _serial_kernel_ms():
+    """Average kernel durations (ms) of the three launches from the committed rocprofv3 summary of one analysis at
+    a time -> ({"chains": .., "average": .., "windows": ..}, file name) or (None, None)."""
+    import csv
+
+    for name in SERIAL_STATS_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path, newline="") as fh:
+                rows = list(csv.DictReader(fh))
+        except OSError:
+            continue
+        out = {}
+        for row in rows:
+            kname = row.get("Name") or row.get("KernelName") or ""
+            avg = row.get("AverageNs") or row.get("Average") or row.get("AverageNs ")
+            for needle, launch in _KERNEL_OF:
+                if needle in kname and avg:
+                    out[launch] = float(avg) * 1e-6
+        if out:
+            return out, name
     return None, None
 
 
@@ -525,15 +584,25 @@ def main():
                 valu_issue = None
         # per launch of the pipeline, each on its own (no other launch in flight): HIP events on the
         # stream the kernel runs on; profiles/r02_serial_kernel_stats.csv is rocprofv3's view of the same
+        # Two clocks per launch: `ms` = rocprofv3's average kernel duration of ONE analysis at a time (committed summary,
+        # static: first wave to last wave of the kernel -- the figure the fractions use); `ms_events_live` = HIP events
+        # on the launch's own stream in THIS run, which also contain the time the launch sits behind its gate and waits
+        # for SIMD slots (the average-diameter launch has the lowest stream priority: 2.2 ms against 0.9).
         per_kernel = None
         try:
             st = res.stage_times()
+            prof, prof_name = _serial_kernel_ms()
             per_kernel = []
-            for name, ms in st.items():
+            for name, ms_live in st.items():
                 fl = ALGO_FLOP_BY_KERNEL[name] * args.frames
-                per_kernel.append({"kernel": name, "ms": ms, "algorithmic_flop_per_launch": fl,
-                                   "achieved_tflops": fl / (ms * 1e-3) / 1e12,
-                                   "frac_fp64_valu": fl / (ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS})
+                ms = prof.get(name) if (prof and args.frames == FRAMES) else None
+                entry = {"kernel": name, "ms": ms if ms is not None else ms_live, "ms_events_live": ms_live,
+                         "ms_source": (f"static: profiles/{prof_name} (rocprofv3 --kernel-trace --stats, one analysis at a time)"
+                                       if ms is not None else "HIP events of this run (no committed profile for this shape)"),
+                         "algorithmic_flop_per_launch": fl}
+                entry["achieved_tflops"] = fl / (entry["ms"] * 1e-3) / 1e12
+                entry["frac_fp64_valu"] = entry["achieved_tflops"] / FP64_VECTOR_PEAK_TFLOPS
+                per_kernel.append(entry)
         except Exception:  # noqa: BLE001 - e.g. a context that runs single launches has no per-launch times
             per_kernel = None
         line = {

@@ -222,6 +222,19 @@ int pw_context_point_capacity(pw_context *ctx);
  * pw_resident_* entry points read n_points / n_points_avg of the flagged records, reserve, launch again. */
 int pw_context_reserve_points(pw_context *ctx, int64_t n_points);
 
+/* A batch of ONE molecule type whose coordinates arrive in pieces, in unit order, while it is being analysed
+ * (the frame loop of the reference reads and analyses frame after frame, trajectory.py:496-522; here the reader
+ * feeds a launch that is already running).  begin: sizes known, radii / masses as a template of template_atoms
+ * entries; pw_resident_launch may follow at once -- the launch's teams wait for the units they are handed.
+ * append: coordinates [count][template_atoms][3] of units first .. first + count - 1, `first` = the number appended
+ * so far; the call returns when the copy has landed (from page-locked memory, pw_context_pinned, a DMA of tens of
+ * microseconds per megabyte) and the buffer may be reused.  Downloading an incomplete batch is PW_E_BAD_ARG; a
+ * launch that waits 5 s for a unit gives up and the download reports it (PW_E_HIP).  Device contexts only;
+ * molecules beyond LDS (PW_E_TOO_LARGE) go through pw_resident_upload. */
+int pw_resident_stream_begin(pw_context *ctx, int64_t n_units, int64_t template_atoms, const double *vdw,
+                             const double *mass, pw_resident **res);
+int pw_resident_stream_append(pw_context *ctx, pw_resident *res, const double *xyz, int64_t first, int64_t count);
+
 /* The same analysis with the intermediate results of find_windows captured per unit (dbg: n_units
  * records, caller-allocated).  Test instrumentation: one launch at a time, no overlap. */
 int pw_analysis_debug(pw_context *ctx, const pw_batch_in *in, uint32_t stages, pw_unit_out *out,

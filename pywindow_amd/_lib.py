@@ -228,6 +228,8 @@ EXPORTED_SYMBOLS = [
     "pw_pairwise_sum",
     "pw_dbscan",
     "pw_resident_upload",
+    "pw_resident_stream_begin",
+    "pw_resident_stream_append",
     "pw_resident_launch",
     "pw_resident_sync",
     "pw_resident_download",
@@ -329,6 +331,8 @@ def load():
     L.pw_pairwise_sum.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int, vp]
     L.pw_dbscan.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, vp, vp]
     L.pw_resident_upload.argtypes = [vp, ctypes.POINTER(BatchIn), ctypes.POINTER(vp)]
+    L.pw_resident_stream_begin.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, vp, ctypes.POINTER(vp)]
+    L.pw_resident_stream_append.argtypes = [vp, vp, vp, ctypes.c_int64, ctypes.c_int64]
     L.pw_resident_launch.argtypes = [vp, vp, ctypes.c_uint32]
     L.pw_resident_sync.argtypes = [vp]
     L.pw_resident_download.argtypes = [vp, vp, vp]
@@ -429,12 +433,12 @@ class Context:
         # params live on the context between set and reset: one analysis with params at a time
         import threading
 
-        self._params_lock = threading.Lock()
         #: held across the multi-call protocols that go through per-context state -- the page-locked staging
         #: buffer (pinned_array -> upload), "the records fetched last" (download -> extra_windows), the capacities
         #: a repeated launch relies on.  The C library serialises single calls on a context by itself
         #: (include/pywindow_amd.h, "Threads"); what belongs together is the caller's to keep together.
         self.lock = threading.RLock()
+        self._params_lock = self.lock           # (params live on the context between set and reset: the same sequences)
 
     def close(self):
         if self._h:
@@ -661,6 +665,21 @@ class Context:
     def upload(self, batch: Batch) -> "Resident":
         return Resident(self, batch)
 
+    def stream_begin(self, n_units: int, vdw, mass) -> "Resident":
+        """A batch of ``n_units`` molecules of one type whose coordinates will arrive in pieces
+        (``pw_resident_stream_begin``): launch it at once, then ``append`` the coordinates in unit order."""
+        vdw = np.ascontiguousarray(vdw, dtype=np.float64)
+        mass = np.ascontiguousarray(mass, dtype=np.float64)
+        if len(vdw) != len(mass) or not len(vdw):
+            raise ValueError("one radius and one mass per atom of the molecule")
+        h = ctypes.c_void_p()
+        _check(load().pw_resident_stream_begin(self._h, int(n_units), len(vdw), vdw.ctypes.data, mass.ctypes.data,
+                                               ctypes.byref(h)), "pw_resident_stream_begin")
+        res = Resident._adopt(self, h, int(n_units))
+        res.atoms = len(vdw)
+        res.appended = 0
+        return res
+
     @property
     def stream(self) -> int:
         return load().pw_context_stream(self._h) or 0
@@ -684,6 +703,17 @@ class Resident:
         obj._h = handle
         return obj
 
+    def append(self, coords) -> None:
+        """Coordinates ``(count, atoms, 3)`` of the next units of a streamed batch (``Context.stream_begin``).
+        ``coords`` should lie in the context's page-locked buffer (``Context.pinned_array``: the copy is then a DMA);
+        the call returns when they are on the device."""
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        if coords.ndim != 3 or coords.shape[1:] != (self.atoms, 3):
+            raise ValueError("coordinates must be (count, atoms, 3)")
+        _check(load().pw_resident_stream_append(self.ctx._h, self._h, coords.ctypes.data, self.appended, len(coords)),
+               "pw_resident_stream_append")
+        self.appended += len(coords)
+
     def launch(self, stages: int = STAGE_ALL):
         self._stages = stages
         _check(load().pw_resident_launch(self.ctx._h, self._h, stages), "pw_resident_launch")
@@ -697,13 +727,14 @@ class Resident:
         has asked for it (``PW_E_RETRY``): the analysis is then launched once more, here."""
         out = np.zeros(self.n_units, dtype=UNIT_OUT_DTYPE)
         if self.n_units:
-            rc = load().pw_resident_download(self.ctx._h, self._h, out.ctypes.data)
-            if rc == E_RETRY:
-                self.launch(getattr(self, "_stages", STAGE_ALL))
+            with self.ctx.lock:       # (the records and "the windows beyond W_MAX of the records fetched last" belong together)
                 rc = load().pw_resident_download(self.ctx._h, self._h, out.ctypes.data)
-            _check(rc, "pw_resident_download")
-            if extra is not None and (out["status"] & ST_WINDOW_OVERFLOW).any():
-                extra.append(self.ctx.extra_windows())
+                if rc == E_RETRY:
+                    self.launch(getattr(self, "_stages", STAGE_ALL))
+                    rc = load().pw_resident_download(self.ctx._h, self._h, out.ctypes.data)
+                _check(rc, "pw_resident_download")
+                if extra is not None and (out["status"] & ST_WINDOW_OVERFLOW).any():
+                    extra.append(self.ctx.extra_windows())
         return out
 
     def download_settled(self, extra=None) -> np.ndarray:

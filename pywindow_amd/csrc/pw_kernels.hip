@@ -25,8 +25,9 @@
 #include "../../include/pywindow_amd.h"
 #include "pw_host.hpp"
 #include <vector>
-// the analysis kernels of this file keep their UnitShared / FitShared and parameters in (static) LDS, not on the stack
-#define PW_TEAM_STATE_IN_LDS 1
+// (no PW_TEAM_STATE_IN_LDS here: this file's stage functions serve kernels that keep their team state in LDS -- chains,
+// average diameter, the workers -- AND kernels that keep it on the stack -- the window search, whose out-of-line stage
+// function spills five times as much when its table of pointers is an LDS object: 269 against 55 scratch stores)
 #include "pw_unit.hpp"
 #include "pw_launch.hpp"
 
@@ -123,13 +124,33 @@ __global__ void __launch_bounds__(256) pw_nb_build_kernel(unsigned* __restrict__
 #ifndef PW_OCC_A
 #define PW_OCC_A PW_OCC
 #endif
+// A batch whose coordinates are still arriving (pw_resident_stream_*): `ready` counts the units whose
+// coordinates are on the device.  The launches that read coordinates without going through the hand-off queue --
+// optimiser chains, average diameter -- take units in index order and wait (bounded) until theirs is there, so the
+// analysis can be launched before the reader has decoded the first frame.  ready == nullptr: everything is there.
+__device__ inline bool wait_for_unit(const unsigned long long* ready, long u, int* error_flag) {
+    if (!ready) return true;
+    long long t0 = wall_clock64();
+    while ((long)__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) <= u) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > 500000000ll) {       // 5 s: the host stopped appending
+            if (error_flag) atomicExch(error_flag, 1);
+            return false;
+        }
+    }
+    // (system scope: the coordinates were written by the copy engine, not by a wave of this device)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return true;
+}
 template <int NW, unsigned MASK>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? PW_OCC8 : (MASK == PW_KERNEL_AVERAGE ? 3 : (MASK == MASK_CHAINS ? PW_OCC_A : PW_OCC)))
 pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
                   const double* __restrict__ vdw, const double* __restrict__ mass, unsigned stages,
                   int nmax, int nrot, int nlb, int nframes, int lean, PwWsArgs wsa, unsigned long long* counter,
                   pw_unit_out* __restrict__ out, int role, UnitQueue* queue, int* __restrict__ slots,
-                  pw_params prm_in, const unsigned* __restrict__ rsq_tab, int vstride, FitArgs fa) {
+                  pw_params prm_in, const unsigned* __restrict__ rsq_tab, int vstride, FitArgs fa,
+                  const unsigned long long* __restrict__ ready) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ long s_unit;
     // the team's table of pointers and its parameters live in LDS (PW_TEAM_STATE_IN_LDS, pw_unit.hpp): the stage
@@ -152,8 +173,12 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
         bind_workspace(ws, wsa, blockIdx.x, rsq_tab, team_slab_bytes(wsa.p_cap), team_adj_words(wsa.p_cap));
     }
     __syncthreads();
-    UnitShared& sh = s_sh;
-    const pw_params& prm = s_prm;
+    // chains and average diameter look their pointers up in LDS; the window search keeps them on its stack (see above)
+    constexpr bool STATE_IN_LDS = MASK == MASK_CHAINS || MASK == PW_KERNEL_AVERAGE;
+    UnitShared sh_stack;
+    if (!STATE_IN_LDS) sh_stack.carve(lds, nmax, nrot, nlb, nframes, lean, wsa.p_cap);
+    UnitShared& sh = STATE_IN_LDS ? (UnitShared&)s_sh : sh_stack;
+    const pw_params& prm = STATE_IN_LDS ? (const pw_params&)s_prm : prm_in;
     for (;;) {
         if (role == PW_ROLE_CONSUMER || role == PW_ROLE_SAMPLER) {
             if (threadIdx.x == 0) {
@@ -185,6 +210,7 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
         } else {
             if (threadIdx.x == 0) {
                 long u = (long)atomicAdd(counter, 1ull);
+                if (u < n_units && !wait_for_unit(ready, u, &queue->error)) u = n_units;
                 s_unit = u < n_units ? u : -1;
             }
         }
@@ -259,7 +285,8 @@ __global__ void __launch_bounds__(64, PW_OCC_A)
 pw_worker_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
                  const double* __restrict__ vdw, const double* __restrict__ mass, int nmax, PwWsArgs wsa,
                  unsigned long long* counter, pw_unit_out* __restrict__ out, UnitQueue* queue, int* __restrict__ slots,
-                 pw_params prm_in, const unsigned* __restrict__ rsq_tab, int vstride, FitArgs fa) {
+                 pw_params prm_in, const unsigned* __restrict__ rsq_tab, int vstride, FitArgs fa,
+                 const unsigned long long* __restrict__ ready) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ UnitShared s_sh;
     __shared__ FitShared s_fs;
@@ -333,7 +360,10 @@ pw_worker_kernel(long n_units, const long* __restrict__ atom_offset, const doubl
         // 2. a chain that has not started?
         long u = -1;
         if (chains_left) {
-            if (threadIdx.x == 0) u = (long)atomicAdd(counter, 1ull);
+            if (threadIdx.x == 0) {
+                u = (long)atomicAdd(counter, 1ull);
+                if (u < n_units && !wait_for_unit(ready, u, &queue->error)) u = n_units;
+            }
             u = wave_uniform_long(u);
             if (u >= n_units) { u = -1; chains_left = false; }
         }
@@ -622,6 +652,9 @@ struct pw_context {
     size_t bigmem_bytes;
     void* pinned;            // page-locked host staging buffer handed to the reader (pw_context_pinned)
     size_t pinned_bytes;
+    unsigned long long* ready_vals;   // page-locked, device-mapped ring of `ready` counters: a streamed batch takes one, the host
+    unsigned long long* ready_dev;    // raises it after each copy, the waiting teams poll it (pw_resident_stream_*); ready_dev:
+    unsigned ready_at;                // the ring's device address
     std::recursive_mutex* mu;      // held by every entry point for the duration of the call (pw_host.hpp)
 };
 
@@ -642,6 +675,9 @@ struct pw_resident {
     long n_atoms;
     int nmax;
     int vstride;             // 1: d_vdw / d_mass per atom; 0: one template of nmax atoms for every unit
+    unsigned long long* d_ready;   // streamed batch (pw_resident_stream_begin): units whose coordinates have arrived -- a counter
+    unsigned long long* h_ready;   // in page-locked host memory that the device reads (d_ready: its device address); else null
+    long ready_units;              // ... as the host has raised it
     long* d_offset;
     double* d_xyz;
     double* d_vdw;
@@ -818,7 +854,7 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
                        r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb, p.nframes, p.lean, wsa,
                        c->counter + counter_slot, r->d_out, role, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab,
-                       r->vstride, c->cur_fit);
+                       r->vstride, c->cur_fit, (const unsigned long long*)r->d_ready);
     HIP_TRY(hipGetLastError());
     return PW_OK;
 }
@@ -1096,6 +1132,7 @@ void pw_context_destroy(pw_context* c) {
     if (c->blocks) for (auto& b : *c->blocks) (void)hipFree(b.p);
     delete c->blocks;
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->ready_vals) (void)hipHostFree(c->ready_vals);
     if (c->bigmem) (void)hipFree(c->bigmem);
     delete c->extra;
     if (c->ev_ext) (void)hipEventDestroy(c->ev_ext);
@@ -1573,7 +1610,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         wsa.nb_off = c->nb_off; wsa.nb_idx = c->nb_idx; wsa.nb_bound = c->nb_bound;
         hipLaunchKernelGGL(pw_worker_kernel, dim3(pa.grid), dim3(64), pa.lds, c->prod, r->n_units, r->d_offset, r->d_xyz, r->d_vdw,
                            r->d_mass, r->nmax, wsa, c->counter + b, r->d_out, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab,
-                           r->vstride, c->cur_fit);
+                           r->vstride, c->cur_fit, (const unsigned long long*)r->d_ready);
         HIP_TRY(hipGetLastError());
     } else {
         rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod, ws_a, -1, b, PW_ROLE_PRODUCER, false);
@@ -1773,6 +1810,102 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
     return PW_OK;
 }
 
+// ---- a batch whose coordinates arrive while it is being analysed --------------------------------------------
+// One molecule type (template_atoms per unit), n_units known, coordinates appended in unit order.  The analysis
+// may be launched right after pw_resident_stream_begin: its chains and average-diameter teams take units in
+// index order and wait for the `ready` counter, which every append raises behind its copy on the API stream.
+// What this hides is the reader: decoding a 1000-frame HISTORY file takes about as long as a third of the
+// analysis' own latency (reference: the frame loop of Trajectory._analysis_serial reads and analyses one frame
+// after the other, trajectory.py:496-522).
+int pw_resident_stream_begin(pw_context* c, int64_t n_units, int64_t template_atoms, const double* vdw, const double* mass,
+                             pw_resident** out) {
+    if (!c || !out || n_units <= 0 || template_atoms <= 0 || !vdw || !mass) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
+    *out = nullptr;
+    PW_HOST_UNSUPPORTED(c, "streamed batches");
+    if (template_atoms > 40000 || n_units * template_atoms > (int64_t)1 << 40) return PW_E_TOO_LARGE;
+    {
+        const int pcap = wanted_p_cap(c) > c->p_cap ? wanted_p_cap(c) : c->p_cap;
+        if (UnitShared::bytes((int)template_atoms, 1, 1, 1, false, pcap) + 64 > 160 * 1024 - 256 - PW_KERNEL_STATIC_LDS) {
+            snprintf(g_err, sizeof(g_err), "molecule with %ld atoms: beyond LDS, upload it in one piece", (long)template_atoms);
+            return PW_E_TOO_LARGE;
+        }
+    }
+    PW_ON_DEVICE(c->device);
+    pw_resident* r = new (std::nothrow) pw_resident();
+    if (!r) return PW_E_NOMEM;
+    memset((void*)r, 0, sizeof(*r));
+    r->n_units = (long)n_units;
+    r->n_atoms = (long)(n_units * template_atoms);
+    r->nmax = (int)template_atoms;
+    r->vstride = 0;
+    r->nbuf = c->nsets ? c->nsets : (r->n_units <= 1500 ? 4 : (r->n_units <= 6000 ? 3 : 2));
+    auto up256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_off = up256(sizeof(long) * (size_t)(r->n_units + 1)), b_xyz = up256(sizeof(double) * 3 * (size_t)r->n_atoms);
+    const size_t b_con = up256(sizeof(double) * (size_t)template_atoms);
+    const size_t b_out = up256((size_t)r->nbuf * sizeof(pw_unit_out) * (size_t)r->n_units + 64);
+    int rcb = block_take(c, b_off + b_xyz + 2 * b_con + b_out + 256, &r->block, &r->block_bytes);
+    if (rcb != PW_OK) { pw_resident_free(c, r); return rcb; }
+    unsigned char* base = (unsigned char*)r->block;
+    r->d_offset = (long*)base; base += b_off;
+    r->d_xyz = (double*)base; base += b_xyz;
+    r->d_vdw = (double*)base; base += b_con;
+    r->d_mass = (double*)base; base += b_con;
+    r->d_outs[0] = (pw_unit_out*)base; base += b_out;
+    {
+        // the counter lives in host memory the device can read: the host raises it when a copy has landed, and no
+        // kernel or copy has to be scheduled beside the launch that is waiting for it
+        constexpr unsigned RING = 4096;
+        if (!c->ready_vals) {
+            hipError_t eh = hipHostMalloc((void**)&c->ready_vals, RING * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent);
+            if (eh == hipSuccess) eh = hipHostGetDevicePointer((void**)&c->ready_dev, c->ready_vals, 0);
+            if (eh != hipSuccess) { set_err("pw_resident_stream_begin (ready counters)", eh); c->ready_vals = nullptr; pw_resident_free(c, r); return PW_E_HIP; }
+        }
+        const unsigned at = c->ready_at++ % RING;
+        r->h_ready = c->ready_vals + at;
+        r->d_ready = c->ready_dev + at;
+        __atomic_store_n(r->h_ready, 0ull, __ATOMIC_RELEASE);
+    }
+    for (int k = 1; k < r->nbuf; ++k) r->d_outs[k] = r->d_outs[0] + (size_t)k * r->n_units;
+    r->d_xw_count = (unsigned*)(r->d_outs[0] + (size_t)r->nbuf * r->n_units);
+    for (int k = 0; k < PW_SETS; ++k) r->written_set[k] = -1;
+    r->d_out = r->d_outs[0];
+    // atom offsets of a uniform batch: k * atoms (built on the host: 8 KB per 1000 units)
+    std::vector<long> off((size_t)r->n_units + 1);
+    for (long u = 0; u <= r->n_units; ++u) off[(size_t)u] = u * (long)template_atoms;
+    hipError_t e = hipMemcpyAsync(r->d_offset, off.data(), sizeof(long) * (r->n_units + 1), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->d_vdw, vdw, sizeof(double) * template_atoms, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->d_mass, mass, sizeof(double) * template_atoms, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(r->d_outs[0], 0, r->nbuf * sizeof(pw_unit_out) * r->n_units + 64, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // (`off` is a local; 10 us of copies)
+    if (e != hipSuccess) { set_err("pw_resident_stream_begin", e); pw_resident_free(c, r); return PW_E_HIP; }
+    c->need_fork = 1;
+    *out = r;
+    return PW_OK;
+}
+
+// coordinates of units [first, first + count): first must be what has been appended so far.  Returns when the copy
+// has landed (from page-locked memory -- pw_context_pinned -- a DMA of tens of microseconds per megabyte).
+int pw_resident_stream_append(pw_context* c, pw_resident* r, const double* xyz, int64_t first, int64_t count) {
+    if (!c || !r || !xyz || count < 0) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
+    if (!r->d_ready || first != r->ready_units || first + count > r->n_units) {
+        snprintf(g_err, sizeof(g_err), "pw_resident_stream_append: units %ld..%ld do not continue the %ld appended so far (of %ld)",
+                 (long)first, (long)(first + count), r->ready_units, r->n_units);
+        return PW_E_BAD_ARG;
+    }
+    if (count == 0) return PW_OK;
+    PW_ON_DEVICE(c->device);
+    const size_t per = (size_t)r->nmax * 3;
+    HIP_TRY(hipMemcpyAsync(r->d_xyz + (size_t)first * per, xyz, sizeof(double) * per * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    // the copy has landed when the API stream is idle again (nothing else is queued on it: the launches run on the
+    // pipeline's own streams); then the counter is raised from the host
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    r->ready_units = (long)(first + count);
+    __atomic_store_n(r->h_ready, (unsigned long long)r->ready_units, __ATOMIC_RELEASE);
+    return PW_OK;
+}
+
 // a batch whose arrays are already on the device (pw_resident_from_cells); takes ownership of the four
 // blocks (taken from the context's cache: part_bytes says how large each is)
 int pw_internal_resident_adopt(pw_context* c, long n_units, long n_atoms, int nmax, long* d_offset, double* d_xyz,
@@ -1848,6 +1981,10 @@ int pw_resident_download(pw_context* c, pw_resident* r, pw_unit_out* out) {
         if (!r->host) return PW_E_BAD_ARG;
         memcpy(out, r->host->out.data(), sizeof(pw_unit_out) * (size_t)r->n_units);
         return PW_OK;
+    }
+    if (r->d_ready && r->ready_units < r->n_units) {
+        snprintf(g_err, sizeof(g_err), "streamed batch: %ld of %ld units appended", r->ready_units, r->n_units);
+        return PW_E_BAD_ARG;
     }
     PW_ON_DEVICE(c->device);
     // wait for the launch that wrote these records -- not for launches of other batches issued since

@@ -17,6 +17,7 @@ from __future__ import annotations
 import ctypes
 import pathlib
 import sys
+import time
 
 import numpy as np
 
@@ -34,6 +35,10 @@ MODULAR_IN_FLIGHT = 2
 #: a plain analysis goes through in ONE piece up to 2 x RUN_PIECE frames and in pieces of RUN_PIECE beyond (what
 #: bounds the device memory of a very long trajectory; see DLPOLY._run for why not smaller)
 RUN_PIECE = 16384
+#: a piece of at least this many frames is STREAMED: its analysis is launched first and the reader feeds it (the
+#: launch's teams wait for the frames they are handed) -- STREAM_CHUNKS appends per piece
+STREAM_MIN = 256
+STREAM_CHUNKS = 4
 
 
 class _FunctionError(Exception):
@@ -68,7 +73,10 @@ class DLPOLY:
         self.system_id = self.filepath.name.split(".")[0]
         self.frames: dict = {}
         self.analysis_output: dict = {}
-        self._record_view = LazyAnalysis()      # the records behind analysis_output (save_records / lazy views)
+        self._stores: list = []                 # the records behind analysis_output, one RecordStore per analysis
+        #: host-side legs of the latest analysis_records / analysis call, milliseconds (the analysis itself runs
+        #: asynchronously: what the host sees of it is the wait in the download)
+        self.last_timings: dict = {}
         L = _lib.load()
         h = ctypes.c_void_p()
         rc = L.pw_history_open(str(self.filepath).encode(), ctypes.byref(h))
@@ -213,7 +221,7 @@ class DLPOLY:
     def _keep(self, store: RecordStore, lazy: bool) -> None:
         """Results of an analysis enter ``analysis_output``: as the reference's nested dicts (default), or --
         ``lazy`` -- as a view that builds a frame's dict from the records when it is first asked for."""
-        self._record_view.attach(store)
+        self._stores.append(store)              # (indexed only when save_records / analysis_store ask for it)
         if lazy or isinstance(self.analysis_output, LazyAnalysis):
             if not isinstance(self.analysis_output, LazyAnalysis):
                 self.analysis_output = LazyAnalysis(self.analysis_output)
@@ -241,7 +249,7 @@ class DLPOLY:
             path = path.with_suffix(".pwrec")
         if override is False and path.is_file():
             raise FileExistsError(f"The file {path} already exists. Use a different filepath, or set the 'override' to True.")
-        return self._record_view.record_store().save(path)
+        return self.analysis_store.save(path)
 
     def load_records(self, filepath) -> RecordStore:
         """Reopen what ``save_records`` wrote: ``analysis_output`` becomes a lazy view of the records
@@ -252,8 +260,12 @@ class DLPOLY:
 
     @property
     def analysis_store(self) -> RecordStore:
-        """The records behind ``analysis_output`` (every frame analysed or loaded so far, in order)."""
-        return self._record_view.record_store()
+        """The records behind ``analysis_output`` (every frame analysed or loaded so far, in order; a frame
+        analysed again with ``override`` keeps its place and takes the later records)."""
+        view = LazyAnalysis()
+        for store in self._stores:
+            view.attach(store)
+        return view.record_store()
 
     def analysis_records(self, frames="all", swap_atoms=None, forcefield=None, device=None) -> np.ndarray:
         """Columnar results: the structured record array (``_lib.UNIT_OUT_DTYPE``) for the
@@ -331,7 +343,9 @@ class DLPOLY:
             res = inflight[0]           # (stays listed until it has been freed: a download that raises leaks nothing)
             try:
                 extra = []
+                t0 = time.perf_counter()
                 parts.append(res.download_settled(extra))
+                self.last_timings["wait_download_ms"] += 1e3 * (time.perf_counter() - t0)
                 extras.extend(engine.offset_extra(e, done[0]) for e in extra)
                 done[0] += res.n_units
             finally:
@@ -340,14 +354,51 @@ class DLPOLY:
 
         # the context's staging buffer, its "records fetched last" list and its capacities are one per context:
         # one trajectory at a time goes through (threads analysing on the same device take turns here)
+        timing = self.last_timings = {"tokenise_ms": 0.0, "upload_ms": 0.0, "launch_ms": 0.0, "wait_download_ms": 0.0,
+                                      "pieces": 0, "streamed": False, "reader_threads": int(_lib.load().pw_history_reader_threads())}
+        clock = time.perf_counter
         with ctx.lock:
             try:
                 for lo in range(0, n, per):
                     sel = frames[lo:lo + per]
-                    coords, _ = self._read_selected(sel, False, out=ctx.pinned_array((len(sel), self.no_of_atoms, 3)))
-                    res = ctx.upload(_lib.Batch.uniform(coords, vdw, mass))
-                    inflight.append(res)
-                    res.launch(_lib.STAGE_ALL)
+                    timing["pieces"] += 1
+                    res = None
+                    # (the page-locked buffer FIRST: growing it waits for the device, which must not be waiting for it)
+                    buf = ctx.pinned_array((len(sel), self.no_of_atoms, 3))
+                    if ctx.device >= 0 and len(sel) >= STREAM_MIN and n <= per:
+                        # one piece, streamed: launch first, then decode chunk after chunk into the page-locked buffer
+                        # and append -- the chains of the first frames run while the reader still decodes the rest
+                        try:
+                            res = ctx.stream_begin(len(sel), vdw, mass)
+                        except _lib.PwHipError:
+                            res = None               # (a molecule beyond LDS: the plain upload below)
+                    if res is not None:
+                        inflight.append(res)
+                        t0 = clock()
+                        res.launch(_lib.STAGE_ALL)
+                        timing["launch_ms"] += 1e3 * (clock() - t0)
+                        step = max(32, -(-len(sel) // STREAM_CHUNKS))
+                        for a in range(0, len(sel), step):
+                            t0 = clock()
+                            self._read_selected(sel[a:a + step], False, out=buf[a:a + step])
+                            t1 = clock()
+                            res.append(buf[a:a + step])
+                            t2 = clock()
+                            timing["tokenise_ms"] += 1e3 * (t1 - t0)
+                            timing["upload_ms"] += 1e3 * (t2 - t1)
+                        timing["streamed"] = True
+                    else:
+                        t0 = clock()
+                        coords, _ = self._read_selected(sel, False, out=buf)
+                        t1 = clock()
+                        res = ctx.upload(_lib.Batch.uniform(coords, vdw, mass))
+                        inflight.append(res)
+                        t2 = clock()
+                        res.launch(_lib.STAGE_ALL)
+                        t3 = clock()
+                        timing["tokenise_ms"] += 1e3 * (t1 - t0)
+                        timing["upload_ms"] += 1e3 * (t2 - t1)
+                        timing["launch_ms"] += 1e3 * (t3 - t2)
                     if len(inflight) > 2:   # at most three pieces on the device, however long the trajectory
                         collect()
                 while inflight:
@@ -418,6 +469,12 @@ class DLPOLY:
         n = len(frames)
         piece = MODULAR_CHUNK if n < 2 * MODULAR_PIECE else min(MODULAR_CHUNK, MODULAR_PIECE)
         parts, waiting, spent = [], [], []
+        # host-side legs, milliseconds: waiting for the reader (it runs on a helper thread beside the device work), the
+        # re-assembly call (copies up, rebuild launch, its wait, the on-device hand-over), queueing the analysis,
+        # waiting for records (the analysis of a piece overlaps the re-assembly of the next)
+        timing = self.last_timings = {"tokenise_wait_ms": 0.0, "rebuild_ms": 0.0, "launch_ms": 0.0, "wait_download_ms": 0.0,
+                                      "pieces": 0, "reader_threads": int(_lib.load().pw_history_reader_threads())}
+        clock = time.perf_counter
 
         extras: list = []
         done = [0]
@@ -426,7 +483,9 @@ class DLPOLY:
             res, n_mol = waiting[0]        # (stays listed until it has been freed: a download that raises leaks nothing)
             try:
                 extra: list = []
+                t0 = clock()
                 recs = res.download_settled(extra) if res is not None else np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE)
+                timing["wait_download_ms"] += 1e3 * (clock() - t0)
                 extras.extend(engine.offset_extra(e, done[0]) for e in extra)
                 done[0] += len(recs)
                 parts.append((recs, n_mol))
@@ -436,8 +495,18 @@ class DLPOLY:
                     res.free()             # (its blocks go back to the context's cache: no device-wide wait, and the
                                            # memory of a long trajectory stays at the pieces in flight)
 
-        def read_piece(i):
-            coords, lattice = self._read_selected(frames[i:i + piece], self.periodic)
+        # Pieces are decoded into the context's page-locked buffer, two halves in turn (a piece has been copied to the
+        # device when resident_from_cells returns, i.e. before the piece after next is decoded): the H2D of a
+        # 1344-atom x 512-frame piece is then one DMA instead of a staged copy through the runtime's bounce buffer.
+        n_pieces = -(-n // piece)
+        halves = None
+        if ctx.device >= 0 and n_pieces > 0:
+            halves = ctx.pinned_array((2 if n_pieces > 1 else 1, min(piece, n), self.no_of_atoms, 3))
+
+        def read_piece(i, k=0):
+            sel_ = frames[i:i + piece]
+            out = halves[k % len(halves)][: len(sel_)] if halves is not None else None
+            coords, lattice = self._read_selected(sel_, self.periodic, out=out)
             return rb.pack_frames(coords, lattice)
 
         # the next piece is tokenised by a helper thread (the native reader releases the interpreter lock)
@@ -450,17 +519,24 @@ class DLPOLY:
             pool = ThreadPoolExecutor(max_workers=1)
         ctx.lock.acquire()                 # (one trajectory at a time per context, see _run)
         try:
-            ahead = pool.submit(read_piece, starts[0]) if pool else None
+            ahead = pool.submit(read_piece, starts[0], 0) if pool else None
             for k, i in enumerate(starts):
+                t0 = clock()
                 if pool:
                     coords, lat, inv = ahead.result()
-                    ahead = pool.submit(read_piece, starts[k + 1]) if k + 1 < len(starts) else None
+                    ahead = pool.submit(read_piece, starts[k + 1], k + 1) if k + 1 < len(starts) else None
                 else:
-                    coords, lat, inv = read_piece(i)
+                    coords, lat, inv = read_piece(i, k)
+                t1 = clock()
                 res, n_mol = ctx.resident_from_cells(topo, vdw, coords, lat, inv, rebuild)
+                t2 = clock()
                 waiting.append((res, n_mol))
                 if res is not None:
                     res.launch(_lib.STAGE_ALL)
+                timing["tokenise_wait_ms"] += 1e3 * (t1 - t0)
+                timing["rebuild_ms"] += 1e3 * (t2 - t1)
+                timing["launch_ms"] += 1e3 * (clock() - t2)
+                timing["pieces"] += 1
                 if len(waiting) > MODULAR_IN_FLIGHT:
                     collect()
             while waiting:

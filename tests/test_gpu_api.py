@@ -278,3 +278,51 @@ def test_two_threads_analyse_trajectories_on_the_shared_context(tmp_path):
     for t in ts:
         t.join(timeout=600)
     assert not errors, errors
+
+
+@pytest.mark.gpu
+def test_streamed_batch_equals_the_uploaded_one(tmp_path):
+    """pw_resident_stream_begin / _append: the analysis is launched BEFORE any coordinate is on the device and the
+    reader feeds it; records byte-identical to the batch uploaded in one piece, whatever the chunking, also when the
+    launch is repeated on the completed batch; an incomplete batch cannot be downloaded; appends must be in order.
+    And the trajectory driver built on it: DLPOLY.analysis_records streams a 1000-frame file (last_timings says so)
+    and returns what the one-piece path returns."""
+    import pywindow_amd as pw
+    from pywindow_amd import _lib, engine, synth, trajectory
+    from pywindow_amd import element_data as E
+
+    elements, frames = synth.synthetic_units(300)
+    ids = E.element_ids(elements)
+    vdw, mass = E.VDW[ids], E.MASS[ids]
+    ctx = engine.context(0)
+    whole = ctx.upload(_lib.Batch.uniform(frames, vdw, mass))
+    whole.launch()
+    expect = whole.download()
+    whole.free()
+    for chunk in (300, 64, 7):
+        buf = ctx.pinned_array(frames.shape)
+        buf[:] = frames
+        res = ctx.stream_begin(len(frames), vdw, mass)
+        res.launch()                                   # nothing has arrived yet: the teams wait
+        with pytest.raises(_lib.PwHipError):
+            res.download()                             # incomplete
+        for lo in range(0, len(frames), chunk):
+            res.append(buf[lo:lo + chunk])
+        got = res.download()
+        assert got.tobytes() == expect.tobytes(), chunk
+        res.launch()                                   # a second analysis of the complete batch
+        assert res.download().tobytes() == expect.tobytes()
+        with pytest.raises(_lib.PwHipError):
+            res.append(buf[:1])                        # nothing left to append
+        res.free()
+    path = synth.write_synthetic_history(tmp_path / "HISTORY", 1000)
+    traj = pw.DLPOLY(path)
+    streamed = traj.analysis_records(forcefield="opls", swap_atoms={"he": "H"})
+    assert traj.last_timings["streamed"] is True and traj.last_timings["pieces"] == 1
+    old = trajectory.STREAM_MIN
+    trajectory.STREAM_MIN = 10 ** 9
+    try:
+        plain = pw.DLPOLY(path).analysis_records(forcefield="opls", swap_atoms={"he": "H"})
+    finally:
+        trajectory.STREAM_MIN = old
+    assert streamed.tobytes() == plain.tobytes() and (streamed["n_windows"] == 4).all()
