@@ -64,4 +64,51 @@ PW_HD inline double pw_min(double a, double b) { return a < b ? a : b; }
 
 constexpr double PW_INF = __builtin_huge_val();
 
+// ---- a division whose divisor is known in advance -------------------------------------------------------------
+// On gfx950 a / b is eleven dependent instructions: v_div_scale x2, v_rcp_f64, two Newton steps on the reciprocal,
+// q = a * r, rem = fma(-b, q, a), v_div_fmas (= fma(rem, r, q)), v_div_fixup.  Everything up to the refined
+// reciprocal r depends on b alone, and the two scale instructions, div_fmas' scaling and the fix-up do NOTHING while
+// both exponents are unremarkable (ISA: V_DIV_SCALE_F64 scales for a denormal or huge divisor, an exponent
+// difference >= 768, a quotient that would be denormal, a dividend exponent <= 53).  pw_recip_hw(b) is that r --
+// the same instructions in the same order -- and pw_div_r(a, b, r) the remaining three, so the quotient has the
+// bits of a / b (checked on the device over 2^26 operand pairs, tests/test_gpu_api.py); operands outside the plain
+// range, a zero divisor included, take a / b itself.  A solve that divides by the same diagonal at every step
+// (pw_lbfgsb.hpp) pays three dependent instructions per step instead of eleven.  On the host both are the plain
+// division (IEEE: the same bits).
+PW_HD inline bool pw_plain_exponent(double a) {
+    // biased exponent in [700, 1400]: 2^-323 <= |a| < 2^378
+    union { double d; unsigned long long u; } c;
+    c.d = a;
+    const unsigned h = (unsigned)(c.u >> 32) & 0x7ff00000u;
+    return (h - 0x2bc00000u) <= 0x2bc00000u;
+}
+PW_HD inline double pw_recip_hw(double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!pw_plain_exponent(b)) return 0.0;          // pw_div_r divides for real
+    const double r0 = __builtin_amdgcn_rcp(b);
+    const double e0 = __builtin_fma(-b, r0, 1.0);
+    const double r1 = __builtin_fma(r0, e0, r0);
+    const double e1 = __builtin_fma(-b, r1, 1.0);
+    return __builtin_fma(r1, e1, r1);
+#else
+    (void)b;
+    return 1.0;
+#endif
+}
+PW_HD inline double pw_div_r(double a, double b, double r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double q = a * r;
+    const double rem = __builtin_fma(-b, q, a);
+    double res = __builtin_fma(rem, r, q);
+    const bool zero = a == 0.0;
+    res = zero ? q : res;                          // (+-0 / b: the sign of the product)
+    const bool fast = (pw_plain_exponent(a) || zero) && r != 0.0;
+    if (__builtin_expect(!fast, 0)) res = a / b;
+    return res;
+#else
+    (void)r;
+    return a / b;
+#endif
+}
+
 }  // namespace pw

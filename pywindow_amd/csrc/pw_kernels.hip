@@ -538,6 +538,51 @@ __global__ void pw_point_gap_kernel(long n_points, const long* __restrict__ unit
     arg[q] = bi;
 }
 
+// pw_div_r against the division it replaces (pw_common.hpp), on operand pairs made up on the device from a counter:
+// mode 0 magnitudes as the optimisers see them (2^-40 .. 2^40), 1 any bit pattern (denormals, infinities, NaNs, zeros:
+// the guarded path), 2 divisors whose significand is all ones or nearly (the hard case of reciprocal-based division),
+// 3 quotients that are exactly representable (a = q * b with short q, b).  out[0] = pairs that differ, out[1..3] =
+// the bits of the first such pair and of the wrong quotient.
+__global__ void pw_div_check_kernel(unsigned long long n, int mode, unsigned long long seed, unsigned long long* out) {
+    const unsigned long long i0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    auto mix = [](unsigned long long z) {
+        z += 0x9e3779b97f4a7c15ull;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    };
+    auto as_d = [](unsigned long long u) { union { unsigned long long u; double d; } c; c.u = u; return c.d; };
+    auto as_u = [](double d) { union { unsigned long long u; double d; } c; c.d = d; return c.u; };
+    for (unsigned long long i = i0; i < n; i += stride) {
+        const unsigned long long r1 = mix(seed + 2 * i), r2 = mix(seed + 2 * i + 1), r3 = mix(r1 ^ r2);
+        double a, b;
+        if (mode == 1) {
+            a = as_d(r1);
+            b = as_d(r2);
+            if ((r3 & 15) == 0) a = as_d(r1 & 0x800fffffffffffffull);                 // denormal / zero dividend
+            if ((r3 & 0xf0) == 0) b = as_d(r2 & 0x800fffffffffffffull);
+            if ((r3 & 0xf00) == 0) a = as_d(r1 & 0x8000000000000000ull);             // +-0
+        } else {
+            const unsigned long long ea = 1023 - 40 + (r3 % 81), eb = 1023 - 40 + ((r3 >> 20) % 81);
+            a = as_d((r1 & 0x800fffffffffffffull) | (ea << 52));
+            b = as_d((r2 & 0x800fffffffffffffull) | (eb << 52));
+            if (mode == 2) b = as_d(as_u(b) | (0x000fffffffffffffull & ~((r3 >> 40) & 0xff)));
+            if (mode == 3) {
+                const double q = as_d((r1 & 0x800ffffff8000000ull) | (ea << 52));
+                b = as_d((r2 & 0x800ffffff0000000ull) | (eb << 52));
+                a = q * b;                                                             // exact: 26 x 24 bits
+            }
+        }
+        const double want = a / b;
+        const double got = pw_div_r(a, b, pw_recip_hw(b));
+        const bool same = as_u(want) == as_u(got) || (want != want && got != got);
+        if (!same) {
+            if (atomicAdd(&out[0], 1ull) == 0ull) { out[1] = as_u(a); out[2] = as_u(b); out[3] = as_u(got); }
+        }
+    }
+}
+
 // Start of a pipeline launch: the record buffer, the hand-off queue with its slots and the three work
 // counters of the launch's set, all in ONE small kernel (six hipMemsetAsync calls took 50 us of
 // stream time each -- a tenth of the step of a small batch).
@@ -657,6 +702,24 @@ struct pw_context {
     unsigned ready_at;                // the ring's device address
     std::recursive_mutex* mu;      // held by every entry point for the duration of the call (pw_host.hpp)
 };
+
+// test hook (tests/test_gpu_api.py): out4 = {pairs that differ, a, b, wrong quotient of the first}; see the kernel
+extern "C" int pw_internal_div_check(int device, unsigned long long n, int mode, unsigned long long seed, unsigned long long* out4) {
+    if (!out4 || device < 0) return PW_E_BAD_ARG;
+    int old = 0;
+    if (hipGetDevice(&old) != hipSuccess || hipSetDevice(device) != hipSuccess) return PW_E_HIP;
+    unsigned long long* d = nullptr;
+    hipError_t e = hipMalloc(&d, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(d, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pw_div_check_kernel, dim3(2048), dim3(256), 0, 0, n, mode, seed, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out4, d, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (d) (void)hipFree(d);
+    (void)hipSetDevice(old);
+    return e == hipSuccess ? PW_OK : PW_E_HIP;
+}
 
 extern "C" void pw_internal_lock(pw_context* c) { if (c && c->mu) c->mu->lock(); }
 extern "C" void pw_internal_unlock(pw_context* c) { if (c && c->mu) c->mu->unlock(); }

@@ -39,6 +39,15 @@
 #define LB_T0(var) do {} while (0)
 #define LB_T1(slot, var) do {} while (0)
 #endif
+// -DPW_PROFILE -DPW_LB_FINE: shader-clock timers of the optimiser's sub-phases in the slots the window search
+// uses otherwise (run the chains' stages only: tests/tools/profile_chains.py)
+#if defined(PW_PROFILE) && defined(PW_LB_FINE) && defined(__HIP_DEVICE_COMPILE__)
+#define LB_F0(var) long long var = clock64()
+#define LB_F1(slot, var) do { if (prof && T::lane() == 0) atomicAdd(&prof[slot], (unsigned long long)(clock64() - var)); } while (0)
+#else
+#define LB_F0(var) do {} while (0)
+#define LB_F1(slot, var) do {} while (0)
+#endif
 
 namespace pw {
 
@@ -62,6 +71,14 @@ enum LbMsg : int {
 
 constexpr int LB_M = 10;
 
+// State of the line search (dcsrch) between its calls.  It lives with the arrays, not in the optimiser object: the
+// search is entered once per function evaluation, reads all of this in one batch, and nothing else ever looks at it --
+// as members of the object these thirteen doubles were live (mostly spilled) across the whole optimiser stage.
+struct LsState {
+    double ginit, gtest, gx, gy, finit, fx, fy, stx, sty, stmin, stmax, width, width1;
+    int brackt, stage;
+};
+
 // The arrays of one optimiser instance: this block lives in team-shared memory (LDS).
 template <int N>
 struct LbMem {
@@ -78,6 +95,11 @@ struct LbMem {
     double z[N], r[N], d[N], t[N], xp[N];
     double wa[8 * M];
     double acc[2 * M];  // running dot products of the systolic triangular solves
+    // what the solves divide by, and the refined hardware reciprocal of each (pw_recip_hw): the diagonal of SY, its
+    // square root, the diagonals of the factors WT and WN.  Device teams only (tables()); rebuilt wherever the
+    // matrix is (matupd, formt, formk).
+    double dsy[M], rsy[M], sqy[M], rsq[M], rwt[M], rwn[M2], iwn[M];
+    LsState ls;
     int nbd[N];
     int index[N], iwhere[N], indx2[N];
 };
@@ -144,6 +166,171 @@ PW_NOINLINE PW_HD inline void lb_trsv_ut_wave(int n, const double* a, int lda, d
     T::wave_sync();
 }
 
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// arguments of an out-of-line function arrive in vector registers: tell the compiler which are the same in every lane
+__device__ inline int lb_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class P>
+__device__ inline P* lb_uniform(P* p) {
+    union { P* p; int i[2]; } a;
+    a.p = p;
+    a.i[0] = __builtin_amdgcn_readfirstlane(a.i[0]);
+    a.i[1] = __builtin_amdgcn_readfirstlane(a.i[1]);
+    return a.p;
+}
+// ---- one wave, everything in registers ------------------------------------------------------------------------
+// The solves below are the ones of lb_trsv_ut_wave / lb_trsv_un_wave with (a) the lane's column (row) of the
+// factor and its diagonal loaded ONCE, before the sweep, instead of two LDS round trips per step, and (b) the
+// division of a step done by every lane on its own element with the tabulated reciprocal (pw_div_r: three
+// dependent instructions, the bits of the true quotient) -- the lane whose turn it is holds the finished numerator,
+// the others compute a value nobody reads.  Same operations on every element, in the same order.
+template <class T, int NMAX>
+__device__ inline __attribute__((always_inline)) double lb_solve_ut_reg(int n, const double* a, int lda, const double* rdiag,
+                                                                       double xk) {
+    PW_ASSUME_LDS(a);
+    PW_ASSUME_LDS(rdiag);
+    const int lane = T::lane();
+    const bool act = lane < n;
+    const int li = act ? lane : 0;
+    const double* ci = a + li * lda;              // my row of U^T = column of U
+    double c[NMAX];
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) c[k] = ci[k];
+    int dli = li * (lda + 1);
+    asm volatile("" : "+v"(dli));                 // (a load of its own: not an indexed read of c[])
+    double dg = a[dli], rd = rdiag[li];
+    if (!act) { dg = 1.0; rd = 1.0; xk = 0.0; }
+    double ak = 0.0;
+#pragma unroll
+    for (int s = 0; s < NMAX; ++s) {
+        if (s >= n) continue;                     // (not a break: the trip count stays a constant, the loop unrolls)
+        const double mine = pw_div_r(xk - ak, dg, rd);
+        const double xs = T::bcast_u(mine, s);
+        xk = lane == s ? xs : xk;
+        if (NMAX > 16 && s < 16) {
+            // rows 16.. take their first 16 terms through the SIMD ddot kernel order
+            if (s == 15) {
+                double sl[4];
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    double a0 = c[l] * T::bcast_u(xk, l);
+                    double a1 = c[4 + l] * T::bcast_u(xk, 4 + l);
+                    double a2 = c[8 + l] * T::bcast_u(xk, 8 + l);
+                    double a3 = c[12 + l] * T::bcast_u(xk, 12 + l);
+                    sl[l] = ((a0 + a1) + a2) + a3;
+                }
+                const double blk = (sl[0] + sl[2]) + (sl[1] + sl[3]);
+                ak = (act && lane >= 16) ? blk : ak;
+            }
+            ak = (act && lane > s && lane < 16) ? pw_fma(xs, c[s], ak) : ak;
+        } else {
+            ak = (act && lane > s) ? pw_fma(xs, c[s], ak) : ak;
+        }
+    }
+    return xk;
+}
+template <class T, int NMAX>
+__device__ inline __attribute__((always_inline)) double lb_solve_un_reg(int n, const double* a, int lda, const double* rdiag,
+                                                                       double xk) {
+    PW_ASSUME_LDS(a);
+    PW_ASSUME_LDS(rdiag);
+    const int lane = T::lane();
+    const bool act = lane < n;
+    const int li = act ? lane : 0;
+    double rw[NMAX];                               // my row of U
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) rw[i] = a[li + i * lda];
+    int dli = li * (lda + 1);
+    asm volatile("" : "+v"(dli));
+    double dg = a[dli], rd = rdiag[li];
+    if (!act) { dg = 1.0; rd = 1.0; xk = 0.0; }
+#pragma unroll
+    for (int i = NMAX - 1; i >= 0; --i) {
+        if (i >= n) continue;
+        const double mine = pw_div_r(xk, dg, rd);
+        const double xi = T::bcast_u(mine, i);
+        xk = lane == i ? xi : xk;
+        xk = lane < i ? pw_fma(-xi, rw[i], xk) : xk;
+    }
+    return xk;
+}
+
+// bmv for one wave: lane i owns p[i] and p[col + i]; reads everything, then writes (Lbfgsb::bmv has the statement)
+template <class T, int N>
+PW_NOINLINE __device__ inline int lb_bmv_wave(LbMem<N>* m, int col, const double* v, double* p) {
+    m = lb_uniform(m); v = lb_uniform(v); p = lb_uniform(p); col = lb_uniform(col);
+    PW_ASSUME_LDS(m);
+    PW_ASSUME_LDS(v);
+    PW_ASSUME_LDS(p);
+    constexpr int M = LB_M;
+    const int lane = T::lane();
+    const bool act = lane < col;
+    const int li = act ? lane : 0;
+    {
+        const unsigned long long z = T::ballot(act && m->wt[li + M * li] == 0.0);      // dtrtrs' singularity test
+        if (z) return (int)__builtin_ctzll(z) + 1;
+    }
+    const double vi = act ? v[li] : 0.0, vc = act ? v[col + li] : 0.0;
+    // p[col + i] = v[col + i] + sum_{k < i} SY(i, k) * v[k] / SY(k, k)
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < M - 1; ++k) {
+        if (k + 1 >= col) continue;
+        const bool on = act && k < lane;
+        const double num = on ? m->sy[li + M * k] * v[k] : 0.0;
+        const double term = pw_div_r(num, m->dsy[k], m->rsy[k]);
+        sum = sum + (on ? term : 0.0);
+    }
+    double xk = lane == 0 ? vc : vc + sum;
+    xk = lb_solve_ut_reg<T, M>(col, m->wt, M, m->rwt, xk);
+    const double sq = act ? m->sqy[li] : 1.0, rs = act ? m->rsq[li] : 1.0;
+    const double pa = pw_div_r(vi, sq, rs);
+    xk = lb_solve_un_reg<T, M>(col, m->wt, M, m->rwt, xk);
+    // p[i] = -p[i] / sqrt(SY(i, i)) + sum_{k > i} SY(k, i) * p[col + k] / SY(i, i)
+    const double pi = pw_div_r(-pa, sq, rs);
+    const double dsi = act ? m->dsy[li] : 1.0, rsi = act ? m->rsy[li] : 1.0;
+    double sum2 = 0.0;
+#pragma unroll
+    for (int k = 1; k < M; ++k) {
+        if (k >= col) continue;
+        const bool on = act && k > lane;
+        const double xv = T::bcast_u(xk, k);
+        const double num = on ? m->sy[k + M * li] * xv : 0.0;
+        const double term = pw_div_r(num, dsi, rsi);
+        sum2 = sum2 + (on ? term : 0.0);
+    }
+    if (act) {
+        p[lane] = pi + sum2;
+        p[col + lane] = xk;
+    }
+    T::wave_sync();
+    return 0;
+}
+// the two solves of subsm on the factor WN (order 2 col <= 20): wv <- WN^-1 diag(-I, I) WN^-T wv
+template <class T, int N>
+PW_NOINLINE __device__ inline int lb_subsm_solves_wave(LbMem<N>* m, int col, double* wv) {
+    m = lb_uniform(m); wv = lb_uniform(wv); col = lb_uniform(col);
+    PW_ASSUME_LDS(m);
+    PW_ASSUME_LDS(wv);
+    constexpr int M2 = 2 * LB_M;
+    const int lane = T::lane();
+    const int n = 2 * col;
+    const bool act = lane < n;
+    const int li = act ? lane : 0;
+    {
+        const unsigned long long z = T::ballot(act && m->wn[li + M2 * li] == 0.0);
+        if (z) return (int)__builtin_ctzll(z) + 1;
+    }
+    double xk = act ? wv[li] : 0.0;
+    xk = lb_solve_ut_reg<T, M2>(n, m->wn, M2, m->rwn, xk);
+    xk = lane < col ? -xk : xk;
+    xk = lb_solve_un_reg<T, M2>(n, m->wn, M2, m->rwn, xk);
+    if (act) wv[lane] = xk;
+    T::wave_sync();
+    return 0;
+}
+#endif
+
 template <int N>
 struct Lbfgsb {
     static constexpr int M = LB_M;
@@ -171,11 +358,8 @@ struct Lbfgsb {
     int nintol, itfile, iback, nskip, head, col, itail, iter, iupdat, nseg, nfgv, info, ifun,
         iword, nfree, nact, ileave, nenter;
     double theta, fold, tol, dnorm, epsmch, gd, stpmx, sbgnrm, stp, gdold, dtd;
-    // line search (dcsrch) state
+    // line search (dcsrch): the rest of its state is LbMem::ls
     int ls_task;  // 0 START, 1 FG, 2 CONVERGENCE, 3 WARNING, 4 ERROR
-    bool brackt;
-    int stage;
-    double ginit, gtest, gx, gy, finit, fx, fy, stx, sty, stmin, stmax, width, width1;
 
     // ------------------------------------------------------------------
     PW_HD void bind(LbMem<N>* m) {
@@ -320,6 +504,36 @@ struct Lbfgsb {
         return 0;
     }
 
+    // ---- tables of divisors and their reciprocals (device teams; LbMem) -----
+    // which: 0 the diagonal of SY and its square root (after matupd), 1 the diagonal of WT (after formt),
+    // 2 / 3 the first / second half of the diagonal of WN (after each of formk's factorisations)
+    template <class T>
+    PW_HD void tables(int which) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_LB_OLD_SOLVES)
+        PW_ASSUME_LDS(mem);
+        if (T::WSIZE == 64) {
+            const int i = T::lane();
+            if (i < col) {
+                if (which == 0) {
+                    const double sv = SY(i, i), q = pw_sqrt(sv);
+                    mem->dsy[i] = sv; mem->rsy[i] = pw_recip_hw(sv); mem->sqy[i] = q; mem->rsq[i] = pw_recip_hw(q);
+                } else if (which == 1) {
+                    mem->rwt[i] = pw_recip_hw(WT(i, i));
+                } else if (which == 2) {
+                    const double dv = WN(i, i), rv = pw_recip_hw(dv);
+                    mem->rwn[i] = rv;
+                    mem->iwn[i] = pw_div_r(1.0, dv, rv);
+                } else {
+                    mem->rwn[col + i] = pw_recip_hw(WN(col + i, col + i));
+                }
+            }
+            T::wave_sync();
+        }
+#else
+        (void)which;
+#endif
+    }
+
     // ---- projgr: infinity norm of the projected gradient ------------------
     PW_HD void projgr() {
         PW_ASSUME_LDS(mem);
@@ -369,6 +583,15 @@ struct Lbfgsb {
     PW_HD int bmv(const double* v, double* p) {
         PW_ASSUME_LDS(mem);
         if (col == 0) return 0;
+        LB_F0(fb);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_LB_OLD_SOLVES)
+        if (T::WSIZE == 64) {
+            const int inf_w = lb_bmv_wave<T, N>(mem, col, v, p);
+            LB_F1(2, fb);
+            return inf_w;
+        }
+#endif
+        LB_F0(fa);
         for (int i = T::lane(); i < col; i += T::WSIZE) {
             if (i == 0) {
                 p[col] = v[col];
@@ -379,11 +602,17 @@ struct Lbfgsb {
             }
         }
         T::wave_sync();
+        LB_F1(3, fa);
+        LB_F0(fu);
         int inf = p_dtrtrs_u<T>(true, col, 1, wt, M, p + col, col);
+        LB_F1(4, fu);
         if (inf != 0) return inf;
         for (int i = T::lane(); i < col; i += T::WSIZE) p[i] = v[i] / pw_sqrt(SY(i, i));
+        LB_F0(fn);
         inf = p_dtrtrs_u<T>(false, col, 1, wt, M, p + col, col);
+        LB_F1(5, fn);
         if (inf != 0) return inf;
+        LB_F0(fe);
         for (int i = T::lane(); i < col; i += T::WSIZE) {
             double pi = -p[i] / pw_sqrt(SY(i, i));
             double sum = 0.0;
@@ -395,6 +624,8 @@ struct Lbfgsb {
             p[i] = pi + sum;
         }
         T::wave_sync();
+        LB_F1(6, fe);
+        LB_F1(2, fb);
         return 0;
     }
 
@@ -468,50 +699,75 @@ struct Lbfgsb {
         int col2 = 2 * col;
         double f1 = 0.0;
         double tl = 0.0, tu = 0.0;
-        for (int i = T::lane(); i < col2; i += T::WSIZE) p[i] = 0.0;
-        T::wave_sync();
+        LB_F0(fc);
+        // The classification of the variables is the same scalar code in every lane; what is spread over the lanes is
+        // p = W^T d (lane j owns p[j] and p[col + j]; the sum over the variables i stays sequential).  A wave keeps its
+        // two sums in registers and its rows of WY / WS, like the N-vectors, are read once, up front -- as LDS
+        // read-modify-writes every variable cost three dependent round trips.
+        constexpr bool WAVE = T::WSIZE == 64;
+        const int lj = T::lane();
+        const bool lon = WAVE && lj < col;
+        double wyl[N], wsl[N], pa = 0.0, pb = 0.0;
+        {
+            const int pj = (head + (lon ? lj : 0)) % M;
+            for (int i = 0; i < N; ++i) { wyl[i] = lon ? WY(pj)[i] : 0.0; wsl[i] = lon ? WS(pj)[i] : 0.0; }
+        }
+        double gl[N], xl[N], ll[N], ul[N], dl[N];
+        int nbl[N], iwl[N];
+        for (int i = 0; i < N; ++i) { gl[i] = g[i]; xl[i] = x[i]; ll[i] = l[i]; ul[i] = u[i]; nbl[i] = nbd[i]; iwl[i] = iwhere[i]; }
+        if (!WAVE) {
+            for (int i = T::lane(); i < col2; i += T::WSIZE) p[i] = 0.0;
+            T::wave_sync();
+        }
+#pragma unroll
         for (int i = 0; i < N; ++i) {
-            double neggi = -g[i];
-            if (iwhere[i] != 3 && iwhere[i] != -1) {
-                if (nbd[i] <= 2) tl = x[i] - l[i];
-                if (nbd[i] >= 2) tu = u[i] - x[i];
-                bool xlower = nbd[i] <= 2 && tl <= 0.0;
-                bool xupper = nbd[i] >= 2 && tu <= 0.0;
-                iwhere[i] = 0;
+            double neggi = -gl[i];
+            if (iwl[i] != 3 && iwl[i] != -1) {
+                if (nbl[i] <= 2) tl = xl[i] - ll[i];
+                if (nbl[i] >= 2) tu = ul[i] - xl[i];
+                bool xlower = nbl[i] <= 2 && tl <= 0.0;
+                bool xupper = nbl[i] >= 2 && tu <= 0.0;
+                iwl[i] = 0;
                 if (xlower) {
-                    if (neggi <= 0.0) iwhere[i] = 1;
+                    if (neggi <= 0.0) iwl[i] = 1;
                 } else if (xupper) {
-                    if (neggi >= 0.0) iwhere[i] = 2;
+                    if (neggi >= 0.0) iwl[i] = 2;
                 } else {
-                    if (pw_abs(neggi) <= 0.0) iwhere[i] = -3;
+                    if (pw_abs(neggi) <= 0.0) iwl[i] = -3;
                 }
             }
             int pointr = head;
-            if (iwhere[i] != 0 && iwhere[i] != -1) {
-                d[i] = 0.0;
+            if (iwl[i] != 0 && iwl[i] != -1) {
+                dl[i] = 0.0;
             } else {
-                d[i] = neggi;
+                dl[i] = neggi;
                 f1 = f1 - neggi * neggi;
-                // lane j owns p[j] and p[col + j]; the sum over the variables i stays sequential
-                for (int j = T::lane(); j < col; j += T::WSIZE) {
-                    int pj = (pointr + j) % M;
-                    p[j] = p[j] + WY(pj)[i] * neggi;
-                    p[col + j] = p[col + j] + WS(pj)[i] * neggi;
+                if (WAVE) {
+                    pa = pa + wyl[i] * neggi;
+                    pb = pb + wsl[i] * neggi;
+                } else {
+                    for (int j = T::lane(); j < col; j += T::WSIZE) {
+                        int pj = (pointr + j) % M;
+                        p[j] = p[j] + WY(pj)[i] * neggi;
+                        p[col + j] = p[col + j] + WS(pj)[i] * neggi;
+                    }
                 }
-                if (nbd[i] <= 2 && nbd[i] != 0 && neggi < 0.0) {
+                if (nbl[i] <= 2 && nbl[i] != 0 && neggi < 0.0) {
                     nbreak += 1;
                     iorder[nbreak - 1] = i;
-                    tt[nbreak - 1] = tl / (-neggi);
-                    if (nbreak == 1 || tt[nbreak - 1] < bkmin) {
-                        bkmin = tt[nbreak - 1];
+                    const double tb = tl / (-neggi);
+                    tt[nbreak - 1] = tb;
+                    if (nbreak == 1 || tb < bkmin) {
+                        bkmin = tb;
                         ibkmin = nbreak;
                     }
-                } else if (nbd[i] >= 2 && neggi > 0.0) {
+                } else if (nbl[i] >= 2 && neggi > 0.0) {
                     nbreak += 1;
                     iorder[nbreak - 1] = i;
-                    tt[nbreak - 1] = tu / neggi;
-                    if (nbreak == 1 || tt[nbreak - 1] < bkmin) {
-                        bkmin = tt[nbreak - 1];
+                    const double tb = tu / neggi;
+                    tt[nbreak - 1] = tb;
+                    if (nbreak == 1 || tb < bkmin) {
+                        bkmin = tb;
                         ibkmin = nbreak;
                     }
                 } else {
@@ -521,20 +777,33 @@ struct Lbfgsb {
                 }
             }
         }
-        T::wave_sync();
-        if (theta != 1.0)
-            for (int j = T::lane(); j < col; j += T::WSIZE) p[col + j] = theta * p[col + j];
+        for (int i = 0; i < N; ++i) { iwhere[i] = iwl[i]; d[i] = dl[i]; }
+        if (WAVE) {
+            if (lon) {
+                p[lj] = pa;
+                p[col + lj] = theta != 1.0 ? theta * pb : pb;
+            }
+            T::wave_sync();
+        } else {
+            T::wave_sync();
+            if (theta != 1.0)
+                for (int j = T::lane(); j < col; j += T::WSIZE) p[col + j] = theta * p[col + j];
+        }
         b_dcopy(N, x, xcp);
         if (nbreak == 0 && nfree_l == N + 1) { T::wave_sync(); return 0; }
         for (int j = T::lane(); j < col2; j += T::WSIZE) c[j] = 0.0;
         T::wave_sync();
         double f2 = -theta * f1;
         double f2_org = f2;
+        LB_F1(7, fc);
         if (col > 0) {
             int inf = bmv<T>(p, v);
             if (inf != 0) return inf;
+            LB_F0(fd);
             f2 = f2 - b_ddot(col2, v, p);
+            LB_F1(15, fd);
         }
+        LB_F0(fz);
         double dtm = -f1 / f2;
         double tsum = 0.0;
         nseg = 1;
@@ -629,6 +898,7 @@ struct Lbfgsb {
             for (int j = T::lane(); j < col2; j += T::WSIZE) c[j] = pw_fma(dtm, p[j], c[j]);
         }
         T::wave_sync();
+        LB_F1(14, fz);
         return 0;
     }
 
@@ -673,6 +943,7 @@ struct Lbfgsb {
     PW_HD int formk() {
         PW_ASSUME_LDS(mem);
         const int nsub = nfree;
+        LB_F0(fk1);
         if (updatd) {
             if (iupdat > M) {
                 // shift the old part of WN1 up-left by one: every target reads a cell of the
@@ -808,10 +1079,17 @@ struct Lbfgsb {
             else WN(jy, is) = WN1(is1, jy);
         }
         T::wave_sync();
+        LB_F1(8, fk1);
+        LB_F0(fk2);
         int inf = p_dpotrf_u<T>(col, wn, M2);
+        LB_F1(9, fk2);
         if (inf != 0) return -1;
+        tables<T>(2);
         int col2 = 2 * col;
+        LB_F0(fk3);
         inf = p_dtrtrs_u<T>(true, col, col, wn, M2, &WN(0, col), M2);
+        LB_F1(10, fk3);
+        LB_F0(fk4);
         for (int e = T::lane(); e < col * col; e += T::WSIZE) {
             int is = col + e / col, js = col + e % col;
             if (js < is) continue;
@@ -819,8 +1097,10 @@ struct Lbfgsb {
         }
         T::wave_sync();
         inf = p_dpotrf_u<T>(col, &WN(col, col), M2);
+        LB_F1(11, fk4);
         (void)col2;
         if (inf != 0) return -2;
+        tables<T>(3);
         return 0;
     }
 
@@ -838,16 +1118,48 @@ struct Lbfgsb {
             T::wave_sync();
             int inf = bmv<T>(wa + 2 * M, wa);
             if (inf != 0) return -8;
-            int pointr = head;
-            for (int j = 0; j < col; ++j) {
-                double a1 = wa[j];
-                double a2 = theta * wa[col + j];
-                for (int i = 0; i < nfree; ++i) {
-                    int k = index[i];
-                    r[i] = r[i] + WY(pointr)[k] * a1 + WS(pointr)[k] * a2;
+            LB_F0(fr);
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (T::WSIZE == 64) {
+                // lane j forms the products of correction pair j, every lane then adds them to its copy of r in
+                // the reference's order (v_readlane); r is read and written once
+                const int lj = T::lane();
+                const bool lon = lj < col;
+                const int pj = (head + (lon ? lj : 0)) % M;
+                const double a1 = lon ? wa[lj] : 0.0, a2 = lon ? theta * wa[col + lj] : 0.0;
+                double t1[N], t2[N], rl[N];
+                for (int i = 0; i < N; ++i) {
+                    const int k = i < nfree ? index[i] : 0;
+                    t1[i] = WY(pj)[k] * a1;
+                    t2[i] = WS(pj)[k] * a2;
+                    rl[i] = r[i];
                 }
-                pointr = (pointr + 1) % M;
+#pragma unroll
+                for (int jj = 0; jj < M; ++jj) {
+                    if (jj >= col) continue;
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                        if (i < nfree) rl[i] = rl[i] + T::bcast_u(t1[i], jj) + T::bcast_u(t2[i], jj);
+                }
+                T::wave_sync();
+                for (int i = 0; i < N; ++i)
+                    if (i < nfree) r[i] = rl[i];
+                T::wave_sync();
+            } else
+#endif
+            {
+                int pointr = head;
+                for (int j = 0; j < col; ++j) {
+                    double a1 = wa[j];
+                    double a2 = theta * wa[col + j];
+                    for (int i = 0; i < nfree; ++i) {
+                        int k = index[i];
+                        r[i] = r[i] + WY(pointr)[k] * a1 + WS(pointr)[k] * a2;
+                    }
+                    pointr = (pointr + 1) % M;
+                }
             }
+            LB_F1(13, fr);
         }
         return 0;
     }
@@ -875,11 +1187,21 @@ struct Lbfgsb {
         }
         T::wave_sync();
         int col2 = 2 * col;
-        int inf = p_dtrtrs_u<T>(true, col2, 1, wn, M2, wv, col2);
-        if (inf != 0) return inf;
-        for (int i = T::lane(); i < col; i += T::WSIZE) wv[i] = -wv[i];
-        T::wave_sync();
-        inf = p_dtrtrs_u<T>(false, col2, 1, wn, M2, wv, col2);
+        LB_F0(fs1);
+        int inf;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_LB_OLD_SOLVES)
+        if (T::WSIZE == 64) {
+            inf = lb_subsm_solves_wave<T, N>(mem, col, wv);
+        } else
+#endif
+        {
+            inf = p_dtrtrs_u<T>(true, col2, 1, wn, M2, wv, col2);
+            if (inf != 0) return inf;
+            for (int i = T::lane(); i < col; i += T::WSIZE) wv[i] = -wv[i];
+            T::wave_sync();
+            inf = p_dtrtrs_u<T>(false, col2, 1, wn, M2, wv, col2);
+        }
+        LB_F1(12, fs1);
         if (inf != 0) return inf;
 #ifdef PW_NO_SPREAD_SUBSM
         if (false) {
@@ -988,7 +1310,7 @@ struct Lbfgsb {
 
     // ---- dcstep (More'-Thuente safeguarded step) -----------------------------------
     PW_HD static void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy,
-                             double& dy, double& stp, double fp, double dp, bool& brackt,
+                             double& dy, double& stp, double fp, double dp, int& brackt,
                              double stpmin, double stpmax) {
         double gamma, p, q, rr, s, sgnd, stpc, stpf, stpq, th;
         sgnd = dp * (dx / pw_abs(dx));
@@ -1073,63 +1395,67 @@ struct Lbfgsb {
         PW_ASSUME_LDS(mem);
         const double p5 = 0.5, p66 = 0.66, xtrapl = 1.1, xtrapu = 4.0;
         if (ls_task == 0) {
+            LsState L;
             if (st < stpmin) ls_task = 4;
             if (st > stpmax) ls_task = 4;
             if (gv >= 0.0) ls_task = 4;
             if (ls_task == 4) return;
-            brackt = false;
-            stage = 1;
-            finit = fv;
-            ginit = gv;
-            gtest = ftol * ginit;
-            width = stpmax - stpmin;
-            width1 = width / p5;
-            stx = 0.0; fx = finit; gx = ginit;
-            sty = 0.0; fy = finit; gy = ginit;
-            stmin = 0.0;
-            stmax = st + xtrapu * st;
+            L.brackt = 0;
+            L.stage = 1;
+            L.finit = fv;
+            L.ginit = gv;
+            L.gtest = ftol * L.ginit;
+            L.width = stpmax - stpmin;
+            L.width1 = L.width / p5;
+            L.stx = 0.0; L.fx = L.finit; L.gx = L.ginit;
+            L.sty = 0.0; L.fy = L.finit; L.gy = L.ginit;
+            L.stmin = 0.0;
+            L.stmax = st + xtrapu * st;
+            mem->ls = L;
             ls_task = 1;
             return;
         }
-        double ftest = finit + st * gtest;
-        if (stage == 1 && fv <= ftest && gv >= 0.0) stage = 2;
-        if (brackt && (st <= stmin || st >= stmax)) ls_task = 3;
-        if (brackt && stmax - stmin <= xtol * stmax) ls_task = 3;
-        if (st == stpmax && fv <= ftest && gv <= gtest) ls_task = 3;
-        if (st == stpmin && (fv > ftest || gv >= gtest)) ls_task = 3;
-        if (fv <= ftest && pw_abs(gv) <= gtol * (-ginit)) ls_task = 2;
-        if (ls_task == 3 || ls_task == 2) return;
-        if (stage == 1 && fv <= fx && fv > ftest) {
-            double fm = fv - st * gtest;
-            double fxm = fx - stx * gtest;
-            double fym = fy - sty * gtest;
-            double gm = gv - gtest;
-            double gxm = gx - gtest;
-            double gym = gy - gtest;
-            dcstep(stx, fxm, gxm, sty, fym, gym, st, fm, gm, brackt, stmin, stmax);
-            fx = fxm + stx * gtest;
-            fy = fym + sty * gtest;
-            gx = gxm + gtest;
-            gy = gym + gtest;
+        LsState L = mem->ls;
+        double ftest = L.finit + st * L.gtest;
+        if (L.stage == 1 && fv <= ftest && gv >= 0.0) L.stage = 2;
+        if (L.brackt && (st <= L.stmin || st >= L.stmax)) ls_task = 3;
+        if (L.brackt && L.stmax - L.stmin <= xtol * L.stmax) ls_task = 3;
+        if (st == stpmax && fv <= ftest && gv <= L.gtest) ls_task = 3;
+        if (st == stpmin && (fv > ftest || gv >= L.gtest)) ls_task = 3;
+        if (fv <= ftest && pw_abs(gv) <= gtol * (-L.ginit)) ls_task = 2;
+        if (ls_task == 3 || ls_task == 2) { mem->ls.stage = L.stage; return; }
+        if (L.stage == 1 && fv <= L.fx && fv > ftest) {
+            double fm = fv - st * L.gtest;
+            double fxm = L.fx - L.stx * L.gtest;
+            double fym = L.fy - L.sty * L.gtest;
+            double gm = gv - L.gtest;
+            double gxm = L.gx - L.gtest;
+            double gym = L.gy - L.gtest;
+            dcstep(L.stx, fxm, gxm, L.sty, fym, gym, st, fm, gm, L.brackt, L.stmin, L.stmax);
+            L.fx = fxm + L.stx * L.gtest;
+            L.fy = fym + L.sty * L.gtest;
+            L.gx = gxm + L.gtest;
+            L.gy = gym + L.gtest;
         } else {
-            dcstep(stx, fx, gx, sty, fy, gy, st, fv, gv, brackt, stmin, stmax);
+            dcstep(L.stx, L.fx, L.gx, L.sty, L.fy, L.gy, st, fv, gv, L.brackt, L.stmin, L.stmax);
         }
-        if (brackt) {
-            if (pw_abs(sty - stx) >= p66 * width1) st = stx + p5 * (sty - stx);
-            width1 = width;
-            width = pw_abs(sty - stx);
+        if (L.brackt) {
+            if (pw_abs(L.sty - L.stx) >= p66 * L.width1) st = L.stx + p5 * (L.sty - L.stx);
+            L.width1 = L.width;
+            L.width = pw_abs(L.sty - L.stx);
         }
-        if (brackt) {
-            stmin = pw_min(stx, sty);
-            stmax = pw_max(stx, sty);
+        if (L.brackt) {
+            L.stmin = pw_min(L.stx, L.sty);
+            L.stmax = pw_max(L.stx, L.sty);
         } else {
-            stmin = st + xtrapl * (st - stx);
-            stmax = st + xtrapu * (st - stx);
+            L.stmin = st + xtrapl * (st - L.stx);
+            L.stmax = st + xtrapu * (st - L.stx);
         }
         st = pw_max(st, stpmin);
         st = pw_min(st, stpmax);
-        if ((brackt && (st <= stmin || st >= stmax)) || (brackt && stmax - stmin <= xtol * stmax))
-            st = stx;
+        if ((L.brackt && (st <= L.stmin || st >= L.stmax)) || (L.brackt && L.stmax - L.stmin <= xtol * L.stmax))
+            st = L.stx;
+        mem->ls = L;
         ls_task = 1;
     }
 
@@ -1181,7 +1507,9 @@ struct Lbfgsb {
                 return false;
             }
         }
+        LB_F0(fl);
         dcsrch(f, gd, stp, ftol, gtol, xtol, 0.0, stpmx);
+        LB_F1(23, fl);
         if (ls_task != 2 && ls_task != 3) {
             task = LB_FG;
             msg = LBM_FG_LNSRCH;
@@ -1260,6 +1588,7 @@ struct Lbfgsb {
             SY(col - 1, col - 1) = dr;
         }
         T::wave_sync();
+        tables<T>(0);
     }
 
     // ---- formt -------------------------------------------------------------------------------
@@ -1280,6 +1609,7 @@ struct Lbfgsb {
         T::wave_sync();
         int inf = p_dpotrf_u<T>(col, wt, M);
         if (inf != 0) return -3;
+        tables<T>(1);
         return 0;
     }
 

@@ -37,6 +37,7 @@ struct HostTeam {
     PW_HD static double bcast_u(double v, int /*uniform_src_lane*/) { return v; }
     PW_HD static int bcast_i(int v, int /*src_lane*/) { return v; }
     PW_HD static int shfl_up_i(int v, int /*delta*/) { return v; }
+    PW_HD static int uniform_i(int v) { return v; }
 };
 
 #if defined(__HIPCC__)
@@ -149,6 +150,8 @@ struct DeviceTeam {
     __device__ static double bcast_u(double v, int src) { return lane_d(v, __builtin_amdgcn_readfirstlane(src)); }
     __device__ static int bcast_i(int v, int src) { return __shfl(v, src, 64); }
     __device__ static int shfl_up_i(int v, int delta) { return __shfl_up(v, delta, 64); }
+    // a value every lane of the wave holds alike, as the scalar it is (loop bounds and branches on it are scalar)
+    __device__ static int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
     // inclusive prefix sum over the lanes of the wave: four row_shr steps inside every row of 16 lanes (a lane
     // without a source adds 0), then the totals of the rows below by v_readlane
     __device__ static int incl_scan_i(int v) {

@@ -484,8 +484,43 @@ PW_HD inline void wave_gap4(const Frame& F, int n, const double* px, const doubl
         double qz = g == 0 ? pz[0] : (g == 1 ? pz[1] : (g == 2 ? pz[2] : pz[3]));
         double pp = sq3(qx, qy, qz);
         double best = PW_INF;
+        const auto& C = *F.cls;
+        const int kk = T::uniform_i(C.k);
+        if (kk > 0) {
+            // Atoms are stored by radius group (load_unit): per group the minimum of the squared-distance terms,
+            // THEN |p|^2, the root and the radius -- one root per group and lane instead of one per atom, the same
+            // bits (rounding is monotone; point_gap_value has the argument).  The rounds -- sixteen atoms of one
+            // group each, a lane past the end repeats the group's last atom, which a minimum does not notice -- are
+            // taken two at a time (eight LDS reads in flight).  (A software pipeline over single rounds, the reads of
+            // round r + 1 issued before round r is reduced, was measured 45 % slower: its scalar control flow.)
+            for (int c = 0; c < kk; ++c) {
+                const int lo = T::uniform_i(C.off[c]), hi = T::uniform_i(C.off[c + 1]);
+                double m2 = PW_INF;
+                int base = lo;
+                for (; base + 16 < hi; base += 32) {
+                    int i0 = base + l, i1 = base + 16 + l;
+                    i1 = i1 < hi ? i1 : hi - 1;
+                    const double x0 = F.x[i0], y0 = F.y[i0], z0 = F.z[i0], s0 = F.xx[i0];
+                    const double x1 = F.x[i1], y1 = F.y[i1], z1 = F.z[i1], s1 = F.xx[i1];
+                    const double g0 = pw_fma(z0, qz, pw_fma(x0, qx, y0 * qy));
+                    const double g1 = pw_fma(z1, qz, pw_fma(x1, qx, y1 * qy));
+                    m2 = __builtin_fmin(m2, pw_m2add(g0, s0));
+                    m2 = __builtin_fmin(m2, pw_m2add(g1, s1));
+                }
+                if (base < hi) {
+                    int i0 = base + l;
+                    i0 = i0 < hi ? i0 : hi - 1;
+                    const double gg = pw_fma(F.z[i0], qz, pw_fma(F.x[i0], qx, F.y[i0] * qy));
+                    m2 = __builtin_fmin(m2, pw_m2add(gg, F.xx[i0]));
+                }
+                m2 = m2 + pp;
+                const double d = pw_sqrt(m2 > 0.0 ? m2 : 0.0);
+                best = __builtin_fmin(best, d - C.vdw[c]);
+            }
+        } else {
 #pragma unroll 4
-        for (int i = l; i < n; i += 16) best = __builtin_fmin(best, gap_atom(F, i, qx, qy, qz, pp));
+            for (int i = l; i < n; i += 16) best = __builtin_fmin(best, gap_atom(F, i, qx, qy, qz, pp));
+        }
         T::row_min4(best, out);
     } else {
         for (int q = 0; q < 4; ++q) out[q] = wave_gap<T>(F, n, px[q], py[q], pz[q], nullptr);
@@ -1651,6 +1686,7 @@ PW_HD inline __attribute__((always_inline)) void stage_opt_impl(UnitShared& sh, 
     (void)ws;
     auto& v = *sh.v;
     if (T::wave() == 0) {
+        const Frame A = sh.A;                // (a copy: `sh` itself is behind a generic pointer, re-read after every store)
         Lbfgsb<3> opt;                       // scalars in registers, arrays in LDS
         Lbfgsb<3>* S = &opt;
         LbMem<3>* Smem = (LbMem<3>*)sh.lb[0];
@@ -1661,7 +1697,7 @@ PW_HD inline __attribute__((always_inline)) void stage_opt_impl(UnitShared& sh, 
         for (int c = 0; c < 3; ++c) x0[c] = (prm.opt_flags & PW_OPT_CUSTOM_START) ? prm.opt_x0[c] : v.com[c];
         // user-supplied start: the default box is built around it (utilities.py:412-421)
         if ((prm.opt_flags & PW_OPT_CUSTOM_START) && !(prm.opt_flags & PW_OPT_CUSTOM_BOUNDS))
-            r = wave_gap<T>(sh.A, n, x0[0], x0[1], x0[2], nullptr);
+            r = wave_gap<T>(A, n, x0[0], x0[1], x0[2], nullptr);
         bool bad;
         if (prm.opt_flags & PW_OPT_CUSTOM_BOUNDS) {
             bad = false;
@@ -1710,7 +1746,13 @@ PW_HD inline __attribute__((always_inline)) void stage_opt_impl(UnitShared& sh, 
                             if (c == 0) qx[1] = x1; else if (c == 1) qy[2] = x1; else qz[3] = x1;
                         }
                         double gv[4];
-                        wave_gap4<T>(sh.A, n, qx, qy, qz, gv);
+#if defined(PW_PROFILE) && defined(PW_LB_FINE)
+                        long long t_g4 = clock64();
+#endif
+                        wave_gap4<T>(A, n, qx, qy, qz, gv);
+#if defined(PW_PROFILE) && defined(PW_LB_FINE)
+                        if (T::lane() == 0) atomicAdd((unsigned long long*)&ws->prof[24], (unsigned long long)(clock64() - t_g4));
+#endif
                         double f0 = -(gv[0] * 2.0);
                         for (int c = 0; c < 3; ++c) {
                             double f1 = -(gv[c + 1] * 2.0);
@@ -1738,7 +1780,7 @@ PW_HD inline __attribute__((always_inline)) void stage_opt_impl(UnitShared& sh, 
         double cx = v.com[0], cy = v.com[1], cz = v.com[2];
         if (!bad) { cx = S->x[0]; cy = S->x[1]; cz = S->x[2]; }
         int arg;
-        double g = wave_gap<T>(sh.A, n, cx, cy, cz, &arg);
+        double g = wave_gap<T>(A, n, cx, cy, cz, &arg);
         if (T::lane() == 0) {
             v.opt_c[0] = cx; v.opt_c[1] = cy; v.opt_c[2] = cz;
             v.opt_g = g;

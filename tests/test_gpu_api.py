@@ -326,3 +326,22 @@ def test_streamed_batch_equals_the_uploaded_one(tmp_path):
     finally:
         trajectory.STREAM_MIN = old
     assert streamed.tobytes() == plain.tobytes() and (streamed["n_windows"] == 4).all()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_division_by_a_tabulated_reciprocal_has_the_bits_of_the_division(mode):
+    """pw_div_r(a, b, pw_recip_hw(b)) (pw_common.hpp: the solves of the optimisers divide by the same diagonal at every
+    step) against a / b on the device, 2^26 operand pairs per class: ordinary magnitudes, arbitrary bit patterns
+    (denormals, infinities, NaNs, signed zeros), divisors with an all-ones significand, exact quotients."""
+    import ctypes
+
+    from pywindow_amd import _lib
+
+    L = _lib.load()
+    L.pw_internal_div_check.argtypes = [ctypes.c_int, ctypes.c_ulonglong, ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p]
+    L.pw_internal_div_check.restype = ctypes.c_int
+    out = (ctypes.c_ulonglong * 4)()
+    assert L.pw_internal_div_check(0, 1 << 26, mode, 20260000 + mode, out) == 0
+    bad = list(out)
+    a, b, got = (np.array(bad[1:], dtype=np.uint64).view(np.float64))
+    assert bad[0] == 0, f"{bad[0]} quotients differ; first: {a!r} / {b!r} gave {got!r}, want {a / b!r}"
