@@ -100,6 +100,7 @@ struct LbMem {
     // matrix is (matupd, formt, formk).
     double dsy[M], rsy[M], sqy[M], rsq[M], rwt[M], rwn[M2], iwn[M];
     LsState ls;
+    int cand[32];       // atoms that can hold the minimum near the current reference point (pw_unit.hpp: NearGap4)
     int nbd[N];
     int index[N], iwhere[N], indx2[N];
 };

@@ -527,6 +527,153 @@ PW_HD inline void wave_gap4(const Frame& F, int n, const double* px, const doubl
     }
 }
 
+// ---- the four-point objective near a reference point ----------------------------------------------------------
+// An optimiser asks for its objective some ninety times per unit, at points that lie within a few tenths of an
+// angstrom of each other, and min_i(|p - a_i| - r_i) is 1-Lipschitz in p for every atom: an atom whose gap at a
+// reference point R exceeds the minimum there by more than 2 delta cannot hold the minimum anywhere within delta of
+// R.  rebuild() evaluates every atom at R once (all lanes), lists the atoms within 2 delta + a margin of the minimum
+// (the margin, 1e-6, is a million times the rounding error of a gap) and hands each lane of a row its share of the
+// list; eval() then takes the minimum over the list only -- one or two atoms per lane instead of eleven -- while the
+// four points stay within delta (1-norm, so also 2-norm) of R, and rebuilds around the new point when they do not.
+// The value is the minimum of the same per-atom expressions, so it has the bits of wave_gap4 (every atom, one root
+// per radius group: the same bits again, see there).  More than 32 candidates: no list, wave_gap4 itself.
+#if defined(__HIP_DEVICE_COMPILE__)
+struct NearList4 { int c0, c1, total; };
+struct NearList1 { int mine, total; };
+// every atom at the reference point (all 64 lanes), the atoms within `slack` of the minimum listed in `cand` (up to
+// 32); a lane's share of the list for the row layout of wave_gap4: positions l and l + 16 of its row-local number l
+template <class T>
+PW_NOINLINE __device__ inline NearList4 near_rebuild4(Frame F, int n, PW_LDS int* cand, double px, double py, double pz,
+                                                      double slack) {
+    const int lane = T::lane();
+    const double pp = sq3(px, py, pz);
+    double best = PW_INF;
+    for (int i = lane; i < n; i += 64) best = __builtin_fmin(best, gap_atom(F, i, px, py, pz, pp));
+    best = T::wave_min(best);
+    const double lim = best + slack;
+    int total = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool in = i < n && gap_atom(F, i < n ? i : 0, px, py, pz, pp) <= lim;
+        const unsigned long long m = T::ballot(in);
+        const int at = total + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (in && at < 32) cand[at] = i;
+        total += (int)__builtin_popcountll(m);
+    }
+    T::wave_sync();
+    NearList4 r;
+    r.c0 = r.c1 = -1;
+    r.total = total;
+    const int l = lane & 15;
+    if (total <= 32) {
+        if (l < total) r.c0 = cand[l];
+        if (l + 16 < total) r.c1 = cand[l + 16];
+    }
+    T::wave_sync();
+    return r;
+}
+// the same for one point and 64 lanes: lane k keeps the k-th listed atom (no list in memory: the lane finds the
+// k-th set bit of the ballots itself)
+template <class T>
+PW_NOINLINE __device__ inline NearList1 near_rebuild1(Frame F, int n, double px, double py, double pz, double slack) {
+    const int lane = T::lane();
+    const double pp = sq3(px, py, pz);
+    double best = PW_INF;
+    for (int i = lane; i < n; i += 64) best = __builtin_fmin(best, gap_atom(F, i, px, py, pz, pp));
+    best = T::wave_min(best);
+    const double lim = best + slack;
+    NearList1 r;
+    r.mine = -1;
+    int total = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool in = i < n && gap_atom(F, i < n ? i : 0, px, py, pz, pp) <= lim;
+        const unsigned long long m = T::ballot(in);
+        const int cnt = (int)__builtin_popcountll(m);
+        const int want = lane - total;
+        if (want >= 0 && want < cnt) {
+            unsigned long long mm = m;
+            for (int k = 0; k < want; ++k) mm &= mm - 1ull;
+            r.mine = i0 + (int)__builtin_ctzll(mm);
+        }
+        total += cnt;
+    }
+    r.total = total;
+    return r;
+}
+template <class T>
+struct NearGap4 {
+    static constexpr double DELTA = 0.3, MARGIN = 1e-6;
+    double rx, ry, rz;      // reference point
+    int c0, c1;             // this lane's candidates (stored positions), -1: none
+    int state;              // 0 no reference yet, 1 list in use, 2 too many candidates around the reference
+
+    __device__ void init() { rx = ry = rz = 0.0; c0 = c1 = -1; state = 0; }
+
+    __device__ void rebuild(const Frame& F, int n, PW_LDS int* cand, double px, double py, double pz) {
+        const NearList4 r = near_rebuild4<T>(F, n, cand, px, py, pz, 2.0 * DELTA + MARGIN);
+        rx = px; ry = py; rz = pz;
+        c0 = r.c0; c1 = r.c1;
+        state = r.total <= 32 ? 1 : 2;
+    }
+
+    __device__ void eval(const Frame& F, int n, PW_LDS int* cand, const double* px, const double* py, const double* pz,
+                         double* out) {
+        const int g = T::lane() >> 4;
+        const double qx = g == 0 ? px[0] : (g == 1 ? px[1] : (g == 2 ? px[2] : px[3]));
+        const double qy = g == 0 ? py[0] : (g == 1 ? py[1] : (g == 2 ? py[2] : py[3]));
+        const double qz = g == 0 ? pz[0] : (g == 1 ? pz[1] : (g == 2 ? pz[2] : pz[3]));
+        const bool near = pw_abs(qx - rx) + pw_abs(qy - ry) + pw_abs(qz - rz) <= DELTA;
+        if (state == 0 || !T::wave_all(near)) rebuild(F, n, cand, px[0], py[0], pz[0]);
+        // (the three difference points lie 1e-8 from the first: within delta of a reference that was just moved there;
+        // if they do not -- a huge relative step -- the list is not used)
+        const bool near2 = pw_abs(qx - rx) + pw_abs(qy - ry) + pw_abs(qz - rz) <= DELTA;
+        if (state != 1 || !T::wave_all(near2)) {
+            wave_gap4<T>(F, n, px, py, pz, out);
+            return;
+        }
+        const double pp = sq3(qx, qy, qz);
+        const int i0 = c0 < 0 ? 0 : c0, i1 = c1 < 0 ? 0 : c1;
+        const double x0 = F.x[i0], y0 = F.y[i0], z0 = F.z[i0], s0 = F.xx[i0], r0 = F.vdw[i0];
+        const double x1 = F.x[i1], y1 = F.y[i1], z1 = F.z[i1], s1 = F.xx[i1], r1 = F.vdw[i1];
+        const double g0 = pw_fma(z0, qz, pw_fma(x0, qx, y0 * qy));
+        const double g1 = pw_fma(z1, qz, pw_fma(x1, qx, y1 * qy));
+        const double d0 = pw_m2add(g0, s0) + pp, d1 = pw_m2add(g1, s1) + pp;
+        const double v0 = pw_sqrt(d0 > 0.0 ? d0 : 0.0) - r0, v1 = pw_sqrt(d1 > 0.0 ? d1 : 0.0) - r1;
+        double best = c0 < 0 ? PW_INF : v0;
+        best = c1 < 0 ? best : __builtin_fmin(best, v1);
+        T::row_min4(best, out);
+    }
+};
+// One point at a time (the simplex search in a window's plane): up to 64 candidates, one per lane.
+template <class T>
+struct NearGap1 {
+    static constexpr double DELTA = 0.3, MARGIN = 1e-6;
+    double rx, ry, rz;
+    int c;                  // this lane's candidate, -1: none
+    int state;              // 0 no reference yet, 1 list in use, 2 too many candidates
+
+    __device__ void init() { rx = ry = rz = 0.0; c = -1; state = 0; }
+
+    __device__ void rebuild(const Frame& F, int n, PW_LDS int* cand, double px, double py, double pz) {
+        (void)cand;
+        const NearList1 r = near_rebuild1<T>(F, n, px, py, pz, 2.0 * DELTA + MARGIN);
+        rx = px; ry = py; rz = pz;
+        c = r.total <= 64 ? r.mine : -1;
+        state = r.total <= 64 ? 1 : 2;
+    }
+
+    __device__ double eval(const Frame& F, int n, PW_LDS int* cand, double px, double py, double pz) {
+        const bool near = pw_abs(px - rx) + pw_abs(py - ry) + pw_abs(pz - rz) <= DELTA;
+        if (state == 0 || !T::wave_all(near)) rebuild(F, n, cand, px, py, pz);
+        if (state != 1) return wave_gap_value<T>(F, n, px, py, pz);
+        const int i = c < 0 ? 0 : c;
+        const double v = gap_atom(F, i, px, py, pz, sq3(px, py, pz));
+        return T::wave_min(c < 0 ? PW_INF : v);
+    }
+};
+#endif
+
 // numpy's float64 add.reduce over a contiguous 1-D array: pairwise blocks of
 // <= 128 with 8 accumulators, halves split at multiples of 8, and the outer
 // iterator feeding 8192-element buffers sequentially.
@@ -1720,6 +1867,10 @@ PW_HD inline __attribute__((always_inline)) void stage_opt_impl(UnitShared& sh, 
         int nit = 0, nfev = 0;
         bool have_last = false;
         double lx = 0.0, ly = 0.0, lz = 0.0, lf = 0.0, lg[3] = {0.0, 0.0, 0.0};
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_NEAR_GAP)
+        NearGap4<T> near_gap;
+        near_gap.init();
+#endif
         if (!bad) {
             S->template setup<T>(Smem, x0, lo, up, nbd, 1e7, 1e-5, 20);
 #ifdef PW_PROFILE
@@ -1748,6 +1899,10 @@ PW_HD inline __attribute__((always_inline)) void stage_opt_impl(UnitShared& sh, 
                         double gv[4];
 #if defined(PW_PROFILE) && defined(PW_LB_FINE)
                         long long t_g4 = clock64();
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_NEAR_GAP)
+                        if (T::WSIZE == 64) near_gap.eval(A, n, (PW_LDS int*)Smem->cand, qx, qy, qz, gv);
+                        else
 #endif
                         wave_gap4<T>(A, n, qx, qy, qz, gv);
 #if defined(PW_PROFILE) && defined(PW_LB_FINE)
@@ -1952,10 +2107,21 @@ PW_NOINLINE PW_HD inline void wave_fmin_xy(const Frame& F, int n, double z, doub
     // placed in scratch (global) memory on the GPU
     double x0s, y0s, f0s, x1s, y1s, f1s, x2s, y2s, f2s;
     int fcalls = 0;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_NEAR_GAP)
+    NearGap1<T> near_gap;
+    near_gap.init();
+    const Frame Fl = F;          // (by value: `F` is behind a generic pointer)
+    auto fun = [&](double x, double y) {
+        fcalls += 1;
+        if (T::WSIZE == 64) return -(near_gap.eval(Fl, n, nullptr, x, y, z) * 2.0);
+        return -(wave_gap_value<T>(Fl, n, x, y, z) * 2.0);
+    };
+#else
     auto fun = [&](double x, double y) {
         fcalls += 1;
         return -(wave_gap_value<T>(F, n, x, y, z) * 2.0);
     };
+#endif
     x0s = x0; y0s = y0;
     x1s = (x0 != 0.0) ? (1.0 + 0.05) * x0 : 0.00025; y1s = y0;
     x2s = x0; y2s = (y0 != 0.0) ? (1.0 + 0.05) * y0 : 0.00025;
@@ -2173,6 +2339,10 @@ PW_NOINLINE PW_HD inline void wave_window(const Frame& FS, const Frame& R, PW_LD
             int nit = 0;
             bool have_last = false;
             double lz = 0.0, lf = 0.0, lg = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_NEAR_GAP)
+            NearGap4<T> near_gap;       // (its list lives in the optimiser block that setup() just cleared)
+            near_gap.init();
+#endif
             for (;;) {
                 PW_T0(t_zs);
                 S->template step<T>();
@@ -2186,6 +2356,10 @@ PW_NOINLINE PW_HD inline void wave_window(const Frame& FS, const Frame& R, PW_LD
                         double z1 = zc + h;
                         double dz = z1 - zc;
                         double zx[4] = {xo, xo, xo, xo}, zy[4] = {yo, yo, yo, yo}, zz[4] = {zc, z1, zc, z1}, gv[4];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_NEAR_GAP)
+                        if (T::WSIZE == 64) near_gap.eval(R, n, (PW_LDS int*)Smem->cand, zx, zy, zz, gv);
+                        else
+#endif
                         wave_gap4<T>(R, n, zx, zy, zz, gv);
                         double f0 = gv[0] * 2.0;
                         double f1 = gv[1] * 2.0;
