@@ -95,6 +95,17 @@ PW_HD inline double pw_recip_hw(double b) {
     return 1.0;
 #endif
 }
+// the three instructions alone: for callers that check afterwards that every dividend was plain and non-zero (and
+// repeat the computation with pw_div_r if one was not)
+PW_HD inline double pw_div_ru(double a, double b, double r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double q = a * r;
+    return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+#else
+    (void)r;
+    return a / b;
+#endif
+}
 PW_HD inline double pw_div_r(double a, double b, double r) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const double q = a * r;

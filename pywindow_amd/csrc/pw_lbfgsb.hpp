@@ -169,6 +169,9 @@ PW_NOINLINE PW_HD inline void lb_trsv_ut_wave(int n, const double* a, int lda, d
 
 
 #if defined(__HIP_DEVICE_COMPILE__)
+// the out-of-line wave routines below ask a team for its lane number, lane-to-lane moves and the wave-level ordering
+// of LDS traffic only -- the same for every team of whole waves, so they are instantiated once, for this one
+typedef DeviceTeam<1> LbWave;
 // arguments of an out-of-line function arrive in vector registers: tell the compiler which are the same in every lane
 __device__ inline int lb_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 template <class P>
@@ -185,9 +188,12 @@ __device__ inline P* lb_uniform(P* p) {
 // division of a step done by every lane on its own element with the tabulated reciprocal (pw_div_r: three
 // dependent instructions, the bits of the true quotient) -- the lane whose turn it is holds the finished numerator,
 // the others compute a value nobody reads.  Same operations on every element, in the same order.
-template <class T, int NMAX>
+// SPEC: the divisions without their guard (pw_div_ru); *tnum receives the lane's own dividend, which the caller
+// checks afterwards (lb_plain) -- if any was zero or outside the plain range the caller repeats the whole computation
+// with SPEC = false, where every division is guarded.
+template <class T, int NMAX, bool SPEC>
 __device__ inline __attribute__((always_inline)) double lb_solve_ut_reg(int n, const double* a, int lda, const double* rdiag,
-                                                                       double xk) {
+                                                                       double xk, double* tnum) {
     PW_ASSUME_LDS(a);
     PW_ASSUME_LDS(rdiag);
     const int lane = T::lane();
@@ -201,11 +207,12 @@ __device__ inline __attribute__((always_inline)) double lb_solve_ut_reg(int n, c
     asm volatile("" : "+v"(dli));                 // (a load of its own: not an indexed read of c[])
     double dg = a[dli], rd = rdiag[li];
     if (!act) { dg = 1.0; rd = 1.0; xk = 0.0; }
+    const double x0 = xk;
     double ak = 0.0;
 #pragma unroll
     for (int s = 0; s < NMAX; ++s) {
         if (s >= n) continue;                     // (not a break: the trip count stays a constant, the loop unrolls)
-        const double mine = pw_div_r(xk - ak, dg, rd);
+        const double mine = SPEC ? pw_div_ru(xk - ak, dg, rd) : pw_div_r(xk - ak, dg, rd);
         const double xs = T::bcast_u(mine, s);
         xk = lane == s ? xs : xk;
         if (NMAX > 16 && s < 16) {
@@ -228,11 +235,12 @@ __device__ inline __attribute__((always_inline)) double lb_solve_ut_reg(int n, c
             ak = (act && lane > s) ? pw_fma(xs, c[s], ak) : ak;
         }
     }
+    if (SPEC) *tnum = act ? x0 - ak : 1.0;        // what this lane divided when its turn came
     return xk;
 }
-template <class T, int NMAX>
+template <class T, int NMAX, bool SPEC>
 __device__ inline __attribute__((always_inline)) double lb_solve_un_reg(int n, const double* a, int lda, const double* rdiag,
-                                                                       double xk) {
+                                                                       double xk, double* tnum) {
     PW_ASSUME_LDS(a);
     PW_ASSUME_LDS(rdiag);
     const int lane = T::lane();
@@ -245,24 +253,33 @@ __device__ inline __attribute__((always_inline)) double lb_solve_un_reg(int n, c
     asm volatile("" : "+v"(dli));
     double dg = a[dli], rd = rdiag[li];
     if (!act) { dg = 1.0; rd = 1.0; xk = 0.0; }
+    double tn = 1.0;
 #pragma unroll
     for (int i = NMAX - 1; i >= 0; --i) {
         if (i >= n) continue;
-        const double mine = pw_div_r(xk, dg, rd);
+        const double mine = SPEC ? pw_div_ru(xk, dg, rd) : pw_div_r(xk, dg, rd);
         const double xi = T::bcast_u(mine, i);
+        if (SPEC) tn = lane == i ? xk : tn;
         xk = lane == i ? xi : xk;
         xk = lane < i ? pw_fma(-xi, rw[i], xk) : xk;
     }
+    if (SPEC) *tnum = tn;
     return xk;
 }
+// the biased exponent field of x, and the test "every dividend between emin and emax was plain" (pw_plain_exponent)
+__device__ inline unsigned lb_expo(double x) {
+    union { double d; unsigned long long u; } c;
+    c.d = x;
+    return (unsigned)(c.u >> 32) & 0x7ff00000u;
+}
+__device__ inline bool lb_plain_range(unsigned emin, unsigned emax) {
+    return (emin - 0x2bc00000u) <= 0x2bc00000u && (emax - 0x2bc00000u) <= 0x2bc00000u;
+}
 
-// bmv for one wave: lane i owns p[i] and p[col + i]; reads everything, then writes (Lbfgsb::bmv has the statement)
-template <class T, int N>
-PW_NOINLINE __device__ inline int lb_bmv_wave(LbMem<N>* m, int col, const double* v, double* p) {
-    m = lb_uniform(m); v = lb_uniform(v); p = lb_uniform(p); col = lb_uniform(col);
-    PW_ASSUME_LDS(m);
-    PW_ASSUME_LDS(v);
-    PW_ASSUME_LDS(p);
+// bmv for one wave: lane i owns p[i] and p[col + i]; reads everything, then writes (Lbfgsb::bmv has the statement).
+// Returns the singularity code of dtrtrs (0: fine), or -1 when SPEC and a dividend was not plain: nothing written.
+template <class T, int N, bool SPEC>
+__device__ inline __attribute__((always_inline)) int lb_bmv_body(LbMem<N>* m, int col, const double* v, double* p) {
     constexpr int M = LB_M;
     const int lane = T::lane();
     const bool act = lane < col;
@@ -272,23 +289,34 @@ PW_NOINLINE __device__ inline int lb_bmv_wave(LbMem<N>* m, int col, const double
         if (z) return (int)__builtin_ctzll(z) + 1;
     }
     const double vi = act ? v[li] : 0.0, vc = act ? v[col + li] : 0.0;
+    unsigned emin = 0x3ff00000u, emax = 0x3ff00000u;      // exponent range of the dividends (SPEC)
     // p[col + i] = v[col + i] + sum_{k < i} SY(i, k) * v[k] / SY(k, k)
     double sum = 0.0;
 #pragma unroll
     for (int k = 0; k < M - 1; ++k) {
         if (k + 1 >= col) continue;
         const bool on = act && k < lane;
-        const double num = on ? m->sy[li + M * k] * v[k] : 0.0;
-        const double term = pw_div_r(num, m->dsy[k], m->rsy[k]);
-        sum = sum + (on ? term : 0.0);
+        if (SPEC) {
+            const double num = on ? m->sy[li + M * k] * v[k] : 1.0;
+            const unsigned e = lb_expo(num);
+            emin = e < emin ? e : emin;
+            emax = e > emax ? e : emax;
+            const double term = pw_div_ru(num, m->dsy[k], m->rsy[k]);
+            sum = sum + (on ? term : 0.0);
+        } else {
+            const double num = on ? m->sy[li + M * k] * v[k] : 0.0;
+            const double term = pw_div_r(num, m->dsy[k], m->rsy[k]);
+            sum = sum + (on ? term : 0.0);
+        }
     }
     double xk = lane == 0 ? vc : vc + sum;
-    xk = lb_solve_ut_reg<T, M>(col, m->wt, M, m->rwt, xk);
+    double t_ut = 1.0, t_un = 1.0;
+    xk = lb_solve_ut_reg<T, M, SPEC>(col, m->wt, M, m->rwt, xk, &t_ut);
     const double sq = act ? m->sqy[li] : 1.0, rs = act ? m->rsq[li] : 1.0;
-    const double pa = pw_div_r(vi, sq, rs);
-    xk = lb_solve_un_reg<T, M>(col, m->wt, M, m->rwt, xk);
+    const double pa = SPEC ? pw_div_ru(vi, sq, rs) : pw_div_r(vi, sq, rs);
+    xk = lb_solve_un_reg<T, M, SPEC>(col, m->wt, M, m->rwt, xk, &t_un);
     // p[i] = -p[i] / sqrt(SY(i, i)) + sum_{k > i} SY(k, i) * p[col + k] / SY(i, i)
-    const double pi = pw_div_r(-pa, sq, rs);
+    const double pi = SPEC ? pw_div_ru(-pa, sq, rs) : pw_div_r(-pa, sq, rs);
     const double dsi = act ? m->dsy[li] : 1.0, rsi = act ? m->rsy[li] : 1.0;
     double sum2 = 0.0;
 #pragma unroll
@@ -296,9 +324,33 @@ PW_NOINLINE __device__ inline int lb_bmv_wave(LbMem<N>* m, int col, const double
         if (k >= col) continue;
         const bool on = act && k > lane;
         const double xv = T::bcast_u(xk, k);
-        const double num = on ? m->sy[k + M * li] * xv : 0.0;
-        const double term = pw_div_r(num, dsi, rsi);
-        sum2 = sum2 + (on ? term : 0.0);
+        if (SPEC) {
+            const double num = on ? m->sy[k + M * li] * xv : 1.0;
+            const unsigned e = lb_expo(num);
+            emin = e < emin ? e : emin;
+            emax = e > emax ? e : emax;
+            const double term = pw_div_ru(num, dsi, rsi);
+            sum2 = sum2 + (on ? term : 0.0);
+        } else {
+            const double num = on ? m->sy[k + M * li] * xv : 0.0;
+            const double term = pw_div_r(num, dsi, rsi);
+            sum2 = sum2 + (on ? term : 0.0);
+        }
+    }
+    if (SPEC) {
+        // every dividend of this lane plain and non-zero, every tabulated reciprocal a real one
+        unsigned e;
+        e = lb_expo(t_ut); emin = e < emin ? e : emin; emax = e > emax ? e : emax;
+        e = lb_expo(t_un); emin = e < emin ? e : emin; emax = e > emax ? e : emax;
+        if (act) {
+            e = lb_expo(vi); emin = e < emin ? e : emin; emax = e > emax ? e : emax;
+            e = lb_expo(pa); emin = e < emin ? e : emin; emax = e > emax ? e : emax;
+        }
+        bool good = lb_plain_range(emin, emax) && rs != 0.0 && rsi != 0.0 && (!act || m->rwt[li] != 0.0);
+#ifdef PW_LB_FORCE_FALLBACK
+        good = false;                     // (test builds: every call takes the guarded path after the speculative one)
+#endif
+        if (T::ballot(!good)) return -1;
     }
     if (act) {
         p[lane] = pi + sum2;
@@ -307,12 +359,27 @@ PW_NOINLINE __device__ inline int lb_bmv_wave(LbMem<N>* m, int col, const double
     T::wave_sync();
     return 0;
 }
-// the two solves of subsm on the factor WN (order 2 col <= 20): wv <- WN^-1 diag(-I, I) WN^-T wv
 template <class T, int N>
-PW_NOINLINE __device__ inline int lb_subsm_solves_wave(LbMem<N>* m, int col, double* wv) {
-    m = lb_uniform(m); wv = lb_uniform(wv); col = lb_uniform(col);
+PW_NOINLINE __device__ inline int lb_bmv_wave_guarded(LbMem<N>* m, int col, const double* v, double* p) {
+    m = lb_uniform(m); v = lb_uniform(v); p = lb_uniform(p); col = lb_uniform(col);
     PW_ASSUME_LDS(m);
-    PW_ASSUME_LDS(wv);
+    PW_ASSUME_LDS(v);
+    PW_ASSUME_LDS(p);
+    return lb_bmv_body<T, N, false>(m, col, v, p);
+}
+template <class T, int N>
+PW_NOINLINE __device__ inline int lb_bmv_wave(LbMem<N>* m, int col, const double* v, double* p) {
+    m = lb_uniform(m); v = lb_uniform(v); p = lb_uniform(p); col = lb_uniform(col);
+    PW_ASSUME_LDS(m);
+    PW_ASSUME_LDS(v);
+    PW_ASSUME_LDS(p);
+    const int r = lb_bmv_body<T, N, true>(m, col, v, p);
+    if (r >= 0) return r;
+    return lb_bmv_wave_guarded<T, N>(m, col, v, p);
+}
+// the two solves of subsm on the factor WN (order 2 col <= 20): wv <- WN^-1 diag(-I, I) WN^-T wv
+template <class T, int N, bool SPEC>
+__device__ inline __attribute__((always_inline)) int lb_subsm_solves_body(LbMem<N>* m, int col, double* wv) {
     constexpr int M2 = 2 * LB_M;
     const int lane = T::lane();
     const int n = 2 * col;
@@ -323,12 +390,37 @@ PW_NOINLINE __device__ inline int lb_subsm_solves_wave(LbMem<N>* m, int col, dou
         if (z) return (int)__builtin_ctzll(z) + 1;
     }
     double xk = act ? wv[li] : 0.0;
-    xk = lb_solve_ut_reg<T, M2>(n, m->wn, M2, m->rwn, xk);
+    double t_ut = 1.0, t_un = 1.0;
+    xk = lb_solve_ut_reg<T, M2, SPEC>(n, m->wn, M2, m->rwn, xk, &t_ut);
     xk = lane < col ? -xk : xk;
-    xk = lb_solve_un_reg<T, M2>(n, m->wn, M2, m->rwn, xk);
+    xk = lb_solve_un_reg<T, M2, SPEC>(n, m->wn, M2, m->rwn, xk, &t_un);
+    if (SPEC) {
+        const unsigned e1 = lb_expo(t_ut), e2 = lb_expo(t_un);
+        bool good = lb_plain_range(e1 < e2 ? e1 : e2, e1 > e2 ? e1 : e2) && (!act || m->rwn[li] != 0.0);
+#ifdef PW_LB_FORCE_FALLBACK
+        good = false;
+#endif
+        if (T::ballot(!good)) return -1;
+    }
     if (act) wv[lane] = xk;
     T::wave_sync();
     return 0;
+}
+template <class T, int N>
+PW_NOINLINE __device__ inline int lb_subsm_solves_wave_guarded(LbMem<N>* m, int col, double* wv) {
+    m = lb_uniform(m); wv = lb_uniform(wv); col = lb_uniform(col);
+    PW_ASSUME_LDS(m);
+    PW_ASSUME_LDS(wv);
+    return lb_subsm_solves_body<T, N, false>(m, col, wv);
+}
+template <class T, int N>
+PW_NOINLINE __device__ inline int lb_subsm_solves_wave(LbMem<N>* m, int col, double* wv) {
+    m = lb_uniform(m); wv = lb_uniform(wv); col = lb_uniform(col);
+    PW_ASSUME_LDS(m);
+    PW_ASSUME_LDS(wv);
+    const int r = lb_subsm_solves_body<T, N, true>(m, col, wv);
+    if (r >= 0) return r;
+    return lb_subsm_solves_wave_guarded<T, N>(m, col, wv);
 }
 #endif
 
@@ -587,7 +679,7 @@ struct Lbfgsb {
         LB_F0(fb);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_LB_OLD_SOLVES)
         if (T::WSIZE == 64) {
-            const int inf_w = lb_bmv_wave<T, N>(mem, col, v, p);
+            const int inf_w = lb_bmv_wave<LbWave, N>(mem, col, v, p);
             LB_F1(2, fb);
             return inf_w;
         }
@@ -1192,7 +1284,7 @@ struct Lbfgsb {
         int inf;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_LB_OLD_SOLVES)
         if (T::WSIZE == 64) {
-            inf = lb_subsm_solves_wave<T, N>(mem, col, wv);
+            inf = lb_subsm_solves_wave<LbWave, N>(mem, col, wv);
         } else
 #endif
         {

@@ -10,6 +10,14 @@ else
   timeout 600 python -m pytest tests/test_gpu_api.py tests/test_gpu_parity.py -m gpu -x -q -k "division or golden or parity or live or opt or lbfgsb or static or every_launch" > $o/gputest.log 2>&1; echo "pytest rc=$?"
 fi
 grep -a "passed\|failed\|error" $o/gputest.log | tail -3
+# variant libraries (tests/tools/libpw_var_*.so, e.g. the forced-fallback build): the parity subset through each
+for var in tests/tools/libpw_var_*.so; do
+  [ -f "$var" ] || continue
+  cp pywindow_amd/libpywindow_hip.so /tmp/pw_keep.so && cp "$var" pywindow_amd/libpywindow_hip.so
+  timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_cliffs.py -m gpu -x -q > $o/gputest_$(basename $var .so).log 2>&1; echo "variant $(basename $var) rc=$?"
+  grep -a "passed\|failed\|error" $o/gputest_$(basename $var .so).log | tail -2
+  cp /tmp/pw_keep.so pywindow_amd/libpywindow_hip.so
+done
 timeout 200 python tests/tools/rowprobe/run_probe.py 1000 2>&1 | grep "product chains" | tee $o/chains_only.txt
 timeout 300 python tests/tools/profile_chains.py 1000 > $o/fine.json 2> $o/fine.err; python - <<P
 import json
