@@ -424,6 +424,161 @@ PW_NOINLINE __device__ inline int lb_subsm_solves_wave(LbMem<N>* m, int col, dou
 }
 #endif
 
+// ---- dcstep (More'-Thuente safeguarded step) -----------------------------------
+PW_HD inline void lb_dcstep(double& stx, double& fx, double& dx, double& sty, double& fy,
+                         double& dy, double& stp, double fp, double dp, int& brackt,
+                         double stpmin, double stpmax) {
+    double gamma, p, q, rr, s, sgnd, stpc, stpf, stpq, th;
+    sgnd = dp * (dx / pw_abs(dx));
+    if (fp > fx) {
+        th = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+        s = pw_max(pw_max(pw_abs(th), pw_abs(dx)), pw_abs(dp));
+        gamma = s * pw_sqrt((th / s) * (th / s) - (dx / s) * (dp / s));
+        if (stp < stx) gamma = -gamma;
+        p = (gamma - dx) + th;
+        q = ((gamma - dx) + gamma) + dp;
+        rr = p / q;
+        stpc = stx + rr * (stp - stx);
+        stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
+        if (pw_abs(stpc - stx) < pw_abs(stpq - stx)) stpf = stpc;
+        else stpf = stpc + (stpq - stpc) / 2.0;
+        brackt = true;
+    } else if (sgnd < 0.0) {
+        th = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+        s = pw_max(pw_max(pw_abs(th), pw_abs(dx)), pw_abs(dp));
+        gamma = s * pw_sqrt((th / s) * (th / s) - (dx / s) * (dp / s));
+        if (stp > stx) gamma = -gamma;
+        p = (gamma - dp) + th;
+        q = ((gamma - dp) + gamma) + dx;
+        rr = p / q;
+        stpc = stp + rr * (stx - stp);
+        stpq = stp + (dp / (dp - dx)) * (stx - stp);
+        if (pw_abs(stpc - stp) > pw_abs(stpq - stp)) stpf = stpc;
+        else stpf = stpq;
+        brackt = true;
+    } else if (pw_abs(dp) < pw_abs(dx)) {
+        th = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+        s = pw_max(pw_max(pw_abs(th), pw_abs(dx)), pw_abs(dp));
+        gamma = s * pw_sqrt(pw_max(0.0, (th / s) * (th / s) - (dx / s) * (dp / s)));
+        if (stp > stx) gamma = -gamma;
+        p = (gamma - dp) + th;
+        q = (gamma + (dx - dp)) + gamma;
+        rr = p / q;
+        if (rr < 0.0 && gamma != 0.0) stpc = stp + rr * (stx - stp);
+        else if (stp > stx) stpc = stpmax;
+        else stpc = stpmin;
+        stpq = stp + (dp / (dp - dx)) * (stx - stp);
+        if (brackt) {
+            if (pw_abs(stpc - stp) < pw_abs(stpq - stp)) stpf = stpc;
+            else stpf = stpq;
+            if (stp > stx) stpf = pw_min(stp + 0.66 * (sty - stp), stpf);
+            else stpf = pw_max(stp + 0.66 * (sty - stp), stpf);
+        } else {
+            if (pw_abs(stpc - stp) > pw_abs(stpq - stp)) stpf = stpc;
+            else stpf = stpq;
+            stpf = pw_min(stpmax, stpf);
+            stpf = pw_max(stpmin, stpf);
+        }
+    } else {
+        if (brackt) {
+            th = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
+            s = pw_max(pw_max(pw_abs(th), pw_abs(dy)), pw_abs(dp));
+            gamma = s * pw_sqrt((th / s) * (th / s) - (dy / s) * (dp / s));
+            if (stp > sty) gamma = -gamma;
+            p = (gamma - dp) + th;
+            q = ((gamma - dp) + gamma) + dy;
+            rr = p / q;
+            stpc = stp + rr * (sty - stp);
+            stpf = stpc;
+        } else if (stp > stx) {
+            stpf = stpmax;
+        } else {
+            stpf = stpmin;
+        }
+    }
+    if (fp > fx) {
+        sty = stp; fy = fp; dy = dp;
+    } else {
+        if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
+        stx = stp; fx = fp; dx = dp;
+    }
+    stp = stpf;
+}
+
+// ---- dcsrch ------------------------------------------------------------------------
+// One call of the line search.  Out of line, and its state in team memory (LsState): a scalar routine of a dozen
+// divisions and a square root whose thirteen doubles of state were live -- spilled -- across the whole optimiser stage
+// while it sat inside it; on its own it has its own registers.  ls_task in, {step, ls_task} out.
+struct LsOut { double st; int task; };
+PW_NOINLINE PW_HD inline LsOut lb_dcsrch(LsState* lsp, int ls_task, double fv, double gv, double st, double ftol, double gtol,
+                                     double xtol, double stpmin, double stpmax) {
+    PW_ASSUME_LDS(lsp);
+    const double p5 = 0.5, p66 = 0.66, xtrapl = 1.1, xtrapu = 4.0;
+    if (ls_task == 0) {
+        LsState L;
+        if (st < stpmin) ls_task = 4;
+        if (st > stpmax) ls_task = 4;
+        if (gv >= 0.0) ls_task = 4;
+        if (ls_task == 4) return LsOut{st, ls_task};
+        L.brackt = 0;
+        L.stage = 1;
+        L.finit = fv;
+        L.ginit = gv;
+        L.gtest = ftol * L.ginit;
+        L.width = stpmax - stpmin;
+        L.width1 = L.width / p5;
+        L.stx = 0.0; L.fx = L.finit; L.gx = L.ginit;
+        L.sty = 0.0; L.fy = L.finit; L.gy = L.ginit;
+        L.stmin = 0.0;
+        L.stmax = st + xtrapu * st;
+        *lsp = L;
+        return LsOut{st, 1};
+    }
+    LsState L = *lsp;
+    double ftest = L.finit + st * L.gtest;
+    if (L.stage == 1 && fv <= ftest && gv >= 0.0) L.stage = 2;
+    if (L.brackt && (st <= L.stmin || st >= L.stmax)) ls_task = 3;
+    if (L.brackt && L.stmax - L.stmin <= xtol * L.stmax) ls_task = 3;
+    if (st == stpmax && fv <= ftest && gv <= L.gtest) ls_task = 3;
+    if (st == stpmin && (fv > ftest || gv >= L.gtest)) ls_task = 3;
+    if (fv <= ftest && pw_abs(gv) <= gtol * (-L.ginit)) ls_task = 2;
+    if (ls_task == 3 || ls_task == 2) { lsp->stage = L.stage; return LsOut{st, ls_task}; }
+    if (L.stage == 1 && fv <= L.fx && fv > ftest) {
+        double fm = fv - st * L.gtest;
+        double fxm = L.fx - L.stx * L.gtest;
+        double fym = L.fy - L.sty * L.gtest;
+        double gm = gv - L.gtest;
+        double gxm = L.gx - L.gtest;
+        double gym = L.gy - L.gtest;
+        lb_dcstep(L.stx, fxm, gxm, L.sty, fym, gym, st, fm, gm, L.brackt, L.stmin, L.stmax);
+        L.fx = fxm + L.stx * L.gtest;
+        L.fy = fym + L.sty * L.gtest;
+        L.gx = gxm + L.gtest;
+        L.gy = gym + L.gtest;
+    } else {
+        lb_dcstep(L.stx, L.fx, L.gx, L.sty, L.fy, L.gy, st, fv, gv, L.brackt, L.stmin, L.stmax);
+    }
+    if (L.brackt) {
+        if (pw_abs(L.sty - L.stx) >= p66 * L.width1) st = L.stx + p5 * (L.sty - L.stx);
+        L.width1 = L.width;
+        L.width = pw_abs(L.sty - L.stx);
+    }
+    if (L.brackt) {
+        L.stmin = pw_min(L.stx, L.sty);
+        L.stmax = pw_max(L.stx, L.sty);
+    } else {
+        L.stmin = st + xtrapl * (st - L.stx);
+        L.stmax = st + xtrapu * (st - L.stx);
+    }
+    st = pw_max(st, stpmin);
+    st = pw_min(st, stpmax);
+    if ((L.brackt && (st <= L.stmin || st >= L.stmax)) || (L.brackt && L.stmax - L.stmin <= xtol * L.stmax))
+        st = L.stx;
+    *lsp = L;
+    return LsOut{st, 1};
+}
+
+
 template <int N>
 struct Lbfgsb {
     static constexpr int M = LB_M;
@@ -1401,157 +1556,7 @@ struct Lbfgsb {
         return 0;
     }
 
-    // ---- dcstep (More'-Thuente safeguarded step) -----------------------------------
-    PW_HD static void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy,
-                             double& dy, double& stp, double fp, double dp, int& brackt,
-                             double stpmin, double stpmax) {
-        double gamma, p, q, rr, s, sgnd, stpc, stpf, stpq, th;
-        sgnd = dp * (dx / pw_abs(dx));
-        if (fp > fx) {
-            th = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
-            s = pw_max(pw_max(pw_abs(th), pw_abs(dx)), pw_abs(dp));
-            gamma = s * pw_sqrt((th / s) * (th / s) - (dx / s) * (dp / s));
-            if (stp < stx) gamma = -gamma;
-            p = (gamma - dx) + th;
-            q = ((gamma - dx) + gamma) + dp;
-            rr = p / q;
-            stpc = stx + rr * (stp - stx);
-            stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
-            if (pw_abs(stpc - stx) < pw_abs(stpq - stx)) stpf = stpc;
-            else stpf = stpc + (stpq - stpc) / 2.0;
-            brackt = true;
-        } else if (sgnd < 0.0) {
-            th = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
-            s = pw_max(pw_max(pw_abs(th), pw_abs(dx)), pw_abs(dp));
-            gamma = s * pw_sqrt((th / s) * (th / s) - (dx / s) * (dp / s));
-            if (stp > stx) gamma = -gamma;
-            p = (gamma - dp) + th;
-            q = ((gamma - dp) + gamma) + dx;
-            rr = p / q;
-            stpc = stp + rr * (stx - stp);
-            stpq = stp + (dp / (dp - dx)) * (stx - stp);
-            if (pw_abs(stpc - stp) > pw_abs(stpq - stp)) stpf = stpc;
-            else stpf = stpq;
-            brackt = true;
-        } else if (pw_abs(dp) < pw_abs(dx)) {
-            th = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
-            s = pw_max(pw_max(pw_abs(th), pw_abs(dx)), pw_abs(dp));
-            gamma = s * pw_sqrt(pw_max(0.0, (th / s) * (th / s) - (dx / s) * (dp / s)));
-            if (stp > stx) gamma = -gamma;
-            p = (gamma - dp) + th;
-            q = (gamma + (dx - dp)) + gamma;
-            rr = p / q;
-            if (rr < 0.0 && gamma != 0.0) stpc = stp + rr * (stx - stp);
-            else if (stp > stx) stpc = stpmax;
-            else stpc = stpmin;
-            stpq = stp + (dp / (dp - dx)) * (stx - stp);
-            if (brackt) {
-                if (pw_abs(stpc - stp) < pw_abs(stpq - stp)) stpf = stpc;
-                else stpf = stpq;
-                if (stp > stx) stpf = pw_min(stp + 0.66 * (sty - stp), stpf);
-                else stpf = pw_max(stp + 0.66 * (sty - stp), stpf);
-            } else {
-                if (pw_abs(stpc - stp) > pw_abs(stpq - stp)) stpf = stpc;
-                else stpf = stpq;
-                stpf = pw_min(stpmax, stpf);
-                stpf = pw_max(stpmin, stpf);
-            }
-        } else {
-            if (brackt) {
-                th = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
-                s = pw_max(pw_max(pw_abs(th), pw_abs(dy)), pw_abs(dp));
-                gamma = s * pw_sqrt((th / s) * (th / s) - (dy / s) * (dp / s));
-                if (stp > sty) gamma = -gamma;
-                p = (gamma - dp) + th;
-                q = ((gamma - dp) + gamma) + dy;
-                rr = p / q;
-                stpc = stp + rr * (sty - stp);
-                stpf = stpc;
-            } else if (stp > stx) {
-                stpf = stpmax;
-            } else {
-                stpf = stpmin;
-            }
-        }
-        if (fp > fx) {
-            sty = stp; fy = fp; dy = dp;
-        } else {
-            if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
-            stx = stp; fx = fp; dx = dp;
-        }
-        stp = stpf;
-    }
-
-    // ---- dcsrch ------------------------------------------------------------------------
-    PW_HD void dcsrch(double fv, double gv, double& st, double ftol, double gtol, double xtol,
-                      double stpmin, double stpmax) {
-        PW_ASSUME_LDS(mem);
-        const double p5 = 0.5, p66 = 0.66, xtrapl = 1.1, xtrapu = 4.0;
-        if (ls_task == 0) {
-            LsState L;
-            if (st < stpmin) ls_task = 4;
-            if (st > stpmax) ls_task = 4;
-            if (gv >= 0.0) ls_task = 4;
-            if (ls_task == 4) return;
-            L.brackt = 0;
-            L.stage = 1;
-            L.finit = fv;
-            L.ginit = gv;
-            L.gtest = ftol * L.ginit;
-            L.width = stpmax - stpmin;
-            L.width1 = L.width / p5;
-            L.stx = 0.0; L.fx = L.finit; L.gx = L.ginit;
-            L.sty = 0.0; L.fy = L.finit; L.gy = L.ginit;
-            L.stmin = 0.0;
-            L.stmax = st + xtrapu * st;
-            mem->ls = L;
-            ls_task = 1;
-            return;
-        }
-        LsState L = mem->ls;
-        double ftest = L.finit + st * L.gtest;
-        if (L.stage == 1 && fv <= ftest && gv >= 0.0) L.stage = 2;
-        if (L.brackt && (st <= L.stmin || st >= L.stmax)) ls_task = 3;
-        if (L.brackt && L.stmax - L.stmin <= xtol * L.stmax) ls_task = 3;
-        if (st == stpmax && fv <= ftest && gv <= L.gtest) ls_task = 3;
-        if (st == stpmin && (fv > ftest || gv >= L.gtest)) ls_task = 3;
-        if (fv <= ftest && pw_abs(gv) <= gtol * (-L.ginit)) ls_task = 2;
-        if (ls_task == 3 || ls_task == 2) { mem->ls.stage = L.stage; return; }
-        if (L.stage == 1 && fv <= L.fx && fv > ftest) {
-            double fm = fv - st * L.gtest;
-            double fxm = L.fx - L.stx * L.gtest;
-            double fym = L.fy - L.sty * L.gtest;
-            double gm = gv - L.gtest;
-            double gxm = L.gx - L.gtest;
-            double gym = L.gy - L.gtest;
-            dcstep(L.stx, fxm, gxm, L.sty, fym, gym, st, fm, gm, L.brackt, L.stmin, L.stmax);
-            L.fx = fxm + L.stx * L.gtest;
-            L.fy = fym + L.sty * L.gtest;
-            L.gx = gxm + L.gtest;
-            L.gy = gym + L.gtest;
-        } else {
-            dcstep(L.stx, L.fx, L.gx, L.sty, L.fy, L.gy, st, fv, gv, L.brackt, L.stmin, L.stmax);
-        }
-        if (L.brackt) {
-            if (pw_abs(L.sty - L.stx) >= p66 * L.width1) st = L.stx + p5 * (L.sty - L.stx);
-            L.width1 = L.width;
-            L.width = pw_abs(L.sty - L.stx);
-        }
-        if (L.brackt) {
-            L.stmin = pw_min(L.stx, L.sty);
-            L.stmax = pw_max(L.stx, L.sty);
-        } else {
-            L.stmin = st + xtrapl * (st - L.stx);
-            L.stmax = st + xtrapu * (st - L.stx);
-        }
-        st = pw_max(st, stpmin);
-        st = pw_min(st, stpmax);
-        if ((L.brackt && (st <= L.stmin || st >= L.stmax)) || (L.brackt && L.stmax - L.stmin <= xtol * L.stmax))
-            st = L.stx;
-        mem->ls = L;
-        ls_task = 1;
-    }
-
+    // ---- dcstep / dcsrch: lb_dcstep, lb_dcsrch (out of line, above) --------------------
     // ---- lnsrlb --------------------------------------------------------------------------
     // returns true if a new (f,g) evaluation is requested, false when the line
     // search finished (task NEW_X) or failed (info != 0)
@@ -1601,7 +1606,11 @@ struct Lbfgsb {
             }
         }
         LB_F0(fl);
-        dcsrch(f, gd, stp, ftol, gtol, xtol, 0.0, stpmx);
+        {
+            const LsOut o = lb_dcsrch(&mem->ls, ls_task, f, gd, stp, ftol, gtol, xtol, 0.0, stpmx);
+            stp = o.st;
+            ls_task = o.task;
+        }
         LB_F1(23, fl);
         if (ls_task != 2 && ls_task != 3) {
             task = LB_FG;
