@@ -381,6 +381,15 @@ int pw_history_frame_info(const pw_history *h, int64_t frame, int64_t *nstep, do
 /* host threads the reader decodes with (PW_READER_THREADS or the hardware concurrency, at most 16; they are
  * started once per process and parked between calls) */
 int pw_history_reader_threads(void);
+/* Frames [first_frame, first_frame + count) decoded into `staging` (count x natoms x 3, normally the context's
+ * page-locked buffer: pw_context_pinned) and appended to the streamed batch `res` (pw_resident_stream_begin) as units
+ * first_unit.. WHILE the decoding goes on: the reader's threads take blocks of frames, one more thread appends the
+ * finished prefix whenever it has grown by min_append frames (<= 0: 64).  The frame loop of
+ * Trajectory._analysis_serial (trajectory.py:496-522: read a frame, analyse it, read the next) with the reading and
+ * the analysis side by side.  legs_ms (may be NULL): [0] ms until the last frame was decoded, [1] from there until the
+ * last append had returned.  Called without holding anything: the appends take the context's mutex one at a time. */
+int pw_history_stream_read(const pw_history *h, int64_t first_frame, int64_t count, pw_context *ctx, pw_resident *res,
+                           int64_t first_unit, double *staging, int64_t min_append, double *legs_ms);
 void pw_history_close(pw_history *h);
 
 #ifdef __cplusplus

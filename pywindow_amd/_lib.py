@@ -256,6 +256,7 @@ EXPORTED_SYMBOLS = [
     "pw_history_read",
     "pw_history_frame_info",
     "pw_history_reader_threads",
+    "pw_history_stream_read",
     "pw_history_close",
 ]
 
@@ -367,6 +368,7 @@ def load():
     L.pw_history_read.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, vp]
     L.pw_history_frame_info.argtypes = [vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]
     L.pw_history_reader_threads.argtypes = []
+    L.pw_history_stream_read.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, vp, vp, ctypes.c_int64, vp, ctypes.c_int64, vp]
     L.pw_history_close.argtypes = [vp]
     L.pw_history_close.restype = None
     _lib = L
@@ -713,6 +715,18 @@ class Resident:
         _check(load().pw_resident_stream_append(self.ctx._h, self._h, coords.ctypes.data, self.appended, len(coords)),
                "pw_resident_stream_append")
         self.appended += len(coords)
+
+    def append_from_history(self, history_handle, first_frame: int, staging, min_append: int = 64) -> tuple[float, float]:
+        """Frames ``first_frame ..`` of an open HISTORY (``pw_history*``) decoded into ``staging`` (``(count, atoms, 3)``,
+        page-locked) and appended as the next units WHILE they are decoded (``pw_history_stream_read``).  Returns
+        (ms until the last frame was decoded, ms from there until the last append had returned)."""
+        if staging.ndim != 3 or staging.shape[1:] != (self.atoms, 3) or not staging.flags.c_contiguous or staging.dtype != np.float64:
+            raise ValueError("staging must be a C-contiguous float64 (count, atoms, 3) array")
+        legs = (ctypes.c_double * 2)()
+        _check(load().pw_history_stream_read(history_handle, int(first_frame), len(staging), self.ctx._h, self._h, self.appended,
+                                             staging.ctypes.data, int(min_append), legs), "pw_history_stream_read")
+        self.appended += len(staging)
+        return float(legs[0]), float(legs[1])
 
     def launch(self, stages: int = STAGE_ALL):
         self._stages = stages

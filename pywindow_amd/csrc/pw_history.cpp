@@ -21,6 +21,8 @@
 
 #include <pthread.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -391,6 +393,72 @@ int pw_history_read(const pw_history* h, int64_t first, int64_t count, double* x
 }
 
 int pw_history_reader_threads(void) { return ReaderTeam::max_threads(); }
+
+// Frames [first_frame, first_frame + count) decoded straight into `staging` (the context's page-locked buffer, count x
+// atoms x 3) and handed to the streamed batch `res` WHILE the decoding goes on: the reader's threads take blocks of
+// eight frames from a counter, and one more thread watches the prefix of finished blocks and appends it
+// (pw_resident_stream_append: a DMA copy, then the launch's `ready` counter) whenever at least `min_append` more frames
+// are complete -- the analysis of the first frames runs while the last are still text, the copies overlap the decoding,
+// and what is left to do once the reader has finished is the analysis of the last few dozen frames, not of a quarter
+// of the trajectory.  legs_ms (may be null): [0] until every frame was decoded, [1] from there until the last append
+// had returned.  The counterpart of the frame loop of Trajectory._analysis_serial (trajectory.py:496-522).
+int pw_history_stream_read(const pw_history* h, int64_t first_frame, int64_t count, pw_context* ctx, pw_resident* res,
+                           int64_t first_unit, double* staging, int64_t min_append, double* legs_ms) {
+    if (!h || !ctx || !res || !staging || first_frame < 0 || count < 0 || first_unit < 0 ||
+        first_frame + count > (int64_t)h->frame_start.size())
+        return PW_E_BAD_ARG;
+    if (count == 0) return PW_OK;
+    if (min_append < 1) min_append = 64;
+    constexpr int64_t B = 8;
+    const int64_t nblocks = (count + B - 1) / B;
+    const size_t per = (size_t)h->natoms * 3;
+    std::vector<std::atomic<int>> done((size_t)nblocks);
+    for (auto& d : done) d.store(0, std::memory_order_relaxed);
+    std::atomic<int64_t> next{0};
+    std::atomic<int> failed{PW_OK};
+    std::atomic<int> decoded_all{0};
+    const auto t0 = std::chrono::steady_clock::now();
+    int append_rc = PW_OK;
+    std::thread appender([&] {
+        int64_t appended = 0, p = 0;
+        for (;;) {
+            const bool all = decoded_all.load(std::memory_order_acquire) != 0;
+            while (p < nblocks && done[(size_t)p].load(std::memory_order_acquire)) ++p;
+            const int64_t have = p * B < count ? p * B : count;
+            if (have - appended >= min_append || (have == count && have > appended)) {
+                append_rc = pw_resident_stream_append(ctx, res, staging + (size_t)appended * per, first_unit + appended, have - appended);
+                if (append_rc != PW_OK) return;
+                appended = have;
+                if (appended == count) return;
+                continue;
+            }
+            if (failed.load(std::memory_order_acquire) != PW_OK || (all && p < nblocks)) return;   // (a block that never finished)
+            std::this_thread::yield();
+        }
+    });
+    int64_t nthreads = ReaderTeam::max_threads();
+    if (nthreads > nblocks) nthreads = nblocks;
+    ReaderTeam::run((int)nthreads, [&](int) {
+        for (;;) {
+            const int64_t b = next.fetch_add(1, std::memory_order_relaxed);
+            if (b >= nblocks || failed.load(std::memory_order_relaxed) != PW_OK) return;
+            const int64_t f0 = b * B, f1 = f0 + B < count ? f0 + B : count;
+            const int rc = read_range(h, first_frame, f0, f1, staging, nullptr);
+            if (rc != PW_OK) { failed.store(rc, std::memory_order_release); return; }
+            done[(size_t)b].store(1, std::memory_order_release);
+        }
+    });
+    decoded_all.store(1, std::memory_order_release);
+    const auto t1 = std::chrono::steady_clock::now();
+    appender.join();
+    const auto t2 = std::chrono::steady_clock::now();
+    if (legs_ms) {
+        legs_ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        legs_ms[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    }
+    const int frc = failed.load(std::memory_order_acquire);
+    return frc != PW_OK ? frc : append_rc;
+}
 
 // nstep and tstep of the "timestep" record of frame f (the reference keeps them as frame_info,
 // trajectory.py:712-721)

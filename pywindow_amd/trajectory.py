@@ -39,6 +39,8 @@ RUN_PIECE = 16384
 #: launch's teams wait for the frames they are handed) -- STREAM_CHUNKS appends per piece
 STREAM_MIN = 256
 STREAM_CHUNKS = 4
+#: consecutive frames go through the native streamed read: an append whenever this many more frames are decoded
+STREAM_APPEND = 64
 
 
 class _FunctionError(Exception):
@@ -377,15 +379,22 @@ class DLPOLY:
                         t0 = clock()
                         res.launch(_lib.STAGE_ALL)
                         timing["launch_ms"] += 1e3 * (clock() - t0)
-                        step = max(32, -(-len(sel) // STREAM_CHUNKS))
-                        for a in range(0, len(sel), step):
-                            t0 = clock()
-                            self._read_selected(sel[a:a + step], False, out=buf[a:a + step])
-                            t1 = clock()
-                            res.append(buf[a:a + step])
-                            t2 = clock()
-                            timing["tokenise_ms"] += 1e3 * (t1 - t0)
-                            timing["upload_ms"] += 1e3 * (t2 - t1)
+                        if sel[-1] - sel[0] + 1 == len(sel) and all(b == a + 1 for a, b in zip(sel, sel[1:])):
+                            # consecutive frames: decoded and appended side by side by the native reader (its threads
+                            # decode blocks of frames, one more appends the finished prefix every STREAM_APPEND frames)
+                            dec_ms, tail_ms = res.append_from_history(self._h, sel[0], buf, STREAM_APPEND)
+                            timing["tokenise_ms"] += dec_ms
+                            timing["upload_ms"] += tail_ms
+                        else:
+                            step = max(32, -(-len(sel) // STREAM_CHUNKS))
+                            for a in range(0, len(sel), step):
+                                t0 = clock()
+                                self._read_selected(sel[a:a + step], False, out=buf[a:a + step])
+                                t1 = clock()
+                                res.append(buf[a:a + step])
+                                t2 = clock()
+                                timing["tokenise_ms"] += 1e3 * (t1 - t0)
+                                timing["upload_ms"] += 1e3 * (t2 - t1)
                         timing["streamed"] = True
                     else:
                         t0 = clock()

@@ -326,6 +326,30 @@ def test_streamed_batch_equals_the_uploaded_one(tmp_path):
     finally:
         trajectory.STREAM_MIN = old
     assert streamed.tobytes() == plain.tobytes() and (streamed["n_windows"] == 4).all()
+    # consecutive frames went through the native streamed read (pw_history_stream_read: decoded and appended side by
+    # side); a selection with a gap takes the chunked appends of the binding, a sub-range the native read again --
+    # each the records of those frames, and the native read by hand with small appends and an offset
+    gap = [f for f in range(1000) if f != 500][:400] + list(range(600, 1000))
+    assert traj.analysis_records(frames=gap, forcefield="opls", swap_atoms={"he": "H"}).tobytes() == plain[gap].tobytes()
+    assert traj.last_timings["streamed"] is True
+    sub = list(range(123, 123 + 321))
+    assert traj.analysis_records(frames=sub, forcefield="opls", swap_atoms={"he": "H"}).tobytes() == plain[sub].tobytes()
+    el = traj.elements({"he": "H"}, "opls")
+    ids = E.element_ids(el)
+    with ctx.lock:
+        buf = ctx.pinned_array((300, len(ids), 3))
+        res = ctx.stream_begin(300, E.VDW[ids], E.MASS[ids])
+        res.launch()
+        res.append_from_history(traj._h, 40, buf[:100], 8)          # units 0..99 = frames 40..139
+        res.append_from_history(traj._h, 140, buf[100:], 1000)      # the rest in one append
+        got = res.download()
+        res.free()
+    assert got.tobytes() == plain[40:340].tobytes()
+    with ctx.lock:
+        res = ctx.stream_begin(300, E.VDW[ids], E.MASS[ids])
+        with pytest.raises(_lib.PwHipError):
+            res.append_from_history(traj._h, 900, buf, 64)            # frames 900..1199 of a 1000-frame file
+        res.free()
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
