@@ -33,7 +33,10 @@
  *     .. pw_context_extra_windows;
  *   - the knobs: pw_context_set_params .. the launches that should see them.
  * pw_history handles are read-only after pw_history_open and may be read from
- * any number of threads.  A second live device context on a device runs its
+ * any number of threads; the reader decodes on a team of host threads started
+ * once per process, and pw_history_stream_read runs one more thread of its own
+ * for the duration of the call (the appends, which take the context's mutex one
+ * at a time like any other caller).  A second live device context on a device runs its
  * analyses as single launches (pw_context_pipelined), not as the pipeline.
  */
 #ifndef PYWINDOW_AMD_H
