@@ -98,7 +98,7 @@ struct LbMem {
     // what the solves divide by, and the refined hardware reciprocal of each (pw_recip_hw): the diagonal of SY, its
     // square root, the diagonals of the factors WT and WN.  Device teams only (tables()); rebuilt wherever the
     // matrix is (matupd, formt, formk).
-    double dsy[M], rsy[M], sqy[M], rsq[M], rwt[M], rwn[M2], iwn[M];
+    double dsy[M], rsy[M], sqy[M], rsq[M], rwt[M], rwn[M2];
     LsState ls;
     int cand[32];       // atoms that can hold the minimum near the current reference point (pw_unit.hpp: NearGap4)
     int nbd[N];
@@ -768,9 +768,7 @@ struct Lbfgsb {
                 } else if (which == 1) {
                     mem->rwt[i] = pw_recip_hw(WT(i, i));
                 } else if (which == 2) {
-                    const double dv = WN(i, i), rv = pw_recip_hw(dv);
-                    mem->rwn[i] = rv;
-                    mem->iwn[i] = pw_div_r(1.0, dv, rv);
+                    mem->rwn[i] = pw_recip_hw(WN(i, i));
                 } else {
                     mem->rwn[col + i] = pw_recip_hw(WN(col + i, col + i));
                 }
