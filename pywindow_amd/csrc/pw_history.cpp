@@ -419,7 +419,7 @@ int pw_history_stream_read(const pw_history* h, int64_t first_frame, int64_t cou
     std::atomic<int> decoded_all{0};
     const auto t0 = std::chrono::steady_clock::now();
     int append_rc = PW_OK;
-    std::thread appender([&] {
+    auto appends = [&] {
         int64_t appended = 0, p = 0;
         for (;;) {
             const bool all = decoded_all.load(std::memory_order_acquire) != 0;
@@ -435,7 +435,14 @@ int pw_history_stream_read(const pw_history* h, int64_t first_frame, int64_t cou
             if (failed.load(std::memory_order_acquire) != PW_OK || (all && p < nblocks)) return;   // (a block that never finished)
             std::this_thread::yield();
         }
-    });
+    };
+    std::thread appender;
+    bool have_appender = true;
+    try {
+        appender = std::thread(appends);
+    } catch (...) {
+        have_appender = false;         // (no thread to be had: decode everything, then append)
+    }
     int64_t nthreads = ReaderTeam::max_threads();
     if (nthreads > nblocks) nthreads = nblocks;
     ReaderTeam::run((int)nthreads, [&](int) {
@@ -450,7 +457,8 @@ int pw_history_stream_read(const pw_history* h, int64_t first_frame, int64_t cou
     });
     decoded_all.store(1, std::memory_order_release);
     const auto t1 = std::chrono::steady_clock::now();
-    appender.join();
+    if (have_appender) appender.join();
+    else appends();
     const auto t2 = std::chrono::steady_clock::now();
     if (legs_ms) {
         legs_ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();

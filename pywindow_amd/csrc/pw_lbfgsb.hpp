@@ -32,7 +32,7 @@
 #include "pw_blas.hpp"
 #include "pw_team.hpp"
 
-#if defined(PW_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(PW_PROFILE) && defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_LB_TIMERS)
 #define LB_T0(var) long long var = wall_clock64()
 #define LB_T1(slot, var) do { if (prof && T::lane() == 0) atomicAdd(&prof[slot], (unsigned long long)(wall_clock64() - var)); } while (0)
 #else

@@ -2937,6 +2937,28 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
                         hi = off;
                     }
                     auto fill = [&](auto tile_, auto pts_) __attribute__((always_inline)) {
+                        if (nb_idx) {
+                            // With the neighbour table a point stands alone: the points whose distances fall into this
+                            // tile go ONE to a thread (a tile holds a few dozen points; handed out by groups -- four
+                            // consecutive points to one thread -- a tile kept a dozen threads busy four points long
+                            // and the stage was tiles x that).  A point its table cannot vouch for sends its group
+                            // through the windowed search and reads its row back (never seen for CC3).
+                            const int E0 = s0 + lo, E1 = s0 + hi;
+                            const int k1 = (E1 - 1) / 10;
+                            for (int k = E0 / 10 + T::tid(); k <= k1; k += T::SIZE) {
+                                double d10[10];
+                                if (!point_tabled(pts_, k, d10)) {
+                                    knn_window_group(pts_, Q4, P, k / NK, W, radius, zstep, ws->knn);
+#pragma unroll
+                                    for (int q = 0; q < 10; ++q) d10[q] = ws->knn[(size_t)k * 10 + q];
+                                }
+                                const int e0 = k * 10 - s0;
+#pragma unroll
+                                for (int q = 0; q < 10; ++q)
+                                    if (e0 + q >= lo && e0 + q < hi) tile_[e0 + q - lo] = d10[q];
+                            }
+                            return;
+                        }
                         if (grp >= ngroups) return;
                         for (int p = 0; p < NK; ++p) {
                             const int k = grp * NK + p;
@@ -2949,12 +2971,28 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
                                 if (e0 + q >= lo && e0 + q < hi) tile_[e0 + q - lo] = d10[q];
                         }
                     };
+#ifdef PW_EPS_FINE
+                    PW_T0(t_f1);
+#endif
                     if (PW_IS_LDS(tile) && PW_IS_LDS(pts)) fill(PW_AS_LDS(tile), PW_AS_LDS(pts)); else fill(tile, pts);
                     T::sync();
+#ifdef PW_EPS_FINE
+                    if (T::wave() == 0) PW_T1(ws, 16, t_f1);
+                    PW_T0(t_f2);
+#endif
                     np_leaf_phase<T>(tile, len, lo, hi, s_tab, s_acc, s_leaf, true);
+#ifdef PW_EPS_FINE
+                    if (T::wave() == 0) PW_T1(ws, 17, t_f2);
+#endif
                     lo = hi;
                 }
+#ifdef PW_EPS_FINE
+                PW_T0(t_f3);
+#endif
                 double part = np_walk_phase<T>(len, s_tab, s_acc, s_leaf);
+#ifdef PW_EPS_FINE
+                if (T::wave() == 0) PW_T1(ws, 18, t_f3);
+#endif
                 if (T::tid() == 0) total = first ? part : total + part;
                 first = false;
                 T::sync();

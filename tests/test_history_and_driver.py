@@ -26,6 +26,19 @@ def test_history_roundtrip(tmp_path):
     assert isinstance(ms, MolecularSystem) and np.array_equal(ms.system["coordinates"], frames[2])
 
 
+def test_streamed_read_rejects_what_it_cannot_do(tmp_path):
+    """pw_history_stream_read without a GPU: its argument checks (a null context or batch, frames beyond the file)
+    -- the call itself is exercised by tests/test_gpu_api.py::test_streamed_batch_equals_the_uploaded_one."""
+    path = synth.write_synthetic_history(tmp_path / "HISTORY", 5)
+    traj = DLPOLY(path)
+    L = _lib.load()
+    buf = np.zeros((5, 168, 3))
+    for args in ((traj._h, 0, 5, None, None, 0, buf.ctypes.data, 64, None),
+                 (None, 0, 5, None, None, 0, buf.ctypes.data, 64, None),
+                 (traj._h, 3, 5, None, None, 0, buf.ctypes.data, 64, None)):
+        assert L.pw_history_stream_read(*args) != 0
+
+
 def test_history_with_lattice_and_velocities(tmp_path):
     lines = ["title", "%10d%10d%10d" % (1, 3, 2)]
     for f in range(2):
