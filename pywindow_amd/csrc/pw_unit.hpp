@@ -2971,28 +2971,12 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
                                 if (e0 + q >= lo && e0 + q < hi) tile_[e0 + q - lo] = d10[q];
                         }
                     };
-#ifdef PW_EPS_FINE
-                    PW_T0(t_f1);
-#endif
                     if (PW_IS_LDS(tile) && PW_IS_LDS(pts)) fill(PW_AS_LDS(tile), PW_AS_LDS(pts)); else fill(tile, pts);
                     T::sync();
-#ifdef PW_EPS_FINE
-                    if (T::wave() == 0) PW_T1(ws, 16, t_f1);
-                    PW_T0(t_f2);
-#endif
                     np_leaf_phase<T>(tile, len, lo, hi, s_tab, s_acc, s_leaf, true);
-#ifdef PW_EPS_FINE
-                    if (T::wave() == 0) PW_T1(ws, 17, t_f2);
-#endif
                     lo = hi;
                 }
-#ifdef PW_EPS_FINE
-                PW_T0(t_f3);
-#endif
                 double part = np_walk_phase<T>(len, s_tab, s_acc, s_leaf);
-#ifdef PW_EPS_FINE
-                if (T::wave() == 0) PW_T1(ws, 18, t_f3);
-#endif
                 if (T::tid() == 0) total = first ? part : total + part;
                 first = false;
                 T::sync();
