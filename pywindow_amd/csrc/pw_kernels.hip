@@ -741,6 +741,8 @@ struct pw_resident {
     unsigned long long* d_ready;   // streamed batch (pw_resident_stream_begin): units whose coordinates have arrived -- a counter
     unsigned long long* h_ready;   // in page-locked host memory that the device reads (d_ready: its device address); else null
     long ready_units;              // ... as the host has raised it
+    int pending;                   // a launch asked for while units were missing, in a shape that shares the stream the
+    unsigned pending_stages;       // appends copy on (one launch per analysis): made by the append that completes the batch
     long* d_offset;
     double* d_xyz;
     double* d_vdw;
@@ -1335,6 +1337,19 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     PW_ON_DEVICE(c->device);
     stages &= PW_STAGE_ALL;
     int rc;
+    if (r->d_ready && r->ready_units < r->n_units) {
+        // A streamed batch whose coordinates are still arriving.  The pipeline's launches run on streams of their own and
+        // wait for the units they are handed; a single launch (a context without the pipeline: PW_FUSED=1, hardware
+        // queues taken by whoever initialised the GPU first -- or stages without the window search) would sit on the
+        // API stream in front of the very copies it waits for.  It is made when the last unit has arrived.
+        const bool large_ = wanted_p_cap(c) > PW_P_CAP_PIPELINE;
+        if (c->fused || (stages & PW_STAGE_WINDOWS) == 0 || large_) {
+            r->pending = 1;
+            r->pending_stages = stages;
+            return PW_OK;
+        }
+    }
+    r->pending = 0;
     {
         // a molecule whose coordinates do not fit a CU's LDS (about 1700 atoms): the same source with the
         // team's shared block in global memory (pw_kernels_big.hip), one launch, every stage in a team
@@ -1971,6 +1986,7 @@ int pw_resident_stream_append(pw_context* c, pw_resident* r, const double* xyz, 
     HIP_TRY(hipStreamSynchronize(c->stream));
     r->ready_units = (long)(first + count);
     __atomic_store_n(r->h_ready, (unsigned long long)r->ready_units, __ATOMIC_RELEASE);
+    if (r->pending && r->ready_units == r->n_units) return pw_resident_launch(c, r, r->pending_stages);   // (see there)
     return PW_OK;
 }
 

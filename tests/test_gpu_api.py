@@ -352,6 +352,61 @@ def test_streamed_batch_equals_the_uploaded_one(tmp_path):
         res.free()
 
 
+def test_streamed_batch_on_a_context_without_the_pipeline():
+    """A context that runs every analysis as ONE launch (PW_FUSED=1; or the hardware queues were taken by whoever
+    initialised the GPU first -- torch before this library without GPU_MAX_HW_QUEUES=12 exported) launches on the stream
+    the appends copy on: the launch of a streamed batch is then made by the append that completes it -- found as a
+    5 s time-out with torch initialised first.  Also stages without the window search on a pipelined context."""
+    import os
+
+    from pywindow_amd import _lib, engine, synth
+    from pywindow_amd import element_data as E
+
+    elements, frames = synth.synthetic_units(300)
+    ids = E.element_ids(elements)
+    vdw, mass = E.VDW[ids], E.MASS[ids]
+    main = engine.context(0)
+    whole = main.upload(_lib.Batch.uniform(frames, vdw, mass))
+    whole.launch()
+    expect = whole.download()
+    whole.free()
+    old = os.environ.get("PW_FUSED")
+    os.environ["PW_FUSED"] = "1"
+    try:
+        ctx = _lib.Context(0)
+    finally:
+        if old is None:
+            del os.environ["PW_FUSED"]
+        else:
+            os.environ["PW_FUSED"] = old
+    assert _lib.load().pw_context_pipelined(ctx._h) == 0
+    buf = ctx.pinned_array(frames.shape)
+    buf[:] = frames
+    res = ctx.stream_begin(len(frames), vdw, mass)
+    res.launch()
+    with pytest.raises(_lib.PwHipError):
+        res.download()                                 # incomplete
+    for lo in range(0, len(frames), 100):
+        res.append(buf[lo:lo + 100])
+    assert res.download().tobytes() == expect.tobytes()
+    res.launch()
+    assert res.download().tobytes() == expect.tobytes()
+    res.free()
+    ctx.close()
+    # the pipelined context, stages that are one launch
+    with main.lock:
+        buf = main.pinned_array(frames.shape)
+        buf[:] = frames
+        res = main.stream_begin(len(frames), vdw, mass)
+        res.launch(_lib.STAGE_BASIC | _lib.STAGE_OPT)
+        for lo in range(0, len(frames), 150):
+            res.append(buf[lo:lo + 150])
+        got = res.download()
+        res.free()
+    for k in ("pore_opt_d", "pore_opt_c", "opt_nit", "opt_nfev", "maxd", "pore_d"):
+        assert np.array_equal(got[k], expect[k]), k
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_division_by_a_tabulated_reciprocal_has_the_bits_of_the_division(mode):
     """pw_div_r(a, b, pw_recip_hw(b)) (pw_common.hpp: the solves of the optimisers divide by the same diagonal at every
