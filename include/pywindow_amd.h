@@ -233,7 +233,9 @@ int pw_context_reserve_points(pw_context *ctx, int64_t n_points);
  * so far; the call returns when the copy has landed (from page-locked memory, pw_context_pinned, a DMA of tens of
  * microseconds per megabyte) and the buffer may be reused.  Downloading an incomplete batch is PW_E_BAD_ARG; a
  * launch that waits 5 s for a unit gives up and the download reports it (PW_E_HIP).  Device contexts only;
- * molecules beyond LDS (PW_E_TOO_LARGE) go through pw_resident_upload. */
+ * molecules beyond LDS (PW_E_TOO_LARGE) go through pw_resident_upload.  On a context that runs an analysis as ONE
+ * launch (pw_context_pipelined() == 0), or for stages without the window search, a launch asked for before the last
+ * unit has arrived is made by the append that completes the batch (nothing overlaps, nothing waits). */
 int pw_resident_stream_begin(pw_context *ctx, int64_t n_units, int64_t template_atoms, const double *vdw,
                              const double *mass, pw_resident **res);
 int pw_resident_stream_append(pw_context *ctx, pw_resident *res, const double *xyz, int64_t first, int64_t count);
