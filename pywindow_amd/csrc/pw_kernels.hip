@@ -131,9 +131,12 @@ __global__ void __launch_bounds__(256) pw_nb_build_kernel(unsigned* __restrict__
 __device__ inline bool wait_for_unit(const unsigned long long* ready, long u, int* error_flag) {
     if (!ready) return true;
     long long t0 = wall_clock64();
-    while ((long)__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) <= u) {
+    for (;;) {
+        const unsigned long long have = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((long)have > u && !(have >> 63)) break;
         __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t0 > 500000000ll) {       // 5 s: the host stopped appending
+        // 5 s: the host stopped appending; the top bit: the host gave the batch up (pw_resident_free of an incomplete one)
+        if ((have >> 63) || wall_clock64() - t0 > 500000000ll) {
             if (error_flag) atomicExch(error_flag, 1);
             return false;
         }
@@ -190,6 +193,8 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
                         int v = __hip_atomic_load(&slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (v >= 0) { u = v; break; }
                         __builtin_amdgcn_s_sleep(32);
+                        // (the producer gave up -- its units never arrived: nothing more will be published)
+                        if (__hip_atomic_load(&queue->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
                         if (wall_clock64() - t0 > 500000000ll) {   // 5 s at 100 MHz: give up, flag it
                             atomicExch(&queue->error, 1);
                             break;
@@ -2145,6 +2150,10 @@ void pw_resident_free(pw_context* c, pw_resident* r) {
     if (r->host) { delete r->host; delete r; return; }
     DeviceScope scope;
     if (c) (void)scope.enter(c->device);
+    // a streamed batch given up before its last unit: the launches that wait for units stop waiting (the top bit of
+    // the counter; they would give up by themselves after 5 s)
+    const bool given_up = r->h_ready && r->ready_units < r->n_units;
+    if (given_up) __atomic_store_n(r->h_ready, (1ull << 63) | (unsigned long long)r->ready_units, __ATOMIC_RELEASE);
     // wait for the launches that touched this batch -- not for the whole device -- and keep its blocks for
     // the next one
     if (c) {
@@ -2152,6 +2161,11 @@ void pw_resident_free(pw_context* c, pw_resident* r) {
             const int ws = r->written_set[k];
             if (ws >= 0 && c->done_valid[ws]) (void)hipEventSynchronize(c->ev_done[ws]);
             if (r->read_valid[k]) (void)hipEventSynchronize(r->ev_read[k]);
+            // (what those launches flagged when they were told to stop is not an error of anybody's next analysis)
+            if (given_up && ws >= 0 && c->queue) {
+                (void)hipMemsetAsync(&c->queue[ws].error, 0, sizeof(c->queue[ws].error), c->stream);
+                if (c->fitq) (void)hipMemsetAsync(&c->fitq[ws].error, 0, sizeof(c->fitq[ws].error), c->stream);
+            }
         }
         (void)hipStreamSynchronize(c->stream);
     }

@@ -83,6 +83,7 @@ pw_sampling_kernel(long n_units, const long* __restrict__ atom_offset, const dou
                 int v = __hip_atomic_load(&slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (v >= 0) { u = v; break; }
                 __builtin_amdgcn_s_sleep(32);
+                if (__hip_atomic_load(&queue->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;   // (the producer gave up)
                 if (wall_clock64() - t0 > 500000000ll) {   // 5 s at 100 MHz: give up, flag it
                     atomicExch(&queue->error, 1);
                     break;

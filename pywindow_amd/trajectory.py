@@ -382,7 +382,10 @@ class DLPOLY:
                         if sel[-1] - sel[0] + 1 == len(sel) and all(b == a + 1 for a, b in zip(sel, sel[1:])):
                             # consecutive frames: decoded and appended side by side by the native reader (its threads
                             # decode blocks of frames, one more appends the finished prefix every STREAM_APPEND frames)
-                            dec_ms, tail_ms = res.append_from_history(self._h, sel[0], buf, STREAM_APPEND)
+                            try:
+                                dec_ms, tail_ms = res.append_from_history(self._h, sel[0], buf, STREAM_APPEND)
+                            except _lib.PwHipError as exc:     # (a frame that cannot be decoded: the reader's error)
+                                raise _TrajectoryError(f"cannot decode frames {sel[0]}..{sel[-1]} ({exc})") from exc
                             timing["tokenise_ms"] += dec_ms
                             timing["upload_ms"] += tail_ms
                         else:

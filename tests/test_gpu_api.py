@@ -405,6 +405,47 @@ def test_streamed_batch_on_a_context_without_the_pipeline():
         res.free()
     for k in ("pore_opt_d", "pore_opt_c", "opt_nit", "opt_nfev", "maxd", "pore_d"):
         assert np.array_equal(got[k], expect[k]), k
+    # a streamed batch given up half way (a reader that failed): freeing it tells the waiting launches to stop -- no
+    # 5 s of waiting for units that never come -- and the context analyses the next batch as if nothing had happened
+    import time
+
+    with main.lock:
+        buf = main.pinned_array(frames.shape)
+        buf[:] = frames
+        res = main.stream_begin(len(frames), vdw, mass)
+        res.launch()
+        res.append(buf[:100])
+        t0 = time.perf_counter()
+        res.free()
+        assert time.perf_counter() - t0 < 1.0
+        whole = main.upload(_lib.Batch.uniform(frames, vdw, mass))
+        whole.launch()
+        assert whole.download().tobytes() == expect.tobytes()
+        whole.free()
+
+
+def test_a_broken_frame_in_a_streamed_trajectory_is_an_error_not_a_stall(tmp_path):
+    """A HISTORY whose frame 270 of 300 has a coordinate line that is not numbers: the streamed read reports it as the
+    plain read does (_TrajectoryError), at once, and the next analysis on the context is unaffected."""
+    import time
+
+    import pywindow_amd as pw
+    from pywindow_amd import synth
+    from pywindow_amd.trajectory import _TrajectoryError
+
+    good = synth.write_synthetic_history(tmp_path / "GOOD", 300)
+    text = open(good).read().split("\n")
+    starts = [i for i, line in enumerate(text) if line.startswith("timestep")]
+    text[starts[270] + 2] = "   not-a-number   1.0   2.0"          # the first atom's coordinate line of frame 270
+    bad = tmp_path / "BAD"
+    open(bad, "w").write("\n".join(text))
+    expect = pw.DLPOLY(good).analysis_records(forcefield="opls", swap_atoms={"he": "H"})
+    t0 = time.perf_counter()
+    with pytest.raises(_TrajectoryError):
+        pw.DLPOLY(bad).analysis_records(forcefield="opls", swap_atoms={"he": "H"})
+    assert time.perf_counter() - t0 < 2.0
+    again = pw.DLPOLY(good).analysis_records(forcefield="opls", swap_atoms={"he": "H"})
+    assert again.tobytes() == expect.tobytes()
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
