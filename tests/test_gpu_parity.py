@@ -493,3 +493,71 @@ def test_every_launch_shape_gives_the_same_records(monkeypatch):
         check_records(got["pipeline"], g, where=f"{tag} pipeline")
         for name in ("split", "split in one translation unit", "one launch"):
             assert got[name].tobytes() == got["pipeline"].tobytes(), (tag, name)
+
+
+def test_device_equals_host_path_on_degenerate_molecules():
+    """One, two, three (collinear), four atoms, duplicate atoms, a ring, a cube, a far-away molecule: whatever the host
+    path (the same source for a one-lane team, pinned to the reference by the CPU suite) gives for them, the device gives
+    too -- every field of every record, statuses included.  These inputs go through corners the CC3 frames never touch
+    (teams with idle lanes, empty radius groups, candidate lists of one atom)."""
+    from pywindow_amd import _lib, engine
+
+    rng = np.random.default_rng(7)
+    ring = [(np.cos(t) * 4.0, np.sin(t) * 4.0, 0.0) for t in np.linspace(0, 2 * np.pi, 12, endpoint=False)]
+    cube = [(x, y, z) for x in (-3.0, 3.0) for y in (-3.0, 3.0) for z in (-3.0, 3.0)]
+    shell = rng.normal(size=(60, 3))
+    shell = 6.0 * shell / np.linalg.norm(shell, axis=1)[:, None]
+    mols = [
+        (["C"], [(0.0, 0.0, 0.0)]),
+        (["C", "H"], [(0.0, 0.0, 0.0), (1.1, 0.0, 0.0)]),
+        (["C", "C", "C"], [(0.0, 0.0, 0.0), (1.5, 0.0, 0.0), (3.0, 0.0, 0.0)]),
+        (["C", "N", "O", "H"], [(0.0, 0.0, 0.0), (1.5, 0.0, 0.0), (0.0, 1.5, 0.0), (0.0, 0.0, 1.5)]),
+        (["C", "C", "H", "H"], [(0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (2.0, 0.0, 0.0), (2.0, 0.0, 0.0)]),
+        (["C"] * 12, ring),
+        (["C", "N"] * 4, cube),
+        (["C"] * 30 + ["H"] * 30, shell),
+        (["C"] * 30 + ["H"] * 30, shell + 1.0e4),
+        (["C", "H", "N", "O", "S", "P", "F", "Cl", "Br", "I"] * 6, shell),      # ten radii: more than the groups hold
+    ]
+    batch = [(np.array(el), np.array(xyz, dtype=np.float64)) for el, xyz in mols]
+    host = engine.analyse(batch, stages=_lib.STAGE_ALL, device=-1)
+    dev = engine.analyse(batch, stages=_lib.STAGE_ALL, device=0)
+    for k in host.dtype.names:
+        a, b = host[k], dev[k]
+        same = np.array_equal(a, b, equal_nan=True) if a.dtype.kind == "f" else np.array_equal(a, b)
+        assert same, (k, a, b)
+
+
+def test_device_equals_host_path_on_random_molecules():
+    """Sixty random molecules -- 5 to 400 atoms of up to seven elements on noisy shells, blobs and pairs of shells --
+    through every stage on the device and on the host path: all fields of all records equal.  (Hollow, dense, tiny and
+    lop-sided inputs: windows or none, any number of radius groups, optimisers that run into their bounds.)"""
+    from pywindow_amd import _lib, engine
+
+    rng = np.random.default_rng(20261004)
+    pool = np.array(["C", "H", "N", "O", "S", "F", "Cl"])
+    batch = []
+    for k in range(60):
+        n = int(rng.integers(5, 401))
+        kind = k % 3
+        p = rng.normal(size=(n, 3))
+        if kind == 0:        # a noisy shell (a cage of sorts)
+            p = p / np.linalg.norm(p, axis=1)[:, None] * rng.uniform(3.0, 12.0) + rng.normal(scale=0.3, size=(n, 3))
+        elif kind == 1:      # a blob
+            p = p * rng.uniform(1.0, 6.0)
+        else:                # two shells, one off centre
+            r = np.where(rng.random(n) < 0.5, rng.uniform(4.0, 7.0), rng.uniform(9.0, 12.0))
+            p = p / np.linalg.norm(p, axis=1)[:, None] * r[:, None]
+            p[: n // 2] += rng.normal(scale=1.5, size=3)
+        el = pool[rng.integers(0, int(rng.integers(1, len(pool) + 1)), size=n)]
+        batch.append((el, p + rng.normal(scale=5.0, size=3)))
+    host = engine.analyse(batch, stages=_lib.STAGE_ALL, device=-1)
+    dev = engine.analyse(batch, stages=_lib.STAGE_ALL, device=0)
+    bad = []
+    for k in host.dtype.names:
+        a, b = host[k], dev[k]
+        same = np.array_equal(a, b, equal_nan=True) if a.dtype.kind == "f" else np.array_equal(a, b)
+        if not same:
+            rows = [u for u in range(len(host)) if not (np.array_equal(a[u], b[u], equal_nan=True) if a.dtype.kind == "f" else np.array_equal(a[u], b[u]))]
+            bad.append((k, rows[:5]))
+    assert not bad, bad
