@@ -652,8 +652,9 @@ struct NearGap1 {
     double rx, ry, rz;
     int c;                  // this lane's candidate, -1: none
     int state;              // 0 no reference yet, 1 list in use, 2 too many candidates
+    double ax, ay, az, aq, ar;      // ... and its coordinates, squared norm and radius: an evaluation reads no memory
 
-    __device__ void init() { rx = ry = rz = 0.0; c = -1; state = 0; }
+    __device__ void init() { rx = ry = rz = 0.0; c = -1; state = 0; ax = ay = az = aq = ar = 0.0; }
 
     __device__ void rebuild(const Frame& F, int n, PW_LDS int* cand, double px, double py, double pz) {
         (void)cand;
@@ -661,14 +662,18 @@ struct NearGap1 {
         rx = px; ry = py; rz = pz;
         c = r.total <= 64 ? r.mine : -1;
         state = r.total <= 64 ? 1 : 2;
+        const int i = c < 0 ? 0 : c;
+        ax = F.x[i]; ay = F.y[i]; az = F.z[i]; aq = F.xx[i]; ar = F.vdw[i];
     }
 
     __device__ double eval(const Frame& F, int n, PW_LDS int* cand, double px, double py, double pz) {
         const bool near = pw_abs(px - rx) + pw_abs(py - ry) + pw_abs(pz - rz) <= DELTA;
         if (state == 0 || !T::wave_all(near)) rebuild(F, n, cand, px, py, pz);
         if (state != 1) return wave_gap_value<T>(F, n, px, py, pz);
-        const int i = c < 0 ? 0 : c;
-        const double v = gap_atom(F, i, px, py, pz, sq3(px, py, pz));
+        // (gap_atom on the lane's own atom, from registers)
+        const double g = pw_fma(az, pz, pw_fma(ax, px, ay * py));
+        const double d2 = pw_m2add(g, aq) + sq3(px, py, pz);
+        const double v = pw_sqrt(d2 > 0.0 ? d2 : 0.0) - ar;
         return T::wave_min(c < 0 ? PW_INF : v);
     }
 };
