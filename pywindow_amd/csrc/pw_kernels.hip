@@ -1519,6 +1519,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     if (r->n_units <= 6L * c->n_cu && pc.grid > c->n_cu) pc.grid = c->n_cu;
     // ... and the average-diameter launch, a fifth of the window search's work, gets by with one team
     // per two CUs whatever the batch (1000 units: 1.84 -> 1.79 ms, 500: 1.28 -> 1.20; 4000: 6.59 -> 6.53)
+    const int pb_planned = pb.grid;
     if (do_avg && pb.grid > (c->n_cu + 1) / 2) pb.grid = (c->n_cu + 1) / 2;
     {
         // PW_C_TEAMS / PW_B_TEAMS: cap the persistent teams of the window / average launches (tuning)
@@ -1532,7 +1533,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
             pc.grid = atoi(ct) < g ? atoi(ct) : (int)g;
         }
         const char* bt = getenv("PW_B_TEAMS");
-        if (bt && do_avg && atoi(bt) > 0 && atoi(bt) < pb.grid) pb.grid = atoi(bt);
+        if (bt && do_avg && atoi(bt) > 0) pb.grid = atoi(bt) < pb_planned ? atoi(bt) : pb_planned;   // (may also raise it)
     }
     if (const char* cslots = split ? nullptr : getenv("PW_C_SLOTS")) {
         // experiment: fewer window-fit slots than waves (less LDS per team, windows fitted in rounds);
