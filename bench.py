@@ -390,6 +390,11 @@ def main():
 
     import torch
 
+    # torch is plumbing here (device memory, streams, the process group): its intra-op pool -- one thread per hardware
+    # thread of the host, 256 on the GPU box against a cgroup quota of 16 cores -- otherwise sits beside the reader's
+    # sixteen threads (file -> records: decode leg 0.87 ms with the pool, 0.60 without; tests/tools/e2e_context.py)
+    torch.set_num_threads(1)
+
     dist = None
     backend = os.environ.get("PW_BENCH_BACKEND", "nccl")       # "gloo": rehearsal of the multi-rank path
     device_index = local_rank
