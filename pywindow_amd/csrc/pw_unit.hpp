@@ -563,6 +563,8 @@ PW_NOINLINE __device__ inline NearList4 near_rebuild4(Frame F, int n, PW_LDS int
     T::wave_sync();
     NearList4 r;
     r.c0 = r.c1 = -1;
+    // (the margin covers the rounding error of a gap for coordinates up to some 3e4 A; beyond, no list)
+    if (!(pp < 1.0e9)) total = 1 << 20;
     r.total = total;
     const int l = lane & 15;
     if (total <= 32) {
@@ -598,6 +600,7 @@ PW_NOINLINE __device__ inline NearList1 near_rebuild1(Frame F, int n, double px,
         }
         total += cnt;
     }
+    if (!(pp < 1.0e9)) total = 1 << 20;             // (see near_rebuild4)
     r.total = total;
     return r;
 }

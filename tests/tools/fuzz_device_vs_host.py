@@ -31,7 +31,7 @@ for k in range(n_mol):
         p = np.stack([np.cos(t) * 8.0, np.sin(t) * 8.0, rng.normal(scale=1.0, size=n)], axis=1) + rng.normal(scale=0.4, size=(n, 3))
     n = len(p)
     el = pool[rng.integers(0, int(rng.integers(1, len(pool) + 1)), size=n)]
-    batch.append((el, p + rng.normal(scale=rng.choice([0.0, 5.0, 500.0]), size=3)))
+    batch.append((el, p + rng.normal(scale=rng.choice([0.0, 5.0, 500.0, 2.0e4, 1.0e5]), size=3)))
 t0 = time.time(); host = engine.analyse(batch, stages=_lib.STAGE_ALL, device=-1); t1 = time.time()
 dev = engine.analyse(batch, stages=_lib.STAGE_ALL, device=0); t2 = time.time()
 bad = {}
