@@ -85,6 +85,10 @@ extern "C" {
 #define PW_ST_Z_BOUNDS 32          /* z_bounds upper < -new_z with lb_z (reference: scipy raises ValueError) */
 #define PW_ST_TOO_FEW_POINTS 64    /* fewer than 10 sampling vectors in find_windows (reference: KDTree.query(k=10)
                                       raises ValueError, utilities.py:1428-1431) */
+#define PW_ST_PATH_TOO_LONG 128    /* find_windows: a sampling vector's path would have more than 2^20 points (sphere radius /
+                                      increment, or / increment2): a pore centre that an open or enormous search box let run
+                                      away.  The reference builds such a path as a Python list (MemoryError, or hours);
+                                      no windows are computed for the unit */
 
 /* Input batch: ragged molecules, atoms of unit u are [atom_offset[u], atom_offset[u+1]). */
 typedef struct pw_batch_in {

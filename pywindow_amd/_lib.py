@@ -27,6 +27,7 @@ ST_WINDOW_DROPPED = 8
 ST_WINDOW_NEGATIVE = 16
 ST_Z_BOUNDS = 32
 ST_TOO_FEW_POINTS = 64
+ST_PATH_TOO_LONG = 128
 
 E_RETRY = -6
 DBSCAN_MAX = 8192

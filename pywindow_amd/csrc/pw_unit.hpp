@@ -96,6 +96,7 @@ constexpr double ONE_PI = 3.141592653589793;
 // position back to the caller's atom index (used for every reported index and for
 // first-index tie-breaks), `inv` is its inverse.
 constexpr int PW_KCLS = 8;
+constexpr double PW_PATH_POINTS_MAX = 1048576.0;      // points of one path scan (PW_ST_PATH_TOO_LONG beyond)
 struct ClassInfo {
     int k;                  // number of groups; 0 => more than PW_KCLS radii, no grouping used
     int off[PW_KCLS + 1];   // group g = stored positions [off[g], off[g+1])
@@ -2750,6 +2751,18 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
     T::sync();
     if (T::wave() == 0) PW_T1(ws, 15, t_md);
     if (T::tid() == 0) { v.maxd = keep_d; v.maxd_i = keep_i; v.maxd_j = keep_j; }
+    if (!(radius / prm.increment < PW_PATH_POINTS_MAX) || !(radius / prm.increment2 < PW_PATH_POINTS_MAX)) {
+        // The path of a sampling vector has radius / increment points, a cluster's refined one radius / increment2.  A pore
+        // centre that an open or enormous search box let run away (the objective has no maximum out there; the sphere is
+        // then as large as its distance) makes the reference build lists of billions of points -- a MemoryError, or hours;
+        // here it would be a launch that never ends.  No windows for this unit, and a status that says why.
+        if (T::tid() == 0) {
+            v.status |= PW_ST_PATH_TOO_LONG;
+            out->n_points = 0; out->sphere_r = radius; out->n_windows = -1; out->n_clusters = 0; out->n_survivors = 0; out->eps = 0.0;
+        }
+        T::sync();
+        return -1;
+    }
     int P = sampling_count(radius, prm.adjust_windows);
     if (T::tid() == 0) {
         out->n_points = P;

@@ -130,6 +130,11 @@ def raise_on_capacity(rec) -> None:
     the workspace of the launch held (``pw_analysis_batch`` grows it and repeats, so this only shows on
     the resident path) is raised here."""
     st = int(rec["status"])
+    if st & _lib.ST_PATH_TOO_LONG:
+        # (the reference builds the path of every sampling vector as a Python list, utilities.py:1100-1129)
+        raise MemoryError(
+            f"find_windows: a sampling sphere of radius {float(rec['sphere_r']):.6g} means more than 2**20 points per path "
+            "scan -- the pore centre ran away (an open or enormous opt_pore_diameter box?)")
     if st & _lib.ST_POINTS_OVERFLOW:
         raise _lib.PwHipError(
             f"sampling-vector workspace too small (find_windows wants {int(rec['n_points'])}, find_average_diameter "
@@ -143,7 +148,7 @@ def raise_on_uncomputable(recs) -> None:
     with fewer than ten sampling vectors makes the reference's trajectory analysis raise ``ValueError`` from
     ``KDTree.query(k=10)`` (utilities.py:1428-1431), so it does here."""
     st = recs["status"]
-    bad = np.flatnonzero(st & _lib.ST_POINTS_OVERFLOW)
+    bad = np.flatnonzero(st & (_lib.ST_POINTS_OVERFLOW | _lib.ST_PATH_TOO_LONG))
     if len(bad):
         raise_on_capacity(recs[bad[0]])
     if (st & _lib.ST_TOO_FEW_POINTS).any():

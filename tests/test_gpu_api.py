@@ -465,3 +465,25 @@ def test_division_by_a_tabulated_reciprocal_has_the_bits_of_the_division(mode):
     bad = list(out)
     a, b, got = (np.array(bad[1:], dtype=np.uint64).view(np.float64))
     assert bad[0] == 0, f"{bad[0]} quotients differ; first: {a!r} / {b!r} gave {got!r}, want {a / b!r}"
+
+
+def test_a_path_that_would_never_end_is_flagged_on_the_device(hip_ctx):
+    """PW_ST_PATH_TOO_LONG (tests/test_host_context.py has the story): on the device the alternative to the status is a
+    launch that never ends.  The unit is flagged within a normal launch and the others are analysed as ever."""
+    import time
+
+    from pywindow_amd import _lib, synth
+    from pywindow_amd import element_data as E
+
+    elements, frames = synth.synthetic_units(40)
+    ids = E.element_ids(elements)
+    batch = _lib.Batch.uniform(frames, E.VDW[ids], E.MASS[ids])
+    ok = hip_ctx.analyse(batch, _lib.STAGE_ALL)
+    t0 = time.perf_counter()
+    rec = hip_ctx.analyse(batch, _lib.STAGE_ALL, _lib.Params(increment=1.0e-6))
+    assert time.perf_counter() - t0 < 5.0
+    assert (rec["status"] & _lib.ST_PATH_TOO_LONG).all() and (rec["n_windows"] == -1).all()
+    for k in ("maxd", "avg_d", "pore_d", "pore_opt_d", "pore_opt_c"):
+        assert np.array_equal(rec[k], ok[k]), k
+    again = hip_ctx.analyse(batch, _lib.STAGE_ALL)
+    assert again.tobytes() == ok.tobytes()

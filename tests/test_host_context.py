@@ -85,6 +85,39 @@ def test_host_context_has_no_cliffs(host_ctx):
             check_window_call(call, rec, extra[0] if extra else np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE))
 
 
+def test_a_path_that_would_never_end_is_an_error(host_ctx):
+    """find_windows walks radius / increment points along every sampling vector (and radius / increment2 along a
+    cluster's refined one); the reference builds those paths as Python lists.  A pore centre that an open search box let
+    run away -- or, here, a step of a millionth of an angstrom -- means millions of points per path: the unit gets
+    PW_ST_PATH_TOO_LONG and no windows instead of a launch that runs for hours, the single-molecule call raises
+    MemoryError, and the other units of the batch are analysed as ever."""
+    import pywindow_amd as pw
+    from pywindow_amd import engine
+
+    g = load_group("static")
+    el, xyz = molecules(g)[0]
+    ids = E.element_ids(el)
+    off = np.array([0, len(xyz), 2 * len(xyz)], np.int64)
+    batch = _lib.Batch(off, np.concatenate([xyz, xyz]), np.tile(E.VDW[ids], 2), np.tile(E.MASS[ids], 2))
+    ok = host_ctx.analyse(batch, _lib.STAGE_ALL)
+    rec = host_ctx.analyse(batch, _lib.STAGE_ALL, _lib.Params(increment2=1.0e-6))
+    assert (rec["status"] & _lib.ST_PATH_TOO_LONG).all() and (rec["n_windows"] == -1).all()
+    for k in ("maxd", "avg_d", "pore_d", "pore_opt_d", "pore_opt_c"):          # everything but the windows is there
+        assert np.array_equal(rec[k], ok[k]), k
+    with pytest.raises(MemoryError):
+        engine.raise_on_capacity(rec[0])
+    with pytest.raises(MemoryError):
+        engine.raise_on_uncomputable(rec)
+    fine = host_ctx.analyse(batch, _lib.STAGE_ALL, _lib.Params(increment2=0.05))
+    assert (fine["status"] == 0).all() and (fine["n_windows"] == 4).all()
+    engine.set_default_device(-1)
+    try:
+        with pytest.raises(MemoryError):
+            pw.utilities.find_windows(el, xyz, increment2=1.0e-6)
+    finally:
+        engine.set_default_device(None)
+
+
 def test_host_context_resident_and_trajectory(tmp_path, host_ctx):
     """The trajectory driver on the host context: the reference's own 20-frame DL_POLY file, frames 3..6,
     against the md20 golden group."""

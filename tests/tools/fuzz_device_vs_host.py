@@ -32,8 +32,26 @@ for k in range(n_mol):
     n = len(p)
     el = pool[rng.integers(0, int(rng.integers(1, len(pool) + 1)), size=n)]
     batch.append((el, p + rng.normal(scale=rng.choice([0.0, 5.0, 500.0, 2.0e4, 1.0e5]), size=3)))
-t0 = time.time(); host = engine.analyse(batch, stages=_lib.STAGE_ALL, device=-1); t1 = time.time()
-dev = engine.analyse(batch, stages=_lib.STAGE_ALL, device=0); t2 = time.time()
+# --knobs: one random set of find_windows / window_analysis / opt_pore_diameter keywords for the whole batch
+prm = None
+if "--knobs" in sys.argv:
+    kw = dict(adjust_windows=float(rng.uniform(0.3, 2.2)), adjust_average=float(rng.uniform(0.3, 2.2)),
+              increment=float(rng.uniform(0.5, 2.5)), pore_opt=bool(rng.random() < 0.8), increment2=float(rng.uniform(0.05, 0.4)),
+              lb_z=bool(rng.random() < 0.5), z_second_mini=bool(rng.random() < 0.5))
+    if rng.random() < 0.4:
+        # (closed boxes only: with an open side the objective is unbounded and the optimiser walks away for its 15 000
+        # iterations -- in the reference too)
+        kw["opt_bounds"] = [(-float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.5, 3.0))) for _ in range(3)]
+    if rng.random() < 0.4:
+        kw["opt_start"] = [float(v) for v in rng.normal(scale=0.5, size=3)]
+    if rng.random() < 0.3:
+        kw["z_bounds"] = (-float(rng.uniform(0.5, 4.0)), float(rng.uniform(0.5, 4.0)))
+    print("knobs:", kw)
+    prm = _lib.Params(**kw)
+    # (custom starts / bounds are in absolute coordinates: keep the molecules at the origin)
+    batch = [(el, xyz - xyz.mean(axis=0)) for el, xyz in batch]
+t0 = time.time(); host = engine.analyse(batch, stages=_lib.STAGE_ALL, device=-1, params=prm); t1 = time.time()
+dev = engine.analyse(batch, stages=_lib.STAGE_ALL, device=0, params=prm); t2 = time.time()
 bad = {}
 for k in host.dtype.names:
     a, b = host[k], dev[k]
