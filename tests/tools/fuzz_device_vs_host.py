@@ -42,6 +42,8 @@ if "--knobs" in sys.argv:
         # (closed boxes only: with an open side the objective is unbounded and the optimiser walks away for its 15 000
         # iterations -- in the reference too)
         kw["opt_bounds"] = [(-float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.5, 3.0))) for _ in range(3)]
+        if "--open" in sys.argv:      # ... unless asked for: runaway centres, PW_ST_PATH_TOO_LONG, seconds per unit
+            kw["opt_bounds"] = [(None if rng.random() < 0.3 else a, None if rng.random() < 0.3 else b) for a, b in kw["opt_bounds"]]
     if rng.random() < 0.4:
         kw["opt_start"] = [float(v) for v in rng.normal(scale=0.5, size=3)]
     if rng.random() < 0.3:
