@@ -30,6 +30,7 @@ ST_TOO_FEW_POINTS = 64
 ST_PATH_TOO_LONG = 128
 
 E_RETRY = -6
+E_HIP = -3
 DBSCAN_MAX = 8192
 
 _PKG = pathlib.Path(__file__).resolve().parent
@@ -745,6 +746,14 @@ class Resident:
             with self.ctx.lock:       # (the records and "the windows beyond W_MAX of the records fetched last" belong together)
                 rc = load().pw_resident_download(self.ctx._h, self._h, out.ctypes.data)
                 if rc == E_RETRY:
+                    self.launch(getattr(self, "_stages", STAGE_ALL))
+                    rc = load().pw_resident_download(self.ctx._h, self._h, out.ctypes.data)
+                if rc == E_HIP and b"timed out" in load().pw_last_error():
+                    # a launch that gave up waiting (5 s) for another launch of the same analysis: the analysis is
+                    # repeated ONCE -- a second time-out is raised -- and the incident is logged with its details
+                    import logging
+
+                    logging.getLogger("pywindow_amd").warning("analysis repeated after: %s", load().pw_last_error().decode(errors="replace"))
                     self.launch(getattr(self, "_stages", STAGE_ALL))
                     rc = load().pw_resident_download(self.ctx._h, self._h, out.ctypes.data)
                 _check(rc, "pw_resident_download")

@@ -137,7 +137,7 @@ __device__ inline bool wait_for_unit(const unsigned long long* ready, long u, in
         __builtin_amdgcn_s_sleep(16);
         // 5 s: the host stopped appending; the top bit: the host gave the batch up (pw_resident_free of an incomplete one)
         if ((have >> 63) || wall_clock64() - t0 > 500000000ll) {
-            if (error_flag) atomicExch(error_flag, 1);
+            if (error_flag) atomicExch(error_flag, (have >> 63) ? 3 : 2);      // (the cause: check_queue_error reports it)
             return false;
         }
     }
@@ -194,7 +194,9 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
                         if (v >= 0) { u = v; break; }
                         __builtin_amdgcn_s_sleep(32);
                         // (the producer gave up -- its units never arrived: nothing more will be published)
+#ifndef PW_NO_CONSUMER_ERROR_CHECK
                         if (__hip_atomic_load(&queue->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+#endif
                         if (wall_clock64() - t0 > 500000000ll) {   // 5 s at 100 MHz: give up, flag it
                             atomicExch(&queue->error, 1);
                             break;
@@ -1784,12 +1786,30 @@ static int check_queue_error(pw_context* c) {
     HIP_TRY(hipMemcpy(q, c->queue, sizeof(q), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(f, c->fitq, sizeof(f), hipMemcpyDeviceToHost));
     bool any = false, anyf = false;
-    for (int b = 0; b < PW_SETS; ++b) { any = any || q[b].error != 0; anyf = anyf || f[b].error != 0; }
+    int which = -1;
+    for (int b = 0; b < PW_SETS; ++b) {
+        if (q[b].error != 0 && which < 0) which = b;
+        any = any || q[b].error != 0;
+        anyf = anyf || f[b].error != 0;
+    }
     if (any || anyf) {
-        (void)hipMemset(c->queue, 0, sizeof(q));
-        (void)hipMemset(c->fitq, 0, sizeof(f));
-        snprintf(g_err, sizeof(g_err), any ? "window launch timed out waiting for the optimiser launch"
-                                           : "fit workers timed out waiting for the sampling launch");
+        // (only the flags: the other sets' queues may belong to analyses that are running)
+        for (int b = 0; b < PW_SETS; ++b) {
+            if (q[b].error != 0) (void)hipMemset(&c->queue[b].error, 0, sizeof(c->queue[b].error));
+            if (f[b].error != 0) (void)hipMemset(&c->fitq[b].error, 0, sizeof(c->fitq[b].error));
+        }
+        if (any) {
+            // cause 1: a window team waited 5 s for a unit of the optimiser launch; 2: a team waited 5 s for the coordinates of a
+            // streamed batch; 3: a streamed batch was given up while its launches were waiting
+            const int cause = q[which].error;
+            snprintf(g_err, sizeof(g_err), "%s (set %d of %d, cause %d: %llu units published, %llu taken, %d optimiser teams started)",
+                     cause == 1 ? "window launch timed out waiting for the optimiser launch"
+                                : (cause == 2 ? "a launch timed out waiting for the coordinates of a streamed batch"
+                                              : "a streamed batch was given up while it was being analysed"),
+                     which, c->cur_sets, cause, q[which].tail, q[which].head, q[which].started);
+        } else {
+            snprintf(g_err, sizeof(g_err), "fit workers timed out waiting for the sampling launch");
+        }
         return PW_E_HIP;
     }
     return PW_OK;
@@ -2298,6 +2318,8 @@ static int launch_and_download(pw_context* c, pw_resident* r, uint32_t stages, p
         rc = pw_resident_launch(c, r, stages);
         if (rc == PW_OK) rc = pw_resident_download(c, r, out);
         if (rc == PW_E_RETRY) continue;
+        // (a launch that gave up waiting for another launch of the same analysis -- 5 s: the analysis is repeated once)
+        if (rc == PW_E_HIP && attempt == 0 && strstr(g_err, "timed out")) continue;
         if (rc != PW_OK) return rc;
         long want = 0;
         for (long u = 0; u < r->n_units; ++u)
