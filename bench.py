@@ -518,7 +518,16 @@ def main():
         for _ in range(20):
             gather()
         barrier(res)
-    elapsed = timed(res, args.steps, args.warmup, gather)
+    retried_after = None
+    try:
+        elapsed = timed(res, args.steps, args.warmup, gather)
+    except _lib.PwHipError as exc:
+        # a launch that gave up waiting for another (5 s, reported with its details): that measurement is void; the K
+        # steps are timed once more and the line says so.  (Never seen on the 1000-frame workload.)
+        if "timed out" not in str(exc) or dist is not None:
+            raise
+        retried_after = str(exc)
+        elapsed = timed(res, args.steps, args.warmup, gather)
     weak_per_rank = list(per_rank)
     out = res.download()
     ok = bool((out["status"] == 0).all())
@@ -620,7 +629,7 @@ def main():
                                 "(examples/Example7_AnalysingTrajectorySingleMol.ipynb:569-575, unknown 2018 hardware)",
             "config": {"workload": "CC3 1000-frame synthetic DL_POLY trajectory (BASELINE configs[1]), "
                                    "per-frame pore+windows, 168 atoms/frame",
-                       "frames_per_gpu": args.frames, "stages": "all", "results_ok": ok,
+                       "frames_per_gpu": args.frames, "stages": "all", "results_ok": ok, "retried_after": retried_after,
                        "successive_steps_overlap": bool(ctx.pipelined), "pipelined": bool(ctx.pipelined), "gate_timeouts": ctx.gate_timeouts,
                        "single_step_latency_ms": single_ms,
                        "windows_eq_4": int((out["n_windows"] == 4).sum()),
@@ -666,13 +675,22 @@ def main():
                     continue
                 _, part = synth.synthetic_units(args.frames // n)
                 r2 = ctx.upload(_lib.Batch.uniform(part, vdw, mass))
-                ms = r2.time_launches(10)
-                r2.free()
+                try:
+                    ms = r2.time_launches(10)
+                except _lib.PwHipError as exc:
+                    model[str(n)] = {"error": repr(exc)}
+                    continue
+                finally:
+                    r2.free()
                 model[str(n)] = {"frames_per_gpu": args.frames // n, "ms_per_step": ms,
                                  "predicted_frames_per_s": args.frames / (ms * 1e-3)}
             line["strong_scaling_model_1gpu"] = model
         if not args.no_secondary and world == 1:
-            line["secondary"] = secondary(ctx, vdw, mass)
+            # (the headline above stands on its own: a secondary figure that fails is reported as such, not fatal)
+            try:
+                line["secondary"] = secondary(ctx, vdw, mass)
+            except Exception as exc:  # noqa: BLE001
+                line["secondary"] = {"error": repr(exc)}
         if cpu is not None:
             line["cpu_baseline"] = cpu
             line["vs_cpu_baseline"] = {"one_core": value / cpu["value"],
