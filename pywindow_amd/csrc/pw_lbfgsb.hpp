@@ -1619,7 +1619,16 @@ struct Lbfgsb {
             if (stp == 1.0) {
                 b_dcopy(N, z, x);
             } else {
-                for (int i = 0; i < N; ++i) x[i] = stp * d[i] + t[i];
+                // "take step and prevent rounding error beyond bound" (SciPy's lnsrlb since its fix of iterates that
+                // left the box by an ulp): a step that ends ON a bound -- stp == stpmx -- is stp * d + t only up to
+                // rounding, and the iterate is put back on the bound.  Found by probing the reference with random
+                // molecules: one in 574 took such a step (tests/golden/bound_step.npz).
+                for (int i = 0; i < N; ++i) {
+                    double xi = stp * d[i] + t[i];
+                    if (nbd[i] == 1 || nbd[i] == 2) xi = pw_max(xi, l[i]);
+                    if (nbd[i] == 2 || nbd[i] == 3) xi = pw_min(xi, u[i]);
+                    x[i] = xi;
+                }
             }
             return true;
         }

@@ -561,3 +561,16 @@ def test_device_equals_host_path_on_random_molecules():
             rows = [u for u in range(len(host)) if not (np.array_equal(a[u], b[u], equal_nan=True) if a.dtype.kind == "f" else np.array_equal(a[u], b[u]))]
             bad.append((k, rows[:5]))
     assert not bad, bad
+
+
+def test_a_line_search_step_that_ends_on_a_bound_on_the_device(hip_ctx):
+    """tests/test_host_context.py::test_a_line_search_step_that_ends_on_a_bound, on the device."""
+    from pywindow_amd import _lib
+    from pywindow_amd import element_data as E
+    from test_host_context import check_bound_step
+
+    g = np.load(GOLDEN / "bound_step.npz")
+    el, xyz = g["elements"], g["coordinates"]
+    ids = E.element_ids(el)
+    rec = hip_ctx.analyse(_lib.Batch(np.array([0, len(xyz)], np.int64), xyz, E.VDW[ids], E.MASS[ids]), _lib.STAGE_ALL)[0]
+    check_bound_step(rec)
