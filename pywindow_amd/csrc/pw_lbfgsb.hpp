@@ -99,6 +99,7 @@ struct LbMem {
     // square root, the diagonals of the factors WT and WN.  Device teams only (tables()); rebuilt wherever the
     // matrix is (matupd, formt, formk).
     double dsy[M], rsy[M], sqy[M], rsq[M], rwt[M], rwn[M2];
+    double le[N], ue[N];    // the bounds a line-search iterate is put back on: l / u where there is one, -inf / +inf else
     LsState ls;
     int cand[32];       // atoms that can hold the minimum near the current reference point (pw_unit.hpp: NearGap4)
     int nbd[N];
@@ -640,6 +641,8 @@ struct Lbfgsb {
             u[i] = up[i];
             nbd[i] = nb[i];
             g[i] = 0.0;
+            m->le[i] = (nb[i] == 1 || nb[i] == 2) ? lo[i] : -PW_INF;
+            m->ue[i] = (nb[i] == 2 || nb[i] == 3) ? up[i] : PW_INF;
         }
         f = 0.0;
         factr = factr_;
@@ -1623,12 +1626,8 @@ struct Lbfgsb {
                 // left the box by an ulp): a step that ends ON a bound -- stp == stpmx -- is stp * d + t only up to
                 // rounding, and the iterate is put back on the bound.  Found by probing the reference with random
                 // molecules: one in 574 took such a step (tests/golden/bound_step.npz).
-                for (int i = 0; i < N; ++i) {
-                    double xi = stp * d[i] + t[i];
-                    if (nbd[i] == 1 || nbd[i] == 2) xi = pw_max(xi, l[i]);
-                    if (nbd[i] == 2 || nbd[i] == 3) xi = pw_min(xi, u[i]);
-                    x[i] = xi;
-                }
+                // (max with -inf / min with +inf where a side is open: LbMem::le / ue, set up once)
+                for (int i = 0; i < N; ++i) x[i] = pw_min(pw_max(stp * d[i] + t[i], mem->le[i]), mem->ue[i]);
             }
             return true;
         }
