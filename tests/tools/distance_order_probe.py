@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Where does the distance primitive's pinned summation order hold?  (diagnostic, CPU only)
+
+The library restates sklearn's euclidean_distances with ONE order of the three-term dot product
+for the N x N call, g = fma(z,z', fma(y,y', x*x')).  That order is what the BLAS under sklearn does for the bulk of
+the matrix; this script finds the entries of a random N x N call where it does not, grouped by where the row / the
+column sits in the matrix, and reports which of a family of candidate orders explains each group.
+
+What it shows on this image (OpenBLAS 0.3.29, SkylakeX kernels): the order holds everywhere when N % 8 < 4 and for
+small matrices; when N % 8 >= 4, some entries whose row or column is one of the four atoms [8*(N//8), 8*(N//8)+4)
+come out one ulp different -- the dgemm edge kernel of those four sums its three products differently, and no
+single order of the family below explains all of them.  See DESIGN.md section 7.
+
+    python tests/tools/distance_order_probe.py [sizes...]
+"""
+import itertools
+import sys
+from fractions import Fraction
+
+import numpy as np
+from sklearn.metrics.pairwise import euclidean_distances
+
+
+def fma(a, b, c):
+    return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+
+def candidates(a, b):
+    out = {}
+    for i0, i1, i2 in itertools.permutations(range(3)):
+        out["fma%d(fma%d(mul%d))" % (i2, i1, i0)] = fma(a[i2], b[i2], fma(a[i1], b[i1], a[i0] * b[i0]))
+        out["fma%d(mul%d)+mul%d" % (i1, i0, i2)] = fma(a[i1], b[i1], a[i0] * b[i0]) + a[i2] * b[i2]
+        if i0 < i1:
+            out["(mul%d+mul%d)+mul%d" % (i0, i1, i2)] = (a[i0] * b[i0] + a[i1] * b[i1]) + a[i2] * b[i2]
+    return out
+
+
+def distance(g, xi, xj):
+    return np.sqrt(max(fma(-2.0, g, xi) + xj, 0.0))
+
+
+def main():
+    sizes = [int(s) for s in sys.argv[1:]] or [16, 20, 21, 45, 78, 100, 119, 168, 170]
+    rng = np.random.default_rng(2)
+    for n in sizes:
+        X = np.round(rng.normal(size=(n, 3)) * 5, 6)
+        D = euclidean_distances(X, X)
+        XX = np.array([(x * x + z * z) + y * y for x, y, z in X])
+        t0 = 8 * (n // 8)
+        tail = range(t0, min(t0 + 4, n)) if n % 8 >= 4 else range(0)
+        regions = {
+            "body x body": [(i, j) for i in range(t0) for j in range(t0) if i != j],
+            "edge-4 rows x body": [(i, j) for i in tail for j in range(t0)],
+            "body x edge-4 columns": [(i, j) for i in range(t0) for j in tail],
+            "edge-4 x edge-4": [(i, j) for i in tail for j in tail if i != j],
+            "rows after the edge-4": [(i, j) for i in range(t0 + len(tail), n) for j in range(n) if i != j],
+            "columns after the edge-4": [(i, j) for i in range(n) for j in range(t0 + len(tail), n) if i != j],
+        }
+        print("N = %d (N %% 8 = %d)" % (n, n % 8))
+        for name, entries in regions.items():
+            if not entries:
+                continue
+            fails = {}
+            for i, j in entries:
+                for k, g in candidates(X[i], X[j]).items():
+                    fails[k] = fails.get(k, 0) + (distance(g, XX[i], XX[j]) != D[i, j])
+            pinned = fails["fma2(fma1(mul0))"]
+            best = sorted(fails.items(), key=lambda kv: kv[1])[:2]
+            print("   %-26s %6d entries, the pinned order differs at %3d; best candidates %s" % (name, len(entries), pinned, best))
+
+
+if __name__ == "__main__":
+    main()
