@@ -59,6 +59,22 @@ void pwo_gaps(int64_t n, const double *xyz, const double *xx, const double *vdw,
 /* max_dim (utilities.py:355-372): argmax over the upper triangle (diagonal
  * included, value 0 + 2 vdw_i) of d_ij + (vdw_i + vdw_j); first maximum in
  * row-major order.  N x N call shape: dgemm association, diagonal forced 0. */
+/* The edge tile of OpenBLAS's dsyrk (SkylakeX kernels), established entry by entry against numpy's X @ X.T
+ * (tests/tools/distance_order_probe.py --rule) and against sklearn on tests/golden/edge_tile.npz: when
+ * N % 8 >= 4 and N < 192, an entry between one of the atoms [8*(N/8), 8*(N/8)+4) and atom c is summed as
+ * fma(z,z', x*x' + y*y') when c is in the first 12*floor(w/12) columns of its 32-column chunk of width
+ * w = min(32, N - 32*floor(c/32)); every other entry as fma(z,z', fma(y,y', x*x')). */
+static int edge_order(int64_t n, int64_t i, int64_t j) {
+    if (n % 8 < 4 || n >= 192) return 0;
+    int64_t t0 = 8 * (n / 8);
+    int ei = i >= t0 && i < t0 + 4, ej = j >= t0 && j < t0 + 4;
+    if (!ei && !ej) return 0;
+    int64_t c = ei ? j : i;
+    int64_t w = n - 32 * (c / 32);
+    if (w > 32) w = 32;
+    return (c % 32) < 12 * (w / 12);
+}
+
 double pwo_max_dim(int64_t n, const double *xyz, const double *xx, const double *vdw,
                    int64_t *oi, int64_t *oj) {
     double best = -INFINITY;
@@ -71,7 +87,8 @@ double pwo_max_dim(int64_t n, const double *xyz, const double *xx, const double 
             if (i == j) {
                 d = 0.0;
             } else {
-                double g = fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0]));
+                double g = edge_order(n, i, j) ? fma(a[2], b[2], a[0] * b[0] + a[1] * b[1])
+                                               : fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0]));
                 double d2 = ((-2.0 * g) + xx[i]) + xx[j];
                 d = sqrt(d2 > 0.0 ? d2 : 0.0);
             }

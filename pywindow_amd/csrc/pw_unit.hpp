@@ -1558,12 +1558,45 @@ PW_HD inline void make_shifted(UnitShared& sh, int n, double cx, double cy, doub
     T::sync();
 }
 
+// The N x N call of the distance primitive (utilities.py:366, X is Y) goes through OpenBLAS's dsyrk, whose
+// SkylakeX kernels do NOT sum the three products of an entry in one order everywhere.  When N % 8 >= 4 the four
+// atoms [8*(N/8), 8*(N/8)+4) are an edge tile of the row panel, and an entry between one of them and atom c is
+//   fma(z,z', x*x' + y*y')        when c sits in the first 12*floor(w/12) columns of its 32-column chunk of width
+//                                 w = min(32, N - 32*floor(c/32))   (the 4x12 micro-kernel),
+//   fma(z,z', fma(y,y', x*x'))    otherwise -- the order of every other entry of the matrix.
+// Established entry by entry against numpy's X @ X.T for every N % 8 >= 4 tried below 192 (tests/tools/
+// distance_order_probe.py --rule), against sklearn on the molecules that exposed it (tests/golden/edge_tile.npz).
+// From N = 192 on the row panel is split (GEMM_P) and the chunks move: not restated, DESIGN.md section 7.
+struct GramEdgeRule {
+    int t0, nfull, limlast;
+    PW_HD explicit GramEdgeRule(int n) {
+        const bool any = (n % 8 >= 4) && n < 192;
+        t0 = any ? 8 * (n / 8) : 0x40000000;
+        nfull = 32 * (n / 32);
+        limlast = 12 * ((n - nfull) / 12);
+    }
+    PW_HD static bool applies(int n) { return (n % 8 >= 4) && n < 192; }
+    PW_HD bool is_edge(int o) const { return (unsigned)(o - t0) < 4u; }
+    PW_HD bool in_wide_kernel(int o) const { return (o & 31) < (o < nfull ? 24 : limlast); }
+    // oi, oj: the caller's numbering of the two atoms
+    PW_HD bool pair_uses_edge_order(int oi, int oj) const {
+        return (is_edge(oi) && in_wide_kernel(oj)) || (is_edge(oj) && in_wide_kernel(oi));
+    }
+};
+template <bool EDGE>
+PW_HD inline __attribute__((always_inline)) double pw_gram_nn(double xi, double yi, double zi, double xj, double yj,
+                                                              double zj, int oi, int oj, const GramEdgeRule& er) {
+    if (EDGE && er.pair_uses_edge_order(oi, oj)) return pw_fma(zi, zj, xi * xj + yi * yj);
+    return pw_fma(zi, zj, pw_fma(yi, yj, xi * xj));
+}
+
 // max_dim over frame F (utilities.py:355-372); result in sh.v->maxd*, all threads.  VALUE_ONLY: the
 // callers that only want the diameter of the shifted molecule (the radius of the sampling sphere)
 // skip the second pass; maxd_i / maxd_j are then not touched.
-template <class T, bool VALUE_ONLY = false>
-PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& sh, const Frame& F, int n,
+template <class T, bool VALUE_ONLY = false, bool EDGE = false>
+PW_HD inline __attribute__((always_inline)) void team_max_dim_body(UnitShared& sh, const Frame& F, int n,
                                                                    double* item_best = nullptr) {
+    const GramEdgeRule er(n);
     // max over pairs (diagonal included) of d_ij + (vdw_i + vdw_j), first maximum in row-major
     // order of the caller's numbering (utilities.py:355-372).  Two passes over the upper triangle:
     //   1. value only -- inside one radius group of the column the maximum of the sum is at the
@@ -1620,13 +1653,13 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
                         }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
-                            double gg = pw_fma(zi, az[u], pw_fma(yi, ay[u], xi * ax[u]));
+                            double gg = pw_gram_nn<EDGE>(xi, yi, zi, ax[u], ay[u], az[u], oi, ap[u], er);
                             double d2 = (oi < ap[u]) ? pw_m2add(gg, xxi) + aq[u] : pw_m2add(gg, aq[u]) + xxi;
                             m2 = __builtin_fmax(m2, d2);
                         }
                     }
                     for (; j < hi; j += K) {
-                        double gg = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
+                        double gg = pw_gram_nn<EDGE>(xi, yi, zi, F.x[j], F.y[j], F.z[j], oi, F.perm[j], er);
                         double d2 = (oi < F.perm[j]) ? pw_m2add(gg, xxi) + F.xx[j] : pw_m2add(gg, F.xx[j]) + xxi;
                         m2 = __builtin_fmax(m2, d2);
                     }
@@ -1689,14 +1722,14 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
                         }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
-                            double gg = pw_fma(zi, az[u], pw_fma(yi, ay[u], xi * ax[u]));
+                            double gg = pw_gram_nn<EDGE>(xi, yi, zi, ax[u], ay[u], az[u], oi, ap[u], er);
                             double d2 = (oi < ap[u]) ? pw_m2add(gg, xxi) + aq[u] : pw_m2add(gg, aq[u]) + xxi;
                             if (d2 >= thr) candidate(d2, ap[u]);
                         }
                     }
                     for (; j < hi; j += K) {
-                        double gg = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
                         int oj = F.perm[j];
+                        double gg = pw_gram_nn<EDGE>(xi, yi, zi, F.x[j], F.y[j], F.z[j], oi, oj, er);
                         double d2 = (oi < oj) ? pw_m2add(gg, xxi) + F.xx[j] : pw_m2add(gg, F.xx[j]) + xxi;
                         if (d2 >= thr) candidate(d2, oj);
                     }
@@ -1714,7 +1747,7 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
                 double d = 0.0;
                 int oj = F.perm[j];
                 if (j != i) {
-                    double gg = pw_fma(zi, F.z[j], pw_fma(yi, F.y[j], xi * F.x[j]));
+                    double gg = pw_gram_nn<EDGE>(xi, yi, zi, F.x[j], F.y[j], F.z[j], oi, oj, er);
                     double d2 = (oi < oj) ? pw_m2add(gg, xxi) + F.xx[j] : pw_m2add(gg, F.xx[j]) + xxi;
                     d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
                 }
@@ -1755,6 +1788,15 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& s
         sh.v->maxd_j = idx % n;
     }
     T::sync();
+}
+
+// (the edge order is its own instantiation: a molecule without an edge tile -- N % 8 < 4, the CC3 cage -- runs the
+// loops as they were)
+template <class T, bool VALUE_ONLY = false>
+PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& sh, const Frame& F, int n,
+                                                                   double* item_best = nullptr) {
+    if (GramEdgeRule::applies(n)) team_max_dim_body<T, VALUE_ONLY, true>(sh, F, n, item_best);
+    else team_max_dim_body<T, VALUE_ONLY, false>(sh, F, n, item_best);
 }
 
 template <class T, bool VALUE_ONLY = false>

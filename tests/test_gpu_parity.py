@@ -574,3 +574,13 @@ def test_a_line_search_step_that_ends_on_a_bound_on_the_device(hip_ctx):
     ids = E.element_ids(el)
     rec = hip_ctx.analyse(_lib.Batch(np.array([0, len(xyz)], np.int64), xyz, E.VDW[ids], E.MASS[ids]), _lib.STAGE_ALL)[0]
     check_bound_step(rec)
+
+
+def test_the_edge_tile_of_the_distance_matrix_on_the_device(hip_ctx):
+    """tests/test_host_context.py::test_the_edge_tile_of_the_distance_matrix, on the device."""
+    from pywindow_amd import _lib
+    from test_host_context import check_edge_tile, edge_tile_batch
+
+    g, batch = edge_tile_batch()
+    check_edge_tile(g, hip_ctx.analyse(batch, _lib.STAGE_ALL))
+

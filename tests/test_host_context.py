@@ -110,6 +110,41 @@ def test_a_line_search_step_that_ends_on_a_bound(host_ctx):
     check_bound_step(rec)
 
 
+def edge_tile_batch():
+    """The molecules of tests/golden/edge_tile.npz as one batch, and the fixture."""
+    g = np.load(GOLDEN / "edge_tile.npz")
+    mols = [(g["m%d_elements" % m], g["m%d_coordinates" % m]) for m in range(int(g["count"]))]
+    ids = [E.element_ids(el) for el, _ in mols]
+    offsets = np.concatenate([[0], np.cumsum([len(x) for _, x in mols])]).astype(np.int64)
+    batch = _lib.Batch(offsets, np.concatenate([x for _, x in mols]), np.concatenate([E.VDW[i] for i in ids]),
+                       np.concatenate([E.MASS[i] for i in ids]))
+    return g, batch
+
+
+def check_edge_tile(g, recs):
+    """Records against tests/golden/edge_tile.npz (written by the reference, tests/golden/make_edge_tile.py)."""
+    for m, rec in enumerate(recs):
+        assert int(rec["status"]) == 0, m
+        for k in ("maxd", "avg_d", "pore_d", "pore_opt_d"):
+            assert float(rec[k]) == float(g["m%d_%s" % (m, k)]), (m, k)
+        assert (int(rec["maxd_i"]), int(rec["maxd_j"])) == tuple(int(a) for a in g["m%d_maxd_atoms" % m]), m
+        assert np.array_equal(rec["pore_opt_c"], g["m%d_pore_opt_c" % m]), m
+        wd, wc = g["m%d_win_d" % m], g["m%d_win_c" % m]
+        assert int(rec["n_windows"]) == len(wd), m
+        assert np.array_equal(rec["win_d"][:len(wd)], wd), m
+        assert np.array_equal(np.asarray(rec["win_c"]).reshape(-1)[:3 * len(wd)], wc.reshape(-1)), m
+
+
+def test_the_edge_tile_of_the_distance_matrix(host_ctx):
+    """sklearn's N x N distance matrix goes through OpenBLAS's dsyrk, whose kernel for the four atoms
+    [8*(N//8), 8*(N//8)+4) of a molecule with N % 8 >= 4 sums the three products of an entry in another order than the
+    body of the matrix does, by column chunk (pw_unit.hpp: GramEdgeRule).  Five random molecules in 1700 have their
+    farthest pair -- of the molecule, or of the molecule shifted to its centre of mass, the radius of the sampling
+    spheres -- on such an entry and came out one ulp away; the fixture is those five with the reference's results."""
+    g, batch = edge_tile_batch()
+    check_edge_tile(g, host_ctx.analyse(batch, _lib.STAGE_ALL))
+
+
 def test_a_path_that_would_never_end_is_an_error(host_ctx):
     """find_windows walks radius / increment points along every sampling vector (and radius / increment2 along a
     cluster's refined one); the reference builds those paths as Python lists.  A pore centre that an open search box let

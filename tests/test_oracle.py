@@ -31,6 +31,27 @@ def test_oracle_reproduces_reference_bit_for_bit(tag, u):
     assert np.array_equal(r["win_c"][:n], g["win_c"][u][:n])
 
 
+def test_oracle_on_the_edge_tile_of_the_distance_matrix():
+    """tests/golden/edge_tile.npz (written by the reference): five molecules whose farthest pair is an entry of the
+    BLAS's edge tile (oracle/pw_prim.c: edge_order) -- every quantity, bit for bit."""
+    import pathlib
+
+    from oracle import pw_oracle as O
+    from pywindow_amd import element_data as E
+
+    g = np.load(pathlib.Path(__file__).resolve().parent / "golden" / "edge_tile.npz")
+    for m in range(int(g["count"])):
+        el, xyz = g["m%d_elements" % m], g["m%d_coordinates" % m]
+        ids = E.element_ids(el)
+        r = O.full_analysis(xyz, E.VDW[ids], E.MASS[ids])
+        for k in ("maxd", "avg_d", "pore_d", "pore_opt_d"):
+            assert r[k] == float(g["m%d_%s" % (m, k)]), (m, k)
+        assert (r["maxd_i"], r["maxd_j"]) == tuple(int(a) for a in g["m%d_maxd_atoms" % m]), m
+        wd = g["m%d_win_d" % m]
+        assert r["n_windows"] == len(wd), m
+        assert np.array_equal(r["win_d"][:len(wd)], wd) and np.array_equal(r["win_c"][:len(wd)], g["m%d_win_c" % m]), m
+
+
 def test_distance_primitive_matches_captured_objective_values():
     """The C primitive against objective values the reference evaluated through
     sklearn's euclidean_distances (L-BFGS-B evaluation traces in the fixtures)."""

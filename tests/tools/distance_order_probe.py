@@ -8,10 +8,12 @@ column sits in the matrix, and reports which of a family of candidate orders exp
 
 What it shows on this image (OpenBLAS 0.3.29, SkylakeX kernels): the order holds everywhere when N % 8 < 4 and for
 small matrices; when N % 8 >= 4, some entries whose row or column is one of the four atoms [8*(N//8), 8*(N//8)+4)
-come out one ulp different -- the dgemm edge kernel of those four sums its three products differently, and no
-single order of the family below explains all of them.  See DESIGN.md section 7.
+come out one ulp different -- the edge kernel of those four sums its three products differently by column chunk.
+The first mode of this script is how that was found (no single order of the family below explains the edge rows);
+--rule checks the rule that does (edge_order below) entry by entry.  See DESIGN.md section 7.
 
     python tests/tools/distance_order_probe.py [sizes...]
+    python tests/tools/distance_order_probe.py --rule [sizes...]     # the rule found, entry by entry (see edge_order)
 """
 import itertools
 import sys
@@ -39,7 +41,46 @@ def distance(g, xi, xj):
     return np.sqrt(max(fma(-2.0, g, xi) + xj, 0.0))
 
 
+def edge_order(n, i, j):
+    """The rule the library and the oracle restate (pw_unit.hpp: GramEdgeRule, pw_prim.c: edge_order)."""
+    if n % 8 < 4 or n >= 192:
+        return False
+    t0 = 8 * (n // 8)
+    ei, ej = t0 <= i < t0 + 4, t0 <= j < t0 + 4
+    if not (ei or ej):
+        return False
+    c = j if ei else i
+    w = min(32, n - 32 * (c // 32))
+    return (c % 32) < 12 * (w // 12)
+
+
+def check_rule(sizes):
+    """Every entry of the edge rows, the rows after them and three body rows of numpy's X @ X.T against the rule."""
+    rng = np.random.default_rng(7)
+    for n in sizes:
+        t0 = 8 * (n // 8)
+        rows = list(range(t0, n)) + [0, 5 % n, max(t0 - 1, 0)]
+        bad = tot = 0
+        for rep in range(3):
+            X = rng.normal(size=(n, 3)) * 5
+            G = X @ X.T
+            for i in rows:
+                for j in range(n):
+                    a, b = X[i], X[j]
+                    if edge_order(n, i, j):
+                        g = fma(a[2], b[2], a[0] * b[0] + a[1] * b[1])
+                    else:
+                        g = fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0]))
+                    tot += 2
+                    bad += (g != G[i, j]) + (g != G[j, i])
+        print("N %4d (N %% 8 = %d): %6d entries, %d off the rule" % (n, n % 8, tot, bad))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--rule":
+        check_rule([int(s) for s in sys.argv[2:]] or [12, 13, 20, 21, 23, 28, 29, 30, 31, 36, 44, 45, 47, 52, 60, 61, 63, 78, 92,
+                                                      95, 100, 119, 124, 127, 140, 156, 159, 168, 170, 172, 175, 180, 183, 188, 191, 196, 204])
+        return
     sizes = [int(s) for s in sys.argv[1:]] or [16, 20, 21, 45, 78, 100, 119, 168, 170]
     rng = np.random.default_rng(2)
     for n in sizes:
