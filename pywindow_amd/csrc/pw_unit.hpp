@@ -15,7 +15,8 @@
 //
 // Distance primitive: the bit-exact restatement of sklearn's
 // euclidean_distances:  g = fma(z,pz, fma(x,px, y*py)),
-// d = sqrt(max(((-2 g) + |r|^2) + |p|^2, 0)), |v|^2 = (v0^2 + v2^2) + v1^2.
+// d = sqrt(max(((-2 g) + |r|^2) + |p|^2, 0)), |v|^2 = (v0^2 + v2^2) + v1^2.  (The N x N call of max_dim has its
+// own order, and another one on the BLAS's edge tile: GramEdgeRule below.)
 //
 // Parallel decomposition: bulk stages are "lanes over points" (each lane owns a
 // sampling vector / grid point and loops over the atoms, which every lane reads
