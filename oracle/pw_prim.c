@@ -61,15 +61,19 @@ void pwo_gaps(int64_t n, const double *xyz, const double *xx, const double *vdw,
  * row-major order.  N x N call shape: dgemm association, diagonal forced 0. */
 /* The edge tile of OpenBLAS's dsyrk (SkylakeX kernels), established entry by entry against numpy's X @ X.T
  * (tests/tools/distance_order_probe.py --rule) and against sklearn on tests/golden/edge_tile.npz: when
- * N % 8 >= 4 and N < 192, an entry between one of the atoms [8*(N/8), 8*(N/8)+4) and atom c is summed as
- * fma(z,z', x*x' + y*y') when c is in the first 12*floor(w/12) columns of its 32-column chunk of width
- * w = min(32, N - 32*floor(c/32)); every other entry as fma(z,z', fma(y,y', x*x')). */
+ * N % 8 >= 4 and N <= 382 (from 383 the BLAS threads the product and the answer depends on the machine), an entry
+ * between one of the atoms [8*(N/8), 8*(N/8)+4) and atom c is summed as fma(z,z', x*x' + y*y') when c is in the
+ * first 12*floor(w/12) columns of the kernel call that covers it -- one call of width P for the columns left of
+ * the last row panel (P = 0 up to N = 192, 32*ceil(floor(N/2)/32) above), one per 32 columns inside it
+ * (w = min(32, N - 32*floor(c/32))); every other entry as fma(z,z', fma(y,y', x*x')). */
 static int edge_order(int64_t n, int64_t i, int64_t j) {
-    if (n % 8 < 4 || n >= 192) return 0;
+    if (n % 8 < 4 || n > 382) return 0;
     int64_t t0 = 8 * (n / 8);
     int ei = i >= t0 && i < t0 + 4, ej = j >= t0 && j < t0 + 4;
     if (!ei && !ej) return 0;
     int64_t c = ei ? j : i;
+    int64_t panel = n > 192 ? 32 * ((n / 2 + 31) / 32) : 0;
+    if (c < panel) return c < 12 * (panel / 12);
     int64_t w = n - 32 * (c / 32);
     if (w > 32) w = 32;
     return (c % 32) < 12 * (w / 12);

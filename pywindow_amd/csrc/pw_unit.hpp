@@ -1561,24 +1561,31 @@ PW_HD inline void make_shifted(UnitShared& sh, int n, double cx, double cy, doub
 
 // The N x N call of the distance primitive (utilities.py:366, X is Y) goes through OpenBLAS's dsyrk, whose
 // SkylakeX kernels do NOT sum the three products of an entry in one order everywhere.  When N % 8 >= 4 the four
-// atoms [8*(N/8), 8*(N/8)+4) are an edge tile of the row panel, and an entry between one of them and atom c is
-//   fma(z,z', x*x' + y*y')        when c sits in the first 12*floor(w/12) columns of its 32-column chunk of width
-//                                 w = min(32, N - 32*floor(c/32))   (the 4x12 micro-kernel),
+// atoms [8*(N/8), 8*(N/8)+4) are an edge tile of the last row panel, and an entry between one of them and atom c is
+//   fma(z,z', x*x' + y*y')        when c sits in the first 12*floor(w/12) columns of the kernel call that covers it
+//                                 (the 4x12 micro-kernel),
 //   fma(z,z', fma(y,y', x*x'))    otherwise -- the order of every other entry of the matrix.
-// Established entry by entry against numpy's X @ X.T for every N % 8 >= 4 tried below 192 (tests/tools/
-// distance_order_probe.py --rule), against sklearn on the molecules that exposed it (tests/golden/edge_tile.npz).
-// From N = 192 on the row panel is split (GEMM_P) and the chunks move: not restated, DESIGN.md section 7.
+// The kernel calls of the last row panel: ONE for all columns left of the panel (w = where the panel starts), then
+// one per 32 columns of the panel itself (w = min(32, N - 32*floor(c/32))).  The panel starts at 0 up to N = 192
+// (GEMM_P) and at 32*ceil(floor(N/2)/32) from there to 382; from 383 atoms the BLAS shares the product among its
+// threads and the panels depend on how many the machine has -- the reference's last bit does too, and nothing is
+// restated there.  Established entry by entry against numpy's X @ X.T (tests/tools/distance_order_probe.py --rule),
+// against sklearn on the molecules that exposed it (tests/golden/edge_tile.npz), against the reference's max_dim on
+// tens of thousands of random molecules.  DESIGN.md section 7.
 struct GramEdgeRule {
-    int t0, nfull, limlast;
+    int t0, panel, panel_wide, nfull, limlast;
+    PW_HD static bool applies(int n) { return (n % 8 >= 4) && n <= 382; }
     PW_HD explicit GramEdgeRule(int n) {
-        const bool any = (n % 8 >= 4) && n < 192;
-        t0 = any ? 8 * (n / 8) : 0x40000000;
+        t0 = applies(n) ? 8 * (n / 8) : 0x40000000;
+        panel = n > 192 ? 32 * ((n / 2 + 31) / 32) : 0;
+        panel_wide = 12 * (panel / 12);
         nfull = 32 * (n / 32);
         limlast = 12 * ((n - nfull) / 12);
     }
-    PW_HD static bool applies(int n) { return (n % 8 >= 4) && n < 192; }
     PW_HD bool is_edge(int o) const { return (unsigned)(o - t0) < 4u; }
-    PW_HD bool in_wide_kernel(int o) const { return (o & 31) < (o < nfull ? 24 : limlast); }
+    PW_HD bool in_wide_kernel(int o) const {
+        return o < panel ? o < panel_wide : (o & 31) < (o < nfull ? 24 : limlast);
+    }
     // oi, oj: the caller's numbering of the two atoms
     PW_HD bool pair_uses_edge_order(int oi, int oj) const {
         return (is_edge(oi) && in_wide_kernel(oj)) || (is_edge(oj) && in_wide_kernel(oi));

@@ -52,6 +52,30 @@ def test_oracle_on_the_edge_tile_of_the_distance_matrix():
         assert np.array_equal(r["win_d"][:len(wd)], wd) and np.array_equal(r["win_c"][:len(wd)], g["m%d_win_c" % m]), m
 
 
+def test_edge_tile_rule_against_sklearn_live():
+    """The N x N restatement (oracle/pw_prim.c: pwo_max_dim with edge_order) against sklearn's own distance matrix on
+    random molecules of every size class: below and above the BLAS's row panel (192), with and without an edge tile,
+    up to the size from which the BLAS threads the product (383).  The rule belongs to OpenBLAS's AVX-512 kernels."""
+    import pathlib
+
+    if "avx512f" not in pathlib.Path("/proc/cpuinfo").read_text():
+        pytest.skip("OpenBLAS picks other dgemm kernels on this CPU: the restated orders are the SkylakeX kernels'")
+    from sklearn.metrics.pairwise import euclidean_distances
+
+    from oracle import pw_oracle as O
+
+    rng = np.random.default_rng(12)
+    radii = np.array([1.2, 1.7, 1.55, 1.52, 1.8])
+    for n in [5, 12, 21, 45, 47, 78, 100, 119, 127, 172, 191, 196, 204, 255, 260, 316, 349, 380, 382] * 6:
+        p = rng.normal(size=(n, 3))
+        xyz = np.round(p / np.linalg.norm(p, axis=1)[:, None] * rng.uniform(3.0, 12.0) + rng.normal(scale=0.2, size=(n, 3)), 6)
+        vdw = radii[rng.integers(0, int(rng.integers(1, 6)), size=n)]
+        d = euclidean_distances(xyz, xyz) + (vdw[:, None] + vdw[None, :])       # utilities.py:366-370
+        d = np.triu(d)
+        i, j = np.unravel_index(np.argmax(d), d.shape)
+        assert O.max_dim(O.Cage(xyz, vdw, np.ones(n))) == (int(i), int(j), float(d[i, j])), n
+
+
 def test_distance_primitive_matches_captured_objective_values():
     """The C primitive against objective values the reference evaluated through
     sklearn's euclidean_distances (L-BFGS-B evaluation traces in the fixtures)."""

@@ -43,13 +43,16 @@ def distance(g, xi, xj):
 
 def edge_order(n, i, j):
     """The rule the library and the oracle restate (pw_unit.hpp: GramEdgeRule, pw_prim.c: edge_order)."""
-    if n % 8 < 4 or n >= 192:
+    if n % 8 < 4 or n > 382:          # from 383 atoms the BLAS threads the product: machine-dependent, not restated
         return False
     t0 = 8 * (n // 8)
     ei, ej = t0 <= i < t0 + 4, t0 <= j < t0 + 4
     if not (ei or ej):
         return False
     c = j if ei else i
+    panel = 32 * ((n // 2 + 31) // 32) if n > 192 else 0      # where the last row panel starts (GEMM_P = 192)
+    if c < panel:                                             # one kernel call for everything left of the panel
+        return c < 12 * (panel // 12)
     w = min(32, n - 32 * (c // 32))
     return (c % 32) < 12 * (w // 12)
 
@@ -79,7 +82,8 @@ def check_rule(sizes):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--rule":
         check_rule([int(s) for s in sys.argv[2:]] or [12, 13, 20, 21, 23, 28, 29, 30, 31, 36, 44, 45, 47, 52, 60, 61, 63, 78, 92,
-                                                      95, 100, 119, 124, 127, 140, 156, 159, 168, 170, 172, 175, 180, 183, 188, 191, 196, 204])
+                                                      95, 100, 119, 124, 127, 140, 156, 159, 168, 170, 172, 175, 180, 183, 188, 191, 196, 204, 223, 255,
+                                                      260, 287, 300, 316, 349, 380, 381, 382, 383, 412])
         return
     sizes = [int(s) for s in sys.argv[1:]] or [16, 20, 21, 45, 78, 100, 119, 168, 170]
     rng = np.random.default_rng(2)
