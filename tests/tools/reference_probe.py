@@ -1,5 +1,5 @@
 """Development container only: the REFERENCE (imported from /root/reference with the golden generator's rdkit stub) against
-the host path (device = -1) on random molecules, every compared quantity bit for bit.   python tests/tools/reference_probe.py [seed] [molecules]"""
+the host path (device = -1) on random molecules, every compared quantity bit for bit.   python tests/tools/reference_probe.py [seed] [molecules] [min atoms] [max atoms]"""
 import sys, pathlib, time, warnings, logging
 import numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests/golden")
@@ -10,9 +10,11 @@ pw = MG.load_reference()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 5)
 pool = np.array(["C", "H", "N", "O", "S", "F", "Cl"])
 n_mol = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+N_LO = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+N_HI = int(sys.argv[4]) if len(sys.argv) > 4 else 140
 mols = []
 for k in range(n_mol):
-    n = int(rng.integers(20, 140))
+    n = int(rng.integers(N_LO, N_HI))
     kind = k % 3
     p = rng.normal(size=(n, 3))
     if kind == 0:
