@@ -56,10 +56,13 @@ def test_edge_tile_rule_against_sklearn_live():
     """The N x N restatement (oracle/pw_prim.c: pwo_max_dim with edge_order) against sklearn's own distance matrix on
     random molecules of every size class: below and above the BLAS's row panel (192), with and without an edge tile,
     up to the size from which the BLAS threads the product (383).  The rule belongs to OpenBLAS's AVX-512 kernels."""
-    import pathlib
+    import numpy  # noqa: F401  (loads the BLAS threadpoolctl reports on)
+    threadpoolctl = pytest.importorskip("threadpoolctl")
 
-    if "avx512f" not in pathlib.Path("/proc/cpuinfo").read_text():
-        pytest.skip("OpenBLAS picks other dgemm kernels on this CPU: the restated orders are the SkylakeX kernels'")
+    blas = [d for d in threadpoolctl.threadpool_info() if d.get("internal_api") == "openblas"]
+    if not blas or any(d.get("architecture") != "SkylakeX" for d in blas):
+        pytest.skip("the restated orders are those of OpenBLAS's SkylakeX kernels; this BLAS runs %r"
+                    % [d.get("architecture") for d in blas])
     from sklearn.metrics.pairwise import euclidean_distances
 
     from oracle import pw_oracle as O
