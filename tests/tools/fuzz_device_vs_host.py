@@ -1,5 +1,5 @@
 """Random molecules through every stage on the device and on the host path (the same source for a one-lane team):
-every field of every record must agree.   python tests/tools/fuzz_device_vs_host.py [molecules] [seed]"""
+every field of every record must agree.   python tests/tools/fuzz_device_vs_host.py [molecules] [seed]   (PW_FUZZ_MAX_ATOMS=400 for larger ones)"""
 import pathlib, sys, time
 import numpy as np
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
@@ -8,10 +8,11 @@ from pywindow_amd import _lib, engine
 n_mol = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
+MAX_ATOMS = int(__import__("os").environ.get("PW_FUZZ_MAX_ATOMS", "300"))     # 300: the records of profiles/ were made with it
 pool = np.array(["C", "H", "N", "O", "S", "F", "Cl", "Br", "P", "I"])
 batch = []
 for k in range(n_mol):
-    n = int(rng.integers(1, 301))
+    n = int(rng.integers(1, MAX_ATOMS + 1))
     kind = int(rng.integers(0, 5))
     p = rng.normal(size=(n, 3))
     if kind == 0:
