@@ -511,12 +511,13 @@ PW_HD inline void lb_dcstep(double& stx, double& fx, double& dx, double& sty, do
 // divisions and a square root whose thirteen doubles of state were live -- spilled -- across the whole optimiser stage
 // while it sat inside it; on its own it has its own registers.  ls_task in, {step, ls_task} out.
 struct LsOut { double st; int task; };
-PW_NOINLINE PW_HD inline LsOut lb_dcsrch(LsState* lsp, int ls_task, double fv, double gv, double st, double ftol, double gtol,
-                                     double xtol, double stpmin, double stpmax) {
-    PW_ASSUME_LDS(lsp);
+// The search proper, on a state the caller holds (registers, for the fused line search of Lbfgsb::linesearch; a copy
+// of the team-memory block for the reverse-communication form below).  ls_task in, {step, ls_task} out.
+PW_HD inline __attribute__((always_inline)) LsOut lb_dcsrch_core(LsState& L, int ls_task, double fv, double gv, double st,
+                                                                 double ftol, double gtol, double xtol, double stpmin,
+                                                                 double stpmax) {
     const double p5 = 0.5, p66 = 0.66, xtrapl = 1.1, xtrapu = 4.0;
     if (ls_task == 0) {
-        LsState L;
         if (st < stpmin) ls_task = 4;
         if (st > stpmax) ls_task = 4;
         if (gv >= 0.0) ls_task = 4;
@@ -532,10 +533,8 @@ PW_NOINLINE PW_HD inline LsOut lb_dcsrch(LsState* lsp, int ls_task, double fv, d
         L.sty = 0.0; L.fy = L.finit; L.gy = L.ginit;
         L.stmin = 0.0;
         L.stmax = st + xtrapu * st;
-        *lsp = L;
         return LsOut{st, 1};
     }
-    LsState L = *lsp;
     double ftest = L.finit + st * L.gtest;
     if (L.stage == 1 && fv <= ftest && gv >= 0.0) L.stage = 2;
     if (L.brackt && (st <= L.stmin || st >= L.stmax)) ls_task = 3;
@@ -543,7 +542,7 @@ PW_NOINLINE PW_HD inline LsOut lb_dcsrch(LsState* lsp, int ls_task, double fv, d
     if (st == stpmax && fv <= ftest && gv <= L.gtest) ls_task = 3;
     if (st == stpmin && (fv > ftest || gv >= L.gtest)) ls_task = 3;
     if (fv <= ftest && pw_abs(gv) <= gtol * (-L.ginit)) ls_task = 2;
-    if (ls_task == 3 || ls_task == 2) { lsp->stage = L.stage; return LsOut{st, ls_task}; }
+    if (ls_task == 3 || ls_task == 2) return LsOut{st, ls_task};
     if (L.stage == 1 && fv <= L.fx && fv > ftest) {
         double fm = fv - st * L.gtest;
         double fxm = L.fx - L.stx * L.gtest;
@@ -575,8 +574,22 @@ PW_NOINLINE PW_HD inline LsOut lb_dcsrch(LsState* lsp, int ls_task, double fv, d
     st = pw_min(st, stpmax);
     if ((L.brackt && (st <= L.stmin || st >= L.stmax)) || (L.brackt && L.stmax - L.stmin <= xtol * L.stmax))
         st = L.stx;
-    *lsp = L;
     return LsOut{st, 1};
+}
+// Reverse-communication form (Lbfgsb::step, which the lockstep tests drive): one call of the search, out of line, its
+// state in team memory between calls.
+PW_NOINLINE PW_HD inline LsOut lb_dcsrch(LsState* lsp, int ls_task, double fv, double gv, double st, double ftol, double gtol,
+                                     double xtol, double stpmin, double stpmax) {
+    PW_ASSUME_LDS(lsp);
+    LsState L;
+    if (ls_task == 0) {
+        L = LsState{};
+    } else {
+        L = *lsp;
+    }
+    const LsOut o = lb_dcsrch_core(L, ls_task, fv, gv, st, ftol, gtol, xtol, stpmin, stpmax);
+    if (!(ls_task == 0 && o.task == 4)) *lsp = L;
+    return o;
 }
 
 
@@ -1728,6 +1741,243 @@ struct Lbfgsb {
         theta = 1.0;
         iupdat = 0;
         updatd = false;
+    }
+
+    // ---- the line search of one iteration in one piece (direct form) ---------------------------------
+    // lnsrlb + dcsrch + the caller's function-and-gradient evaluations as ONE loop: the iterate, the direction, the
+    // start point and the thirteen doubles of the More-Thuente state stay in registers from the first trial step to the
+    // last -- in the reverse-communication form every trial step went through step()'s entry dispatch, a round trip of
+    // the state through team memory and a dozen dependent LDS reads (x, d, t, g, the bounds).  Same statements in the
+    // same order as lnsrlb(false), lnsrlb(true) ..., so the same bits.  fg(x, f, g): the objective and its gradient at
+    // x (N doubles each).  Returns true when the search ended at a new iterate (task NEW_X; x, g in team memory are the
+    // new point's), false when it failed (info != 0 or maxls trial steps: x, g, f restored, as step() does).
+    template <class T, class FG>
+    PW_HD __attribute__((always_inline)) bool linesearch(FG& fg) {
+        PW_ASSUME_LDS(mem);
+        const double big = 1.0e10, ftol = 1.0e-3, gtol = 0.9, xtol = 0.1;
+        double dv[N], xv[N], zv[N], gv[N], tv[N], lev[N], uev[N];
+        int nbv[N];
+        for (int i = 0; i < N; ++i) {
+            dv[i] = d[i]; xv[i] = x[i]; zv[i] = z[i]; gv[i] = g[i]; lev[i] = mem->le[i]; uev[i] = mem->ue[i]; nbv[i] = nbd[i];
+        }
+        dnorm = b_dnrm2(N, d);
+        dtd = dnorm * dnorm;
+        stpmx = big;
+        if (cnstnd) {
+            if (iter == 0) {
+                stpmx = 1.0;
+            } else {
+                for (int i = 0; i < N; ++i) {
+                    double a1 = dv[i];
+                    if (nbv[i] != 0) {
+                        if (a1 < 0.0 && nbv[i] <= 2) {
+                            double a2 = l[i] - xv[i];
+                            if (a2 >= 0.0) stpmx = 0.0;
+                            else if (a1 * stpmx < a2) stpmx = a2 / a1;
+                        } else if (a1 > 0.0 && nbv[i] >= 2) {
+                            double a2 = u[i] - xv[i];
+                            if (a2 <= 0.0) stpmx = 0.0;
+                            else if (a1 * stpmx > a2) stpmx = a2 / a1;
+                        }
+                    }
+                }
+            }
+        }
+        if (iter == 0 && !boxed) stp = pw_min(1.0 / dnorm, stpmx);
+        else stp = 1.0;
+        for (int i = 0; i < N; ++i) { tv[i] = xv[i]; t[i] = xv[i]; r[i] = gv[i]; }
+        fold = f;
+        ifun = 0;
+        iback = 0;
+        ls_task = 0;
+        LsState L = LsState{};
+        bool ok;
+        for (;;) {
+            // gd = b_ddot(N, g, d): the sequential FMA chain of the BLAS kernel's tail (N < 16)
+            double dot = 0.0;
+            for (int i = 0; i < N; ++i) dot = pw_fma(dv[i], gv[i], dot);
+            gd = dot;
+            if (ifun == 0) {
+                gdold = gd;
+                if (gd >= 0.0) { info = -4; ok = false; break; }
+            }
+            {
+                const LsOut o = lb_dcsrch_core(L, ls_task, f, gd, stp, ftol, gtol, xtol, 0.0, stpmx);
+                stp = o.st;
+                ls_task = o.task;
+            }
+            if (ls_task == 2 || ls_task == 3) {
+                task = LB_NEW_X;
+                msg = 0;
+                ok = true;
+                break;
+            }
+            task = LB_FG;
+            msg = LBM_FG_LNSRCH;
+            ifun += 1;
+            nfgv += 1;
+            iback = ifun - 1;
+            if (stp == 1.0) {
+                for (int i = 0; i < N; ++i) xv[i] = zv[i];
+            } else {
+                // "take step and prevent rounding error beyond bound" (see lnsrlb)
+                for (int i = 0; i < N; ++i) xv[i] = pw_min(pw_max(stp * dv[i] + tv[i], lev[i]), uev[i]);
+            }
+            if (iback >= maxls) { ok = false; break; }
+            fg(xv, f, gv);
+        }
+        if (ok) {
+            for (int i = 0; i < N; ++i) { x[i] = xv[i]; g[i] = gv[i]; }
+        } else {
+            // (r holds the gradient at the start point: written above, nothing in between touches it)
+            for (int i = 0; i < N; ++i) { x[i] = tv[i]; g[i] = r[i]; }
+            f = fold;
+        }
+        T::wave_sync();
+        return ok;
+    }
+
+    // ---- the driver in direct form: setulb/mainlb and SciPy's loop around it (_lbfgsb_py.py:427-456) -----------
+    // What step() does between two returns, written as the loop it is, with the caller's evaluations as a function
+    // object: no entry dispatch, no state that has to survive a return, and the line search in one piece (above).
+    // SciPy's driver tests maxiter and maxfun at a new iterate only ("interruptions due to maxfun are postponed");
+    // fg.nfev is the evaluation count it compares with maxfun.  On return task / msg say why it stopped (task ==
+    // LB_NEW_X: one of the two limits), nit is the number of iterates.  step() stays: the lockstep tests drive
+    // SciPy's own setulb call by call against it, and every routine it calls is the one called here.
+    template <class T, class FG>
+    PW_HD __attribute__((always_inline)) void minimize(FG& fg, int maxiter, int maxfun, int* nit_out) {
+        PW_ASSUME_LDS(mem);
+        int nit = 0;
+        *nit_out = 0;
+        // task == LB_START
+        epsmch = 2.220446049250313e-16;
+        col = 0; head = 0; theta = 1.0; iupdat = 0; updatd = false;
+        iback = 0; itail = 0; iword = 0; nact = 0; ileave = 0; nenter = 0;
+        fold = 0.0; dnorm = 0.0; gd = 0.0; stpmx = 0.0; sbgnrm = 0.0; stp = 0.0;
+        gdold = 0.0; dtd = 0.0;
+        iter = 0; nfgv = 0; nseg = 0; nintol = 0; nskip = 0; nfree = N; ifun = 0;
+        tol = factr * epsmch;
+        info = 0;
+        ls_task = 0;
+        for (int i = 0; i < N; ++i) { index[i] = 0; indx2[i] = 0; }
+        active();
+        task = LB_FG;
+        msg = LBM_FG_START;
+        T::wave_sync();
+        {
+            double xv[N], gv[N];
+            for (int i = 0; i < N; ++i) xv[i] = x[i];
+            fg(xv, f, gv);
+            for (int i = 0; i < N; ++i) g[i] = gv[i];
+            T::wave_sync();
+        }
+        nfgv = 1;
+        projgr();
+        if (sbgnrm <= pgtol) {
+            task = LB_CONVERGENCE;
+            msg = LBM_CONV_PGTOL;
+            return;
+        }
+        for (;;) {  // label 222
+            iword = -1;
+            bool wrk;
+            if (!cnstnd && col > 0) {
+                b_dcopy(N, x, z);
+                wrk = updatd;
+                nseg = 0;
+            } else {
+                LB_T0(tc);
+                int inf = cauchy<T>();
+                LB_T1(16, tc);
+                if (inf != 0) { refresh(); continue; }
+                nintol += nseg;
+                wrk = freev();
+                nact = N - nfree;
+            }
+            if (!(nfree == 0 || col == 0)) {
+                if (wrk) {
+                    LB_T0(tk);
+                    int inf = formk<T>();
+                    LB_T1(17, tk);
+                    if (inf != 0) { refresh(); continue; }
+                }
+                LB_T0(tm);
+                int inf = cmprlb<T>();
+                LB_T1(18, tm);
+                LB_T0(tsb);
+                if (inf == 0) inf = subsm<T>();
+                LB_T1(19, tsb);
+                if (inf != 0) { refresh(); continue; }
+            }
+            for (int i = 0; i < N; ++i) d[i] = z[i] - x[i];
+            T::wave_sync();
+            LB_T0(tl);
+            const bool newx = linesearch<T>(fg);
+            LB_T1(20, tl);
+            if (!newx) {
+                if (col == 0) {
+                    if (info == 0) {
+                        info = -9;
+                        nfgv -= 1;
+                        ifun -= 1;
+                        iback -= 1;
+                    }
+                    task = LB_ABNORMAL;
+                    msg = 0;
+                    iter += 1;
+                    *nit_out = nit;
+                    return;
+                }
+                if (info == 0) nfgv -= 1;
+                refresh();
+                continue;
+            }
+            iter += 1;
+            projgr();
+            // ---- what SciPy's loop does with a new iterate ----
+            nit += 1;
+            *nit_out = nit;
+            if (nit >= maxiter || fg.nfev > maxfun) return;      // (task stays LB_NEW_X)
+            // ---- 777 ----
+            if (sbgnrm <= pgtol) {
+                task = LB_CONVERGENCE;
+                msg = LBM_CONV_PGTOL;
+                return;
+            }
+            double ddum = pw_max(pw_max(pw_abs(fold), pw_abs(f)), 1.0);
+            if ((fold - f) <= tol * ddum) {
+                task = LB_CONVERGENCE;
+                msg = LBM_CONV_FTOL;
+                if (iback >= 10) info = -5;
+                return;
+            }
+            for (int i = 0; i < N; ++i) r[i] = g[i] - r[i];
+            double rr = b_dnrm2(N, r);
+            rr = rr * rr;
+            double dr;
+            if (stp == 1.0) {
+                dr = gd - gdold;
+                ddum = -gdold;
+            } else {
+                dr = (gd - gdold) * stp;
+                b_dscal(N, stp, d);
+                ddum = -gdold * stp;
+            }
+            if (dr <= epsmch * ddum) {
+                nskip += 1;
+                updatd = false;
+                continue;
+            }
+            updatd = true;
+            iupdat += 1;
+            LB_T0(tu);
+            matupd<T>(rr, dr);
+            LB_T1(21, tu);
+            LB_T0(tf);
+            int inf = formt<T>();
+            LB_T1(22, tf);
+            if (inf != 0) { refresh(); continue; }
+        }
     }
 
     // ---- the driver (setulb/mainlb): call repeatedly ----------------------------------------

@@ -1885,6 +1885,71 @@ PW_HD inline double fd_step(double x, double lb, double ub) {
     return h;
 }
 
+// The objective of opt_pore_diameter as scipy.optimize hands it to L-BFGS-B: f = -pore_diameter(x) and its
+// forward-difference gradient (fd_step), the four points evaluated at once; scipy's ScalarFunction re-uses f and g
+// when asked for the point it evaluated last (_differentiable_functions.py: fun_and_grad).  nfev counts the
+// evaluations as scipy does (what its driver compares with maxfun).
+template <class T>
+struct PoreObjective {
+    const Frame& A;
+    int n;
+    const double* lo;
+    const double* up;
+    PW_LDS int* cand;
+    bool have_last;
+    double lx, ly, lz, lf, lg[3];
+    int nfev;
+    unsigned long long* prof;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_NEAR_GAP)
+    NearGap4<T> near_gap;
+#endif
+    PW_HD PoreObjective(const Frame& A_, int n_, const double* lo_, const double* up_, PW_LDS int* cand_)
+        : A(A_), n(n_), lo(lo_), up(up_), cand(cand_), have_last(false), lx(0.0), ly(0.0), lz(0.0), lf(0.0), nfev(0),
+          prof(nullptr) {
+        lg[0] = lg[1] = lg[2] = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_NEAR_GAP)
+        near_gap.init();
+#endif
+    }
+    PW_HD __attribute__((always_inline)) void operator()(const double* xq, double& fo, double* go) {
+        const double px = xq[0], py = xq[1], pz = xq[2];
+        if (!(have_last && px == lx && py == ly && pz == lz)) {
+            double qx[4] = {px, px, px, px}, qy[4] = {py, py, py, py}, qz[4] = {pz, pz, pz, pz};
+            double dxs[3];
+            for (int c = 0; c < 3; ++c) {
+                double xc = c == 0 ? px : (c == 1 ? py : pz);
+                double h = fd_step(xc, lo[c], up[c]);
+                double x1 = xc + h;
+                dxs[c] = x1 - xc;
+                if (c == 0) qx[1] = x1; else if (c == 1) qy[2] = x1; else qz[3] = x1;
+            }
+            double gv[4];
+#if defined(PW_PROFILE) && defined(PW_LB_FINE) && defined(__HIP_DEVICE_COMPILE__)
+            long long t_g4 = clock64();
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_NEAR_GAP)
+            if (T::WSIZE == 64) near_gap.eval(A, n, cand, qx, qy, qz, gv);
+            else
+#endif
+            wave_gap4<T>(A, n, qx, qy, qz, gv);
+#if defined(PW_PROFILE) && defined(PW_LB_FINE) && defined(__HIP_DEVICE_COMPILE__)
+            if (prof && T::lane() == 0) atomicAdd(&prof[24], (unsigned long long)(clock64() - t_g4));
+#endif
+            double f0 = -(gv[0] * 2.0);
+            for (int c = 0; c < 3; ++c) {
+                double f1 = -(gv[c + 1] * 2.0);
+                lg[c] = (f1 - f0) / dxs[c];
+            }
+            lf = f0;
+            lx = px; ly = py; lz = pz;
+            have_last = true;
+            nfev += 4;
+        }
+        fo = lf;
+        go[0] = lg[0]; go[1] = lg[1]; go[2] = lg[2];
+    }
+};
+
 // ---- stage: optimised pore (wave 0) --------------------------------------------------------
 template <class T>
 PW_HD inline __attribute__((always_inline)) void stage_opt_impl(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
@@ -1924,72 +1989,22 @@ PW_HD inline __attribute__((always_inline)) void stage_opt_impl(UnitShared& sh, 
             bad = !(r > 0.0);
         }
         int nit = 0, nfev = 0;
-        bool have_last = false;
-        double lx = 0.0, ly = 0.0, lz = 0.0, lf = 0.0, lg[3] = {0.0, 0.0, 0.0};
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_NEAR_GAP)
-        NearGap4<T> near_gap;
-        near_gap.init();
-#endif
         if (!bad) {
             S->template setup<T>(Smem, x0, lo, up, nbd, 1e7, 1e-5, 20);
 #ifdef PW_PROFILE
             S->prof = ws->prof;
 #endif
-            for (;;) {
-                PW_T0(t_s);
-                S->template step<T>();
-                T::wave_sync();
-                PW_T1(ws, 0, t_s);
-                if (S->task == LB_FG) {
-                    double px = S->x[0], py = S->x[1], pz = S->x[2];
-                    // scipy's ScalarFunction re-uses f and g when asked for the point it
-                    // evaluated last (_differentiable_functions.py: fun_and_grad)
-                    PW_T0(t_e);
-                    if (!(have_last && px == lx && py == ly && pz == lz)) {
-                        double qx[4] = {px, px, px, px}, qy[4] = {py, py, py, py}, qz[4] = {pz, pz, pz, pz};
-                        double dxs[3];
-                        for (int c = 0; c < 3; ++c) {
-                            double xc = c == 0 ? px : (c == 1 ? py : pz);
-                            double h = fd_step(xc, lo[c], up[c]);
-                            double x1 = xc + h;
-                            dxs[c] = x1 - xc;
-                            if (c == 0) qx[1] = x1; else if (c == 1) qy[2] = x1; else qz[3] = x1;
-                        }
-                        double gv[4];
-#if defined(PW_PROFILE) && defined(PW_LB_FINE)
-                        long long t_g4 = clock64();
+            PoreObjective<T> fg(A, n, lo, up, (PW_LDS int*)Smem->cand);
+#ifdef PW_PROFILE
+            fg.prof = ws->prof;
 #endif
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_NEAR_GAP)
-                        if (T::WSIZE == 64) near_gap.eval(A, n, (PW_LDS int*)Smem->cand, qx, qy, qz, gv);
-                        else
-#endif
-                        wave_gap4<T>(A, n, qx, qy, qz, gv);
-#if defined(PW_PROFILE) && defined(PW_LB_FINE)
-                        if (T::lane() == 0) atomicAdd((unsigned long long*)&ws->prof[24], (unsigned long long)(clock64() - t_g4));
-#endif
-                        double f0 = -(gv[0] * 2.0);
-                        for (int c = 0; c < 3; ++c) {
-                            double f1 = -(gv[c + 1] * 2.0);
-                            lg[c] = (f1 - f0) / dxs[c];
-                        }
-                        lf = f0;
-                        lx = px; ly = py; lz = pz;
-                        have_last = true;
-                        nfev += 4;
-                    }
-                    S->f = lf;
-                    S->g[0] = lg[0]; S->g[1] = lg[1]; S->g[2] = lg[2];
-                    T::wave_sync();
-                    PW_T1(ws, 1, t_e);
-                } else if (S->task == LB_NEW_X) {
-                    // scipy's driver: maxiter = maxfun = 15000, both tested at a new iterate only
-                    // (_lbfgsb_py.py: "interruptions due to maxfun are postponed")
-                    nit += 1;
-                    if (nit >= 15000 || nfev > 15000) break;
-                } else {
-                    break;
-                }
-            }
+            // scipy's driver: maxiter = maxfun = 15000, both tested at a new iterate only
+            // (_lbfgsb_py.py: "interruptions due to maxfun are postponed")
+            PW_T0(t_s);
+            S->template minimize<T>(fg, 15000, 15000, &nit);
+            T::wave_sync();
+            PW_T1(ws, 0, t_s);
+            nfev = fg.nfev;
         }
         double cx = v.com[0], cy = v.com[1], cz = v.com[2];
         if (!bad) { cx = S->x[0]; cy = S->x[1]; cz = S->x[2]; }
@@ -2257,6 +2272,51 @@ PW_NOINLINE PW_HD inline void wave_fmin_xy(const Frame& F, int n, double z, doub
     *n_eval += fcalls;
 }
 
+// The objective of the neck search along z (utilities.py:1296-1303: minimise the diameter at (xo, yo, z)) with its
+// forward-difference derivative, as PoreObjective does for the pore centre.
+template <class T>
+struct NeckObjective {
+    const Frame& R;
+    int n;
+    double xo, yo, lo, up;
+    PW_LDS int* cand;
+    bool have_last;
+    double lz, lf, lg;
+    int nfev;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_NEAR_GAP)
+    NearGap4<T> near_gap;
+#endif
+    PW_HD NeckObjective(const Frame& R_, int n_, double xo_, double yo_, double lo_, double up_, PW_LDS int* cand_)
+        : R(R_), n(n_), xo(xo_), yo(yo_), lo(lo_), up(up_), cand(cand_), have_last(false), lz(0.0), lf(0.0), lg(0.0), nfev(0) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_NEAR_GAP)
+        near_gap.init();
+#endif
+    }
+    PW_HD __attribute__((always_inline)) void operator()(const double* xq, double& fo, double* go) {
+        const double zc = xq[0];
+        if (!(have_last && zc == lz)) {
+            double h = fd_step(zc, lo, up);
+            double z1 = zc + h;
+            double dz = z1 - zc;
+            double zx[4] = {xo, xo, xo, xo}, zy[4] = {yo, yo, yo, yo}, zz[4] = {zc, z1, zc, z1}, gv[4];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_NEAR_GAP)
+            if (T::WSIZE == 64) near_gap.eval(R, n, cand, zx, zy, zz, gv);
+            else
+#endif
+            wave_gap4<T>(R, n, zx, zy, zz, gv);
+            double f0 = gv[0] * 2.0;
+            double f1 = gv[1] * 2.0;
+            nfev += 2;
+            lf = f0;
+            lg = (f1 - f0) / dz;
+            lz = zc;
+            have_last = true;
+        }
+        fo = lf;
+        go[0] = lg;
+    }
+};
+
 // ---- one window (utilities.py:1191-1361), executed by ONE wave -------------------------------
 // per-cluster arrays of the window fits: in the team's LDS (UnitVars) for up to PW_W_MAX clusters, in the
 // team's global slab beyond -- the number of clusters has no upper limit (utilities.py:1481-1536)
@@ -2396,49 +2456,13 @@ PW_NOINLINE PW_HD inline void wave_window(const Frame& FS, const Frame& R, PW_LD
             x01[0] = x01[0] < lo1[0] ? lo1[0] : (x01[0] > up1[0] ? up1[0] : x01[0]);
             S->template setup<T>(Smem, x01, lo1, up1, nbd1, 1e7, 1e-5, 20);
             int nit = 0;
-            bool have_last = false;
-            double lz = 0.0, lf = 0.0, lg = 0.0;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_NEAR_GAP)
-            NearGap4<T> near_gap;       // (its list lives in the optimiser block that setup() just cleared)
-            near_gap.init();
-#endif
-            for (;;) {
-                PW_T0(t_zs);
-                S->template step<T>();
-                T::wave_sync();
-                PW_T1(ws, 4, t_zs);
-                if (S->task == LB_FG) {
-                    PW_T0(t_ze);
-                    double zc = S->x[0];
-                    if (!(have_last && zc == lz)) {
-                        double h = fd_step(zc, lo1[0], up1[0]);
-                        double z1 = zc + h;
-                        double dz = z1 - zc;
-                        double zx[4] = {xo, xo, xo, xo}, zy[4] = {yo, yo, yo, yo}, zz[4] = {zc, z1, zc, z1}, gv[4];
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_NEAR_GAP)
-                        if (T::WSIZE == 64) near_gap.eval(R, n, (PW_LDS int*)Smem->cand, zx, zy, zz, gv);
-                        else
-#endif
-                        wave_gap4<T>(R, n, zx, zy, zz, gv);
-                        double f0 = gv[0] * 2.0;
-                        double f1 = gv[1] * 2.0;
-                        evals += 2;
-                        lf = f0;
-                        lg = (f1 - f0) / dz;
-                        lz = zc;
-                        have_last = true;
-                    }
-                    S->f = lf;
-                    S->g[0] = lg;
-                    T::wave_sync();
-                    PW_T1(ws, 5, t_ze);
-                } else if (S->task == LB_NEW_X) {
-                    nit += 1;
-                    if (nit >= 15000) break;      // (a neck search takes a handful of evaluations)
-                } else {
-                    break;
-                }
-            }
+            // (the candidate list of the objective lives in the optimiser block that setup() just cleared)
+            NeckObjective<T> fg(R, n, xo, yo, lo1[0], up1[0], (PW_LDS int*)Smem->cand);
+            PW_T0(t_zs);
+            S->template minimize<T>(fg, 15000, 15000, &nit);
+            T::wave_sync();
+            PW_T1(ws, 4, t_zs);
+            evals += fg.nfev;
             zopt = S->x[0];
         }
         if (phase == 1) break;
