@@ -61,10 +61,18 @@ def build(force: bool = False, verbose: bool = True) -> pathlib.Path:
         [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread", str(obj_k), str(obj_m), str(obj_b), str(obj_r), str(obj_s), str(obj_h),
          str(obj_c), "-o", str(OUT)],
     ]
-    for cmd in cmds:
+    # the translation units are independent: compile them side by side (PW_BUILD_JOBS, default 4), then link
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(cmd):
         if verbose:
             print("+", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+
+    jobs = max(1, int(os.environ.get("PW_BUILD_JOBS", "4")))
+    with ThreadPoolExecutor(jobs) as pool:
+        list(pool.map(run, cmds[:-1]))
+    run(cmds[-1])
     text = subprocess.run(["strings", str(OUT)], capture_output=True, text=True).stdout
     if "amdgcn-amd-amdhsa--gfx950" not in text:
         raise RuntimeError("built library does not contain a gfx950 code object")

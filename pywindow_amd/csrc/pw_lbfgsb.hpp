@@ -497,11 +497,20 @@ PW_HD inline void lb_dcstep(double& stx, double& fx, double& dx, double& sty, do
             stpf = stpmin;
         }
     }
-    if (fp > fx) {
-        sty = stp; fy = fp; dy = dp;
-    } else {
-        if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
-        stx = stp; fx = fp; dx = dp;
+    // the interval update, as selects on values: written as conditional stores through the reference parameters the
+    // compiler turned it into stores through a selected POINTER, which kept the whole line-search state in scratch
+    // memory on the GPU
+    {
+        const bool hi = fp > fx;
+        const bool sw = !hi && sgnd < 0.0;
+        const double nsty = hi ? stp : (sw ? stx : sty);
+        const double nfy = hi ? fp : (sw ? fx : fy);
+        const double ndy = hi ? dp : (sw ? dx : dy);
+        const double nstx = hi ? stx : stp;
+        const double nfx = hi ? fx : fp;
+        const double ndx = hi ? dx : dp;
+        sty = nsty; fy = nfy; dy = ndy;
+        stx = nstx; fx = nfx; dx = ndx;
     }
     stp = stpf;
 }
@@ -543,20 +552,26 @@ PW_HD inline __attribute__((always_inline)) LsOut lb_dcsrch_core(LsState& L, int
     if (st == stpmin && (fv > ftest || gv >= L.gtest)) ls_task = 3;
     if (fv <= ftest && pw_abs(gv) <= gtol * (-L.ginit)) ls_task = 2;
     if (ls_task == 3 || ls_task == 2) return LsOut{st, ls_task};
-    if (L.stage == 1 && fv <= L.fx && fv > ftest) {
-        double fm = fv - st * L.gtest;
-        double fxm = L.fx - L.stx * L.gtest;
-        double fym = L.fy - L.sty * L.gtest;
-        double gm = gv - L.gtest;
-        double gxm = L.gx - L.gtest;
-        double gym = L.gy - L.gtest;
-        lb_dcstep(L.stx, fxm, gxm, L.sty, fym, gym, st, fm, gm, L.brackt, L.stmin, L.stmax);
-        L.fx = fxm + L.stx * L.gtest;
-        L.fy = fym + L.sty * L.gtest;
-        L.gx = gxm + L.gtest;
-        L.gy = gym + L.gtest;
-    } else {
-        lb_dcstep(L.stx, L.fx, L.gx, L.sty, L.fy, L.gy, st, fv, gv, L.brackt, L.stmin, L.stmax);
+    {
+        // dcstep on the function itself or, in the first stage while the sufficient-decrease test fails, on the
+        // modified function (minus gtest * step).  ONE call either way, its operands chosen by selects: with a call
+        // in each branch the compiler merged the two inlined copies behind pointers to the operands, and the state
+        // they pointed to lived in scratch memory.
+        const bool mod = L.stage == 1 && fv <= L.fx && fv > ftest;
+        double fp = mod ? fv - st * L.gtest : fv;
+        double fxw = mod ? L.fx - L.stx * L.gtest : L.fx;
+        double fyw = mod ? L.fy - L.sty * L.gtest : L.fy;
+        double dp = mod ? gv - L.gtest : gv;
+        double gxw = mod ? L.gx - L.gtest : L.gx;
+        double gyw = mod ? L.gy - L.gtest : L.gy;
+        double stx = L.stx, sty = L.sty;
+        int brackt = L.brackt;
+        lb_dcstep(stx, fxw, gxw, sty, fyw, gyw, st, fp, dp, brackt, L.stmin, L.stmax);
+        L.stx = stx; L.sty = sty; L.brackt = brackt;
+        L.fx = mod ? fxw + stx * L.gtest : fxw;
+        L.fy = mod ? fyw + sty * L.gtest : fyw;
+        L.gx = mod ? gxw + L.gtest : gxw;
+        L.gy = mod ? gyw + L.gtest : gyw;
     }
     if (L.brackt) {
         if (pw_abs(L.sty - L.stx) >= p66 * L.width1) st = L.stx + p5 * (L.sty - L.stx);
@@ -1754,6 +1769,7 @@ struct Lbfgsb {
     template <class T, class FG>
     PW_HD __attribute__((always_inline)) bool linesearch(FG& fg) {
         PW_ASSUME_LDS(mem);
+        LB_F0(fh);
         const double big = 1.0e10, ftol = 1.0e-3, gtol = 0.9, xtol = 0.1;
         double dv[N], xv[N], zv[N], gv[N], tv[N], lev[N], uev[N];
         int nbv[N];
@@ -1792,6 +1808,7 @@ struct Lbfgsb {
         ls_task = 0;
         LsState L = LsState{};
         bool ok;
+        LB_F1(26, fh);
         for (;;) {
             // gd = b_ddot(N, g, d): the sequential FMA chain of the BLAS kernel's tail (N < 16)
             double dot = 0.0;
@@ -1801,11 +1818,13 @@ struct Lbfgsb {
                 gdold = gd;
                 if (gd >= 0.0) { info = -4; ok = false; break; }
             }
+            LB_F0(fl);
             {
                 const LsOut o = lb_dcsrch_core(L, ls_task, f, gd, stp, ftol, gtol, xtol, 0.0, stpmx);
                 stp = o.st;
                 ls_task = o.task;
             }
+            LB_F1(23, fl);
             if (ls_task == 2 || ls_task == 3) {
                 task = LB_NEW_X;
                 msg = 0;
@@ -1824,7 +1843,9 @@ struct Lbfgsb {
                 for (int i = 0; i < N; ++i) xv[i] = pw_min(pw_max(stp * dv[i] + tv[i], lev[i]), uev[i]);
             }
             if (iback >= maxls) { ok = false; break; }
+            LB_F0(fe);
             fg(xv, f, gv);
+            LB_F1(25, fe);
         }
         if (ok) {
             for (int i = 0; i < N; ++i) { x[i] = xv[i]; g[i] = gv[i]; }
