@@ -174,7 +174,8 @@ PW_HD inline void b_dtrsv_ut(int n, const double* a, int lda, double* x) {
 // solved (FMA chain from zero, then one subtraction) followed by a
 // right-looking solve that multiplies by the pre-inverted diagonal.  n <= 15
 // here (no full 16-row block), which covers col <= m = 10.
-PW_HD inline void b_dtrsm_ut_col(int n, const double* a, int lda, double* x) {
+// dinv: the reciprocals 1 / a(i, i) where the caller has them tabulated (the same quotients), else null.
+PW_HD inline void b_dtrsm_ut_col(int n, const double* a, int lda, double* x, const double* dinv = nullptr) {
     int s = 0;
     for (int bs = 8; bs > 0; bs >>= 1) {
         if (!(n & bs)) continue;
@@ -188,7 +189,7 @@ PW_HD inline void b_dtrsm_ut_col(int n, const double* a, int lda, double* x) {
             }
         }
         for (int i = s; i < e; ++i) {
-            x[i] = x[i] * (1.0 / a[i + (long)i * lda]);
+            x[i] = x[i] * (dinv ? dinv[i] : 1.0 / a[i + (long)i * lda]);
             double nx = -x[i];
             for (int k = i + 1; k < e; ++k) x[k] = pw_fma(nx, a[i + (long)k * lda], x[k]);
         }

@@ -44,9 +44,13 @@
 #if defined(PW_PROFILE) && defined(PW_LB_FINE) && defined(__HIP_DEVICE_COMPILE__)
 #define LB_F0(var) long long var = clock64()
 #define LB_F1(slot, var) do { if (prof && T::lane() == 0) atomicAdd(&prof[slot], (unsigned long long)(clock64() - var)); } while (0)
+#define LB_M0(var) long long var = clock64()
+#define LB_M1(slot, var) do { if (m->prof_fine && T::lane() == 0) atomicAdd(&m->prof_fine[slot], (unsigned long long)(clock64() - var)); } while (0)
 #else
 #define LB_F0(var) do {} while (0)
 #define LB_F1(slot, var) do {} while (0)
+#define LB_M0(var) do {} while (0)
+#define LB_M1(slot, var) do {} while (0)
 #endif
 
 namespace pw {
@@ -99,8 +103,12 @@ struct LbMem {
     // square root, the diagonals of the factors WT and WN.  Device teams only (tables()); rebuilt wherever the
     // matrix is (matupd, formt, formk).
     double dsy[M], rsy[M], sqy[M], rsq[M], rwt[M], rwn[M2];
+    double iwn[M];      // 1 / WN(i, i), i < col: the quotients potf2 scales its rows with, which trsm's solve multiplies by
     double le[N], ue[N];    // the bounds a line-search iterate is put back on: l / u where there is one, -inf / +inf else
     LsState ls;
+#if defined(PW_PROFILE) && defined(PW_LB_FINE)
+    unsigned long long* prof_fine;  // sub-phase timers of the out-of-line wave routines (diagnostic builds only)
+#endif
     int cand[32];       // atoms that can hold the minimum near the current reference point (pw_unit.hpp: NearGap4)
     int nbd[N];
     int index[N], iwhere[N], indx2[N];
@@ -289,6 +297,7 @@ __device__ inline __attribute__((always_inline)) int lb_bmv_body(LbMem<N>* m, in
         const unsigned long long z = T::ballot(act && m->wt[li + M * li] == 0.0);      // dtrtrs' singularity test
         if (z) return (int)__builtin_ctzll(z) + 1;
     }
+    LB_M0(tb0);
     const double vi = act ? v[li] : 0.0, vc = act ? v[col + li] : 0.0;
     unsigned emin = 0x3ff00000u, emax = 0x3ff00000u;      // exponent range of the dividends (SPEC)
     // p[col + i] = v[col + i] + sum_{k < i} SY(i, k) * v[k] / SY(k, k)
@@ -312,10 +321,16 @@ __device__ inline __attribute__((always_inline)) int lb_bmv_body(LbMem<N>* m, in
     }
     double xk = lane == 0 ? vc : vc + sum;
     double t_ut = 1.0, t_un = 1.0;
+    LB_M1(3, tb0);
+    LB_M0(tb1);
     xk = lb_solve_ut_reg<T, M, SPEC>(col, m->wt, M, m->rwt, xk, &t_ut);
+    LB_M1(4, tb1);
+    LB_M0(tb2);
     const double sq = act ? m->sqy[li] : 1.0, rs = act ? m->rsq[li] : 1.0;
     const double pa = SPEC ? pw_div_ru(vi, sq, rs) : pw_div_r(vi, sq, rs);
     xk = lb_solve_un_reg<T, M, SPEC>(col, m->wt, M, m->rwt, xk, &t_un);
+    LB_M1(5, tb2);
+    LB_M0(tb3);
     // p[i] = -p[i] / sqrt(SY(i, i)) + sum_{k > i} SY(k, i) * p[col + k] / SY(i, i)
     const double pi = SPEC ? pw_div_ru(-pa, sq, rs) : pw_div_r(-pa, sq, rs);
     const double dsi = act ? m->dsy[li] : 1.0, rsi = act ? m->rsy[li] : 1.0;
@@ -358,6 +373,7 @@ __device__ inline __attribute__((always_inline)) int lb_bmv_body(LbMem<N>* m, in
         p[col + lane] = xk;
     }
     T::wave_sync();
+    LB_M1(6, tb3);
     return 0;
 }
 template <class T, int N>
@@ -423,6 +439,88 @@ PW_NOINLINE __device__ inline int lb_subsm_solves_wave(LbMem<N>* m, int col, dou
     if (r >= 0) return r;
     return lb_subsm_solves_wave_guarded<T, N>(m, col, wv);
 }
+// ---- Cholesky factorisation of order <= 10 by one wave, the matrix in registers --------------------------------
+// potf2 'U' as b_dpotrf_u / Lbfgsb::p_dpotrf_u do it (lapack/potf2/potf2_U.c with the dgemv_t micro-kernels of
+// pw_blas.hpp), lane k holding column k of the upper triangle: the pivot's column travels by v_readlane, a column's
+// running inner product (b_ddot's sequential FMA chain, i ascending) is kept up to date as its entries become final,
+// and nothing goes through team memory between the first load and the last store -- the LDS form pays two round
+// trips and two wave-level syncs per column.  For n <= 10 the three dgemv_t micro-kernels give the same bits where
+// they can occur: with four rows done (m1 == 4) 4x4, 4x2 and 4x1 all compute (l0 + l2) + (l1 + l3) of separately
+// rounded products, and with eight (m1 == 8, pivots 8 and 9) at most one column is left, which is the 4x1 kernel.
+// Also leaves the tables the solves want: rtab[j] = pw_recip_hw(U(j, j)) and, if asked for, itab[j] = 1 / U(j, j)
+// (the quotient potf2 itself scales the row with).  Returns 0, or -1 when a pivot was not positive: nothing has been
+// written then and the caller takes the team-memory routine, which leaves what LAPACK leaves.
+template <class T, int N>
+PW_NOINLINE __device__ inline int lb_potrf_wave(LbMem<N>* m, double* a, int lda, int n, double* rtab, double* itab) {
+    constexpr int NMAX = LB_M;
+    m = lb_uniform(m); a = lb_uniform(a); rtab = lb_uniform(rtab); itab = lb_uniform(itab);
+    lda = lb_uniform(lda); n = lb_uniform(n);
+    PW_ASSUME_LDS(m);
+    PW_ASSUME_LDS(a);
+    PW_ASSUME_LDS(rtab);
+    const int lane = T::lane();
+    const bool act = lane < n;
+    const int li = act ? lane : 0;
+    double c[NMAX];
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) c[i] = a[i + li * lda];      // (rows below the diagonal: never used, never stored)
+    double dsum = 0.0;          // b_ddot(j, column, column) of MY column, as far as its entries are final
+    double inv_mine = 1.0, piv_mine = 1.0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        if (j >= n) continue;
+        // pivot: lane j's c[j] - ddot(j, cj, cj)
+        const double ajj = T::bcast_u(c[j] - dsum, j);
+        bad = bad || !(ajj > 0.0);
+        const double sq = pw_sqrt(ajj);
+        const double inv = 1.0 / sq;
+        // the pivot column's finished entries, for the product with the columns to its right
+        double x[NMAX];
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i) x[i] = i < j ? T::bcast_u(c[i], j) : 0.0;
+        // b_dgemv_t_elem(m = j, ...) on my column: y = c[j] - sum_i c[i] x[i] in the micro-kernels' association
+        double yk = c[j];
+        const int m1 = j & -4, m3 = j & 3;
+        if (m1) {
+            double l0 = c[0] * x[0], l1 = c[1] * x[1], l2 = c[2] * x[2], l3 = c[3] * x[3];
+            if (m1 == 8) {
+                l0 = l0 + c[4] * x[4];
+                l1 = l1 + c[5] * x[5];
+                l2 = l2 + c[6] * x[6];
+                l3 = l3 + c[7] * x[7];
+            }
+            yk = yk - ((l0 + l2) + (l1 + l3));
+        }
+        if (m3 == 1) {
+            yk = pw_fma(c[m1], -x[m1], yk);
+        } else if (m3 == 2) {
+            double t = c[m1 + 1] * (-x[m1 + 1]);
+            t = pw_fma(c[m1], -x[m1], t);
+            yk = yk + t;
+        } else if (m3 == 3) {
+            double t = c[m1 + 1] * (-x[m1 + 1]);
+            t = pw_fma(c[m1], -x[m1], t);
+            t = pw_fma(c[m1 + 2], -x[m1 + 2], t);
+            yk = yk + t;
+        }
+        const double cj = lane > j ? yk * inv : (lane == j ? sq : c[j]);
+        c[j] = cj;
+        dsum = lane > j ? pw_fma(cj, cj, dsum) : dsum;
+        inv_mine = lane == j ? inv : inv_mine;
+        piv_mine = lane == j ? sq : piv_mine;
+    }
+    if (T::ballot(bad) != 0ull) return -1;
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i)
+            if (i <= lane) a[i + lane * lda] = c[i];
+        rtab[lane] = pw_recip_hw(piv_mine);
+        if (itab) itab[lane] = inv_mine;
+    }
+    T::wave_sync();
+    return 0;
+}
 #endif
 
 // ---- dcstep (More'-Thuente safeguarded step) -----------------------------------
@@ -430,7 +528,13 @@ PW_HD inline void lb_dcstep(double& stx, double& fx, double& dx, double& sty, do
                          double& dy, double& stp, double fp, double dp, int& brackt,
                          double stpmin, double stpmax) {
     double gamma, p, q, rr, s, sgnd, stpc, stpf, stpq, th;
-    sgnd = dp * (dx / pw_abs(dx));
+    // dx / |dx| is +-1 exactly for every finite non-zero dx (0 / 0 and inf / inf: the division itself, a NaN)
+    {
+        const double adx = pw_abs(dx);
+        double unit = dx < 0.0 ? -1.0 : 1.0;
+        if (__builtin_expect(!(adx > 0.0 && adx < PW_INF), 0)) unit = dx / adx;
+        sgnd = dp * unit;
+    }
     if (fp > fx) {
         th = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
         s = pw_max(pw_max(pw_abs(th), pw_abs(dx)), pw_abs(dp));
@@ -768,8 +872,10 @@ struct Lbfgsb {
             T::wave_sync();
         }
     }
+    // dinv: 1 / a(i, i) where the caller has them tabulated (the quotients trsm forms itself otherwise), else null
     template <class T>
-    PW_HD int p_dtrtrs_u(bool trans, int n, int nrhs, const double* a, int lda, double* b, int ldb) {
+    PW_HD int p_dtrtrs_u(bool trans, int n, int nrhs, const double* a, int lda, double* b, int ldb,
+                         const double* dinv = nullptr) {
         PW_ASSUME_LDS(mem);
         for (int i = 0; i < n; ++i)
             if (a[i + (long)i * lda] == 0.0) return i + 1;
@@ -777,10 +883,30 @@ struct Lbfgsb {
             if (trans) p_dtrsv_ut<T>(n, a, lda, b);
             else p_dtrsv_un<T>(n, a, lda, b);
         } else {
-            for (int c = T::lane(); c < nrhs; c += T::WSIZE) b_dtrsm_ut_col(n, a, lda, b + (long)c * ldb);
+            for (int c = T::lane(); c < nrhs; c += T::WSIZE) b_dtrsm_ut_col(n, a, lda, b + (long)c * ldb, dinv);
             T::wave_sync();
         }
         return 0;
+    }
+
+    // ---- the three Cholesky factorisations: WT (which = 1), the first and the second diagonal block of WN (2, 3) ----
+    // with the tables the solves use.  One wave: the matrix in registers (lb_potrf_wave); else, and when a pivot is
+    // not positive, the team-memory routine.
+    template <class T>
+    PW_HD int factor(int which) {
+        PW_ASSUME_LDS(mem);
+        double* a = which == 1 ? wt : (which == 2 ? wn : &WN(col, col));
+        const int lda = which == 1 ? M : M2;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_LB_OLD_SOLVES) && !defined(PW_LB_OLD_POTRF)
+        if (T::WSIZE == 64) {
+            double* rt = which == 1 ? mem->rwt : (which == 2 ? mem->rwn : mem->rwn + col);
+            double* it = which == 2 ? mem->iwn : (double*)nullptr;
+            if (lb_potrf_wave<LbWave, N>(mem, a, lda, col, rt, it) == 0) return 0;
+        }
+#endif
+        const int inf = p_dpotrf_u<T>(col, a, lda);
+        if (inf == 0) tables<T>(which);
+        return inf;
     }
 
     // ---- tables of divisors and their reciprocals (device teams; LbMem) -----
@@ -800,6 +926,7 @@ struct Lbfgsb {
                     mem->rwt[i] = pw_recip_hw(WT(i, i));
                 } else if (which == 2) {
                     mem->rwn[i] = pw_recip_hw(WN(i, i));
+                    mem->iwn[i] = 1.0 / WN(i, i);
                 } else {
                     mem->rwn[col + i] = pw_recip_hw(WN(col + i, col + i));
                 }
@@ -1303,6 +1430,10 @@ struct Lbfgsb {
             T::wave_sync();
         }
         int upcl = updatd ? col - 1 : col;
+        // (no variable entered or left the free set -- the rule while no bound is active: every sum below is an
+        // empty one, and x + 0 - 0 = x for the entries of WN1, none of which is a negative zero -- they are sums
+        // that start from +0 -- so the two loops are skipped)
+        if (nenter > 0 || ileave <= N) {
         // modify the old parts in blocks (1,1) and (2,2): pairs (iy, jy <= iy)
         for (int e = T::lane(); e < upcl * upcl; e += T::WSIZE) {
             int iy = e / upcl, jy = e % upcl;
@@ -1340,6 +1471,7 @@ struct Lbfgsb {
             if (is <= jy + M) WN1(is, jy) = WN1(is, jy) + temp1 - temp3;
             else WN1(is, jy) = WN1(is, jy) - temp1 + temp3;
         }
+        }
         T::wave_sync();
         // form the upper triangle of WN from WN1: pairs (iy, jy)
         for (int e = T::lane(); e < col * col; e += T::WSIZE) {
@@ -1358,13 +1490,16 @@ struct Lbfgsb {
         T::wave_sync();
         LB_F1(8, fk1);
         LB_F0(fk2);
-        int inf = p_dpotrf_u<T>(col, wn, M2);
+        int inf = factor<T>(2);
         LB_F1(9, fk2);
         if (inf != 0) return -1;
-        tables<T>(2);
         int col2 = 2 * col;
         LB_F0(fk3);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_LB_OLD_SOLVES) && !defined(PW_LB_OLD_POTRF)
+        inf = p_dtrtrs_u<T>(true, col, col, wn, M2, &WN(0, col), M2, T::WSIZE == 64 ? mem->iwn : (const double*)nullptr);
+#else
         inf = p_dtrtrs_u<T>(true, col, col, wn, M2, &WN(0, col), M2);
+#endif
         LB_F1(10, fk3);
         LB_F0(fk4);
         for (int e = T::lane(); e < col * col; e += T::WSIZE) {
@@ -1373,11 +1508,10 @@ struct Lbfgsb {
             WN(is, js) = WN(is, js) + b_ddot(col, &WN(0, is), &WN(0, js));
         }
         T::wave_sync();
-        inf = p_dpotrf_u<T>(col, &WN(col, col), M2);
+        inf = factor<T>(3);
         LB_F1(11, fk4);
         (void)col2;
         if (inf != 0) return -2;
-        tables<T>(3);
         return 0;
     }
 
@@ -1451,6 +1585,7 @@ struct Lbfgsb {
         double* xs = z;   // on entry the Cauchy point, on exit the subspace minimiser
         if (nsub <= 0) return 0;
         T::wave_sync();
+        LB_F0(fsh);
         for (int i = T::lane(); i < col; i += T::WSIZE) {
             int pi = (head + i) % M;
             double temp1 = 0.0, temp2 = 0.0;
@@ -1463,6 +1598,7 @@ struct Lbfgsb {
             wv[col + i] = theta * temp2;
         }
         T::wave_sync();
+        LB_F1(29, fsh);
         int col2 = 2 * col;
         LB_F0(fs1);
         int inf;
@@ -1480,6 +1616,7 @@ struct Lbfgsb {
         }
         LB_F1(12, fs1);
         if (inf != 0) return inf;
+        LB_F0(fst);
 #ifdef PW_NO_SPREAD_SUBSM
         if (false) {
 #else
@@ -1539,6 +1676,7 @@ struct Lbfgsb {
                 xs[k] = xk + dk;
             }
         }
+        LB_F1(30, fst);
         if (iword == 0) return 0;
         double dd_p = 0.0;
         for (int i = 0; i < N; ++i) dd_p = dd_p + (xs[i] - x[i]) * g[i];
@@ -1743,9 +1881,8 @@ struct Lbfgsb {
             }
         }
         T::wave_sync();
-        int inf = p_dpotrf_u<T>(col, wt, M);
+        int inf = factor<T>(1);
         if (inf != 0) return -3;
-        tables<T>(1);
         return 0;
     }
 

@@ -1914,16 +1914,33 @@ struct PoreObjective {
     PW_HD __attribute__((always_inline)) void operator()(const double* xq, double& fo, double* go) {
         const double px = xq[0], py = xq[1], pz = xq[2];
         if (!(have_last && px == lx && py == ly && pz == lz)) {
+            LB_F0(f_pre);
             double qx[4] = {px, px, px, px}, qy[4] = {py, py, py, py}, qz[4] = {pz, pz, pz, pz};
             double dxs[3];
+            // the usual case first, all three coordinates with one branch: the step 1e-8 is representable at x, x + h
+            // stays inside the box and fits it -- fd_step then returns h = 1e-8 as it is
+            bool plain = true;
+            double x1s[3];
             for (int c = 0; c < 3; ++c) {
-                double xc = c == 0 ? px : (c == 1 ? py : pz);
-                double h = fd_step(xc, lo[c], up[c]);
-                double x1 = xc + h;
-                dxs[c] = x1 - xc;
-                if (c == 0) qx[1] = x1; else if (c == 1) qy[2] = x1; else qz[3] = x1;
+                const double xc = c == 0 ? px : (c == 1 ? py : pz);
+                const double xh = xc + 1e-8;
+                x1s[c] = xh;
+                dxs[c] = xh - xc;
+                plain = plain && (dxs[c] != 0.0) && !(xh < lo[c]) && !(xh > up[c]) &&
+                        (1e-8 <= pw_max(xc - lo[c], up[c] - xc));
             }
+            if (!plain) {
+                for (int c = 0; c < 3; ++c) {
+                    double xc = c == 0 ? px : (c == 1 ? py : pz);
+                    double h = fd_step(xc, lo[c], up[c]);
+                    double x1 = xc + h;
+                    dxs[c] = x1 - xc;
+                    x1s[c] = x1;
+                }
+            }
+            qx[1] = x1s[0]; qy[2] = x1s[1]; qz[3] = x1s[2];
             double gv[4];
+            LB_F1(27, f_pre);
 #if defined(PW_PROFILE) && defined(PW_LB_FINE) && defined(__HIP_DEVICE_COMPILE__)
             long long t_g4 = clock64();
 #endif
@@ -1935,6 +1952,7 @@ struct PoreObjective {
 #if defined(PW_PROFILE) && defined(PW_LB_FINE) && defined(__HIP_DEVICE_COMPILE__)
             if (prof && T::lane() == 0) atomicAdd(&prof[24], (unsigned long long)(clock64() - t_g4));
 #endif
+            LB_F0(f_post);
             double f0 = -(gv[0] * 2.0);
             for (int c = 0; c < 3; ++c) {
                 double f1 = -(gv[c + 1] * 2.0);
@@ -1944,6 +1962,7 @@ struct PoreObjective {
             lx = px; ly = py; lz = pz;
             have_last = true;
             nfev += 4;
+            LB_F1(28, f_post);
         }
         fo = lf;
         go[0] = lg[0]; go[1] = lg[1]; go[2] = lg[2];
@@ -1993,6 +2012,9 @@ PW_HD inline __attribute__((always_inline)) void stage_opt_impl(UnitShared& sh, 
             S->template setup<T>(Smem, x0, lo, up, nbd, 1e7, 1e-5, 20);
 #ifdef PW_PROFILE
             S->prof = ws->prof;
+#endif
+#if defined(PW_PROFILE) && defined(PW_LB_FINE)
+            Smem->prof_fine = ws->prof;
 #endif
             PoreObjective<T> fg(A, n, lo, up, (PW_LDS int*)Smem->cand);
 #ifdef PW_PROFILE

@@ -35,9 +35,10 @@ L.pw_debug_stage_ticks(ctx._h, buf)
 t = np.array(list(buf), float) / 2    # two launches (warm-up + timed)
 nit = float(recs["opt_nit"].mean()); nfg = float(recs["opt_nfev"].mean()) / 4
 coarse = {0: "opt.step", 1: "opt.eval", 16: "lb.cauchy", 17: "lb.formk", 18: "lb.cmprlb", 19: "lb.subsm", 20: "lb.lnsrlb", 21: "lb.matupd", 22: "lb.formt"}
-fine = {2: "bmv(all calls)", 3: "bmv.A lower sum", 4: "bmv.trsv_ut", 5: "bmv.trsv_un", 6: "bmv.E upper sum", 7: "cauchy.head", 15: "cauchy.ddot",
+fine = {2: "bmv(all calls)", 3: "bmv.loads+lower sum", 4: "bmv.solve_ut", 5: "bmv.solve_un", 6: "bmv.upper sum+check+store", 7: "cauchy.head", 15: "cauchy.ddot",
         14: "cauchy.tail", 8: "formk.wn1+wn", 9: "formk.potrf1", 10: "formk.trtrs", 11: "formk.syrk+potrf2", 12: "subsm.trsv x2", 13: "cmprlb.tail",
-        23: "lnsrlb.dcsrch", 24: "eval.wave_gap4", 25: "lnsrlb.fg(all of it)", 26: "lnsrlb.head"}
+        23: "lnsrlb.dcsrch", 24: "eval.wave_gap4", 25: "lnsrlb.fg(all of it)", 26: "lnsrlb.head", 27: "fg.pre(fd steps)", 28: "fg.post(gradient)",
+        29: "subsm.head", 30: "subsm.tail"}
 out = {"units": n, "kernel_ms": ms, "mean_nit": nit, "mean_fg_calls": nfg,
        "us_per_unit(100MHz)": {v: round(t[k] / 100.0 / n, 2) for k, v in coarse.items()},
        "kcycles_per_unit": {v: round(t[k] / 1000.0 / n, 1) for k, v in fine.items()},
