@@ -65,6 +65,8 @@ extern "C" {
 #define PW_E_TOO_LARGE (-4) /* a molecule has more atoms than fit in LDS */
 #define PW_E_NOMEM (-5)
 #define PW_E_RETRY (-6)     /* a capacity was grown for this batch: launch the analysis again, then download */
+#define PW_E_TIMEOUT (-7)   /* a launch of the pipeline gave up waiting for another one (pw_last_error names the wait);
+                               the records are incomplete: repeat the analysis (pw_context_retries counts repeats) */
 
 /* stage selection bits for pw_analysis_* */
 #define PW_STAGE_BASIC 1u   /* molecular_weight, center_of_mass, max_dim, pore_diameter */
@@ -221,6 +223,18 @@ int pw_context_pipelined(pw_context *ctx);
  * head gates << 16 | residency gates << 32).  A gate is never a dependency - a time-out costs 20 ms (2 s for a
  * residency gate) and changes no result; zero on a healthy device. */
 int pw_context_gate_timeouts(pw_context *ctx, uint64_t *count);
+/* How many analyses were REPEATED on this context after a launch gave up waiting for another one (PW_E_TIMEOUT):
+ * by pw_analysis_batch / pw_analysis_debug themselves (they repeat once), and by callers of the pw_resident_*
+ * entry points, who repeat on PW_E_TIMEOUT and say so with pw_context_count_retry.  Zero on a healthy device;
+ * pw_retries_total() is the same over every context of the process.  (The reference has nothing to compare:
+ * its Pool workers either return or raise, trajectory.py:553-586.) */
+int pw_context_retries(pw_context *ctx, uint64_t *count);
+int pw_context_count_retry(pw_context *ctx);
+uint64_t pw_retries_total(void);
+/* diagnostic: the hand-off queues of the pipeline's sets as they are now -- out[4 * s + 0..3] = units taken by
+ * window teams (head), published by optimiser chains (tail), optimiser teams started, error flag of set s;
+ * s < 4 (cap >= 16).  Reads device memory without waiting for anything. */
+int pw_context_queue_state(pw_context *ctx, uint64_t *out, int cap);
 /* sampling vectors the team workspaces of this context currently hold per molecule (>= PW_P_MAX) */
 int pw_context_point_capacity(pw_context *ctx);
 /* at least n_points sampling vectors per molecule in the workspaces of every later launch.  pw_analysis_batch
@@ -236,7 +250,7 @@ int pw_context_reserve_points(pw_context *ctx, int64_t n_points);
  * append: coordinates [count][template_atoms][3] of units first .. first + count - 1, `first` = the number appended
  * so far; the call returns when the copy has landed (from page-locked memory, pw_context_pinned, a DMA of tens of
  * microseconds per megabyte) and the buffer may be reused.  Downloading an incomplete batch is PW_E_BAD_ARG; a
- * launch that waits 5 s for a unit gives up and the download reports it (PW_E_HIP).  Device contexts only;
+ * launch that waits 5 s for a unit gives up and the download reports it (PW_E_TIMEOUT).  Device contexts only;
  * molecules beyond LDS (PW_E_TOO_LARGE) go through pw_resident_upload.  On a context that runs an analysis as ONE
  * launch (pw_context_pipelined() == 0), or for stages without the window search, a launch asked for before the last
  * unit has arrived is made by the append that completes the batch (nothing overlaps, nothing waits). */
@@ -285,7 +299,7 @@ int pw_resident_stage_times(pw_context *ctx, pw_resident *res, float *ms3);
 /* raw device pointer of the result records (for RCCL gathers by the host side) */
 void *pw_resident_device_results(pw_resident *res);
 /* For callers that read the records on the device (pw_resident_results_ready): waits for the latest
- * launch of the batch, fails with PW_E_HIP if its window launch timed out, and loads its windows beyond
+ * launch of the batch, fails with PW_E_TIMEOUT if its window launch timed out, and loads its windows beyond
  * PW_W_MAX into the context's list (*count of them; pw_context_extra_windows reads them).  PW_E_RETRY: the
  * device list for them has just been allocated -- launch again.  pw_resident_download does all of this. */
 int pw_resident_extra_windows(pw_context *ctx, pw_resident *res, int64_t *count);

@@ -31,6 +31,7 @@ ST_PATH_TOO_LONG = 128
 
 E_RETRY = -6
 E_HIP = -3
+E_TIMEOUT = -7
 DBSCAN_MAX = 8192
 
 _PKG = pathlib.Path(__file__).resolve().parent
@@ -43,6 +44,10 @@ class PwHipError(RuntimeError):
 
 class PwRetry(PwHipError):
     """``PW_E_RETRY``: a capacity was grown for this batch; launch the analysis again."""
+
+
+class PwTimeoutError(PwHipError):
+    """``PW_E_TIMEOUT``: a launch of the pipeline gave up waiting for another one; the records are incomplete."""
 
 
 class BatchIn(ctypes.Structure):
@@ -225,6 +230,10 @@ EXPORTED_SYMBOLS = [
     "pw_context_reserve_points",
     "pw_context_pipelined",
     "pw_context_gate_timeouts",
+    "pw_context_retries",
+    "pw_context_count_retry",
+    "pw_retries_total",
+    "pw_context_queue_state",
     "pw_analysis_debug",
     "pw_point_gaps",
     "pw_pairwise_sum",
@@ -330,6 +339,11 @@ def load():
     L.pw_context_reserve_points.argtypes = [vp, ctypes.c_int64]
     L.pw_context_pipelined.argtypes = [vp]
     L.pw_context_gate_timeouts.argtypes = [vp, vp]
+    L.pw_context_retries.argtypes = [vp, vp]
+    L.pw_context_count_retry.argtypes = [vp]
+    L.pw_retries_total.argtypes = []
+    L.pw_retries_total.restype = ctypes.c_uint64
+    L.pw_context_queue_state.argtypes = [vp, vp, ctypes.c_int]
     L.pw_point_gaps.argtypes = [vp, ctypes.POINTER(BatchIn), vp, vp, ctypes.c_int64, vp, vp]
     L.pw_pairwise_sum.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int, vp]
     L.pw_dbscan.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_double, ctypes.c_int, vp, vp]
@@ -380,7 +394,15 @@ def load():
 def _check(rc: int, what: str):
     if rc != 0:
         msg = load().pw_last_error().decode(errors="replace")
+        if rc == E_TIMEOUT:
+            raise PwTimeoutError(f"{what} failed with code {rc}: {msg}")
         raise PwHipError(f"{what} failed with code {rc}: {msg}")
+
+
+def retries_total() -> int:
+    """Analyses repeated after a launch gave up waiting for another one (``PW_E_TIMEOUT``), over every context
+    of this process.  Zero on a healthy device."""
+    return int(load().pw_retries_total())
 
 
 def _dptr(a):
@@ -495,6 +517,20 @@ class Context:
         v = ctypes.c_uint64(0)
         _check(load().pw_context_gate_timeouts(self._h, ctypes.byref(v)), "pw_context_gate_timeouts")
         return {"tail": int(v.value & 0xffff), "head": int((v.value >> 16) & 0xffff), "residency": int(v.value >> 32)}
+
+    @property
+    def retries(self) -> int:
+        """Analyses repeated on this context after ``PW_E_TIMEOUT`` (by the library or by this binding)."""
+        v = ctypes.c_uint64(0)
+        _check(load().pw_context_retries(self._h, ctypes.byref(v)), "pw_context_retries")
+        return int(v.value)
+
+    def queue_state(self) -> list:
+        """Diagnostic: the hand-off queues of the pipeline's sets as they are now."""
+        buf = (ctypes.c_uint64 * 16)()
+        _check(load().pw_context_queue_state(self._h, buf, 16), "pw_context_queue_state")
+        return [{"set": b, "taken": int(buf[4 * b]), "published": int(buf[4 * b + 1]), "started": int(buf[4 * b + 2]),
+                 "error": int(buf[4 * b + 3])} for b in range(4)]
 
     def reserve_points(self, n_points: int) -> None:
         """At least ``n_points`` sampling vectors per molecule in the workspaces of every later launch
@@ -748,12 +784,14 @@ class Resident:
                 if rc == E_RETRY:
                     self.launch(getattr(self, "_stages", STAGE_ALL))
                     rc = load().pw_resident_download(self.ctx._h, self._h, out.ctypes.data)
-                if rc == E_HIP and b"timed out" in load().pw_last_error():
-                    # a launch that gave up waiting (5 s) for another launch of the same analysis: the analysis is
-                    # repeated ONCE -- a second time-out is raised -- and the incident is logged with its details
+                if rc == E_TIMEOUT:
+                    # a launch that gave up waiting for another launch of the same analysis: the analysis is
+                    # repeated ONCE -- a second time-out is raised -- and the repeat is COUNTED (Context.retries,
+                    # retries_total(): the bench line and the suite's last test look at them) and logged
                     import logging
 
                     logging.getLogger("pywindow_amd").warning("analysis repeated after: %s", load().pw_last_error().decode(errors="replace"))
+                    load().pw_context_count_retry(self.ctx._h)
                     self.launch(getattr(self, "_stages", STAGE_ALL))
                     rc = load().pw_resident_download(self.ctx._h, self._h, out.ctypes.data)
                 _check(rc, "pw_resident_download")
@@ -767,12 +805,15 @@ class Resident:
         a sphere of thousands of angstroms) raises the context's capacity and the analysis is launched again,
         so no capacity of the engine shows in a result.  Download and extra windows under the context's lock."""
         with self.ctx.lock:
-            for _attempt in range(3):
+            attempt = 0
+            while True:
                 mine = []
                 out = self.download(mine)
                 flagged = out[(out["status"] & ST_POINTS_OVERFLOW) != 0]
                 want = int(max(flagged["n_points"].max(), flagged["n_points_avg"].max())) if len(flagged) else 0
-                if want <= self.ctx.point_capacity:
+                attempt += 1
+                # (no launch after the last download: what is returned is what the latest launch wrote)
+                if want <= self.ctx.point_capacity or attempt >= 3:
                     break
                 self.ctx.reserve_points(want)
                 self.launch(getattr(self, "_stages", STAGE_ALL))

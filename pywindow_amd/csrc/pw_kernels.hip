@@ -423,12 +423,20 @@ pw_worker_kernel(long n_units, const long* __restrict__ atom_offset, const doubl
 // Gate: one wave, no LDS.  Holds the stream it is launched on until every team of the
 // optimiser launch is resident, so that launches queued behind it cannot take the LDS those
 // teams need.  It can never block them itself, and its wait is bounded.
+// A gate that expires (2 s) does NOT let the launches behind it go: teams that wait for units while the optimiser
+// teams cannot become resident is the state the gate exists to prevent.  It sets the queue's error flag (cause 4)
+// instead -- the consumers behind it leave at once, the download reports PW_E_TIMEOUT and the analysis is repeated,
+// counted (pw_context_retries).
 __global__ void pw_gate_kernel(UnitQueue* queue, int expected, unsigned long long* timeouts) {
     if (threadIdx.x != 0) return;
     long long t0 = wall_clock64();
     while (__hip_atomic_load(&queue->started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
         __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t0 > 200000000ll) { atomicAdd(timeouts, 1ull << 32); break; }   // 2 s
+        if (wall_clock64() - t0 > 200000000ll) {   // 2 s
+            atomicAdd(timeouts, 1ull << 32);
+            atomicCAS(&queue->error, 0, 4);
+            break;
+        }
     }
 }
 
@@ -622,7 +630,9 @@ __global__ void pw_set_debug_kernel(TeamWorkspace* ws, int blocks, pw_unit_debug
 
 }  // namespace
 
+static std::atomic<unsigned long long> g_retries_total{0};
 struct pw_context {
+    unsigned long long retries = 0;   // analyses repeated after PW_E_TIMEOUT (pw_context_retries)
     int device;
     hipStream_t stream;      // main stream (launch order, timing events)
     hipStream_t aux;         // second stream: stages that do not depend on the optimiser
@@ -1801,16 +1811,18 @@ static int check_queue_error(pw_context* c) {
         if (any) {
             // cause 1: a window team waited 5 s for a unit of the optimiser launch; 2: a team waited 5 s for the coordinates of a
             // streamed batch; 3: a streamed batch was given up while its launches were waiting
+            // ... 4: the optimiser teams of a launch were not all resident within 2 s (pw_gate_kernel)
             const int cause = q[which].error;
             snprintf(g_err, sizeof(g_err), "%s (set %d of %d, cause %d: %llu units published, %llu taken, %d optimiser teams started)",
                      cause == 1 ? "window launch timed out waiting for the optimiser launch"
                                 : (cause == 2 ? "a launch timed out waiting for the coordinates of a streamed batch"
-                                              : "a streamed batch was given up while it was being analysed"),
+                                              : (cause == 4 ? "the optimiser launch timed out becoming resident (residency gate)"
+                                                            : "a streamed batch was given up while it was being analysed")),
                      which, c->cur_sets, cause, q[which].tail, q[which].head, q[which].started);
         } else {
             snprintf(g_err, sizeof(g_err), "fit workers timed out waiting for the sampling launch");
         }
-        return PW_E_HIP;
+        return PW_E_TIMEOUT;
     }
     return PW_OK;
 }
@@ -2214,6 +2226,38 @@ int pw_context_gate_timeouts(pw_context* c, uint64_t* count) {
     return PW_OK;
 }
 
+static void count_retry(pw_context* c) {
+    c->retries += 1;
+    g_retries_total.fetch_add(1);
+    fprintf(stderr, "pywindow_amd: analysis repeated after a time-out: %s\n", g_err);
+}
+int pw_context_retries(pw_context* c, uint64_t* count) {
+    if (!c || !count) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
+    *count = (uint64_t)c->retries;
+    return PW_OK;
+}
+int pw_context_count_retry(pw_context* c) {
+    if (!c) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
+    count_retry(c);
+    return PW_OK;
+}
+uint64_t pw_retries_total(void) { return (uint64_t)g_retries_total.load(); }
+int pw_context_queue_state(pw_context* c, uint64_t* out, int cap) {
+    if (!c || !out || cap < 4 * PW_SETS) return PW_E_BAD_ARG;
+    PW_LOCK_CONTEXT(c);
+    for (int k = 0; k < 4 * PW_SETS; ++k) out[k] = 0;
+    if (c->device < 0 || !c->queue) return PW_OK;
+    PW_ON_DEVICE(c->device);
+    UnitQueue q[PW_SETS];
+    HIP_TRY(hipMemcpy(q, c->queue, sizeof(q), hipMemcpyDeviceToHost));
+    for (int b = 0; b < PW_SETS; ++b) {
+        out[4 * b] = q[b].head; out[4 * b + 1] = q[b].tail; out[4 * b + 2] = (uint64_t)q[b].started; out[4 * b + 3] = (uint64_t)q[b].error;
+    }
+    return PW_OK;
+}
+
 void* pw_resident_device_results(pw_resident* r) { return r ? (r->host ? (void*)r->host->out.data() : (void*)r->d_out) : nullptr; }
 int64_t pw_resident_units(pw_resident* r) { return r ? r->n_units : 0; }
 
@@ -2319,7 +2363,7 @@ static int launch_and_download(pw_context* c, pw_resident* r, uint32_t stages, p
         if (rc == PW_OK) rc = pw_resident_download(c, r, out);
         if (rc == PW_E_RETRY) continue;
         // (a launch that gave up waiting for another launch of the same analysis -- 5 s: the analysis is repeated once)
-        if (rc == PW_E_HIP && attempt == 0 && strstr(g_err, "timed out")) continue;
+        if (rc == PW_E_TIMEOUT && attempt == 0) { count_retry(c); continue; }
         if (rc != PW_OK) return rc;
         long want = 0;
         for (long u = 0; u < r->n_units; ++u)

@@ -104,6 +104,10 @@ struct LbMem {
     // matrix is (matupd, formt, formk).
     double dsy[M], rsy[M], sqy[M], rsq[M], rwt[M], rwn[M2];
     double iwn[M];      // 1 / WN(i, i), i < col: the quotients potf2 scales its rows with, which trsm's solve multiplies by
+    // bmv's two triangular sums, one (row, column) pair per lane: the quotients of a sum wait here for the lane that
+    // adds them up in the reference's order; pair[lane] = row | column << 8 of lane's pair (row > column; 255: none)
+    double tri[48];
+    int pair[64];
     double le[N], ue[N];    // the bounds a line-search iterate is put back on: l / u where there is one, -inf / +inf else
     LsState ls;
 #if defined(PW_PROFILE) && defined(PW_LB_FINE)
@@ -286,7 +290,8 @@ __device__ inline bool lb_plain_range(unsigned emin, unsigned emax) {
 }
 
 // bmv for one wave: lane i owns p[i] and p[col + i]; reads everything, then writes (Lbfgsb::bmv has the statement).
-// Returns the singularity code of dtrtrs (0: fine), or -1 when SPEC and a dividend was not plain: nothing written.
+// Returns the singularity code of dtrtrs (0: fine; non-zero: nothing written), or -1 when SPEC and a dividend was not
+// plain: p may hold part of a result then, and the guarded routine the caller takes next rewrites all of it.
 template <class T, int N, bool SPEC>
 __device__ inline __attribute__((always_inline)) int lb_bmv_body(LbMem<N>* m, int col, const double* v, double* p) {
     constexpr int M = LB_M;
@@ -300,23 +305,36 @@ __device__ inline __attribute__((always_inline)) int lb_bmv_body(LbMem<N>* m, in
     LB_M0(tb0);
     const double vi = act ? v[li] : 0.0, vc = act ? v[col + li] : 0.0;
     unsigned emin = 0x3ff00000u, emax = 0x3ff00000u;      // exponent range of the dividends (SPEC)
+    // The two triangular sums, one quotient per lane: lane q owns the pair (a, b), a > b (LbMem::pair), i.e. the entry
+    // SY(a, b) and the divisor SY(b, b) of BOTH sums -- the first wants SY(a, b) v[b] / SY(b, b) in row a, the second
+    // SY(a, b) p[col + a] / SY(b, b) in row b.  The quotients go through LbMem::tri to the lane that owns the row,
+    // which adds them in the reference's order (column ascending / row ascending, from +0).
+    const int pk = m->pair[lane];
+    const int pa_ = pk & 0xff, pb_ = (pk >> 8) & 0xff;
+    const bool pact = pa_ < col;
+    const int sa = pact ? pa_ : 1, sb = pact ? pb_ : 0;
+    const double sy_ab = m->sy[sa + M * sb], d_b = m->dsy[sb], r_b = m->rsy[sb];
     // p[col + i] = v[col + i] + sum_{k < i} SY(i, k) * v[k] / SY(k, k)
-    double sum = 0.0;
-#pragma unroll
-    for (int k = 0; k < M - 1; ++k) {
-        if (k + 1 >= col) continue;
-        const bool on = act && k < lane;
+    {
+        const double num = pact ? sy_ab * v[sb] : 1.0;
         if (SPEC) {
-            const double num = on ? m->sy[li + M * k] * v[k] : 1.0;
             const unsigned e = lb_expo(num);
             emin = e < emin ? e : emin;
             emax = e > emax ? e : emax;
-            const double term = pw_div_ru(num, m->dsy[k], m->rsy[k]);
-            sum = sum + (on ? term : 0.0);
-        } else {
-            const double num = on ? m->sy[li + M * k] * v[k] : 0.0;
-            const double term = pw_div_r(num, m->dsy[k], m->rsy[k]);
-            sum = sum + (on ? term : 0.0);
+        }
+        const double term = SPEC ? pw_div_ru(num, d_b, r_b) : pw_div_r(num, d_b, r_b);
+        if (lane < 48) m->tri[lane] = term;
+    }
+    T::wave_sync();
+    double sum = 0.0;
+    {
+        const int base = li * (li - 1) / 2;
+#pragma unroll
+        for (int k = 0; k < M - 1; ++k) {
+            if (k + 1 >= col) continue;
+            const bool on = act && k < lane;
+            const double term = m->tri[on ? base + k : 0];
+            sum = sum + (on ? term : 0.0);          // (+0 leaves a sum that started from +0 as it is)
         }
     }
     double xk = lane == 0 ? vc : vc + sum;
@@ -333,25 +351,26 @@ __device__ inline __attribute__((always_inline)) int lb_bmv_body(LbMem<N>* m, in
     LB_M0(tb3);
     // p[i] = -p[i] / sqrt(SY(i, i)) + sum_{k > i} SY(k, i) * p[col + k] / SY(i, i)
     const double pi = SPEC ? pw_div_ru(-pa, sq, rs) : pw_div_r(-pa, sq, rs);
-    const double dsi = act ? m->dsy[li] : 1.0, rsi = act ? m->rsy[li] : 1.0;
+    if (act) p[col + lane] = xk;                // (the second half of the result; the pairs read it from here)
+    T::wave_sync();
+    {
+        const double num = pact ? sy_ab * p[col + sa] : 1.0;
+        if (SPEC) {
+            const unsigned e = lb_expo(num);
+            emin = e < emin ? e : emin;
+            emax = e > emax ? e : emax;
+        }
+        const double term = SPEC ? pw_div_ru(num, d_b, r_b) : pw_div_r(num, d_b, r_b);
+        if (lane < 48) m->tri[lane] = term;
+    }
+    T::wave_sync();
     double sum2 = 0.0;
 #pragma unroll
     for (int k = 1; k < M; ++k) {
         if (k >= col) continue;
         const bool on = act && k > lane;
-        const double xv = T::bcast_u(xk, k);
-        if (SPEC) {
-            const double num = on ? m->sy[k + M * li] * xv : 1.0;
-            const unsigned e = lb_expo(num);
-            emin = e < emin ? e : emin;
-            emax = e > emax ? e : emax;
-            const double term = pw_div_ru(num, dsi, rsi);
-            sum2 = sum2 + (on ? term : 0.0);
-        } else {
-            const double num = on ? m->sy[k + M * li] * xv : 0.0;
-            const double term = pw_div_r(num, dsi, rsi);
-            sum2 = sum2 + (on ? term : 0.0);
-        }
+        const double term = m->tri[on ? k * (k - 1) / 2 + lane : 0];
+        sum2 = sum2 + (on ? term : 0.0);
     }
     if (SPEC) {
         // every dividend of this lane plain and non-zero, every tabulated reciprocal a real one
@@ -362,16 +381,13 @@ __device__ inline __attribute__((always_inline)) int lb_bmv_body(LbMem<N>* m, in
             e = lb_expo(vi); emin = e < emin ? e : emin; emax = e > emax ? e : emax;
             e = lb_expo(pa); emin = e < emin ? e : emin; emax = e > emax ? e : emax;
         }
-        bool good = lb_plain_range(emin, emax) && rs != 0.0 && rsi != 0.0 && (!act || m->rwt[li] != 0.0);
+        bool good = lb_plain_range(emin, emax) && rs != 0.0 && (!pact || r_b != 0.0) && (!act || m->rwt[li] != 0.0);
 #ifdef PW_LB_FORCE_FALLBACK
         good = false;                     // (test builds: every call takes the guarded path after the speculative one)
 #endif
         if (T::ballot(!good)) return -1;
     }
-    if (act) {
-        p[lane] = pi + sum2;
-        p[col + lane] = xk;
-    }
+    if (act) p[lane] = pi + sum2;
     T::wave_sync();
     LB_M1(6, tb3);
     return 0;
@@ -767,6 +783,15 @@ struct Lbfgsb {
             T::wave_sync();
         }
         bind(m);
+        if (T::WSIZE == 64) {
+            // lane p of a wave owns the pair (a, b), a > b, with p = a (a - 1) / 2 + b (45 pairs for m = 10)
+            const int p = T::lane();
+            int a = 1;
+            for (int t = 2; t < M; ++t) a += p >= t * (t - 1) / 2 ? 1 : 0;
+            const int b = p - a * (a - 1) / 2;
+            m->pair[p] = p < M * (M - 1) / 2 ? (a | b << 8) : 255;
+            T::wave_sync();
+        }
         for (int i = 0; i < N; ++i) {
             x[i] = x0[i];
             l[i] = lo[i];

@@ -511,13 +511,12 @@ class DLPOLY:
         # device when resident_from_cells returns, i.e. before the piece after next is decoded): the H2D of a
         # 1344-atom x 512-frame piece is then one DMA instead of a staged copy through the runtime's bounce buffer.
         n_pieces = -(-n // piece)
-        halves = None
-        if ctx.device >= 0 and n_pieces > 0:
-            halves = ctx.pinned_array((2 if n_pieces > 1 else 1, min(piece, n), self.no_of_atoms, 3))
+        halves = [None]                    # (taken under the context's lock, below: asking for a larger buffer frees
+                                           # the one another thread on this context may be decoding into)
 
         def read_piece(i, k=0):
             sel_ = frames[i:i + piece]
-            out = halves[k % len(halves)][: len(sel_)] if halves is not None else None
+            out = halves[0][k % len(halves[0])][: len(sel_)] if halves[0] is not None else None
             coords, lattice = self._read_selected(sel_, self.periodic, out=out)
             return rb.pack_frames(coords, lattice)
 
@@ -531,6 +530,8 @@ class DLPOLY:
             pool = ThreadPoolExecutor(max_workers=1)
         ctx.lock.acquire()                 # (one trajectory at a time per context, see _run)
         try:
+            if ctx.device >= 0 and n_pieces > 0:
+                halves[0] = ctx.pinned_array((2 if n_pieces > 1 else 1, min(piece, n), self.no_of_atoms, 3))
             ahead = pool.submit(read_piece, starts[0], 0) if pool else None
             for k, i in enumerate(starts):
                 t0 = clock()
