@@ -106,7 +106,7 @@ struct LbMem {
     double iwn[M];      // 1 / WN(i, i), i < col: the quotients potf2 scales its rows with, which trsm's solve multiplies by
     // bmv's two triangular sums, one (row, column) pair per lane: the quotients of a sum wait here for the lane that
     // adds them up in the reference's order; pair[lane] = row | column << 8 of lane's pair (row > column; 255: none)
-    double tri[48];
+    double tri[64];     // (also the col x nsub products of subsm's last step: two kinds, at [term] and [32 + term])
     int pair[64];
     double le[N], ue[N];    // the bounds a line-search iterate is put back on: l / u where there is one, -inf / +inf else
     LsState ls;
@@ -323,18 +323,20 @@ __device__ inline __attribute__((always_inline)) int lb_bmv_body(LbMem<N>* m, in
             emax = e > emax ? e : emax;
         }
         const double term = SPEC ? pw_div_ru(num, d_b, r_b) : pw_div_r(num, d_b, r_b);
-        if (lane < 48) m->tri[lane] = term;
+        m->tri[lane] = term;
     }
     T::wave_sync();
     double sum = 0.0;
     {
+        // (straight-line: every read first -- a branch per term would make each a round trip of its own)
         const int base = li * (li - 1) / 2;
+        double q[M - 1];
+#pragma unroll
+        for (int k = 0; k < M - 1; ++k) q[k] = m->tri[(base + k) & 63];
 #pragma unroll
         for (int k = 0; k < M - 1; ++k) {
-            if (k + 1 >= col) continue;
-            const bool on = act && k < lane;
-            const double term = m->tri[on ? base + k : 0];
-            sum = sum + (on ? term : 0.0);          // (+0 leaves a sum that started from +0 as it is)
+            const bool on = act && k < lane && k + 1 < col;
+            sum = sum + (on ? q[k] : 0.0);          // (+0 leaves a sum that started from +0 as it is)
         }
     }
     double xk = lane == 0 ? vc : vc + sum;
@@ -361,16 +363,19 @@ __device__ inline __attribute__((always_inline)) int lb_bmv_body(LbMem<N>* m, in
             emax = e > emax ? e : emax;
         }
         const double term = SPEC ? pw_div_ru(num, d_b, r_b) : pw_div_r(num, d_b, r_b);
-        if (lane < 48) m->tri[lane] = term;
+        m->tri[lane] = term;
     }
     T::wave_sync();
     double sum2 = 0.0;
+    {
+        double q[M];
 #pragma unroll
-    for (int k = 1; k < M; ++k) {
-        if (k >= col) continue;
-        const bool on = act && k > lane;
-        const double term = m->tri[on ? k * (k - 1) / 2 + lane : 0];
-        sum2 = sum2 + (on ? term : 0.0);
+        for (int k = 1; k < M; ++k) q[k] = m->tri[(k * (k - 1) / 2 + li) & 63];
+#pragma unroll
+        for (int k = 1; k < M; ++k) {
+            const bool on = act && k > lane && k < col;
+            sum2 = sum2 + (on ? q[k] : 0.0);
+        }
     }
     if (SPEC) {
         // every dividend of this lane plain and non-zero, every tabulated reciprocal a real one
@@ -1645,26 +1650,45 @@ struct Lbfgsb {
 #ifdef PW_NO_SPREAD_SUBSM
         if (false) {
 #else
-        if (T::WSIZE == 64 && col * nsub <= T::WSIZE) {
+        if (T::WSIZE == 64 && col * nsub <= 32) {
 #endif
-            // the col x nsub terms by one lane each (a division apiece), then every lane adds them to
-            // its copy of dd in the reference's order, fetching them with v_readlane
+            // the col x nsub terms by one lane each (a division apiece) into team memory (LbMem::tri: the first kind at
+            // [term], the second at [32 + term]), then every lane adds them to its copy of dd in the reference's order --
+            // sixty reads of addresses that are the same in every lane, issued back to back (as v_readlane moves with a
+            // run-time lane number they were sixty scalar round trips) -- and scales the result by 1 / theta
             const int t = T::lane();
-            const int jy_ = t / nsub, i_ = t - jy_ * nsub;
-            double t1 = 0.0, t2 = 0.0;
-            if (jy_ < col) {
+            const int nsu = T::uniform_i(nsub), cu = T::uniform_i(col);
+            const int jy_ = nsu == 3 ? t / 3 : (nsu == 2 ? t >> 1 : t), i_ = t - jy_ * nsu;
+            const double rth = 1.0 / theta;
+            if (jy_ < cu) {
                 const int pj = (head + jy_) % M, k = index[i_];
-                t1 = WY(pj)[k] * wv[jy_] / theta;
-                t2 = WS(pj)[k] * wv[col + jy_];
+                mem->tri[t] = WY(pj)[k] * wv[jy_] / theta;
+                mem->tri[32 + t] = WS(pj)[k] * wv[cu + jy_];
             }
             double acc_[N];
-            for (int i = 0; i < N; ++i) acc_[i] = i < nsub ? dd[i] : 0.0;
-            for (int jy = 0; jy < col; ++jy)
-                for (int i = 0; i < N; ++i)
-                    if (i < nsub) acc_[i] = acc_[i] + T::bcast_u(t1, jy * nsub + i) + T::bcast_u(t2, jy * nsub + i);
+            for (int i = 0; i < N; ++i) acc_[i] = dd[i < nsu ? i : 0];
+            T::wave_sync();
+            // straight-line: all sixty reads first (a term that does not exist reads a slot that holds something
+            // else and is replaced by -0, which added to anything leaves it as it is -- +0 would turn a -0 into +0)
+            double q1[M * N], q2[M * N];
+#pragma unroll
+            for (int jy = 0; jy < M; ++jy)
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const int at = (jy * nsu + i) & 31;
+                    q1[jy * N + i] = mem->tri[at];
+                    q2[jy * N + i] = mem->tri[32 + at];
+                }
+#pragma unroll
+            for (int jy = 0; jy < M; ++jy)
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const bool on = jy < cu && i < nsu;
+                    acc_[i] = acc_[i] + (on ? q1[jy * N + i] : -0.0) + (on ? q2[jy * N + i] : -0.0);
+                }
             T::wave_sync();
             for (int i = 0; i < N; ++i)
-                if (i < nsub) dd[i] = acc_[i];
+                if (i < nsu) dd[i] = rth * acc_[i];          // (b_dscal(nsub, 1 / theta, dd))
             T::wave_sync();
         } else {
             int pointr = head;
@@ -1676,30 +1700,46 @@ struct Lbfgsb {
                 }
                 pointr = (pointr + 1) % M;
             }
+            b_dscal(nsub, 1.0 / theta, dd);
         }
-        b_dscal(nsub, 1.0 / theta, dd);
-        // projected-search safeguard (Morales & Nocedal)
+        // projected-search safeguard (Morales & Nocedal).  Everything is read first, then written: the free variables
+        // are distinct, so this is the reference's loop -- without a round trip through team memory per statement
         iword = 0;
         b_dcopy(N, xs, xp);
-        for (int i = 0; i < nsub; ++i) {
-            int k = index[i];
-            double dk = dd[i];
-            double xk = xs[k];
-            if (nbd[k] != 0) {
-                if (nbd[k] == 1) {
-                    xs[k] = pw_max(l[k], xk + dk);
-                    if (xs[k] == l[k]) iword = 1;
-                } else if (nbd[k] == 2) {
-                    xk = pw_max(l[k], xk + dk);
-                    xs[k] = pw_min(u[k], xk);
-                    if (xs[k] == l[k] || xs[k] == u[k]) iword = 1;
-                } else if (nbd[k] == 3) {
-                    xs[k] = pw_min(u[k], xk + dk);
-                    if (xs[k] == u[k]) iword = 1;
-                }
-            } else {
-                xs[k] = xk + dk;
+        {
+            int kk[N], nb[N];
+            double dk[N], xk[N], lk[N], uk[N];
+            for (int i = 0; i < N; ++i) {
+                const bool on = i < nsub;
+                kk[i] = on ? index[i] : 0;
             }
+            for (int i = 0; i < N; ++i) {
+                dk[i] = dd[i < nsub ? i : 0]; xk[i] = xs[kk[i]]; nb[i] = nbd[kk[i]]; lk[i] = l[kk[i]]; uk[i] = u[kk[i]];
+            }
+            T::wave_sync();
+            for (int i = 0; i < N; ++i) {
+                if (i >= nsub) continue;
+                double nx;
+                bool hit = false;
+                if (nb[i] != 0) {
+                    nx = xk[i];
+                    if (nb[i] == 1) {
+                        nx = pw_max(lk[i], xk[i] + dk[i]);
+                        hit = nx == lk[i];
+                    } else if (nb[i] == 2) {
+                        nx = pw_min(uk[i], pw_max(lk[i], xk[i] + dk[i]));
+                        hit = nx == lk[i] || nx == uk[i];
+                    } else if (nb[i] == 3) {
+                        nx = pw_min(uk[i], xk[i] + dk[i]);
+                        hit = nx == uk[i];
+                    }
+                } else {
+                    nx = xk[i] + dk[i];
+                }
+                if (hit) iword = 1;
+                xs[kk[i]] = nx;
+            }
+            T::wave_sync();
         }
         LB_F1(30, fst);
         if (iword == 0) return 0;
