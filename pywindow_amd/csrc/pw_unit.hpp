@@ -2339,6 +2339,150 @@ struct NeckObjective {
     }
 };
 
+// ---- the 20 x 20 grid of a window fit, bounded from above first ------------------------------------------------
+// scipy.optimize.brute evaluates the window's objective f = -2 min_i gap_i(p) at 400 points of the plane z = zopt and
+// hands the FIRST point with the lowest f to the simplex search (utilities.py:1307-1314): only that point's index is
+// used, i.e. the point with the largest clearance m(p) = min_i gap_i(p), lowest index among equals.  The plain form
+// evaluates every atom at every point (67 000 pairs per window).  Here:
+//   1. the atoms nearest to the hole -- gap at the grid's centre within TAU of the smallest: the ring of a window,
+//      a dozen or two -- are copied (stored order, so still grouped by radius) into `scratch`, the window's
+//      optimiser block, idle between the neck search and the simplex;
+//   2. every point gets an UPPER bound u(p) >= m(p): the minimum over those atoms alone (the same per-atom numbers,
+//      so the bound is exact arithmetic, not an estimate) -- a lane's seven points share every read;
+//   3. the point with the largest bound is evaluated over ALL atoms: L = m(that point), a LOWER bound of the
+//      maximum;
+//   4. only points with u(p) >= L can reach the maximum -- the ring atoms ARE what limits the clearance near a
+//      window, so that is a point or two; each is evaluated over all atoms, largest value / lowest index wins.
+// Nothing here depends on how well the ring was chosen except the number of points left in step 4 (more than 24: the
+// caller evaluates the plain form).  Returns false (nothing done) for ungrouped radii, more than 256 atoms per
+// lane-pass or a ring that does not fit.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T>
+PW_NOINLINE __device__ inline bool wave_brute_bounded(Frame R, int n, PW_LDS double* scratch, int cap, double zopt,
+                                                      double gstart, double gstep, int* gidx_out) {
+    constexpr double TAU = 1.0;
+    const PW_LDS ClassInfo* C = R.cls;
+    const int kk = T::uniform_i(C->k);
+    cap = T::uniform_i(cap);
+    n = T::uniform_i(n);
+    if (kk == 0 || cap < 16 || n > 256) return false;
+    PW_LDS double *sx = scratch, *sy = scratch + cap, *sz = scratch + 2 * cap, *sq = scratch + 3 * cap;
+    const int lane = T::lane();
+    // 1. every atom at the centre of the grid; a lane keeps its (up to four) atoms
+    const double cx = 9.5 * gstep + gstart, cy = cx;
+    const double ppc = sq3(cx, cy, zopt);
+    double ax[4], ay[4], az[4], aq[4], ag[4];
+    double b = PW_INF;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = lane + 64 * t;
+        const int ic = i < n ? i : 0;
+        ax[t] = R.x[ic]; ay[t] = R.y[ic]; az[t] = R.z[ic]; aq[t] = R.xx[ic];
+        const double gg = pw_fma(az[t], zopt, pw_fma(ax[t], cx, ay[t] * cy));
+        const double d2 = pw_m2add(gg, aq[t]) + ppc;
+        ag[t] = i < n ? pw_sqrt(d2 > 0.0 ? d2 : 0.0) - R.vdw[ic] : PW_INF;
+        b = __builtin_fmin(b, ag[t]);
+    }
+    const double lim = T::wave_min(b) + TAU;
+    if (!(lim < PW_INF)) return false;
+    int coff[PW_KCLS + 1];
+#pragma unroll
+    for (int g = 0; g <= PW_KCLS; ++g) coff[g] = 0;
+    int total = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (64 * t >= n) continue;
+        const bool in = ag[t] <= lim;
+        const unsigned long long mk = T::ballot(in);
+        const int at = total + (int)__builtin_popcountll(mk & ((1ull << lane) - 1ull));
+        if (in && at < cap) { sx[at] = ax[t]; sy[at] = ay[t]; sz[at] = az[t]; sq[at] = aq[t]; }
+        // where the groups start in the list: listed atoms stored before a group's first atom
+#pragma unroll
+        for (int g = 0; g <= PW_KCLS; ++g) {
+            const int first = g < kk ? T::uniform_i(C->off[g]) : n;            // (g >= kk: the end of the list)
+            const int below = first - 64 * t;                                  // atoms of this pass stored before it
+            const unsigned long long lt = below >= 64 ? ~0ull : (below <= 0 ? 0ull : ((1ull << below) - 1ull));
+            coff[g] += (int)__builtin_popcountll(mk & lt);
+        }
+        total += (int)__builtin_popcountll(mk);
+    }
+    if (total > cap || total == 0) return false;
+    T::wave_sync();
+    // 2. upper bounds: a lane's seven points over the ring
+    double qx[7], qy[7], pp[7], ub[7];
+#pragma unroll
+    for (int p = 0; p < 7; ++p) {
+        int q = lane + 64 * p;
+        if (q >= 400) q = lane;
+        qx[p] = (double)(q / 20) * gstep + gstart;
+        qy[p] = (double)(q % 20) * gstep + gstart;
+        pp[p] = sq3(qx[p], qy[p], zopt);
+        ub[p] = PW_INF;
+    }
+#pragma unroll
+    for (int g = 0; g < PW_KCLS; ++g) {
+        if (g >= kk) continue;
+        double m2[7];
+#pragma unroll
+        for (int p = 0; p < 7; ++p) m2[p] = PW_INF;
+        const int jlo = coff[g], jhi = coff[g + 1];
+        for (int j = jlo; j < jhi; ++j) {
+            const double x = sx[j], y = sy[j], z = sz[j], xx = sq[j];
+#pragma unroll
+            for (int p = 0; p < 7; ++p) {
+                const double gg = pw_fma(z, zopt, pw_fma(x, qx[p], y * qy[p]));
+                m2[p] = __builtin_fmin(m2[p], pw_m2add(gg, xx));
+            }
+        }
+        const double r = C->vdw[g];
+#pragma unroll
+        for (int p = 0; p < 7; ++p) {
+            const double m2p = m2[p] + pp[p];
+            const double d = pw_sqrt(m2p > 0.0 ? m2p : 0.0);
+            ub[p] = __builtin_fmin(ub[p], d - r);
+        }
+    }
+    // 3. the point with the largest bound (lowest index among equals), over all atoms
+    double ubest = -PW_INF;
+    int uq = 0x7fffffff;
+#pragma unroll
+    for (int p = 0; p < 7; ++p) {
+        const int q = lane + 64 * p;
+        if (q < 400 && ub[p] > ubest) { ubest = ub[p]; uq = q; }
+    }
+    {
+        double neg = -ubest;                  // (argmin of the negated bound: smallest index among equals)
+        T::wave_argmin(neg, uq);
+        ubest = -neg;
+    }
+    if (!(ubest < PW_INF) || uq >= 400) return false;
+    double best = wave_gap_value<T>(R, n, (double)(uq / 20) * gstep + gstart, (double)(uq % 20) * gstep + gstart, zopt);
+    int bestq = uq;
+    // 4. what can still reach it
+    int left = 0;
+    unsigned long long sv[7];
+#pragma unroll
+    for (int p = 0; p < 7; ++p) {
+        const int q = lane + 64 * p;
+        sv[p] = T::ballot(q < 400 && q != uq && ub[p] >= best);
+        left += (int)__builtin_popcountll(sv[p]);
+    }
+    if (left > 24) return false;
+#pragma unroll
+    for (int p = 0; p < 7; ++p) {
+        unsigned long long mk = sv[p];
+        while (mk) {
+            const int q = (int)__builtin_ctzll(mk) + 64 * p;
+            mk &= mk - 1ull;
+            const double m = wave_gap_value<T>(R, n, (double)(q / 20) * gstep + gstart, (double)(q % 20) * gstep + gstart, zopt);
+            if (m > best || (m == best && q < bestq)) { best = m; bestq = q; }
+        }
+    }
+    *gidx_out = bestq;
+    return true;
+}
+#endif
+
 // ---- one window (utilities.py:1191-1361), executed by ONE wave -------------------------------
 // per-cluster arrays of the window fits: in the team's LDS (UnitVars) for up to PW_W_MAX clusters, in the
 // team's global slab beyond -- the number of clusters has no upper limit (utilities.py:1481-1536)
@@ -2495,7 +2639,15 @@ PW_NOINLINE PW_HD inline void wave_window(const Frame& FS, const Frame& R, PW_LD
         double gstep = (hlf - gstart) / 19.0;
         double gbest = PW_INF;
         int gidx = 0x7fffffff;
-        if (T::WSIZE == 64) {
+        bool listed = false;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_GRID_LISTS)
+        if (T::WSIZE == 64)
+            listed = wave_brute_bounded<T>(R, n, (PW_LDS double*)lbmem, (int)(sizeof(LbMem<1>) / 8 / 4), zopt, gstart, gstep, &gidx);
+#endif
+        if (listed) {
+            // (done, and gidx is the same in every lane: the grid bounded from above first, wave_brute_bounded)
+            gbest = 0.0;
+        } else if (T::WSIZE == 64) {
             // a lane's (up to) seven grid points share one pass over the atoms (PW_TILE_GRID of them at a time)
             constexpr int NP = PW_TILE_GRID;
             for (int p0 = 0; p0 < 7; p0 += NP) {
