@@ -14,8 +14,7 @@ import sys
 PKG = pathlib.Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 OUT = PKG / "libpywindow_hip.so"
-SOURCES = ["pw_kernels.hip", "pw_kernels_sampling.hip", "pw_kernels_big.hip", "pw_rebuild.hip", "pw_shape.hip", "pw_history.cpp",
-           "pw_hostpath.cpp"]
+SOURCES = ["pw_kernels.hip", "pw_kernels_big.hip", "pw_rebuild.hip", "pw_shape.hip", "pw_history.cpp", "pw_hostpath.cpp"]
 # -ffp-contract=off: the numerical core relies on explicit fma() only (pw_common.hpp)
 
 
@@ -41,7 +40,6 @@ def build(force: bool = False, verbose: bool = True) -> pathlib.Path:
     # hipcc command silently drops --offload-arch) and linked by hipcc
     obj_k = CSRC / "pw_kernels.o"
     obj_b = CSRC / "pw_kernels_big.o"
-    obj_m = CSRC / "pw_kernels_sampling.o"
     obj_r = CSRC / "pw_rebuild.o"
     obj_s = CSRC / "pw_shape.o"
     obj_h = CSRC / "pw_history.o"
@@ -50,15 +48,13 @@ def build(force: bool = False, verbose: bool = True) -> pathlib.Path:
     cmds = [
         [hipcc(), *hip_flags, str(CSRC / "pw_kernels.hip"), "-o", str(obj_k)],
         [hipcc(), *hip_flags, str(CSRC / "pw_kernels_big.hip"), "-o", str(obj_b)],
-        # the sampling launch of the split window search: a translation unit of its own (its register budget)
-        [hipcc(), *hip_flags, str(CSRC / "pw_kernels_sampling.hip"), "-o", str(obj_m)],
         [hipcc(), *hip_flags, str(CSRC / "pw_rebuild.hip"), "-o", str(obj_r)],
         [hipcc(), *hip_flags, str(CSRC / "pw_shape.hip"), "-o", str(obj_s)],
         ["g++", "-O2", "-std=c++17", "-fPIC", "-c", str(CSRC / "pw_history.cpp"), "-o", str(obj_h)],
         # the explicit host path (pw_context_create(-1)): the unit pipeline for a one-lane team, g++
         ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-fPIC", "-pthread", "-c", str(CSRC / "pw_hostpath.cpp"),
          "-o", str(obj_c)],
-        [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread", str(obj_k), str(obj_m), str(obj_b), str(obj_r), str(obj_s), str(obj_h),
+        [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread", str(obj_k), str(obj_b), str(obj_r), str(obj_s), str(obj_h),
          str(obj_c), "-o", str(OUT)],
     ]
     # the translation units are independent: compile them side by side (PW_BUILD_JOBS, default 4), then link

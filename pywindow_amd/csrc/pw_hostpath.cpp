@@ -90,19 +90,15 @@ extern "C" int pw_hostpath_run(const pw_batch_in* in, unsigned stages, pw_unit_o
     std::atomic<int> failed{0};
     unsigned xcount = 0;            // (bumped with atomic increments: pw_unit.hpp team_atomic_inc)
     const int vstride = in->template_atoms > 0 ? 0 : 1;
-    // PW_HOST_SPLIT=1: the window search in the pipeline's two parts (default: one team does it all)
-    const char* split_env = getenv("PW_HOST_SPLIT");
-    const bool split = split_env && split_env[0] == '1';
     auto worker = [&]() {
         const size_t bytes = UnitShared::bytes(nmax, 1, 8, 2, false, p_cap);
         unsigned char* lds = (unsigned char*)aligned_alloc(16, (bytes + 15) & ~(size_t)15);
         TeamWorkspace* ws = (TeamWorkspace*)calloc(1, sizeof(TeamWorkspace));
         unsigned char* slab = (unsigned char*)malloc(team_slab_bytes(p_cap));
         unsigned long long* adj = (unsigned long long*)malloc(sizeof(unsigned long long) * team_adj_words(p_cap));
-        unsigned char* fit_lds = (unsigned char*)aligned_alloc(16, (FitShared::bytes(nmax) + 15) & ~(size_t)15);
-        if (!lds || !ws || !slab || !adj || !fit_lds) {
+        if (!lds || !ws || !slab || !adj) {
             failed = 1;
-            free(lds); free(ws); free(slab); free(adj); free(fit_lds);
+            free(lds); free(ws); free(slab); free(adj);
             return;
         }
         bind_team_slab(ws, slab, p_cap);
@@ -124,39 +120,12 @@ extern "C" int pw_hostpath_run(const pw_batch_in* in, unsigned stages, pw_unit_o
             const long a0 = (long)in->atom_offset[u];
             const int n = (int)(in->atom_offset[u + 1] - a0);
             memset(&out[u], 0, sizeof(pw_unit_out));
-            if (split && (stages & PW_STAGE_WINDOWS)) {
-                // the pipeline's launch shape, one step after the other: sampling up to the clustering, the
-                // clusters handed over in a ticket, every fit on a frame of its own, the record assembled last
-                // (pw_kernels.hip: the sampling launch and the fit workers); a unit with more clusters than a
-                // ticket holds goes through the fused window search instead
-                const double* xyz = in->xyz + 3 * a0;
-                const double* vdw = in->vdw + a0 * vstride;
-                FitTicket ticket;
-                memset(&ticket, 0, sizeof(ticket));
-                int ncl = -1;
-                analyse_unit<HostTeam>(sh, ws, n, xyz, vdw, in->mass + a0 * vstride,
-                                       (stages & ~PW_STAGE_WINDOWS) | PW_STAGE_WIN_BULK, &out[u], prm, &ticket, &ncl);
-                if (ncl > PW_W_MAX) {
-                    analyse_unit<HostTeam>(sh, ws, n, xyz, vdw, in->mass + a0 * vstride,
-                                           PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY, &out[u], prm);
-                } else if (ncl >= 1) {
-                    FitShared fs;
-                    fs.carve(fit_lds, nmax);
-                    int evals = 0;
-                    for (int c = 0; c < ncl; ++c) {
-                        memset(fit_lds, 0xff, FitShared::bytes(nmax));       // (nothing may depend on what the block held)
-                        evals += fit_item<HostTeam>(fs, ws, n, xyz, vdw, &out[u], &ticket, c, prm);
-                    }
-                    out[u].status |= windows_finish(ticket_arrays(&ticket), ncl, &out[u], ws, u);
-                    out[u].n_eval += evals;
-                }
-            } else {
-                analyse_unit<HostTeam>(sh, ws, n, in->xyz + 3 * a0, in->vdw + a0 * vstride, in->mass + a0 * vstride, stages,
-                                       &out[u], prm);
-            }
+            analyse_unit<HostTeam>(sh, ws, n, in->xyz + 3 * a0, in->vdw + a0 * vstride, in->mass + a0 * vstride, stages,
+                                   &out[u], prm);
+
             if ((stages & PW_STAGE_WINDOWS) && out[u].n_points >= PW_NB_PMIN) g_tables.ensure(out[u].n_points);
         }
-        free(adj); free(slab); free(ws); free(lds); free(fit_lds);
+        free(adj); free(slab); free(ws); free(lds);
     };
     if (threads == 1) {
         worker();

@@ -26,7 +26,7 @@
 #include "pw_host.hpp"
 #include <vector>
 // (no PW_TEAM_STATE_IN_LDS here: this file's stage functions serve kernels that keep their team state in LDS -- chains,
-// average diameter, the workers -- AND kernels that keep it on the stack -- the window search, whose out-of-line stage
+// average diameter -- AND kernels that keep it on the stack -- the window search, whose out-of-line stage
 // function spills five times as much when its table of pointers is an LDS object: 269 against 55 scratch stores)
 #include "pw_unit.hpp"
 #include "pw_launch.hpp"
@@ -37,13 +37,6 @@ using namespace pw;
 extern "C" int pw_hostpath_run(const pw_batch_in* in, unsigned stages, pw_unit_out* out, const pw_params* prm, int p_cap,
                                int threads, pw_unit_debug* dbg, pw_extra_window* xw, unsigned xw_cap, unsigned* xw_count);
 extern "C" int pw_hostpath_default_threads(void);
-// pw_kernels_sampling.hip: the sampling launch of the split window search, a translation unit built for its own
-// register budget
-extern "C" int pw_internal_sampling_launch(void* stream, int grid, size_t lds_bytes, long n_units, const long* atom_offset,
-                                           const double* xyz, const double* vdw, const double* mass, int nmax, int nrot, int nlb,
-                                           const PwWsArgs* wsa, pw_unit_out* out, UnitQueue* queue, int* slots,
-                                           const pw_params* prm, const unsigned* rsq_tab, int vstride, const FitArgs* fa);
-extern "C" size_t pw_internal_sampling_static_lds(void);
 // pw_kernels_big.hip: the same source with the team's shared block in global memory (molecules beyond LDS)
 extern "C" size_t pw_internal_big_block_bytes(int nmax, int p_cap);
 extern "C" int pw_internal_big_launch(void* stream, int grid, long n_units, const long* atom_offset, const double* xyz,
@@ -77,15 +70,14 @@ void set_err(const char* what, hipError_t e) {
 // ones filling the SIMDs that the long tails of the earlier ones leave idle.
 constexpr int PW_SETS = 4;      // (2 + 2 x PW_SETS streams, each needs a hardware queue of its own: GPU_MAX_HW_QUEUES = 12)
 
-// static LDS of an analysis kernel (team state: UnitShared, FitShared, parameters, the unit slot): what every
+// static LDS of an analysis kernel (team state: UnitShared, parameters, the unit slot): what every
 // launch plan leaves free beside its dynamic request
 constexpr size_t PW_KERNEL_STATIC_LDS = 1024;
 
-constexpr unsigned MASK_ANY = 0xffffffffu & ~PW_STAGE_WIN_BULK;      // (only the sampling launch carries that half-stage)
+constexpr unsigned MASK_ANY = 0xffffffffu;
 constexpr unsigned MASK_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE;
 constexpr unsigned MASK_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
-constexpr unsigned MASK_SAMPLING = PW_STAGE_WIN_BULK | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 
 // Neighbour tables of the sampling sphere, one block per vector count P (pw_unit.hpp: nb_build_point): the
 // P unit vectors go to LDS, every thread tabulates the rows of its points.
@@ -152,7 +144,7 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
                   const double* __restrict__ vdw, const double* __restrict__ mass, unsigned stages,
                   int nmax, int nrot, int nlb, int nframes, int lean, PwWsArgs wsa, unsigned long long* counter,
                   pw_unit_out* __restrict__ out, int role, UnitQueue* queue, int* __restrict__ slots,
-                  pw_params prm_in, const unsigned* __restrict__ rsq_tab, int vstride, FitArgs fa,
+                  pw_params prm_in, const unsigned* __restrict__ rsq_tab, int vstride,
                   const unsigned long long* __restrict__ ready) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ long s_unit;
@@ -183,7 +175,7 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
     UnitShared& sh = STATE_IN_LDS ? (UnitShared&)s_sh : sh_stack;
     const pw_params& prm = STATE_IN_LDS ? (const pw_params&)s_prm : prm_in;
     for (;;) {
-        if (role == PW_ROLE_CONSUMER || role == PW_ROLE_SAMPLER) {
+        if (role == PW_ROLE_CONSUMER) {
             if (threadIdx.x == 0) {
                 long pos = (long)atomicAdd(&queue->head, 1ull);
                 long u = -1;
@@ -207,13 +199,6 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
                 }
                 s_unit = u;
             }
-        } else if (role == PW_ROLE_LIST) {
-            // the units the sampling launch could not hand over (more clusters than a ticket holds): that launch
-            // has ended, so the list and its length are final
-            if (threadIdx.x == 0) {
-                long i = (long)atomicAdd(counter, 1ull);
-                s_unit = i < (long)fa.q->n_deferred ? (long)fa.deferred[i] : -1;
-            }
         } else {
             if (threadIdx.x == 0) {
                 long u = (long)atomicAdd(counter, 1ull);
@@ -230,35 +215,7 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
         // vstride 0: one molecule type, vdw / mass hold a single template (per-trajectory constants)
         const long v0 = a0 * vstride;
         if (threadIdx.x == 0) ws->unit = u;     // (read by the debug capture only; ordered by load_unit's barrier)
-        int ncl = -1;
-        analyse_unit<T, MASK>(sh, ws, n, xyz + 3 * a0, vdw + v0, mass + v0, stages & MASK, out + u, prm,
-                              role == PW_ROLE_SAMPLER ? (FitTicket*)fa.tickets + u : (FitTicket*)nullptr, &ncl);
-        if (role == PW_ROLE_SAMPLER) {
-            // (the sampling half of the window search inside this translation unit -- PW_SPLIT=2: the same hand-over
-            // as pw_kernels_sampling.hip, at this kernel's register budget)
-            ncl = __builtin_amdgcn_readfirstlane(ncl);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                if (ncl > PW_W_MAX) {
-                    const int at = atomicAdd(&fa.q->n_deferred, 1);
-                    fa.deferred[at] = (int)u;
-                } else if (ncl >= 1) {
-                    const long pos = (long)atomicAdd(&fa.q->tail, (unsigned long long)ncl);
-                    for (int i = 0; i < ncl; ++i)
-                        __hip_atomic_store(&fa.slots2[pos + i], (int)u * 16 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                const int done = atomicAdd(&fa.q->units_done, 1) + 1;
-                if (done == (int)n_units) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    const unsigned long long t = __hip_atomic_load(&fa.q->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&fa.q->final, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            __syncthreads();       // (keeps this thread-0 region and the one at the top of the loop apart)
-        }
+        analyse_unit<T, MASK>(sh, ws, n, xyz + 3 * a0, vdw + v0, mass + v0, stages & MASK, out + u, prm);
         if (role == PW_ROLE_PRODUCER) {
             // analyse_unit ended with a team barrier; thread 0 wrote the record
             if (threadIdx.x == 0) {
@@ -269,154 +226,6 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
                 __hip_atomic_store(&slots[pos], (int)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-    }
-}
-
-// ---- one-wave workers: optimiser chains AND window fits ----------------------------------------------------
-// The two serial, latency-bound parts of an analysis have the same shape -- one wave, a frame of the molecule
-// and one optimiser block in LDS, a 256-register budget -- so one launch of one-wave teams does both: a worker
-// takes a published fit item if there is one, else the next unit whose pore-centre chain has not started, and
-// when there is neither it leaves (its SIMD slot and LDS go to the next analysis), except the first n_pool
-// workers, which wait until the sampling launch has closed the fit queue.  The chains are what stage_basic +
-// stage_opt were in the optimiser launch (published to `queue` for the sampling teams); a fit is fit_item
-// (pw_unit.hpp): the frame shifted on the way in, one cluster of the unit's ticket, and the worker that
-// finishes a unit's last cluster assembles the record.
-__device__ inline long wave_uniform_long(long v) {
-    union { long l; int i[2]; } a;
-    a.l = v;
-    a.i[0] = __builtin_amdgcn_readfirstlane(a.i[0]);
-    a.i[1] = __builtin_amdgcn_readfirstlane(a.i[1]);
-    return a.l;
-}
-__global__ void __launch_bounds__(64, PW_OCC_A)
-pw_worker_kernel(long n_units, const long* __restrict__ atom_offset, const double* __restrict__ xyz,
-                 const double* __restrict__ vdw, const double* __restrict__ mass, int nmax, PwWsArgs wsa,
-                 unsigned long long* counter, pw_unit_out* __restrict__ out, UnitQueue* queue, int* __restrict__ slots,
-                 pw_params prm_in, const unsigned* __restrict__ rsq_tab, int vstride, FitArgs fa,
-                 const unsigned long long* __restrict__ ready) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    __shared__ UnitShared s_sh;
-    __shared__ FitShared s_fs;
-    __shared__ pw_params s_prm;
-    static_assert(sizeof(UnitShared) + sizeof(FitShared) + sizeof(pw_params) + 16 <= PW_KERNEL_STATIC_LDS, "static LDS of the workers");
-    using T = DeviceTeam<1>;
-    __builtin_amdgcn_s_setprio(PW_A_PRIO);
-    if (threadIdx.x == 0) atomicAdd(&queue->started, 1);
-    TeamWorkspace* ws = (TeamWorkspace*)wsa.ws + blockIdx.x;
-    if (threadIdx.x == 0) {
-        s_sh.carve(lds, nmax, 0, 1, 1, 1, wsa.p_cap);      // a chain: the input frame, no window variables, one optimiser block
-        s_fs.carve(lds, nmax);                             // a fit: the same bytes laid out for it
-        s_prm = prm_in;
-        bind_workspace(ws, wsa, blockIdx.x, rsq_tab, team_slab_bytes(wsa.p_cap), team_adj_words(wsa.p_cap));
-    }
-    __syncthreads();
-    UnitShared& sh = s_sh;
-    FitShared& fs = s_fs;
-    const pw_params& prm = s_prm;
-    bool chains_left = true;
-    for (;;) {
-        // 1. a fit that is ready?  (head never passes tail: items are taken with a compare-and-swap)
-        long item = -1;
-        if (threadIdx.x == 0) {
-            for (;;) {
-                unsigned long long h = __hip_atomic_load(&fa.q->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long t = __hip_atomic_load(&fa.q->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (h >= t) break;
-                if (__hip_atomic_compare_exchange_strong(&fa.q->head, &h, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT)) {
-                    // the publisher stores the slot right after moving the tail: a short wait at most
-                    long long t0 = wall_clock64();
-                    for (;;) {
-                        const int v = __hip_atomic_load(&fa.slots2[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (v >= 0) { item = v; break; }
-                        __builtin_amdgcn_s_sleep(4);
-                        if (wall_clock64() - t0 > 500000000ll) { atomicExch(&fa.q->error, 1); break; }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    break;
-                }
-            }
-        }
-        item = wave_uniform_long(item);
-        if (item >= 0) {
-            const long u = item >> 4;
-            const int cluster = (int)(item & 15);
-            const long a0 = atom_offset[u];
-            const int n = (int)(atom_offset[u + 1] - a0);
-            if (threadIdx.x == 0) ws->unit = u;
-            T::wave_sync();
-            FitTicket* ticket = (FitTicket*)fa.tickets + u;
-            const int evals = (fa.debug & 2) ? 0 : fit_item<T>(fs, ws, n, xyz + 3 * a0, vdw + a0 * vstride, out + u, ticket, cluster, prm);
-            if (threadIdx.x == 0) {
-                atomicAdd(&out[u].n_eval, evals);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                const int left = atomicSub(&ticket->remaining, 1);
-                if (left == 1) {
-                    // the unit's last fit: every other worker's results are visible after the acquire
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const int st = windows_finish(ticket_arrays(ticket), ticket->ncl, out + u, ws, u);
-                    if (st) atomicOr(&out[u].status, st);
-                }
-            }
-            T::wave_sync();
-            continue;
-        }
-        // 2. a chain that has not started?
-        long u = -1;
-        if (chains_left) {
-            if (threadIdx.x == 0) {
-                u = (long)atomicAdd(counter, 1ull);
-                if (u < n_units && !wait_for_unit(ready, u, &queue->error)) u = n_units;
-            }
-            u = wave_uniform_long(u);
-            if (u >= n_units) { u = -1; chains_left = false; }
-        }
-        if (u >= 0) {
-            const long a0 = atom_offset[u];
-            const int n = (int)(atom_offset[u + 1] - a0);
-            const long v0 = a0 * vstride;
-            if (threadIdx.x == 0) ws->unit = u;
-            analyse_unit<T, MASK_CHAINS>(sh, ws, n, xyz + 3 * a0, vdw + v0, mass + v0, MASK_CHAINS, out + u, prm);
-            if (threadIdx.x == 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                long pos = (long)atomicAdd(&queue->tail, 1ull);
-                __hip_atomic_store(&slots[pos], (int)u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            // (a wave-level barrier between this lane-0 region and the one at the top of the loop: without a
-            // convergent operation between them the compiler may thread lane 0 from one straight into the other)
-            T::wave_sync();
-            continue;
-        }
-        // 3. nothing to do right now.  Up to n_pool idle workers wait (at low priority) until there is a fit or
-        // there will never be another; beyond that an idle worker leaves -- its SIMD slot and LDS go to the next
-        // analysis.  (A waiter that leaves its place first gives it up, so the count never leaks.)
-        int leave = 0;
-        if (threadIdx.x == 0) {
-            if (atomicAdd(&fa.q->waiting, 1) >= fa.n_pool) {
-                leave = 1;
-            } else {
-                __builtin_amdgcn_s_setprio(0);
-                long long t0 = wall_clock64();
-                for (;;) {
-                    const unsigned long long h = __hip_atomic_load(&fa.q->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long t = __hip_atomic_load(&fa.q->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (h < t) break;
-                    const unsigned long long fin = __hip_atomic_load(&fa.q->final, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (h >= fin) { leave = 1; break; }
-                    __builtin_amdgcn_s_sleep(64);
-                    if (wall_clock64() - t0 > 500000000ll) { atomicExch(&fa.q->error, 1); leave = 1; break; }
-                }
-                __builtin_amdgcn_s_setprio(PW_A_PRIO);
-            }
-            atomicSub(&fa.q->waiting, 1);
-        }
-        leave = __builtin_amdgcn_readfirstlane(leave);
-        if (leave) break;
     }
 }
 
@@ -603,22 +412,15 @@ __global__ void pw_div_check_kernel(unsigned long long n, int mode, unsigned lon
 // stream time each -- a tenth of the step of a small batch).
 __global__ void pw_reset_kernel(unsigned long long* __restrict__ out8, long n8, UnitQueue* queue, int* __restrict__ slots,
                                 long n_units, unsigned long long* ca, unsigned long long* cb,
-                                unsigned long long* cc, unsigned long long* cd, unsigned* xw_count,
-                                FitQueue* fitq, int* __restrict__ slots2) {
+                                unsigned long long* cc, unsigned long long* cd, unsigned* xw_count) {
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = i0; i < n8; i += stride) out8[i] = 0ull;
     for (long i = i0; i < n_units; i += stride) slots[i] = -1;
-    if (slots2)
-        for (long i = i0; i < 16 * n_units; i += stride) slots2[i] = -1;
     if (i0 == 0) {
         queue->tail = 0; queue->head = 0; queue->error = 0; queue->started = 0;
         *ca = 0; *cb = 0; *cc = 0; *cd = 0;
         *xw_count = 0u;
-        if (fitq) {
-            fitq->tail = 0; fitq->head = 0; fitq->final = ~0ull;
-            fitq->units_done = 0; fitq->n_deferred = 0; fitq->waiting = 0;     // (error is sticky until the host has seen it)
-        }
     }
 }
 
@@ -672,17 +474,6 @@ struct pw_context {
     int need_fork;           // main stream carries work the next pipeline launch must wait for
     UnitQueue* cur_queue;
     int* cur_slots;
-    FitArgs cur_fit;         // the split window search's hand-offs of the current launch (zeros otherwise)
-    // the split window search (sampling launch + fit workers): per set a queue, 16 item slots, a ticket and a
-    // deferred-list entry per unit (sized like `slots`)
-    int split;               // PW_SPLIT: 0 (default) the window search as ONE launch of 4-wave teams; 1 sampling launch
-                             // (pw_kernels_sampling.hip, three waves per SIMD) + fits by the one-wave workers; 2 the same with
-                             // the sampling launch as an instance of this file's kernel.  Measured slower: DESIGN.md section 3
-    int fit_pool;            // PW_FIT_POOL: workers that stay until the fit queue is closed
-    FitQueue* fitq;
-    int* slots2;
-    FitTicket* tickets;
-    int* deferred;
     hipEvent_t ev0, ev1, ev_fork;
     int fused;               // PW_FUSED=1: one launch per analysis instead of the pipeline (also chosen when the
                              // streams of the pipeline do not run concurrently, see pw_context_create)
@@ -878,16 +669,19 @@ struct LaunchPlan {
 
 // team width, LDS carve and grid for one launch.  want_nw: preferred waves per team;
 // rot/lb: whether window frames / optimiser states are needed (per wave).
+// want_nw: 1 (one wave per unit: stages without bulk loops) or 4.  A molecule whose rotated window frames and optimiser
+// blocks do not fit beside each other for four waves gets fewer fit SLOTS (4 -> 2 -> 1: the windows of a unit are then
+// fitted in rounds, UnitShared::nslots), not fewer waves -- the bulk stages keep the whole team, and the library carries
+// one general kernel shape instead of four.
 static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool rot, int lb_per_team,
                        LaunchPlan* p, int nframes = 2, int lean = 0) {
     const size_t max_lds = 160 * 1024 - 256 - PW_KERNEL_STATIC_LDS;
-    int nw = want_nw;
-    for (;;) {
-        int nslot = nw < 4 ? nw : 4;
+    const int nw = want_nw >= 4 ? 4 : 1;
+    for (int nslot = nw < 4 ? nw : 4;; nslot >>= 1) {
         int nrot = rot ? nslot : 0;
         int nlb = lb_per_team < 0 ? nslot : lb_per_team;
         size_t lds = UnitShared::bytes(nmax, nrot, nlb, nframes, lean, wanted_p_cap(c) > c->p_cap ? wanted_p_cap(c) : c->p_cap) + 64;
-        if (lds <= max_lds || nw == 1) {
+        if (lds <= max_lds || nslot == 1) {
             if (lds > max_lds) {
                 snprintf(g_err, sizeof(g_err), "molecule with %d atoms does not fit in LDS", nmax);
                 return PW_E_TOO_LARGE;
@@ -895,10 +689,9 @@ static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool 
             p->nw = nw; p->nrot = nrot; p->nlb = nlb; p->lds = lds; p->nframes = nframes; p->lean = lean;
             break;
         }
-        nw >>= 1;
     }
     int per_cu = (int)(c->lds_per_cu / (p->lds + PW_KERNEL_STATIC_LDS));
-    int wave_cap = p->nw == 8 ? 1 : 16 / p->nw;  // kernels are built for 2 waves per SIMD (8-wave teams: one team per CU)
+    int wave_cap = 16 / p->nw;   // kernels are built for 2 waves per SIMD
     if (per_cu > wave_cap) per_cu = wave_cap;
     if (per_cu < 1) per_cu = 1;
     long grid = (long)c->n_cu * per_cu;
@@ -939,7 +732,7 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
                        r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb, p.nframes, p.lean, wsa,
                        c->counter + counter_slot, r->d_out, role, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab,
-                       r->vstride, c->cur_fit, (const unsigned long long*)r->d_ready);
+                       r->vstride, (const unsigned long long*)r->d_ready);
     HIP_TRY(hipGetLastError());
     return PW_OK;
 }
@@ -953,12 +746,15 @@ static int launch_plan(pw_context* c, pw_resident* r, unsigned stages, const Lau
         return launch_nw<4, MASK_AVERAGE>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
     if (stages == MASK_WINDOWS && p.nw == 4)
         return launch_nw<4, MASK_WINDOWS>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
-    if (stages == MASK_SAMPLING && p.nw == 4)
-        return launch_nw<4, MASK_SAMPLING>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
-    if (p.nw == 8) return launch_nw<8, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
-    if (p.nw == 4) return launch_nw<4, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
-    if (p.nw == 2) return launch_nw<2, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
-    return launch_nw<1, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
+    // single launches: one wave per unit for the stages the chains kernel holds (basic, optimised pore), the general
+    // four-wave kernel for everything else
+    if (p.nw == 1 && (stages & ~MASK_CHAINS) == 0)
+        return launch_nw<1, MASK_CHAINS>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
+    if (p.nw != 4) {
+        snprintf(g_err, sizeof(g_err), "internal: no kernel for %d-wave teams with stages 0x%x", p.nw, stages);
+        return PW_E_BAD_ARG;
+    }
+    return launch_nw<4, MASK_ANY>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
 }
 
 // the API stream (uploads, downloads, single-launch analyses, timing marks) follows every
@@ -1071,8 +867,6 @@ int pw_context_create(int device, pw_context** out) {
     CTX_TRY(hipMemset(c->counter, 0, (4 * PW_SETS + 3) * sizeof(unsigned long long)));
     CTX_TRY(hipMalloc((void**)&c->queue, PW_SETS * sizeof(UnitQueue)));
     CTX_TRY(hipMemset(c->queue, 0, PW_SETS * sizeof(UnitQueue)));
-    CTX_TRY(hipMalloc((void**)&c->fitq, PW_SETS * sizeof(FitQueue)));
-    CTX_TRY(hipMemset(c->fitq, 0, PW_SETS * sizeof(FitQueue)));
     c->flip = -1;
     c->extra = new (std::nothrow) std::vector<pw_extra_window>();
     c->blocks = new (std::nothrow) std::vector<pw_context::Block>();
@@ -1123,14 +917,7 @@ int pw_context_create(int device, pw_context** out) {
     CTX_TRY(hipEventCreateWithFlags(&c->ev_ext, hipEventDisableTiming));
     const char* fz = getenv("PW_FUSED");
     c->fused = (fz && fz[0] == '1') ? 1 : 0;
-    {
-        const char* sp_ = getenv("PW_SPLIT");
-        c->split = (sp_ && sp_[0] == '1') ? 1 : ((sp_ && sp_[0] == '2') ? 2 : 0);
-        const char* fp_ = getenv("PW_FIT_POOL");
-        c->fit_pool = fp_ && atoi(fp_) > 0 ? atoi(fp_) : 0;      // 0: by the size of the chip (pw_resident_launch)
-    }
-    const char* cw = getenv("PW_C_WAVES");
-    c->c_waves = (cw && cw[0] == '8') ? 8 : 4;
+    c->c_waves = 4;
     c->prm = default_params();
     if (!c->fused && !(getenv("PW_STREAM_PROBE") && getenv("PW_STREAM_PROBE")[0] == '0')) {
         // Do the ten streams of the pipeline really run side by side?  (PW_STREAM_PROBE=0 skips the question:
@@ -1241,10 +1028,6 @@ void pw_context_destroy(pw_context* c) {
     if (c->adj) (void)hipFree(c->adj);
     if (c->pool) (void)hipFree(c->pool);
     if (c->queue) (void)hipFree(c->queue);
-    if (c->fitq) (void)hipFree(c->fitq);
-    if (c->slots2) (void)hipFree(c->slots2);
-    if (c->tickets) (void)hipFree(c->tickets);
-    if (c->deferred) (void)hipFree(c->deferred);
     if (c->rsq_tab) (void)hipFree(c->rsq_tab);
     if (c->nb_off) (void)hipFree(c->nb_off);
     if (c->nb_idx) (void)hipFree(c->nb_idx);
@@ -1482,49 +1265,10 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         rc = plan_launch(c, r->n_units, r->nmax, 4, false, b_lb, &pb, 1, true);
         if (rc != PW_OK) return rc;
     }
-    // The window search: split (default) = a sampling launch of 4-wave teams up to the clustering + the fits by
-    // the one-wave workers of launch A; PW_SPLIT=0 (and team shapes the sampling kernel is not built for) = ONE
-    // launch of 4-wave teams that do both (round 3's shape; also what follows up on units with more clusters
-    // than a ticket holds)
-    bool split = c->split != 0 && c->c_waves == 4;
-    LaunchPlan pcf;                              // the fused window search
-    rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pcf, 1);      // one frame, shifted in place
+    // The window search: ONE launch of 4-wave teams, sampling and fits (the split into a sampling launch and one-wave
+    // fit workers that round 4 built was 4-25x slower and is gone: profiles/r04_split_*)
+    rc = plan_launch(c, r->n_units, r->nmax, c->c_waves, true, -1, &pc, 1);      // one frame, shifted in place
     if (rc != PW_OK) return rc;
-    if (pcf.nw != 4) split = false;
-    pc = pcf;
-    if (split) {
-        // the same arena (the window frames and optimiser blocks the fused search would carve are this launch's
-        // scratch), no per-cluster arrays
-        int s_rot = 4, s_lb = 4;
-        if (const char* e = getenv("PW_S_ARENA")) {       // tuning: "rot,lb" slots that make up the arena
-            int a = 0, b2 = 0;
-            if (sscanf(e, "%d,%d", &a, &b2) == 2 && a >= 0 && a <= 4 && b2 >= 0 && b2 <= 8 && a + b2 > 0) { s_rot = a; s_lb = b2; }
-        }
-        pc.nrot = s_rot; pc.nlb = s_lb; pc.lean = 2;
-        pc.lds = UnitShared::bytes(r->nmax, s_rot, s_lb, 1, 2, wanted_p_cap(c) > c->p_cap ? wanted_p_cap(c) : c->p_cap) + 64;
-        const size_t s_static = pw_internal_sampling_static_lds();
-        if (pc.lds + s_static > 160 * 1024 - 256) split = false, pc = pcf;
-        else {
-            int per_cu = (int)(c->lds_per_cu / (pc.lds + s_static));
-            if (per_cu > 4) per_cu = 4;
-            long g = (long)c->n_cu * (per_cu < 1 ? 1 : per_cu);
-            pc.grid = (int)(g < r->n_units ? g : r->n_units);
-        }
-    }
-    int pool = 0;
-    if (split) {
-        // workers: one per unit plus the pool, at most what the chip holds at a time
-        pool = c->fit_pool > 0 ? c->fit_pool : c->n_cu;
-        int per_cu = (int)(c->lds_per_cu / pa.lds);
-        if (per_cu > 16) per_cu = 16;
-        long cap = (long)c->n_cu * (per_cu < 1 ? 1 : per_cu);
-        // (a small batch gets spare workers -- a lone unit's four windows are fitted side by side, not one after the
-        // other; a large one is its own pool: the workers whose chains end first wait for the first fits)
-        long want = r->n_units;
-        const long spare = 4 * r->n_units < pool ? 4 * r->n_units : pool;
-        if (want < spare) want = spare;
-        pa.grid = (int)(want < cap ? want : cap);
-    }
     // A batch of up to a few units per SIMD is latency-bound by its optimiser chains: one window team
     // per CU keeps LDS free for the chains of the next launch (measured on 1000 units: 2.56 -> 2.45 ms);
     // larger batches want every team the LDS admits (4000 units: 9.2 ms against 10.0).
@@ -1547,7 +1291,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         const char* bt = getenv("PW_B_TEAMS");
         if (bt && do_avg && atoi(bt) > 0) pb.grid = atoi(bt) < pb_planned ? atoi(bt) : pb_planned;   // (may also raise it)
     }
-    if (const char* cslots = split ? nullptr : getenv("PW_C_SLOTS")) {
+    if (const char* cslots = getenv("PW_C_SLOTS")) {
         // experiment: fewer window-fit slots than waves (less LDS per team, windows fitted in rounds);
         // PW_C_TEAMS then sets the number of teams (up to what the smaller request admits per CU)
         int k = atoi(cslots);
@@ -1598,17 +1342,6 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         if (c->slots) HIP_TRY(hipFree(c->slots));
         c->slots = nullptr;
         HIP_TRY(hipMalloc((void**)&c->slots, PW_SETS * sizeof(int) * (size_t)r->n_units));
-        if (c->slots2) HIP_TRY(hipFree(c->slots2));
-        c->slots2 = nullptr;
-        if (c->tickets) HIP_TRY(hipFree(c->tickets));
-        c->tickets = nullptr;
-        if (c->deferred) HIP_TRY(hipFree(c->deferred));
-        c->deferred = nullptr;
-        if (c->split) {
-            HIP_TRY(hipMalloc((void**)&c->slots2, PW_SETS * sizeof(int) * 16 * (size_t)r->n_units));
-            HIP_TRY(hipMalloc((void**)&c->tickets, PW_SETS * sizeof(FitTicket) * (size_t)r->n_units));
-            HIP_TRY(hipMalloc((void**)&c->deferred, PW_SETS * sizeof(int) * (size_t)r->n_units));
-        }
         c->slots_cap = r->n_units;
         for (int k = 0; k < PW_SETS; ++k) c->done_valid[k] = c->tail_valid[k] = c->head_valid[k] = 0;
     }
@@ -1628,15 +1361,6 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     r->d_out = r->d_outs[r->cur];
     c->cur_queue = c->queue + b;
     c->cur_slots = c->slots + (size_t)b * c->slots_cap;
-    memset(&c->cur_fit, 0, sizeof(c->cur_fit));
-    if (split) {
-        c->cur_fit.q = c->fitq + b;
-        c->cur_fit.slots2 = c->slots2 + (size_t)b * 16 * c->slots_cap;
-        c->cur_fit.tickets = (void*)(c->tickets + (size_t)b * c->slots_cap);
-        c->cur_fit.deferred = c->deferred + (size_t)b * c->slots_cap;
-        c->cur_fit.n_pool = pool;
-        if (const char* e = getenv("PW_SPLIT_DEBUG")) c->cur_fit.debug = atoi(e);
-    }
     if (c->need_fork) {
         // uploads, single-launch analyses and timing marks on the main stream come first
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
@@ -1668,8 +1392,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(pw_reset_kernel, dim3((unsigned)blocks), dim3(256), 0, c->prod, (unsigned long long*)r->d_out, n8,
                            c->cur_queue, c->cur_slots, r->n_units, c->counter + b, c->counter + PW_SETS + b,
-                           c->counter + 2 * PW_SETS + b, c->counter + 3 * PW_SETS + b, r->d_xw_count + r->cur,
-                           c->cur_fit.q, c->cur_fit.slots2);
+                           c->counter + 2 * PW_SETS + b, c->counter + 3 * PW_SETS + b, r->d_xw_count + r->cur);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev_reset[b], c->prod));
@@ -1691,37 +1414,12 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     c->last_res[b] = (const void*)r;
     // several optimiser launches can be in flight: separate work counters and workspaces
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][0], c->prod));
-    if (split) {
-        // the one-wave workers: the chains of every unit, and the window fits the sampling launch hands over
-        static std::atomic<unsigned long long> attr_done{0};
-        const unsigned long long bit = 1ull << (c->device & 63);
-        if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-            HIP_TRY(hipFuncSetAttribute((const void*)pw_worker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        160 * 1024 - 256 - (int)PW_KERNEL_STATIC_LDS));
-            attr_done.fetch_or(bit, std::memory_order_release);
-        }
-        if (getenv("PW_PLAN_DEBUG"))
-            fprintf(stderr, "launch workers grid %d (pool %d) lds %zu | sampling grid %d lds %zu\n", pa.grid, pool, pa.lds, pc.grid, pc.lds);
-        PwWsArgs wsa;
-        wsa.ws = c->ws + ws_a;
-        wsa.slab = c->slab + (size_t)ws_a * team_slab_bytes(c->p_cap);
-        wsa.adj = nullptr;
-        wsa.xwin = r->d_xw[r->cur]; wsa.xwin_count = r->d_xw_count + r->cur; wsa.xwin_cap = r->xw_cap;
-        wsa.p_cap = c->p_cap;
-        wsa.nb_off = c->nb_off; wsa.nb_idx = c->nb_idx; wsa.nb_bound = c->nb_bound;
-        hipLaunchKernelGGL(pw_worker_kernel, dim3(pa.grid), dim3(64), pa.lds, c->prod, r->n_units, r->d_offset, r->d_xyz, r->d_vdw,
-                           r->d_mass, r->nmax, wsa, c->counter + b, r->d_out, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab,
-                           r->vstride, c->cur_fit, (const unsigned long long*)r->d_ready);
-        HIP_TRY(hipGetLastError());
-    } else {
-        rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod, ws_a, -1, b, PW_ROLE_PRODUCER, false);
-        if (rc != PW_OK) return rc;
-    }
+    rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod, ws_a, -1, b, PW_ROLE_PRODUCER, false);
+    if (rc != PW_OK) return rc;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][1], c->prod));
     HIP_TRY(hipEventRecord(c->ev_prod[b], c->prod));
     hipStream_t cs = c->cons[b];
     HIP_TRY(hipStreamWaitEvent(cs, c->ev_reset[b], 0));
-    // (the residency gate counts the workers that carry a chain: the spare ones of the split pipeline only ever fit)
     hipLaunchKernelGGL(pw_gate_kernel, dim3(1), dim3(64), 0, cs, c->cur_queue,
                        (long)pa.grid < r->n_units ? pa.grid : (int)r->n_units, c->counter + 4 * PW_SETS + 2);
     HIP_TRY(hipGetLastError());
@@ -1740,35 +1438,8 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         }
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][0], cs));
-    if (split) {
-        if (c->split == 2) {
-            // the sampling launch as an instance of this translation unit's kernel (its register budget: two waves per SIMD)
-            rc = launch_plan(c, r, MASK_SAMPLING, pc, cs, ws_c, b * c->max_c, PW_SETS + b, PW_ROLE_SAMPLER, false);
-            if (rc != PW_OK) return rc;
-        } else {
-            PwWsArgs wsa;
-            wsa.ws = c->ws + ws_c;
-            wsa.slab = c->slab + (size_t)ws_c * team_slab_bytes(c->p_cap);
-            wsa.adj = c->adj + (size_t)(b * c->max_c) * team_adj_words(c->p_cap);
-            wsa.xwin = r->d_xw[r->cur]; wsa.xwin_count = r->d_xw_count + r->cur; wsa.xwin_cap = r->xw_cap;
-            wsa.p_cap = c->p_cap;
-            wsa.nb_off = c->nb_off; wsa.nb_idx = c->nb_idx; wsa.nb_bound = c->nb_bound;
-            rc = pw_internal_sampling_launch((void*)cs, pc.grid, pc.lds, r->n_units, r->d_offset, r->d_xyz, r->d_vdw, r->d_mass,
-                                             r->nmax, pc.nrot, pc.nlb, &wsa, r->d_out, c->cur_queue, c->cur_slots, &c->prm,
-                                             c->rsq_tab, r->vstride, &c->cur_fit);
-            if (rc != PW_OK) return rc;
-        }
-        // follow-up: units with more clusters than a ticket holds, through the fused window search (a handful of
-        // teams that find an empty list and leave, nearly always)
-        LaunchPlan pl = pcf;
-        pl.grid = pcf.grid < 16 ? pcf.grid : 16;
-        if (pl.grid > pc.grid) pl.grid = pc.grid;
-        rc = launch_plan(c, r, MASK_WINDOWS, pl, cs, ws_c, b * c->max_c, PW_SETS + b, PW_ROLE_LIST, false);
-        if (rc != PW_OK) return rc;
-    } else {
-        rc = launch_plan(c, r, MASK_WINDOWS, pc, cs, ws_c, b * c->max_c, PW_SETS + b, PW_ROLE_CONSUMER, false);
-        if (rc != PW_OK) return rc;
-    }
+    rc = launch_plan(c, r, MASK_WINDOWS, pc, cs, ws_c, b * c->max_c, PW_SETS + b, PW_ROLE_CONSUMER, false);
+    if (rc != PW_OK) return rc;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][1], cs));
     if (do_avg) {
         HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_gate[b], 0));
@@ -1792,36 +1463,24 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
 // for a finished one -- neither downloaded nor timed
 static int check_queue_error(pw_context* c) {
     UnitQueue q[PW_SETS];
-    FitQueue f[PW_SETS];
     HIP_TRY(hipMemcpy(q, c->queue, sizeof(q), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(f, c->fitq, sizeof(f), hipMemcpyDeviceToHost));
-    bool any = false, anyf = false;
     int which = -1;
-    for (int b = 0; b < PW_SETS; ++b) {
+    for (int b = 0; b < PW_SETS; ++b)
         if (q[b].error != 0 && which < 0) which = b;
-        any = any || q[b].error != 0;
-        anyf = anyf || f[b].error != 0;
-    }
-    if (any || anyf) {
+    if (which >= 0) {
         // (only the flags: the other sets' queues may belong to analyses that are running)
-        for (int b = 0; b < PW_SETS; ++b) {
+        for (int b = 0; b < PW_SETS; ++b)
             if (q[b].error != 0) (void)hipMemset(&c->queue[b].error, 0, sizeof(c->queue[b].error));
-            if (f[b].error != 0) (void)hipMemset(&c->fitq[b].error, 0, sizeof(c->fitq[b].error));
-        }
-        if (any) {
-            // cause 1: a window team waited 5 s for a unit of the optimiser launch; 2: a team waited 5 s for the coordinates of a
-            // streamed batch; 3: a streamed batch was given up while its launches were waiting
-            // ... 4: the optimiser teams of a launch were not all resident within 2 s (pw_gate_kernel)
-            const int cause = q[which].error;
-            snprintf(g_err, sizeof(g_err), "%s (set %d of %d, cause %d: %llu units published, %llu taken, %d optimiser teams started)",
-                     cause == 1 ? "window launch timed out waiting for the optimiser launch"
-                                : (cause == 2 ? "a launch timed out waiting for the coordinates of a streamed batch"
-                                              : (cause == 4 ? "the optimiser launch timed out becoming resident (residency gate)"
-                                                            : "a streamed batch was given up while it was being analysed")),
-                     which, c->cur_sets, cause, q[which].tail, q[which].head, q[which].started);
-        } else {
-            snprintf(g_err, sizeof(g_err), "fit workers timed out waiting for the sampling launch");
-        }
+        // cause 1: a window team waited 5 s for a unit of the optimiser launch; 2: a team waited 5 s for the coordinates of a
+        // streamed batch; 3: a streamed batch was given up while its launches were waiting; 4: the optimiser teams of a
+        // launch were not all resident within 2 s (pw_gate_kernel)
+        const int cause = q[which].error;
+        snprintf(g_err, sizeof(g_err), "%s (set %d of %d, cause %d: %llu units published, %llu taken, %d optimiser teams started)",
+                 cause == 1 ? "window launch timed out waiting for the optimiser launch"
+                            : (cause == 2 ? "a launch timed out waiting for the coordinates of a streamed batch"
+                                          : (cause == 4 ? "the optimiser launch timed out becoming resident (residency gate)"
+                                                        : "a streamed batch was given up while it was being analysed")),
+                 which, c->cur_sets, cause, q[which].tail, q[which].head, q[which].started);
         return PW_E_TIMEOUT;
     }
     return PW_OK;
@@ -2197,7 +1856,6 @@ void pw_resident_free(pw_context* c, pw_resident* r) {
             // (what those launches flagged when they were told to stop is not an error of anybody's next analysis)
             if (given_up && ws >= 0 && c->queue) {
                 (void)hipMemsetAsync(&c->queue[ws].error, 0, sizeof(c->queue[ws].error), c->stream);
-                if (c->fitq) (void)hipMemsetAsync(&c->fitq[ws].error, 0, sizeof(c->fitq[ws].error), c->stream);
             }
         }
         (void)hipStreamSynchronize(c->stream);

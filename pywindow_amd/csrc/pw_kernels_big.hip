@@ -48,7 +48,7 @@ pw_analyse_big_kernel(long n_units, const long* __restrict__ atom_offset, const 
         int n = (int)(atom_offset[u + 1] - a0);
         const long v0 = a0 * vstride;
         if (threadIdx.x == 0) ws->unit = u;
-        analyse_unit<T, 0xffffffffu & ~PW_STAGE_WIN_BULK>(sh, ws, n, xyz + 3 * a0, vdw + v0, mass + v0, stages, out + u, prm);
+        analyse_unit<T, 0xffffffffu>(sh, ws, n, xyz + 3 * a0, vdw + v0, mass + v0, stages, out + u, prm);
     }
 }
 

@@ -31,32 +31,7 @@ struct UnitQueue {
     int error;                 // set when a consumer gives up waiting
     int started;               // producer teams that have begun (gate for the other launches)
 };
-// Second hand-off, between the sampling launch (4-wave teams: find_windows up to the clustering) and the fit
-// workers (one wave per window): one item per cluster, unit * 16 + cluster, published in completion order; the
-// clusters' vectors and the workers' results travel in the unit's FitTicket (pw_unit.hpp).  The sampling team
-// that finishes the last unit closes the queue (`final` = the number of items there will ever be).  Units with
-// more clusters than a ticket holds are listed in `deferred` for the follow-up launch of the fused window search.
-struct FitQueue {
-    unsigned long long tail;     // items published (slots2[0 .. tail) are being / have been written)
-    unsigned long long head;     // items taken
-    unsigned long long final;    // ~0 until the last unit has been sampled, then the final tail
-    int units_done;              // units the sampling launch has finished
-    int n_deferred;
-    int error;
-    int waiting;                 // workers parked until there is a fit or the queue closes (at most FitArgs::n_pool)
-};
-enum : int { PW_ROLE_PLAIN = 0, PW_ROLE_PRODUCER = 1, PW_ROLE_CONSUMER = 2, PW_ROLE_SAMPLER = 3, PW_ROLE_LIST = 4 };
-
-// what the two hand-offs of the split window search need (null / unused in every other launch)
-struct FitArgs {
-    FitQueue* q;
-    int* slots2;            // 16 per unit
-    void* tickets;          // FitTicket (pw_unit.hpp), one per unit
-    int* deferred;          // one per unit
-    int n_pool;             // idle workers that may wait for fits at a time (pw_worker_kernel); the others leave
-    int debug;              // PW_SPLIT_DEBUG (diagnosis): 1 every unit goes to the follow-up launch, 2 fits are not computed
-};
-
+enum : int { PW_ROLE_PLAIN = 0, PW_ROLE_PRODUCER = 1, PW_ROLE_CONSUMER = 2 };
 
 #if defined(__HIPCC__)
 // (slab_bytes / adj_words: team_slab_bytes(p_cap) / team_adj_words(p_cap) of the caller's pw_unit.hpp)

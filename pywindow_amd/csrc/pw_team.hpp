@@ -165,41 +165,6 @@ struct DeviceTeam {
         return v + (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
     }
 };
-// A ROW of 16 lanes as a team: four of them share a wavefront, each running its own optimiser chain
-// (pw_row_chains_kernel).  Only what pw_lbfgsb.hpp asks of a team: lane numbering, a lane-to-lane move with a
-// per-row source (ds_bpermute: the source lane differs between the rows, v_readlane cannot do that), and the
-// wave-level ordering of LDS traffic.  Row reductions (value / value+index over 16 lanes) use the DPP row
-// shifts of DeviceTeam.
-struct RowTeam {
-    static constexpr int NWAVES = 1;
-    static constexpr int WSIZE = 16;
-    static constexpr int SIZE = 16;
-    __device__ static int tid() { return threadIdx.x & 15; }
-    __device__ static int lane() { return threadIdx.x & 15; }
-    __device__ static int wave() { return 0; }
-    __device__ static void wave_sync() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    __device__ static void sync() { wave_sync(); }
-    __device__ static double bcast_u(double v, int src) { return __shfl(v, src, 16); }
-    // minimum over the row, in every lane of the row
-    __device__ static double row_min(double v) {
-        using D = DeviceTeam<1>;
-        D::min_step<0x111, 0xf, 0xf>(v);
-        D::min_step<0x112, 0xf, 0xf>(v);
-        D::min_step<0x114, 0xf, 0xe>(v);
-        D::min_step<0x118, 0xf, 0xc>(v);
-        return __shfl(v, 15, 16);
-    }
-    // (value, index) minimum with smallest-index tie-break over the row, in every lane of the row
-    __device__ static void row_argmin(double& v, int& idx) {
-        DeviceTeam<1>::arg_reduce16<true>(v, idx);
-        v = __shfl(v, 15, 16);
-        idx = __shfl(idx, 15, 16);
-    }
-};
 #endif
 
 }  // namespace pw

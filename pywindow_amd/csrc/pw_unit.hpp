@@ -235,8 +235,7 @@ struct UnitShared {
     // nrot = rotated window frames, nlb = optimiser states (both 0..nwaves)
     // nframes = 1: one frame - the optimiser-chain launch works on the input frame only, the other
     // launches of the pipeline shift it in place; lean = 1: without the window-search variables and the DBSCAN
-    // bit sets (chains, average diameter), 2: with the bit sets but without the per-cluster arrays of the window
-    // fits (the sampling launch: its clusters go to a FitTicket)
+    // bit sets (chains, average diameter)
     PW_HD static size_t bytes(int nmax, int nrot, int nlb, int nframes = 2, int lean = 0, int pcap = PW_P_MAX) {
         size_t n = (size_t)((nmax + 1) & ~1);
         size_t b = lean ? offsetof(UnitVars, win_first) : sizeof(UnitVars);
@@ -2968,14 +2967,12 @@ PW_PRAGMA(unroll PW_UNROLL_KNN)
 // is bulk loops over sampling vectors and atoms and needs no optimiser state.  Returns the number of clusters
 // (their chosen vectors in wa.vec, wa.ok cleared), or -1 when the search has ended (no vector reaches the
 // outside, or a capacity flag: the record is final).  wave_window fits one cluster; windows_finish assembles
-// the record.  One team can do all three in a row (stage_windows: single launches, the host path, molecules
-// beyond LDS), or the pipeline hands the clusters over in a FitTicket: the sampling launch (4-wave teams, a
-// register budget without the optimisers' state) writes it, one-wave fit workers consume it.
-// defer_large: more clusters than a ticket holds (PW_W_MAX) are not set up here -- the count is returned and
-// the caller sends the unit through stage_windows instead.
+// the record.  One team does all three in a row (stage_windows).  (Round 4 also handed the clusters from a sampling
+// launch to one-wave fit workers through a ticket per unit: measured 4-25x slower, removed in round 5 -- DESIGN.md
+// section 3, profiles/r04_split_*.)
 template <class T>
 PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
-                                                                  const pw_params& prm, WinArrays& wa, bool defer_large) {
+                                                                  const pw_params& prm, WinArrays& wa) {
     PW_ASSUME_TEAM_STATE(sh, prm);
     PW_DCHECK(__builtin_amdgcn_read_exec() == ~0ull, 111);
     auto& v = *sh.v;
@@ -3446,7 +3443,6 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
         // the per-cluster arrays: team LDS for what a record holds, the team's global slab beyond
         // (clusters <= core points <= survivors <= p_cap)
         if (label > PW_W_MAX) {
-            if (defer_large) return label;
             wa.vec = ws->xw; wa.d = ws->xw + 3 * (size_t)ws->p_cap; wa.c = ws->xw + 4 * (size_t)ws->p_cap; wa.ok = ws->xw_ok;
         }
         for (int c = T::tid(); c < label; c += T::SIZE) wa.ok[c] = 0;
@@ -3516,18 +3512,12 @@ PW_HD inline int windows_finish(const WinArrays& wa, int ncl, pw_unit_out* out, 
 }
 
 template <class T>
-PW_NOINLINE PW_HD inline int stage_windows_bulk(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
-                                                const pw_params& prm, WinArrays& wa) {
-    return windows_bulk_impl<T>(sh, ws, n, out, prm, wa, true);
-}
-
-template <class T>
 PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
                                              const pw_params& prm) {
     auto& v = *sh.v;
     WinArrays wa;
     wa.vec = (double*)&v.win_vec[0][0]; wa.d = (double*)v.win_d; wa.c = (double*)&v.win_c[0][0]; wa.ok = (int*)v.win_ok;
-    if (windows_bulk_impl<T>(sh, ws, n, out, prm, wa, false) < 0) return;
+    if (windows_bulk_impl<T>(sh, ws, n, out, prm, wa) < 0) return;
     PW_T0(t_w);
     // ---- one window per cluster, clusters dealt round-robin to the waves -------------------
     const int ncl = v.n_clusters;
@@ -3549,154 +3539,11 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     T::sync();
 }
 
-// ---- hand-over between the sampling launch and the fit workers ---------------------------------------------
-// One ticket per unit in global memory.  The sampling team fills ncl / remaining / vec and publishes one queue
-// item per cluster; the worker that fits cluster c writes ok[c], d[c], c[c]; the worker that takes `remaining`
-// to zero assembles the record (windows_finish).  Units with more clusters than a ticket holds never get one
-// (they go through stage_windows in a follow-up launch).
-struct FitTicket {
-    int ncl;
-    int remaining;
-    double vec[PW_W_MAX][3];
-    double d[PW_W_MAX];
-    double c[PW_W_MAX][3];
-    int ok[PW_W_MAX];
-};
-PW_HD inline WinArrays ticket_arrays(FitTicket* t) {
-    WinArrays wa;
-    wa.vec = &t->vec[0][0]; wa.d = t->d; wa.c = &t->c[0][0]; wa.ok = t->ok;
-    return wa;
-}
-
-// Team memory of one fit worker (ONE wave): the molecule's frame -- shifted on the way in, rotated in place by
-// the fit -- radii, an index array, the radius groups, one optimiser block.  Smaller than what an optimiser
-// chain asks for (UnitShared::bytes(nmax, 0, 1, 1, 1)), so the workers of one launch can do either.
-struct FitVars {
-    ClassInfo cls;
-    int evals;
-};
-struct FitShared {
-    PW_LDS FitVars* v;
-    ldouble* vdw;
-    lint* perm;
-    Frame F;
-    PW_LDS void* lb;
-    PW_HD static size_t bytes(int nmax) {
-        const size_t n = (size_t)((nmax + 1) & ~1);
-        return ((sizeof(FitVars) + 15) & ~(size_t)15) + n * 8 + n * 4 + n * 8 * 4 + ((sizeof(LbMem<1>) + 15) & ~(size_t)15);
-    }
-    PW_HD void carve(unsigned char* base, int nmax) {
-        const size_t n = (size_t)((nmax + 1) & ~1);
-        PW_LDS unsigned char* p = (PW_LDS unsigned char*)base;
-        v = (PW_LDS FitVars*)p;
-        p += (sizeof(FitVars) + 15) & ~(size_t)15;
-        ldouble* d = (ldouble*)p;
-        vdw = d; d += n;
-        F.x = d; d += n; F.y = d; d += n; F.z = d; d += n; F.xx = d; d += n;
-        perm = (lint*)d; d += n / 2;
-        lb = (PW_LDS void*)d;
-        F.vdw = vdw; F.perm = perm; F.cls = &v->cls;
-    }
-};
-
-// The frame of a fit, by one wave: atoms grouped by radius like load_unit does (groups in order of first
-// appearance, ascending atom index inside a group; more than PW_KCLS radii: no grouping), coordinates minus
-// `shift` with |r|^2 -- the same numbers make_shifted produces, and every evaluation of the fit is a minimum
-// over atoms (or over groups of per-group minima), so the order inside the arrays cannot show in a result.
-// Groups are found with wave ballots: n x groups / 64 steps instead of load_unit's n^2 / 64.
-template <class T>
-PW_HD inline void load_fit_frame(FitShared& fs, int n, const double* xyz, const double* vdw, const double* shift) {
-    PW_LDS ClassInfo& C = fs.v->cls;
-    const unsigned long long below = T::lane() >= 63 ? ~0ull >> 1 : ((1ull << T::lane()) - 1ull);
-    for (int i = T::lane(); i < n; i += T::WSIZE) fs.vdw[i] = vdw[i];       // caller's order for the moment
-    T::wave_sync();
-    int k = 0;
-    bool many = false;
-    for (int base = 0; base < n && !many; base += T::WSIZE) {
-        const int i = base + T::lane();
-        const double r = i < n ? fs.vdw[i] : 0.0;
-        bool fresh = i < n;
-        for (int g = 0; g < k; ++g) fresh = fresh && !(r == C.vdw[g]);
-        for (;;) {
-            const unsigned long long m = T::ballot(fresh);
-            if (!m) break;
-            if (k == PW_KCLS) { many = true; break; }
-            const double rf = T::bcast_u(r, __builtin_ctzll(m));
-            C.vdw[k] = rf;                      // (every lane stores the same value)
-            k += 1;
-            fresh = fresh && !(r == rf);
-        }
-        T::wave_sync();
-    }
-    if (many) {
-        if (T::lane() == 0) { C.k = 0; C.off[0] = 0; }
-        for (int i = T::lane(); i < n; i += T::WSIZE) fs.perm[i] = i;
-    } else {
-        // positions: group by group, chunk by chunk (stable)
-        int off = 0;
-        for (int g = 0; g < k; ++g) {
-            const double rg = C.vdw[g];
-            if (T::lane() == 0) C.off[g] = off;
-            for (int base = 0; base < n; base += T::WSIZE) {
-                const int i = base + T::lane();
-                const bool mine = i < n && fs.vdw[i] == rg;
-                const unsigned long long m = T::ballot(mine);
-                if (mine) fs.perm[i] = off + __builtin_popcountll(m & below);
-                off += __builtin_popcountll(m);
-            }
-        }
-        if (T::lane() == 0) { C.k = k; C.off[k] = n; }
-    }
-    T::wave_sync();
-    for (int i = T::lane(); i < n; i += T::WSIZE) {
-        const int pos = fs.perm[i];
-        const double x = xyz[3 * i] - shift[0], y = xyz[3 * i + 1] - shift[1], z = xyz[3 * i + 2] - shift[2];
-        fs.F.x[pos] = x; fs.F.y[pos] = y; fs.F.z[pos] = z;
-        fs.F.xx[pos] = sq3(x, y, z);
-    }
-    T::wave_sync();
-    if (!many)      // radii in stored order (every read of the caller-order copy is done)
-        for (int g = 0; g < k; ++g) {
-            const double rg = C.vdw[g];
-            for (int p = C.off[g] + T::lane(); p < C.off[g + 1]; p += T::WSIZE) fs.vdw[p] = rg;
-        }
-    T::wave_sync();
-}
-
-// the shift of find_windows as windows_bulk forms it, from the record (centre of mass and optimised pore
-// centre are there once the optimiser launch has published the unit)
-PW_HD inline void window_shift(const pw_unit_out* out, const pw_params& prm, double* shift) {
-    for (int c = 0; c < 3; ++c) {
-        const double adjust = prm.pore_opt ? out->com[c] - out->pore_opt_c[c] : 0.0;
-        shift[c] = out->com[c] - adjust;
-    }
-}
-
-// One fit by one wave: cluster `cluster` of the unit whose ticket this is.  Returns (lane 0) the number of
-// objective evaluations.
-template <class T>
-PW_HD inline int fit_item(FitShared& fs, TeamWorkspace* ws, int n, const double* xyz, const double* vdw,
-                          const pw_unit_out* out, FitTicket* ticket, int cluster, const pw_params& prm) {
-    double shift[3];
-    window_shift(out, prm, shift);
-#ifdef PW_SABOTAGE
-    shift[0] += 1e-9;
-#endif
-    load_fit_frame<T>(fs, n, xyz, vdw, shift);
-    if (T::lane() == 0) fs.v->evals = 0;
-    T::wave_sync();
-    const WinArrays wa = ticket_arrays(ticket);
-    wave_window<T>(fs.F, fs.F, fs.lb, ws, n, cluster, shift, prm, wa, (int*)&fs.v->evals);
-    T::wave_sync();
-    return fs.v->evals;
-}
-
 // ---- the unit ------------------------------------------------------------------------------------
 // internal stage bits used when one analysis is split over several launches
 constexpr unsigned PW_STAGE_REUSE_OPT = 16u;   // pore centre already in the record (earlier launch)
 constexpr unsigned PW_STAGE_MERGE = 32u;       // record is shared with other launches: no resets
 constexpr unsigned PW_STAGE_COM_ONLY = 64u;    // only what later stages need from stage_basic
-constexpr unsigned PW_STAGE_WIN_BULK = 128u;   // find_windows up to the clustering; the clusters go to a FitTicket
 
 PW_HD inline void record_or_status(pw_unit_out* out, int st, int evals) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -3710,17 +3557,13 @@ PW_HD inline void record_or_status(pw_unit_out* out, int st, int evals) {
 
 constexpr unsigned PW_KERNEL_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 
-// ticket / bulk_ncl (PW_STAGE_WIN_BULK only): where the clusters of the window search go, and how many there
-// are: -1 the search has ended, 0 none (two empty arrays), 1 .. PW_W_MAX to be fitted from the ticket, more:
-// nothing was set up and nothing merged into the record -- the caller runs PW_STAGE_WINDOWS on the unit instead
 template <class T, unsigned KMASK = 0xffffffffu>
 PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const double* xyz,
                                const double* vdw, const double* mass, unsigned stages,
-                               pw_unit_out* out, const pw_params& prm, FitTicket* ticket = nullptr,
-                               int* bulk_ncl = nullptr) {
+                               pw_unit_out* out, const pw_params& prm) {
     const bool merge = (stages & PW_STAGE_MERGE) != 0;
     const bool reuse_opt = (stages & PW_STAGE_REUSE_OPT) != 0;
-    if ((stages & (PW_STAGE_WINDOWS | PW_STAGE_WIN_BULK)) && !reuse_opt && prm.pore_opt) stages |= PW_STAGE_OPT;
+    if ((stages & PW_STAGE_WINDOWS) && !reuse_opt && prm.pore_opt) stages |= PW_STAGE_OPT;
     if (T::tid() == 0 && !merge) {
         out->status = 0;
         out->n_eval = 0;
@@ -3766,23 +3609,7 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
         if (!(prm.pore_opt && (sh.v->status & PW_ST_NEGATIVE_PORE))) stage_windows<T>(sh, ws, n, out, prm);
         else if (T::tid() == 0) out->n_windows = -1;     // no window search: None, whichever launch shape
     }
-    bool deferred = false;
-    if ((KMASK & PW_STAGE_WIN_BULK) && (stages & PW_STAGE_WIN_BULK)) {
-        int ncl = -1;
-        if (!(prm.pore_opt && (sh.v->status & PW_ST_NEGATIVE_PORE))) {
-            WinArrays wa = ticket_arrays(ticket);
-            ncl = stage_windows_bulk<T>(sh, ws, n, out, prm, wa);
-            if (T::tid() == 0) {
-                if (ncl == 0) out->n_windows = 0;        // every survivor is noise: two empty arrays
-                if (ncl >= 1 && ncl <= PW_W_MAX) { ticket->ncl = ncl; ticket->remaining = ncl; }
-            }
-            deferred = ncl > PW_W_MAX;
-        } else if (T::tid() == 0) {
-            out->n_windows = -1;
-        }
-        *bulk_ncl = ncl;
-    }
-    if (T::tid() == 0 && !deferred) {
+    if (T::tid() == 0) {
         if (merge) {
             record_or_status(out, sh.v->status, sh.v->n_eval);
         } else {

@@ -309,27 +309,3 @@ def test_hip_large_and_small_molecules_in_one_batch(hip_ctx):
         assert int(recs[u]["n_windows"]) == n and np.array_equal(recs[u]["win_d"][: max(n, 0)], g["win_d"][k][: max(n, 0)])
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("split", ["1", "2"])
-def test_split_window_search_has_no_cliffs(monkeypatch, split):
-    """The capacity fixtures through the split window search (PW_SPLIT=1 / 2: sampling launch -> FitTickets -> one-wave
-    fit workers): a unit with more clusters than a ticket holds goes to the follow-up launch of the fused search,
-    dropped / negative windows, no survivors, all-noise clusterings and the growing sampling-vector workspace all
-    give the reference's answers -- the records of the default pipeline, byte for byte."""
-    mols, calls = load_cliffs()
-    monkeypatch.setenv("PW_SPLIT", split)
-    ctx = _lib.Context(0)
-    try:
-        for call in calls:
-            if call["kind"] == "avg" or call["error"]:
-                continue
-            el, xyz = mols[call["mol"]]
-            prm, stages = params_of(call)
-            if prm.adjust_windows > 4.0:
-                continue                      # (beyond the pipeline's capacity an analysis is a single launch anyway)
-            extra = []
-            ids = E.element_ids(el)
-            rec = ctx.analyse(_lib.Batch(np.array([0, len(xyz)], np.int64), xyz, E.VDW[ids], E.MASS[ids]), stages, prm, extra)[0]
-            check_window_call(call, rec, extra[0] if extra else np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE))
-    finally:
-        ctx.close()

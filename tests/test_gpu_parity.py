@@ -462,11 +462,10 @@ def test_other_cages_with_fresh_noise_against_live_oracle(hip_ctx):
 
 
 def test_every_launch_shape_gives_the_same_records(monkeypatch):
-    """One analysis, four launch shapes, the same bytes: the default pipeline (optimiser chains | average diameter
-    | window search, three launches), PW_SPLIT=1 (the window search split: a sampling launch of 4-wave teams built
-    for three waves per SIMD, the fits by one-wave workers that also run the chains, hand-over through FitTickets),
-    PW_SPLIT=2 (the same with the sampling launch inside the main translation unit) and PW_FUSED=1 (every stage in
-    one team).  On the real MD frames and on the static molecules (60 to 468 atoms, none to six windows)."""
+    """One analysis, two launch shapes, the same bytes: the default pipeline (optimiser chains | average diameter
+    | window search, three launches) and PW_FUSED=1 (every stage in one team).  On the real MD frames and on the
+    static molecules (60 to 468 atoms, none to six windows).  (Round 4's split window search -- a third and fourth
+    shape -- was measured 4-25x slower and removed in round 5.)"""
     from pywindow_amd import _lib
 
     for tag in ("md20", "static"):
@@ -474,10 +473,8 @@ def test_every_launch_shape_gives_the_same_records(monkeypatch):
         off, xyz, vdw, mass = group_batch(g)
         batch = _lib.Batch(off, xyz, vdw, mass)
         got = {}
-        for name, env in (("pipeline", {}), ("split", {"PW_SPLIT": "1"}), ("split in one translation unit", {"PW_SPLIT": "2"}),
-                          ("one launch", {"PW_FUSED": "1"})):
-            for k in ("PW_SPLIT", "PW_FUSED"):
-                monkeypatch.delenv(k, raising=False)
+        for name, env in (("pipeline", {}), ("one launch", {"PW_FUSED": "1"})):
+            monkeypatch.delenv("PW_FUSED", raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             ctx = _lib.Context(0)
@@ -491,8 +488,7 @@ def test_every_launch_shape_gives_the_same_records(monkeypatch):
             res.free()
             ctx.close()
         check_records(got["pipeline"], g, where=f"{tag} pipeline")
-        for name in ("split", "split in one translation unit", "one launch"):
-            assert got[name].tobytes() == got["pipeline"].tobytes(), (tag, name)
+        assert got["one launch"].tobytes() == got["pipeline"].tobytes(), tag
 
 
 def test_device_equals_host_path_on_degenerate_molecules():

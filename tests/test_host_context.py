@@ -18,15 +18,6 @@ def host_ctx():
     return _lib.Context(-1, host_threads=4)
 
 
-@pytest.fixture(autouse=True, params=["one team", "sampling + fit workers"])
-def launch_shape(request, monkeypatch):
-    """Every test twice: the window search by one team, and in the pipeline's two parts (PW_HOST_SPLIT=1:
-    sampling up to the clustering -> FitTicket -> one fit per cluster on a frame of its own -> assembly; the
-    code of the GPU's sampling launch and fit workers, pw_unit.hpp windows_bulk / fit_item / windows_finish)."""
-    monkeypatch.setenv("PW_HOST_SPLIT", "1" if request.param != "one team" else "0")
-    return request.param
-
-
 @pytest.mark.parametrize("tag", GROUPS)
 def test_host_context_matches_reference(host_ctx, tag):
     g = load_group(tag)

@@ -18,7 +18,7 @@ for var in tests/tools/libpw_var_*.so; do
   grep -a "passed\|failed\|error" $o/gputest_$(basename $var .so).log | tail -2
   cp /tmp/pw_keep.so pywindow_amd/libpywindow_hip.so
 done
-timeout 200 python tests/tools/rowprobe/run_probe.py 1000 2>&1 | grep "product chains" | tee $o/chains_only.txt
+timeout 200 python tests/tools/chains_only.py 1000 2>&1 | grep "product chains" | tee $o/chains_only.txt
 timeout 300 python tests/tools/profile_chains.py 1000 > $o/fine.json 2> $o/fine.err; python - <<P
 import json
 d=json.load(open("$o/fine.json"))

@@ -11,7 +11,7 @@ if "--build" in sys.argv:
     obj = f"/tmp/pwk_prof_{tag}.o"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-DPW_PROFILE",
                            "-DPW_LB_FINE", *[a for a in sys.argv if a.startswith("-D")], "-c", str(csrc / "pw_kernels.hip"), "-o", obj])
-    rest = [str(csrc / o) for o in ("pw_kernels_sampling.o", "pw_kernels_big.o", "pw_rebuild.o", "pw_shape.o", "pw_history.o", "pw_hostpath.o")]
+    rest = [str(csrc / o) for o in ("pw_kernels_big.o", "pw_rebuild.o", "pw_shape.o", "pw_history.o", "pw_hostpath.o")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread", obj, *rest, "-o", str(so)])
     sys.exit(0)
 from pywindow_amd import _lib, synth

@@ -33,14 +33,10 @@ cp $(find $O/pw -name "*counter_collection.csv" | head -1) $O/pmc_write_size.csv
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU -d $O/pv -o pv --output-format csv -- python3 $T/run_stage.py 15 1000 4 > $O/pv.log 2>&1
 cp $(find $O/pv -name "*counter_collection.csv" | head -1) $O/pmc_instruction_counters.csv
 python3 $T/counter_summary.py $O/pmc_instruction_counters.csv 1000 $O/instruction_counters.json > /dev/null
-# 7. the split window search (PW_SPLIT=1: sampling launch + one-wave fit workers), serial kernel stats
-( export PW_SPLIT=1 PW_TAIL_GATE=0 PW_HEAD_GATE=0 PW_SETS_IN_FLIGHT=2
-  timeout 300 rocprofv3 --kernel-trace --stats -d $O/sp -o sp --output-format csv -- python3 $T/timeline.py 1000 8 > $O/sp.log 2>&1 )
-cp $(find $O/sp -name "*kernel_stats.csv" | head -1) $O/split_serial_kernel_stats.csv
 # 8. a molecule beyond LDS (pw_analyse_big_kernel): the 2865-atom shell of the capacity fixtures
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/bg -o bg --output-format csv -- python3 $T/big_unit_probe.py > $O/bg.log 2>&1
 cp $(find $O/bg -name "*kernel_stats.csv" | head -1) $O/big_kernel_stats.csv
 # 9. HISTORY file -> records: streamed against one piece
 timeout 300 python3 $T/e2e_stream.py > $O/e2e_stream.txt 2>&1
-rm -rf $O/ov $O/se $O/tl $O/pf $O/pw $O/pv $O/sp $O/bg
+rm -rf $O/ov $O/se $O/tl $O/pf $O/pw $O/pv $O/bg
 ls -la $O
