@@ -46,8 +46,8 @@ ALGO_FLOP_BY_KERNEL = {
 HBM_PEAK_GBS = 8000.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 # static inputs measured with rocprofv3 --pmc (separate passes; committed summaries), NOT by this run
-TRAFFIC_FILES = ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01j_hbm_traffic.json")
-COUNTER_FILES = ("r04_instruction_counters.json", "r03_instruction_counters.json", "r02_instruction_counters.json", "r01j_instruction_counters.json")
+TRAFFIC_FILES = ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01j_hbm_traffic.json")
+COUNTER_FILES = ("r05_instruction_counters.json", "r04_instruction_counters.json", "r03_instruction_counters.json", "r02_instruction_counters.json", "r01j_instruction_counters.json")
 # the only figure for this metric the reference's repository holds: 715-frame CC3 trajectory,
 # traj.analysis(ncpus=8) in 286.5 s (examples/Example7_AnalysingTrajectorySingleMol.ipynb:569-575)
 REFERENCE_NOTEBOOK_FPS = 715 / 286.5
@@ -205,6 +205,40 @@ def _median_legs(legs):
     return out
 
 
+def _cold_first_call(path):
+    """File name -> records in a FRESH process, milliseconds by leg: importing the package and loading the library,
+    creating the device context (streams, probe, neighbour tables), opening + indexing the file, the first
+    analysis_records call (first launch of every kernel).  None when the child fails."""
+    import subprocess
+
+    code = (
+        "import time, json, sys\n"
+        "t0 = time.perf_counter()\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import pywindow_amd as pw\n"
+        "from pywindow_amd import _lib, engine\n"
+        "_lib.load()\n"
+        "t1 = time.perf_counter()\n"
+        "ctx = engine.context(0)\n"
+        "t2 = time.perf_counter()\n"
+        f"traj = pw.DLPOLY({path!r})\n"
+        "t3 = time.perf_counter()\n"
+        "recs = traj.analysis_records(forcefield='opls', swap_atoms={'he': 'H'})\n"
+        "t4 = time.perf_counter()\n"
+        "recs2 = traj.analysis_records(forcefield='opls', swap_atoms={'he': 'H'})\n"
+        "t5 = time.perf_counter()\n"
+        "print(json.dumps({'import_and_load_ms': 1e3 * (t1 - t0), 'context_ms': 1e3 * (t2 - t1), 'open_index_ms': 1e3 * (t3 - t2),"
+        " 'first_analysis_ms': 1e3 * (t4 - t3), 'second_analysis_ms': 1e3 * (t5 - t4), 'open_plus_first_analysis_ms': 1e3 * (t4 - t2),"
+        " 'units': int(len(recs)), 'ok': bool((recs['status'] == 0).all())}))\n"
+    )
+    try:
+        proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(line[-1]) if line else None
+    except Exception:
+        return None
+
+
 def secondary(ctx, vdw, mass):
     """BASELINE.json's other shapes, reported beside the headline (not part of `value`), each the
     median of five repetitions after a warm-up."""
@@ -233,9 +267,27 @@ def secondary(ctx, vdw, mass):
             return recs
 
         med, reps = _median_ms(e2e, reps=9, warm=2)      # (host-side legs: the box's other tenants show up in them)
+
+        # ... and what comes before the first frame can be read: opening and indexing the file (the DLPOLY constructor:
+        # mmap, the scan for "timestep" records, the atom keys of frame 0 -- the counterpart of _check_history /
+        # _map_history, reference trajectory.py:647-689, 768-833), warm, and the whole thing in a FRESH process
+        def open_only():
+            t = pw.DLPOLY(path)
+            n = t.no_of_frames
+            del t
+            return n
+
+        open_med, open_reps = _median_ms(open_only, reps=9, warm=2)
+        cold = _cold_first_call(path)
         out["e2e_history_to_records"] = {"frames": FRAMES, "ms": med, "frames_per_s": FRAMES / (med * 1e-3), "reps_ms": reps,
+                                         "open_index_ms": open_med, "open_index_reps_ms": open_reps,
+                                         "open_plus_analysis_ms": open_med + med,
+                                         "cold_first_call_ms": cold,
                                          "includes": "tokenising the HISTORY text, H2D, all launches, D2H of the records; the "
-                                                     "analysis is launched first and the reader feeds it (streamed batch)",
+                                                     "analysis is launched first and the reader feeds it (streamed batch).  "
+                                                     "open_index_ms: the DLPOLY(path) constructor, warm; open_plus_analysis_ms: "
+                                                     "file name to records, warm; cold_first_call_ms: the same in a fresh "
+                                                     "process (library load, context creation with its tables, first launch)",
                                          "breakdown_ms": _median_legs(legs[2:]),
                                          "breakdown_note": "host-side legs, medians: the analysis runs asynchronously -- what the "
                                                            "host sees of it is wait_download (which contains the D2H copy)"}
@@ -310,6 +362,105 @@ def secondary(ctx, vdw, mass):
     return out
 
 
+def secondary_multi(ctx, vdw, mass, dist, rank, world, local_rank, backend, tdev, barrier, make_gather, max_over_ranks, args):
+    """BASELINE configs 4 and 5 on N > 1 ranks (every rank calls this: it ends in collectives).
+    (i) config 5, the screen: each rank its ceil(units / N) units resident, ONE launch, the gather of the records
+        inside the timed region (RCCL all_gather_into_tensor over xGMI on the device buffers; gloo in rehearsals).
+    (ii) config 4, the periodic trajectory: ONE HISTORY file per node in /dev/shm, DLPOLY.analysis(modular=True,
+        rebuild=True) sharded by frame, ragged gather of the records to rank 0 (trajectory.py: _analysis_modular).
+    Replaces, on the reference's side, Trajectory._analysis_parallel + pool.get (trajectory.py:496-586)."""
+    import tempfile
+
+    import pywindow_amd as pw
+    from pywindow_amd import _lib, synth
+
+    out = {}
+    rec_bytes = _lib.UNIT_OUT_DTYPE.itemsize
+    # ---- (i) the screen ----
+    total = int(args.multi_units)
+    per = -(-total // world)
+    t_gen = time.perf_counter()
+    _, mine = synth.screen_units(per, first=rank * per)
+    t_gen = time.perf_counter() - t_gen
+    res = ctx.upload(_lib.Batch.uniform(mine, vdw, mass))
+    gather = make_gather(res, per)
+    res.launch(); gather(); barrier(res)                    # warm-up: workspaces grow, the communicator sees the size
+    t0 = time.perf_counter()
+    res.launch()
+    gather()
+    barrier(res)
+    el = max_over_ranks(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    gather()
+    barrier(res)
+    el_g = max_over_ranks(time.perf_counter() - t0)
+    mine_recs = res.download()
+    allrec = gather.records()
+    ok = None
+    if rank == 0:
+        ok = bool(len(allrec) == world * per and allrec[:per].tobytes() == mine_recs.tobytes()
+                  and (allrec["status"] == 0).all() and (allrec["n_atoms"] == N_ATOMS).all())
+    out["config5_screen"] = {
+        "workload": "combinatorial screen, %d units of 168 atoms (BASELINE configs[4]: 5000 cages x 100 frames), "
+                    "%d per rank resident, ONE launch per rank + the gather of the records" % (world * per, per),
+        "units": world * per, "units_per_rank": per, "ms": 1e3 * el, "units_per_s": world * per / el,
+        "gather_alone_ms": 1e3 * el_g, "gather_bytes_per_rank": per * rec_bytes,
+        "gather_bytes_received_per_rank": world * per * rec_bytes, "gather_ok": ok, "backend": backend,
+        "generate_s_rank0": round(t_gen, 2), "windows_eq_4_rank0": int((mine_recs["n_windows"] == 4).sum()),
+        "includes": "launch of the three-kernel pipeline on every rank, all_gather of the fixed-size records (in the timed "
+                    "region), barrier; max over ranks.  Not included: generating and uploading the coordinates"}
+    res.free()
+    del mine
+    # ---- (ii) the periodic trajectory ----
+    cell = os.path.join(ROOT, "tests", "golden", "rebuild.npz")
+    frames = int(args.multi_frames)
+    if os.path.exists(cell) and frames > 0:
+        g = np.load(cell)
+        el_, xyz, lat = g["cc3_cell__in_elements"], g["cc3_cell__in_coordinates"], g["cc3_cell__in_lattice"]
+        base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+        hdir = os.path.join(base, "pw_bench_%d_%d" % (os.getuid(), frames))
+        hpath = os.path.join(hdir, "HISTORY_periodic")
+        t_w = 0.0
+        if local_rank == 0 and not os.path.exists(hpath):
+            os.makedirs(hdir, exist_ok=True)
+            t_w = time.perf_counter()
+            distinct = [xyz + np.random.default_rng(4 + k).normal(0.0, 0.02, size=xyz.shape) for k in range(64)]
+            tmp = hpath + ".tmp%d" % os.getpid()
+            synth.write_history_cycled(tmp, el_, distinct, frames, cell=np.asarray(lat, float).T)
+            os.replace(tmp, hpath)
+            t_w = time.perf_counter() - t_w
+        dist.barrier()
+        traj = pw.DLPOLY(hpath)
+        traj.analysis(frames=list(range(min(64 * world, frames))), modular=True, rebuild=True, lazy=True)     # warm-up
+        traj.analysis_output = {}
+        traj._stores = []
+        barrier_plain = lambda: (dist.barrier())
+        barrier_plain()
+        t0 = time.perf_counter()
+        traj.analysis(frames="all", modular=True, rebuild=True, lazy=True)
+        barrier_plain()
+        el4 = max_over_ranks(time.perf_counter() - t0)
+        legs = dict(traj.last_timings)
+        n_units = None
+        all_ok = None
+        if rank == 0:
+            store = traj.analysis_store()
+            n_units = int(len(store.records))
+            all_ok = bool((store.records["status"] == 0).all() and n_units == 8 * frames)
+        out["config4_periodic"] = {
+            "workload": "%d-frame periodic DL_POLY HISTORY (8 CC3 cages / 1344 atoms per cell; 64 distinct frames cycled), "
+                        "one file per node in %s, DLPOLY.analysis(modular=True, rebuild=True) sharded by frame (BASELINE "
+                        "configs[3])" % (frames, base),
+            "frames": frames, "frames_per_rank": -(-frames // world), "cages": n_units, "ms": 1e3 * el4,
+            "frames_per_s": frames / el4, "cages_per_s": (8 * frames) / el4, "file_mb": round(os.path.getsize(hpath) / 1e6, 1),
+            "write_s": round(t_w, 2), "gather_ok": all_ok, "backend": backend,
+            "breakdown_ms_rank0": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in legs.items()},
+            "expected_gather_bytes_per_rank": 8 * (-(-frames // world)) * rec_bytes,
+            "includes": "every rank: tokenising its frames of the shared file, H2D, periodic re-assembly, analysis of its cages, "
+                        "D2H; then the ragged gather of records and (frame, molecule) tags to rank 0; max over ranks"}
+    return out
+
+
 def _load_profile(names):
     for name in names:
         try:
@@ -320,7 +471,44 @@ def _load_profile(names):
     return None, None
 
 
-SERIAL_STATS_FILES = ("r04_serial_kernel_stats.csv", "r03_serial_kernel_stats.csv")
+def _csrc_sha16():
+    """Hash of pywindow_amd/csrc/* as tests/tools/provenance.py computes it (what a profile summary is tied to)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pywindow_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _provenance_of(name, data=None):
+    """Where a committed profile summary comes from (commit, date, hash of the kernels' sources -- written into the
+    summary by tests/tools/provenance.py at the end of a profile round) and whether the kernels have changed since:
+    {"file", "head", "date", "csrc_sha16", "stale"}; stale is None for summaries older than the stamps."""
+    info = None
+    if isinstance(data, dict):
+        info = data.get("provenance")
+    if info is None and name is not None:
+        try:
+            with open(os.path.join(ROOT, "profiles", name + ".provenance.json")) as fh:
+                info = json.load(fh)
+        except (OSError, ValueError):
+            info = None
+    out = {"file": None if name is None else "profiles/" + name, "head": None, "date": None, "csrc_sha16": None, "stale": None}
+    if info:
+        out.update({k: info.get(k) for k in ("head", "date", "csrc_sha16", "dirty")})
+        try:
+            out["stale"] = bool(info.get("csrc_sha16") != _csrc_sha16())
+        except OSError:
+            out["stale"] = None
+    return out
+
+
+SERIAL_STATS_FILES = ("r05_serial_kernel_stats.csv", "r04_serial_kernel_stats.csv", "r03_serial_kernel_stats.csv")
 # which launch a kernel name of the stats file belongs to (template arguments: waves per team, stage mask)
 _KERNEL_OF = (("pw_analyse_kernel<1, 37u>", "chains"), ("pw_analyse_kernel<4, 98u>", "average"),
               ("pw_analyse_kernel<4, 120u>", "windows"))
@@ -374,6 +562,10 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--multi-units", type=int, default=500000,
+                    help="N > 1: units of the config-5 screen, all ranks together (BASELINE: 5000 cages x 100 frames)")
+    ap.add_argument("--multi-frames", type=int, default=10000,
+                    help="N > 1: frames of the config-4 periodic trajectory, all ranks together (BASELINE: 10k frames x 8 cages)")
     ap.add_argument("--no-strong", action="store_true")
     args = ap.parse_args()
 
@@ -541,6 +733,13 @@ def main():
             gather_ok = bool(len(allrec) == world * args.frames and mine.tobytes() == out.tobytes()
                              and (allrec["status"] == 0).all() and (allrec["n_atoms"] == N_ATOMS).all())
 
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=tdev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     # ---- strong scaling: ONE trajectory of `frames` frames split over the ranks -----------------------
     strong = None
     if dist is not None and not args.no_strong:
@@ -559,6 +758,16 @@ def main():
             res_s.free()
         else:
             strong = {"skipped": f"{args.frames} frames do not split evenly over {world} ranks"}
+
+    # ---- BASELINE configs 4 and 5 across the ranks (N > 1 only; every rank takes part) ------------------
+    multi = None
+    if dist is not None and world > 1 and not args.no_secondary:
+        res.sync()
+        try:
+            multi = secondary_multi(ctx, vdw, mass, dist, rank, world, local_rank, backend, tdev, barrier,
+                                    lambda r, per: StepGather(r, per), max_over_ranks, args)
+        except Exception as exc:  # noqa: BLE001  (every rank raises or none: the collectives are symmetric)
+            multi = {"error": repr(exc)}
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
@@ -595,7 +804,8 @@ def main():
                 valu_issue = {"wave_instructions_per_launch": per_unit * args.frames,
                               "frac": per_unit * args.frames * vi["simd_cycles_per_wave_instruction"]
                                       / (vi["simds"] * vi["clock_ghz"] * 1e9 * k_ms * 1e-3),
-                              "source": f"static: profiles/{cname} (rocprofv3 --pmc SQ_INSTS_VALU), not measured by this run"}
+                              "source": f"static: profiles/{cname} (rocprofv3 --pmc SQ_INSTS_VALU), not measured by this run",
+                              "provenance": _provenance_of(cname, cj)}
             except (KeyError, TypeError, ZeroDivisionError):
                 valu_issue = None
         # per launch of the pipeline, each on its own (no other launch in flight): HIP events on the
@@ -661,7 +871,14 @@ def main():
                          "traffic_note": None if tname is None else
                          f"static: fabric bytes per launch from rocprofv3 PMC (profiles/{tname}), not measured by this run; "
                          "includes Infinity-Cache hits on the re-used per-team workspaces",
-                         "valu_issue_measured": valu_issue},
+                         "traffic_provenance": _provenance_of(tname, tj),
+                         "valu_issue_measured": valu_issue,
+                         "profile_inputs": {
+                             "what": "the static inputs of this line (traffic, VALU issue, per_kernel[*].ms) and the tree they were "
+                                     "measured on; stale = the sources under pywindow_amd/csrc have changed since",
+                             "csrc_sha16_now": _csrc_sha16(),
+                             "traffic": _provenance_of(tname, tj), "counters": _provenance_of(cname, cj),
+                             "serial_kernel_stats": _provenance_of(prof_name if per_kernel else None)}},
         }
         if strong is not None:
             if "value" in strong:
@@ -689,6 +906,8 @@ def main():
                 model[str(n)] = {"frames_per_gpu": args.frames // n, "ms_per_step": ms,
                                  "predicted_frames_per_s": args.frames / (ms * 1e-3)}
             line["strong_scaling_model_1gpu"] = model
+        if multi is not None:
+            line["secondary_multi"] = multi
         if not args.no_secondary and world == 1:
             # (the headline above stands on its own: a secondary figure that fails is reported as such, not fatal)
             try:

@@ -13,6 +13,7 @@
 // contiguous (frames, atoms, 3) buffers that go straight to the GPU.
 #include <fcntl.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
@@ -24,6 +25,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <new>
@@ -32,6 +34,9 @@
 #include <vector>
 
 #include "../../include/pywindow_amd.h"
+
+// (pw_kernels.hip) the calling thread's error text, as pw_last_error() returns it
+extern "C" void pw_internal_set_error(const char* msg);
 
 struct pw_history {
     int fd;
@@ -53,15 +58,21 @@ namespace {
 // team busy runs its ranges on threads of its own, as every call used to.  A forked child starts a fresh team.
 class ReaderTeam {
   public:
+    static constexpr int MAXT = 16;
     static int max_threads() {
         unsigned hw = std::thread::hardware_concurrency();
         int n = hw ? (int)hw : 1;
         if (const char* e = getenv("PW_READER_THREADS")) if (atoi(e) > 0) n = atoi(e);
-        return n > 16 ? 16 : n;
+        return n > MAXT ? MAXT : n;
     }
-    // fn(t) for t in [0, n): returns when all have run
+    // fn(t) for t in [0, n): returns when all have run.  Range t belongs to thread t (the caller is thread 0) -- so a
+    // region is spread over the threads however unevenly they wake up: a worker that came back early used to take
+    // every remaining range while the others were still waking, and a read ran serially -- and whoever finishes its
+    // own range takes over ranges nobody has started yet, so one slow thread does not hold the region up either.
+    // An exception thrown by fn is rethrown here once every range has ended.
     static void run(int n, const std::function<void(int)>& fn) {
         if (n <= 1) { if (n == 1) fn(0); return; }
+        if (n > MAXT) n = MAXT;
         ReaderTeam* team = instance();
         std::unique_lock<std::mutex> region(team->region_, std::try_to_lock);
         if (!region.owns_lock() || !team->start(n - 1)) {
@@ -75,15 +86,22 @@ class ReaderTeam {
             std::lock_guard<std::mutex> g(team->m_);
             team->fn_ = &fn;
             team->n_ = n;
-            team->next_ = 1;
-            team->left_ = n - 1;
+            team->left_ = n;
+            team->error_ = nullptr;
             team->epoch_ += 1;
         }
         team->wake_.notify_all();
-        fn(0);
-        std::unique_lock<std::mutex> g(team->m_);
-        team->done_.wait(g, [&] { return team->left_ == 0; });
-        team->fn_ = nullptr;
+        team->work(0);
+        std::exception_ptr err;
+        {
+            std::unique_lock<std::mutex> g(team->m_);
+            team->done_.wait(g, [&] { return team->left_ == 0; });
+            team->fn_ = nullptr;
+            team->n_ = 0;
+            err = team->error_;
+            team->error_ = nullptr;
+        }
+        if (err) std::rethrow_exception(err);
     }
 
   private:
@@ -99,37 +117,70 @@ class ReaderTeam {
     }
     bool start(int want) {          // (caller holds region_)
         try {
-            while ((int)threads_.size() < want && (int)threads_.size() < 15) {
-                threads_.emplace_back([this] { loop(); });
+            while ((int)threads_.size() < want && (int)threads_.size() < MAXT - 1) {
+                const int id = (int)threads_.size() + 1;
+                threads_.emplace_back([this, id] { loop(id); });
                 threads_.back().detach();
             }
         } catch (...) {
         }
         return (int)threads_.size() >= want;
     }
-    void loop() {
+    // thread `me` of the current region: its own range first, then whatever nobody has claimed
+    void work(int me) {
+        const std::function<void(int)>* fn;
+        int n;
+        unsigned long e;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn = fn_;
+            n = n_;
+            e = epoch_;
+        }
+        if (!fn) return;
+        int finished = 0;
+        std::exception_ptr err;
+        for (int k = 0; k < n; ++k) {
+            const int t = (me + k) % n;
+            if (me >= n && k == 0) continue;             // (a worker beyond this region's width only helps out)
+            // a range is claimed by raising its mark to the region's number: a thread that is still holding an older
+            // region's function (it woke up late) can never claim a range of this one
+            unsigned long cur = claimed_[t].load(std::memory_order_acquire);
+            bool mine = false;
+            while (cur < e && !(mine = claimed_[t].compare_exchange_weak(cur, e, std::memory_order_acq_rel))) {}
+            if (!mine) continue;
+            try {
+                (*fn)(t);
+            } catch (...) {
+                if (!err) err = std::current_exception();
+            }
+            finished += 1;
+        }
+        if (finished || err) {
+            std::lock_guard<std::mutex> g(m_);
+            if (err && !error_) error_ = err;
+            left_ -= finished;
+            if (left_ == 0) done_.notify_all();
+        }
+    }
+    void loop(int me) {
         unsigned long seen = 0;
         for (;;) {
-            const std::function<void(int)>* fn = nullptr;
-            int t = -1;
             {
                 std::unique_lock<std::mutex> g(m_);
-                wake_.wait(g, [&] { return epoch_ != seen && next_ < n_; });
-                // (several ranges may be left: take one, stay awake for the next)
-                t = next_++;
-                fn = fn_;
-                if (next_ >= n_) seen = epoch_;
+                wake_.wait(g, [&] { return epoch_ != seen; });
+                seen = epoch_;
             }
-            (*fn)(t);
-            std::lock_guard<std::mutex> g(m_);
-            if (--left_ == 0) done_.notify_all();
+            work(me);
         }
     }
     std::mutex region_, m_;
     std::condition_variable wake_, done_;
     std::vector<std::thread> threads_;
     const std::function<void(int)>* fn_ = nullptr;
-    int n_ = 0, next_ = 0, left_ = 0;
+    std::atomic<unsigned long> claimed_[MAXT] = {};
+    std::exception_ptr error_;
+    int n_ = 0, left_ = 0;
     unsigned long epoch_ = 0;
 };
 
@@ -417,8 +468,14 @@ int pw_history_stream_read(const pw_history* h, int64_t first_frame, int64_t cou
     std::atomic<int64_t> next{0};
     std::atomic<int> failed{PW_OK};
     std::atomic<int> decoded_all{0};
+    std::atomic<int64_t> bad_frame{-1};
     const auto t0 = std::chrono::steady_clock::now();
     int append_rc = PW_OK;
+    std::string append_err;              // the appender thread's error text (pw_last_error is per thread)
+    // the appender sleeps until a decoder has finished a block (or 200 us have passed): it used to spin on yield(),
+    // a core of the reader's own on machines with no more cores than reader threads
+    std::mutex bm;
+    std::condition_variable bcv;
     auto appends = [&] {
         int64_t appended = 0, p = 0;
         for (;;) {
@@ -427,13 +484,14 @@ int pw_history_stream_read(const pw_history* h, int64_t first_frame, int64_t cou
             const int64_t have = p * B < count ? p * B : count;
             if (have - appended >= min_append || (have == count && have > appended)) {
                 append_rc = pw_resident_stream_append(ctx, res, staging + (size_t)appended * per, first_unit + appended, have - appended);
-                if (append_rc != PW_OK) return;
+                if (append_rc != PW_OK) { append_err = pw_last_error(); return; }
                 appended = have;
                 if (appended == count) return;
                 continue;
             }
             if (failed.load(std::memory_order_acquire) != PW_OK || (all && p < nblocks)) return;   // (a block that never finished)
-            std::this_thread::yield();
+            std::unique_lock<std::mutex> g(bm);
+            bcv.wait_for(g, std::chrono::microseconds(200));
         }
     };
     std::thread appender;
@@ -451,11 +509,19 @@ int pw_history_stream_read(const pw_history* h, int64_t first_frame, int64_t cou
             if (b >= nblocks || failed.load(std::memory_order_relaxed) != PW_OK) return;
             const int64_t f0 = b * B, f1 = f0 + B < count ? f0 + B : count;
             const int rc = read_range(h, first_frame, f0, f1, staging, nullptr);
-            if (rc != PW_OK) { failed.store(rc, std::memory_order_release); return; }
+            if (rc != PW_OK) {
+                int64_t none = -1;
+                bad_frame.compare_exchange_strong(none, first_frame + f0);
+                failed.store(rc, std::memory_order_release);
+                bcv.notify_all();
+                return;
+            }
             done[(size_t)b].store(1, std::memory_order_release);
+            bcv.notify_all();
         }
     });
     decoded_all.store(1, std::memory_order_release);
+    bcv.notify_all();
     const auto t1 = std::chrono::steady_clock::now();
     if (have_appender) appender.join();
     else appends();
@@ -464,8 +530,18 @@ int pw_history_stream_read(const pw_history* h, int64_t first_frame, int64_t cou
         legs_ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
         legs_ms[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
     }
+    // the failing thread's reason, in the CALLING thread's error text (the appends ran on a thread of their own, the
+    // decoders on the reader's threads)
     const int frc = failed.load(std::memory_order_acquire);
-    return frc != PW_OK ? frc : append_rc;
+    if (frc != PW_OK) {
+        char msg[160];
+        snprintf(msg, sizeof(msg), "HISTORY: a frame in the block starting at frame %lld cannot be decoded (%lld atoms expected)",
+                 (long long)bad_frame.load(), (long long)h->natoms);
+        pw_internal_set_error(msg);
+        return frc;
+    }
+    if (append_rc != PW_OK) pw_internal_set_error(append_err.c_str());
+    return append_rc;
 }
 
 // nstep and tstep of the "timestep" record of frame f (the reference keeps them as frame_info,

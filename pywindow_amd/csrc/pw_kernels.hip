@@ -1884,6 +1884,8 @@ int pw_context_gate_timeouts(pw_context* c, uint64_t* count) {
     return PW_OK;
 }
 
+// for the translation units that have no error text of their own (pw_history.cpp): the calling thread's
+extern "C" void pw_internal_set_error(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }
 static void count_retry(pw_context* c) {
     c->retries += 1;
     g_retries_total.fetch_add(1);

@@ -3512,8 +3512,8 @@ PW_HD inline int windows_finish(const WinArrays& wa, int ncl, pw_unit_out* out, 
 }
 
 template <class T>
-PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
-                                             const pw_params& prm) {
+PW_HD inline __attribute__((always_inline)) void stage_windows_impl(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
+                                                                    const pw_params& prm) {
     auto& v = *sh.v;
     WinArrays wa;
     wa.vec = (double*)&v.win_vec[0][0]; wa.d = (double*)v.win_d; wa.c = (double*)&v.win_c[0][0]; wa.ok = (int*)v.win_ok;
@@ -3539,6 +3539,14 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     T::sync();
 }
 
+// out of line for the kernels that hold several stages; the window launch's own kernel (PW_KERNEL_WINDOWS) inlines the
+// stage -- a kernel saves no callee-saved registers, an out-of-line stage that fills the register file saves a hundred
+template <class T>
+PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out,
+                                             const pw_params& prm) {
+    stage_windows_impl<T>(sh, ws, n, out, prm);
+}
+
 // ---- the unit ------------------------------------------------------------------------------------
 // internal stage bits used when one analysis is split over several launches
 constexpr unsigned PW_STAGE_REUSE_OPT = 16u;   // pore centre already in the record (earlier launch)
@@ -3556,6 +3564,7 @@ PW_HD inline void record_or_status(pw_unit_out* out, int st, int evals) {
 }
 
 constexpr unsigned PW_KERNEL_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
+constexpr unsigned PW_KERNEL_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 
 template <class T, unsigned KMASK = 0xffffffffu>
 PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const double* xyz,
@@ -3606,7 +3615,13 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
         if (T::wave() == 0) PW_T1(ws, 13, t_a);
     }
     if (stages & PW_STAGE_WINDOWS) {
-        if (!(prm.pore_opt && (sh.v->status & PW_ST_NEGATIVE_PORE))) stage_windows<T>(sh, ws, n, out, prm);
+        if (!(prm.pore_opt && (sh.v->status & PW_ST_NEGATIVE_PORE))) {
+#ifdef PW_INLINE_WINDOW_STAGE
+            if (KMASK == PW_KERNEL_WINDOWS) stage_windows_impl<T>(sh, ws, n, out, prm);
+            else
+#endif
+            stage_windows<T>(sh, ws, n, out, prm);
+        }
         else if (T::tid() == 0) out->n_windows = -1;     // no window search: None, whichever launch shape
     }
     if (T::tid() == 0) {

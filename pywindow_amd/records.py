@@ -117,16 +117,31 @@ class RecordStore:
             raise ValueError("header too large")
         # the file is sized first and filled through a memory map: one copy into the page cache, no write() calls
         # (measured 2x faster than tofile() on the container's disk)
-        with open(path, "wb") as fh:
-            fh.truncate(at)
-        out = np.memmap(path, dtype=np.uint8, mode="r+", shape=(at,))
-        out[:len(head)] = np.frombuffer(head, dtype=np.uint8)
-        for k, a in arrays.items():
-            if a.nbytes:
-                o = meta["arrays"][k]["offset"]
-                out[o:o + a.nbytes] = a.view(np.uint8).reshape(-1)
-        out.flush()
-        del out
+        # ... into a temporary file beside the target, moved over it at the end: the arrays of a store that was LOADED
+        # from `path` are read-only memory maps of that very file, and truncating it first would pull the pages from
+        # under them (load, then save to the same name); a reader also never sees a half-written file
+        import os
+        import tempfile
+
+        fd, tmp = tempfile.mkstemp(prefix=path.name + ".", suffix=".tmp", dir=str(path.parent))
+        try:
+            with os.fdopen(fd, "wb") as fh:
+                fh.truncate(at)
+            out = np.memmap(tmp, dtype=np.uint8, mode="r+", shape=(at,))
+            out[:len(head)] = np.frombuffer(head, dtype=np.uint8)
+            for k, a in arrays.items():
+                if a.nbytes:
+                    o = meta["arrays"][k]["offset"]
+                    out[o:o + a.nbytes] = a.view(np.uint8).reshape(-1)
+            out.flush()
+            del out
+            os.replace(tmp, path)
+        except BaseException:
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
+            raise
         return path
 
     @classmethod

@@ -100,6 +100,39 @@ def write_history(path, elements, frames, title: str = "synthetic trajectory (py
     return path
 
 
+def write_history_cycled(path, elements, distinct_frames, n_frames: int,
+                         title: str = "synthetic trajectory, distinct frames cycled (pywindow_amd.synth)",
+                         tstep: float = 0.0007, cell=None) -> pathlib.Path:
+    """A LONG keytrj=0 HISTORY file in seconds: the text of ``distinct_frames`` (a list of (N,3) arrays) is
+    formatted once and the file is ``n_frames`` "timestep" records that cycle through those bodies -- the same layout
+    and the same parsing / analysis work per frame as ``write_history``, without formatting ten million lines in
+    Python (a 10 000-frame, 1344-atom trajectory is 1 GB of text)."""
+    elements = list(elements)
+    natms = len(elements)
+    imcon = 0
+    cell_lines = ""
+    if cell is not None:
+        cell = np.asarray(cell, dtype=float)
+        cubic = np.allclose(cell, np.diag(np.diag(cell))) and np.allclose(np.diag(cell), cell[0, 0])
+        imcon = 1 if cubic else 3
+        cell_lines = "".join("%20.10f%20.10f%20.10f\n" % tuple(row) for row in cell)
+    keys = ["%-8s%10d%12.6f%12.6f\n" % (el, i + 1, 0.0, 0.0) for i, el in enumerate(elements)]
+    bodies = []
+    for xyz in distinct_frames:
+        rows = np.asarray(xyz, dtype=float).tolist()
+        body = [None] * (2 * natms)
+        body[0::2] = keys
+        body[1::2] = ["%12.4E%12.4E%12.4E\n" % (r[0], r[1], r[2]) for r in rows]
+        bodies.append((cell_lines + "".join(body)).encode())
+    path = pathlib.Path(path)
+    with path.open("wb") as fh:
+        fh.write((title + "\n" + "%10d%10d%10d\n" % (0, imcon, natms)).encode())
+        for k in range(n_frames):
+            fh.write(("timestep%10d%10d%10d%10d%12.6f\n" % (k + 1, natms, 0, imcon, tstep)).encode())
+            fh.write(bodies[k % len(bodies)])
+    return path
+
+
 def write_synthetic_history(
     path,
     n_frames: int,
@@ -135,6 +168,21 @@ def synthetic_units(
     out = np.empty((n_frames,) + base.shape)
     for k in range(n_frames):
         out[k] = quantise_like_history(noisy_frame(base, seed_base + first + k, sigma))
+    return elements, out
+
+
+def screen_units(n_units: int, first: int = 0, frames_per_cage: int = 100, sigma: float = 0.10,
+                 seed_base: int = SEED_BASE) -> tuple[np.ndarray, np.ndarray]:
+    """BASELINE config 5 (combinatorial screen: random-perturbed cages x frames): unit u is frame u % frames_per_cage
+    of cage u // frames_per_cage, CC3 + N(0, sigma) with seed ``seed_base + 1000 * cage + frame`` (SURVEY.md 8d) -- so
+    a unit's coordinates do not depend on how the screen is sharded.  No text round trip (a screen's coordinates are
+    not read from a HISTORY file).  Returns ``(elements, coordinates (n_units, N, 3))`` for units first ..."""
+    elements, base = load_cc3_base()
+    out = np.empty((n_units,) + base.shape)
+    for i in range(n_units):
+        u = first + i
+        cage, frame = divmod(u, frames_per_cage)
+        out[i] = base + np.random.default_rng(seed_base + 1000 * cage + frame).normal(0.0, sigma, size=base.shape)
     return elements, out
 
 

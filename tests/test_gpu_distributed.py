@@ -193,7 +193,7 @@ def test_two_ranks_on_two_gpus_over_rccl(hip_ctx, tmp_path):
     assert got[1][2] == {}
 
 
-def _run_bench_child(extra_env, gpus=2, frames=240):
+def _run_bench_child(extra_env, gpus=2, frames=240, multi=None):
     """``python bench.py --gpus N`` as a FRESH child process (it starts its own ranks through
     torch.distributed.run before touching a GPU); returns the parsed JSON line."""
     import json
@@ -207,7 +207,9 @@ def _run_bench_child(extra_env, gpus=2, frames=240):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1",
-           "--frames", str(frames), "--no-cpu-baseline", "--no-secondary"]
+           "--frames", str(frames), "--no-cpu-baseline"]
+    # multi = (units, frames): BASELINE configs 5 and 4 across the ranks at reduced size (bench.py: secondary_multi)
+    cmd += ["--no-secondary"] if multi is None else ["--multi-units", str(multi[0]), "--multi-frames", str(multi[1])]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
@@ -229,6 +231,21 @@ def _check_multi_rank_line(line, world, frames):
         strong["efficiency"] * world)
 
 
+def _check_multi_blocks(line, world, units, frames):
+    """The blocks the first real SCALE run has to carry for BASELINE configs 4 and 5 (round-4 review, item 5)."""
+    multi = line["secondary_multi"]
+    assert "error" not in multi, multi
+    c5 = multi["config5_screen"]
+    per = -(-units // world)
+    assert c5["units"] == world * per and c5["units_per_rank"] == per and c5["gather_ok"] is True
+    assert c5["units_per_s"] > 0 and c5["gather_bytes_per_rank"] == per * 696 and c5["gather_alone_ms"] > 0
+    c4 = multi["config4_periodic"]
+    assert c4["frames"] == frames and c4["cages"] == 8 * frames and c4["gather_ok"] is True
+    assert c4["frames_per_s"] > 0 and c4["frames_per_rank"] == -(-frames // world)
+    assert c4["expected_gather_bytes_per_rank"] == 8 * c4["frames_per_rank"] * 696
+    assert c4["breakdown_ms_rank0"]["pieces"] >= 1
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_executes_on_hardware_gloo():
     """The multi-rank command itself, executed: two ranks started by ``bench.py --gpus 2`` on this box's
@@ -236,9 +253,10 @@ def test_bench_two_ranks_executes_on_hardware_gloo():
     group forms, every step ends with the gather inside the timed region, rank 0 checks the gathered
     records against its own and prints the line, a strong-scaling block included.  (Trajectory fan-out of
     the reference: trajectory.py:553-586.)"""
-    line = _run_bench_child({"PW_BENCH_BACKEND": "gloo", "PW_BENCH_DEVICE": "0"})
+    line = _run_bench_child({"PW_BENCH_BACKEND": "gloo", "PW_BENCH_DEVICE": "0"}, multi=(1500, 96))
     _check_multi_rank_line(line, 2, 240)
     assert line["config"]["backend"] == "gloo"
+    _check_multi_blocks(line, 2, 1500, 96)
 
 
 @pytest.mark.gpu
@@ -248,8 +266,9 @@ def test_bench_eight_ranks_dry_run_gloo():
     has to say -- the world size the process group reports, a gather that rank 0 verified, per-rank step times,
     the strong-scaling block, and where every rank ran (device ordinal, PCI bus id), so that "did RCCL see eight
     ranks on eight GPUs" is answerable from the JSON alone."""
-    line = _run_bench_child({"PW_BENCH_BACKEND": "gloo", "PW_BENCH_DEVICE": "0"}, gpus=8, frames=64)
+    line = _run_bench_child({"PW_BENCH_BACKEND": "gloo", "PW_BENCH_DEVICE": "0"}, gpus=8, frames=64, multi=(1000, 64))
     _check_multi_rank_line(line, 8, 64)
+    _check_multi_blocks(line, 8, 1000, 64)
     cfg = line["config"]
     assert cfg["world_size_reported_by_backend"] == 8 and cfg["world_size_env"] == 8
     assert [r["rank"] for r in cfg["ranks"]] == list(range(8)) and [r["local_rank"] for r in cfg["ranks"]] == list(range(8))

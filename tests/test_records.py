@@ -172,3 +172,22 @@ def test_config5_sized_result_saves_and_reopens_within_a_second(tmp_path):
             assert save < 1.0 and reopen < 0.2
         finally:
             shutil.rmtree(folder, ignore_errors=True)
+
+
+def test_a_loaded_store_can_be_saved_over_its_own_file(tmp_path):
+    """load_records(p) then save to the same name: the loaded arrays are memory maps of p, so the file must not be
+    truncated under them (advisor, round 4) -- the bytes on disk afterwards are the bytes before."""
+    from pywindow_amd.records import RecordStore
+
+    recs = np.zeros(500, dtype=_lib.UNIT_OUT_DTYPE)
+    recs["pore_d"] = np.arange(500)
+    recs["n_windows"] = 4
+    store = RecordStore(recs, np.arange(500))
+    p = store.save(tmp_path / "again")
+    before = p.read_bytes()
+    loaded = RecordStore.load(p)
+    assert isinstance(loaded.records, np.memmap)
+    loaded.save(p)
+    assert p.read_bytes() == before
+    assert float(RecordStore.load(p).records["pore_d"][499]) == 499.0
+    assert [f.name for f in tmp_path.iterdir()] == [p.name]          # (no temporary file left behind)

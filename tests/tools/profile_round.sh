@@ -40,3 +40,5 @@ cp $(find $O/bg -name "*kernel_stats.csv" | head -1) $O/big_kernel_stats.csv
 timeout 300 python3 $T/e2e_stream.py > $O/e2e_stream.txt 2>&1
 rm -rf $O/ov $O/se $O/tl $O/pf $O/pw $O/pv $O/bg
 ls -la $O
+# 10. where these numbers come from: commit (.pw_head, written by `provenance.py stamp` before gpurun), date, hash of csrc/*
+python3 $T/provenance.py annotate $O/hbm_traffic.json $O/instruction_counters.json $O/serial_kernel_stats.csv $O/overlapped_kernel_stats.csv $O/big_kernel_stats.csv > $O/provenance.json
