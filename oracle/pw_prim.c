@@ -66,13 +66,25 @@ void pwo_gaps(int64_t n, const double *xyz, const double *xx, const double *vdw,
  * first 12*floor(w/12) columns of the kernel call that covers it -- one call of width P for the columns left of
  * the last row panel (P = 0 up to N = 192, 32*ceil(floor(N/2)/32) above), one per 32 columns inside it
  * (w = min(32, N - 32*floor(c/32))); every other entry as fma(z,z', fma(y,y', x*x')). */
+/* Where the last row panel starts: panels of 192 rows (GEMM_P) while at least 384 are left, then what is left in two
+ * halves rounded to 32, then the rest -- the level-3 driver's recurrence with ONE BLAS thread (from 383 atoms OpenBLAS
+ * threads the product and the reference's last bit follows the core count; the platform restated is one thread). */
+static int64_t last_panel_start(int64_t n) {
+    int64_t start = 0;
+    for (;;) {
+        int64_t rem = n - start;
+        int64_t mi = rem >= 384 ? 192 : (rem > 192 ? 32 * ((rem / 2 + 31) / 32) : rem);
+        if (start + mi >= n) return start;
+        start += mi;
+    }
+}
 static int edge_order(int64_t n, int64_t i, int64_t j) {
-    if (n % 8 < 4 || n > 382) return 0;
+    if (n % 8 < 4) return 0;
     int64_t t0 = 8 * (n / 8);
     int ei = i >= t0 && i < t0 + 4, ej = j >= t0 && j < t0 + 4;
     if (!ei && !ej) return 0;
     int64_t c = ei ? j : i;
-    int64_t panel = n > 192 ? 32 * ((n / 2 + 31) / 32) : 0;
+    int64_t panel = last_panel_start(n);
     if (c < panel) return c < 12 * (panel / 12);
     int64_t w = n - 32 * (c / 32);
     if (w > 32) w = 32;

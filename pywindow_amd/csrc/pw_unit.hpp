@@ -1573,10 +1573,24 @@ PW_HD inline void make_shifted(UnitShared& sh, int n, double cx, double cy, doub
 // tens of thousands of random molecules.  DESIGN.md section 7.
 struct GramEdgeRule {
     int t0, panel, panel_wide, nfull, limlast;
-    PW_HD static bool applies(int n) { return (n % 8 >= 4) && n <= 382; }
+    PW_HD static bool applies(int n) { return n % 8 >= 4; }
+    // where the last row panel of the BLAS's level-3 driver starts (GEMM_P = 192, panels rounded to 32): a panel of 192
+    // rows while at least 384 are left, then what is left in two halves, then the rest.  This is the recurrence of ONE
+    // BLAS thread (probed entry by entry up to 8197 atoms, round 5); up to 382 atoms it is what every thread count
+    // gives, from 383 OpenBLAS shares the product among its threads and the reference's own last bit follows the core
+    // count -- the platform restated here is OPENBLAS_NUM_THREADS=1.
+    PW_HD static int last_panel_start(int n) {
+        int start = 0;
+        for (;;) {
+            const int rem = n - start;
+            const int mi = rem >= 384 ? 192 : (rem > 192 ? 32 * ((rem / 2 + 31) / 32) : rem);
+            if (start + mi >= n) return start;
+            start += mi;
+        }
+    }
     PW_HD explicit GramEdgeRule(int n) {
         t0 = applies(n) ? 8 * (n / 8) : 0x40000000;
-        panel = n > 192 ? 32 * ((n / 2 + 31) / 32) : 0;
+        panel = last_panel_start(n);
         panel_wide = 12 * (panel / 12);
         nfull = 32 * (n / 32);
         limlast = 12 * ((n - nfull) / 12);

@@ -580,3 +580,12 @@ def test_the_edge_tile_of_the_distance_matrix_on_the_device(hip_ctx):
     g, batch = edge_tile_batch()
     check_edge_tile(g, hip_ctx.analyse(batch, _lib.STAGE_ALL))
 
+
+
+def test_max_dim_beyond_the_blas_threading_size_on_the_device(hip_ctx):
+    """tests/test_host_context.py::test_max_dim_beyond_the_blas_threading_size, on the device: 383 ... 1340 atoms, the
+    deciding pair on the BLAS's edge tile, scikit-learn with one BLAS thread as the reference."""
+    from test_host_context import max_dim_beyond_382
+
+    tot, bad = max_dim_beyond_382(hip_ctx, seed=6)
+    assert tot == 30 and bad == 0

@@ -201,3 +201,39 @@ def test_host_context_serves_the_analysis_only(host_ctx):
     L = _lib.load()
     h = ctypes.c_void_p()
     assert L.pw_context_create(-2, ctypes.byref(h)) == -1        # PW_E_NO_DEVICE: only -1 names the host
+
+
+def max_dim_beyond_382(ctx, seed=5, rounds=2):
+    """max_dim of molecules of 383 ... 1340 atoms whose deciding pair has an atom of the BLAS's edge tile, against
+    scikit-learn's distance matrix computed with ONE BLAS thread (from 383 atoms OpenBLAS threads the product and the
+    reference's last bit follows the thread count; the platform restated is one thread -- DESIGN.md section 7,
+    utilities.py:355-372).  Returns (molecules, mismatches)."""
+    threadpoolctl = pytest.importorskip("threadpoolctl")
+    blas = [d for d in threadpoolctl.threadpool_info() if d.get("internal_api") == "openblas"]
+    if not blas or any(d.get("architecture") != "SkylakeX" for d in blas):
+        pytest.skip("the restated orders are those of OpenBLAS's SkylakeX kernels")
+    from sklearn.metrics.pairwise import euclidean_distances
+
+    rng = np.random.default_rng(seed)
+    radii = np.array([1.2, 1.7, 1.55, 1.52, 1.8])
+    tot = bad = 0
+    with threadpoolctl.threadpool_limits(limits=1, user_api="blas"):
+        for n in [383, 388, 396, 412, 444, 476, 508, 572, 580, 700, 765, 772, 900, 1004, 1340] * rounds:
+            p = rng.normal(size=(n, 3))
+            xyz = p / np.linalg.norm(p, axis=1)[:, None] * rng.uniform(6.0, 12.0) + rng.normal(scale=0.2, size=(n, 3))
+            if n % 8 >= 4:
+                t0 = 8 * (n // 8)
+                xyz[t0:t0 + 4] *= rng.uniform(1.05, 1.3)
+            xyz = np.round(xyz, 6)
+            vdw = radii[rng.integers(0, int(rng.integers(1, 6)), size=n)]
+            d = np.triu(euclidean_distances(xyz, xyz) + (vdw[:, None] + vdw[None, :]))
+            i, j = np.unravel_index(np.argmax(d), d.shape)
+            r = ctx.analyse(_lib.Batch(np.array([0, n], np.int64), xyz, vdw, np.ones(n)), _lib.STAGE_BASIC)[0]
+            tot += 1
+            bad += not (int(r["maxd_i"]) == int(i) and int(r["maxd_j"]) == int(j) and float(r["maxd"]) == float(d[i, j]))
+    return tot, bad
+
+
+def test_max_dim_beyond_the_blas_threading_size(host_ctx):
+    tot, bad = max_dim_beyond_382(host_ctx)
+    assert tot == 30 and bad == 0

@@ -55,7 +55,8 @@ def test_oracle_on_the_edge_tile_of_the_distance_matrix():
 def test_edge_tile_rule_against_sklearn_live():
     """The N x N restatement (oracle/pw_prim.c: pwo_max_dim with edge_order) against sklearn's own distance matrix on
     random molecules of every size class: below and above the BLAS's row panel (192), with and without an edge tile,
-    up to the size from which the BLAS threads the product (383).  The rule belongs to OpenBLAS's AVX-512 kernels."""
+    up to the size from which the BLAS threads the product (383) with whatever thread count this machine gives, and
+    beyond it with one BLAS thread.  The rule belongs to OpenBLAS's AVX-512 kernels."""
     import numpy  # noqa: F401  (loads the BLAS threadpoolctl reports on)
     threadpoolctl = pytest.importorskip("threadpoolctl")
 
@@ -77,6 +78,22 @@ def test_edge_tile_rule_against_sklearn_live():
         d = np.triu(d)
         i, j = np.unravel_index(np.argmax(d), d.shape)
         assert O.max_dim(O.Cage(xyz, vdw, np.ones(n))) == (int(i), int(j), float(d[i, j])), n
+    # From 383 atoms OpenBLAS shares the product among its threads and the entries of the edge tile follow the thread
+    # count: the platform restated there is ONE BLAS thread, whose level-3 panel recurrence (pw_prim.c:
+    # last_panel_start) explains every entry probed up to 8197 atoms.  The deciding pair is forced onto an edge atom
+    # (the four atoms of the last partial 8-block moved outwards), so that the edge rule decides the value.
+    with threadpoolctl.threadpool_limits(limits=1, user_api="blas"):
+        for n in [383, 388, 396, 412, 444, 476, 508, 572, 580, 700, 765, 772, 900, 1004, 1012, 1340] * 2:
+            p = rng.normal(size=(n, 3))
+            xyz = p / np.linalg.norm(p, axis=1)[:, None] * rng.uniform(6.0, 12.0) + rng.normal(scale=0.2, size=(n, 3))
+            if n % 8 >= 4:
+                t0 = 8 * (n // 8)
+                xyz[t0:t0 + 4] *= rng.uniform(1.05, 1.3)
+            xyz = np.round(xyz, 6)
+            vdw = radii[rng.integers(0, int(rng.integers(1, 6)), size=n)]
+            d = np.triu(euclidean_distances(xyz, xyz) + (vdw[:, None] + vdw[None, :]))
+            i, j = np.unravel_index(np.argmax(d), d.shape)
+            assert O.max_dim(O.Cage(xyz, vdw, np.ones(n))) == (int(i), int(j), float(d[i, j])), n
 
 
 def test_distance_primitive_matches_captured_objective_values():

@@ -41,16 +41,29 @@ def distance(g, xi, xj):
     return np.sqrt(max(fma(-2.0, g, xi) + xj, 0.0))
 
 
+def last_panel_start(n):
+    """Panels of 192 rows while at least 384 are left, then what is left in two halves rounded to 32, then the rest:
+    the level-3 driver's recurrence with ONE BLAS thread (run this script with OPENBLAS_NUM_THREADS=1 beyond 382 atoms:
+    from 383 OpenBLAS threads the product and the entries follow the thread count)."""
+    start = 0
+    while True:
+        rem = n - start
+        mi = 192 if rem >= 384 else (32 * ((rem // 2 + 31) // 32) if rem > 192 else rem)
+        if start + mi >= n:
+            return start
+        start += mi
+
+
 def edge_order(n, i, j):
     """The rule the library and the oracle restate (pw_unit.hpp: GramEdgeRule, pw_prim.c: edge_order)."""
-    if n % 8 < 4 or n > 382:          # from 383 atoms the BLAS threads the product: machine-dependent, not restated
+    if n % 8 < 4:
         return False
     t0 = 8 * (n // 8)
     ei, ej = t0 <= i < t0 + 4, t0 <= j < t0 + 4
     if not (ei or ej):
         return False
     c = j if ei else i
-    panel = 32 * ((n // 2 + 31) // 32) if n > 192 else 0      # where the last row panel starts (GEMM_P = 192)
+    panel = last_panel_start(n)                               # where the last row panel starts (GEMM_P = 192)
     if c < panel:                                             # one kernel call for everything left of the panel
         return c < 12 * (panel // 12)
     w = min(32, n - 32 * (c // 32))
