@@ -221,7 +221,7 @@ def _cold_first_call(path):
         "t1 = time.perf_counter()\n"
         "ctx = engine.context(0)\n"
         "t2 = time.perf_counter()\n"
-        f"traj = pw.DLPOLY({path!r})\n"
+        f"traj = pw.DLPOLY({str(path)!r})\n"
         "t3 = time.perf_counter()\n"
         "recs = traj.analysis_records(forcefield='opls', swap_atoms={'he': 'H'})\n"
         "t4 = time.perf_counter()\n"
@@ -234,9 +234,9 @@ def _cold_first_call(path):
     try:
         proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
         line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
-        return json.loads(line[-1]) if line else None
-    except Exception:
-        return None
+        return json.loads(line[-1]) if line else {"error": (proc.stderr or proc.stdout)[-400:]}
+    except Exception as exc:  # noqa: BLE001
+        return {"error": repr(exc)}
 
 
 def secondary(ctx, vdw, mass):
@@ -444,7 +444,7 @@ def secondary_multi(ctx, vdw, mass, dist, rank, world, local_rank, backend, tdev
         n_units = None
         all_ok = None
         if rank == 0:
-            store = traj.analysis_store()
+            store = traj.analysis_store
             n_units = int(len(store.records))
             all_ok = bool((store.records["status"] == 0).all() and n_units == 8 * frames)
         out["config4_periodic"] = {
