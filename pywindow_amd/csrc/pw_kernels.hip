@@ -610,6 +610,11 @@ extern "C" void pw_internal_block_give(pw_context* c, void* p, size_t bytes) { b
 // or what a unit of an earlier analysis asked for, whichever is larger
 // analyses in flight (= buffer sets of a batch) when PW_SETS_IN_FLIGHT does not say: see launch_pipeline
 static int auto_sets(long n_units) { return n_units <= 600 ? 4 : (n_units <= 3000 ? 3 : 2); }
+// the share of the previous launch's units that must have been published / taken before the next optimiser / window
+// launch of the same batch starts, where the environment does not say: round 5's re-sweep on the faster chains --
+// 1000 units 1.26 ms at 70 % against 1.29 at 50 %, 250 units 0.62-0.66 ms at 50 % against 0.71 at 70 %
+// (profiles/r05_resweep.txt)
+static int gate_pct(int configured, long n_units) { return configured >= 0 ? configured : (n_units <= 600 ? 50 : 70); }
 
 static int wanted_p_cap(const pw_context* c) {
     int p = params_p_cap(c->prm.adjust_windows, c->prm.adjust_average);
@@ -902,13 +907,13 @@ int pw_context_create(int device, pw_context** out) {
     }
     {
         const char* hg = getenv("PW_HEAD_GATE");
-        c->head_pct = hg ? atoi(hg) : 50;
-        if (c->head_pct < 0 || c->head_pct > 100) c->head_pct = 0;
+        c->head_pct = hg ? atoi(hg) : -1;        // (-1: by batch size, gate_pct below)
+        if (c->head_pct < -1 || c->head_pct > 100) c->head_pct = 0;
     }
     {
         const char* tg = getenv("PW_TAIL_GATE");
-        c->tail_pct = tg ? atoi(tg) : 50;
-        if (c->tail_pct < 0 || c->tail_pct > 100) c->tail_pct = 0;
+        c->tail_pct = tg ? atoi(tg) : -1;
+        if (c->tail_pct < -1 || c->tail_pct > 100) c->tail_pct = 0;
     }
     c->need_fork = 1;
     CTX_TRY(hipEventCreate(&c->ev0));
@@ -1272,11 +1277,15 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     // A batch of up to a few units per SIMD is latency-bound by its optimiser chains: one window team
     // per CU keeps LDS free for the chains of the next launch (measured on 1000 units: 2.56 -> 2.45 ms);
     // larger batches want every team the LDS admits (4000 units: 9.2 ms against 10.0).
+    // (round 5, after the optimiser chains got a third faster: beyond that, five teams per four CUs -- 4000 units 4.80 ms
+    // against 5.14 with two per CU, 8192: 9.41 / 10.1, 20 000: 22.8 / 24.3; profiles/r05_resweep.txt)
     if (r->n_units <= 6L * c->n_cu && pc.grid > c->n_cu) pc.grid = c->n_cu;
+    else if (pc.grid > c->n_cu + c->n_cu / 4) pc.grid = c->n_cu + c->n_cu / 4;
     // ... and the average-diameter launch, a fifth of the window search's work, gets by with one team
     // per two CUs whatever the batch (1000 units: 1.84 -> 1.79 ms, 500: 1.28 -> 1.20; 4000: 6.59 -> 6.53)
     const int pb_planned = pb.grid;
-    if (do_avg && pb.grid > (c->n_cu + 1) / 2) pb.grid = (c->n_cu + 1) / 2;
+    // (round 5: three teams per eight CUs -- 1000 units 1.25-1.27 ms against 1.29 with one per two CUs, 4000 the same)
+    if (do_avg && pb.grid > (3 * c->n_cu + 7) / 8) pb.grid = (3 * c->n_cu + 7) / 8;
     {
         // PW_C_TEAMS / PW_B_TEAMS: cap the persistent teams of the window / average launches (tuning)
         const char* ct = getenv("PW_C_TEAMS");
@@ -1355,7 +1364,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     const int ws_a = ns * c->max_c + b * c->max_a, ws_c = b * c->max_c;
     {
         const char* ps = getenv("PW_PROD_STREAMS");
-        c->prod = c->prods[((ps && ps[0] == '2') || c->tail_pct > 0) ? b : 0];
+        c->prod = c->prods[((ps && ps[0] == '2') || c->tail_pct != 0) ? b : 0];
     }
     r->cur = (r->cur + 1) % r->nbuf;
     r->d_out = r->d_outs[r->cur];
@@ -1403,8 +1412,9 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     // ordering against the previous launch.
     const bool same_batch = p >= 0 && c->last_res[p] == (const void*)r;
     const bool have_prev = p >= 0 && p != b && c->done_valid[p] && c->last_units[p] > 0 && same_batch;
-    if (c->tail_pct > 0 && have_prev) {
-        unsigned long long need = (unsigned long long)((c->last_units[p] * c->tail_pct) / 100);
+    const int tail_pct = gate_pct(c->tail_pct, r->n_units), head_pct = gate_pct(c->head_pct, r->n_units);
+    if (tail_pct > 0 && have_prev) {
+        unsigned long long need = (unsigned long long)((c->last_units[p] * tail_pct) / 100);
         hipLaunchKernelGGL(pw_tail_gate_kernel, dim3(1), dim3(64), 0, c->prod, c->queue + p, need, c->counter + 4 * PW_SETS + 2);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_tail[b], c->prod));
@@ -1426,9 +1436,9 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     HIP_TRY(hipEventRecord(c->ev_gate[b], cs));
     c->head_valid[b] = 0;
     if (have_prev) {
-        if (c->head_pct > 0) {
+        if (head_pct > 0) {
             // start beside the tail of the previous window launch, not behind it
-            unsigned long long need_h = (unsigned long long)((c->last_units[p] * c->head_pct) / 100);
+            unsigned long long need_h = (unsigned long long)((c->last_units[p] * head_pct) / 100);
             hipLaunchKernelGGL(pw_head_gate_kernel, dim3(1), dim3(64), 0, cs, c->queue + p, need_h, c->counter + 4 * PW_SETS + 2);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev_head[b], cs));
