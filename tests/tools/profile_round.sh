@@ -33,12 +33,20 @@ cp $(find $O/pw -name "*counter_collection.csv" | head -1) $O/pmc_write_size.csv
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU -d $O/pv -o pv --output-format csv -- python3 $T/run_stage.py 15 1000 4 > $O/pv.log 2>&1
 cp $(find $O/pv -name "*counter_collection.csv" | head -1) $O/pmc_instruction_counters.csv
 python3 $T/counter_summary.py $O/pmc_instruction_counters.csv 1000 $O/instruction_counters.json > /dev/null
+# 7. what the scratch frames cost: scratch / flat instruction counts and the cycles waves spend waiting, per launch
+#    (round-4 review item 4: "a counter experiment that prices it")
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_FLAT SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -d $O/ps -o ps --output-format csv -- python3 $T/run_stage.py 15 1000 4 > $O/ps.log 2>&1
+cp $(find $O/ps -name "*counter_collection.csv" | head -1) $O/pmc_scratch_counters.csv
+python3 $T/counter_summary.py $O/pmc_scratch_counters.csv 1000 $O/scratch_counters.json > /dev/null
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/pq -o pq --output-format csv -- python3 $T/run_stage.py 15 1000 4 > $O/pq.log 2>&1
+cp $(find $O/pq -name "*counter_collection.csv" | head -1) $O/pmc_wait_counters.csv
+python3 $T/counter_summary.py $O/pmc_wait_counters.csv 1000 $O/wait_counters.json > /dev/null
 # 8. a molecule beyond LDS (pw_analyse_big_kernel): the 2865-atom shell of the capacity fixtures
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/bg -o bg --output-format csv -- python3 $T/big_unit_probe.py > $O/bg.log 2>&1
 cp $(find $O/bg -name "*kernel_stats.csv" | head -1) $O/big_kernel_stats.csv
 # 9. HISTORY file -> records: streamed against one piece
 timeout 300 python3 $T/e2e_stream.py > $O/e2e_stream.txt 2>&1
-rm -rf $O/ov $O/se $O/tl $O/pf $O/pw $O/pv $O/bg
+rm -rf $O/ov $O/se $O/tl $O/pf $O/pw $O/pv $O/ps $O/pq $O/bg
 ls -la $O
 # 10. where these numbers come from: commit (.pw_head, written by `provenance.py stamp` before gpurun), date, hash of csrc/*
-python3 $T/provenance.py annotate $O/hbm_traffic.json $O/instruction_counters.json $O/serial_kernel_stats.csv $O/overlapped_kernel_stats.csv $O/big_kernel_stats.csv > $O/provenance.json
+python3 $T/provenance.py annotate $O/hbm_traffic.json $O/instruction_counters.json $O/scratch_counters.json $O/wait_counters.json $O/serial_kernel_stats.csv $O/overlapped_kernel_stats.csv $O/big_kernel_stats.csv > $O/provenance.json
