@@ -2499,6 +2499,136 @@ PW_NOINLINE __device__ inline bool wave_brute_bounded(Frame R, int n, PW_LDS dou
 }
 #endif
 
+// ---- the refined path scan of a window fit over the atoms around the path -------------------------------------
+// window_analysis walks the cluster's vector in steps of increment2 (0.1 A: ~116 points, utilities.py:1226) and needs
+// three things of the walk: that every point has a positive gap, the smallest gap m*, and the FIRST point that has it.
+// All three are decided by the atoms that can come within m* of some point of the path.  m* is at most the gap T0 at any
+// single point (four points of the outer half are evaluated over all atoms), and an atom's gap at a point of the
+// segment is at least its distance to the segment minus its radius: so the atoms with dist(a, segment) - r <= T0 (+ a
+// margin a million times the rounding error) contain every atom that attains m* anywhere -- the walk over those alone
+// has the same minimum at the same points (elsewhere its values are upper bounds, which is all a minimum needs).
+// For a cage that is the rim of one window and the wall around the path, a fifth of the atoms.  `scratch`: the
+// window's optimiser block, not yet in use.  Returns false (nothing done) when the radii are ungrouped, the list does
+// not fit or a value is not finite: the caller walks the path over all atoms.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T>
+PW_NOINLINE __device__ inline bool wave_path_tube(Frame F, int n, PW_LDS double* scratch, int cap, double cx, double cy,
+                                                  double cz, int chunks, double* pbest_out, int* ppos_out, bool* ok_out) {
+    const PW_LDS ClassInfo* C = F.cls;
+    const int kk = T::uniform_i(C->k);
+    cap = T::uniform_i(cap);
+    n = T::uniform_i(n);
+    chunks = T::uniform_i(chunks);
+    if (kk == 0 || cap < 16 || n > 256 || chunks < 16) return false;
+    PW_LDS double *sx = scratch, *sy = scratch + cap, *sz = scratch + 2 * cap, *sq = scratch + 3 * cap;
+    const int lane = T::lane();
+    // 1. an upper bound of the smallest gap: four points of the outer half, every atom
+    double T0;
+    {
+        double px[4], py[4], pz[4], gv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = (int)(((long)chunks * (4 + q)) / 8);
+            px[q] = cx * (double)k; py[q] = cy * (double)k; pz[q] = cz * (double)k;
+        }
+        wave_gap4<T>(F, n, px, py, pz, gv);
+        T0 = __builtin_fmin(__builtin_fmin(gv[0], gv[1]), __builtin_fmin(gv[2], gv[3]));
+    }
+    if (!(pw_abs(T0) < 1.0e6)) return false;
+    // 2. the atoms within T0 + radius of the segment from the origin to the last point, copied in stored order
+    const double ex = cx * (double)chunks, ey = cy * (double)chunks, ez = cz * (double)chunks;
+    const double len2 = sq3(ex, ey, ez);
+    if (!(len2 > 0.0) || !(len2 < 1.0e12)) return false;
+    int coff[PW_KCLS + 1];
+#pragma unroll
+    for (int g = 0; g <= PW_KCLS; ++g) coff[g] = 0;
+    int total = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (64 * t >= n) continue;
+        const int i = lane + 64 * t;
+        const int ic = i < n ? i : 0;
+        const double ax = F.x[ic], ay = F.y[ic], az = F.z[ic], aq = F.xx[ic];
+        double s = (ax * ex + ay * ey + az * ez) / len2;
+        s = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+        const double dx = ax - s * ex, dy = ay - s * ey, dz = az - s * ez;
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        const double lim = T0 + F.vdw[ic] + 1e-6;
+        const bool in = i < n && lim >= 0.0 && d2 <= lim * lim * (1.0 + 1e-9);
+        const unsigned long long mk = T::ballot(in);
+        const int at = total + (int)__builtin_popcountll(mk & ((1ull << lane) - 1ull));
+        if (in && at < cap) { sx[at] = ax; sy[at] = ay; sz[at] = az; sq[at] = aq; }
+#pragma unroll
+        for (int g = 0; g <= PW_KCLS; ++g) {
+            const int first = g < kk ? T::uniform_i(C->off[g]) : n;
+            const int below = first - 64 * t;
+            const unsigned long long lt = below >= 64 ? ~0ull : (below <= 0 ? 0ull : ((1ull << below) - 1ull));
+            coff[g] += (int)__builtin_popcountll(mk & lt);
+        }
+        total += (int)__builtin_popcountll(mk);
+    }
+    if (total > cap || total == 0) return false;
+    T::wave_sync();
+    // 3. the walk over the list: two points per lane and pass, point_gap_value's operations
+    double pbest = PW_INF;
+    int ppos = 0x7fffffff;
+    bool ok = true;
+    for (int k0 = lane; k0 <= chunks; k0 += 128) {
+        const int k1 = k0 + 64 <= chunks ? k0 + 64 : k0;
+        const double qx[2] = {cx * (double)k0, cx * (double)k1};
+        const double qy[2] = {cy * (double)k0, cy * (double)k1};
+        const double qz[2] = {cz * (double)k0, cz * (double)k1};
+        double best[2] = {PW_INF, PW_INF};
+        const double pp[2] = {sq3(qx[0], qy[0], qz[0]), sq3(qx[1], qy[1], qz[1])};
+#pragma unroll
+        for (int g = 0; g < PW_KCLS; ++g) {
+            if (g >= kk) continue;
+            double m2[2] = {PW_INF, PW_INF};
+            const int jlo = coff[g], jhi = coff[g + 1];
+            int j = jlo;
+            for (; j + 4 <= jhi; j += 4) {
+                double bx[4], by[4], bz[4], bq[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { bx[t] = sx[j + t]; by[t] = sy[j + t]; bz[t] = sz[j + t]; bq[t] = sq[j + t]; }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const double gg = pw_fma(bz[t], qz[p], pw_fma(bx[t], qx[p], by[t] * qy[p]));
+                        m2[p] = __builtin_fmin(m2[p], pw_m2add(gg, bq[t]));
+                    }
+            }
+            for (; j < jhi; ++j) {
+                const double bx = sx[j], by = sy[j], bz = sz[j], bq = sq[j];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const double gg = pw_fma(bz, qz[p], pw_fma(bx, qx[p], by * qy[p]));
+                    m2[p] = __builtin_fmin(m2[p], pw_m2add(gg, bq));
+                }
+            }
+            const double r = C->vdw[g];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const double m2p = m2[p] + pp[p];
+                const double d = pw_sqrt(m2p > 0.0 ? m2p : 0.0);
+                best[p] = __builtin_fmin(best[p], d - r);
+            }
+        }
+        if (!(best[0] > 0.0)) ok = false;
+        if (best[0] < pbest) { pbest = best[0]; ppos = k0; }
+        if (k1 != k0) {
+            if (!(best[1] > 0.0)) ok = false;
+            if (best[1] < pbest) { pbest = best[1]; ppos = k1; }
+        }
+    }
+    T::wave_sync();
+    *pbest_out = pbest;
+    *ppos_out = ppos;
+    *ok_out = ok;
+    return true;
+}
+#endif
+
 // ---- one window (utilities.py:1191-1361), executed by ONE wave -------------------------------
 // per-cluster arrays of the window fits: in the team's LDS (UnitVars) for up to PW_W_MAX clusters, in the
 // team's global slab beyond -- the number of clusters has no upper limit (utilities.py:1481-1536)
@@ -2527,7 +2657,14 @@ PW_NOINLINE PW_HD inline void wave_window(const Frame& FS, const Frame& R, PW_LD
     double pbest = PW_INF;
     int ppos = 0x7fffffff;
     bool ok = true;
-    if (T::WSIZE == 64) {
+    bool tubed = false;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_PATH_TUBE)
+    if (T::WSIZE == 64)
+        tubed = wave_path_tube<T>(FS, n, (PW_LDS double*)lbmem, (int)(sizeof(LbMem<1>) / 8 / 4), cx, cy, cz, chunks, &pbest, &ppos, &ok);
+#endif
+    if (tubed) {
+        // (done: the walk over the atoms around the path, wave_path_tube)
+    } else if (T::WSIZE == 64) {
         // two path points per lane and pass over the atoms
         for (int k0 = T::lane(); k0 <= chunks; k0 += 2 * T::WSIZE) {
             int k1 = k0 + T::WSIZE <= chunks ? k0 + T::WSIZE : k0;
