@@ -656,10 +656,9 @@ struct NearGap1 {
     double rx, ry, rz;
     int c;                  // this lane's candidate, -1: none
     int state;              // 0 no reference yet, 1 list in use, 2 too many candidates
-    bool one_row;           // the list fits the first sixteen lanes: the minimum is a row's, four DPP steps instead of six
     double ax, ay, az, aq, ar;      // ... and its coordinates, squared norm and radius: an evaluation reads no memory
 
-    __device__ void init() { rx = ry = rz = 0.0; c = -1; state = 0; one_row = false; ax = ay = az = aq = ar = 0.0; }
+    __device__ void init() { rx = ry = rz = 0.0; c = -1; state = 0; ax = ay = az = aq = ar = 0.0; }
 
     __device__ void rebuild(const Frame& F, int n, PW_LDS int* cand, double px, double py, double pz) {
         (void)cand;
@@ -667,7 +666,6 @@ struct NearGap1 {
         rx = px; ry = py; rz = pz;
         c = r.total <= 64 ? r.mine : -1;
         state = r.total <= 64 ? 1 : 2;
-        one_row = r.total <= 16;
         const int i = c < 0 ? 0 : c;
         ax = F.x[i]; ay = F.y[i]; az = F.z[i]; aq = F.xx[i]; ar = F.vdw[i];
     }
@@ -680,11 +678,6 @@ struct NearGap1 {
         const double g = pw_fma(az, pz, pw_fma(ax, px, ay * py));
         const double d2 = pw_m2add(g, aq) + sq3(px, py, pz);
         const double v = pw_sqrt(d2 > 0.0 ? d2 : 0.0) - ar;
-        if (one_row) {
-            double o[4];
-            T::row_min4(c < 0 ? PW_INF : v, o);
-            return o[0];
-        }
         return T::wave_min(c < 0 ? PW_INF : v);
     }
 };
