@@ -589,3 +589,33 @@ def test_max_dim_beyond_the_blas_threading_size_on_the_device(hip_ctx):
 
     tot, bad = max_dim_beyond_382(hip_ctx, seed=6)
     assert tot == 30 and bad == 0
+
+
+def test_device_equals_host_path_on_large_molecules():
+    """Molecules of 650 ... 1550 atoms: four wave teams whose window frames no longer fit LDS four at a time get fewer fit
+    SLOTS (2, then 1: the windows of a unit are fitted in rounds -- plan_launch, round 5; rounds 1-4 ran such molecules on
+    two- and one-wave teams).  Hollow shells with a few holes, so that windows exist; every field of every record
+    against the host path, one molecule per analysis and all of them in one batch."""
+    from pywindow_amd import _lib, engine
+
+    rng = np.random.default_rng(20261005)
+    pool = np.array(["C", "H", "N", "O"])
+    batch = []
+    for n in (650, 900, 1150, 1400, 1550):
+        p = rng.normal(size=(n, 3))
+        p = p / np.linalg.norm(p, axis=1)[:, None] * (5.0 + 0.004 * n)
+        holes = rng.normal(size=(3, 3))
+        holes /= np.linalg.norm(holes, axis=1)[:, None]
+        keep = np.all((p / np.linalg.norm(p, axis=1)[:, None]) @ holes.T < 0.93, axis=1)
+        p = p[keep] + rng.normal(scale=0.15, size=(int(keep.sum()), 3))
+        batch.append((pool[rng.integers(0, 4, size=len(p))], p))
+    host = engine.analyse(batch, stages=_lib.STAGE_ALL, device=-1)
+    dev = engine.analyse(batch, stages=_lib.STAGE_ALL, device=0)
+    assert (host["n_windows"] >= 1).sum() >= 3          # (the holes are found: the fit slots are exercised)
+    for k in host.dtype.names:
+        for u in range(len(batch)):
+            same = np.array_equal(host[k][u], dev[k][u], equal_nan=True) if host[k].dtype.kind == "f" else np.array_equal(host[k][u], dev[k][u])
+            assert same, (k, u, len(batch[u][0]))
+    for u, mol in enumerate(batch):
+        one = engine.analyse([mol], stages=_lib.STAGE_ALL, device=0)
+        assert one[0].tobytes() == dev[u].tobytes(), u
