@@ -421,16 +421,28 @@ def secondary_multi(ctx, vdw, mass, dist, rank, world, local_rank, backend, tdev
         hdir = os.path.join(base, "pw_bench_%d_%d" % (os.getuid(), frames))
         hpath = os.path.join(hdir, "HISTORY_periodic")
         t_w = 0.0
+        failed = 0.0
         if local_rank == 0 and not os.path.exists(hpath):
-            os.makedirs(hdir, exist_ok=True)
-            t_w = time.perf_counter()
-            distinct = [xyz + np.random.default_rng(4 + k).normal(0.0, 0.02, size=xyz.shape) for k in range(64)]
-            tmp = hpath + ".tmp%d" % os.getpid()
-            synth.write_history_cycled(tmp, el_, distinct, frames, cell=np.asarray(lat, float).T)
-            os.replace(tmp, hpath)
-            t_w = time.perf_counter() - t_w
+            try:
+                os.makedirs(hdir, exist_ok=True)
+                t_w = time.perf_counter()
+                distinct = [xyz + np.random.default_rng(4 + k).normal(0.0, 0.02, size=xyz.shape) for k in range(64)]
+                tmp = hpath + ".tmp%d" % os.getpid()
+                synth.write_history_cycled(tmp, el_, distinct, frames, cell=np.asarray(lat, float).T)
+                os.replace(tmp, hpath)
+                t_w = time.perf_counter() - t_w
+            except Exception:  # noqa: BLE001  (no room in /dev/shm, ...: every rank must learn of it, none may wait)
+                failed = 1.0
         dist.barrier()
-        traj = pw.DLPOLY(hpath)
+        traj = None
+        if not failed:
+            try:
+                traj = pw.DLPOLY(hpath)
+            except Exception:  # noqa: BLE001
+                failed = 1.0
+        if max_over_ranks(failed) > 0.0:           # (one collective: all ranks skip the block together)
+            out["config4_periodic"] = {"skipped": "the shared HISTORY file could not be written or opened on some rank", "path": hpath}
+            return out
         traj.analysis(frames=list(range(min(64 * world, frames))), modular=True, rebuild=True, lazy=True)     # warm-up
         traj.analysis_output = {}
         traj._stores = []
