@@ -470,6 +470,15 @@ def secondary_multi(ctx, vdw, mass, dist, rank, world, local_rank, backend, tdev
             "expected_gather_bytes_per_rank": 8 * (-(-frames // world)) * rec_bytes,
             "includes": "every rank: tokenising its frames of the shared file, H2D, periodic re-assembly, analysis of its cages, "
                         "D2H; then the ragged gather of records and (frame, molecule) tags to rank 0; max over ranks"}
+        # the file is a gigabyte of shared memory: it goes when every rank is done with it
+        del traj
+        dist.barrier()
+        if local_rank == 0:
+            try:
+                os.remove(hpath)
+                os.rmdir(hdir)
+            except OSError:
+                pass
     return out
 
 
