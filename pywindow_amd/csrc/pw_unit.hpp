@@ -202,6 +202,8 @@ struct UnitVars {
     // cross-wave reduction scratch
     double red_v[16];
     int red_i[16];
+    int md_list[64];   // team_max_dim_few: the atoms that can be an end of the maximum dimension (stored positions)
+    int md_count;
     // ---- window search only: everything from here on is NOT allocated for the optimiser-chain
     // launch (UnitShared::bytes with nframes == 1) ----
     int win_first;     // marks where the window-search variables start (offsetof)
@@ -1611,13 +1613,140 @@ PW_HD inline __attribute__((always_inline)) double pw_gram_nn(double xi, double 
     return pw_fma(zi, zj, pw_fma(yi, yj, xi * xj));
 }
 
+// ---- max_dim over the few atoms that can be an end of it ------------------------------------------------------
+// max_dim is the one N x N block of the path: the largest d_ij + (vdw_i + vdw_j) over all pairs.  Only atoms of the
+// outermost shell can be an end of it.  With s_i = |a_i - c| + vdw_i about any centre c, every entry is at most
+// s_i + s_j (triangle inequality), and the best partner of the atom with the largest s -- one row of the matrix, with
+// the reference's arithmetic -- is a lower bound L of the maximum: an atom with s_i + s_max < L cannot be in a maximal
+// pair.  For a cage that leaves a dozen atoms of 168, and the N x N block becomes a hundred pairs, each evaluated
+// with the arithmetic of the full block (Gram form, edge rule, row norm first) -- the same maximum, the same first
+// index.  The margin covers what the Gram form's computed distance can exceed the true one by (its cancellation
+// error grows with the square of the coordinates: 4e-15 * max |a|^2 / L) a million times over for a molecule near the
+// origin.  More than 64 atoms left (a hollow shell: every atom has an antipode) or a one-lane team: false, nothing
+// done -- the caller runs the full block.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T, bool VALUE_ONLY, bool EDGE>
+__device__ inline __attribute__((always_inline)) bool team_max_dim_few(UnitShared& sh, const Frame& F, int n,
+                                                                       const GramEdgeRule& er, const double* centre) {
+    auto& v = *sh.v;
+    const double cx = centre ? centre[0] : 0.0, cy = centre ? centre[1] : 0.0, cz = centre ? centre[2] : 0.0;
+    // 1. s_i, its maximum (any atom that has it), the largest squared norm
+    double smax = -PW_INF, nmax = 0.0;
+    int imax = 0x7fffffff;
+    for (int i = T::tid(); i < n; i += T::SIZE) {
+        const double dx = F.x[i] - cx, dy = F.y[i] - cy, dz = F.z[i] - cz;
+        const double si = pw_sqrt(dx * dx + dy * dy + dz * dz) + F.vdw[i];
+        if (si > smax) { smax = si; imax = i; }
+        nmax = pw_max(nmax, F.xx[i]);
+    }
+    T::wave_argmax(smax, imax);
+    nmax = -T::wave_min(-nmax);
+    if (T::lane() == 0) { v.red_v[T::wave()] = smax; v.red_i[T::wave()] = imax; v.red_v[8 + T::wave()] = nmax; }
+    T::sync();
+    {
+        double bb = v.red_v[0], nn = v.red_v[8];
+        int bi = v.red_i[0];
+        for (int w = 1; w < T::NWAVES; ++w) {
+            if (v.red_v[w] > bb || (v.red_v[w] == bb && v.red_i[w] < bi)) { bb = v.red_v[w]; bi = v.red_i[w]; }
+            nn = pw_max(nn, v.red_v[8 + w]);
+        }
+        smax = bb; imax = bi; nmax = nn;
+    }
+    T::sync();
+    if (!(smax < PW_INF) || imax >= n) return false;
+    // 2. L: the best partner of that atom, the reference's arithmetic (the diagonal entry included)
+    const double xi = F.x[imax], yi = F.y[imax], zi = F.z[imax], xxi = F.xx[imax], vi = F.vdw[imax];
+    const int oi = F.perm[imax];
+    double L = -PW_INF;
+    for (int j = T::tid(); j < n; j += T::SIZE) {
+        const int oj = F.perm[j];
+        double d = 0.0;
+        if (j != imax) {
+            const double gg = pw_gram_nn<EDGE>(xi, yi, zi, F.x[j], F.y[j], F.z[j], oi, oj, er);
+            const double d2 = (oi < oj) ? pw_m2add(gg, xxi) + F.xx[j] : pw_m2add(gg, F.xx[j]) + xxi;
+            d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
+        }
+        L = pw_max(L, d + (vi + F.vdw[j]));
+    }
+    L = -T::wave_min(-L);
+    if (T::lane() == 0) v.red_v[T::wave()] = L;
+    T::sync();
+    L = v.red_v[0];
+    for (int w = 1; w < T::NWAVES; ++w) L = pw_max(L, v.red_v[w]);
+    T::sync();
+    if (!(L < PW_INF)) return false;
+    // 3. the atoms that can reach it, listed (any order: the pairs below are compared by the caller's numbering)
+    const double margin = 1e-6 + 4e-15 * nmax / pw_max(L, 1e-3);
+    const double thr = (L - smax) - margin;
+    if (T::tid() == 0) v.md_count = 0;
+    T::sync();
+    for (int i0 = 0; i0 < n; i0 += T::SIZE) {
+        const int i = i0 + T::tid();
+        bool in = false;
+        if (i < n) {
+            const double dx = F.x[i] - cx, dy = F.y[i] - cy, dz = F.z[i] - cz;
+            in = pw_sqrt(dx * dx + dy * dy + dz * dz) + F.vdw[i] >= thr;
+        }
+        const unsigned long long mk = T::ballot(in);
+        int base = 0;
+        if (T::lane() == 0 && mk) base = atomicAdd((PW_LDS int*)&v.md_count, (int)__builtin_popcountll(mk));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int at = base + (int)__builtin_popcountll(mk & ((1ull << T::lane()) - 1ull));
+        if (in && at < 64) v.md_list[at] = i;
+    }
+    T::sync();
+    const int m = v.md_count;
+    if (m > 64) { T::sync(); return false; }
+    // 4. every pair of the list (row < column in the caller's numbering; the diagonal with it)
+    double bv = -PW_INF, bidx = PW_INF;
+    for (int p = T::tid(); p < m * m; p += T::SIZE) {
+        const int a = p / m, b = p - a * m;
+        const int ia = v.md_list[a], ib = v.md_list[b];
+        const int oa = F.perm[ia], ob = F.perm[ib];
+        if (oa > ob) continue;
+        double d = 0.0;
+        if (ia != ib) {
+            const double gg = pw_gram_nn<EDGE>(F.x[ia], F.y[ia], F.z[ia], F.x[ib], F.y[ib], F.z[ib], oa, ob, er);
+            const double d2 = pw_m2add(gg, F.xx[ia]) + F.xx[ib];              // (oa < ob: the row norm first)
+            d = pw_sqrt(d2 > 0.0 ? d2 : 0.0);
+        }
+        const double val = d + (F.vdw[ia] + F.vdw[ib]);
+        const double idx = (double)(oa * n + ob);
+        if (val > bv || (val == bv && idx < bidx)) { bv = val; bidx = idx; }
+    }
+    int ii = (int)(bidx < 2147483647.0 ? bidx : 2147483647.0);
+    T::wave_argmax(bv, ii);
+    if (T::lane() == 0) { v.red_v[T::wave()] = bv; v.red_i[T::wave()] = ii; }
+    T::sync();
+    if (T::tid() == 0) {
+        double bb = v.red_v[0];
+        int bi = v.red_i[0];
+        for (int w = 1; w < T::NWAVES; ++w) {
+            const double vv = v.red_v[w];
+            const int vi2 = v.red_i[w];
+            if (vv > bb || (vv == bb && vi2 < bi)) { bb = vv; bi = vi2; }
+        }
+        v.maxd = bb;
+        if (!VALUE_ONLY) { v.maxd_i = bi / n; v.maxd_j = bi % n; }
+    }
+    T::sync();
+    return true;
+}
+#endif
+
 // max_dim over frame F (utilities.py:355-372); result in sh.v->maxd*, all threads.  VALUE_ONLY: the
 // callers that only want the diameter of the shifted molecule (the radius of the sampling sphere)
 // skip the second pass; maxd_i / maxd_j are then not touched.
 template <class T, bool VALUE_ONLY = false, bool EDGE = false>
 PW_HD inline __attribute__((always_inline)) void team_max_dim_body(UnitShared& sh, const Frame& F, int n,
-                                                                   double* item_best = nullptr) {
+                                                                   double* item_best = nullptr, const double* centre = nullptr) {
     const GramEdgeRule er(n);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_MAXDIM_FEW)
+    // (the atoms of the outermost shell only, when they are few: team_max_dim_few)
+    if (T::WSIZE == 64 && team_max_dim_few<T, VALUE_ONLY, EDGE>(sh, F, n, er, centre)) return;
+#else
+    (void)centre;
+#endif
     // max over pairs (diagonal included) of d_ij + (vdw_i + vdw_j), first maximum in row-major
     // order of the caller's numbering (utilities.py:355-372).  Two passes over the upper triangle:
     //   1. value only -- inside one radius group of the column the maximum of the sum is at the
@@ -1815,15 +1944,18 @@ PW_HD inline __attribute__((always_inline)) void team_max_dim_body(UnitShared& s
 // loops as they were)
 template <class T, bool VALUE_ONLY = false>
 PW_HD inline __attribute__((always_inline)) void team_max_dim_impl(UnitShared& sh, const Frame& F, int n,
-                                                                   double* item_best = nullptr) {
-    if (GramEdgeRule::applies(n)) team_max_dim_body<T, VALUE_ONLY, true>(sh, F, n, item_best);
-    else team_max_dim_body<T, VALUE_ONLY, false>(sh, F, n, item_best);
+                                                                   double* item_best = nullptr, const double* centre = nullptr) {
+    if (GramEdgeRule::applies(n)) team_max_dim_body<T, VALUE_ONLY, true>(sh, F, n, item_best, centre);
+    else team_max_dim_body<T, VALUE_ONLY, false>(sh, F, n, item_best, centre);
 }
 
+// centre: a point near the middle of the molecule (the centre of mass of the input frame; null: the origin, where a
+// shifted frame has it) -- only the bounds of team_max_dim_few use it, never a result
 template <class T, bool VALUE_ONLY = false>
-PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n, double* item_best = nullptr) {
+PW_NOINLINE PW_HD inline void team_max_dim(UnitShared& sh, const Frame& F, int n, double* item_best = nullptr,
+                                           const double* centre = nullptr) {
     PW_ASSUME_TEAM_SH(sh);
-    team_max_dim_impl<T, VALUE_ONLY>(sh, F, n, item_best);
+    team_max_dim_impl<T, VALUE_ONLY>(sh, F, n, item_best, centre);
 }
 
 // ---- stage: basic -------------------------------------------------------------------------
@@ -1856,7 +1988,10 @@ PW_HD inline __attribute__((always_inline)) void stage_basic_impl(UnitShared& sh
     }
     T::sync();
     if (com_only) return;
-    team_max_dim<T>(sh, sh.A, n, 2 * n + 2 <= ws->p_cap ? ws->vals : nullptr);
+    {
+        const double com3[3] = {v.com[0], v.com[1], v.com[2]};
+        team_max_dim<T>(sh, sh.A, n, 2 * n + 2 <= ws->p_cap ? ws->vals : nullptr, com3);
+    }
     if (T::wave() == 0) {
         int arg;
         double g = wave_gap<T>(sh.A, n, v.com[0], v.com[1], v.com[2], &arg);
