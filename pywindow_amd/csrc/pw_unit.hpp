@@ -1419,8 +1419,11 @@ PW_HD inline double np_floordiv(double a, double b) {
 
 // vector_analysis (utilities.py:1100-1129) by ONE thread: walk 0 -> v.
 // returns false if some point is inside a vdW sphere.
+// m0: the gap at the origin.  Every path starts there (its first point is 0 * step), so the caller evaluates it once
+// for all of them and the walk begins at the second point; the points that are left go six to a pass over the atoms,
+// the last pass five when no more are left (eleven points -- the usual count -- are 6 + 5, not two passes of six).
 PW_NOINLINE PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx, double vy, double vz,
-                                   double inc, double* out_2gap, int* out_pos, double* out_chunk,
+                                   double inc, double m0, double* out_2gap, int* out_pos, double* out_chunk,
                                    int* n_eval) {
     double nrm = norm3(vx, vy, vz);
     int chunks = (int)np_floordiv(nrm, inc);
@@ -1428,10 +1431,17 @@ PW_NOINLINE PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx,
     double best = PW_INF;
     int pos = 0;
     bool ok = true;
-    // six path points per pass over the atoms (the reference stops at the first point inside a
+    int k0 = 0;
+    if (chunks >= 1) {
+        // (the steps are finite: point 0 is the origin exactly, whatever the signs of its zeros)
+        if (!(m0 > 0.0)) ok = false;
+        best = m0;
+        k0 = 1;
+    }
+    // NP path points per pass over the atoms (the reference stops at the first point inside a
     // sphere; evaluating the rest changes nothing: the vector is rejected either way)
-    constexpr int NP = PW_TILE_PATH;
-    for (int k0 = 0; k0 <= chunks && ok; k0 += NP) {
+    auto tile = [&](auto np_) __attribute__((always_inline)) {
+        constexpr int NP = decltype(np_)::value;
         double qx[NP], qy[NP], qz[NP], m[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -1446,6 +1456,11 @@ PW_NOINLINE PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx,
                 else if (m[p] < best) { best = m[p]; pos = k0 + p; }
             }
         }
+        k0 += NP;
+    };
+    while (k0 <= chunks && ok) {
+        if (PW_TILE_PATH > 5 && chunks - k0 + 1 <= 5) tile(std::integral_constant<int, 5>());
+        else tile(std::integral_constant<int, PW_TILE_PATH>());
     }
     if (n_eval) *n_eval += chunks + 1;
     if (!ok) return false;
@@ -3634,6 +3649,8 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
         // (path, point) per thread, then one thread per path folds its points.
         // (a last round that still fills a quarter of the team stays with one path per thread: a
         // thread's six points share every atom read, a (path, point) item reads all atoms for one)
+        // (the first point of every path: the origin)
+        const double m_origin = wave_gap_value<T>(sh.S, n, 0.0, 0.0, 0.0);
         int whole = T::SIZE > 1 ? (ncand / T::SIZE) * T::SIZE : ncand;
         if ((ncand - whole) * 4 >= T::SIZE) whole = ncand;
         for (int j = T::tid(); j < whole; j += T::SIZE) {
@@ -3641,7 +3658,7 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
             PW_DCHECK(k >= 0 && k < P, 105);
             double g2, chunk[3];
             int pos;
-            bool ok = path_scan_thread(sh.S, n, pts[PT(k, 0)], pts[PT(k, 1)], pts[PT(k, 2)], prm.increment,
+            bool ok = path_scan_thread(sh.S, n, pts[PT(k, 0)], pts[PT(k, 1)], pts[PT(k, 2)], prm.increment, m_origin,
                                        &g2, &pos, chunk, &evals);
             flag[j] = ok ? 1 : 0;
             tmpv[j] = g2;
@@ -3672,7 +3689,7 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
                 if (chunks + 1 > PCAP) {                   // very fine increments: the plain walk
                     double chunk[3];
                     int pos;
-                    ok = path_scan_thread(sh.S, n, vx, vy, vz, prm.increment, &g2, &pos, chunk, &evals);
+                    ok = path_scan_thread(sh.S, n, vx, vy, vz, prm.increment, m_origin, &g2, &pos, chunk, &evals);
                 } else {
                     double best = PW_INF;
                     for (int q = 0; q <= chunks; ++q) {
