@@ -183,7 +183,14 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
                     long long t0 = wall_clock64();
                     for (;;) {
                         int v = __hip_atomic_load(&slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (v >= 0) { u = v; break; }
+                        if (v >= 0) {
+                            u = v;
+#ifdef PW_PROFILE
+                            // (diagnostic builds: what a consumer team spends waiting for its next unit, slot 1)
+                            atomicAdd((unsigned long long*)&ws->prof[1], (unsigned long long)(wall_clock64() - t0));
+#endif
+                            break;
+                        }
                         __builtin_amdgcn_s_sleep(32);
                         // (the producer gave up -- its units never arrived: nothing more will be published)
 #ifndef PW_NO_CONSUMER_ERROR_CHECK
