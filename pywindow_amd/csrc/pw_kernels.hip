@@ -82,7 +82,7 @@ constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STA
 // Neighbour tables of the sampling sphere, one block per vector count P (pw_unit.hpp: nb_build_point): the
 // P unit vectors go to LDS, every thread tabulates the rows of its points.
 __global__ void __launch_bounds__(256) pw_nb_build_kernel(unsigned* __restrict__ off, unsigned short* __restrict__ idx,
-                                                          double* __restrict__ bound) {
+                                                          double* __restrict__ bound, double* __restrict__ unit) {
     __shared__ double ux[PW_NB_PMAX], uy[PW_NB_PMAX], uz[PW_NB_PMAX];
     // (large P first: their blocks run longest)
     const int P = PW_NB_PMAX - (int)blockIdx.x;
@@ -92,6 +92,12 @@ __global__ void __launch_bounds__(256) pw_nb_build_kernel(unsigned* __restrict__
     __syncthreads();
     const unsigned first = nb_dense_offset(P);
     if (threadIdx.x == 0) off[P] = first;
+    // (the unit vectors themselves: team_sphere_points scales them instead of computing sines and cosines per unit)
+    if (unit)
+        for (int k = threadIdx.x; k < P; k += blockDim.x) {
+            double* q = unit + 3 * ((size_t)first + k);
+            q[0] = ux[k]; q[1] = uy[k]; q[2] = uz[k];
+        }
     for (int k = threadIdx.x; k < P; k += blockDim.x)
         nb_build_point(P, k, ux, uy, uz, idx + (size_t)(first + k) * PW_NB_K, bound + first + k);
 }
@@ -492,6 +498,7 @@ struct pw_context {
     unsigned* nb_off;        // neighbour tables of the sampling sphere for P = PW_NB_PMIN .. PW_NB_PMAX (pw_unit.hpp)
     unsigned short* nb_idx;
     double* nb_bound;
+    double* nb_unit;         // the unit vectors of every tabulated P (50 MB)
     // team workspaces of the pipeline: C0 | A0 | B | A1 | C1, each region sized for the largest grid
     // any launch on this context has asked for so far.  The layout only changes when a maximum
     // grows, and growing synchronises the device first, so two launches in flight -- which may have
@@ -740,7 +747,7 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
     wsa.xwin_count = r->d_xw_count + r->cur;
     wsa.xwin_cap = r->xw_cap;
     wsa.p_cap = c->p_cap;
-    wsa.nb_off = c->nb_off; wsa.nb_idx = c->nb_idx; wsa.nb_bound = c->nb_bound;
+    wsa.nb_off = c->nb_off; wsa.nb_idx = c->nb_idx; wsa.nb_bound = c->nb_bound; wsa.nb_unit = c->nb_unit;
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
                        r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb, p.nframes, p.lean, wsa,
                        c->counter + counter_slot, r->d_out, role, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab,
@@ -994,8 +1001,10 @@ int pw_context_create(int device, pw_context** out) {
             CTX_TRY(hipMemset(c->nb_off, 0xff, (PW_NB_PMAX + 1) * sizeof(unsigned)));
             CTX_TRY(hipMalloc((void**)&c->nb_idx, rows * PW_NB_K * sizeof(unsigned short)));
             CTX_TRY(hipMalloc((void**)&c->nb_bound, rows * sizeof(double)));
+            const char* nu = getenv("PW_UNIT_TABLE");
+            if (!(nu && nu[0] == '0')) CTX_TRY(hipMalloc((void**)&c->nb_unit, rows * 3 * sizeof(double)));
             hipLaunchKernelGGL(pw_nb_build_kernel, dim3(PW_NB_PMAX - PW_NB_PMIN + 1), dim3(256), 0, c->stream, c->nb_off,
-                               c->nb_idx, c->nb_bound);
+                               c->nb_idx, c->nb_bound, c->nb_unit);
             CTX_TRY(hipGetLastError());
             CTX_TRY(hipStreamSynchronize(c->stream));
         }
@@ -1044,6 +1053,7 @@ void pw_context_destroy(pw_context* c) {
     if (c->nb_off) (void)hipFree(c->nb_off);
     if (c->nb_idx) (void)hipFree(c->nb_idx);
     if (c->nb_bound) (void)hipFree(c->nb_bound);
+    if (c->nb_unit) (void)hipFree(c->nb_unit);
     if (c->slots) (void)hipFree(c->slots);
     for (int b = 0; b < PW_SETS; ++b)
         if (c->prods[b]) (void)hipStreamDestroy(c->prods[b]);
@@ -1202,7 +1212,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
             wsa.ws = c->ws; wsa.slab = c->slab; wsa.adj = c->adj;
             wsa.xwin = r->d_xw[r->cur]; wsa.xwin_count = r->d_xw_count + r->cur; wsa.xwin_cap = r->xw_cap;
             wsa.p_cap = c->p_cap;
-            wsa.nb_off = c->nb_off; wsa.nb_idx = c->nb_idx; wsa.nb_bound = c->nb_bound;
+            wsa.nb_off = c->nb_off; wsa.nb_idx = c->nb_idx; wsa.nb_bound = c->nb_bound; wsa.nb_unit = c->nb_unit;
             return pw_internal_big_launch((void*)c->stream, (int)grid, r->n_units, r->d_offset, r->d_xyz, r->d_vdw, r->d_mass,
                                           stages, r->nmax, &wsa, c->bigmem, bb, c->counter + 4 * PW_SETS + 1, r->d_out, &c->prm,
                                           c->rsq_tab, r->vstride);

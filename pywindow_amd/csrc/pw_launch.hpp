@@ -17,6 +17,7 @@ struct PwWsArgs {
     const unsigned* nb_off;         // neighbour tables of the sampling sphere (pw_unit.hpp), null: none
     const unsigned short* nb_idx;
     const double* nb_bound;
+    const double* nb_unit;          // the unit vectors themselves, 3 per point (null: the teams compute them)
 };
 
 // Hand-off between the optimiser launch (producer, one wave per unit) and the window
@@ -41,7 +42,7 @@ __device__ inline void bind_workspace(WS* ws, const PwWsArgs& a, unsigned team, 
     bind_team_slab(ws, a.slab + (size_t)team * slab_bytes, a.p_cap);
     ws->adj = a.adj ? a.adj + (size_t)team * adj_words : nullptr;
     ws->xwin = a.xwin; ws->xwin_count = a.xwin_count; ws->xwin_cap = a.xwin_cap;
-    ws->nb_off = a.nb_off; ws->nb_idx = a.nb_idx; ws->nb_bound = a.nb_bound;
+    ws->nb_off = a.nb_off; ws->nb_idx = a.nb_idx; ws->nb_bound = a.nb_bound; ws->nb_unit = a.nb_unit;
     ws->rsq = rsq_tab;
 }
 #endif

@@ -133,6 +133,7 @@ struct TeamWorkspace {
     // neighbour tables of the sampling sphere (see NbTables below); null: none (the windowed search runs)
     const unsigned* nb_off;
     const unsigned short* nb_idx;
+    const double* nb_unit;    // the P unit vectors of every tabulated P, 3 doubles per point at 3 * (nb_off[P] + k); null: none
     const double* nb_bound;
     // launch-wide list of the windows beyond PW_W_MAX (appended with an atomic counter)
     pw_extra_window* xwin;
@@ -1054,6 +1055,24 @@ constexpr unsigned PW_NB_NONE = 0xffffffffu;
 // first point of the table of P when the tables of PW_NB_PMIN .. P - 1 precede it
 PW_HD inline unsigned nb_dense_offset(int P) {
     return (unsigned)(((long)(P - 1) * P - (long)(PW_NB_PMIN - 1) * PW_NB_PMIN) / 2);
+}
+// The sampling vectors of a sphere of radius R with P points, handed to store(k, x, y, z) by the team.  Sphere::point is
+// (ring * cos) * R, (ring * sin) * R, z * R: with the context's table of unit vectors (Sphere::point at R = 1, written
+// by the kernel that builds the neighbour tables) a vector is three loads and three products -- the same bits, since
+// x * 1.0 is x -- instead of a sine and a cosine of k golden angles in numpy's arithmetic (a third of the stage before
+// the rays, for every unit of every launch that samples a sphere).  No table (host path, PW_NB_TABLES=0): computed.
+template <class T, class ST>
+PW_HD inline __attribute__((always_inline)) void team_sphere_points(const TeamWorkspace* ws, const Sphere& sp, ST store) {
+    const int P = sp.P;
+    const double* u = nullptr;
+    if (ws->nb_unit && ws->nb_off && P >= PW_NB_PMIN && P <= PW_NB_PMAX && ws->nb_off[P] != PW_NB_NONE)
+        u = ws->nb_unit + 3 * (size_t)ws->nb_off[P];
+    for (int k = T::tid(); k < P; k += T::SIZE) {
+        double x, y, z;
+        if (u) { x = u[3 * k] * sp.R; y = u[3 * k + 1] * sp.R; z = u[3 * k + 2] * sp.R; }
+        else sp.point(k, &x, &y, &z);
+        store(k, x, y, z);
+    }
 }
 // one row of a table: the PW_NB_K nearest of point k among the P unit vectors u*, and the bound
 PW_HD inline void nb_build_point(int P, int k, const double* ux, const double* uy, const double* uz,
@@ -2277,11 +2296,11 @@ PW_HD inline __attribute__((always_inline)) void stage_average_impl(UnitShared& 
         ScratchArena a2 = arena;
         double* apts = (double*)a2.take((size_t)P * 24);
         if (apts) {
-            for (int k = T::tid(); k < P; k += T::SIZE) {
-                sp.point(k, &apts[k], &apts[P + k], &apts[2 * P + k]);
+            team_sphere_points<T>(ws, sp, [&](int k, double x, double y, double z) {
+                apts[k] = x; apts[P + k] = y; apts[2 * P + k] = z;
                 vals[k] = -1.0;
                 flag[k] = 0;
-            }
+            });
             ConeBand* bands = (ConeBand*)a2.take((size_t)n * sizeof(ConeBand));
             int cap = (int)(a2.left / 4);
             unsigned* pairs = (unsigned*)a2.take((size_t)cap * 4);
@@ -3345,8 +3364,7 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
     // (the per-vector arrays of the later stages are taken after the DBSCAN radius is known: until then
     // everything behind the sampling points belongs to the k-NN mean)
     ScratchArena arena_pts = arena;
-    for (int k = T::tid(); k < P; k += T::SIZE)
-        sp.point(k, &pts[PT(k, 0)], &pts[PT(k, 1)], &pts[PT(k, 2)]);
+    team_sphere_points<T>(ws, sp, [&](int k, double x, double y, double z) { pts[PT(k, 0)] = x; pts[PT(k, 1)] = y; pts[PT(k, 2)] = z; });
     T::sync();
     if (T::wave() == 0) PW_T1(ws, 26, t_pre);
     // ---- eps: mean of all 10-NN distances (self included), utilities.py:1427-1434 ----
