@@ -491,6 +491,30 @@ def test_every_launch_shape_gives_the_same_records(monkeypatch):
         assert got["one launch"].tobytes() == got["pipeline"].tobytes(), tag
 
 
+def test_sampling_vectors_from_the_table_are_the_computed_ones(monkeypatch):
+    """The context's table of unit vectors (three products a sampling vector) against the vectors computed per unit
+    (PW_UNIT_TABLE=0: a sine and a cosine each), and against no tables at all (PW_NB_TABLES=0: the windowed neighbour
+    search too): the same bytes, on the MD frames, the static molecules and the `adjust` fixtures' sphere sizes."""
+    from pywindow_amd import _lib
+
+    for tag in ("md20", "static"):
+        g = load_group(tag)
+        off, xyz, vdw, mass = group_batch(g)
+        batch = _lib.Batch(off, xyz, vdw, mass)
+        got = {}
+        for name, env in (("table", {}), ("computed", {"PW_UNIT_TABLE": "0"}), ("no tables", {"PW_NB_TABLES": "0"})):
+            monkeypatch.delenv("PW_UNIT_TABLE", raising=False)
+            monkeypatch.delenv("PW_NB_TABLES", raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ctx = _lib.Context(0)
+            got[name] = ctx.analyse(batch, 15)
+            ctx.close()
+        check_records(got["table"], g, where=f"{tag} unit table")
+        assert got["computed"].tobytes() == got["table"].tobytes(), tag
+        assert got["no tables"].tobytes() == got["table"].tobytes(), tag
+
+
 def test_device_equals_host_path_on_degenerate_molecules():
     """One, two, three (collinear), four atoms, duplicate atoms, a ring, a cube, a far-away molecule: whatever the host
     path (the same source for a one-lane team, pinned to the reference by the CPU suite) gives for them, the device gives
