@@ -35,7 +35,12 @@
 // constant clock accumulated per stage by lane 0 of each wave into TeamWorkspace::prof.
 #if defined(PW_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define PW_T0(var) long long var = wall_clock64()
+#if defined(PW_ZPROF) && defined(PW_LB_FINE)
+// (the optimiser's sub-phase timers of the neck search take the window stages' slots: those stay silent)
+#define PW_T1(ws, slot, var) do { (void)var; } while (0)
+#else
 #define PW_T1(ws, slot, var) do { if (T::lane() == 0) atomicAdd((unsigned long long*)&(ws)->prof[slot], (unsigned long long)(wall_clock64() - var)); } while (0)
+#endif
 #else
 #define PW_T0(var) do {} while (0)
 #define PW_T1(ws, slot, var) do {} while (0)
@@ -2192,14 +2197,14 @@ PW_HD inline __attribute__((always_inline)) void stage_opt_impl(UnitShared& sh, 
         int nit = 0, nfev = 0;
         if (!bad) {
             S->template setup<T>(Smem, x0, lo, up, nbd, 1e7, 1e-5, 20);
-#ifdef PW_PROFILE
+#if defined(PW_PROFILE) && !defined(PW_ZPROF)
             S->prof = ws->prof;
 #endif
-#if defined(PW_PROFILE) && defined(PW_LB_FINE)
+#if defined(PW_PROFILE) && defined(PW_LB_FINE) && !defined(PW_ZPROF)
             Smem->prof_fine = ws->prof;
 #endif
             PoreObjective<T> fg(A, n, lo, up, (PW_LDS int*)Smem->cand);
-#ifdef PW_PROFILE
+#if defined(PW_PROFILE) && !defined(PW_ZPROF)
             fg.prof = ws->prof;
 #endif
             // scipy's driver: maxiter = maxfun = 15000, both tested at a new iterate only
@@ -2943,6 +2948,12 @@ PW_NOINLINE PW_HD inline void wave_window(const Frame& FS, const Frame& R, PW_LD
             // np.clip(x0, lb, ub)
             x01[0] = x01[0] < lo1[0] ? lo1[0] : (x01[0] > up1[0] ? up1[0] : x01[0]);
             S->template setup<T>(Smem, x01, lo1, up1, nbd1, 1e7, 1e-5, 20);
+#if defined(PW_PROFILE) && defined(PW_ZPROF)
+            S->prof = ws->prof;       // (-DPW_ZPROF: the optimiser's timers are the neck search's, not the chains')
+#if defined(PW_LB_FINE)
+            Smem->prof_fine = ws->prof;
+#endif
+#endif
             int nit = 0;
             // (the candidate list of the objective lives in the optimiser block that setup() just cleared)
             NeckObjective<T> fg(R, n, xo, yo, lo1[0], up1[0], (PW_LDS int*)Smem->cand);
