@@ -1012,12 +1012,172 @@ struct Lbfgsb {
         }
     }
 
+    // ---- one or two correction pairs: the 2 col x 2 col systems of formk and subsm in scalars ---------------------
+    // The statements of the BLAS restatements (pw_blas.hpp: potf2 'U', trsv 'U' 'T' / 'N' with true divisions, trsm's
+    // reciprocal of the diagonal for several right-hand sides, ddot's FMA chain from +0.0) written out for n = 1, 2, 4
+    // on named scalars: every lane computes the same values, nothing goes through team memory between the first load
+    // and the last store, and nothing is indexed (a local array indexed in a loop lives in scratch memory on the GPU).
+    // potf2 'U' of [a b; . c]: returns 0, or the 1-based index of the first non-positive pivot (stored, as potf2 does)
+    PW_HD static int potf2_1(double& a) {
+        const double t = a - 0.0;
+        if (t <= 0.0) { a = t; return 1; }
+        a = pw_sqrt(t);
+        return 0;
+    }
+    PW_HD static int potf2_2(double& a, double& b, double& c) {
+        if (potf2_1(a) != 0) return 1;
+        b = b * (1.0 / a);
+        const double t = c - pw_fma(b, b, 0.0);
+        if (t <= 0.0) { c = t; return 2; }
+        c = pw_sqrt(t);
+        return 0;
+    }
+    // subsm's two solves (dtrtrs 'U','T' then 'U','N' on the factor of K, the first col entries negated in between)
+    template <class T>
+    PW_HD int subsm_solves_small(double* wv) {
+        if (col == 1) {
+            const double a00 = WN(0, 0), a01 = WN(0, 1), a11 = WN(1, 1);
+            if (a00 == 0.0) return 1;
+            if (a11 == 0.0) return 2;
+            double x0 = wv[0], x1 = wv[1];
+            x0 = x0 / a00;
+            x1 = (x1 - pw_fma(x0, a01, 0.0)) / a11;
+            x0 = -x0;
+            x1 = x1 / a11;
+            x0 = pw_fma(-x1, a01, x0);
+            x0 = x0 / a00;
+            T::wave_sync();
+            wv[0] = x0; wv[1] = x1;
+            T::wave_sync();
+            return 0;
+        }
+        const double a00 = WN(0, 0), a01 = WN(0, 1), a02 = WN(0, 2), a03 = WN(0, 3);
+        const double a11 = WN(1, 1), a12 = WN(1, 2), a13 = WN(1, 3);
+        const double a22 = WN(2, 2), a23 = WN(2, 3), a33 = WN(3, 3);
+        if (a00 == 0.0) return 1;
+        if (a11 == 0.0) return 2;
+        if (a22 == 0.0) return 3;
+        if (a33 == 0.0) return 4;
+        double x0 = wv[0], x1 = wv[1], x2 = wv[2], x3 = wv[3];
+        x0 = x0 / a00;
+        x1 = (x1 - pw_fma(x0, a01, 0.0)) / a11;
+        x2 = (x2 - pw_fma(x1, a12, pw_fma(x0, a02, 0.0))) / a22;
+        x3 = (x3 - pw_fma(x2, a23, pw_fma(x1, a13, pw_fma(x0, a03, 0.0)))) / a33;
+        x0 = -x0; x1 = -x1;
+        x3 = x3 / a33;
+        { const double nx = -x3; x0 = pw_fma(nx, a03, x0); x1 = pw_fma(nx, a13, x1); x2 = pw_fma(nx, a23, x2); }
+        x2 = x2 / a22;
+        { const double nx = -x2; x0 = pw_fma(nx, a02, x0); x1 = pw_fma(nx, a12, x1); }
+        x1 = x1 / a11;
+        x0 = pw_fma(-x1, a01, x0);
+        x0 = x0 / a00;
+        T::wave_sync();
+        wv[0] = x0; wv[1] = x1; wv[2] = x2; wv[3] = x3;
+        T::wave_sync();
+        return 0;
+    }
+    // formk from the first factorisation on: potrf of the leading block, the solve of the off-diagonal block (one
+    // right-hand side: TRSV's division; two: TRSM's reciprocals), the rank update of the trailing block and its potrf.
+    // Returns formk's own codes (0, -1, -2).
+    template <class T>
+    PW_HD int formk_tail_small() {
+        int ret = 0;
+        if (col == 1) {
+            double a00 = WN(0, 0), a01 = WN(0, 1), a11 = WN(1, 1);
+            if (potf2_1(a00) != 0) {
+                ret = -1;
+            } else {
+                if (a00 != 0.0) a01 = a01 / a00;
+                a11 = a11 + pw_fma(a01, a01, 0.0);
+                if (potf2_1(a11) != 0) ret = -2;
+            }
+            T::wave_sync();
+            WN(0, 0) = a00; WN(0, 1) = a01; WN(1, 1) = a11;
+            T::wave_sync();
+            return ret;
+        }
+        double a00 = WN(0, 0), a01 = WN(0, 1), a02 = WN(0, 2), a03 = WN(0, 3);
+        double a11 = WN(1, 1), a12 = WN(1, 2), a13 = WN(1, 3);
+        double a22 = WN(2, 2), a23 = WN(2, 3), a33 = WN(3, 3);
+        if (potf2_2(a00, a01, a11) != 0) {
+            ret = -1;
+        } else {
+            if (a00 != 0.0 && a11 != 0.0) {
+                const double i0 = 1.0 / a00, i1 = 1.0 / a11;
+                a02 = a02 * i0; a12 = pw_fma(-a02, a01, a12); a12 = a12 * i1;
+                a03 = a03 * i0; a13 = pw_fma(-a03, a01, a13); a13 = a13 * i1;
+            }
+            a22 = a22 + pw_fma(a12, a12, pw_fma(a02, a02, 0.0));
+            a23 = a23 + pw_fma(a13, a12, pw_fma(a03, a02, 0.0));
+            a33 = a33 + pw_fma(a13, a13, pw_fma(a03, a03, 0.0));
+            if (potf2_2(a22, a23, a33) != 0) ret = -2;
+        }
+        T::wave_sync();
+        WN(0, 0) = a00; WN(0, 1) = a01; WN(0, 2) = a02; WN(0, 3) = a03;
+        WN(1, 1) = a11; WN(1, 2) = a12; WN(1, 3) = a13;
+        WN(2, 2) = a22; WN(2, 3) = a23; WN(3, 3) = a33;
+        T::wave_sync();
+        return ret;
+    }
+
     // ---- bmv: product of the 2m x 2m middle matrix with a vector ----------
+    // One or two correction pairs -- every call of the one-dimensional neck search of a window fit, the first
+    // iterations of every chain: the product written out.  The statements of the general form below for col = 1, 2
+    // (sums from +0.0 in their order, dtrsv's divisions, the same singularity test), every lane the same scalars:
+    // a dozen flops, where the lane-parallel routine -- built for twenty rows -- spends 2.6 k cycles on its out-of-line
+    // call, its tables and its lane exchanges (tests/tools/profile_zsearch.py).
+    template <class T>
+    PW_HD int bmv_small(const double* v, double* p) {
+        const double w00 = WT(0, 0);
+        if (w00 == 0.0) return 1;
+        const double sy00 = SY(0, 0);
+        const double q0 = pw_sqrt(sy00);
+        if (col == 1) {
+            const double v0 = v[0], v1 = v[1];
+            double p1 = v1 / w00;                   // U^T x = b
+            const double p0 = v0 / q0;
+            p1 = p1 / w00;                          // U x = b
+            const double pi0 = -p0 / q0;
+            p[0] = pi0 + 0.0;
+            p[1] = p1;
+            T::wave_sync();
+            return 0;
+        }
+        const double w11 = WT(1, 1), w01 = WT(0, 1);
+        if (w11 == 0.0) return 2;
+        const double v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+        const double sy10 = SY(1, 0), sy11 = SY(1, 1);
+        const double q1 = pw_sqrt(sy11);
+        double p2 = v2;
+        double p3 = v3 + (0.0 + sy10 * v0 / sy00);
+        // U^T x = b (dtrsv 'U', 'T': x[0] / u00, then the DOT accumulator from +0.0)
+        p2 = p2 / w00;
+        p3 = (p3 - pw_fma(p2, w01, 0.0)) / w11;
+        const double p0 = v0 / q0, p1 = v1 / q1;
+        // U x = b (dtrsv 'U', 'N': back substitution, AXPY order)
+        p3 = p3 / w11;
+        p2 = pw_fma(-p3, w01, p2);
+        p2 = p2 / w00;
+        const double pi0 = -p0 / q0, pi1 = -p1 / q1;
+        p[0] = pi0 + (0.0 + sy10 * p3 / sy00);
+        p[1] = pi1 + 0.0;
+        p[2] = p2;
+        p[3] = p3;
+        T::wave_sync();
+        return 0;
+    }
     template <class T>
     PW_HD int bmv(const double* v, double* p) {
         PW_ASSUME_LDS(mem);
         if (col == 0) return 0;
         LB_F0(fb);
+#ifndef PW_LB_NO_SMALL
+        if (col <= 2) {
+            const int inf_s = bmv_small<T>(v, p);
+            LB_F1(2, fb);
+            return inf_s;
+        }
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_LB_OLD_SOLVES)
         if (T::WSIZE == 64) {
             const int inf_w = lb_bmv_wave<LbWave, N>(mem, col, v, p);
@@ -1519,6 +1679,14 @@ struct Lbfgsb {
         }
         T::wave_sync();
         LB_F1(8, fk1);
+#ifndef PW_LB_NO_SMALL
+        if (col <= 2) {
+            LB_F0(fks);
+            const int rs = formk_tail_small<T>();
+            LB_F1(9, fks);
+            return rs;
+        }
+#endif
         LB_F0(fk2);
         int inf = factor<T>(2);
         LB_F1(9, fk2);
@@ -1632,6 +1800,11 @@ struct Lbfgsb {
         int col2 = 2 * col;
         LB_F0(fs1);
         int inf;
+#ifndef PW_LB_NO_SMALL
+        if (col <= 2) {
+            inf = subsm_solves_small<T>(wv);
+        } else
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_LB_OLD_SOLVES)
         if (T::WSIZE == 64) {
             inf = lb_subsm_solves_wave<LbWave, N>(mem, col, wv);
