@@ -2107,6 +2107,27 @@ struct Lbfgsb {
     template <class T>
     PW_HD int formt() {
         PW_ASSUME_LDS(mem);
+#ifndef PW_LB_NO_SMALL
+        if (col <= 2) {
+            // (one or two correction pairs: the statements below and potf2 in scalars, see bmv_small; the reciprocal
+            // table of WT's diagonal is the lane-parallel product's, which does not run at this size)
+            double w00 = theta * SS(0, 0), w01 = 0.0, w11 = 0.0;
+            int inf;
+            if (col == 1) {
+                inf = potf2_1(w00);
+            } else {
+                w01 = theta * SS(0, 1);
+                const double ddum = 0.0 + SY(1, 0) * SY(1, 0) / SY(0, 0);
+                w11 = ddum + theta * SS(1, 1);
+                inf = potf2_2(w00, w01, w11);
+            }
+            T::wave_sync();
+            WT(0, 0) = w00;
+            if (col == 2) { WT(0, 1) = w01; WT(1, 1) = w11; }
+            T::wave_sync();
+            return inf != 0 ? -3 : 0;
+        }
+#endif
         for (int e = T::lane(); e < col * col; e += T::WSIZE) {
             int i = e / col, j = e % col;
             if (j < i) continue;
