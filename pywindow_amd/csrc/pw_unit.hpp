@@ -1314,6 +1314,28 @@ PW_HD inline void team_store_max_pos(double* p, double v) {     // *p = max(*p, 
     if (v > *p) *p = v;
 #endif
 }
+// How team_ray_tests reads ray vector k: `first(k)` is where its x component sits, `at(off, ...)` reads the three
+// components from there, and STEP64 is what 64 rays further on adds to `off` -- the band walk computes the offset of a
+// lane's first ray once per atom instead of the layout's index arithmetic once per ray.  P: the pointer type (a
+// team-memory pointer where the vectors are known to be there: ds_read instead of flat_load).
+template <class P>
+struct SpiralRays {             // the window search's layout: component c of ray k at [(c * 4 + (k & 3)) * Q4 + (k >> 2)]
+    P pts;
+    int Q4;
+    static constexpr int STEP64 = 16;
+    PW_HD int first(int k) const { return (k & 3) * Q4 + (k >> 2); }
+    PW_HD void at(int off, double* x, double* y, double* z) const { *x = pts[off]; *y = pts[off + 4 * Q4]; *z = pts[off + 8 * Q4]; }
+    PW_HD void operator()(int k, double* x, double* y, double* z) const { at(first(k), x, y, z); }
+};
+template <class P>
+struct PlanarRays {             // the average diameter's layout: x | y | z, P each
+    P a;
+    int n;
+    static constexpr int STEP64 = 64;
+    PW_HD int first(int k) const { return k; }
+    PW_HD void at(int off, double* x, double* y, double* z) const { *x = a[off]; *y = a[n + off]; *z = a[2 * n + off]; }
+    PW_HD void operator()(int k, double* x, double* y, double* z) const { at(k, x, y, z); }
+};
 // per-atom cone data computed by one lane each (band of ray indices, threshold on dot(ray vector, rel))
 struct ConeBand { double thr; int klo, khi; };     // khi < 0: two-sided test (|dot|), khi = -khi - 1
 template <class T, bool FAR, class GETP>
@@ -1367,12 +1389,14 @@ PW_HD inline __attribute__((always_inline)) bool team_ray_tests(const Frame& F, 
         PW_DCHECK(P >= 10 && P <= 4096, 102);
         PW_DCHECK(b.klo >= 0 && khi < P, 103);
         const double rx = F.x[i] - c0, ry = F.y[i] - c1, rz = F.z[i] - c2;
-        for (int kb = b.klo; kb <= khi; kb += T::WSIZE) {
+        int off = getp.first(b.klo + T::lane());
+        for (int kb = b.klo; kb <= khi; kb += T::WSIZE, off += GETP::STEP64) {
             const int k = kb + T::lane();
             bool f = false;
             if (k <= khi) {
                 double px, py, pz;
-                getp(k, &px, &py, &pz);
+                if (T::WSIZE == 64) getp.at(off, &px, &py, &pz);      // (the offsets step by 64 rays)
+                else getp(k, &px, &py, &pz);
                 const double dot = pw_fma(pz, rz, pw_fma(px, rx, py * ry));
                 f = two_sided ? pw_abs(dot) >= b.thr : dot >= b.thr;
             }
@@ -2311,7 +2335,8 @@ PW_HD inline __attribute__((always_inline)) void stage_average_impl(UnitShared& 
             unsigned* pairs = (unsigned*)a2.take((size_t)cap * 4);
             if (cap < 4 * P) { pairs = (unsigned*)ws->knn; cap = 16 * ws->p_cap; }
             if (!bands && (size_t)n * sizeof(ConeBand) <= (size_t)ws->p_cap * 16) bands = (ConeBand*)(ws->knn + 8 * (size_t)ws->p_cap);
-            auto getp = [&](int k, double* x, double* y, double* z) { *x = apts[k]; *y = apts[P + k]; *z = apts[2 * P + k]; };
+            // (apts comes from the arena: team memory)
+            PlanarRays<decltype(PW_AS_LDS(apts))> getp{PW_AS_LDS(apts), P};
             if (bands)
                 done = team_ray_tests<T, true>(sh.S, n, cen, sp, getp, bands, pairs, cap, (PW_LDS int*)&v.red_i[0], flag, 1, vals);
         }
@@ -3625,9 +3650,11 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
             unsigned* pairs = (unsigned*)a2.take((size_t)cap * 4);
             if (cap < 4 * P) { pairs = (unsigned*)ws->knn; cap = 16 * ws->p_cap; }
             if (!bands && (size_t)n * sizeof(ConeBand) <= (size_t)ws->p_cap * 16) bands = (ConeBand*)(ws->knn + 8 * (size_t)ws->p_cap);
-            auto getp = [&](int k, double* x, double* y, double* z) { *x = pts[PT(k, 0)]; *y = pts[PT(k, 1)]; *z = pts[PT(k, 2)]; };
-            if (bands)
-                done = team_ray_tests<T, false>(sh.S, n, cen, sp, getp, bands, pairs, cap, (PW_LDS int*)&v.red_i[0], flag, 0, nullptr);
+            auto run = [&](auto pts_) __attribute__((always_inline)) {
+                SpiralRays<decltype(pts_)> getp{pts_, Q4};
+                return team_ray_tests<T, false>(sh.S, n, cen, sp, getp, bands, pairs, cap, (PW_LDS int*)&v.red_i[0], flag, 0, nullptr);
+            };
+            if (bands) done = PW_IS_LDS(pts) ? run(PW_AS_LDS(pts)) : run(pts);
         }
         if (done) {
         } else if (T::SIZE > 1) {
