@@ -3123,37 +3123,49 @@ PW_HD inline __attribute__((always_inline)) int team_dbscan(PW_LDS unsigned long
     }
     const bool have_cp = cp != nullptr;
     auto cluster = [&](auto cp_, auto adj_, auto labels_) __attribute__((always_inline)) {
-        PW_ROW_ITEMS_BEGIN
-            double px, py, pz;
-            if (have_cp) { px = cp_[3 * i]; py = cp_[3 * i + 1]; pz = cp_[3 * i + 2]; }
-            else { const int pik = surv_k[i]; px = pts[PT(pik, 0)]; py = pts[PT(pik, 1)]; pz = pts[PT(pik, 2)]; }
-            unsigned long long bits = 0;
-            const int jend = (wd * 64 + 64 < ns) ? wd * 64 + 64 : ns;
-            int j = wd * 64;
-            if (have_cp) {
-                for (; j + 8 <= jend; j += 8) {
-                    double qx[8], qy[8], qz[8];
+        // (the rows are computed HALF a word -- 32 candidate points -- to a work item: 540 whole-word items on 256 threads are
+        // three rounds for one wave and two for the others, 1080 halves are five against four: 2.5 words, not 3)
+        {
+            using A32 = std::conditional_t<std::is_same<decltype(adj_), unsigned long long*>::value, unsigned*, PW_LDS unsigned*>;
+            A32 adj32 = (A32)adj_;
+            const int nh = 2 * words;
+            int i = T::tid(), h = 0;
+            while (i >= ns && h < nh) { i -= ns; ++h; }
+            while (h < nh) {
+                double px, py, pz;
+                if (have_cp) { px = cp_[3 * i]; py = cp_[3 * i + 1]; pz = cp_[3 * i + 2]; }
+                else { const int pik = surv_k[i]; px = pts[PT(pik, 0)]; py = pts[PT(pik, 1)]; pz = pts[PT(pik, 2)]; }
+                unsigned bits = 0;
+                const int j0 = h * 32;
+                const int jend = j0 + 32 < ns ? j0 + 32 : ns;
+                int j = j0;
+                if (have_cp) {
+                    for (; j + 8 <= jend; j += 8) {
+                        double qx[8], qy[8], qz[8];
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) { qx[t] = cp_[3 * (j + t)]; qy[t] = cp_[3 * (j + t) + 1]; qz[t] = cp_[3 * (j + t) + 2]; }
+                        for (int t = 0; t < 8; ++t) { qx[t] = cp_[3 * (j + t)]; qy[t] = cp_[3 * (j + t) + 1]; qz[t] = cp_[3 * (j + t) + 2]; }
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        double ax = px - qx[t], ay = py - qy[t], az = pz - qz[t];
-                        double d = ax * ax;      // (0.0 + ax * ax is ax * ax exactly)
-                        d = d + ay * ay; d = d + az * az;
-                        if (d <= e2) bits |= 1ull << (j + t - wd * 64);
+                        for (int t = 0; t < 8; ++t) {
+                            double ax = px - qx[t], ay = py - qy[t], az = pz - qz[t];
+                            double d = ax * ax;      // (0.0 + ax * ax is ax * ax exactly)
+                            d = d + ay * ay; d = d + az * az;
+                            if (d <= e2) bits |= 1u << (j + t - j0);
+                        }
                     }
                 }
+                for (; j < jend; ++j) {
+                    const int pjk = surv_k[j];
+                    double ax = px - pts[PT(pjk, 0)], ay = py - pts[PT(pjk, 1)], az = pz - pts[PT(pjk, 2)];
+                    double d = ax * ax;
+                    d = d + ay * ay; d = d + az * az;
+                    if (d <= e2) bits |= 1u << (j - j0);
+                }
+                adj32[((size_t)i * stride + (h >> 1)) * 2 + (h & 1)] = bits;
+                if (bits) team_atomic_add(&labels_[i], __builtin_popcount(bits));
+                i += T::SIZE;
+                while (i >= ns && h < nh) { i -= ns; ++h; }
             }
-            for (; j < jend; ++j) {
-                const int pjk = surv_k[j];
-                double ax = px - pts[PT(pjk, 0)], ay = py - pts[PT(pjk, 1)], az = pz - pts[PT(pjk, 2)];
-                double d = ax * ax;
-                d = d + ay * ay; d = d + az * az;
-                if (d <= e2) bits |= 1ull << (j - wd * 64);
-            }
-            adj_[(size_t)i * stride + wd] = bits;
-            if (bits) team_atomic_add(&labels_[i], __builtin_popcountll(bits));
-        PW_ROW_ITEMS_END
+        }
         T::sync();
         // core points (at least min_samples = 5 neighbours, itself included) start as their own
         // component; the others carry "none"
