@@ -968,25 +968,38 @@ PW_HD inline void np_leaf_phase(const double* src, int len, int e_lo, int e_hi, 
 // right part is the larger one, and it is a leaf (<= 128 elements) at depth 7 at the latest for a
 // chunk of 8192.  The result is valid on thread 0.  acc8: at least 128 doubles; leafbuf: 256 doubles
 // (leaf sums by 64-element slot in the first 128).
-template <class T, class DP>
-PW_HD inline __attribute__((always_inline)) double np_walk_phase_t(int len, DP acc8, DP leafbuf) {
+template <class T, class DP, class IP>
+PW_HD inline __attribute__((always_inline)) double np_walk_phase_t(int len, IP tab, DP acc8, DP leafbuf) {
     int depth = 0;
     for (int l = len; l > 128; ++depth) { int n2 = l / 2; n2 -= n2 % 8; l -= n2; }
     // (one wave: its lanes see each other's LDS writes without a team barrier)
     if (T::wave() == 0) {
+        // the tree first, top down, one halving per node: node t of depth d is entry (1 << d) + t of `tab` (free once the
+        // leaf sums are in: offset | length << 16, length 0: no such node).  Naming a node by the turns from the root and
+        // re-deriving its extent at every level was seven halvings per node and level -- most of this phase.
+        if (T::lane() == 0) tab[1] = len << 16;
+        T::wave_sync();
+        for (int d = 1; d <= depth; ++d) {
+            for (int t = T::lane(); t < (1 << d); t += T::WSIZE) {
+                const int par = tab[((1 << d) + t) >> 1];
+                const int po = par & 0xffff, pl = par >> 16;
+                int e = 0;
+                if (pl > 128) {
+                    int n2 = pl / 2;
+                    n2 -= n2 % 8;
+                    e = (t & 1) ? ((po + n2) | ((pl - n2) << 16)) : (po | (n2 << 16));
+                }
+                tab[(1 << d) + t] = e;
+            }
+            T::wave_sync();
+        }
         for (int d = depth; d >= 0; --d) {
             DP mine = (d & 1) ? leafbuf + 128 : acc8;
             DP below = (d & 1) ? acc8 : leafbuf + 128;
             for (int t = T::lane(); t < (1 << d); t += T::WSIZE) {
-                int off = 0, l = len;
-                bool exists = true;
-                for (int k = d - 1; k >= 0; --k) {
-                    if (l <= 128) { exists = false; break; }
-                    int n2 = l / 2;
-                    n2 -= n2 % 8;
-                    if ((t >> k) & 1) { off += n2; l -= n2; } else { l = n2; }
-                }
-                if (exists) mine[t] = l <= 128 ? leafbuf[off >> 6] : below[2 * t] + below[2 * t + 1];
+                const int e = tab[(1 << d) + t];
+                const int off = e & 0xffff, l = e >> 16;
+                if (l > 0) mine[t] = l <= 128 ? leafbuf[off >> 6] : below[2 * t] + below[2 * t + 1];
             }
             T::wave_sync();
         }
@@ -996,9 +1009,8 @@ PW_HD inline __attribute__((always_inline)) double np_walk_phase_t(int len, DP a
 }
 template <class T>
 PW_HD inline double np_walk_phase(int len, int* tab, double* acc8, double* leafbuf) {
-    (void)tab;
-    if (PW_IS_LDS(acc8) && PW_IS_LDS(leafbuf)) return np_walk_phase_t<T>(len, PW_AS_LDS(acc8), PW_AS_LDS(leafbuf));
-    return np_walk_phase_t<T>(len, acc8, leafbuf);
+    if (PW_IS_LDS(acc8) && PW_IS_LDS(leafbuf) && PW_IS_LDS(tab)) return np_walk_phase_t<T>(len, PW_AS_LDS(tab), PW_AS_LDS(acc8), PW_AS_LDS(leafbuf));
+    return np_walk_phase_t<T>(len, tab, acc8, leafbuf);
 }
 template <class T>
 PW_HD inline double np_sum_team(const double* a, int n, int* tab, double* acc8, double* leafbuf,
