@@ -19,8 +19,19 @@ for key, vals in sorted(acc.items()):
     name = ("A optimiser chains (1 wave/unit)" if key[1] == 64 else
             "C window search" if key[2] == 120 else "B average diameter" if key[2] == 98 else f"<{key[1] // 64}, {key[2]}>")
     row = {"grid": key[0], "workgroup": key[1]}
+    # A counter pass serialises the kernels of the process: a consumer launch dispatched ahead of its producer then finds
+    # no units, waits out its time limit and retires a few thousand instructions (seen once in round 4, once in round 5:
+    # DESIGN.md section 7).  Such a dispatch -- under a tenth of the median of its kind in SQ_INSTS_VALU -- says nothing
+    # about the kernel and is left out, and reported.
+    keep = list(range(len(next(iter(vals.values())))))
+    if "SQ_INSTS_VALU" in vals and len(vals["SQ_INSTS_VALU"]) > 1:
+        ref = sorted(vals["SQ_INSTS_VALU"])[len(vals["SQ_INSTS_VALU"]) // 2]
+        keep = [i for i, x in enumerate(vals["SQ_INSTS_VALU"]) if x >= 0.1 * ref]
+        if len(keep) < len(vals["SQ_INSTS_VALU"]):
+            row["dispatches_left_out"] = len(vals["SQ_INSTS_VALU"]) - len(keep)
     for c, v in vals.items():
-        row[c] = sum(v) / len(v)
+        vv = [v[i] for i in keep if i < len(v)] or v
+        row[c] = sum(vv) / len(vv)
         if c != "SQ_WAVES":
             total[c] += row[c]
     kernels[name] = row
