@@ -168,6 +168,9 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
         if (threadIdx.x == 0) atomicAdd(&queue->started, 1);
     }
     TeamWorkspace* ws = (TeamWorkspace*)wsa.ws + blockIdx.x;
+#ifdef PW_PROFILE
+    if (threadIdx.x < 32) pw_prof_lds[threadIdx.x] = 0;     // (the team's timers: summed here, flushed when it leaves)
+#endif
     if (threadIdx.x == 0) {
         s_sh.carve(lds, nmax, nrot, nlb, nframes, lean, wsa.p_cap);     // as planned by the host (plan_launch)
         s_prm = prm_in;
@@ -193,7 +196,7 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
                             u = v;
 #ifdef PW_PROFILE
                             // (diagnostic builds: what a consumer team spends waiting for its next unit, slot 1)
-                            atomicAdd((unsigned long long*)&ws->prof[1], (unsigned long long)(wall_clock64() - t0));
+                            atomicAdd(&pw_prof_lds[1], (unsigned long long)(wall_clock64() - t0));
 #endif
                             break;
                         }
@@ -240,6 +243,10 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
             }
         }
     }
+#ifdef PW_PROFILE
+    __syncthreads();
+    if (threadIdx.x < 32 && pw_prof_lds[threadIdx.x]) atomicAdd(&ws->prof[threadIdx.x], pw_prof_lds[threadIdx.x]);
+#endif
 }
 
 // Gate: one wave, no LDS.  Holds the stream it is launched on until every team of the

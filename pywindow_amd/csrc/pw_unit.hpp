@@ -33,13 +33,21 @@
 
 // Optional in-kernel stage timers (diagnostic build only: -DPW_PROFILE): the 100 MHz
 // constant clock accumulated per stage by lane 0 of each wave into TeamWorkspace::prof.
+// (The sums are kept in team memory -- pw_prof_lds, one array per team -- and added to TeamWorkspace::prof once, when
+// the team leaves its kernel: accumulated by global atomics, a timer's atomic was still in flight at the next wait on
+// the vector-memory counter, and whatever stage that wait belonged to was charged its round trip -- 12 us under load,
+// measured with two timers in a row; the diagnostic build ran 0.2 ms per analysis behind the product because of it.)
+#if defined(PW_PROFILE) && defined(__HIPCC__)
+__shared__ unsigned long long pw_prof_lds[32];
+#define PW_PROF_BASE(ws) ((unsigned long long*)pw_prof_lds)
+#endif
 #if defined(PW_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define PW_T0(var) long long var = wall_clock64()
 #if defined(PW_ZPROF) && defined(PW_LB_FINE)
 // (the optimiser's sub-phase timers of the neck search take the window stages' slots: those stay silent)
 #define PW_T1(ws, slot, var) do { (void)var; } while (0)
 #else
-#define PW_T1(ws, slot, var) do { if (T::lane() == 0) atomicAdd((unsigned long long*)&(ws)->prof[slot], (unsigned long long)(wall_clock64() - var)); } while (0)
+#define PW_T1(ws, slot, var) do { if (T::lane() == 0) atomicAdd(&pw_prof_lds[slot], (unsigned long long)(wall_clock64() - var)); } while (0)
 #endif
 #else
 #define PW_T0(var) do {} while (0)
@@ -2234,14 +2242,14 @@ PW_HD inline __attribute__((always_inline)) void stage_opt_impl(UnitShared& sh, 
         if (!bad) {
             S->template setup<T>(Smem, x0, lo, up, nbd, 1e7, 1e-5, 20);
 #if defined(PW_PROFILE) && !defined(PW_ZPROF)
-            S->prof = ws->prof;
+            S->prof = PW_PROF_BASE(ws);
 #endif
 #if defined(PW_PROFILE) && defined(PW_LB_FINE) && !defined(PW_ZPROF)
-            Smem->prof_fine = ws->prof;
+            Smem->prof_fine = PW_PROF_BASE(ws);
 #endif
             PoreObjective<T> fg(A, n, lo, up, (PW_LDS int*)Smem->cand);
 #if defined(PW_PROFILE) && !defined(PW_ZPROF)
-            fg.prof = ws->prof;
+            fg.prof = PW_PROF_BASE(ws);
 #endif
             // scipy's driver: maxiter = maxfun = 15000, both tested at a new iterate only
             // (_lbfgsb_py.py: "interruptions due to maxfun are postponed")
@@ -2986,9 +2994,9 @@ PW_NOINLINE PW_HD inline void wave_window(const Frame& FS, const Frame& R, PW_LD
             x01[0] = x01[0] < lo1[0] ? lo1[0] : (x01[0] > up1[0] ? up1[0] : x01[0]);
             S->template setup<T>(Smem, x01, lo1, up1, nbd1, 1e7, 1e-5, 20);
 #if defined(PW_PROFILE) && defined(PW_ZPROF)
-            S->prof = ws->prof;       // (-DPW_ZPROF: the optimiser's timers are the neck search's, not the chains')
+            S->prof = PW_PROF_BASE(ws);       // (-DPW_ZPROF: the optimiser's timers are the neck search's, not the chains')
 #if defined(PW_LB_FINE)
-            Smem->prof_fine = ws->prof;
+            Smem->prof_fine = PW_PROF_BASE(ws);
 #endif
 #endif
             int nit = 0;
