@@ -3,7 +3,9 @@
 The package keeps the reference's ``Molecule`` / ``MolecularSystem`` / ``DLPOLY``
 API surface for that path and executes it with hand-written FP64 HIP kernels for
 gfx950 (``csrc/``), through a C ABI (``include/pywindow_amd.h``) bound with
-ctypes.  There is no CPU implementation in this package.
+ctypes.  Nothing here falls back to a CPU: without the HIP library or a device every call raises.  (The one
+CPU path that exists is explicit -- a context created with ``device=-1`` runs the same kernel source compiled for
+the host, ``csrc/pw_hostpath.cpp``; nothing selects it but the caller.)
 """
 
 import os as _os
