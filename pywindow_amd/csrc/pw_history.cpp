@@ -72,7 +72,18 @@ class ReaderTeam {
     // An exception thrown by fn is rethrown here once every range has ended.
     static void run(int n, const std::function<void(int)>& fn) {
         if (n <= 1) { if (n == 1) fn(0); return; }
-        if (n > MAXT) n = MAXT;
+        if (n > MAXT) {
+            // more ranges than the team has threads (no caller asks for that today: max_threads() is what they cut
+            // their work by): the first MAXT - 1 side by side with the rest of them, in turn, on the calling thread's
+            // range -- never a range that silently does not run
+            const int extra_first = MAXT - 1;
+            const std::function<void(int)> folded = [&](int t) {
+                if (t < extra_first) { fn(t); return; }
+                for (int k = extra_first; k < n; ++k) fn(k);
+            };
+            run(MAXT, folded);
+            return;
+        }
         ReaderTeam* team = instance();
         std::unique_lock<std::mutex> region(team->region_, std::try_to_lock);
         if (!region.owns_lock() || !team->start(n - 1)) {

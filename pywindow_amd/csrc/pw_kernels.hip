@@ -75,9 +75,10 @@ constexpr int PW_SETS = 4;      // (2 + 2 x PW_SETS streams, each needs a hardwa
 constexpr size_t PW_KERNEL_STATIC_LDS = 1024;
 
 constexpr unsigned MASK_ANY = 0xffffffffu;
-constexpr unsigned MASK_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE;
+constexpr unsigned MASK_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE | PW_STAGE_WINPREP;
 constexpr unsigned MASK_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
-constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
+constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY | PW_STAGE_REUSE_PREP;
+static_assert(MASK_WINDOWS == PW_KERNEL_WINDOWS, "the window launch's kernel");
 
 // Neighbour tables of the sampling sphere, one block per vector count P (pw_unit.hpp: nb_build_point): the
 // P unit vectors go to LDS, every thread tabulates the rows of its points.
@@ -167,6 +168,8 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
         __builtin_amdgcn_s_setprio(PW_A_PRIO);
         if (threadIdx.x == 0) atomicAdd(&queue->started, 1);
     }
+    int left = 0;                  // (thread 0 of a consumer team: it has given its place in queue->active up already)
+    if ((role & 0xff) == PW_ROLE_CONSUMER && threadIdx.x == 0) atomicAdd(&queue->active, 1);
     TeamWorkspace* ws = (TeamWorkspace*)wsa.ws + blockIdx.x;
 #ifdef PW_PROFILE
     if (threadIdx.x < 32) pw_prof_lds[threadIdx.x] = 0;     // (the team's timers: summed here, flushed when it leaves)
@@ -184,35 +187,83 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
     UnitShared& sh = STATE_IN_LDS ? (UnitShared&)s_sh : sh_stack;
     const pw_params& prm = STATE_IN_LDS ? (const pw_params&)s_prm : prm_in;
     for (;;) {
-        if (role == PW_ROLE_CONSUMER) {
+        if ((role & 0xff) == PW_ROLE_CONSUMER) {
             if (threadIdx.x == 0) {
-                long pos = (long)atomicAdd(&queue->head, 1ull);
+                // A position is claimed once a unit has been published for it (head < tail): a team never sits on a
+                // position whose chain is still running.  What that buys is the END of a launch: the last quarter of the
+                // positions belongs to the slow chains, and with claim-then-wait every team of the launch held one of
+                // them -- a CU's window slot, four wave slots and 63 KB of LDS each -- until its chain came in.  Now a team
+                // that finds nothing to take LEAVES when the next analysis has been launched (its window teams are
+                // waiting for exactly those CUs) and enough teams stay for what is still to come: one for every
+                // `keep` unclaimed units (role >> 8; 0: nobody leaves early).  A lone analysis keeps all its teams.
+#ifdef PW_CLAIM_FIRST
                 long u = -1;
+                long long t0 = wall_clock64();
+                long pos = (long)atomicAdd(&queue->head, 1ull);
                 if (pos < n_units) {
-                    long long t0 = wall_clock64();
                     for (;;) {
                         int v = __hip_atomic_load(&slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (v >= 0) {
-                            u = v;
-#ifdef PW_PROFILE
-                            // (diagnostic builds: what a consumer team spends waiting for its next unit, slot 1)
-                            atomicAdd(&pw_prof_lds[1], (unsigned long long)(wall_clock64() - t0));
-#endif
-                            break;
-                        }
+                        if (v >= 0) { u = v; break; }
                         __builtin_amdgcn_s_sleep(32);
-                        // (the producer gave up -- its units never arrived: nothing more will be published)
-#ifndef PW_NO_CONSUMER_ERROR_CHECK
                         if (__hip_atomic_load(&queue->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-#endif
-                        if (wall_clock64() - t0 > 500000000ll) {   // 5 s at 100 MHz: give up, flag it
-                            atomicExch(&queue->error, 1);
-                            break;
-                        }
+                        if (wall_clock64() - t0 > 500000000ll) { atomicExch(&queue->error, 1); break; }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
+#ifdef PW_PROFILE
+                if (u >= 0) atomicAdd(&pw_prof_lds[1], (unsigned long long)(wall_clock64() - t0));
+#endif
+#else
+                const int keep = role >> 8;
+                long u = -1;
+                long long t0 = wall_clock64();
+#ifdef PW_PROFILE
+                const long long t_begin = t0;
+#endif
+                unsigned long long last_tail = ~0ull;
+                for (;;) {
+                    const unsigned long long h = __hip_atomic_load(&queue->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((long)h >= n_units) break;                          // every unit has a team
+                    const unsigned long long t = __hip_atomic_load(&queue->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (h < t) {
+                        if (atomicCAS(&queue->head, h, h + 1ull) != h) continue;          // (somebody else took it: look again)
+                        // (the slot is written right behind the tail's increment)
+                        int v;
+                        while ((v = __hip_atomic_load(&slots[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (wall_clock64() - t0 > 500000000ll) break;
+                        }
+                        if (v < 0) atomicExch(&queue->error, 1);
+                        u = v;
+                        break;
+                    }
+                    if (keep > 0 && __hip_atomic_load(&queue->successor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        const long remaining = n_units - (long)h;
+                        const long want = (remaining + keep - 1) / keep;
+                        const int a = __hip_atomic_load(&queue->active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((long)a > (want < 1 ? 1 : want) && atomicCAS(&queue->active, a, a - 1) == a) { left = 1; break; }
+                    }
+                    __builtin_amdgcn_s_sleep(32);
+                    // (the producer gave up -- its units never arrived: nothing more will be published)
+#ifndef PW_NO_CONSUMER_ERROR_CHECK
+                    if (__hip_atomic_load(&queue->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+#endif
+                    if (t != last_tail) { last_tail = t; t0 = wall_clock64(); }      // (the limit is on time WITHOUT a publication)
+                    if (wall_clock64() - t0 > 500000000ll) {   // 5 s at 100 MHz: give up, flag it
+                        atomicExch(&queue->error, 1);
+                        break;
+                    }
+                }
+#ifdef PW_PROFILE
+                // (diagnostic builds: what a consumer team spends waiting for its next unit, slot 1)
+                if (u >= 0) atomicAdd(&pw_prof_lds[1], (unsigned long long)(wall_clock64() - t_begin));
+#endif
+                if (u >= 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+#endif
                 s_unit = u;
             }
         } else {
@@ -243,6 +294,7 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
             }
         }
     }
+    if ((role & 0xff) == PW_ROLE_CONSUMER && threadIdx.x == 0 && !left) atomicSub(&queue->active, 1);
 #ifdef PW_PROFILE
     __syncthreads();
     if (threadIdx.x < 32 && pw_prof_lds[threadIdx.x]) atomicAdd(&ws->prof[threadIdx.x], pw_prof_lds[threadIdx.x]);
@@ -432,13 +484,28 @@ __global__ void pw_div_check_kernel(unsigned long long n, int mode, unsigned lon
 // stream time each -- a tenth of the step of a small batch).
 __global__ void pw_reset_kernel(unsigned long long* __restrict__ out8, long n8, UnitQueue* queue, int* __restrict__ slots,
                                 long n_units, unsigned long long* ca, unsigned long long* cb,
-                                unsigned long long* cc, unsigned long long* cd, unsigned* xw_count) {
+                                unsigned long long* cc, unsigned long long* cd, unsigned* xw_count, int keep_prep,
+                                UnitQueue* prev) {
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
+#ifdef PW_EXP_SENS
+    // (sensitivity experiment: the sampling sphere's set-up survives from the previous launch of the same records)
+    if (keep_prep) {
+        constexpr long W = sizeof(pw_unit_out) / 8;
+        for (long i = i0; i < n8; i += stride) {
+            const long w = i % W;
+            if (w == (long)(offsetof(pw_unit_out, n_points) / 8) || w == (long)(offsetof(pw_unit_out, eps) / 8) ||
+                w == (long)(offsetof(pw_unit_out, sphere_r) / 8)) continue;
+            out8[i] = 0ull;
+        }
+    } else
+#endif
     for (long i = i0; i < n8; i += stride) out8[i] = 0ull;
     for (long i = i0; i < n_units; i += stride) slots[i] = -1;
     if (i0 == 0) {
-        queue->tail = 0; queue->head = 0; queue->error = 0; queue->started = 0;
+        queue->tail = 0; queue->head = 0; queue->error = 0; queue->started = 0; queue->active = 0; queue->successor = 0;
+        // (the launch before this one learns that somebody is waiting for its CUs)
+        if (prev) __hip_atomic_store(&prev->successor, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *ca = 0; *cb = 0; *cc = 0; *cd = 0;
         *xw_count = 0u;
     }
@@ -766,11 +833,11 @@ static int launch_plan(pw_context* c, pw_resident* r, unsigned stages, const Lau
                        int ws_first, int adj_first, int counter_slot, int role = PW_ROLE_PLAIN,
                        bool reset_counter = true) {
     // the three launches of the pipeline have kernels of their own
-    if (stages == MASK_CHAINS && p.nw == 1)
+    if ((stages | PW_STAGE_WINPREP) == MASK_CHAINS && p.nw == 1)
         return launch_nw<1, MASK_CHAINS>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
     if (stages == MASK_AVERAGE && p.nw == 4)
         return launch_nw<4, MASK_AVERAGE>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
-    if (stages == MASK_WINDOWS && p.nw == 4)
+    if ((stages | PW_STAGE_REUSE_PREP) == MASK_WINDOWS && p.nw == 4)
         return launch_nw<4, MASK_WINDOWS>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
     // single launches: one wave per unit for the stages the chains kernel holds (basic, optimised pore), the general
     // four-wave kernel for everything else
@@ -1324,6 +1391,17 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         const char* bt = getenv("PW_B_TEAMS");
         if (bt && do_avg && atoi(bt) > 0) pb.grid = atoi(bt) < pb_planned ? atoi(bt) : pb_planned;   // (may also raise it)
     }
+    if (const char* cl = getenv("PW_C_LDS_KB")) {
+        // tuning: pad the LDS request of the window teams.  From 80 KB on two of them no longer fit a CU: the teams of the
+        // next analysis' window launch then become resident one CU at a time, as the teams of the previous one leave, and
+        // never take the wave slots (a CU has eight at two waves per SIMD) that the optimiser chains live on
+        const size_t want = (size_t)atoi(cl) * 1024;
+        if (want > pc.lds && want <= 160 * 1024 - 256 - PW_KERNEL_STATIC_LDS) {
+            pc.lds = want;
+            const int per_cu = (int)(c->lds_per_cu / (pc.lds + PW_KERNEL_STATIC_LDS));
+            if (pc.grid > c->n_cu * per_cu) pc.grid = c->n_cu * per_cu;
+        }
+    }
     if (const char* cslots = getenv("PW_C_SLOTS")) {
         // experiment: fewer window-fit slots than waves (less LDS per team, windows fitted in rounds);
         // PW_C_TEAMS then sets the number of teams (up to what the smaller request admits per CU)
@@ -1418,6 +1496,18 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     // the gates of the launch after this set's previous user read the queue that is reset below
     if (c->tail_valid[nx]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_tail[nx], 0));
     if (c->head_valid[nx]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_head[nx], 0));
+    int keep_prep = 0;
+    unsigned exp_chain = ~0u, exp_win = ~0u;       // (stage bits the sensitivity experiment takes away)
+#ifdef PW_EXP_SENS
+    {
+        static int launches = 0;
+        const char* m = getenv("PW_EXP_PREP_MODE");
+        const int mode = m ? atoi(m) : 0;
+        if (mode == 1) exp_win = ~PW_STAGE_REUSE_PREP;                           // the chains pay, nobody gains
+        if (mode == 2 && launches >= 12) { exp_chain = ~PW_STAGE_WINPREP; keep_prep = 1; }   // the window teams gain, nobody pays
+        ++launches;
+    }
+#endif
     {
         static_assert(sizeof(pw_unit_out) % 8 == 0, "records are cleared in 8-byte words");
         const long n8 = (long)(sizeof(pw_unit_out) / 8) * r->n_units;
@@ -1425,7 +1515,8 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(pw_reset_kernel, dim3((unsigned)blocks), dim3(256), 0, c->prod, (unsigned long long*)r->d_out, n8,
                            c->cur_queue, c->cur_slots, r->n_units, c->counter + b, c->counter + PW_SETS + b,
-                           c->counter + 2 * PW_SETS + b, c->counter + 3 * PW_SETS + b, r->d_xw_count + r->cur);
+                           c->counter + 2 * PW_SETS + b, c->counter + 3 * PW_SETS + b, r->d_xw_count + r->cur, keep_prep,
+                           (p >= 0 && p != b && c->done_valid[p]) ? c->queue + p : (UnitQueue*)nullptr);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev_reset[b], c->prod));
@@ -1448,7 +1539,13 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     c->last_res[b] = (const void*)r;
     // several optimiser launches can be in flight: separate work counters and workspaces
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][0], c->prod));
-    rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod, ws_a, -1, b, PW_ROLE_PRODUCER, false);
+    // (PW_CHAIN_PREP=0: the window teams work out the sampling sphere's radius and the DBSCAN radius themselves, as until round 5)
+    // PW_TAIL_KEEP: the idle teams at the end of a window launch that has a successor -- one stays per so many unclaimed units
+    // (0: all stay, rounds 1-5's behaviour)
+    static const int tail_keep = getenv("PW_TAIL_KEEP") ? (atoi(getenv("PW_TAIL_KEEP")) & 0xff) : 4;
+    static const bool chain_prep = !(getenv("PW_CHAIN_PREP") && getenv("PW_CHAIN_PREP")[0] == '0');
+    rc = launch_plan(c, r, (PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE | (chain_prep ? PW_STAGE_WINPREP : 0u)) & exp_chain, pa, c->prod,
+                     ws_a, -1, b, PW_ROLE_PRODUCER, false);
     if (rc != PW_OK) return rc;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][1], c->prod));
     HIP_TRY(hipEventRecord(c->ev_prod[b], c->prod));
@@ -1472,7 +1569,8 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         }
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][0], cs));
-    rc = launch_plan(c, r, MASK_WINDOWS, pc, cs, ws_c, b * c->max_c, PW_SETS + b, PW_ROLE_CONSUMER, false);
+    rc = launch_plan(c, r, (chain_prep ? MASK_WINDOWS : (MASK_WINDOWS & ~PW_STAGE_REUSE_PREP)) & exp_win, pc, cs, ws_c, b * c->max_c,
+                     PW_SETS + b, PW_ROLE_CONSUMER | (tail_keep << 8), false);
     if (rc != PW_OK) return rc;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][1], cs));
     if (do_avg) {
@@ -1515,7 +1613,8 @@ static int check_queue_error(pw_context* c) {
                                           : (cause == 4 ? "the optimiser launch timed out becoming resident (residency gate)"
                                                         : "a streamed batch was given up while it was being analysed")),
                  which, c->cur_sets, cause, q[which].tail, q[which].head, q[which].started);
-        return PW_E_TIMEOUT;
+        // (a batch that was given up is not a time-out: nothing to repeat, nothing to count)
+        return cause == 3 ? PW_E_HIP : PW_E_TIMEOUT;
     }
     return PW_OK;
 }

@@ -28,9 +28,12 @@ struct PwWsArgs {
 // (MI355X guide, "Inter-workgroup communication").  Every spin is bounded.
 struct UnitQueue {
     unsigned long long tail;   // next free slot (producers)
-    unsigned long long head;   // next slot to consume
+    unsigned long long head;   // next slot to consume (a consumer claims a position only once it is published: head <= tail)
     int error;                 // set when a consumer gives up waiting
     int started;               // producer teams that have begun (gate for the other launches)
+    int active;                // consumer teams in their loop
+    int successor;             // the analysis after this one has been launched: its window teams want the CUs that this
+                               // launch's idle teams hold (set by that launch's reset kernel)
 };
 enum : int { PW_ROLE_PLAIN = 0, PW_ROLE_PRODUCER = 1, PW_ROLE_CONSUMER = 2 };
 

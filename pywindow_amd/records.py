@@ -135,6 +135,15 @@ class RecordStore:
                     out[o:o + a.nbytes] = a.view(np.uint8).reshape(-1)
             out.flush()
             del out
+            # mkstemp creates the file 0600: give it what open(path, "wb") would have given -- the mode of the file it
+            # replaces, else 0666 less the umask
+            try:
+                mode = os.stat(path).st_mode & 0o7777
+            except OSError:
+                um = os.umask(0)
+                os.umask(um)
+                mode = 0o666 & ~um
+            os.chmod(tmp, mode)
             os.replace(tmp, path)
         except BaseException:
             try:

@@ -314,7 +314,12 @@ class DLPOLY:
             # RCCL gather (device pointer -> tensor view, stream-ordered, no host copy on the way)
             recs = self._run_and_gather_on_device(mine, vdw, mass, device, len(sel), rank, world, dist)
         else:
-            recs = self._run(mine, vdw, mass, device)
+            err = None
+            try:
+                recs = self._run(mine, vdw, mass, device)
+            except Exception as exc:  # noqa: BLE001  (local to this rank: the others must hear of it before the gather)
+                err = exc
+            _all_ranks_ok(dist, world, device, err)
             if dist is not None and world > 1:
                 recs = gather_records(recs, len(sel), rank, world, dist)
         extra = engine.offset_extra(getattr(self, "_extra", np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE)), lo)
@@ -431,12 +436,17 @@ class DLPOLY:
         res = None
         ctx = engine.context(dev)
         with ctx.lock:
-            if frames:
-                coords, _ = self._read_selected(frames, False)
-                res = ctx.upload(_lib.Batch.uniform(coords, vdw, mass))
-                res.launch(_lib.STAGE_ALL)
+            err = None
+            try:
+                if frames:
+                    coords, _ = self._read_selected(frames, False)
+                    res = ctx.upload(_lib.Batch.uniform(coords, vdw, mass))
+                    res.launch(_lib.STAGE_ALL)
+            except Exception as exc:  # noqa: BLE001  (local to this rank: the others must hear of it before the gather)
+                err = exc
             self._extra = np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE)
             try:
+                _all_ranks_ok(dist, world, dev, err)
                 recs = gather_records_device(res, n_total, rank, world, dist, torch.device("cuda", dev))
                 if res is not None:
                     # the gather read the records on the device; what only the host can see comes now: a
@@ -579,7 +589,12 @@ class DLPOLY:
         el = self.elements(swap_atoms, forcefield)
         dist, rank, world = _dist_state(distributed)
         lo, hi = shard_range(len(sel), rank, world)
-        recs, uframe, umol = self._run_modular(sel[lo:hi], rebuild, el, device)
+        err = None
+        try:
+            recs, uframe, umol = self._run_modular(sel[lo:hi], rebuild, el, device)
+        except Exception as exc:  # noqa: BLE001  (local to this rank)
+            err = exc
+        _all_ranks_ok(dist, world, device, err)
         extra = getattr(self, "_extra", np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE))
         if dist is not None and world > 1:
             tags = np.stack([uframe, umol], axis=1).astype(np.int64)
@@ -616,6 +631,30 @@ def _dist_state(distributed):
     if dist_mod is not None and dist_mod.is_available() and dist_mod.is_initialized():
         return dist_mod, dist_mod.get_rank(), dist_mod.get_world_size()
     return None, 0, 1
+
+
+class PwRankError(RuntimeError):
+    """Another rank of the job failed in a step that is local to a rank (reading, uploading, launching, downloading):
+    every rank leaves the analysis together instead of waiting in a collective the failed rank will never enter."""
+
+
+def _all_ranks_ok(dist, world: int, device, error: BaseException | None) -> None:
+    """One all-reduce of a flag in front of a collective section.  ``error``: what this rank caught in its local
+    step, or None.  Raises on EVERY rank when any rank failed: the rank's own exception where it has one,
+    :class:`PwRankError` on the others.  (The counterpart in the reference: a worker's exception reaches the parent
+    through ``pool.get()``, trajectory.py:563-586.)"""
+    if dist is None or world <= 1:
+        if error is not None:
+            raise error
+        return
+    import torch
+
+    flag = torch.tensor([1 if error is not None else 0], dtype=torch.int64, device=_collective_device(dist, device))
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if error is not None:
+        raise error
+    if int(flag.item()) != 0:
+        raise PwRankError("another rank failed in a local step of the analysis (see its output); no records were gathered")
 
 
 def _collective_device(dist, device: int | None):

@@ -173,3 +173,52 @@ def test_trajectory_driver_shards_and_gathers_world2(tmp_path, modular):
         for f in range(7):
             assert sorted(out[f]) == list(range(2 + f % 3))
             assert all(out[f][m] == (100 + m, f * 10.0 + m) for m in out[f])
+
+
+def _failing_rank_worker(rank, world, port, q):
+    """DLPOLY.analysis on two ranks where rank 1's LOCAL step raises: both ranks must leave the analysis with an
+    exception -- rank 1 its own, rank 0 PwRankError -- instead of rank 0 waiting in the gather for ever."""
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pywindow_amd as pw
+    from pywindow_amd import synth, trajectory
+
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        path = synth.write_synthetic_history(os.path.join(tmp, "HISTORY"), 6)
+        traj = pw.DLPOLY(path)
+
+        def run(frames, vdw, mass, device):                      # (stands in for upload / launch / download)
+            if rank == 1:
+                raise ValueError("rank 1 cannot")
+            return np.zeros(len(frames), dtype=trajectory._lib.UNIT_OUT_DTYPE)
+
+        traj._run = run
+        try:
+            traj.analysis(forcefield="opls", swap_atoms={"he": "H"})
+            q.put((rank, "returned"))
+        except trajectory.PwRankError:
+            q.put((rank, "PwRankError"))
+        except ValueError as exc:
+            q.put((rank, "ValueError: %s" % exc))
+    dist.destroy_process_group()
+
+
+def test_a_rank_that_fails_locally_takes_the_others_out_of_the_gather():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got == {0: "PwRankError", 1: "ValueError: rank 1 cannot"}

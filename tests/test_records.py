@@ -191,3 +191,24 @@ def test_a_loaded_store_can_be_saved_over_its_own_file(tmp_path):
     assert p.read_bytes() == before
     assert float(RecordStore.load(p).records["pore_d"][499]) == 499.0
     assert [f.name for f in tmp_path.iterdir()] == [p.name]          # (no temporary file left behind)
+
+
+def test_a_saved_store_has_the_mode_of_an_ordinary_file(tmp_path):
+    """save() writes through a temporary file (mkstemp: 0600) and renames it: the result must still carry what
+    open(path, 'wb') would have given -- 0666 less the umask for a new file, the old file's mode for one that is
+    replaced (advisor, round 5)."""
+    import os
+    import stat
+
+    from pywindow_amd.records import RecordStore
+
+    store = RecordStore(np.zeros(3, dtype=_lib.UNIT_OUT_DTYPE), np.arange(3))
+    old = os.umask(0o022)
+    try:
+        p = store.save(tmp_path / "fresh")
+        assert stat.S_IMODE(p.stat().st_mode) == 0o644
+        os.chmod(p, 0o640)
+        store.save(p)
+        assert stat.S_IMODE(p.stat().st_mode) == 0o640
+    finally:
+        os.umask(old)
