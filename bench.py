@@ -567,10 +567,8 @@ def _provenance_of(name, data=None):
 
 SERIAL_STATS_FILES = ("r05_serial_kernel_stats.csv", "r04_serial_kernel_stats.csv", "r03_serial_kernel_stats.csv")
 # which launch a kernel name of the stats file belongs to (template arguments: waves per team, stage mask)
-# (round 6: the chains kernel carries the window search's set-up stage, mask 165; the window kernel takes it over, mask 376)
-_KERNEL_OF = (("pw_analyse_kernel<1, 165u>", "chains"), ("pw_analyse_kernel<4, 98u>", "average"),
-              ("pw_analyse_kernel<4, 376u>", "windows"),
-              ("pw_analyse_kernel<1, 37u>", "chains"), ("pw_analyse_kernel<4, 120u>", "windows"))
+_KERNEL_OF = (("pw_analyse_kernel<1, 37u>", "chains"), ("pw_analyse_kernel<4, 98u>", "average"),
+              ("pw_analyse_kernel<4, 120u>", "windows"))
 
 
 def _serial_kernel_ms():

@@ -66,7 +66,13 @@ extern "C" {
 #define PW_E_NOMEM (-5)
 #define PW_E_RETRY (-6)     /* a capacity was grown for this batch: launch the analysis again, then download */
 #define PW_E_TIMEOUT (-7)   /* a launch of the pipeline gave up waiting for another one (pw_last_error names the wait);
-                               the records are incomplete: repeat the analysis (pw_context_retries counts repeats) */
+                               the records are incomplete: repeat the analysis (pw_context_retries counts repeats).
+                               Every wait inside a kernel is bounded by time WITHOUT PROGRESS of the other side:
+                               PW_WAIT_LIMIT_MS (default 250) between launches of one analysis -- a window team that sees
+                               no unit published, a residency gate that sees no optimiser team start -- and
+                               PW_STREAM_LIMIT_MS (default 5000) for the host's next append to a streamed batch; both are
+                               read by pw_context_create.  A wait during which the other side keeps making progress (a
+                               device shared with another tenant, a batch of long chains) is never cut short. */
 
 /* stage selection bits for pw_analysis_* */
 #define PW_STAGE_BASIC 1u   /* molecular_weight, center_of_mass, max_dim, pore_diameter */
@@ -219,12 +225,14 @@ int64_t pw_context_extra_windows(pw_context *ctx, pw_extra_window *buf, int64_t 
  * environment BEFORE the process first initialises HIP; pw_context_create measures whether they do and
  * falls back (with a line on stderr) instead of letting gate kernels wait for launches queued behind them */
 int pw_context_pipelined(pw_context *ctx);
-/* diagnostic: how many pacing gates of the pipeline gave up waiting since the context was created (tail gates |
- * head gates << 16 | residency gates << 32).  A gate is never a dependency - a time-out costs 20 ms (2 s for a
- * residency gate) and changes no result; zero on a healthy device. */
+/* diagnostic: how many gates of the pipeline gave up waiting since the context was created (tail gates |
+ * head gates << 16 | residency gates << 32).  Tail and head gates only pace launches: an expiry costs 20 ms and
+ * changes no result.  A residency gate that sees no optimiser team start for PW_WAIT_LIMIT_MS lets the launches
+ * behind it go when some teams HAVE started (the device is busy; nothing is lost) and gives the analysis up
+ * (PW_E_TIMEOUT) when not one has.  Zero on a healthy device. */
 int pw_context_gate_timeouts(pw_context *ctx, uint64_t *count);
 /* How many analyses were REPEATED on this context after a launch gave up waiting for another one (PW_E_TIMEOUT):
- * by pw_analysis_batch / pw_analysis_debug themselves (they repeat once), and by callers of the pw_resident_*
+ * by pw_analysis_batch / pw_analysis_debug themselves (up to PW_TIMEOUT_REPEATS times, default 2), and by callers of the pw_resident_*
  * entry points, who repeat on PW_E_TIMEOUT and say so with pw_context_count_retry.  Zero on a healthy device;
  * pw_retries_total() is the same over every context of the process.  (The reference has nothing to compare:
  * its Pool workers either return or raise, trajectory.py:553-586.) */
@@ -250,7 +258,7 @@ int pw_context_reserve_points(pw_context *ctx, int64_t n_points);
  * append: coordinates [count][template_atoms][3] of units first .. first + count - 1, `first` = the number appended
  * so far; the call returns when the copy has landed (from page-locked memory, pw_context_pinned, a DMA of tens of
  * microseconds per megabyte) and the buffer may be reused.  Downloading an incomplete batch is PW_E_BAD_ARG; a
- * launch that waits 5 s for a unit gives up and the download reports it (PW_E_TIMEOUT).  Device contexts only;
+ * launch that sees no unit appended for PW_STREAM_LIMIT_MS (5 s) gives up and the download reports it (PW_E_TIMEOUT).  Device contexts only;
  * molecules beyond LDS (PW_E_TOO_LARGE) go through pw_resident_upload.  On a context that runs an analysis as ONE
  * launch (pw_context_pipelined() == 0), or for stages without the window search, a launch asked for before the last
  * unit has arrived is made by the append that completes the batch (nothing overlaps, nothing waits). */

@@ -399,6 +399,17 @@ def _check(rc: int, what: str):
         raise PwHipError(f"{what} failed with code {rc}: {msg}")
 
 
+def timeout_repeats() -> int:
+    """How often an analysis is repeated after ``PW_E_TIMEOUT`` before the error is raised (``PW_TIMEOUT_REPEATS``,
+    default 2; the library's ``pw_analysis_batch`` reads the same variable)."""
+    import os
+
+    try:
+        return max(0, int(os.environ.get("PW_TIMEOUT_REPEATS", "2")))
+    except ValueError:
+        return 2
+
+
 def retries_total() -> int:
     """Analyses repeated after a launch gave up waiting for another one (``PW_E_TIMEOUT``), over every context
     of this process.  Zero on a healthy device."""
@@ -784,14 +795,17 @@ class Resident:
                 if rc == E_RETRY:
                     self.launch(getattr(self, "_stages", STAGE_ALL))
                     rc = load().pw_resident_download(self.ctx._h, self._h, out.ctypes.data)
-                if rc == E_TIMEOUT:
-                    # a launch that gave up waiting for another launch of the same analysis: the analysis is
-                    # repeated ONCE -- a second time-out is raised -- and the repeat is COUNTED (Context.retries,
-                    # retries_total(): the bench line and the suite's last test look at them) and logged
+                repeats = 0
+                while rc == E_TIMEOUT and repeats < timeout_repeats():
+                    # a launch that saw another launch of the same analysis make no progress for a whole limit
+                    # (PW_WAIT_LIMIT_MS, 250 ms): the analysis is repeated, up to PW_TIMEOUT_REPEATS (2) times -- the
+                    # next time-out is raised -- and every repeat is COUNTED (Context.retries, retries_total(): the
+                    # bench line and the suite's last test look at them) and logged
                     import logging
 
                     logging.getLogger("pywindow_amd").warning("analysis repeated after: %s", load().pw_last_error().decode(errors="replace"))
                     load().pw_context_count_retry(self.ctx._h)
+                    repeats += 1
                     self.launch(getattr(self, "_stages", STAGE_ALL))
                     rc = load().pw_resident_download(self.ctx._h, self._h, out.ctypes.data)
                 _check(rc, "pw_resident_download")

@@ -75,10 +75,9 @@ constexpr int PW_SETS = 4;      // (2 + 2 x PW_SETS streams, each needs a hardwa
 constexpr size_t PW_KERNEL_STATIC_LDS = 1024;
 
 constexpr unsigned MASK_ANY = 0xffffffffu;
-constexpr unsigned MASK_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE | PW_STAGE_WINPREP;
+constexpr unsigned MASK_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE;
 constexpr unsigned MASK_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
-constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY | PW_STAGE_REUSE_PREP;
-static_assert(MASK_WINDOWS == PW_KERNEL_WINDOWS, "the window launch's kernel");
+constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 
 // Neighbour tables of the sampling sphere, one block per vector count P (pw_unit.hpp: nb_build_point): the
 // P unit vectors go to LDS, every thread tabulates the rows of its points.
@@ -127,15 +126,18 @@ __global__ void __launch_bounds__(256) pw_nb_build_kernel(unsigned* __restrict__
 // coordinates are on the device.  The launches that read coordinates without going through the hand-off queue --
 // optimiser chains, average diameter -- take units in index order and wait (bounded) until theirs is there, so the
 // analysis can be launched before the reader has decoded the first frame.  ready == nullptr: everything is there.
-__device__ inline bool wait_for_unit(const unsigned long long* ready, long u, int* error_flag) {
+__device__ inline bool wait_for_unit(const unsigned long long* ready, long u, int* error_flag, long long limit) {
     if (!ready) return true;
     long long t0 = wall_clock64();
+    unsigned long long seen = ~0ull;
     for (;;) {
         const unsigned long long have = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((long)have > u && !(have >> 63)) break;
         __builtin_amdgcn_s_sleep(16);
-        // 5 s: the host stopped appending; the top bit: the host gave the batch up (pw_resident_free of an incomplete one)
-        if ((have >> 63) || wall_clock64() - t0 > 500000000ll) {
+        if (have != seen) { seen = have; t0 = wall_clock64(); }     // (the limit is on time WITHOUT an append)
+        // the limit (5 s by default: this side waits for the HOST -- a reader, a disk): the host stopped appending;
+        // the top bit: the host gave the batch up (pw_resident_free of an incomplete one)
+        if ((have >> 63) || wall_clock64() - t0 > limit) {
             if (error_flag) atomicExch(error_flag, (have >> 63) ? 3 : 2);      // (the cause: check_queue_error reports it)
             return false;
         }
@@ -168,8 +170,6 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
         __builtin_amdgcn_s_setprio(PW_A_PRIO);
         if (threadIdx.x == 0) atomicAdd(&queue->started, 1);
     }
-    int left = 0;                  // (thread 0 of a consumer team: it has given its place in queue->active up already)
-    if ((role & 0xff) == PW_ROLE_CONSUMER && threadIdx.x == 0) atomicAdd(&queue->active, 1);
     TeamWorkspace* ws = (TeamWorkspace*)wsa.ws + blockIdx.x;
 #ifdef PW_PROFILE
     if (threadIdx.x < 32) pw_prof_lds[threadIdx.x] = 0;     // (the team's timers: summed here, flushed when it leaves)
@@ -187,89 +187,54 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
     UnitShared& sh = STATE_IN_LDS ? (UnitShared&)s_sh : sh_stack;
     const pw_params& prm = STATE_IN_LDS ? (const pw_params&)s_prm : prm_in;
     for (;;) {
-        if ((role & 0xff) == PW_ROLE_CONSUMER) {
+        if (role == PW_ROLE_CONSUMER) {
             if (threadIdx.x == 0) {
-                // A position is claimed once a unit has been published for it (head < tail): a team never sits on a
-                // position whose chain is still running.  What that buys is the END of a launch: the last quarter of the
-                // positions belongs to the slow chains, and with claim-then-wait every team of the launch held one of
-                // them -- a CU's window slot, four wave slots and 63 KB of LDS each -- until its chain came in.  Now a team
-                // that finds nothing to take LEAVES when the next analysis has been launched (its window teams are
-                // waiting for exactly those CUs) and enough teams stay for what is still to come: one for every
-                // `keep` unclaimed units (role >> 8; 0: nobody leaves early).  A lone analysis keeps all its teams.
-#ifdef PW_CLAIM_FIRST
-                long u = -1;
-                long long t0 = wall_clock64();
                 long pos = (long)atomicAdd(&queue->head, 1ull);
+                long u = -1;
                 if (pos < n_units) {
+                    long long t0 = wall_clock64();
+#ifdef PW_PROFILE
+                    const long long t_begin = t0;
+#endif
+                    unsigned long long seen = ~0ull;
+                    int spins = 0;
                     for (;;) {
                         int v = __hip_atomic_load(&slots[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (v >= 0) { u = v; break; }
-                        __builtin_amdgcn_s_sleep(32);
-                        if (__hip_atomic_load(&queue->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                        if (wall_clock64() - t0 > 500000000ll) { atomicExch(&queue->error, 1); break; }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
+                        if (v >= 0) {
+                            u = v;
 #ifdef PW_PROFILE
-                if (u >= 0) atomicAdd(&pw_prof_lds[1], (unsigned long long)(wall_clock64() - t0));
+                            // (diagnostic builds: what a consumer team spends waiting for its next unit, slot 1)
+                            atomicAdd(&pw_prof_lds[1], (unsigned long long)(wall_clock64() - t_begin));
 #endif
-#else
-                const int keep = role >> 8;
-                long u = -1;
-                long long t0 = wall_clock64();
-#ifdef PW_PROFILE
-                const long long t_begin = t0;
-#endif
-                unsigned long long last_tail = ~0ull;
-                for (;;) {
-                    const unsigned long long h = __hip_atomic_load(&queue->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((long)h >= n_units) break;                          // every unit has a team
-                    const unsigned long long t = __hip_atomic_load(&queue->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (h < t) {
-                        if (atomicCAS(&queue->head, h, h + 1ull) != h) continue;          // (somebody else took it: look again)
-                        // (the slot is written right behind the tail's increment)
-                        int v;
-                        while ((v = __hip_atomic_load(&slots[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {
-                            __builtin_amdgcn_s_sleep(2);
-                            if (wall_clock64() - t0 > 500000000ll) break;
+                            break;
                         }
-                        if (v < 0) atomicExch(&queue->error, 1);
-                        u = v;
-                        break;
-                    }
-                    if (keep > 0 && __hip_atomic_load(&queue->successor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        const long remaining = n_units - (long)h;
-                        const long want = (remaining + keep - 1) / keep;
-                        const int a = __hip_atomic_load(&queue->active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((long)a > (want < 1 ? 1 : want) && atomicCAS(&queue->active, a, a - 1) == a) { left = 1; break; }
-                    }
-                    __builtin_amdgcn_s_sleep(32);
-                    // (the producer gave up -- its units never arrived: nothing more will be published)
+                        __builtin_amdgcn_s_sleep(32);
+                        // (the producer gave up -- its units never arrived: nothing more will be published)
 #ifndef PW_NO_CONSUMER_ERROR_CHECK
-                    if (__hip_atomic_load(&queue->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                        if (__hip_atomic_load(&queue->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
 #endif
-                    if (t != last_tail) { last_tail = t; t0 = wall_clock64(); }      // (the limit is on time WITHOUT a publication)
-                    if (wall_clock64() - t0 > 500000000ll) {   // 5 s at 100 MHz: give up, flag it
-                        atomicExch(&queue->error, 1);
-                        break;
+                        // The limit is on time WITHOUT A PUBLICATION by the optimiser launch (250 ms by default; a chain
+                        // publishes every few microseconds, the slowest takes 2 ms): a wait during which the producers
+                        // keep coming in -- a device shared with another tenant, a batch of long chains -- is never cut
+                        // short, a producer launch that is not running at all is noticed within the limit.
+                        if ((++spins & 15) == 0) {
+                            const unsigned long long pub = __hip_atomic_load(&queue->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (pub != seen) { seen = pub; t0 = wall_clock64(); }
+                        }
+                        if (wall_clock64() - t0 > wsa.wait_ticks) {
+                            atomicExch(&queue->error, 1);
+                            break;
+                        }
                     }
-                }
-#ifdef PW_PROFILE
-                // (diagnostic builds: what a consumer team spends waiting for its next unit, slot 1)
-                if (u >= 0) atomicAdd(&pw_prof_lds[1], (unsigned long long)(wall_clock64() - t_begin));
-#endif
-                if (u >= 0) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-#endif
                 s_unit = u;
             }
         } else {
             if (threadIdx.x == 0) {
                 long u = (long)atomicAdd(counter, 1ull);
-                if (u < n_units && !wait_for_unit(ready, u, &queue->error)) u = n_units;
+                if (u < n_units && !wait_for_unit(ready, u, &queue->error, wsa.stream_wait_ticks)) u = n_units;
                 s_unit = u < n_units ? u : -1;
             }
         }
@@ -294,7 +259,6 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
             }
         }
     }
-    if ((role & 0xff) == PW_ROLE_CONSUMER && threadIdx.x == 0 && !left) atomicSub(&queue->active, 1);
 #ifdef PW_PROFILE
     __syncthreads();
     if (threadIdx.x < 32 && pw_prof_lds[threadIdx.x]) atomicAdd(&ws->prof[threadIdx.x], pw_prof_lds[threadIdx.x]);
@@ -304,18 +268,25 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
 // Gate: one wave, no LDS.  Holds the stream it is launched on until every team of the
 // optimiser launch is resident, so that launches queued behind it cannot take the LDS those
 // teams need.  It can never block them itself, and its wait is bounded.
-// A gate that expires (2 s) does NOT let the launches behind it go: teams that wait for units while the optimiser
-// teams cannot become resident is the state the gate exists to prevent.  It sets the queue's error flag (cause 4)
-// instead -- the consumers behind it leave at once, the download reports PW_E_TIMEOUT and the analysis is repeated,
-// counted (pw_context_retries).
-__global__ void pw_gate_kernel(UnitQueue* queue, int expected, unsigned long long* timeouts) {
+// Its limit (PW_WAIT_LIMIT_MS, 250 ms) is on time WITHOUT A TEAM STARTING; what an expiry means is said where it is handled.
+__global__ void pw_gate_kernel(UnitQueue* queue, int expected, unsigned long long* timeouts, long long limit) {
     if (threadIdx.x != 0) return;
     long long t0 = wall_clock64();
-    while (__hip_atomic_load(&queue->started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+    int seen = -1;
+    for (;;) {
+        const int started = __hip_atomic_load(&queue->started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (started >= expected) break;
         __builtin_amdgcn_s_sleep(16);
-        if (wall_clock64() - t0 > 200000000ll) {   // 2 s
+        if (started != seen) { seen = started; t0 = wall_clock64(); }      // (the limit is on time without a team starting)
+        if (wall_clock64() - t0 > limit) {
+            // Counted either way.  Teams HAVE started and then none for a whole limit: the device is busy with something
+            // else (another tenant, earlier analyses' chains); the launches behind the gate may go -- the window teams are
+            // capped at five per four CUs (launch_pipeline), so the optimiser teams that are still to come always find
+            // wave slots and LDS, and the consumers' own limit watches the publications from here on.  NOT ONE team has
+            // started: the optimiser launch is not running at all -- its stream is behind something that does not move --
+            // and consumers would only wait for it: the analysis is given up (cause 4, PW_E_TIMEOUT).
             atomicAdd(timeouts, 1ull << 32);
-            atomicCAS(&queue->error, 0, 4);
+            if (started == 0) atomicCAS(&queue->error, 0, 4);
             break;
         }
     }
@@ -484,28 +455,13 @@ __global__ void pw_div_check_kernel(unsigned long long n, int mode, unsigned lon
 // stream time each -- a tenth of the step of a small batch).
 __global__ void pw_reset_kernel(unsigned long long* __restrict__ out8, long n8, UnitQueue* queue, int* __restrict__ slots,
                                 long n_units, unsigned long long* ca, unsigned long long* cb,
-                                unsigned long long* cc, unsigned long long* cd, unsigned* xw_count, int keep_prep,
-                                UnitQueue* prev) {
+                                unsigned long long* cc, unsigned long long* cd, unsigned* xw_count) {
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
-#ifdef PW_EXP_SENS
-    // (sensitivity experiment: the sampling sphere's set-up survives from the previous launch of the same records)
-    if (keep_prep) {
-        constexpr long W = sizeof(pw_unit_out) / 8;
-        for (long i = i0; i < n8; i += stride) {
-            const long w = i % W;
-            if (w == (long)(offsetof(pw_unit_out, n_points) / 8) || w == (long)(offsetof(pw_unit_out, eps) / 8) ||
-                w == (long)(offsetof(pw_unit_out, sphere_r) / 8)) continue;
-            out8[i] = 0ull;
-        }
-    } else
-#endif
     for (long i = i0; i < n8; i += stride) out8[i] = 0ull;
     for (long i = i0; i < n_units; i += stride) slots[i] = -1;
     if (i0 == 0) {
-        queue->tail = 0; queue->head = 0; queue->error = 0; queue->started = 0; queue->active = 0; queue->successor = 0;
-        // (the launch before this one learns that somebody is waiting for its CUs)
-        if (prev) __hip_atomic_store(&prev->successor, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        queue->tail = 0; queue->head = 0; queue->error = 0; queue->started = 0;
         *ca = 0; *cb = 0; *cc = 0; *cd = 0;
         *xw_count = 0u;
     }
@@ -522,6 +478,9 @@ __global__ void pw_set_debug_kernel(TeamWorkspace* ws, int blocks, pw_unit_debug
 static std::atomic<unsigned long long> g_retries_total{0};
 struct pw_context {
     unsigned long long retries = 0;   // analyses repeated after PW_E_TIMEOUT (pw_context_retries)
+    long long wait_ticks;             // PW_WAIT_LIMIT_MS (default 250): a launch waits this long for another one WITHOUT PROGRESS
+    long long stream_wait_ticks;      // PW_STREAM_LIMIT_MS (default 5000): ... and for the host's next append to a streamed batch
+    int timeout_repeats;              // PW_TIMEOUT_REPEATS (default 2): how often pw_analysis_batch repeats an analysis after PW_E_TIMEOUT
     int device;
     hipStream_t stream;      // main stream (launch order, timing events)
     hipStream_t aux;         // second stream: stages that do not depend on the optimiser
@@ -822,6 +781,8 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
     wsa.xwin_cap = r->xw_cap;
     wsa.p_cap = c->p_cap;
     wsa.nb_off = c->nb_off; wsa.nb_idx = c->nb_idx; wsa.nb_bound = c->nb_bound; wsa.nb_unit = c->nb_unit;
+    // (a chain's length grows with the molecule: the limit with it -- CC3's 168 atoms: as configured)
+    wsa.wait_ticks = c->wait_ticks * (1 + r->nmax / 512); wsa.stream_wait_ticks = c->stream_wait_ticks;
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
                        r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb, p.nframes, p.lean, wsa,
                        c->counter + counter_slot, r->d_out, role, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab,
@@ -833,11 +794,11 @@ static int launch_plan(pw_context* c, pw_resident* r, unsigned stages, const Lau
                        int ws_first, int adj_first, int counter_slot, int role = PW_ROLE_PLAIN,
                        bool reset_counter = true) {
     // the three launches of the pipeline have kernels of their own
-    if ((stages | PW_STAGE_WINPREP) == MASK_CHAINS && p.nw == 1)
+    if (stages == MASK_CHAINS && p.nw == 1)
         return launch_nw<1, MASK_CHAINS>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
     if (stages == MASK_AVERAGE && p.nw == 4)
         return launch_nw<4, MASK_AVERAGE>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
-    if ((stages | PW_STAGE_REUSE_PREP) == MASK_WINDOWS && p.nw == 4)
+    if (stages == MASK_WINDOWS && p.nw == 4)
         return launch_nw<4, MASK_WINDOWS>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
     // single launches: one wave per unit for the stages the chains kernel holds (basic, optimised pore), the general
     // four-wave kernel for everything else
@@ -1012,6 +973,14 @@ int pw_context_create(int device, pw_context** out) {
     c->fused = (fz && fz[0] == '1') ? 1 : 0;
     c->c_waves = 4;
     c->prm = default_params();
+    {
+        auto ms_env = [](const char* name, long dflt) { const char* e = getenv(name); long v = e ? atol(e) : dflt; return v > 0 ? v : dflt; };
+        c->wait_ticks = 100000ll * ms_env("PW_WAIT_LIMIT_MS", 250);          // (wall_clock64: 100 MHz)
+        c->stream_wait_ticks = 100000ll * ms_env("PW_STREAM_LIMIT_MS", 5000);
+        const char* tr = getenv("PW_TIMEOUT_REPEATS");
+        c->timeout_repeats = tr ? atoi(tr) : 2;
+        if (c->timeout_repeats < 0) c->timeout_repeats = 0;
+    }
     if (!c->fused && !(getenv("PW_STREAM_PROBE") && getenv("PW_STREAM_PROBE")[0] == '0')) {
         // Do the ten streams of the pipeline really run side by side?  (PW_STREAM_PROBE=0 skips the question:
         // a profiler that serialises kernels -- rocprofv3 --pmc -- would otherwise turn the pipeline off and
@@ -1287,6 +1256,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
             wsa.xwin = r->d_xw[r->cur]; wsa.xwin_count = r->d_xw_count + r->cur; wsa.xwin_cap = r->xw_cap;
             wsa.p_cap = c->p_cap;
             wsa.nb_off = c->nb_off; wsa.nb_idx = c->nb_idx; wsa.nb_bound = c->nb_bound; wsa.nb_unit = c->nb_unit;
+            wsa.wait_ticks = c->wait_ticks; wsa.stream_wait_ticks = c->stream_wait_ticks;
             return pw_internal_big_launch((void*)c->stream, (int)grid, r->n_units, r->d_offset, r->d_xyz, r->d_vdw, r->d_mass,
                                           stages, r->nmax, &wsa, c->bigmem, bb, c->counter + 4 * PW_SETS + 1, r->d_out, &c->prm,
                                           c->rsq_tab, r->vstride);
@@ -1391,17 +1361,6 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         const char* bt = getenv("PW_B_TEAMS");
         if (bt && do_avg && atoi(bt) > 0) pb.grid = atoi(bt) < pb_planned ? atoi(bt) : pb_planned;   // (may also raise it)
     }
-    if (const char* cl = getenv("PW_C_LDS_KB")) {
-        // tuning: pad the LDS request of the window teams.  From 80 KB on two of them no longer fit a CU: the teams of the
-        // next analysis' window launch then become resident one CU at a time, as the teams of the previous one leave, and
-        // never take the wave slots (a CU has eight at two waves per SIMD) that the optimiser chains live on
-        const size_t want = (size_t)atoi(cl) * 1024;
-        if (want > pc.lds && want <= 160 * 1024 - 256 - PW_KERNEL_STATIC_LDS) {
-            pc.lds = want;
-            const int per_cu = (int)(c->lds_per_cu / (pc.lds + PW_KERNEL_STATIC_LDS));
-            if (pc.grid > c->n_cu * per_cu) pc.grid = c->n_cu * per_cu;
-        }
-    }
     if (const char* cslots = getenv("PW_C_SLOTS")) {
         // experiment: fewer window-fit slots than waves (less LDS per team, windows fitted in rounds);
         // PW_C_TEAMS then sets the number of teams (up to what the smaller request admits per CU)
@@ -1496,18 +1455,6 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     // the gates of the launch after this set's previous user read the queue that is reset below
     if (c->tail_valid[nx]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_tail[nx], 0));
     if (c->head_valid[nx]) HIP_TRY(hipStreamWaitEvent(c->prod, c->ev_head[nx], 0));
-    int keep_prep = 0;
-    unsigned exp_chain = ~0u, exp_win = ~0u;       // (stage bits the sensitivity experiment takes away)
-#ifdef PW_EXP_SENS
-    {
-        static int launches = 0;
-        const char* m = getenv("PW_EXP_PREP_MODE");
-        const int mode = m ? atoi(m) : 0;
-        if (mode == 1) exp_win = ~PW_STAGE_REUSE_PREP;                           // the chains pay, nobody gains
-        if (mode == 2 && launches >= 12) { exp_chain = ~PW_STAGE_WINPREP; keep_prep = 1; }   // the window teams gain, nobody pays
-        ++launches;
-    }
-#endif
     {
         static_assert(sizeof(pw_unit_out) % 8 == 0, "records are cleared in 8-byte words");
         const long n8 = (long)(sizeof(pw_unit_out) / 8) * r->n_units;
@@ -1515,8 +1462,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(pw_reset_kernel, dim3((unsigned)blocks), dim3(256), 0, c->prod, (unsigned long long*)r->d_out, n8,
                            c->cur_queue, c->cur_slots, r->n_units, c->counter + b, c->counter + PW_SETS + b,
-                           c->counter + 2 * PW_SETS + b, c->counter + 3 * PW_SETS + b, r->d_xw_count + r->cur, keep_prep,
-                           (p >= 0 && p != b && c->done_valid[p]) ? c->queue + p : (UnitQueue*)nullptr);
+                           c->counter + 2 * PW_SETS + b, c->counter + 3 * PW_SETS + b, r->d_xw_count + r->cur);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev_reset[b], c->prod));
@@ -1539,20 +1485,14 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     c->last_res[b] = (const void*)r;
     // several optimiser launches can be in flight: separate work counters and workspaces
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][0], c->prod));
-    // (PW_CHAIN_PREP=0: the window teams work out the sampling sphere's radius and the DBSCAN radius themselves, as until round 5)
-    // PW_TAIL_KEEP: the idle teams at the end of a window launch that has a successor -- one stays per so many unclaimed units
-    // (0: all stay, rounds 1-5's behaviour)
-    static const int tail_keep = getenv("PW_TAIL_KEEP") ? (atoi(getenv("PW_TAIL_KEEP")) & 0xff) : 4;
-    static const bool chain_prep = !(getenv("PW_CHAIN_PREP") && getenv("PW_CHAIN_PREP")[0] == '0');
-    rc = launch_plan(c, r, (PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE | (chain_prep ? PW_STAGE_WINPREP : 0u)) & exp_chain, pa, c->prod,
-                     ws_a, -1, b, PW_ROLE_PRODUCER, false);
+    rc = launch_plan(c, r, PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE, pa, c->prod, ws_a, -1, b, PW_ROLE_PRODUCER, false);
     if (rc != PW_OK) return rc;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[0][1], c->prod));
     HIP_TRY(hipEventRecord(c->ev_prod[b], c->prod));
     hipStream_t cs = c->cons[b];
     HIP_TRY(hipStreamWaitEvent(cs, c->ev_reset[b], 0));
     hipLaunchKernelGGL(pw_gate_kernel, dim3(1), dim3(64), 0, cs, c->cur_queue,
-                       (long)pa.grid < r->n_units ? pa.grid : (int)r->n_units, c->counter + 4 * PW_SETS + 2);
+                       (long)pa.grid < r->n_units ? pa.grid : (int)r->n_units, c->counter + 4 * PW_SETS + 2, c->wait_ticks);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev_gate[b], cs));
     c->head_valid[b] = 0;
@@ -1569,8 +1509,7 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         }
     }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][0], cs));
-    rc = launch_plan(c, r, (chain_prep ? MASK_WINDOWS : (MASK_WINDOWS & ~PW_STAGE_REUSE_PREP)) & exp_win, pc, cs, ws_c, b * c->max_c,
-                     PW_SETS + b, PW_ROLE_CONSUMER | (tail_keep << 8), false);
+    rc = launch_plan(c, r, MASK_WINDOWS, pc, cs, ws_c, b * c->max_c, PW_SETS + b, PW_ROLE_CONSUMER, false);
     if (rc != PW_OK) return rc;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][1], cs));
     if (do_avg) {
@@ -1603,9 +1542,9 @@ static int check_queue_error(pw_context* c) {
         // (only the flags: the other sets' queues may belong to analyses that are running)
         for (int b = 0; b < PW_SETS; ++b)
             if (q[b].error != 0) (void)hipMemset(&c->queue[b].error, 0, sizeof(c->queue[b].error));
-        // cause 1: a window team waited 5 s for a unit of the optimiser launch; 2: a team waited 5 s for the coordinates of a
-        // streamed batch; 3: a streamed batch was given up while its launches were waiting; 4: the optimiser teams of a
-        // launch were not all resident within 2 s (pw_gate_kernel)
+        // cause 1: a window team saw no unit published by the optimiser launch for a whole limit (PW_WAIT_LIMIT_MS, 250 ms);
+        // 2: a team saw no coordinates appended to a streamed batch for PW_STREAM_LIMIT_MS (5 s); 3: a streamed batch was given
+        // up while its launches were waiting; 4: NOT ONE optimiser team of a launch started within the limit (pw_gate_kernel)
         const int cause = q[which].error;
         snprintf(g_err, sizeof(g_err), "%s (set %d of %d, cause %d: %llu units published, %llu taken, %d optimiser teams started)",
                  cause == 1 ? "window launch timed out waiting for the optimiser launch"
@@ -1976,7 +1915,7 @@ void pw_resident_free(pw_context* c, pw_resident* r) {
     DeviceScope scope;
     if (c) (void)scope.enter(c->device);
     // a streamed batch given up before its last unit: the launches that wait for units stop waiting (the top bit of
-    // the counter; they would give up by themselves after 5 s)
+    // the counter; they would give up by themselves after PW_STREAM_LIMIT_MS)
     const bool given_up = r->h_ready && r->ready_units < r->n_units;
     if (given_up) __atomic_store_n(r->h_ready, (1ull << 63) | (unsigned long long)r->ready_units, __ATOMIC_RELEASE);
     // wait for the launches that touched this batch -- not for the whole device -- and keep its blocks for
@@ -2151,12 +2090,14 @@ int pw_resident_stage_times(pw_context* c, pw_resident* r, float* ms) {
 // either way the launch is repeated, so no limit of the engine ever shows in a result
 static int launch_and_download(pw_context* c, pw_resident* r, uint32_t stages, pw_unit_out* out) {
     int rc = PW_OK;
+    int timeouts = 0;
     for (int attempt = 0; attempt < 4; ++attempt) {
         rc = pw_resident_launch(c, r, stages);
         if (rc == PW_OK) rc = pw_resident_download(c, r, out);
         if (rc == PW_E_RETRY) continue;
-        // (a launch that gave up waiting for another launch of the same analysis -- 5 s: the analysis is repeated once)
-        if (rc == PW_E_TIMEOUT && attempt == 0) { count_retry(c); continue; }
+        // (a launch that saw another launch of the same analysis make no progress for a whole limit: the analysis is
+        // repeated, up to PW_TIMEOUT_REPEATS times, every repeat counted)
+        if (rc == PW_E_TIMEOUT && timeouts < c->timeout_repeats) { ++timeouts; --attempt; count_retry(c); continue; }
         if (rc != PW_OK) return rc;
         long want = 0;
         for (long u = 0; u < r->n_units; ++u)

@@ -18,6 +18,11 @@ struct PwWsArgs {
     const unsigned short* nb_idx;
     const double* nb_bound;
     const double* nb_unit;          // the unit vectors themselves, 3 per point (null: the teams compute them)
+    // How long a team of one launch waits for ANOTHER launch of the same analysis without seeing it make any
+    // progress (ticks of the 100 MHz wall clock; pw_context::wait_ticks, PW_WAIT_LIMIT_MS, default 250 ms) before it
+    // gives the analysis up (PW_E_TIMEOUT).  A wait during which the other side keeps publishing is never cut short.
+    long long wait_ticks;
+    long long stream_wait_ticks;    // ... and for the HOST to append coordinates to a streamed batch (PW_STREAM_LIMIT_MS, default 5 s)
 };
 
 // Hand-off between the optimiser launch (producer, one wave per unit) and the window
@@ -28,12 +33,9 @@ struct PwWsArgs {
 // (MI355X guide, "Inter-workgroup communication").  Every spin is bounded.
 struct UnitQueue {
     unsigned long long tail;   // next free slot (producers)
-    unsigned long long head;   // next slot to consume (a consumer claims a position only once it is published: head <= tail)
+    unsigned long long head;   // next slot to consume
     int error;                 // set when a consumer gives up waiting
     int started;               // producer teams that have begun (gate for the other launches)
-    int active;                // consumer teams in their loop
-    int successor;             // the analysis after this one has been launched: its window teams want the CUs that this
-                               // launch's idle teams hold (set by that launch's reset kernel)
 };
 enum : int { PW_ROLE_PLAIN = 0, PW_ROLE_PRODUCER = 1, PW_ROLE_CONSUMER = 2 };
 

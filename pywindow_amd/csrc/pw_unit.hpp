@@ -221,7 +221,6 @@ struct UnitVars {
     // ---- window search only: everything from here on is NOT allocated for the optimiser-chain
     // launch (UnitShared::bytes with nframes == 1) ----
     int win_first;     // marks where the window-search variables start (offsetof)
-    int prep;          // 1: radius / P / eps of the sampling sphere came with the record (stage_winprep of the optimiser launch)
     // sampling vector chosen for each cluster (largest 2*gap, first occurrence)
     double win_vec[PW_W_MAX][3];
     // window results by cluster
@@ -3382,21 +3381,12 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
     T::sync();
     if (T::wave() == 0) PW_T1(ws, 14, t_pre);
     PW_T0(t_md);
-    // The radius of the sampling sphere, its number of points and the DBSCAN radius depend on the molecule and the pore
-    // centre only: in the pipeline the optimiser launch's wave works them out behind its chain (stage_winprep) and they
-    // arrive with the record -- the same functions on the same numbers, so the same bits.
-    const bool prep = v.prep != 0;
-    double radius;
-    if (prep) {
-        radius = v.radius;
-    } else {
-        team_max_dim<T, true>(sh, sh.S, n, 2 * n + 2 <= ws->p_cap ? ws->vals : nullptr);
-        PW_DCHECK(__builtin_amdgcn_read_exec() == ~0ull, 112);
-        radius = v.maxd / 2.0;
-        T::sync();
-        if (T::tid() == 0) { v.maxd = keep_d; v.maxd_i = keep_i; v.maxd_j = keep_j; }
-    }
+    team_max_dim<T, true>(sh, sh.S, n, 2 * n + 2 <= ws->p_cap ? ws->vals : nullptr);
+    PW_DCHECK(__builtin_amdgcn_read_exec() == ~0ull, 112);
+    double radius = v.maxd / 2.0;
+    T::sync();
     if (T::wave() == 0) PW_T1(ws, 15, t_md);
+    if (T::tid() == 0) { v.maxd = keep_d; v.maxd_i = keep_i; v.maxd_j = keep_j; }
     if (!(radius / prm.increment < PW_PATH_POINTS_MAX) || !(radius / prm.increment2 < PW_PATH_POINTS_MAX)) {
         // The path of a sampling vector has radius / increment points, a cluster's refined one radius / increment2.  A pore
         // centre that an open or enormous search box let run away (the objective has no maximum out there; the sphere is
@@ -3447,9 +3437,7 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
     if (T::wave() == 0) PW_T1(ws, 26, t_pre);
     // ---- eps: mean of all 10-NN distances (self included), utilities.py:1427-1434 ----
     PW_T0(t_eps);
-    if (prep && v.P == P) {
-        if (T::tid() == 0) out->eps = v.eps;          // (v.eps: read from the record by analyse_unit, before the resets above)
-    } else {
+    {
         PW_T0(t_knn);
         // A thread takes FOUR consecutive points (a "group").  With this P's neighbour table (the sixteen nearest
         // points of every point on the unit sphere, NbTables) a point is sixteen exact distances that must come
@@ -3950,179 +3938,11 @@ PW_NOINLINE PW_HD inline void stage_windows(UnitShared& sh, TeamWorkspace* ws, i
     stage_windows_impl<T>(sh, ws, n, out, prm);
 }
 
-// ---- what the window search needs before its first bulk loop, by ONE wave (the optimiser launch, behind its chain) ----
-// find_windows begins with three things that depend on the molecule and the pore centre only: the radius of the
-// sampling sphere (max_dim of the molecule shifted to the pore centre, utilities.py:1398), the number of sampling
-// vectors (:1409) and the DBSCAN radius -- the mean of the ten nearest-neighbour distances of every vector (:1427-1434).
-// In the pipeline the window teams are what bounds a step (one team per CU, 280 us per unit of which these three are
-// 30), while a chain's wave slot is idle half of the time: so the wave that has just found the pore centre works them
-// out as well, with the functions the window team would have used (team_max_dim, the neighbour tables, numpy's pairwise
-// sum in tiles: none of them depends on the team's shape), and hands them over in the record (sphere_r, n_points,
-// eps > 0).  Anything unusual -- no tables, a point its table cannot vouch for, a capacity flag -- and nothing is
-// handed over: the window team then computes all three itself, as it does in every other launch shape.
-#if defined(__HIP_DEVICE_COMPILE__)
-// the DBSCAN radius of P points on a sphere of radius R from the context's tables: unit vectors (x R: the sampling
-// vectors, team_sphere_points) and the sixteen nearest of every point (NbTables).  mem: team memory for the sum's leaf
-// table, accumulators and a tile of the flattened (P, 10) array.  false: not computed.
-template <class T>
-PW_NOINLINE __device__ inline bool team_knn_eps_tabled(const TeamWorkspace* ws, double R, int P, PW_LDS unsigned char* mem,
-                                                       size_t mem_bytes, PW_LDS double* slot, double* eps_out) {
-    if (!ws->nb_off || !ws->nb_unit || !ws->nb_idx || !ws->nb_bound || P < PW_NB_PMIN || P > PW_NB_PMAX) return false;
-    const unsigned first = ws->nb_off[P];
-    if (first == PW_NB_NONE) return false;
-    const unsigned short* nb_idx = ws->nb_idx + (size_t)first * PW_NB_K;
-    const double* nb_bound = ws->nb_bound + first;
-    const double* u = ws->nb_unit + 3 * (size_t)first;
-    ScratchArena a;
-    a.cur = (unsigned char*)mem;
-    a.left = mem_bytes;
-    int* s_tab = (int*)a.take(324 * 4);
-    double* s_leaf = (double*)a.take(256 * 8);
-    if (!s_tab || !s_leaf) return false;
-    const long words = (long)(a.left / 8) - 160;
-    int slots = (int)(words / (64 + 8)) - 2;
-    if (slots > 64) slots = 64;
-    if (slots < 4) return false;
-    size_t acc_words = 8 * (size_t)(slots + 2);
-    if (acc_words < 128) acc_words = 128;
-    double* s_acc = (double*)a.take(acc_words * 8);
-    double* tile = (double*)a.take((size_t)slots * 64 * 8);
-    const int tile_cap = slots * 64 - 128;
-    if (!s_acc || !tile || tile_cap < 128) return false;
-    PW_LDS double* tile_ = PW_AS_LDS(tile);
-    const double slack = (R * R) * (1.0 - 1e-9);
-    const int n_el = P * 10;
-    bool bad = false;
-    double total = 0.0;
-    bool first_chunk = true;
-    for (int s0 = 0; s0 < n_el; s0 += 8192) {
-        const int len = n_el - s0 < 8192 ? n_el - s0 : 8192;
-        np_leaf_table<T>(len, s_tab);           // (visible after the barrier behind the first tile's fill)
-        int lo = 0;
-        while (lo < len) {
-            int hi = len;
-            if (lo + tile_cap < len) {
-                int off, l;
-                np_descend(len, lo + tile_cap, &off, &l);
-                hi = off;
-            }
-            // the points whose distances fall into this tile, one to a thread (windows_bulk_impl: point_tabled)
-            const int E0 = s0 + lo, E1 = s0 + hi;
-            const int k1 = (E1 - 1) / 10;
-            for (int k = E0 / 10 + T::tid(); k <= k1; k += T::SIZE) {
-                const double px = u[3 * k] * R, py = u[3 * k + 1] * R, pz = u[3 * k + 2] * R;
-                const unsigned* row = (const unsigned*)(nb_idx + (size_t)k * PW_NB_K);   // (32-byte rows)
-                unsigned w[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) w[c] = row[c];
-                double qx[PW_NB_K], qy[PW_NB_K], qz[PW_NB_K];
-#pragma unroll
-                for (int c = 0; c < PW_NB_K; ++c) {
-                    const int j = (int)((w[c >> 1] >> (16 * (c & 1))) & 0xffffu);
-                    qx[c] = u[3 * j]; qy[c] = u[3 * j + 1]; qz[c] = u[3 * j + 2];
-                }
-                double prev = -1.0, cd[PW_NB_K], d10[10];
-                bool sorted = true;
-#pragma unroll
-                for (int c = 0; c < PW_NB_K; ++c) {
-                    const double ax = px - qx[c] * R, ay = py - qy[c] * R, az = pz - qz[c] * R;
-                    double d = ax * ax;
-                    d = d + ay * ay; d = d + az * az;
-                    sorted = sorted && d >= prev;
-                    prev = d;
-                    cd[c] = d;
-                    if (c < 10) d10[c] = d;
-                }
-                if (!sorted) {
-#pragma unroll
-                    for (int q = 0; q < 10; ++q) d10[q] = PW_INF;
-#pragma unroll
-                    for (int c = 0; c < PW_NB_K; ++c) {
-                        double v_ = cd[c];
-#pragma unroll
-                        for (int q = 0; q < 10; ++q) {
-                            const double lo_ = __builtin_fmin(d10[q], v_);
-                            v_ = __builtin_fmax(d10[q], v_);
-                            d10[q] = lo_;
-                        }
-                    }
-                }
-                if (!(d10[9] < nb_bound[k] * slack)) bad = true;        // (the windowed search is the window team's)
-                const int e0 = k * 10 - s0;
-#pragma unroll
-                for (int q = 0; q < 10; ++q)
-                    if (e0 + q >= lo && e0 + q < hi) tile_[e0 + q - lo] = pw_sqrt(d10[q]);
-            }
-            T::sync();
-            np_leaf_phase<T>(tile, len, lo, hi, s_tab, s_acc, s_leaf, true);
-            lo = hi;
-        }
-        const double part = np_walk_phase<T>(len, s_tab, s_acc, s_leaf);
-        if (T::tid() == 0) total = first_chunk ? part : total + part;
-        first_chunk = false;
-        T::sync();
-    }
-    if (T::tid() == 0) *slot = total;
-    // (one flag for the team: a wave's lanes agree by ballot, the waves through the slot's neighbour)
-    bad = T::wave_any(bad);
-    if (T::NWAVES > 1) {
-        if (T::tid() == 0) slot[1] = 0.0;
-        T::sync();
-        if (bad && T::lane() == 0) slot[1] = 1.0;
-        T::sync();
-        bad = slot[1] != 0.0;
-    } else {
-        T::sync();
-    }
-    const double sum = *slot;
-    T::sync();
-    if (bad) return false;
-    const double m = sum / (double)(P * 10);
-    *eps_out = m + pw_pow_np(m, 0.5);
-    return true;
-}
-
-// Runs in the optimiser launch's kernel, after stage_opt; the frame is shifted IN PLACE (the launch keeps one frame and
-// nothing of it is read afterwards), and the frame and the optimiser block are the eps stage's team memory.
-template <class T>
-PW_NOINLINE __device__ inline void stage_winprep(UnitShared& sh, TeamWorkspace* ws, int n, pw_unit_out* out, const pw_params& prm) {
-    PW_ASSUME_TEAM_STATE(sh, prm);
-    auto& v = *sh.v;
-    if (prm.pore_opt && (v.status & PW_ST_NEGATIVE_PORE)) return;          // (no window search for this unit)
-    if (sh.S.x != sh.A.x) return;                                           // (a launch with two frames is not the chains')
-    // utilities.py:1380-1393, as windows_bulk_impl forms it
-    double shift[3];
-    for (int c = 0; c < 3; ++c) {
-        const double adjust = prm.pore_opt ? v.com[c] - v.opt_c[c] : 0.0;
-        shift[c] = v.com[c] - adjust;
-    }
-    for (int i = T::tid(); i < n; i += T::SIZE) {
-        const double x = sh.A.x[i] - shift[0], y = sh.A.y[i] - shift[1], z = sh.A.z[i] - shift[2];
-        sh.S.x[i] = x; sh.S.y[i] = y; sh.S.z[i] = z;
-        sh.S.xx[i] = sq3(x, y, z);
-    }
-    T::sync();
-    team_max_dim<T, true>(sh, sh.S, n, nullptr);
-    const double radius = v.maxd / 2.0;
-    T::sync();
-    if (!(radius / prm.increment < PW_PATH_POINTS_MAX) || !(radius / prm.increment2 < PW_PATH_POINTS_MAX)) return;
-    const int P = sampling_count(radius, prm.adjust_windows);
-    if (P > ws->p_cap || P < 10) return;
-    PW_LDS unsigned char* mem = (PW_LDS unsigned char*)sh.A.x;
-    const size_t mem_bytes = (size_t)((sh.scratch + sh.scratch_bytes) - mem);
-    double eps = 0.0;
-    if (!team_knn_eps_tabled<T>(ws, radius, P, mem, mem_bytes, (PW_LDS double*)&v.red_v[14], &eps)) return;
-    if (T::tid() == 0 && eps > 0.0) { out->sphere_r = radius; out->n_points = P; out->eps = eps; }
-}
-#endif
-
 // ---- the unit ------------------------------------------------------------------------------------
 // internal stage bits used when one analysis is split over several launches
 constexpr unsigned PW_STAGE_REUSE_OPT = 16u;   // pore centre already in the record (earlier launch)
 constexpr unsigned PW_STAGE_MERGE = 32u;       // record is shared with other launches: no resets
 constexpr unsigned PW_STAGE_COM_ONLY = 64u;    // only what later stages need from stage_basic
-constexpr unsigned PW_STAGE_WINPREP = 128u;    // after the pore centre: sphere radius, vector count and DBSCAN radius into the record
-constexpr unsigned PW_STAGE_REUSE_PREP = 256u; // ... and the launch that takes them from there (with PW_STAGE_REUSE_OPT)
 
 PW_HD inline void record_or_status(pw_unit_out* out, int st, int evals) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -4135,7 +3955,7 @@ PW_HD inline void record_or_status(pw_unit_out* out, int st, int evals) {
 }
 
 constexpr unsigned PW_KERNEL_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
-constexpr unsigned PW_KERNEL_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY | PW_STAGE_REUSE_PREP;
+constexpr unsigned PW_KERNEL_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 
 template <class T, unsigned KMASK = 0xffffffffu>
 PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const double* xyz,
@@ -4170,32 +3990,14 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
         stage_basic<T>(sh, ws, n, out, (stages & PW_STAGE_COM_ONLY) != 0);
     }
     if (stages & PW_STAGE_OPT) stage_opt<T>(sh, ws, n, out, prm);
-#if defined(__HIP_DEVICE_COMPILE__)
-    // (only the optimiser launch's own kernel carries the stage: its mask has no window search)
-    if ((KMASK & PW_STAGE_WINPREP) && !(KMASK & PW_STAGE_WINDOWS) && T::WSIZE == 64 && (stages & PW_STAGE_WINPREP) &&
-        (stages & PW_STAGE_OPT)) {
-        PW_T0(t_wp);
-        stage_winprep<T>(sh, ws, n, out, prm);
-        T::sync();
-        if (T::wave() == 0) PW_T1(ws, 5, t_wp);
-    }
-#endif
     if (reuse_opt) {
         if (T::tid() == 0) {
             sh.v->opt_c[0] = out->pore_opt_c[0];
             sh.v->opt_c[1] = out->pore_opt_c[1];
             sh.v->opt_c[2] = out->pore_opt_c[2];
             if (out->status & PW_ST_NEGATIVE_PORE) sh.v->status |= PW_ST_NEGATIVE_PORE;
-            if (stages & PW_STAGE_WINDOWS) {
-                // what stage_winprep left in the record (eps > 0: it did), before the window search resets those fields
-                const double e = (stages & PW_STAGE_REUSE_PREP) ? out->eps : 0.0;
-                sh.v->prep = e > 0.0 ? 1 : 0;
-                if (e > 0.0) { sh.v->eps = e; sh.v->radius = out->sphere_r; sh.v->P = out->n_points; }
-            }
         }
         T::sync();
-    } else if ((stages & PW_STAGE_WINDOWS) && T::tid() == 0) {
-        sh.v->prep = 0;
     }
     if (stages & PW_STAGE_AVG) {
         PW_T0(t_a);
