@@ -46,8 +46,9 @@ ALGO_FLOP_BY_KERNEL = {
 HBM_PEAK_GBS = 8000.0
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 # static inputs measured with rocprofv3 --pmc (separate passes; committed summaries), NOT by this run
-TRAFFIC_FILES = ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01j_hbm_traffic.json")
-COUNTER_FILES = ("r05_instruction_counters.json", "r04_instruction_counters.json", "r03_instruction_counters.json", "r02_instruction_counters.json", "r01j_instruction_counters.json")
+TRAFFIC_FILES = ("r06_hbm_traffic.json", "r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01j_hbm_traffic.json")
+COUNTER_FILES = ("r06_instruction_counters.json", "r05_instruction_counters.json", "r04_instruction_counters.json", "r03_instruction_counters.json", "r02_instruction_counters.json", "r01j_instruction_counters.json")
+FP64_FILES = ("r06_fp64_counters.json",)
 # the only figure for this metric the reference's repository holds: 715-frame CC3 trajectory,
 # traj.analysis(ncpus=8) in 286.5 s (examples/Example7_AnalysingTrajectorySingleMol.ipynb:569-575)
 REFERENCE_NOTEBOOK_FPS = 715 / 286.5
@@ -565,7 +566,7 @@ def _provenance_of(name, data=None):
     return out
 
 
-SERIAL_STATS_FILES = ("r05_serial_kernel_stats.csv", "r04_serial_kernel_stats.csv", "r03_serial_kernel_stats.csv")
+SERIAL_STATS_FILES = ("r06_serial_kernel_stats.csv", "r05_serial_kernel_stats.csv", "r04_serial_kernel_stats.csv", "r03_serial_kernel_stats.csv")
 # which launch a kernel name of the stats file belongs to (template arguments: waves per team, stage mask)
 _KERNEL_OF = (("pw_analyse_kernel<1, 37u>", "chains"), ("pw_analyse_kernel<4, 98u>", "average"),
               ("pw_analyse_kernel<4, 120u>", "windows"))
@@ -865,6 +866,26 @@ def main():
                               "provenance": _provenance_of(cname, cj)}
             except (KeyError, TypeError, ZeroDivisionError):
                 valu_issue = None
+        # what the vector ALUs really execute in double precision (rocprofv3 --pmc SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64, a
+        # committed summary like the two above): executed flop per launch and the fraction of the FP64 vector peak that is,
+        # at the kernel time measured in this run -- beside `frac`, which prices the ALGORITHMIC 2e7 flop per unit
+        fj, fname = _load_profile(FP64_FILES)
+        executed = None
+        if fj is not None:
+            try:
+                ex_launch = fj["executed_fp64_flop_per_unit"] * args.frames
+                executed = {"executed_fp64_flop_per_launch": ex_launch,
+                            "frac_executed": ex_launch / (k_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                            "executed_over_algorithmic": ex_launch / (ALGO_FLOP_PER_UNIT * args.frames),
+                            "by_kernel": {k: {"executed_fp64_flop": v["executed_fp64_flop"] * args.frames / fj["units_per_launch"],
+                                              "fp64_share_of_valu": v.get("fp64_share_of_valu")} for k, v in fj["kernels"].items()},
+                            "what": "(2 FMA + MUL + ADD + TRANS) F64 wave instructions x 64 lanes (inactive lanes included): what the "
+                                    "ALUs are occupied with in double precision -- pruned evaluations do not appear, address "
+                                    "arithmetic, integer work and the single-precision screens are not counted",
+                            "source": f"static: profiles/{fname} (rocprofv3 --pmc), not measured by this run",
+                            "provenance": _provenance_of(fname, fj)}
+            except (KeyError, TypeError, ZeroDivisionError):
+                executed = None
         # per launch of the pipeline, each on its own (no other launch in flight): HIP events on the
         # stream the kernel runs on; profiles/r02_serial_kernel_stats.csv is rocprofv3's view of the same
         # Two clocks per launch: `ms` = rocprofv3's average kernel duration of ONE analysis at a time (committed summary,
@@ -892,10 +913,13 @@ def main():
             "metric": "trajectory frames/sec full_analysis (pore+windows), CC3 1k-frame",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": value / REFERENCE_NOTEBOOK_FPS, "dtype": "f64", "data": "synthetic",
-            "vs_baseline_note": "BASELINE.md holds no published benchmark; the denominator is the only figure for this metric in the "
-                                "reference's repository: 715-frame CC3 trajectory, analysis(ncpus=8), 286.5 s = 2.50 frames/s "
-                                "(examples/Example7_AnalysingTrajectorySingleMol.ipynb:569-575, unknown 2018 hardware)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline_note": "BASELINE.md holds no published number for this metric (section 1: none), so there is nothing to "
+                                "divide by.  The comparisons that mean something are in cpu_baseline / vs_cpu_baseline: the oracle "
+                                "on one core and on every core this container may use, and the kernels' own source on those cores. "
+                                "(The reference's repository holds one incidental timing, a 2018 notebook on unknown hardware: "
+                                "715 frames in 286.5 s on 8 processes = %.2f frames/s, "
+                                "examples/Example7_AnalysingTrajectorySingleMol.ipynb:569-575.)" % REFERENCE_NOTEBOOK_FPS,
             "config": {"workload": "CC3 1000-frame synthetic DL_POLY trajectory (BASELINE configs[1]), "
                                    "per-frame pore+windows, 168 atoms/frame",
                        "frames_per_gpu": args.frames, "stages": "all", "results_ok": ok, "retried_after": retried_after,
@@ -915,6 +939,9 @@ def main():
             "roofline": {"bound": "fp64_valu", "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS,
                          "algorithmic_flop_per_launch": ALGO_FLOP_PER_UNIT * args.frames,
+                         "executed_fp64_flop_per_launch": None if executed is None else executed["executed_fp64_flop_per_launch"],
+                         "frac_executed": None if executed is None else executed["frac_executed"],
+                         "executed": executed,
                          "kernel": "pw_analyse_kernel x 3 (one analysis = optimiser chains | average diameter | window search, concurrent)",
                          "kernel_ms": k_ms,
                          "kernel_ms_note": "HIP events on the launch streams around back-to-back analyses / their number: the steady-state "
@@ -935,6 +962,7 @@ def main():
                                      "measured on; stale = the sources under pywindow_amd/csrc have changed since",
                              "csrc_sha16_now": _csrc_sha16(),
                              "traffic": _provenance_of(tname, tj), "counters": _provenance_of(cname, cj),
+                             "fp64_counters": _provenance_of(fname, fj),
                              "serial_kernel_stats": _provenance_of(prof_name if per_kernel else None)}},
         }
         if strong is not None:
@@ -943,7 +971,16 @@ def main():
                 strong["one_gpu_frames_per_s"] = units_per_s
                 strong["speedup"] = strong["value"] / units_per_s
                 strong["efficiency"] = strong["value"] / (world * units_per_s)
+                # first class, beside the weak headline
+                line["value_strong"] = strong["value"]
+                line["efficiency_strong"] = strong["efficiency"]
             line["strong"] = strong
+            line["config"]["scaling_note"] = (
+                "`value` is WEAK scaling: every rank analyses its own %d frames per step (what a job with more trajectories "
+                "than GPUs does).  BASELINE's metric names ONE 1k-frame trajectory on 1/2/4/8 GPUs, i.e. STRONG scaling: that "
+                "is `value_strong` / `efficiency_strong` (`strong`: the same trajectory split into %d contiguous shards, the "
+                "gather of the records included).  A shard of a few hundred frames is bound by the latency of its slowest "
+                "optimiser chain, not by throughput (DESIGN.md section 5), so value_strong stays far below value." % (args.frames, world))
         if world == 1:
             # what strong scaling of the 1000-frame trajectory can reach: a rank's share analysed on this
             # GPU (ranks are independent; the gather is not in these numbers)
@@ -971,6 +1008,35 @@ def main():
                 line["secondary"] = secondary(ctx, vdw, mass)
             except Exception as exc:  # noqa: BLE001
                 line["secondary"] = {"error": repr(exc)}
+            # the end-to-end figures, where the driver keeps them (it preserves `config` whole): what the headline leaves
+            # out -- reading the file, H2D, D2H, the cold start -- and BASELINE's other shapes on this GPU
+            sec = line["secondary"]
+
+            def pick(*path):
+                cur = sec
+                for k in path:
+                    if not isinstance(cur, dict) or k not in cur:
+                        return None
+                    cur = cur[k]
+                return cur
+
+            cold = pick("e2e_history_to_records", "cold_first_call_ms")
+            line["config"]["end_to_end"] = {
+                "what": "medians measured by this run after the headline (details under `secondary`): the 1000-frame HISTORY "
+                        "file to records (tokenise + H2D + analysis + D2H), the same from the file NAME, a fresh process "
+                        "(import, context, open, first analysis), the 1024-frame periodic HISTORY (8 cages per frame: "
+                        "tokenise + re-assembly + analysis), and a 4000-unit resident batch",
+                "e2e_history_to_records_ms": pick("e2e_history_to_records", "ms"),
+                "e2e_history_to_records_frames_per_s": pick("e2e_history_to_records", "frames_per_s"),
+                "e2e_open_plus_analysis_ms": pick("e2e_history_to_records", "open_plus_analysis_ms"),
+                "e2e_history_to_dicts_ms": pick("e2e_history_to_dicts", "ms"),
+                "cold_first_call_ms": None if not isinstance(cold, dict) or "error" in cold else {
+                    "total": sum(cold[k] for k in ("import_and_load_ms", "context_ms", "open_index_ms", "first_analysis_ms")),
+                    "context_ms": cold["context_ms"], "first_analysis_ms": cold["first_analysis_ms"]},
+                "periodic_history_e2e": {"ms": pick("periodic_history_e2e", "ms"), "cages_per_s": pick("periodic_history_e2e", "cages_per_s"),
+                                         "breakdown_ms": pick("periodic_history_e2e", "breakdown_ms")},
+                "periodic_cell_cages_per_s": pick("periodic_cell", "cages_per_s"),
+                "throughput_batch_units_per_s": pick("throughput_batch", "units_per_s")}
         if cpu is not None:
             line["cpu_baseline"] = cpu
             line["vs_cpu_baseline"] = {"one_core": value / cpu["value"],

@@ -541,6 +541,7 @@ struct pw_context {
     hipEvent_t ev_t[3][2];   // pw_resident_stage_times: start / stop of the chains, average and window launches
     int timing;              // record them during the next pipeline launch
     pw_unit_debug* dbg;      // per-unit stage capture of the current debug analysis, else null
+    hipStream_t rb_stream;   // the periodic re-assembly's own stream, highest priority (pw_internal_rebuild_stream), created on first use
     void* pool;              // device scratch kept between calls (the team slabs of the periodic re-assembly)
     size_t pool_bytes;
     // device blocks of freed batches, kept for the next upload (hipMalloc / hipFree cost tens of microseconds
@@ -897,7 +898,24 @@ int pw_context_create(int device, pw_context** out) {
         snprintf(g_err, sizeof(g_err), "no usable HIP device (count=%d, requested %d)", n, device);
         return PW_E_NO_DEVICE;
     }
+    // PW_CONTEXT_TIMING=1: where the time of this call goes, one line on stderr (the cold start of a process is mostly
+    // this call: DESIGN.md section 6)
+    const bool ctx_timing = getenv("PW_CONTEXT_TIMING") && getenv("PW_CONTEXT_TIMING")[0] == '1';
+    timespec ct0;
+    clock_gettime(CLOCK_MONOTONIC, &ct0);
+    double ct_last = 0.0;
+    char ct_text[400] = "";
+    auto ct_mark = [&](const char* what) {
+        if (!ctx_timing) return;
+        timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        const double ms = (t.tv_sec - ct0.tv_sec) * 1e3 + (t.tv_nsec - ct0.tv_nsec) * 1e-6;
+        const size_t at = strlen(ct_text);
+        snprintf(ct_text + at, sizeof(ct_text) - at, " %s %.1f", what, ms - ct_last);
+        ct_last = ms;
+    };
     PW_ON_DEVICE(device);
+    ct_mark("device");
     pw_context* c = new (std::nothrow) pw_context();
     if (!c) return PW_E_NOMEM;
     memset(c, 0, sizeof(*c));
@@ -916,6 +934,7 @@ int pw_context_create(int device, pw_context** out) {
     CTX_TRY(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount;
     c->lds_per_cu = 160 * 1024;
+    ct_mark("properties");
     CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CTX_TRY(hipMalloc((void**)&c->counter, (4 * PW_SETS + 3) * sizeof(unsigned long long)));      // per set: chains | windows | average | basic; + 2 for single launches; + the gates' time-outs
     CTX_TRY(hipMemset(c->counter, 0, (4 * PW_SETS + 3) * sizeof(unsigned long long)));
@@ -965,6 +984,7 @@ int pw_context_create(int device, pw_context** out) {
         if (c->tail_pct < -1 || c->tail_pct > 100) c->tail_pct = 0;
     }
     c->need_fork = 1;
+    ct_mark("streams+events");
     CTX_TRY(hipEventCreate(&c->ev0));
     CTX_TRY(hipEventCreate(&c->ev1));
     CTX_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -1024,6 +1044,7 @@ int pw_context_create(int device, pw_context** out) {
                     q ? ", possibly exported after HIP was initialised" : "");
         }
     }
+    ct_mark("stream-probe");
     {
         unsigned* host = new (std::nothrow) unsigned[65536];
         if (!host) { pw_context_destroy(c); return PW_E_NOMEM; }
@@ -1035,6 +1056,7 @@ int pw_context_create(int device, pw_context** out) {
         delete[] host;
         if (e2 != hipSuccess) { set_err("rsqrt14 table upload", e2); pw_context_destroy(c); return PW_E_HIP; }
     }
+    ct_mark("rsqrt-table");
     {
         // the neighbour tables of the sampling sphere: 2.1 M rows of 40 bytes, built once (a few ms)
         const char* nb = getenv("PW_NB_TABLES");
@@ -1053,6 +1075,8 @@ int pw_context_create(int device, pw_context** out) {
         }
     }
 #undef CTX_TRY
+    ct_mark("neighbour-tables");
+    if (ctx_timing) fprintf(stderr, "pywindow_amd: pw_context_create, ms by leg:%s\n", ct_text);
     *out = c;
     return PW_OK;
 }
@@ -1100,6 +1124,7 @@ void pw_context_destroy(pw_context* c) {
     if (c->slots) (void)hipFree(c->slots);
     for (int b = 0; b < PW_SETS; ++b)
         if (c->prods[b]) (void)hipStreamDestroy(c->prods[b]);
+    if (c->rb_stream) (void)hipStreamDestroy(c->rb_stream);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c->mu;
@@ -1157,6 +1182,26 @@ int pw_internal_pool(pw_context* c, size_t bytes, void** out) {
     return PW_OK;
 }
 char* pw_internal_error_buffer(void) { return g_err; }
+
+// The stream of the periodic re-assembly (pw_rebuild.hip).  A trajectory goes through in pieces, and the re-assembly of
+// piece k + 1 runs while piece k is being analysed: on the API stream (normal priority) its teams -- 74 KB of LDS each --
+// stood in line behind the analysis' own and a launch that takes 1.5 ms alone took 5.6 (profiles/r06_periodic_*), with the
+// next analysis waiting for it.  On a stream of the highest priority its workgroups are placed first.  Every call on it
+// ends with a host synchronisation, so nothing else has to be ordered against it.  PW_RB_STREAM=0: the API stream.
+void* pw_internal_rebuild_stream(pw_context* c) {
+    if (!c || c->device < 0) return nullptr;
+    const char* e = getenv("PW_RB_STREAM");
+    if (e && e[0] == '0') return (void*)c->stream;
+    if (!c->rb_stream) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&c->rb_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+            c->rb_stream = nullptr;
+            return (void*)c->stream;
+        }
+    }
+    return (void*)c->rb_stream;
+}
 
 void* pw_context_stream(pw_context* c) { return c ? (void*)c->stream : nullptr; }
 

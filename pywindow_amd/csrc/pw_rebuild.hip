@@ -7,6 +7,7 @@
 // lists, visit stamps); the traversal itself is a chain of short dependent steps, so the
 // launch is sized for many concurrent frames rather than for wide teams.
 #include <hip/hip_runtime.h>
+#include <time.h>
 #include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
@@ -38,6 +39,9 @@ pw_rebuild_kernel(pw_cell_in in, pw_cell_out out, unsigned char* __restrict__ sl
     const int n = in.n_atoms;
     RebuildWs* w = RebuildWs::carve(slabs + (size_t)blockIdx.x * slab_bytes, n, in.rebuild, T::SIZE);
     w->attach_fast(fast, n, in.rebuild, with_bits != 0, with_scan != 0);
+    // (the walk is one wave's chain of dependent look-ups: beside the bulk waves of an analysis it must win the issue
+    // arbitration, like the optimiser chains -- the next piece's analysis waits for this launch)
+    __builtin_amdgcn_s_setprio(2);
     __syncthreads();
     for (;;) {
         if (threadIdx.x == 0) {
@@ -113,6 +117,7 @@ struct Buffers {
         }                                                                                  \
     } while (0)
 
+extern "C" void* pw_internal_rebuild_stream(pw_context* ctx);      // (pw_kernels.hip: highest priority, see there)
 extern "C" int pw_internal_resident_adopt(pw_context* ctx, long n_units, long n_atoms, int nmax, long* d_offset,
                                           double* d_xyz, double* d_vdw, double* d_mass, const size_t* part_bytes,
                                           pw_resident** out);
@@ -139,7 +144,7 @@ int rebuild_on_device(pw_context* ctx, const pw_cell_in* in, int atoms_cap, int 
     }
     if (in->lattice && !in->lattice_inv) return PW_E_BAD_ARG;
     // (the callers -- the two entry points below -- have made the context's device current)
-    hipStream_t st = (hipStream_t)pw_context_stream(ctx);
+    hipStream_t st = (hipStream_t)pw_internal_rebuild_stream(ctx);
     const long F = (long)in->n_frames;
     const int n = in->n_atoms;
     hipDeviceProp_t prop;
@@ -295,11 +300,11 @@ extern "C" int pw_discrete_molecules(pw_context* ctx, const pw_cell_in* in, cons
     RB_TRY(dev_scope_.enter(pw_context_device(ctx)));
     Buffers buf;
     buf.ctx = ctx;
-    buf.st = (hipStream_t)pw_context_stream(ctx);
+    buf.st = (hipStream_t)pw_internal_rebuild_stream(ctx);
     DeviceCells dev;
     int rc = rebuild_on_device(ctx, in, out->atoms_cap, out->mols_cap, buf, &dev);
     if (rc != PW_OK) return rc;
-    hipStream_t st = (hipStream_t)pw_context_stream(ctx);
+    hipStream_t st = (hipStream_t)pw_internal_rebuild_stream(ctx);
     const long F = (long)in->n_frames;
     RB_TRY(hipMemcpyAsync(out->n_mol, dev.n_mol, sizeof(int) * F, hipMemcpyDeviceToHost, st));
     RB_TRY(hipMemcpyAsync(out->status, dev.status, sizeof(int) * F, hipMemcpyDeviceToHost, st));
@@ -324,13 +329,25 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
         return PW_E_NO_DEVICE;
     }
     RB_TRY(dev_scope_.enter(pw_context_device(ctx)));
+    // PW_RB_TIMING=1: the host-side legs of this call on stderr (ms): queued = uploads and the re-assembly launch queued,
+    // rebuilt = that launch and the scan finished (first wait), gathered = the ragged batch built (second wait), adopted
+    const bool rb_timing = getenv("PW_RB_TIMING") && getenv("PW_RB_TIMING")[0] == '1';
+    timespec rt0;
+    clock_gettime(CLOCK_MONOTONIC, &rt0);
+    double rt[4] = {0, 0, 0, 0};
+    auto rt_mark = [&](int k) {
+        timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        rt[k] = (t.tv_sec - rt0.tv_sec) * 1e3 + (t.tv_nsec - rt0.tv_nsec) * 1e-6;
+    };
     Buffers buf;
     buf.ctx = ctx;
-    buf.st = (hipStream_t)pw_context_stream(ctx);
+    buf.st = (hipStream_t)pw_internal_rebuild_stream(ctx);
     DeviceCells dev;
     int rc = rebuild_on_device(ctx, in, atoms_cap, mols_cap, buf, &dev);
     if (rc != PW_OK) return rc;
-    hipStream_t st = (hipStream_t)pw_context_stream(ctx);
+    rt_mark(0);
+    hipStream_t st = (hipStream_t)pw_internal_rebuild_stream(ctx);
     const long F = (long)in->n_frames;
     const int n = in->n_atoms;
     long *d_ubase, *d_abase;
@@ -350,6 +367,7 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
     RB_TRY(hipMemcpyAsync(&totals[0], d_ubase + F, sizeof(long), hipMemcpyDeviceToHost, st));
     RB_TRY(hipMemcpyAsync(&totals[1], d_abase + F, sizeof(long), hipMemcpyDeviceToHost, st));
     RB_TRY(hipStreamSynchronize(st));
+    rt_mark(1);
     buf.synced = true;             // (until the gather below is queued)
     for (long f = 0; f < F; ++f)
         if (status[f] & (PW_RB_ATOMS_OVERFLOW | PW_RB_MOLS_OVERFLOW)) {
@@ -391,9 +409,14 @@ extern "C" int pw_resident_from_cells(pw_context* ctx, const pw_cell_in* in, con
     int nmax = 0;
     RBF_TRY(hipMemcpyAsync(&nmax, d_nmax, sizeof(int), hipMemcpyDeviceToHost, st));
     RBF_TRY(hipStreamSynchronize(st));
+    rt_mark(2);
     buf.synced = true;
 #undef RBF_TRY
     rc = pw_internal_resident_adopt(ctx, U, A, nmax, d_offset, d_xyz, d_uv, d_um, part_bytes, res);
     if (rc != PW_OK) drop();
+    rt_mark(3);
+    if (rb_timing)
+        fprintf(stderr, "pywindow_amd: pw_resident_from_cells %ld frames: queued %.2f rebuilt %.2f gathered %.2f adopted %.2f ms\n", F,
+                rt[0], rt[1] - rt[0], rt[2] - rt[1], rt[3] - rt[2]);
     return rc;
 }

@@ -28,10 +28,11 @@ from .records import LazyAnalysis, RecordStore
 
 #: most frames a modular analysis pushes through the device in one piece (see Trajectory._run_modular)
 MODULAR_CHUNK = 8192
-#: ... a long one in pieces of MODULAR_PIECE frames, up to MODULAR_IN_FLIGHT of them analysed while the next is
-#: being read and re-assembled
+#: ... a long one in pieces of MODULAR_PIECE frames, MODULAR_GROUP pieces to a group: a group's pieces are re-assembled
+#: one after the other with the device to themselves (each while the reader decodes the next), then analysed back to back
 MODULAR_PIECE = 512
-MODULAR_IN_FLIGHT = 2
+MODULAR_GROUP = 16
+MODULAR_IN_FLIGHT = 2      # (until round 5: pieces analysed while the next was re-assembled; PW_MODULAR_GROUP=0 is that schedule)
 #: a plain analysis goes through in ONE piece up to 2 x RUN_PIECE frames and in pieces of RUN_PIECE beyond (what
 #: bounds the device memory of a very long trajectory; see DLPOLY._run for why not smaller)
 RUN_PIECE = 16384
@@ -476,20 +477,36 @@ class DLPOLY:
             return np.zeros(0, dtype=_lib.UNIT_OUT_DTYPE), np.zeros(0, np.int64), np.zeros(0, np.int64)
         if rebuild and not self.periodic:
             raise KeyError("lattice")   # create_supercell needs the cell (utilities.py:776-779)
-        ids = element_ids(el)
-        topo = rb.CellTopology(el)
-        vdw = VDW[ids]
+        # (per-atom constants of the trajectory: the same for every call with the same elements)
+        key = np.asarray(el).tobytes()
+        cached = getattr(self, "_topology", None)
+        if cached is None or cached[0] != key:
+            ids = element_ids(el)
+            cached = self._topology = (key, rb.CellTopology(el), np.ascontiguousarray(VDW[ids]))
+        topo, vdw = cached[1], cached[2]
         dev = engine.resolve_device(device)
 
         # frames -> molecules -> units without leaving the device: every molecule of every frame of a
         # piece is one unit of ONE analysis launch.  Long trajectories go through in pieces (the frames
         # and the re-assembled molecules of a piece are resident on the device at once; each piece is two
-        # launches); the analysis launch of a piece is asynchronous, so the next piece is tokenised on the
-        # host -- and re-assembled on the device -- while the previous one is still being analysed.  At most
-        # MODULAR_IN_FLIGHT pieces wait for their download.
+        # launches), and the pieces in GROUPS: first every piece of a group is re-assembled -- the device to itself,
+        # piece k on the device while the reader's threads decode piece k + 1 -- then the group's analyses are
+        # launched back to back (different batches: nothing paces them) and collected.  Until round 5 the analysis of
+        # piece k was launched at once and piece k + 1 re-assembled beside it: a re-assembly team needs 74 KB of LDS
+        # and cannot be placed while the analysis' persistent teams hold the CUs -- the launch that takes 1.9 ms alone
+        # (512 frames, copy included) took 6 beside an analysis, on a stream of the highest priority as on the API
+        # stream, and the next analysis waited for it (profiles/r06_periodic_*: 1024 frames 19.6 -> 16 ms, 10 000 frames
+        # 205 -> 125 ms).  PW_MODULAR_GROUP=0: the old schedule (MODULAR_IN_FLIGHT pieces waiting for their download).
         ctx = engine.context(dev)
         n = len(frames)
-        piece = MODULAR_CHUNK if n < 2 * MODULAR_PIECE else min(MODULAR_CHUNK, MODULAR_PIECE)
+        import os as _os
+
+        m_piece = int(_os.environ.get("PW_MODULAR_PIECE", MODULAR_PIECE))
+        m_flight = int(_os.environ.get("PW_MODULAR_IN_FLIGHT", MODULAR_IN_FLIGHT))
+        m_group = int(_os.environ.get("PW_MODULAR_GROUP", MODULAR_GROUP))
+        piece = MODULAR_CHUNK if n < 2 * m_piece else min(MODULAR_CHUNK, m_piece)
+        if -(-n // piece) < 4:
+            m_group = 0          # (two or three pieces: the analysis of the first beside the re-assembly of the second wins)
         parts, waiting, spent = [], [], []
         # host-side legs, milliseconds: waiting for the reader (it runs on a helper thread beside the device work), the
         # re-assembly call (copies up, rebuild launch, its wait, the on-device hand-over), queueing the analysis,
@@ -554,14 +571,27 @@ class DLPOLY:
                 res, n_mol = ctx.resident_from_cells(topo, vdw, coords, lat, inv, rebuild)
                 t2 = clock()
                 waiting.append((res, n_mol))
-                if res is not None:
-                    res.launch(_lib.STAGE_ALL)
                 timing["tokenise_wait_ms"] += 1e3 * (t1 - t0)
                 timing["rebuild_ms"] += 1e3 * (t2 - t1)
-                timing["launch_ms"] += 1e3 * (clock() - t2)
                 timing["pieces"] += 1
-                if len(waiting) > MODULAR_IN_FLIGHT:
-                    collect()
+                if m_group <= 0:
+                    # (the schedule of rounds 1-5: analysed at once, the next piece re-assembled beside it)
+                    if res is not None:
+                        res.launch(_lib.STAGE_ALL)
+                    timing["launch_ms"] += 1e3 * (clock() - t2)
+                    if len(waiting) > m_flight:
+                        collect()
+                    continue
+                if len(waiting) >= m_group or k + 1 == len(starts):
+                    # the group is re-assembled: its analyses, back to back; they are collected before the next group's
+                    # first re-assembly is queued (the reader goes on decoding the next piece meanwhile)
+                    for r_, _ in waiting:
+                        if r_ is not None:
+                            r_.launch(_lib.STAGE_ALL)
+                    timing["launch_ms"] += 1e3 * (clock() - t2)
+                    timing["groups"] = timing.get("groups", 0) + 1
+                    while waiting:
+                        collect()
             while waiting:
                 collect()
         finally:
@@ -571,13 +601,16 @@ class DLPOLY:
                 if res is not None:
                     res.free()
             ctx.lock.release()
-        recs = np.concatenate([p[0] for p in parts])
+        # (the records as bytes: numpy copies a structured array field by field, a byte array with memcpy)
+        recs = parts[0][0] if len(parts) == 1 else np.concatenate(
+            [np.ascontiguousarray(p[0]).view(np.uint8).reshape(-1) for p in parts]).view(_lib.UNIT_OUT_DTYPE)
         engine.raise_on_uncomputable(recs)
         self._extra = np.concatenate(extras) if extras else np.zeros(0, dtype=_lib.EXTRA_WINDOW_DTYPE)
-        n_mol = np.concatenate([p[1] for p in parts])
+        n_mol = np.concatenate([p[1] for p in parts]).astype(np.int64)
         unit_frame = np.repeat(np.asarray(frames, np.int64), n_mol)
-        unit_mol = (np.concatenate([np.arange(k) for k in n_mol]).astype(np.int64) if len(n_mol)
-                    else np.zeros(0, np.int64))
+        # molecule index inside its frame: 0 .. n_mol[f] - 1 (position in the batch minus the frame's first unit)
+        first = np.cumsum(n_mol) - n_mol
+        unit_mol = np.arange(int(n_mol.sum()), dtype=np.int64) - np.repeat(first, n_mol)
         return recs, unit_frame, unit_mol
 
     def _analysis_modular(self, frames, override, rebuild, swap_atoms, forcefield, device, distributed, lazy=False):

@@ -9,7 +9,7 @@
 import numpy as np
 import pytest
 
-from _util import GOLDEN, LIVE_TOL_WINDOW, rel
+from _util import GOLDEN, LIVE_TOL_WINDOW, ROOT, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -136,3 +136,46 @@ def test_full_unit_counts_in_one_launch(hip_ctx, units, label):
     pick = np.sort(rng.choice(units, 256, replace=False))
     small = hip_ctx.analyse(_lib.Batch.uniform(coords[pick], vdw, mass))
     assert small.tobytes() == recs[pick].tobytes(), label
+
+
+def test_config4_ten_thousand_frame_file_on_one_gpu(hip_ctx, monkeypatch):
+    """BASELINE configs[3] at its full length through the FILE path on one GPU (round-5 review: the file path had only
+    run at 1024 frames): a 10 000-frame periodic HISTORY (8 CC3 cages / 1344 atoms per cell; 64 distinct noisy frames
+    cycled -- 1.08 GB of text in shared memory, written in a quarter of a second) tokenised, re-assembled and analysed
+    by DLPOLY.modular_records(rebuild=True) in twenty pieces.  Every cage status 0 with its four windows; the first
+    1024 frames byte-identical to the same frames analysed on their own (two pieces, the interleaved schedule); and,
+    the frames being a cycle of 64, every block of 64 frames byte-identical to the first -- 156 independent repetitions
+    of the same 512 analyses in other pieces, beside other neighbours."""
+    import os
+    import tempfile
+
+    import pywindow_amd as pw
+    from pywindow_amd import synth
+
+    g = np.load(ROOT / "tests" / "golden" / "rebuild.npz")
+    el, xyz, lat = g["cc3_cell__in_elements"], g["cc3_cell__in_coordinates"], g["cc3_cell__in_lattice"]
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    frames = 10_000
+    with tempfile.TemporaryDirectory(dir=base) as tmp:
+        path = os.path.join(tmp, "HISTORY_periodic")
+        distinct = [xyz + np.random.default_rng(4 + k).normal(0.0, 0.02, size=xyz.shape) for k in range(64)]
+        synth.write_history_cycled(path, el, distinct, frames, cell=np.asarray(lat, float).T)
+        traj = pw.DLPOLY(path)
+        assert (traj.no_of_frames, traj.no_of_atoms) == (frames, 1344)
+        recs, uframe, umol = traj.modular_records("all", rebuild=True)
+        legs = dict(traj.last_timings)
+        assert legs["pieces"] == 20 and legs.get("groups", 0) >= 1, legs
+        assert len(recs) == 8 * frames
+        assert np.array_equal(uframe, np.repeat(np.arange(frames), 8)) and np.array_equal(umol, np.tile(np.arange(8), frames))
+        assert (recs["status"] == 0).all() and (recs["n_atoms"] == 168).all()
+        assert (recs["n_windows"] == 4).sum() > 0.99 * len(recs)
+        head, _, _ = traj.modular_records(list(range(1024)), rebuild=True)
+        assert traj.last_timings["pieces"] == 2
+        assert head.tobytes() == recs[: 8 * 1024].tobytes()
+        block = recs[: 8 * 64].tobytes()
+        for k in range(1, frames // 64):
+            assert recs[8 * 64 * k: 8 * 64 * (k + 1)].tobytes() == block, k
+        # the schedule of rounds 1-5 (every piece analysed at once, the next re-assembled beside it): the same bytes
+        monkeypatch.setenv("PW_MODULAR_GROUP", "0")
+        old, _, _ = traj.modular_records(list(range(3072)), rebuild=True)
+        assert old.tobytes() == recs[: 8 * 3072].tobytes()

@@ -9,7 +9,7 @@
 #   4. kernel trace of four overlapped analyses                           -> overlapped_timeline.txt
 #   5. --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes)               -> hbm_traffic.json
 #   6. --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU            -> instruction_counters.json
-tag=${1:-r04}
+tag=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/$tag
 mkdir -p $O
@@ -33,6 +33,10 @@ cp $(find $O/pw -name "*counter_collection.csv" | head -1) $O/pmc_write_size.csv
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU -d $O/pv -o pv --output-format csv -- python3 $T/run_stage.py 15 1000 4 > $O/pv.log 2>&1
 cp $(find $O/pv -name "*counter_collection.csv" | head -1) $O/pmc_instruction_counters.csv
 python3 $T/counter_summary.py $O/pmc_instruction_counters.csv 1000 $O/instruction_counters.json > /dev/null
+# 6b. what the vector ALUs execute in double precision (round-5 review, item 2): FMA / MUL / ADD / TRANS F64 wave instructions
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 -d $O/p6 -o p6 --output-format csv -- python3 $T/run_stage.py 15 1000 4 > $O/p6.log 2>&1
+cp $(find $O/p6 -name "*counter_collection.csv" | head -1) $O/pmc_fp64_counters.csv
+python3 $T/fp64_summary.py $O/pmc_fp64_counters.csv 1000 $O/fp64_counters.json > /dev/null
 # 7. what the scratch frames cost: scratch / flat instruction counts and the cycles waves spend waiting, per launch
 #    (round-4 review item 4: "a counter experiment that prices it")
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_FLAT SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -d $O/ps -o ps --output-format csv -- python3 $T/run_stage.py 15 1000 4 > $O/ps.log 2>&1
@@ -46,7 +50,7 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/bg -o bg --output-format csv 
 cp $(find $O/bg -name "*kernel_stats.csv" | head -1) $O/big_kernel_stats.csv
 # 9. HISTORY file -> records: streamed against one piece
 timeout 300 python3 $T/e2e_stream.py > $O/e2e_stream.txt 2>&1
-rm -rf $O/ov $O/se $O/tl $O/pf $O/pw $O/pv $O/ps $O/pq $O/bg
+rm -rf $O/ov $O/se $O/tl $O/pf $O/pw $O/pv $O/p6 $O/ps $O/pq $O/bg
 ls -la $O
 # 10. where these numbers come from: commit (.pw_head, written by `provenance.py stamp` before gpurun), date, hash of csrc/*
-python3 $T/provenance.py annotate $O/hbm_traffic.json $O/instruction_counters.json $O/scratch_counters.json $O/wait_counters.json $O/serial_kernel_stats.csv $O/overlapped_kernel_stats.csv $O/big_kernel_stats.csv > $O/provenance.json
+python3 $T/provenance.py annotate $O/hbm_traffic.json $O/instruction_counters.json $O/fp64_counters.json $O/scratch_counters.json $O/wait_counters.json $O/serial_kernel_stats.csv $O/overlapped_kernel_stats.csv $O/big_kernel_stats.csv > $O/provenance.json
