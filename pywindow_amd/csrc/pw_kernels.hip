@@ -1071,7 +1071,8 @@ int pw_context_create(int device, pw_context** out) {
             hipLaunchKernelGGL(pw_nb_build_kernel, dim3(PW_NB_PMAX - PW_NB_PMIN + 1), dim3(256), 0, c->stream, c->nb_off,
                                c->nb_idx, c->nb_bound, c->nb_unit);
             CTX_TRY(hipGetLastError());
-            CTX_TRY(hipStreamSynchronize(c->stream));
+            // (no wait: the kernel takes 8 ms and the first thing to read the tables is an analysis launch, which is
+            // ordered behind everything on the API stream -- need_fork below, and single launches run on that stream)
         }
     }
 #undef CTX_TRY
