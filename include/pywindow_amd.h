@@ -302,7 +302,8 @@ void pw_resident_free(pw_context *ctx, pw_resident *res);
  * writes the average milliseconds per launch. */
 int pw_resident_time(pw_context *ctx, pw_resident *res, uint32_t stages, int iters, float *ms_per_launch);
 /* one analysis on its own, timed per launch of the pipeline with HIP events on the launch's own
- * stream: ms[0] optimiser chains, ms[1] average diameter, ms[2] window search (measurement only) */
+ * stream: ms[0] optimiser chains, ms[1] average diameter (0: since round 6 that stage runs inside the window teams
+ * unless PW_B_LAUNCH=1 asks for its own launch), ms[2] window search (measurement only) */
 int pw_resident_stage_times(pw_context *ctx, pw_resident *res, float *ms3);
 /* raw device pointer of the result records (for RCCL gathers by the host side) */
 void *pw_resident_device_results(pw_resident *res);

@@ -853,11 +853,15 @@ class Resident:
         return float(ms.value)
 
     def stage_times(self) -> dict:
-        """Milliseconds of the three launches of ONE analysis run on its own (HIP events on each
-        launch's stream): ``{"chains", "average", "windows"}``."""
+        """Milliseconds of the launches of ONE analysis run on its own (HIP events on each launch's stream):
+        ``{"chains", "windows"}`` -- the average diameter is a stage of the window teams -- or, with ``PW_B_LAUNCH=1``,
+        ``{"chains", "average", "windows"}`` (the three launches of rounds 1-5)."""
         ms = (ctypes.c_float * 3)()
         _check(load().pw_resident_stage_times(self.ctx._h, self._h, ms), "pw_resident_stage_times")
-        return {"chains": float(ms[0]), "average": float(ms[1]), "windows": float(ms[2])}
+        out = {"chains": float(ms[0]), "windows": float(ms[2])}
+        if ms[1] > 0.0:
+            out["average"] = float(ms[1])
+        return out
 
     @property
     def device_results_ptr(self) -> int:

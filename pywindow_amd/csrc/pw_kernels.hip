@@ -78,6 +78,8 @@ constexpr unsigned MASK_ANY = 0xffffffffu;
 constexpr unsigned MASK_CHAINS = PW_STAGE_BASIC | PW_STAGE_OPT | PW_STAGE_MERGE;
 constexpr unsigned MASK_AVERAGE = PW_STAGE_AVG | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
 constexpr unsigned MASK_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | PW_STAGE_MERGE | PW_STAGE_COM_ONLY;
+// ... and the window launch that runs the average-diameter stage as well (round 6: the pipeline's default)
+constexpr unsigned MASK_WINDOWS_AVG = MASK_WINDOWS | PW_STAGE_AVG;
 
 // Neighbour tables of the sampling sphere, one block per vector count P (pw_unit.hpp: nb_build_point): the
 // P unit vectors go to LDS, every thread tabulates the rows of its points.
@@ -540,6 +542,7 @@ struct pw_context {
     hipEvent_t ev_ext;       // ordering against a caller's stream (pw_resident_results_ready)
     hipEvent_t ev_t[3][2];   // pw_resident_stage_times: start / stop of the chains, average and window launches
     int timing;              // record them during the next pipeline launch
+    int timed_avg;           // ... and whether that launch had an average-diameter launch of its own (else the stage ran in the window teams)
     pw_unit_debug* dbg;      // per-unit stage capture of the current debug analysis, else null
     hipStream_t rb_stream;   // the periodic re-assembly's own stream, highest priority (pw_internal_rebuild_stream), created on first use
     void* pool;              // device scratch kept between calls (the team slabs of the periodic re-assembly)
@@ -801,6 +804,8 @@ static int launch_plan(pw_context* c, pw_resident* r, unsigned stages, const Lau
         return launch_nw<4, MASK_AVERAGE>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
     if (stages == MASK_WINDOWS && p.nw == 4)
         return launch_nw<4, MASK_WINDOWS>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
+    if (stages == MASK_WINDOWS_AVG && p.nw == 4)
+        return launch_nw<4, MASK_WINDOWS_AVG>(c, r, stages, p, st, ws_first, adj_first, counter_slot, role, reset_counter);
     // single launches: one wave per unit for the stages the chains kernel holds (basic, optimised pore), the general
     // four-wave kernel for everything else
     if (p.nw == 1 && (stages & ~MASK_CHAINS) == 0)
@@ -1368,6 +1373,15 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
         if (getenv("PW_PLAN_DEBUG")) fprintf(stderr, "plan A: grid %d lds %zu\n", pa.grid, pa.lds);
     }
     bool do_avg = (stages & PW_STAGE_AVG) != 0;
+    // Round 6: the average diameter is a stage of the WINDOW teams (before the window search of the unit they have just
+    // taken), not a launch of its own.  Its teams -- four waves, one per SIMD of a CU, 96 of them persistent -- took the
+    // four wave slots of their CU that the optimiser chains live on (two 256-register waves fill a SIMD, and a
+    // 168-register wave beside one leaves no room for a second), i.e. 384 of the chip's 1024 chain slots, busy or not;
+    // as a stage of the window teams the same work needs no slots of its own and a fifth more window teams fit
+    // (1000 units 1.16 -> 1.13 ms per step, 4000 units 4.41 -> 4.13 ms, 500 units 0.91 -> 0.64:
+    // profiles/r06_avg_in_window_teams.txt).  PW_B_LAUNCH=1: the separate launch of rounds 1-5.
+    bool avg_in_c = false;
+    if (do_avg && !(getenv("PW_B_LAUNCH") && getenv("PW_B_LAUNCH")[0] == '1')) { avg_in_c = true; do_avg = false; }
     pb.grid = 0;
     if (do_avg) {
         // one frame; the optimiser-state slots are this launch's scratch arena: 7 (51 KB) hold the ray vectors and
@@ -1386,7 +1400,14 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
     // larger batches want every team the LDS admits (4000 units: 9.2 ms against 10.0).
     // (round 5, after the optimiser chains got a third faster: beyond that, five teams per four CUs -- 4000 units 4.80 ms
     // against 5.14 with two per CU, 8192: 9.41 / 10.1, 20 000: 22.8 / 24.3; profiles/r05_resweep.txt)
-    if (r->n_units <= 6L * c->n_cu && pc.grid > c->n_cu) pc.grid = c->n_cu;
+    if (avg_in_c) {
+        // (with the average-diameter teams gone: five window teams per four CUs up to 1500 units -- 1000 units 1.126 ms with
+        // 320 teams, 1.163 with 304, 1.187 with 288, 1.127 with 352 -- eleven per eight CUs beyond: 4000 units 4.13 ms with
+        // 352 teams, 4.27 with 320, 4.31 with 384; small batches one team per two units)
+        const long cap = r->n_units <= 6L * c->n_cu ? c->n_cu + c->n_cu / 4 : c->n_cu + (3 * c->n_cu) / 8;
+        if (pc.grid > cap) pc.grid = (int)cap;
+        if (r->n_units <= 300 && pc.grid > (r->n_units + 1) / 2) pc.grid = (int)((r->n_units + 1) / 2);
+    } else if (r->n_units <= 6L * c->n_cu && pc.grid > c->n_cu) pc.grid = c->n_cu;
     else if (pc.grid > c->n_cu + c->n_cu / 4) pc.grid = c->n_cu + c->n_cu / 4;
     // ... and the average-diameter launch, a fifth of the window search's work, gets by with one team
     // per two CUs whatever the batch (1000 units: 1.84 -> 1.79 ms, 500: 1.28 -> 1.20; 4000: 6.59 -> 6.53)
@@ -1554,8 +1575,8 @@ int pw_resident_launch(pw_context* c, pw_resident* r, uint32_t stages) {
             HIP_TRY(hipStreamWaitEvent(cs, c->ev_done[p], 0));
         }
     }
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][0], cs));
-    rc = launch_plan(c, r, MASK_WINDOWS, pc, cs, ws_c, b * c->max_c, PW_SETS + b, PW_ROLE_CONSUMER, false);
+    if (c->timing) { c->timed_avg = do_avg ? 1 : 0; HIP_TRY(hipEventRecord(c->ev_t[2][0], cs)); }
+    rc = launch_plan(c, r, avg_in_c ? MASK_WINDOWS_AVG : MASK_WINDOWS, pc, cs, ws_c, b * c->max_c, PW_SETS + b, PW_ROLE_CONSUMER, false);
     if (rc != PW_OK) return rc;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t[2][1], cs));
     if (do_avg) {
@@ -2126,7 +2147,10 @@ int pw_resident_stage_times(pw_context* c, pw_resident* r, float* ms) {
     c->timing = 0;
     if (rc == PW_OK) rc = pw_resident_sync(c);
     if (rc != PW_OK) return rc;
-    for (int k = 0; k < 3; ++k) HIP_TRY(hipEventElapsedTime(&ms[k], c->ev_t[k][0], c->ev_t[k][1]));
+    for (int k = 0; k < 3; ++k) {
+        if (k == 1 && !c->timed_avg) { ms[k] = 0.f; continue; }      // (no launch of its own: a stage of the window teams)
+        HIP_TRY(hipEventElapsedTime(&ms[k], c->ev_t[k][0], c->ev_t[k][1]));
+    }
     return PW_OK;
 }
 

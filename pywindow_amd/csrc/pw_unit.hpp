@@ -4004,6 +4004,18 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
         if (KMASK == PW_KERNEL_AVERAGE) stage_average_impl<T, true>(sh, ws, n, out, prm);
         else stage_average<T>(sh, ws, n, out, prm);
         if (T::wave() == 0) PW_T1(ws, 13, t_a);
+        if ((stages & PW_STAGE_WINDOWS) && sh.S.x == sh.A.x) {
+            // A team that keeps ONE frame has just shifted it in place (to the centre of mass) and the window search
+            // shifts the INPUT frame (to the pore centre): the coordinates come in again -- the scatter of load_unit,
+            // the grouping is kept -- instead of every window team of the pipeline carrying a second frame (5 KB of LDS)
+            for (int i = T::tid(); i < n; i += T::SIZE) {
+                const int pos = sh.inv[i];
+                const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+                sh.A.x[pos] = x; sh.A.y[pos] = y; sh.A.z[pos] = z;
+                sh.A.xx[pos] = sq3(x, y, z);
+            }
+            T::sync();
+        }
     }
     if (stages & PW_STAGE_WINDOWS) {
         if (!(prm.pore_opt && (sh.v->status & PW_ST_NEGATIVE_PORE))) {

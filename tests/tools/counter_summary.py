@@ -17,7 +17,8 @@ for r in csv.DictReader(open(path)):
 kernels, total = {}, defaultdict(float)
 for key, vals in sorted(acc.items()):
     name = ("A optimiser chains (1 wave/unit)" if key[1] == 64 else
-            "C window search" if key[2] == 120 else "B average diameter" if key[2] == 98 else f"<{key[1] // 64}, {key[2]}>")
+            "C window search" if key[2] == 120 else "C window search + average diameter" if key[2] == 122 else
+            "B average diameter" if key[2] == 98 else f"<{key[1] // 64}, {key[2]}>")
     row = {"grid": key[0], "workgroup": key[1]}
     # A counter pass serialises the kernels of the process: a consumer launch dispatched ahead of its producer then finds
     # no units, waits out its time limit and retires a few thousand instructions (seen once in round 4, once in round 5:

@@ -18,7 +18,7 @@ for r in csv.DictReader(open(path)):
         continue
     m = re.search(r"pw_analyse_kernel<(\d+), (\d+)u?>", r["Kernel_Name"])
     acc[(int(r["Workgroup_Size"]), int(m.group(2)) if m else -1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
-names = {37: "chains", 98: "average", 120: "windows"}
+names = {37: "chains", 98: "average", 120: "windows", 122: "windows+average"}
 kernels, total = {}, defaultdict(float)
 for key, vals in sorted(acc.items()):
     name = names.get(key[1], "<%d, %d>" % (key[0] // 64, key[1]))

@@ -25,6 +25,8 @@ for key, vals in sorted(acc.items()):
         name = roles[64]
     elif key[2] == 120:
         name = "C window search (4 waves/unit, persistent consumer)"
+    elif key[2] == 122:
+        name = "C window search + average diameter (4 waves/unit, persistent consumer)"
     elif key[2] == 98:
         name = "B average diameter (4 waves/unit)"
     else:
