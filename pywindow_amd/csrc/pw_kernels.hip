@@ -156,7 +156,7 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
                   int nmax, int nrot, int nlb, int nframes, int lean, PwWsArgs wsa, unsigned long long* counter,
                   pw_unit_out* __restrict__ out, int role, UnitQueue* queue, int* __restrict__ slots,
                   pw_params prm_in, const unsigned* __restrict__ rsq_tab, int vstride,
-                  const unsigned long long* __restrict__ ready) {
+                  const unsigned long long* __restrict__ ready, const unsigned char* __restrict__ tmpl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ long s_unit;
     // the team's table of pointers and its parameters live in LDS (PW_TEAM_STATE_IN_LDS, pw_unit.hpp): the stage
@@ -249,7 +249,8 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
         // vstride 0: one molecule type, vdw / mass hold a single template (per-trajectory constants)
         const long v0 = a0 * vstride;
         if (threadIdx.x == 0) ws->unit = u;     // (read by the debug capture only; ordered by load_unit's barrier)
-        analyse_unit<T, MASK>(sh, ws, n, xyz + 3 * a0, vdw + v0, mass + v0, stages & MASK, out + u, prm);
+        // (tmpl: the radius groups of a one-molecule-type batch, worked out once on the host -- pw_unit.hpp: load_unit)
+        analyse_unit<T, MASK>(sh, ws, n, xyz + 3 * a0, vdw + v0, mass + v0, stages & MASK, out + u, prm, vstride == 0 ? tmpl : nullptr);
         if (role == PW_ROLE_PRODUCER) {
             // analyse_unit ended with a team barrier; thread 0 wrote the record
             if (threadIdx.x == 0) {
@@ -606,6 +607,7 @@ struct pw_resident {
     double* d_xyz;
     double* d_vdw;
     double* d_mass;
+    unsigned char* d_tmpl;   // one molecule type: the radius groups of the template (pw_unit.hpp: template_groups_build), else null
     void* block;             // one device block holds every array of an uploaded batch (from the context's cache)
     size_t block_bytes;
     void* parts[5];          // ... or, for a batch assembled on the device (pw_resident_from_cells), one block per array
@@ -757,6 +759,11 @@ static int plan_launch(pw_context* c, long n_units, int nmax, int want_nw, bool 
     return PW_OK;
 }
 
+// PW_TEMPLATE_GROUPS=0: every unit works its radius groups out itself, as until round 5 (A/B comparisons)
+static bool template_groups_on() {
+    static const bool on = !(getenv("PW_TEMPLATE_GROUPS") && getenv("PW_TEMPLATE_GROUPS")[0] == '0');
+    return on;
+}
 template <int NW, unsigned MASK>
 static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const LaunchPlan& p, hipStream_t st,
                      int ws_first, int adj_first, int counter_slot, int role, bool reset_counter) {
@@ -790,7 +797,7 @@ static int launch_nw(pw_context* c, pw_resident* r, unsigned stages, const Launc
     hipLaunchKernelGGL(kern, dim3(p.grid), dim3(NW * 64), p.lds, st, r->n_units, r->d_offset,
                        r->d_xyz, r->d_vdw, r->d_mass, stages, r->nmax, p.nrot, p.nlb, p.nframes, p.lean, wsa,
                        c->counter + counter_slot, r->d_out, role, c->cur_queue, c->cur_slots, c->prm, c->rsq_tab,
-                       r->vstride, (const unsigned long long*)r->d_ready);
+                       r->vstride, (const unsigned long long*)r->d_ready, (const unsigned char*)(template_groups_on() ? r->d_tmpl : nullptr));
     HIP_TRY(hipGetLastError());
     return PW_OK;
 }
@@ -1697,8 +1704,9 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
         const size_t b_off = up256(sizeof(long) * (size_t)(r->n_units + 1)), b_xyz = up256(sizeof(double) * 3 * (size_t)natoms);
         const size_t b_con = up256(sizeof(double) * (size_t)nconst);
         const size_t b_out = up256((size_t)r->nbuf * sizeof(pw_unit_out) * (size_t)r->n_units + 64);
+        const size_t b_tmpl = in->template_atoms > 0 ? up256(template_groups_bytes(nmax)) : 0;
         {
-            int rcb = block_take(c, b_off + b_xyz + 2 * b_con + b_out, &r->block, &r->block_bytes);
+            int rcb = block_take(c, b_off + b_xyz + 2 * b_con + b_tmpl + b_out, &r->block, &r->block_bytes);
             if (rcb != PW_OK) { pw_resident_free(c, r); return rcb; }
         }
         unsigned char* base = (unsigned char*)r->block;
@@ -1706,6 +1714,12 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
         r->d_xyz = (double*)base; base += b_xyz;
         r->d_vdw = (double*)base; base += b_con;
         r->d_mass = (double*)base; base += b_con;
+        std::vector<unsigned char> tmpl_host;
+        if (b_tmpl) {
+            r->d_tmpl = base; base += b_tmpl;
+            tmpl_host.resize(template_groups_bytes(nmax));
+            template_groups_build(in->vdw, nmax, tmpl_host.data());
+        }
         r->d_outs[0] = (pw_unit_out*)base;
         for (int k = 1; k < r->nbuf; ++k) r->d_outs[k] = r->d_outs[0] + (size_t)k * r->n_units;
         r->d_xw_count = (unsigned*)(r->d_outs[0] + (size_t)r->nbuf * r->n_units);   // (extra-window counters)
@@ -1720,6 +1734,7 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
                               c->stream));
         UP_TRY(hipMemcpyAsync(r->d_mass, in->mass, sizeof(double) * nconst, hipMemcpyHostToDevice,
                               c->stream));
+        if (r->d_tmpl) UP_TRY(hipMemcpyAsync(r->d_tmpl, tmpl_host.data(), tmpl_host.size(), hipMemcpyHostToDevice, c->stream));
         UP_TRY(hipMemsetAsync(r->d_outs[0], 0, r->nbuf * sizeof(pw_unit_out) * r->n_units + 64, c->stream));
         UP_TRY(hipStreamSynchronize(c->stream));
     }
@@ -1763,13 +1778,17 @@ int pw_resident_stream_begin(pw_context* c, int64_t n_units, int64_t template_at
     const size_t b_off = up256(sizeof(long) * (size_t)(r->n_units + 1)), b_xyz = up256(sizeof(double) * 3 * (size_t)r->n_atoms);
     const size_t b_con = up256(sizeof(double) * (size_t)template_atoms);
     const size_t b_out = up256((size_t)r->nbuf * sizeof(pw_unit_out) * (size_t)r->n_units + 64);
-    int rcb = block_take(c, b_off + b_xyz + 2 * b_con + b_out + 256, &r->block, &r->block_bytes);
+    const size_t b_tmpl = up256(template_groups_bytes((int)template_atoms));
+    int rcb = block_take(c, b_off + b_xyz + 2 * b_con + b_tmpl + b_out + 256, &r->block, &r->block_bytes);
     if (rcb != PW_OK) { pw_resident_free(c, r); return rcb; }
     unsigned char* base = (unsigned char*)r->block;
     r->d_offset = (long*)base; base += b_off;
     r->d_xyz = (double*)base; base += b_xyz;
     r->d_vdw = (double*)base; base += b_con;
     r->d_mass = (double*)base; base += b_con;
+    r->d_tmpl = base; base += b_tmpl;
+    std::vector<unsigned char> tmpl_host(template_groups_bytes((int)template_atoms));
+    template_groups_build(vdw, (int)template_atoms, tmpl_host.data());
     r->d_outs[0] = (pw_unit_out*)base; base += b_out;
     {
         // the counter lives in host memory the device can read: the host raises it when a copy has landed, and no
@@ -1795,6 +1814,7 @@ int pw_resident_stream_begin(pw_context* c, int64_t n_units, int64_t template_at
     hipError_t e = hipMemcpyAsync(r->d_offset, off.data(), sizeof(long) * (r->n_units + 1), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(r->d_vdw, vdw, sizeof(double) * template_atoms, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(r->d_mass, mass, sizeof(double) * template_atoms, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->d_tmpl, tmpl_host.data(), tmpl_host.size(), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(r->d_outs[0], 0, r->nbuf * sizeof(pw_unit_out) * r->n_units + 64, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // (`off` is a local; 10 us of copies)
     if (e != hipSuccess) { set_err("pw_resident_stream_begin", e); pw_resident_free(c, r); return PW_E_HIP; }

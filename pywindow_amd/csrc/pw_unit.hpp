@@ -30,6 +30,7 @@
 #include "pw_lbfgsb.hpp"
 #include "pw_math.hpp"
 #include "pw_team.hpp"
+#include <string.h>
 
 // Optional in-kernel stage timers (diagnostic build only: -DPW_PROFILE): the 100 MHz
 // constant clock accumulated per stage by lane 0 of each wave into TeamWorkspace::prof.
@@ -1539,10 +1540,83 @@ PW_NOINLINE PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx,
 }
 
 // ---- stage: load --------------------------------------------------------------------------
+// The grouping of the atoms by radius is a property of the RADII: in a batch of one molecule type (a trajectory: one
+// template of radii for every unit) it is the same for every unit, and working it out per unit -- every atom against
+// every other, twice -- was 35 us of a chain's wave and 10 us of a window team (in-kernel timer, round 6).  For such a
+// batch the host works it out once (template_groups_build, the statements of load_unit below) and the launches read it:
+// a blob of ClassInfo | inv[npad] | perm[npad] | radii in stored order [npad], npad = n rounded up to even.
+PW_HD inline size_t template_groups_bytes(int n) {
+    const size_t npad = (size_t)((n + 1) & ~1);
+    return ((sizeof(ClassInfo) + 7) & ~(size_t)7) + npad * 4 * 2 + npad * 8;
+}
+inline void template_groups_build(const double* vdw, int n, unsigned char* blob) {
+    const size_t npad = (size_t)((n + 1) & ~1);
+    ClassInfo* cls = (ClassInfo*)blob;
+    int* inv = (int*)(blob + ((sizeof(ClassInfo) + 7) & ~(size_t)7));
+    int* perm = inv + npad;
+    double* vs = (double*)(perm + npad);
+    memset(blob, 0, template_groups_bytes(n));
+    // key_i = first atom with the same radius; groups in order of first appearance, stable inside a group
+    int ngrp = 0;
+    for (int i = 0; i < n; ++i) {
+        int key = i;
+        for (int j = 0; j < i; ++j)
+            if (vdw[j] == vdw[i]) { key = j; break; }
+        perm[i] = key;                                   // (keys, until the scatter below)
+        if (key == i) ++ngrp;
+    }
+    if (ngrp > PW_KCLS) {
+        cls->k = 0; cls->off[0] = 0;
+        for (int i = 0; i < n; ++i) inv[i] = i;
+    } else {
+        cls->k = ngrp;
+        for (int i = 0; i < n; ++i) {
+            const int key = perm[i];
+            int pos = 0, cid = 0;
+            for (int j = 0; j < n; ++j) {
+                const int kj = perm[j];
+                pos += (kj < key) || (kj == key && j < i);
+                cid += (kj == j) && (j < key);
+            }
+            inv[i] = pos;
+            if (key == i) { cls->vdw[cid] = vdw[i]; cls->off[cid] = pos; }
+        }
+        cls->off[ngrp] = n;
+    }
+    for (int i = 0; i < n; ++i) { vs[inv[i]] = vdw[i]; }
+    for (int i = 0; i < n; ++i) perm[inv[i]] = i;       // (every key has been read)
+}
+
 template <class T>
 PW_HD inline void load_unit(UnitShared& sh, int n, const double* xyz, const double* vdw,
-                            const double* mass) {
+                            const double* mass, const unsigned char* tmpl = nullptr) {
     auto& v = *sh.v;
+    if (tmpl) {
+        // the grouping comes with the batch (see above): one pass, one barrier
+        const size_t npad = (size_t)((n + 1) & ~1);
+        const ClassInfo* tc = (const ClassInfo*)tmpl;
+        const int* t_inv = (const int*)(tmpl + ((sizeof(ClassInfo) + 7) & ~(size_t)7));
+        const int* t_perm = t_inv + npad;
+        const double* t_vs = (const double*)(t_perm + npad);
+        for (int i = T::tid(); i < n; i += T::SIZE) {
+            const int pos = t_inv[i];
+            const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+            sh.A.x[pos] = x; sh.A.y[pos] = y; sh.A.z[pos] = z;
+            sh.A.xx[pos] = sq3(x, y, z);
+            sh.inv[i] = pos;
+            sh.perm[i] = t_perm[i];
+            sh.vdw[i] = t_vs[i];
+            sh.mass[i] = mass[i];
+        }
+        if (T::tid() == 0) {
+            v.n_eval = 0; v.status = 0;
+            v.cls.k = tc->k;
+            for (int g = 0; g <= PW_KCLS; ++g) v.cls.off[g] = tc->off[g];
+            for (int g = 0; g < PW_KCLS; ++g) v.cls.vdw[g] = tc->vdw[g];
+        }
+        T::sync();
+        return;
+    }
     // Group atoms by radius, stable (ascending atom index inside a group), groups in order of
     // first appearance -- computed by every thread for its own atoms:
     //   key_i  = index of the first atom with the same radius
@@ -3960,7 +4034,7 @@ constexpr unsigned PW_KERNEL_WINDOWS = PW_STAGE_WINDOWS | PW_STAGE_REUSE_OPT | P
 template <class T, unsigned KMASK = 0xffffffffu>
 PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const double* xyz,
                                const double* vdw, const double* mass, unsigned stages,
-                               pw_unit_out* out, const pw_params& prm) {
+                               pw_unit_out* out, const pw_params& prm, const unsigned char* tmpl = nullptr) {
     const bool merge = (stages & PW_STAGE_MERGE) != 0;
     const bool reuse_opt = (stages & PW_STAGE_REUSE_OPT) != 0;
     if ((stages & PW_STAGE_WINDOWS) && !reuse_opt && prm.pore_opt) stages |= PW_STAGE_OPT;
@@ -3979,7 +4053,9 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
             out->win_c[w][0] = out->win_c[w][1] = out->win_c[w][2] = 0.0;
         }
     }
-    load_unit<T>(sh, n, xyz, vdw, mass);
+    PW_T0(t_load);
+    load_unit<T>(sh, n, xyz, vdw, mass, tmpl);
+    if (T::wave() == 0) PW_T1(ws, 5, t_load);      // (diagnostic builds: slot 5, every launch's load stage together)
     if (reuse_opt) {
         // the optimiser launch already wrote the centre of mass
         if (T::tid() == 0) { sh.v->com[0] = out->com[0]; sh.v->com[1] = out->com[1]; sh.v->com[2] = out->com[2]; }

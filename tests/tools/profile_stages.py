@@ -29,7 +29,7 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 1  
 ms = res.time_launches(iters)
 L.pw_debug_stage_ticks(ctx._h, buf)
 names2 = {14:"win.pre.shift",15:"win.pre.maxdim",16:"lb.cauchy",17:"lb.formk",18:"lb.cmprlb",19:"lb.subsm",20:"lb.lnsrlb",21:"lb.matupd",22:"lb.formt",24:"eps.knn",25:"eps.sum",26:"win.pre(shift,maxdim,points)",27:"avg.pre(shift,maxdim)",28:"avg.rays",29:"avg.compact+sum",11:"dbscan.adjacency",23:"dbscan.bfs",30:"smp.rays+compact",31:"smp.paths"}
-names = ["opt.step", "consumer.wait", "win.path", "win.rotate", "win.z.step", "win.z.eval", "win.brute", "win.nm", "eps", "sampling", "dbscan", "-", "windows(total)", "average"]
+names = ["opt.step", "consumer.wait", "win.path", "win.rotate", "win.z.step", "load_unit(all launches)", "win.brute", "win.nm", "eps", "sampling", "dbscan", "-", "windows(total)", "average"]
 nl = iters + 1     # (pw_resident_time's warm-up launch counts too)
 t = np.array(list(buf), float)[:14] / 100.0 / nl   # -> microseconds per launch
 t2 = np.array(list(buf), float) / 100.0 / nl
