@@ -4055,7 +4055,9 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
     }
     PW_T0(t_load);
     load_unit<T>(sh, n, xyz, vdw, mass, tmpl);
+#ifndef PW_TIME_BASIC
     if (T::wave() == 0) PW_T1(ws, 5, t_load);      // (diagnostic builds: slot 5, every launch's load stage together)
+#endif
     if (reuse_opt) {
         // the optimiser launch already wrote the centre of mass
         if (T::tid() == 0) { sh.v->com[0] = out->com[0]; sh.v->com[1] = out->com[1]; sh.v->com[2] = out->com[2]; }
@@ -4063,7 +4065,13 @@ PW_HD inline void analyse_unit(UnitShared& sh, TeamWorkspace* ws, int n, const d
     } else if (KMASK == PW_KERNEL_AVERAGE) {
         stage_basic_impl<T>(sh, ws, n, out, true);
     } else {
+#ifdef PW_TIME_BASIC
+        PW_T0(t_basic);
+#endif
         stage_basic<T>(sh, ws, n, out, (stages & PW_STAGE_COM_ONLY) != 0);
+#ifdef PW_TIME_BASIC
+        if (T::wave() == 0) PW_T1(ws, 5, t_basic);       // (diagnostic: slot 5 is then the basic stage, not the load)
+#endif
     }
     if (stages & PW_STAGE_OPT) stage_opt<T>(sh, ws, n, out, prm);
     if (reuse_opt) {

@@ -378,6 +378,21 @@ def test_uniform_batch_constants_travel_once(hip_ctx):
     with pytest.raises(_lib.PwHipError):
         bad = _lib.Batch(np.array([0, 100, 268], np.int64), frames[:2].reshape(-1, 3)[:268], vdw, mass, template_atoms=168)
         hip_ctx.analyse(bad)
+    # The two forms take different LOAD paths since round 6: a template's radius groups are worked out once on the host
+    # (template_groups_build), a per-atom batch groups every unit on the device.  Molecules with one, three, eight and
+    # ten distinct radii (more than eight: no grouping at all), radii in every order of first appearance.
+    rng = np.random.default_rng(6)
+    pool = np.unique(E.VDW[E.VDW > 0])
+    for n_radii, n_atoms in ((1, 40), (3, 57), (8, 90), (10, 75), (4, 168)):
+        radii = rng.permutation(pool)[:n_radii]
+        v = radii[rng.integers(0, n_radii, size=n_atoms)]
+        m = rng.uniform(1.0, 40.0, size=n_atoms)
+        shell = rng.normal(size=(n_atoms, 3))
+        shell = shell / np.linalg.norm(shell, axis=1)[:, None] * rng.uniform(7.0, 10.0)
+        fr = shell[None] + rng.normal(0.0, 0.15, size=(5, n_atoms, 3))
+        a = hip_ctx.analyse(_lib.Batch.uniform(fr, v, m))
+        b = hip_ctx.analyse(_lib.Batch(np.arange(6, dtype=np.int64) * n_atoms, fr.reshape(-1, 3), np.tile(v, 5), np.tile(m, 5)))
+        assert a.tobytes() == b.tobytes(), (n_radii, n_atoms)
 
 
 def test_reference_platform_branch_is_reported():
