@@ -220,7 +220,7 @@ int pw_analysis_batch(pw_context *ctx, const pw_batch_in *in, uint32_t stages, p
  * most `cap` entries to buf and returns how many exist.  find_windows has no upper limit on the
  * number of windows (utilities.py:1526-1536); the record keeps the first PW_W_MAX. */
 int64_t pw_context_extra_windows(pw_context *ctx, pw_extra_window *buf, int64_t cap);
-/* 1 when analyses on this context run as the overlapped three-launch pipeline, 0 when as single launches:
+/* 1 when analyses on this context run as the overlapped two-launch pipeline (optimiser chains | average diameter + window search), 0 when as single launches:
  * the pipeline needs its ten HIP streams to run concurrently, i.e. GPU_MAX_HW_QUEUES >= 10 in the
  * environment BEFORE the process first initialises HIP; pw_context_create measures whether they do and
  * falls back (with a line on stderr) instead of letting gate kernels wait for launches queued behind them */
