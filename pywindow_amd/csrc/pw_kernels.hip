@@ -175,6 +175,9 @@ pw_analyse_kernel(long n_units, const long* __restrict__ atom_offset, const doub
     TeamWorkspace* ws = (TeamWorkspace*)wsa.ws + blockIdx.x;
 #ifdef PW_PROFILE
     if (threadIdx.x < 32) pw_prof_lds[threadIdx.x] = 0;     // (the team's timers: summed here, flushed when it leaves)
+#ifdef PW_BARRIER_PROF
+    if (threadIdx.x < 8) pw_bar_acc[threadIdx.x] = 0;
+#endif
 #endif
     if (threadIdx.x == 0) {
         s_sh.carve(lds, nmax, nrot, nlb, nframes, lean, wsa.p_cap);     // as planned by the host (plan_launch)

@@ -41,6 +41,11 @@ struct HostTeam {
 };
 
 #if defined(__HIPCC__)
+#if defined(PW_BARRIER_PROF)
+// Diagnostic build (-DPW_PROFILE -DPW_BARRIER_PROF, tests/tools/profile_barriers.py): what every wave of a team waits at
+// the team's barriers, 100 MHz ticks, collected per wave and handed to the stage timer that closes next (PW_T1).
+__shared__ unsigned long long pw_bar_acc[8];
+#endif
 template <int NW>
 struct DeviceTeam {
     static constexpr int NWAVES = NW;
@@ -49,7 +54,15 @@ struct DeviceTeam {
     __device__ static int tid() { return threadIdx.x; }
     __device__ static int lane() { return threadIdx.x & 63; }
     __device__ static int wave() { return threadIdx.x >> 6; }
+#if defined(PW_BARRIER_PROF)
+    __device__ static void sync() {
+        const long long t0 = wall_clock64();
+        __syncthreads();
+        if (lane() == 0) atomicAdd(&pw_bar_acc[wave()], (unsigned long long)(wall_clock64() - t0));
+    }
+#else
     __device__ static void sync() { __syncthreads(); }
+#endif
     // waves execute in lockstep; LDS traffic inside one wave only needs the
     // compiler not to reorder across this point and the LDS queue drained
     __device__ static void wave_sync() {

@@ -47,6 +47,11 @@ __shared__ unsigned long long pw_prof_lds[32];
 #if defined(PW_ZPROF) && defined(PW_LB_FINE)
 // (the optimiser's sub-phase timers of the neck search take the window stages' slots: those stay silent)
 #define PW_T1(ws, slot, var) do { (void)var; } while (0)
+#elif defined(PW_BARRIER_PROF)
+// (the barrier-wait build: a slot receives what the team's waves waited at barriers since the last timer closed)
+#define PW_T1(ws, slot, var) do { (void)var; if (T::lane() == 0) { unsigned long long w_ = 0; \
+        for (int k_ = 0; k_ < T::NWAVES; ++k_) w_ += atomicExch(&pw_bar_acc[k_], 0ull); \
+        atomicAdd(&pw_prof_lds[slot], w_); } } while (0)
 #else
 #define PW_T1(ws, slot, var) do { if (T::lane() == 0) atomicAdd(&pw_prof_lds[slot], (unsigned long long)(wall_clock64() - var)); } while (0)
 #endif

@@ -8,5 +8,5 @@ PW_FUZZ_MAX_ATOMS=420 timeout 600 python tests/tools/fuzz_device_vs_host.py 1000
 timeout 600 python tests/tools/soak_growth.py 300 5 2>&1 | tail -1 | tee $o/soak.txt
 bash tests/tools/profile_round.sh $tag > $o/profile_round.log 2>&1
 timeout 200 python3 tests/tools/profile_stages.py 1000 2>&1 | tail -1 > $o/stage_timers.txt
-timeout 300 python3 tests/tools/profile_chains.py 1000 2>/dev/null | tail -1 > $o/chain_subphase_timers.json
+timeout 300 python3 tests/tools/profile_chains.py 1000 2>/dev/null > $o/chain_subphase_timers.json
 timeout 200 python3 tests/tools/chains_only.py 1000 2>&1 | grep "product chains" | tee $o/chains_only.txt

@@ -10,5 +10,11 @@ ctx = _lib.Context(0)
 res = ctx.upload(_lib.Batch.uniform(frames, E.VDW[ids], E.MASS[ids]))
 for _ in range(it):
     res.launch(st)
-res.sync()
-print("done", st, n, it)
+try:
+    res.sync()
+    print("done", st, n, it)
+except _lib.PwTimeoutError as e:
+    # a counter pass (rocprofv3 --pmc) runs ONE kernel at a time, in an order of its own: a residency gate dispatched
+    # ahead of its optimiser launch waits its limit out and reports it; the launches complete all the same (the
+    # consumers run after the chains) and their counters are what this run is for.
+    print("done", st, n, it, "-- with a residency gate expired under the profiler's kernel serialisation:", e)
