@@ -1721,7 +1721,7 @@ int pw_resident_upload(pw_context* c, const pw_batch_in* in, pw_resident** out) 
         if (b_tmpl) {
             r->d_tmpl = base; base += b_tmpl;
             tmpl_host.resize(template_groups_bytes(nmax));
-            template_groups_build(in->vdw, nmax, tmpl_host.data());
+            template_groups_build(in->vdw, in->mass, nmax, tmpl_host.data());
         }
         r->d_outs[0] = (pw_unit_out*)base;
         for (int k = 1; k < r->nbuf; ++k) r->d_outs[k] = r->d_outs[0] + (size_t)k * r->n_units;
@@ -1791,7 +1791,7 @@ int pw_resident_stream_begin(pw_context* c, int64_t n_units, int64_t template_at
     r->d_mass = (double*)base; base += b_con;
     r->d_tmpl = base; base += b_tmpl;
     std::vector<unsigned char> tmpl_host(template_groups_bytes((int)template_atoms));
-    template_groups_build(vdw, (int)template_atoms, tmpl_host.data());
+    template_groups_build(vdw, mass, (int)template_atoms, tmpl_host.data());
     r->d_outs[0] = (pw_unit_out*)base; base += b_out;
     {
         // the counter lives in host memory the device can read: the host raises it when a copy has landed, and no

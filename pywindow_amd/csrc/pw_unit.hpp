@@ -201,6 +201,7 @@ PW_HD inline void bind_team_slab(TeamWorkspace* ws, unsigned char* slab, int p_c
 struct UnitVars {
     double com[3];
     double mw;
+    int mw_given;      // the batch brought its molecular weight (one molecule type: template_groups_build)
     double centroid[3];
     double maxd;
     int maxd_i, maxd_j;
@@ -1549,12 +1550,24 @@ PW_NOINLINE PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx,
 // template of radii for every unit) it is the same for every unit, and working it out per unit -- every atom against
 // every other, twice -- was 35 us of a chain's wave and 10 us of a window team (in-kernel timer, round 6).  For such a
 // batch the host works it out once (template_groups_build, the statements of load_unit below) and the launches read it:
-// a blob of ClassInfo | inv[npad] | perm[npad] | radii in stored order [npad], npad = n rounded up to even.
+// a blob of ClassInfo | inv[npad] | perm[npad] | radii in stored order [npad] | the molecular weight (numpy's sum of the
+// masses: the same for every unit as well), npad = n rounded up to even.
 PW_HD inline size_t template_groups_bytes(int n) {
     const size_t npad = (size_t)((n + 1) & ~1);
-    return ((sizeof(ClassInfo) + 7) & ~(size_t)7) + npad * 4 * 2 + npad * 8;
+    return ((sizeof(ClassInfo) + 7) & ~(size_t)7) + npad * 4 * 2 + npad * 8 + 8;
 }
-inline void template_groups_build(const double* vdw, int n, unsigned char* blob) {
+// numpy's sum of the masses (np.sum over a contiguous vector: pairwise, chunks of 8192)
+PW_HD inline double molecular_weight_sum(const double* mass, int n) {
+    double tot = 0.0;
+    for (int s0 = 0; s0 < n; s0 += 8192) {
+        // (np_sum_lean: the recursion walked with scalars only -- np_sum_small's leaf tables were 500 bytes of
+        // scratch per lane in every kernel that contains this stage)
+        double part = np_sum_lean(mass + s0, n - s0 < 8192 ? n - s0 : 8192);
+        tot = s0 == 0 ? part : tot + part;
+    }
+    return tot;
+}
+inline void template_groups_build(const double* vdw, const double* mass, int n, unsigned char* blob) {
     const size_t npad = (size_t)((n + 1) & ~1);
     ClassInfo* cls = (ClassInfo*)blob;
     int* inv = (int*)(blob + ((sizeof(ClassInfo) + 7) & ~(size_t)7));
@@ -1590,6 +1603,7 @@ inline void template_groups_build(const double* vdw, int n, unsigned char* blob)
     }
     for (int i = 0; i < n; ++i) { vs[inv[i]] = vdw[i]; }
     for (int i = 0; i < n; ++i) perm[inv[i]] = i;       // (every key has been read)
+    vs[npad] = molecular_weight_sum(mass, n);
 }
 
 template <class T>
@@ -1615,6 +1629,7 @@ PW_HD inline void load_unit(UnitShared& sh, int n, const double* xyz, const doub
         }
         if (T::tid() == 0) {
             v.n_eval = 0; v.status = 0;
+            v.mw = t_vs[npad]; v.mw_given = 1;
             v.cls.k = tc->k;
             for (int g = 0; g <= PW_KCLS; ++g) v.cls.off[g] = tc->off[g];
             for (int g = 0; g < PW_KCLS; ++g) v.cls.vdw[g] = tc->vdw[g];
@@ -1631,7 +1646,7 @@ PW_HD inline void load_unit(UnitShared& sh, int n, const double* xyz, const doub
         sh.vdw[i] = r;                 // caller's order for the moment
         sh.mass[i] = mass[i];
     }
-    if (T::tid() == 0) { v.n_eval = 0; v.status = 0; v.cls.k = 0; }
+    if (T::tid() == 0) { v.n_eval = 0; v.status = 0; v.cls.k = 0; v.mw_given = 0; }
     T::sync();
     for (int i = T::tid(); i < n; i += T::SIZE) {
         double r = sh.vdw[i];
@@ -1699,16 +1714,45 @@ PW_HD inline double seq_sum_blocks(int n, F term) {
 template <class F>
 PW_HD inline double seq_sum_blocked(int n, F term) { return seq_sum_blocks<8>(n, term); }
 
+// Room for three columns of n terms in the caller's atom order, in the team memory that is idle while a frame is being
+// prepared (window frames / optimiser states: UnitShared::scratch): the row-sequential sums of a unit -- centre of mass,
+// centroid -- are ONE dependent chain of n additions each, and their terms used to be fetched by the summing lane
+// itself, two reads deep through the permutation (4 us of a team with three lanes at work).  Written here by the whole
+// team, the columns are read back contiguously, sixteen terms in flight.  nullptr: no room (or a one-thread team).
+template <class T>
+PW_HD inline ldouble* seq_sum_columns(const UnitShared& sh, int n) {
+    const size_t np = (size_t)((n + 1) & ~1);
+    if (T::SIZE < 64 || sh.scratch_bytes < 3 * np * 8) return nullptr;
+    return (ldouble*)sh.scratch;
+}
+// the three sums by the first three threads (after a barrier behind the columns' writes); fin(c, sum)
+template <class T, class FIN>
+PW_HD inline void seq_sum_columns_add(const ldouble* cols, int n, FIN fin) {
+    const size_t np = (size_t)((n + 1) & ~1);
+    if (T::tid() < 3) {
+        const ldouble* a = cols + (size_t)T::tid() * np;
+        fin(T::tid(), seq_sum_blocks<16>(n, [&](int i) { return a[i]; }));
+    }
+}
+
 // shifted copy S = A - c (elementwise), with |r|^2 and the row-sequential centroid
 template <class T>
 PW_HD inline void make_shifted(UnitShared& sh, int n, double cx, double cy, double cz) {
+    ldouble* cols = seq_sum_columns<T>(sh, n);
+    const size_t np = (size_t)((n + 1) & ~1);
     for (int i = T::tid(); i < n; i += T::SIZE) {
         double x = sh.A.x[i] - cx, y = sh.A.y[i] - cy, z = sh.A.z[i] - cz;
         sh.S.x[i] = x; sh.S.y[i] = y; sh.S.z[i] = z;
         sh.S.xx[i] = sq3(x, y, z);
+        if (cols) { const int ci = sh.perm[i]; cols[ci] = x; cols[np + ci] = y; cols[2 * np + ci] = z; }
     }
     T::sync();
     // centroid: np.sum(coordinates, axis=0) / N -- rows added in the caller's atom order
+    if (cols) {
+        seq_sum_columns_add<T>(cols, n, [&](int c, double s) { sh.v->centroid[c] = s / (double)n; });
+        T::sync();
+        return;
+    }
     auto cen_comp = [&](int c) {
         const ldouble* a = c == 0 ? sh.S.x : (c == 1 ? sh.S.y : sh.S.z);
         double s = seq_sum_blocked(n, [&](int i) { return a[sh.inv[i]]; });
@@ -2126,18 +2170,21 @@ PW_HD inline __attribute__((always_inline)) void stage_basic_impl(UnitShared& sh
                                                                   pw_unit_out* out, bool com_only) {
     auto& v = *sh.v;
     (void)ws;
-    if (T::tid() == 0) {
-        double tot = 0.0;
-        for (int s0 = 0; s0 < n; s0 += 8192) {
-            // (np_sum_lean: the recursion walked with scalars only -- np_sum_small's leaf tables were 500 bytes of
-            // scratch per lane in every kernel that contains this stage)
-            double part = np_sum_lean((const double*)(sh.mass + s0), n - s0 < 8192 ? n - s0 : 8192);
-            tot = s0 == 0 ? part : tot + part;
-        }
-        v.mw = tot;
-    }
-    T::sync();
     // centre of mass: per component the row-sequential sum of x_i*m_i over the mass
+    ldouble* cols = seq_sum_columns<T>(sh, n);
+    if (cols) {
+        const size_t np = (size_t)((n + 1) & ~1);
+        for (int i = T::tid(); i < n; i += T::SIZE) {
+            const int pos = sh.inv[i];
+            const double m = sh.mass[i];
+            cols[i] = sh.A.x[pos] * m; cols[np + i] = sh.A.y[pos] * m; cols[2 * np + i] = sh.A.z[pos] * m;
+        }
+    }
+    if (T::tid() == 0 && !v.mw_given) v.mw = molecular_weight_sum((const double*)sh.mass, n);
+    T::sync();
+    if (cols) {
+        seq_sum_columns_add<T>(cols, n, [&](int c, double s) { v.com[c] = s / v.mw; });
+    } else {
     auto com_comp = [&](int c) {
         const ldouble* a = c == 0 ? sh.A.x : (c == 1 ? sh.A.y : sh.A.z);
         double s = seq_sum_blocked(n, [&](int i) { return a[sh.inv[i]] * sh.mass[i]; });
@@ -2147,6 +2194,7 @@ PW_HD inline __attribute__((always_inline)) void stage_basic_impl(UnitShared& sh
         if (T::tid() < 3) com_comp(T::tid());
     } else if (T::tid() == 0) {
         com_comp(0); com_comp(1); com_comp(2);
+    }
     }
     T::sync();
     if (com_only) return;
