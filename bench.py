@@ -575,8 +575,9 @@ _KERNEL_OF = (("pw_analyse_kernel<1, 37u>", "chains"), ("pw_analyse_kernel<4, 98
 
 
 def _serial_kernel_ms():
-    """Average kernel durations (ms) of the three launches from the committed rocprofv3 summary of one analysis at
-    a time -> ({"chains": .., "average": .., "windows": ..}, file name) or (None, None)."""
+    """Average kernel durations (ms) of an analysis' launches from the committed rocprofv3 summary of one analysis at
+    a time -> ({"chains": .., "windows+average": ..} -- rounds 1-5: "chains", "average", "windows" --, file name) or
+    (None, None)."""
     import csv
 
     for name in SERIAL_STATS_FILES:
@@ -893,7 +894,7 @@ def main():
         # Two clocks per launch: `ms` = rocprofv3's average kernel duration of ONE analysis at a time (committed summary,
         # static: first wave to last wave of the kernel -- the figure the fractions use); `ms_events_live` = HIP events
         # on the launch's own stream in THIS run, which also contain the time the launch sits behind its gate and waits
-        # for SIMD slots (the average-diameter launch has the lowest stream priority: 2.2 ms against 0.9).
+        # for SIMD slots.
         per_kernel = None
         try:
             st = res.stage_times()
