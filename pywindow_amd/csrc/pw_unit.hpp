@@ -63,6 +63,9 @@ __shared__ unsigned long long pw_prof_lds[32];
 // unroll factors of the three bulk loops (measured: tests/tools/variant_sweep.sh)
 #define PW_PRAGMA_(x) _Pragma(#x)
 #define PW_PRAGMA(x) PW_PRAGMA_(x)
+#ifndef PW_UNROLL_LIST
+#define PW_UNROLL_LIST 4
+#endif
 #ifndef PW_UNROLL_GAP
 #define PW_UNROLL_GAP 2
 #endif
@@ -424,9 +427,12 @@ PW_HD inline double point_gap_value(const Frame& F, int n, double px, double py,
 // NP points at once by ONE thread (register blocking): every atom is read from LDS once and
 // used for all NP points, so the loop is bound by arithmetic instead of LDS reads.  Each value is
 // bit-identical to point_gap_value of that point.
+// cand / coff (optional): the atoms to go through instead of all of them -- stored positions, ascending, coff[g] = where
+// group g's begin in cand (wave_path_candidates: every atom left out is PROVABLY farther from every one of the points
+// than the value the caller compares with; the values of the points that matter are the same bits).
 template <int NP>
 PW_HD inline void points_gap_values(const Frame& F, int n, const double* px, const double* py, const double* pz,
-                                    double* out) {
+                                    double* out, const lint* cand = nullptr, const lint* coff = nullptr) {
     const auto& C = *F.cls;
     if (C.k == 0) {
         for (int p = 0; p < NP; ++p) out[p] = point_gap(F, n, px[p], py[p], pz[p], nullptr);
@@ -443,6 +449,19 @@ PW_HD inline void points_gap_values(const Frame& F, int n, const double* px, con
         double m2[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) m2[p] = PW_INF;
+        if (cand) {
+            const int chi = coff[g + 1];
+PW_PRAGMA(unroll PW_UNROLL_LIST)
+            for (int c = coff[g]; c < chi; ++c) {
+                const int i = cand[c];
+                const double x = F.x[i], y = F.y[i], z = F.z[i], xx = F.xx[i];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    double gg = pw_fma(z, qz[p], pw_fma(x, qx[p], y * qy[p]));
+                    m2[p] = __builtin_fmin(m2[p], pw_m2add(gg, xx));
+                }
+            }
+        } else {
         const int hi = C.off[g + 1];
 PW_PRAGMA(unroll PW_UNROLL_GAP)
         for (int i = C.off[g]; i < hi; ++i) {
@@ -452,6 +471,7 @@ PW_PRAGMA(unroll PW_UNROLL_GAP)
                 double gg = pw_fma(z, qz[p], pw_fma(x, qx[p], y * qy[p]));
                 m2[p] = __builtin_fmin(m2[p], pw_m2add(gg, xx));
             }
+        }
         }
         const double r = C.vdw[g];
 #pragma unroll
@@ -1499,7 +1519,7 @@ PW_HD inline double np_floordiv(double a, double b) {
 // the last pass five when no more are left (eleven points -- the usual count -- are 6 + 5, not two passes of six).
 PW_NOINLINE PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx, double vy, double vz,
                                    double inc, double m0, double* out_2gap, int* out_pos, double* out_chunk,
-                                   int* n_eval) {
+                                   int* n_eval, const lint* cand = nullptr, const lint* coff = nullptr) {
     double nrm = norm3(vx, vy, vz);
     int chunks = (int)np_floordiv(nrm, inc);
     double cx = vx / (double)chunks, cy = vy / (double)chunks, cz = vz / (double)chunks;
@@ -1523,7 +1543,7 @@ PW_NOINLINE PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx,
             int k = k0 + p <= chunks ? k0 + p : chunks;
             qx[p] = cx * (double)k; qy[p] = cy * (double)k; qz[p] = cz * (double)k;
         }
-        points_gap_values<NP>(F, n, qx, qy, qz, m);
+        points_gap_values<NP>(F, n, qx, qy, qz, m, cand, coff);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             if (k0 + p <= chunks && ok) {
@@ -1542,6 +1562,82 @@ PW_NOINLINE PW_HD inline bool path_scan_thread(const Frame& F, int n, double vx,
     *out_2gap = best * 2.0;
     *out_pos = pos;
     out_chunk[0] = cx; out_chunk[1] = cy; out_chunk[2] = cz;
+    return true;
+}
+
+// The atoms that can matter to the paths of ONE wave (a path each in the lanes that `have` one; vx, vy, vz its end point).
+// A path's result is the smallest gap over its points and where it is first reached, and it starts at m0, the gap at
+// the origin (path_scan_thread): an atom whose gap is PROVABLY above m0 at every point but the origin of every path of
+// the wave changes nothing -- not the minimum, not its place, not the test for a point inside a sphere (that needs a gap
+// <= 0 < m0).  The wave's directions lie in a band of latitudes z1 <= u_z <= z2; the angle between an atom's direction and
+// ANY direction of the band is at least its distance in latitude to the band, theta1.  With rho the atom's distance from
+// the origin, c1 = cos(theta1) (0 beyond a right angle) and t1 = inc <= the distance of a path's second point from the origin, the
+// squared distance from the atom to a point at t >= t1 along such a direction is at least rho^2 + t^2 - 2 t rho c1, i.e.
+// at least rho^2 (1 - c1^2) where rho c1 >= t1 and rho^2 + t1^2 - 2 t1 rho c1 otherwise.  An atom goes on the list unless
+// that bound exceeds (r + m0)^2, margins of 1e-9 on every side (the quantities are good to 1e-15).  The list is in stored
+// order (so the groups by radius stay contiguous): cand[0 .. coff[k]), group g at [coff[g], coff[g + 1]).  Lanes test
+// atoms, 64 at a time: a hundred instructions for a wave's list.  false: no list (ungrouped radii, a path without a
+// second point, m0 <= 0 -- every path fails at the origin then): the caller scans all atoms.
+template <class T>
+PW_HD inline bool wave_path_candidates(const Frame& F, int n, bool have, double vx, double vy, double vz, double inc,
+                                       double m0, lint* cand, lint* coff) {
+    const auto& C = *F.cls;
+    if (C.k == 0 || !(m0 > 0.0)) return false;
+    double uz_lo = PW_INF, uz_hi = -PW_INF, t1 = PW_INF;
+    bool odd = false;
+    if (have) {
+        // (a path of at least one step: its length / floor(length / inc) is at least inc -- no floor division here)
+        const double nrm = norm3(vx, vy, vz);
+        odd = !(nrm >= inc * (1.0 + 1e-9)) || !(nrm < PW_INF) || !(inc > 0.0);
+        if (!odd) uz_lo = uz_hi = vz / nrm;
+    }
+    if (T::wave_any(odd)) return false;
+    double z1 = T::wave_min(uz_lo) - 1e-9, z2 = -T::wave_min(-uz_hi) + 1e-9;
+    t1 = inc * (1.0 - 1e-9);
+    if (!(z1 <= z2)) return false;               // (no lane has a path)
+    z1 = pw_max(z1, -1.0); z2 = pw_min(z2, 1.0);
+    const double s1 = pw_sqrt(pw_max(1.0 - z1 * z1, 0.0)), s2 = pw_sqrt(pw_max(1.0 - z2 * z2, 0.0));
+    const double m0p = m0 * (1.0 + 1e-9) + 1e-9;
+    // lane g counts the listed atoms below group g's first position: coff[g]
+    const int mycut = T::lane() <= C.k ? C.off[T::lane() <= PW_KCLS ? T::lane() : PW_KCLS] : n;
+    int mycount = 0, cnt = 0;
+    for (int base = 0; base < n; base += T::WSIZE) {
+        const int i = base + T::lane();
+        bool keep = false;
+        if (i < n) {
+            const double xx = F.xx[i], z = F.z[i], r = F.vdw[i];
+            const double rho = pw_sqrt(xx);
+            const double zd = rho > 0.0 ? z / rho : 0.0;
+            const double sd = pw_sqrt(pw_max(1.0 - zd * zd, 0.0));
+            double c1 = 1.0;
+            if (zd > z2) c1 = sd * s2 + zd * z2;
+            else if (zd < z1) c1 = sd * s1 + zd * z1;
+            c1 = pw_min(1.0, pw_max(0.0, c1 + 1e-9));
+            const double ts = rho * c1;
+            const double low = ts >= t1 ? xx * (1.0 - c1 * c1) : (xx + t1 * t1) - 2.0 * t1 * ts;
+            const double lim = (r + m0p) * (r + m0p);
+            keep = !(low * (1.0 - 1e-9) - 1e-9 > lim * (1.0 + 1e-9));
+        }
+        const unsigned long long bal = T::ballot(keep);
+        const int pos = cnt + __builtin_popcountll(bal & ((1ull << T::lane()) - 1ull));
+        if (keep) cand[pos] = i;
+        if (T::WSIZE > 1) {
+            int w = mycut - base;
+            w = w < 0 ? 0 : (w > 64 ? 64 : w);
+            mycount += __builtin_popcountll(bal & (w >= 64 ? ~0ull : ((1ull << w) - 1ull)));
+        }
+        cnt += __builtin_popcountll(bal);
+    }
+    if (T::WSIZE > 1) {
+        if (T::lane() <= C.k) coff[T::lane()] = mycount;
+    } else {
+        int c = 0;
+        for (int g = 0; g <= C.k; ++g) {
+            while (c < cnt && cand[c] < C.off[g]) ++c;
+            coff[g] = c;
+        }
+    }
+    T::wave_sync();
     return true;
 }
 
@@ -3868,56 +3964,66 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
         const double m_origin = wave_gap_value<T>(sh.S, n, 0.0, 0.0, 0.0);
         int whole = T::SIZE > 1 ? (ncand / T::SIZE) * T::SIZE : ncand;
         if ((ncand - whole) * 4 >= T::SIZE) whole = ncand;
-        for (int j = T::tid(); j < whole; j += T::SIZE) {
-            int k = labels[j];
-            PW_DCHECK(k >= 0 && k < P, 105);
-            double g2, chunk[3];
-            int pos;
-            bool ok = path_scan_thread(sh.S, n, pts[PT(k, 0)], pts[PT(k, 1)], pts[PT(k, 2)], prm.increment, m_origin,
-                                       &g2, &pos, chunk, &evals);
-            flag[j] = ok ? 1 : 0;
-            tmpv[j] = g2;
-        }
-        const int left = ncand - whole;
-        if (left > 0) {
-            constexpr int PCAP = 64;                       // points per path handled this way
-            double* pm = ws->knn + ws->p_cap;              // free since the DBSCAN radius is known (the first
-                                                           // p_cap entries may hold tmpv); 9 p_cap >= 255 x 64
-            bool fits = true;
-            for (int item = T::tid(); item < left * PCAP; item += T::SIZE) {
-                int j = whole + item / PCAP, q = item % PCAP;
-                int k = labels[j];
-                double vx = pts[PT(k, 0)], vy = pts[PT(k, 1)], vz = pts[PT(k, 2)];
-                int chunks = (int)np_floordiv(norm3(vx, vy, vz), prm.increment);
-                if (chunks + 1 > PCAP) { fits = false; continue; }
-                if (q > chunks) continue;
-                double cx = vx / (double)chunks, cy = vy / (double)chunks, cz = vz / (double)chunks;
-                pm[(size_t)(j - whole) * PCAP + q] = point_gap_value(sh.S, n, cx * (double)q, cy * (double)q, cz * (double)q);
+        // (a wave's 64 paths -- consecutive survivors: a band of latitudes -- go through the atoms that can matter to
+        // them, two thirds of the molecule: wave_path_candidates; the list lives behind the path values)
+        lint* cand_w = nullptr;
+        lint* coff_w = nullptr;
+        {
+            ScratchArena a3 = arena;
+            const size_t per_wave = (size_t)n + PW_KCLS + 2;
+            int* c_all = (int*)a3.take((size_t)T::NWAVES * per_wave * 4);
+            if (c_all && PW_IS_LDS(c_all)) {
+                cand_w = (lint*)PW_AS_LDS(c_all) + (size_t)T::wave() * per_wave;
+                coff_w = cand_w + n;
             }
-            T::sync();
-            for (int j = whole + T::tid(); j < ncand; j += T::SIZE) {
-                int k = labels[j];
-                double vx = pts[PT(k, 0)], vy = pts[PT(k, 1)], vz = pts[PT(k, 2)];
-                int chunks = (int)np_floordiv(norm3(vx, vy, vz), prm.increment);
-                double g2 = 0.0;
-                bool ok = true;
-                if (chunks + 1 > PCAP) {                   // very fine increments: the plain walk
-                    double chunk[3];
-                    int pos;
-                    ok = path_scan_thread(sh.S, n, vx, vy, vz, prm.increment, m_origin, &g2, &pos, chunk, &evals);
-                } else {
-                    double best = PW_INF;
-                    for (int q = 0; q <= chunks; ++q) {
-                        double m = pm[(size_t)(j - whole) * PCAP + q];
-                        if (!(m > 0.0)) { ok = false; break; }
-                        if (m < best) best = m;
-                    }
-                    g2 = best * 2.0;
-                }
+        }
+        for (int j0 = 0; j0 < whole; j0 += T::SIZE) {
+            const int j = j0 + T::tid();
+            const bool have = j < whole;
+            const int k = have ? labels[j] : 0;
+            PW_DCHECK(k >= 0 && k < P, 105);
+            const double vx = pts[PT(k, 0)], vy = pts[PT(k, 1)], vz = pts[PT(k, 2)];
+            const bool listed = cand_w != nullptr &&
+                                wave_path_candidates<T>(sh.S, n, have, vx, vy, vz, prm.increment, m_origin, cand_w, coff_w);
+            if (have) {
+                double g2, chunk[3];
+                int pos;
+                bool ok = path_scan_thread(sh.S, n, vx, vy, vz, prm.increment, m_origin, &g2, &pos, chunk, &evals,
+                                           listed ? cand_w : nullptr, listed ? coff_w : nullptr);
                 flag[j] = ok ? 1 : 0;
                 tmpv[j] = g2;
             }
-            (void)fits;
+        }
+        const int left = ncand - whole;
+        if (left > 0) {
+            // The paths of a last, partial round (fewer than a quarter of the team's threads): ONE WAVE per path, the
+            // atoms spread over its lanes, point after point (wave_gap_value: the same value as the one-thread scan).
+            // (Until round 6 a path's points went one to a thread, every thread through all atoms for its point: nine
+            // lanes of a wave busy, 12.7 us for the four paths a CC3 frame usually leaves -- in-kernel timer; 3 us now.)
+            for (int j = whole + T::wave(); j < ncand; j += T::NWAVES) {
+                const int k = labels[j];
+                const double vx = pts[PT(k, 0)], vy = pts[PT(k, 1)], vz = pts[PT(k, 2)];
+                const int chunks = (int)np_floordiv(norm3(vx, vy, vz), prm.increment);
+                double g2 = 0.0;
+                bool ok = true;
+                if (chunks >= 1) {
+                    // (path_scan_thread's statements: the first point is the origin, its gap the caller's m_origin)
+                    const double cx = vx / (double)chunks, cy = vy / (double)chunks, cz = vz / (double)chunks;
+                    double best = m_origin;
+                    if (!(m_origin > 0.0)) ok = false;
+                    for (int q = 1; q <= chunks && ok; ++q) {
+                        const double m = wave_gap_value<T>(sh.S, n, cx * (double)q, cy * (double)q, cz * (double)q);
+                        if (!(m > 0.0)) ok = false;
+                        else if (m < best) best = m;
+                    }
+                    g2 = best * 2.0;
+                } else {
+                    double chunk[3];
+                    int pos;
+                    ok = path_scan_thread(sh.S, n, vx, vy, vz, prm.increment, m_origin, &g2, &pos, chunk, &evals);
+                }
+                if (T::lane() == 0) { flag[j] = ok ? 1 : 0; tmpv[j] = g2; }
+            }
         }
         T::sync();
         if (T::wave() == 0) PW_T1(ws, 31, t_path);    // path scans
