@@ -3144,12 +3144,27 @@ PW_NOINLINE PW_HD inline void wave_window(const Frame& FS, const Frame& R, PW_LD
     double new_z = norm3(cx * (double)ppos, cy * (double)ppos, cz * (double)ppos);
     // (iii) rotation angles (utilities.py:1235-1259)
     // angle_between_vectors (utilities.py:1088-1097): x[i] ** 2 on float64 scalars is libm's pow
-    const double vx2 = pw_square_np(vx), vy2 = pw_square_np(vy), vz2 = pw_square_np(vz);
+    // (A wave computes these scalars in every lane alike.  The library functions among them -- three squares through
+    // pow, two arc cosines, two sines and cosines -- go through ONE evaluation each, their arguments side by side in the
+    // first lanes: the same instructions on the same values, a third of the dependent chain.)
+    double vx2, vy2, vz2;
+    if (T::WSIZE == 64) {
+        const double sq = pw_square_np(T::lane() == 1 ? vy : (T::lane() == 2 ? vz : vx));
+        vx2 = T::bcast_u(sq, 0); vy2 = T::bcast_u(sq, 1); vz2 = T::bcast_u(sq, 2);
+    } else {
+        vx2 = pw_square_np(vx); vy2 = pw_square_np(vy); vz2 = pw_square_np(vz);
+    }
     double c1 = pw_abs(vx * 1.0 + vy * 0.0 + 0.0 * 0.0) /
                 (pw_sqrt(vx2 + vy2 + 0.0) * pw_sqrt(1.0 + 0.0 + 0.0));
     double c2 = pw_abs(vx * 0.0 + vy * 0.0 + vz * 1.0) /
                 (pw_sqrt(vx2 + vy2 + vz2) * pw_sqrt(0.0 + 0.0 + 1.0));
-    double a1 = pw_acos_np(c1, ws->rsq), a2 = pw_acos_np(c2, ws->rsq);
+    double a1, a2;
+    if (T::WSIZE == 64) {
+        const double ac = pw_acos_np(T::lane() == 1 ? c2 : c1, ws->rsq);
+        a1 = T::bcast_u(ac, 0); a2 = T::bcast_u(ac, 1);
+    } else {
+        a1 = pw_acos_np(c1, ws->rsq); a2 = pw_acos_np(c2, ws->rsq);
+    }
     const double a1_raw = a1, a2_raw = a2;       // what angle_between_vectors returned (stage capture)
     bool sxp = vx >= 0.0, syp = vy >= 0.0, szp = vz >= 0.0;
     if (szp) {
@@ -3164,8 +3179,14 @@ PW_NOINLINE PW_HD inline void wave_window(const Frame& FS, const Frame& R, PW_LD
         else { a1 = -a1; a2 = ONE_PI - a2; }
     }
     double s1, co1, s2, co2;
-    pw_sincos(a1, &s1, &co1);
-    pw_sincos(a2, &s2, &co2);
+    if (T::WSIZE == 64) {
+        double sv, cv;
+        pw_sincos(T::lane() == 1 ? a2 : a1, &sv, &cv);
+        s1 = T::bcast_u(sv, 0); co1 = T::bcast_u(cv, 0); s2 = T::bcast_u(sv, 1); co2 = T::bcast_u(cv, 1);
+    } else {
+        pw_sincos(a1, &s1, &co1);
+        pw_sincos(a2, &s2, &co2);
+    }
     // rows of a 3x3 matrix times a vector through BLAS dgemv: fma(m2,v2, fma(m0,v0, m1*v1))
     auto row = [](double m0, double m1, double m2, double x, double y, double z) {
         return pw_fma(m2, z, pw_fma(m0, x, m1 * y));
@@ -3290,9 +3311,10 @@ PW_NOINLINE PW_HD inline void wave_window(const Frame& FS, const Frame& R, PW_LD
     double dfin = wave_gap_value<T>(R, n, xo, yo, zopt) * 2.0;
     evals += 1;
     double wx = xo, wy = yo, wz = zopt + new_z;
-    double sm2, cm2, sm1, cm1;
-    pw_sincos(-a2, &sm2, &cm2);
-    pw_sincos(-a1, &sm1, &cm1);
+    // (the sine and cosine of -a2 and -a1: the library's sine is odd and its cosine even bit for bit -- every branch of
+    // s_sin.c works on |x| and restores the sign, the reduction of a large argument is odd operation by operation;
+    // tests/test_math.py holds the restatement to the library on both signs)
+    const double sm2 = -s2, cm2 = co2, sm1 = -s1, cm1 = co1;
     double tx = row(cm2, 0.0, sm2, wx, wy, wz);
     double ty = row(0.0, 1.0, 0.0, wx, wy, wz);
     double tz = row(-sm2, 0.0, cm2, wx, wy, wz);

@@ -42,6 +42,24 @@ def test_sincos_equal_the_c_library(L):
             assert all(float(s[k]) == math.sin(float(th[k])) for k in range(0, len(th), 997))
 
 
+def test_sine_is_odd_and_cosine_even_bit_for_bit(L):
+    """wave_window takes the sine and cosine of -a from those of a (the back-rotation of a window's centre): true of the
+    C library -- numpy's scalar sin / cos -- and of the restatement, bit for bit, over the range of the rotation angles
+    (|a| <= 5 pi / 2) and beyond."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(0, 8, 300000), rng.uniform(8, 3000, 100000), rng.uniform(0, 1e-6, 1000),
+                        np.arange(1, 41) * np.pi / 4])
+    assert np.array_equal(np.sin(-x), -np.sin(x)) and np.array_equal(np.cos(-x), np.cos(x))
+    for th in (x, -x):
+        s = np.empty_like(th)
+        c = np.empty_like(th)
+        L.hs_sincos(len(th), P(th), P(s), P(c))
+        if th is x:
+            s_pos, c_pos = s, c
+    assert np.array_equal(s, -s_pos) and np.array_equal(c, c_pos)
+    assert np.array_equal(np.signbit(s), ~np.signbit(s_pos) | (s_pos != s_pos))
+
+
 def test_scalar_power_equals_the_c_library(L):
     """float64 scalar ** in numpy is glibc's pow(): x ** 2 is NOT always x * x."""
     import math
