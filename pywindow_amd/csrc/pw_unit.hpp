@@ -3394,7 +3394,11 @@ PW_HD inline __attribute__((always_inline)) int team_dbscan(PW_LDS unsigned long
             if (!(cp[3 * i + 2] >= cp[3 * (i + 1) + 2])) chg[1] = 1;
     }
     T::sync();
+#ifndef PW_NO_SCAN_LISTS
     const bool z_falls = have_cp && chg[1] == 0;
+#else
+    const bool z_falls = false;
+#endif
     auto cluster = [&](auto cp_, auto adj_, auto labels_) __attribute__((always_inline)) {
         // (the rows are computed HALF a word -- 32 candidate points -- to a work item: 540 whole-word items on 256 threads are
         // three rounds for one wave and two for the others, 1080 halves are five against four: 2.5 words, not 3)
@@ -4013,10 +4017,12 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
             ScratchArena a3 = arena;
             const size_t per_wave = (size_t)n + PW_KCLS + 2;
             int* c_all = (int*)a3.take((size_t)T::NWAVES * per_wave * 4);
+#ifndef PW_NO_SCAN_LISTS      // (tests/test_scan_lists.py builds the host probe with and without: the same records)
             if (c_all && PW_IS_LDS(c_all)) {
                 cand_w = (lint*)PW_AS_LDS(c_all) + (size_t)T::wave() * per_wave;
                 coff_w = cand_w + n;
             }
+#endif
         }
         for (int j0 = 0; j0 < whole; j0 += T::SIZE) {
             const int j = j0 + T::tid();
