@@ -4046,14 +4046,52 @@ PW_HD inline __attribute__((always_inline)) int windows_bulk_impl(UnitShared& sh
             // The paths of a last, partial round (fewer than a quarter of the team's threads): ONE WAVE per path, the
             // atoms spread over its lanes, point after point (wave_gap_value: the same value as the one-thread scan).
             // (Until round 6 a path's points went one to a thread, every thread through all atoms for its point: nine
-            // lanes of a wave busy, 12.7 us for the four paths a CC3 frame usually leaves -- in-kernel timer; 3 us now.)
+            // lanes of a wave busy, 12.7 us for the four paths a CC3 frame usually leaves -- in-kernel timer.)
             for (int j = whole + T::wave(); j < ncand; j += T::NWAVES) {
                 const int k = labels[j];
                 const double vx = pts[PT(k, 0)], vy = pts[PT(k, 1)], vz = pts[PT(k, 2)];
                 const int chunks = (int)np_floordiv(norm3(vx, vy, vz), prm.increment);
                 double g2 = 0.0;
                 bool ok = true;
-                if (chunks >= 1) {
+                bool all_at_once = false;
+                if constexpr (T::WSIZE == 64) all_at_once = chunks >= 1 && chunks <= 16 && sh.S.cls->k > 0;
+                if (all_at_once) {
+                    if constexpr (T::WSIZE == 64) {
+                        // All points of the path at once: four lanes to a point, each a quarter of every radius group
+                        // (points_gap_values' arithmetic: the smallest squared distance of a group, then one root), the
+                        // four folded by lane exchanges; then the path's statements over the points in order.
+                        const auto& C = *sh.S.cls;
+                        const Frame& F = sh.S;
+                        const double cx = vx / (double)chunks, cy = vy / (double)chunks, cz = vz / (double)chunks;
+                        const int sub = T::lane() & 3;
+                        const int q = (T::lane() >> 2) + 1 <= chunks ? (T::lane() >> 2) + 1 : chunks;
+                        const double qx = cx * (double)q, qy = cy * (double)q, qz = cz * (double)q;
+                        const double pp = sq3(qx, qy, qz);
+                        double gap = PW_INF;
+                        for (int g = 0; g < C.k; ++g) {
+                            double m2 = PW_INF;
+                            const int hi = C.off[g + 1];
+                            for (int i = C.off[g] + sub; i < hi; i += 4) {
+                                const double x = F.x[i], y = F.y[i], z = F.z[i], xx = F.xx[i];
+                                const double gg = pw_fma(z, qz, pw_fma(x, qx, y * qy));
+                                m2 = __builtin_fmin(m2, pw_m2add(gg, xx));
+                            }
+                            m2 = __builtin_fmin(m2, T::xor_d(m2, 1));
+                            m2 = __builtin_fmin(m2, T::xor_d(m2, 2));
+                            const double m2p = m2 + pp;
+                            const double d = pw_sqrt(m2p > 0.0 ? m2p : 0.0);
+                            gap = __builtin_fmin(gap, d - C.vdw[g]);
+                        }
+                        double best = m_origin;
+                        if (!(m_origin > 0.0)) ok = false;
+                        for (int q2 = 1; q2 <= chunks && ok; ++q2) {
+                            const double m = T::bcast_u(gap, 4 * (q2 - 1));
+                            if (!(m > 0.0)) ok = false;
+                            else if (m < best) best = m;
+                        }
+                        g2 = best * 2.0;
+                    }
+                } else if (chunks >= 1) {
                     // (path_scan_thread's statements: the first point is the origin, its gap the caller's m_origin)
                     const double cx = vx / (double)chunks, cy = vy / (double)chunks, cz = vz / (double)chunks;
                     double best = m_origin;
