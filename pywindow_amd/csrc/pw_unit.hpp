@@ -3477,11 +3477,19 @@ PW_HD inline __attribute__((always_inline)) int team_dbscan(PW_LDS unsigned long
                 unsigned long long b = adj_[(size_t)i * stride + wd] & core[wd];
                 if (b != 0 && ((core[i >> 6] >> (i & 63)) & 1ull)) {
                     int m = NONE;
+                    // (four neighbours' labels requested together: taken one at a time, every bit of the word was a
+                    // round trip to team memory behind the one before)
                     while (b) {
-                        const int j = wd * 64 + __builtin_ctzll(b);
+                        const int j0 = wd * 64 + __builtin_ctzll(b);
                         b &= b - 1;
-                        const int lj = labels_[j];
-                        m = lj < m ? lj : m;
+                        int j1 = j0, j2 = j0, j3 = j0;
+                        if (b) { j1 = wd * 64 + __builtin_ctzll(b); b &= b - 1; }
+                        if (b) { j2 = wd * 64 + __builtin_ctzll(b); b &= b - 1; }
+                        if (b) { j3 = wd * 64 + __builtin_ctzll(b); b &= b - 1; }
+                        const int l0 = labels_[j0], l1 = labels_[j1], l2 = labels_[j2], l3 = labels_[j3];
+                        const int la = l0 < l1 ? l0 : l1, lb = l2 < l3 ? l2 : l3;
+                        const int lm = la < lb ? la : lb;
+                        m = lm < m ? lm : m;
                     }
                     if (m < labels_[i]) { team_atomic_min(&labels_[i], m); *changed = 1; }
                 }
