@@ -1,7 +1,9 @@
 """DBSCAN of the window search on its own (row a-9d): ``sklearn.cluster.DBSCAN(eps, min_samples=5)`` as
 find_windows calls it (utilities.py:1478-1487).  Oracle: scikit-learn itself, on point sets built to
 exercise what the cage fixtures do not -- border points between clusters (their label depends on the
-ORDER in which sklearn grows the clusters), noise, more points than threads, a single cluster, none."""
+ORDER in which sklearn grows the clusters), noise, more points than threads, a single cluster, none.  Every set also in
+order of falling z, as the window search hands its survivors over: the adjacency rows then skip blocks of candidates
+that are out of reach in z (round 6), which an unordered cloud never exercises."""
 import ctypes
 
 import numpy as np
@@ -48,6 +50,10 @@ CASES = [(n, kind) for kind in ("blobs", "chain", "bridges", "sparse", "lattice"
 CASES += [(2049, "blobs"), (3001, "bridges"), (5000, "lattice"), (8192, "blobs")]
 
 
+def _by_falling_z(pts):
+    return np.ascontiguousarray(pts[np.argsort(-pts[:, 2], kind="stable")])
+
+
 def _sklearn_labels(pts, eps):
     return sklearn_cluster.DBSCAN(eps=eps, min_samples=5).fit(pts).labels_.astype(np.int32)
 
@@ -57,14 +63,15 @@ def test_host_team_dbscan_is_sklearn(hostsim):
     L.hs_dbscan.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_double, ctypes.c_void_p]
     kinds = set()
     for n, kind in CASES:
-        pts, eps = _cloud(n, kind, 7 * n + len(kind))
-        want = _sklearn_labels(pts, eps)
-        got = np.zeros(n, dtype=np.int32)
-        k = L.hs_dbscan(pts.ctypes.data, n, eps, got.ctypes.data)
-        assert np.array_equal(got, want), (n, kind)
-        assert k == (want.max() + 1 if (want >= 0).any() else 0), (n, kind)
-        if (want >= 0).any() and (want < 0).any():
-            kinds.add(kind)
+        cloud, eps = _cloud(n, kind, 7 * n + len(kind))
+        for pts in (cloud, _by_falling_z(cloud)):
+            want = _sklearn_labels(pts, eps)
+            got = np.zeros(n, dtype=np.int32)
+            k = L.hs_dbscan(pts.ctypes.data, n, eps, got.ctypes.data)
+            assert np.array_equal(got, want), (n, kind)
+            assert k == (want.max() + 1 if (want >= 0).any() else 0), (n, kind)
+            if (want >= 0).any() and (want < 0).any():
+                kinds.add(kind)
     assert {"blobs", "bridges"} <= kinds          # (the point sets do mix clusters and noise)
 
 
@@ -76,11 +83,12 @@ def test_gpu_team_dbscan_is_sklearn(one_wave, global_memory):
     ctx = _lib.Context(0)
     try:
         for n, kind in CASES:
-            pts, eps = _cloud(n, kind, 7 * n + len(kind))
-            want = _sklearn_labels(pts, eps)
-            for rep in range(2):           # (the propagation is racy by design: the fixed point must not be)
-                got, k = ctx.dbscan(pts, eps, one_wave=one_wave, global_memory=global_memory)
-                assert np.array_equal(got, want), (n, kind, rep)
-                assert k == (want.max() + 1 if (want >= 0).any() else 0), (n, kind)
+            cloud, eps = _cloud(n, kind, 7 * n + len(kind))
+            for ordered, pts in ((False, cloud), (True, _by_falling_z(cloud))):
+                want = _sklearn_labels(pts, eps)
+                for rep in range(2):           # (the propagation is racy by design: the fixed point must not be)
+                    got, k = ctx.dbscan(pts, eps, one_wave=one_wave, global_memory=global_memory)
+                    assert np.array_equal(got, want), (n, kind, ordered, rep)
+                    assert k == (want.max() + 1 if (want >= 0).any() else 0), (n, kind, ordered)
     finally:
         ctx.close()
